@@ -1,0 +1,77 @@
+"""ctypes binding of libsarnet_hip.so (the C-ABI declared in include/sarnet.h).
+
+The prototypes are parsed from the header so it stays the single source of truth.  There is NO fallback:
+if the shared library is missing or a symbol is absent, importing/calling fails loudly.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsarnet_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sarnet.h")
+
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every `int|size_t sar_*(...)` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(sar_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        at = []
+        for a in args.split(","):
+            a = a.strip()
+            if "*" in a or "sarStream_t" in a:
+                at.append(ctypes.c_void_p)
+            else:
+                at.append(_CT[a.split()[-2] if len(a.split()) > 1 else a])
+        protos[name] = (_CT[ret], at)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: build it with `python __graft_entry__.py build` "
+                              "(make -C aesrc2020_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        self.fn = {}
+        for name, (ret, at) in self.protos.items():
+            f = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
+            f.restype = ret; f.argtypes = at
+            self.fn[name] = f
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def ptr(t):
+    """torch tensor (or None) -> raw device pointer."""
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args, stream=None):
+    """Invoke a C-ABI entry point on torch's current HIP stream; raises on a non-zero status."""
+    import torch
+    L = lib()
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    conv = [a.data_ptr() if hasattr(a, "data_ptr") else a for a in args]
+    rc = L.fn[name](*conv, stream)
+    if rc != 0:
+        raise RuntimeError("%s failed with status %d (args=%r)" % (name, rc, [getattr(a, "shape", a) for a in args]))
+
+
+def ctc_workspace_bytes(B, L, max_label_len):
+    return lib().fn["sar_ctc_workspace_bytes"](B, L, max_label_len)

@@ -1,0 +1,70 @@
+// Shared device helpers for the SAR-Net gfx950 (CDNA4) kernels.
+// Wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SAR_OK 0
+#define SAR_EINVAL (-1)
+#define SAR_ELAUNCH (-2)
+
+#define SAR_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return SAR_ELAUNCH;           \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum; `red` is a __shared__ float[16] scratch. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.f / (1.f + expf(-a)); }
+
+// log(exp(a)+exp(b)) with -inf handling
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + logf(expf(a - m) + expf(b - m));
+}
+
+// activation codes shared by host and device (include/sarnet.h mirrors them)
+enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };

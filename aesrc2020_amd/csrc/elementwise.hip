@@ -1,0 +1,192 @@
+// Small HBM-bound helpers for the SAR-Net step on gfx950: activation backward, row softmax (Dense softmax heads,
+// model.py:268,296,150), column sums (bias gradients), axpy, GlobalAveragePooling1D (model.py:125),
+// row-wise l2_normalize (model.py:162), 2-D transpose (GRU recurrent kernel for BPTT), fill.
+#include "common.h"
+
+namespace {
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, long n,
+                               int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float g = dy[i], v = y[i];
+        dz[i] = act == ACT_TANH ? g * (1.f - v * v) : (act == ACT_RELU ? (v > 0.f ? g : 0.f) : g);
+    }
+}
+
+// one block per row
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ z, float* __restrict__ p, int N) {
+    __shared__ float red[16];
+    const float* zr = z + (long)blockIdx.x * N; float* pr = p + (long)blockIdx.x * N;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) m = fmaxf(m, zr[i]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) { const float e = expf(zr[i] - m); pr[i] = e; s += e; }
+    s = block_sum(s, red);
+    const float inv = 1.f / s;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) pr[i] *= inv;
+}
+
+// dz = p * (dp - sum(dp*p))
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p,
+                                                          float* __restrict__ dz, int N) {
+    __shared__ float red[16];
+    const long o = (long)blockIdx.x * N;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) s = fmaf(dp[o + i], p[o + i], s);
+    s = block_sum(s, red);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) dz[o + i] = p[o + i] * (dp[o + i] - s);
+}
+
+// out[c] += sum_r x[r][c]; block handles a row chunk, 256 threads over columns (loop), atomics per block
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long R, int C,
+                                                     int rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s += x[r * C + c];
+        atomicAdd(out + c, s);
+    }
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, float a, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void fill_kernel(float* __restrict__ y, float v, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = v;
+}
+
+// x (B, L, C) -> y (B, C) mean over L
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int L, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * C) return;
+    const int b = (int)(i / C), c = (int)(i % C);
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += x[((long)b * L + l) * C + c];
+    y[i] = s / L;
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int L, int C, int accumulate) {
+    const long n = (long)B * L * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const int b = (int)(i / ((long)L * C));
+        const float g = dy[(long)b * C + c] / L;
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// rows: v = x * rsqrt(max(sum x^2, 1e-12)); one wave per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ v,
+                                                         float* __restrict__ inv, int R, int C) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float a = x[(long)r * C + c]; s = fmaf(a, a, s); }
+    s = wave_sum(s);
+    const float k = 1.f / sqrtf(fmaxf(s, 1e-12f));
+    if (lane == 0) inv[r] = (s >= 1e-12f) ? k : -k;      // sign flags the clamped branch for backward
+    for (int c = lane; c < C; c += 64) v[(long)r * C + c] = x[(long)r * C + c] * k;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dv, const float* __restrict__ v,
+                                                         const float* __restrict__ inv, float* __restrict__ dx, int R,
+                                                         int C, int accumulate) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float k = inv[r];
+    float s = 0.f;
+    if (k > 0.f) for (int c = lane; c < C; c += 64) s = fmaf(dv[(long)r * C + c], v[(long)r * C + c], s);
+    s = wave_sum(s);
+    const float ak = fabsf(k);
+    for (int c = lane; c < C; c += 64) {
+        const long i = (long)r * C + c;
+        const float g = (dv[i] - v[i] * s) * ak;
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        if (r < R && c < C) t[j][threadIdx.x] = x[(long)r * C + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < R && c < C) y[(long)c * R + r] = t[threadIdx.x][j];
+    }
+}
+
+}  // namespace
+
+static int ew_blocks(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+extern "C" int sar_act_bwd_f32(const float* dy, const float* y, float* dz, long n, int act, hipStream_t stream) {
+    if (!dy || !y || !dz) return SAR_EINVAL;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, dy, y, dz, n, act);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_softmax_fwd_f32(const float* z, float* p, int rows, int N, hipStream_t stream) {
+    if (!z || !p || rows <= 0 || N <= 0) return SAR_EINVAL;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(rows), dim3(N <= 64 ? 64 : 256), 0, stream, z, p, N);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_softmax_bwd_f32(const float* dp, const float* p, float* dz, int rows, int N, hipStream_t stream) {
+    if (!dp || !p || !dz || rows <= 0 || N <= 0) return SAR_EINVAL;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(N <= 64 ? 64 : 256), 0, stream, dp, p, dz, N);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_colsum_f32(const float* x, float* out, long R, int C, hipStream_t stream) {
+    if (!x || !out || R <= 0 || C <= 0) return SAR_EINVAL;
+    int rpb = (int)((R + 511) / 512); if (rpb < 8) rpb = 8;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(R, rpb)), dim3(256), 0, stream, x, out, R, C, rpb);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_axpy_f32(const float* x, float* y, float a, long n, hipStream_t stream) {
+    if (!x || !y) return SAR_EINVAL;
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, x, y, a, n);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_fill_f32(float* y, float v, long n, hipStream_t stream) {
+    if (!y) return SAR_EINVAL;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, stream, y, v, n);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_avgpool1d_fwd_f32(const float* x, float* y, int B, int L, int C, hipStream_t stream) {
+    if (!x || !y) return SAR_EINVAL;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv((long)B * C, 256)), dim3(256), 0, stream, x, y, B, L, C);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_avgpool1d_bwd_f32(const float* dy, float* dx, int B, int L, int C, int accumulate, hipStream_t stream) {
+    if (!dy || !dx) return SAR_EINVAL;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_blocks((long)B * L * C)), dim3(256), 0, stream, dy, dx, B, L, C, accumulate);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_l2norm_rows_fwd_f32(const float* x, float* v, float* inv, int R, int C, hipStream_t stream) {
+    if (!x || !v || !inv) return SAR_EINVAL;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, x, v, inv, R, C);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_l2norm_rows_bwd_f32(const float* dv, const float* v, const float* inv, float* dx, int R, int C,
+                                       int accumulate, hipStream_t stream) {
+    if (!dv || !v || !inv || !dx) return SAR_EINVAL;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, stream, dv, v, inv, dx, R, C, accumulate);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_transpose_f32(const float* x, float* y, int R, int C, hipStream_t stream) {
+    if (!x || !y) return SAR_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(32, 8), 0, stream, x, y, R, C);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}

@@ -1,0 +1,131 @@
+// Generic fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain),
+// used by Dense fwd/bwd, the GRU input/recurrent-weight GEMMs and the VLAD assignment conv.
+//   C[M,N] (+)= act( op(A)[M,K] * op(B)[K,N] + bias[N] )
+// Layout flags: a_kc = A stored (M,K) row-major (k contiguous); !a_kc = A stored (K,M).
+//               b_kc = B stored (N,K) row-major (k contiguous); !b_kc = B stored (K,N).
+// Tile 64x64x16, 4 waves (2x2), one 32x32 accumulator per wave. LDS tiles are k-major
+// ([k][m] / [k][n]) so the MFMA operand reads (lane&31 -> m/n, lane>>5 -> k) are conflict-free.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDP = 68;  // LDP: padded row (floats), keeps 16-B alignment
+
+template <bool KC>
+__device__ __forceinline__ void load_tile(float (&r)[4], const float* __restrict__ P, int ld, int mn0, int k0,
+                                          int MN, int K, int tid, bool vec_ok) {
+    // Tile is 64 (m or n) x 16 (k); each of 256 threads fetches 4 consecutive elements along the contiguous dim.
+    if (KC) {
+        const int mn = mn0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+        if (mn < MN && vec_ok && k + 3 < K) {
+            const float4 v = *reinterpret_cast<const float4*>(P + (long)mn * ld + k);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (mn < MN && k + i < K) ? P[(long)mn * ld + k + i] : 0.f;
+        }
+    } else {
+        const int k = k0 + (tid >> 4), mn = mn0 + (tid & 15) * 4;
+        if (k < K && vec_ok && mn + 3 < MN) {
+            const float4 v = *reinterpret_cast<const float4*>(P + (long)k * ld + mn);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = (k < K && mn + i < MN) ? P[(long)k * ld + mn + i] : 0.f;
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(const float (&r)[4], float (*S)[LDP], int tid) {
+    if (KC) {
+        const int mn = tid >> 2, k = (tid & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S[k + i][mn] = r[i];
+    } else {
+        const int k = tid >> 4, mn = (tid & 15) * 4;
+        *reinterpret_cast<float4*>(&S[k][mn]) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, const float* __restrict__ bias, int M,
+                                                       int N, int K, int lda, int ldb, int ldc, int act,
+                                                       int accumulate, int splitk) {
+    __shared__ __attribute__((aligned(16))) float As[BK][LDP];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // split-K: slice z handles k-tiles [kt0, kt1)
+    const int nkt = (K + BK - 1) / BK;
+    const int per = (nkt + splitk - 1) / splitk;
+    const int kt0 = blockIdx.z * per, kt1 = min(nkt, kt0 + per);
+    const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float ra[4], rb[4];
+    if (kt0 < kt1) {
+        load_tile<A_KC>(ra, A, lda, m0, kt0 * BK, M, K, tid, a_vec);
+        load_tile<B_KC>(rb, B, ldb, n0, kt0 * BK, N, K, tid, b_vec);
+    }
+    for (int kt = kt0; kt < kt1; ++kt) {
+        store_tile<A_KC>(ra, As, tid);
+        store_tile<B_KC>(rb, Bs, tid);
+        __syncthreads();
+        if (kt + 1 < kt1) {
+            load_tile<A_KC>(ra, A, lda, m0, (kt + 1) * BK, M, K, tid, a_vec);
+            load_tile<B_KC>(rb, B, ldb, n0, (kt + 1) * BK, N, K, tid, b_vec);
+        }
+#pragma unroll
+        for (int k = 0; k < BK; k += 2) {
+            const float a = As[k + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[k + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= N) return;
+    const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= M) continue;
+        float v = acc[r] + bv;
+        float* dst = C + (long)row * ldc + col;
+        if (splitk > 1) {
+            atomicAdd(dst, v);
+        } else {
+            if (act == ACT_TANH) v = tanhf(v);
+            else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+}  // namespace
+
+// C-ABI: see include/sarnet.h
+extern "C" int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                            int ldb, int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk,
+                            hipStream_t stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splitk < 1) return SAR_EINVAL;
+    if (splitk > 1 && act != ACT_NONE) return SAR_EINVAL;  // split-K accumulates atomically: C must be pre-zeroed (or hold the addend)
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk), block(256);
+#define LAUNCH(AK, BK_)                                                                                              \
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, block, 0, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, \
+                       act, accumulate, splitk)
+    if (a_kc && b_kc) LAUNCH(true, true);
+    else if (a_kc && !b_kc) LAUNCH(true, false);
+    else if (!a_kc && b_kc) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}

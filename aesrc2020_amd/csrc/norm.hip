@@ -1,0 +1,396 @@
+// Normalisation kernels for SAR-Net on gfx950 (all HBM-bound: float4 loads, fp64 cross-block sums).
+//  * training-mode BatchNormalization over (R, C) views, eps = 1e-3 (resnet.py:25; model.py:29-30; App. A):
+//      stats -> finalize (mean, rstd, scale=gamma*rstd, shift=beta-mean*scale; moving averages)
+//      the normalise+ReLU itself is folded into the consuming conv (conv.hip) or done by bn_apply
+//      backward = reduce (sum dz, sum dz*xhat) + apply; dz = dact * (x*scale+shift > 0) when relu is set
+//  * BatchNormalization on 2-D (B, C) inputs (model.py:286,289): thread-per-channel
+//  * LayerNormalization (keras_layer_normalization, eps = 1e-14, model.py:32-33): wave-per-row
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// ---- per-channel sum / sum-of-squares of x (R, C), C % 4 == 0, C <= 1024 -----------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, long R,
+                                                       int C, int tpr /* pow2 >= C/4, <= 256 */) {
+    __shared__ float4 s1[256], s2[256];
+    const int cv = threadIdx.x % tpr, rg = threadIdx.x / tpr, nrg = 256 / tpr;
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (cv * 4 < C) {
+        for (long r = (long)blockIdx.x * nrg + rg; r < R; r += (long)gridDim.x * nrg) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * C + cv * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            b.x = fmaf(v.x, v.x, b.x); b.y = fmaf(v.y, v.y, b.y); b.z = fmaf(v.z, v.z, b.z); b.w = fmaf(v.w, v.w, b.w);
+        }
+    }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < tpr && threadIdx.x * 4 < C) {
+        double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+        for (int g = 0; g < nrg; ++g) {
+            const float4 u = s1[g * tpr + threadIdx.x], w = s2[g * tpr + threadIdx.x];
+            d1[0] += u.x; d1[1] += u.y; d1[2] += u.z; d1[3] += u.w;
+            d2[0] += w.x; d2[1] += w.y; d2[2] += w.z; d2[3] += w.w;
+        }
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(sums + threadIdx.x * 4 + j, d1[j]);
+            atomicAdd(sums + C + threadIdx.x * 4 + j, d2[j]);
+        }
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
+                                   float* __restrict__ mov_var, long R, int C, float eps, float momentum,
+                                   int unbiased_moving_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c] / (double)R;
+    double var = sums[C + c] / (double)R - mu * mu;
+    if (var < 0) var = 0;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)mu; rstd[c] = (float)rs;
+    const float sc = gamma[c] * (float)rs;
+    scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
+    if (mov_mean) {
+        const double v = unbiased_moving_var && R > 1 ? var * (double)R / (double)(R - 1) : var;
+        mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * (float)mu;
+        mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * (float)v;
+    }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                const float* __restrict__ shift, float* __restrict__ y, long n4, int C, int relu) {
+    const int C4 = C / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+// sums[0:C] = sum dz ; sums[C:2C] = sum dz*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dact, const float* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            double* __restrict__ sums, long R, int C, int tpr, int relu) {
+    __shared__ float4 s1[256], s2[256];
+    const int cv = threadIdx.x % tpr, rg = threadIdx.x / tpr, nrg = 256 / tpr;
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (cv * 4 < C) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + cv * 4), sh = *reinterpret_cast<const float4*>(shift + cv * 4);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + cv * 4), rs = *reinterpret_cast<const float4*>(rstd + cv * 4);
+        for (long r = (long)blockIdx.x * nrg + rg; r < R; r += (long)gridDim.x * nrg) {
+            const float4 v = *reinterpret_cast<const float4*>(x + r * C + cv * 4);
+            float4 g = *reinterpret_cast<const float4*>(dact + r * C + cv * 4);
+            if (relu) {
+                if (fmaf(v.x, sc.x, sh.x) <= 0.f) g.x = 0.f;
+                if (fmaf(v.y, sc.y, sh.y) <= 0.f) g.y = 0.f;
+                if (fmaf(v.z, sc.z, sh.z) <= 0.f) g.z = 0.f;
+                if (fmaf(v.w, sc.w, sh.w) <= 0.f) g.w = 0.f;
+            }
+            a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+            b.x = fmaf(g.x, (v.x - mu.x) * rs.x, b.x); b.y = fmaf(g.y, (v.y - mu.y) * rs.y, b.y);
+            b.z = fmaf(g.z, (v.z - mu.z) * rs.z, b.z); b.w = fmaf(g.w, (v.w - mu.w) * rs.w, b.w);
+        }
+    }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x < tpr && threadIdx.x * 4 < C) {
+        double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+        for (int g = 0; g < nrg; ++g) {
+            const float4 u = s1[g * tpr + threadIdx.x], w = s2[g * tpr + threadIdx.x];
+            d1[0] += u.x; d1[1] += u.y; d1[2] += u.z; d1[3] += u.w;
+            d2[0] += w.x; d2[1] += w.y; d2[2] += w.z; d2[3] += w.w;
+        }
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(sums + threadIdx.x * 4 + j, d1[j]);
+            atomicAdd(sums + C + threadIdx.x * 4 + j, d2[j]);
+        }
+    }
+}
+
+// dx = scale*(dz - s1/R - xhat*s2/R) [+ add];  block 0 also accumulates dgamma += s2, dbeta += s1
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dact, const float* __restrict__ x,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const double* __restrict__ sums, const float* __restrict__ add,
+                                    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    long R, int C, int relu) {
+    const int C4 = C / 4;
+    const long n4 = R * C4;
+    const double invR = 1.0 / (double)R;
+    if (blockIdx.x == 0 && dgamma) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 g = reinterpret_cast<const float4*>(dact)[i];
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+        if (relu) {
+            if (fmaf(v.x, sc.x, sh.x) <= 0.f) g.x = 0.f;
+            if (fmaf(v.y, sc.y, sh.y) <= 0.f) g.y = 0.f;
+            if (fmaf(v.z, sc.z, sh.z) <= 0.f) g.z = 0.f;
+            if (fmaf(v.w, sc.w, sh.w) <= 0.f) g.w = 0.f;
+        }
+        float4 o;
+        o.x = sc.x * (g.x - (float)(sums[c + 0] * invR) - (v.x - mu.x) * rs.x * (float)(sums[C + c + 0] * invR));
+        o.y = sc.y * (g.y - (float)(sums[c + 1] * invR) - (v.y - mu.y) * rs.y * (float)(sums[C + c + 1] * invR));
+        o.z = sc.z * (g.z - (float)(sums[c + 2] * invR) - (v.z - mu.z) * rs.z * (float)(sums[C + c + 2] * invR));
+        o.w = sc.w * (g.w - (float)(sums[c + 3] * invR) - (v.w - mu.w) * rs.w * (float)(sums[C + c + 3] * invR));
+        if (add) { const float4 e = reinterpret_cast<const float4*>(add)[i]; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+        reinterpret_cast<float4*>(dx)[i] = o;
+    }
+}
+
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
+}
+
+// ---- 2-D BatchNorm: x (B, C), thread per channel ---------------------------------------------------------
+__global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+                                float* __restrict__ rstd, float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                int B, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu = 0.f;
+    for (int b = 0; b < B; ++b) mu += x[(long)b * C + c];
+    mu /= B;
+    float var = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = x[(long)b * C + c] - mu; var = fmaf(d, d, var); }
+    var /= B;
+    const float rs = 1.f / sqrtf(var + eps);
+    mean[c] = mu; rstd[c] = rs;
+    const float g = gamma[c], be = beta[c];
+    for (int b = 0; b < B; ++b) y[(long)b * C + c] = (x[(long)b * C + c] - mu) * rs * g + be;
+    if (mov_mean) {
+        mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * mu;
+        mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * var;
+    }
+}
+
+__global__ void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c], rs = rstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g = dy[(long)b * C + c];
+        s1 += g; s2 = fmaf(g, (x[(long)b * C + c] - mu) * rs, s2);
+    }
+    dgamma[c] += s2; dbeta[c] += s1;
+    const float k = gamma[c] * rs, m1 = s1 / B, m2 = s2 / B;
+    for (int b = 0; b < B; ++b) {
+        const float xh = (x[(long)b * C + c] - mu) * rs;
+        dx[(long)b * C + c] = k * (dy[(long)b * C + c] - m1 - xh * m2);
+    }
+}
+
+// ---- LayerNorm: x (R, C), one wave per row, C % 4 == 0, C <= 2048 -------------------------------------
+constexpr int LN_MAXV = 8;   // float4 per lane
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long R, int C,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C4 = C / 4;
+    for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+        float4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c4 = lane + j * 64;
+            if (c4 < C4) { v[j] = reinterpret_cast<const float4*>(x + r * C)[c4]; s += v[j].x + v[j].y + v[j].z + v[j].w; }
+        }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c4 = lane + j * 64;
+            if (c4 < C4) {
+                const float a = v[j].x - mu, b = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+                q += a * a + b * b + c * c + d * d;
+            }
+        }
+        const float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c4 = lane + j * 64;
+            if (c4 < C4) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
+                float4 o;
+                o.x = (v[j].x - mu) * rs * g.x + be.x; o.y = (v[j].y - mu) * rs * g.y + be.y;
+                o.z = (v[j].z - mu) * rs * g.z + be.z; o.w = (v[j].w - mu) * rs * g.w + be.w;
+                reinterpret_cast<float4*>(y + r * C)[c4] = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
+                                                     int C, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // 4 waves x 2 x C
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C4 = C / 4;
+    float4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = ag[j]; }
+    for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+        const float mu = mean[r], rs = rstd[r];
+        float4 xh[LN_MAXV], g[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c4 = lane + j * 64;
+            if (c4 < C4) {
+                const float4 v = reinterpret_cast<const float4*>(x + r * C)[c4];
+                const float4 d = reinterpret_cast<const float4*>(dy + r * C)[c4];
+                const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+                xh[j] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+                g[j] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                s1 += g[j].x + g[j].y + g[j].z + g[j].w;
+                s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
+                ag[j].x = fmaf(d.x, xh[j].x, ag[j].x); ag[j].y = fmaf(d.y, xh[j].y, ag[j].y);
+                ag[j].z = fmaf(d.z, xh[j].z, ag[j].z); ag[j].w = fmaf(d.w, xh[j].w, ag[j].w);
+                ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int c4 = lane + j * 64;
+            if (c4 < C4) {
+                float4 o;
+                o.x = rs * (g[j].x - m1 - xh[j].x * m2); o.y = rs * (g[j].y - m1 - xh[j].y * m2);
+                o.z = rs * (g[j].z - m1 - xh[j].z * m2); o.w = rs * (g[j].w - m1 - xh[j].w * m2);
+                float4* d = reinterpret_cast<float4*>(dx + r * C) + c4;
+                if (accumulate) { const float4 e = *d; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+                *d = o;
+            }
+        }
+    }
+    // cross-wave reduce of the parameter-gradient partials, then one atomic per column per block
+    float* sg = sm + wave * 2 * C; float* sb = sg + C;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int c4 = lane + j * 64;
+        if (c4 < C4) { reinterpret_cast<float4*>(sg)[c4] = ag[j]; reinterpret_cast<float4*>(sb)[c4] = ab[j]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < 4; ++w) { a += sm[w * 2 * C + c]; b += sm[w * 2 * C + C + c]; }
+        atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b);
+    }
+}
+
+}  // namespace
+
+static int pow2_tpr(int C) { int v = C / 4, p = 1; while (p < v) p <<= 1; return p; }
+
+// sums: double[2C] workspace. Computes batch statistics of x (R,C) and the folded scale/shift.
+extern "C" int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, double* sums, float* mean,
+                                float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
+                                int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream) {
+    if (!x || !gamma || !beta || !sums || !mean || !rstd || !scale || !shift || C % 4 || C > 1024 || R <= 0) return SAR_EINVAL;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return SAR_ELAUNCH;
+    const int tpr = pow2_tpr(C), nrg = 256 / tpr;
+    long nb = (R + nrg * 8 - 1) / (nrg * 8);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((int)nb), dim3(256), 0, stream, x, sums, R, C, tpr);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, gamma, beta, mean, rstd, scale,
+                       shift, moving_mean, moving_var, R, C, eps, momentum, unbiased_moving_var);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, long R, int C, int relu,
+                                hipStream_t stream) {
+    if (!x || !scale || !shift || !y || C % 4) return SAR_EINVAL;
+    const long n4 = R * (C / 4);
+    const int nb = (int)(n4 / 256 + 1 < 8192 ? n4 / 256 + 1 : 8192);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nb), dim3(256), 0, stream, x, scale, shift, y, n4, C, relu);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// Backward of y = [relu](bn(x)) given dact = dL/dy.  dx (+)= ...; dgamma/dbeta accumulate.  `add` (optional, same
+// shape) is summed into dx (residual/shortcut gradient).  dx may alias dact or add.
+extern "C" int sar_bn_bwd_f32(const float* dact, const float* x, const float* scale, const float* shift,
+                              const float* mean, const float* rstd, double* sums, const float* add, float* dx,
+                              float* dgamma, float* dbeta, long R, int C, int relu, hipStream_t stream) {
+    if (!dact || !x || !scale || !shift || !mean || !rstd || !sums || !dx || C % 4 || C > 1024) return SAR_EINVAL;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return SAR_ELAUNCH;
+    const int tpr = pow2_tpr(C), nrg = 256 / tpr;
+    long nb = (R + nrg * 8 - 1) / (nrg * 8);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)nb), dim3(256), 0, stream, dact, x, scale, shift, mean, rstd, sums, R, C, tpr, relu);
+    const long n4 = R * (C / 4);
+    const int nb2 = (int)(n4 / 256 + 1 < 8192 ? n4 / 256 + 1 : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(256), 0, stream, dact, x, scale, shift, mean, rstd, sums, add, dx, dgamma, dbeta, R, C, relu);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_bn_param_grads_f32(const double* sums, float* dgamma, float* dbeta, int C, hipStream_t stream) {
+    if (!sums || !dgamma || !dbeta) return SAR_EINVAL;
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, dgamma, dbeta, C);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_bn1d_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                float* moving_mean, float* moving_var, int B, int C, float eps, float momentum,
+                                hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0) return SAR_EINVAL;
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, x, gamma, beta, y, mean, rstd, moving_mean, moving_var, B, C, eps, momentum);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_bn1d_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return SAR_EINVAL;
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, B, C);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                     float* rstd, long R, int C, float eps, hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
+    const int nb = (int)((R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                     const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
+                                     int accumulate, hipStream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
+    const int nb = (int)((R + 3) / 4 < 256 ? (R + 3) / 4 : 256);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}

@@ -1,0 +1,213 @@
+"""Host-side runtime for the SAR-Net hot path: flat parameter/gradient/Adam buffers in HBM, a scratch pool,
+and thin wrappers that launch the C-ABI kernels (include/sarnet.h) on torch's current HIP stream.
+
+PyTorch is used for device memory, streams, HIP-graph capture and torch.distributed only; every FLOP of the
+train step runs in libsarnet_hip.so.  There is no CPU path: constructing a ParamStore without a HIP device
+raises.
+"""
+import math
+import numpy as np
+import torch
+
+from . import _lib
+
+CHUNK = 256            # Adam/L2 chunk (elements); every parameter is padded to a multiple of it
+ACT = {None: 0, "linear": 0, "tanh": 1, "relu": 2}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("aesrc2020_amd needs a HIP device (MI355X); there is no CPU fallback. "
+                           "The CPU oracle lives in oracle/ and is test infrastructure only.")
+    _lib.lib()
+
+
+class ParamRef:
+    __slots__ = ("name", "shape", "init", "l2", "offset", "size", "w", "g", "constraint")
+
+    def __init__(self, name, shape, init, l2, constraint=None):
+        self.name, self.shape, self.init, self.l2, self.constraint = name, tuple(shape), init, float(l2), constraint
+        self.size = int(np.prod(shape)); self.offset = -1; self.w = None; self.g = None
+
+
+class ParamStore:
+    """Flat fp32 buffers [params | grads | adam m | adam v] + per-chunk L2 table.
+    Parameters are laid out in creation (= forward) order, so the tail of the gradient buffer (heads, GRUs)
+    is complete first during backward and the head (conv stack) last -- the two all-reduce buckets of parallel.py."""
+
+    def __init__(self):
+        self.refs = []; self.by_name = {}; self.finalized = False
+        self.state_refs = []          # non-trainable (BN moving statistics)
+
+    def add(self, name, shape, init, l2=0.0, constraint=None):
+        assert not self.finalized, "ParamStore already finalized"
+        if name in self.by_name:
+            raise ValueError("duplicate parameter name " + name)
+        r = ParamRef(name, shape, np.asarray(init, np.float32).reshape(shape), l2, constraint)
+        self.refs.append(r); self.by_name[name] = r
+        return r
+
+    def add_state(self, name, shape, init):
+        r = ParamRef(name, shape, np.asarray(init, np.float32).reshape(shape), 0.0)
+        self.state_refs.append(r); self.by_name[name] = r
+        return r
+
+    def finalize(self, device="cuda"):
+        require_gpu()
+        off = 0
+        for r in self.refs:
+            r.offset = off; off += -(-r.size // CHUNK) * CHUNK
+        self.n = off
+        host = np.zeros(off, np.float32); l2 = np.zeros(off // CHUNK, np.float32)
+        for r in self.refs:
+            host[r.offset:r.offset + r.size] = r.init.ravel()
+            l2[r.offset // CHUNK:(r.offset + r.size + CHUNK - 1) // CHUNK] = r.l2
+        self.flat = torch.zeros(4, off, dtype=torch.float32, device=device)
+        self.params, self.grads, self.m, self.v = self.flat[0], self.flat[1], self.flat[2], self.flat[3]
+        self.params.copy_(torch.from_numpy(host))
+        self.chunk_l2 = torch.from_numpy(l2).to(device)
+        for r in self.refs:
+            r.w = self.params[r.offset:r.offset + r.size].view(r.shape)
+            r.g = self.grads[r.offset:r.offset + r.size].view(r.shape)
+            r.init = None
+        for r in self.state_refs:
+            r.w = torch.from_numpy(r.init).to(device); r.init = None
+        # device-side Adam state block: {lr, decay, b1, b2, eps, lr_t, int iterations, grad_scale}
+        self.adam_state = torch.zeros(8, dtype=torch.float32, device=device)
+        self.l2_loss = torch.zeros(1, dtype=torch.float32, device=device)
+        self.finalized = True
+        return self
+
+    def set_adam(self, lr, decay=2e-4, b1=0.9, b2=0.999, eps=1e-7, iterations=0, grad_scale=1.0):
+        h = torch.tensor([lr, decay, b1, b2, eps, 0.0, 0.0, grad_scale], dtype=torch.float32)
+        h.view(torch.int32)[6] = int(iterations)
+        self.adam_state.copy_(h)
+
+    def set_lr(self, lr):
+        self.adam_state[0:1].copy_(torch.tensor([lr], dtype=torch.float32))
+
+    def get_lr(self):
+        return float(self.adam_state[0].item())
+
+    @property
+    def iterations(self):
+        return int(self.adam_state.view(torch.int32)[6].item())
+
+    def zero_grads(self):
+        _lib.call("sar_fill_f32", self.grads, 0.0, self.n)
+
+    def adam_step(self):
+        """L2 gradient + Keras Adam over the whole flat buffer, then the unit_norm constraints."""
+        _lib.call("sar_fill_f32", self.l2_loss, 0.0, 1)
+        _lib.call("sar_adam_prepare", self.adam_state)
+        _lib.call("sar_adam_l2_step_f32", self.params, self.grads, self.m, self.v, self.chunk_l2, self.adam_state,
+                  self.l2_loss, self.n)
+        for r in self.refs:
+            if r.constraint == "unit_norm":
+                _lib.call("sar_unit_norm_f32", r.w, r.shape[0], r.shape[1])
+
+    def n_params(self):
+        return sum(r.size for r in self.refs)
+
+    def state_dict(self):
+        """name -> numpy array in the reference's (Keras) tensor layouts."""
+        d = {r.name: r.w.detach().cpu().numpy().copy() for r in self.refs}
+        d.update({r.name: r.w.detach().cpu().numpy().copy() for r in self.state_refs})
+        return d
+
+    def load_state_dict(self, d, by_name=True, skip_mismatch=True):
+        loaded, skipped = [], []
+        for r in self.refs + self.state_refs:
+            if r.name not in d:
+                continue
+            a = np.asarray(d[r.name], np.float32)
+            if tuple(a.shape) != r.shape:
+                if skip_mismatch:
+                    skipped.append(r.name); continue
+                raise ValueError("shape mismatch for %s: %s vs %s" % (r.name, a.shape, r.shape))
+            r.w.copy_(torch.from_numpy(a).to(r.w.device)); loaded.append(r.name)
+        return loaded, skipped
+
+
+# ------------------------------------------------------------------------------------------------ store context
+_STACK = []
+
+
+class store_scope:
+    """`with store_scope(store):` -- layers constructed inside register their weights there (the analogue of the
+    Keras default graph the reference's layer constructors rely on)."""
+
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        _STACK.append(self.store); return self.store
+
+    def __exit__(self, *a):
+        _STACK.pop()
+
+
+def current_store():
+    if not _STACK:
+        raise RuntimeError("no active ParamStore: construct layers inside `with store_scope(store):` (SAR_Net does)")
+    return _STACK[-1]
+
+
+# ------------------------------------------------------------------------------------------------ buffers
+class Buffers:
+    """Named static device buffers (activations, saved state, scratch).  Shapes are fixed per model instance, so
+    everything is allocated once (first eager step) and then reused -- a requirement for HIP-graph replay."""
+
+    def __init__(self, device="cuda"):
+        self.device = device; self.d = {}
+
+    def get(self, key, shape, dtype=torch.float32):
+        shape = tuple(int(s) for s in shape)
+        t = self.d.get(key)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device); self.d[key] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.d.values())
+
+
+# ------------------------------------------------------------------------------------------------ initialisers
+def he_normal(rng, shape, fan_in):
+    """keras he_normal = VarianceScaling(2, fan_in, truncated normal) (model.py:39; resnet.py:34,54,86,116)."""
+    std = math.sqrt(2.0 / fan_in) / .87962566103423978
+    w = rng.standard_normal(shape) * std
+    bad = np.abs(w) > 2 * std
+    while bad.any():
+        w[bad] = rng.standard_normal(int(bad.sum())) * std; bad = np.abs(w) > 2 * std
+    return w
+
+
+def glorot_uniform(rng, shape, fan_in, fan_out):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, shape)
+
+
+def orthogonal(rng, shape):
+    """keras Orthogonal(gain=1): (VLAD.py:19; model.py:91,101)."""
+    rows, cols = shape[0], int(np.prod(shape[1:]))
+    a = rng.standard_normal((rows, cols))
+    u, _, vt = np.linalg.svd(a, full_matrices=False)
+    return (u if u.shape == (rows, cols) else vt).reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------ kernel wrappers
+def same_pads(n, k, s):
+    out = -(-n // s); tot = max((out - 1) * s + k - n, 0)
+    return out, tot // 2
+
+
+def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=0, accumulate=0, splitk=1):
+    _lib.call("sar_gemm_f32", A, B, C, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, accumulate, splitk)
+
+
+def pick_splitk(M, N, K):
+    tiles = -(-M // 64) * -(-N // 64)
+    if tiles >= 128 or K < 512:
+        return 1
+    return int(max(1, min(32, 256 // tiles, K // 256)))

@@ -1,0 +1,151 @@
+/* sarnet.h -- C-ABI of libsarnet_hip.so: the MI355X (gfx950) kernels of the SAR-Net train-step hot path.
+ *
+ * The reference (pika-online/AESRC2020) has no FFI of its own: every op below replaces a third-party
+ * Keras/TF/cuDNN op that the cited reference line *invokes*.  Citations are file:line under /root/reference.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (no allocation, no
+ *     synchronisation, no host<->device copies inside the library); launches go to the caller's `stream`,
+ *     so a sequence of calls can be captured into a HIP graph.
+ *   - return 0 on success, SAR_EINVAL (-1) for a rejected argument/shape, SAR_ELAUNCH (-2) if HIP refused.
+ *   - tensors are fp32, row-major; images NHWC; conv kernels HWIO; Dense (in,out); GRU kernel (in,3H) /
+ *     recurrent (H,3H) / bias (6H) in Keras z,r,h order -- i.e. the reference's own weight layouts.
+ *   - "accumulate" outputs add into the destination (gradient fan-in); parameter gradients always accumulate.
+ */
+#ifndef SARNET_H_
+#define SARNET_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* sarStream_t; /* == hipStream_t */
+
+#define SAR_OK 0
+#define SAR_EINVAL (-1)
+#define SAR_ELAUNCH (-2)
+enum { SAR_ACT_NONE = 0, SAR_ACT_TANH = 1, SAR_ACT_RELU = 2 };
+enum { SAR_HEAD_SPHEREFACE = 0, SAR_HEAD_COSFACE = 1, SAR_HEAD_ARCFACE = 2 };
+
+/* ---- Dense / GEMM: keras Dense at model.py:35-42 (DS), 150, 163; GRU projections model.py:44-50; 1x1
+ * assignment conv model.py:89-105.  C[M,N] (+)= act(op(A) op(B) + bias).  a_kc: A is (M,K) row-major else (K,M);
+ * b_kc: B is (N,K) row-major else (K,N).  splitk>1 accumulates atomically (act must be NONE). */
+int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                 int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk, sarStream_t stream);
+
+/* ---- ResNet convolutions: Conv2D at resnet.py:39-42, 60-63, 82-87, 113-117 (TF SAME / VALID padding given as
+ * explicit pad_top/pad_left).  scale/shift (nullable) fold the preceding BatchNormalization+ReLU
+ * (resnet.py:22-26) into the operand load: P(x)=relu(x*scale+shift).  residual (nullable) is the Add() of
+ * resnet.py:89.  Cin, Cout must be multiples of 16. */
+int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                       const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                       int KW, int stride, int pad_top, int pad_left, sarStream_t stream);
+int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                         int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int accumulate,
+                         sarStream_t stream);
+int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift, float* dw, int B,
+                         int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top,
+                         int pad_left, sarStream_t stream);
+/* 7x7/2 stem on the 1-channel fbank image: resnet.py:173 / 191.  C0 <= 64, C0 % 4 == 0. */
+int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ho,
+                             int Wo, int C0, int pad_top, int pad_left, sarStream_t stream);
+int sar_stem_conv7x7_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int B, int H, int W, int Ho,
+                               int Wo, int C0, int pad_top, int pad_left, sarStream_t stream);
+/* BN+ReLU (resnet.py:43) fused with MaxPooling2D 3x3/2 'same' (resnet.py:174,192). idx = argmax window slot. */
+int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, const float* shift, float* out, uint8_t* idx,
+                                int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
+                                sarStream_t stream);
+int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint8_t* idx, const float* x,
+                                const float* mean, const float* rstd, const float* scale, double* sums, float* dx,
+                                int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
+                                sarStream_t stream);
+
+/* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
+ * x is viewed (R, C).  sums = double[2C] scratch. */
+int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, double* sums, float* mean, float* rstd,
+                     float* scale, float* shift, float* moving_mean, float* moving_var, long R, int C, float eps,
+                     float momentum, int unbiased_moving_var, sarStream_t stream);
+int sar_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, long R, int C, int relu,
+                     sarStream_t stream);
+int sar_bn_bwd_f32(const float* dact, const float* x, const float* scale, const float* shift, const float* mean,
+                   const float* rstd, double* sums, const float* add, float* dx, float* dgamma, float* dbeta, long R,
+                   int C, int relu, sarStream_t stream);
+int sar_bn_param_grads_f32(const double* sums, float* dgamma, float* dbeta, int C, sarStream_t stream);
+int sar_bn1d_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                     float* moving_mean, float* moving_var, int B, int C, float eps, float momentum,
+                     sarStream_t stream);
+int sar_bn1d_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                     float* dx, float* dgamma, float* dbeta, int B, int C, sarStream_t stream);
+
+/* ---- LayerNormalization (keras_layer_normalization, eps = K.epsilon()^2): model.py:4,32-33 */
+int sar_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                          long R, int C, float eps, sarStream_t stream);
+int sar_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                          float* dx, float* dgamma, float* dbeta, long R, int C, int accumulate, sarStream_t stream);
+
+/* ---- Bidirectional(CuDNNGRU), merge_mode='concat': model.py:44-50.  xa_* = x*kernel + bias[:3H] (B,L,3H);
+ * out (B,L,2H) = [fwd | bwd]; gates (2,B,L,4,H), hprev (2,B,L,H) are saved for BPTT; UT_* = U^T (3H,H);
+ * dai/dah (2,B,L,3H) are the input-side / recurrent-side pre-activation gradients. */
+int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const float* U_fwd, const float* U_bwd,
+                      const float* bh_fwd, const float* bh_bwd, float* out, float* gates, float* hprev, int B, int L,
+                      int H, sarStream_t stream);
+int sar_bigru_bwd_f32(const float* dout, const float* gates, const float* hprev, const float* UT_fwd,
+                      const float* UT_bwd, float* dai, float* dah, int B, int L, int H, sarStream_t stream);
+int sar_bigru_last_fwd_f32(const float* out, float* y, int B, int L, int H, sarStream_t stream); /* seq=False, model.py:128 */
+int sar_bigru_last_bwd_f32(const float* dy, float* dout, int B, int L, int H, sarStream_t stream);
+
+/* ---- K.ctc_batch_cost(labels, y_pred, input_length, label_length): model.py:62-64.  labels float32 (B,maxU). */
+size_t sar_ctc_workspace_bytes(int B, int L, int max_label_len);
+int sar_ctc_batch_cost_fwd_f32(const float* probs, const float* labels, const int* in_len, const int* lab_len,
+                               float* loss, void* workspace, size_t workspace_bytes, int B, int L, int V,
+                               int max_label_len, sarStream_t stream);
+int sar_ctc_batch_cost_bwd_f32(const float* probs, const float* labels, const int* in_len, const int* lab_len,
+                               const float* loss, const float* dloss, const void* workspace, size_t workspace_bytes,
+                               float* dprobs, int B, int L, int V, int max_label_len, sarStream_t stream);
+int sar_ctc_greedy_decode_f32(const float* probs, const int* in_len, int* decoded, int* decoded_len, int B, int L,
+                              int V, sarStream_t stream); /* K.ctc_decode(greedy=True), model.py:385-389 */
+
+/* ---- VladPooling.call: VLAD.py:26-49.  feat (B,L,D), score (B,L,K+G), centers (K+G,D) -> out (B,K*D). */
+int sar_vlad_fwd_f32(const float* feat, const float* score, const float* centers, float* out, float* A, float* inv,
+                     int B, int L, int D, int K, int G, sarStream_t stream);
+int sar_vlad_bwd_f32(const float* dout, const float* feat, const float* A, const float* centers, const float* out,
+                     const float* inv, float* dfeat, float* dscore, float* dcenters, int B, int L, int D, int K, int G,
+                     int accumulate_dfeat, sarStream_t stream);
+
+/* ---- SphereFace/CosFace/ArcFace.call: losses.py:28-47, 74-91, 121-144 */
+int sar_margin_head_fwd_f32(const float* x, const float* y, const float* W, float* probs, float* cosv, float* inv_x,
+                            float* inv_w, int B, int D, int A, int mode, float s, float m, sarStream_t stream);
+int sar_margin_head_bwd_f32(const float* dprobs, const float* probs, const float* cosv, const float* x, const float* y,
+                            const float* W, const float* inv_x, const float* inv_w, float* dx, float* dW, float* dwn_ws,
+                            int B, int D, int A, int mode, float s, float m, int accumulate_dx, sarStream_t stream);
+/* ---- circle_loss: losses.py:157-172 ; Keras categorical_crossentropy: model.py:350,354 */
+int sar_circle_loss_fwd_f32(const float* y, const float* s, float* loss, int B, int A, float gamma, float margin, sarStream_t stream);
+int sar_circle_loss_bwd_f32(const float* y, const float* s, const float* dloss, float* ds, int B, int A, float gamma, float margin, sarStream_t stream);
+int sar_cce_fwd_f32(const float* y, const float* p, float* loss, int B, int A, sarStream_t stream);
+int sar_cce_bwd_f32(const float* y, const float* p, const float* dloss, float* dp, int B, int A, sarStream_t stream);
+
+/* ---- small helpers */
+int sar_act_bwd_f32(const float* dy, const float* y, float* dz, long n, int act, sarStream_t stream);
+int sar_softmax_fwd_f32(const float* z, float* p, int rows, int N, sarStream_t stream);
+int sar_softmax_bwd_f32(const float* dp, const float* p, float* dz, int rows, int N, sarStream_t stream);
+int sar_colsum_f32(const float* x, float* out, long R, int C, sarStream_t stream);                /* out += */
+int sar_axpy_f32(const float* x, float* y, float a, long n, sarStream_t stream);
+int sar_fill_f32(float* y, float v, long n, sarStream_t stream);
+int sar_avgpool1d_fwd_f32(const float* x, float* y, int B, int L, int C, sarStream_t stream);     /* model.py:125 */
+int sar_avgpool1d_bwd_f32(const float* dy, float* dx, int B, int L, int C, int accumulate, sarStream_t stream);
+int sar_l2norm_rows_fwd_f32(const float* x, float* v, float* inv, int R, int C, sarStream_t stream); /* model.py:162 */
+int sar_l2norm_rows_bwd_f32(const float* dv, const float* v, const float* inv, float* dx, int R, int C, int accumulate, sarStream_t stream);
+int sar_transpose_f32(const float* x, float* y, int R, int C, sarStream_t stream);
+
+/* ---- Adam(lr, decay=2e-4) + l2 regularisers + unit_norm: model.py:197, 35-48, 163.
+ * state: device block {float lr, decay, beta1, beta2, eps, lr_t; int iterations; float grad_scale}. */
+int sar_adam_prepare(void* state, sarStream_t stream);
+int sar_adam_l2_step_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
+                         const void* state, float* l2_loss, long n, sarStream_t stream);
+int sar_unit_norm_f32(float* w, int D, int A, sarStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SARNET_H_ */

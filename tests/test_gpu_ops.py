@@ -1,0 +1,380 @@
+"""GPU parity tests: every C-ABI entry point of libsarnet_hip.so against the CPU oracle (oracle/ops_np.py)
+on the same seeded inputs.  Tolerance: fp32 kernels vs the float64 oracle, max-abs error relative to the
+reference's max-abs value <= 2e-4 (north-star asks 1e-3 on logits / CTC loss)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_np as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def L():
+    from aesrc2020_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.lib()
+    return _lib
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def zeros(*shape, dtype=torch.float32):
+    return torch.zeros(*shape, dtype=dtype, device="cuda")
+
+
+def check(got, ref, tol=TOL, name="", scale=None):
+    """max-abs error relative to `scale` (default: the reference's max-abs value)."""
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.all(np.isfinite(got)), name
+    err = np.abs(got - ref).max() / ((np.abs(ref).max() if scale is None else scale) + 1e-6)
+    assert err <= tol, "%s: rel-to-max error %.3e > %.1e" % (name, err, tol)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (70, 33, 19), (2496, 256, 256), (5, 8, 300)])
+def test_gemm_layouts(L, a_kc, b_kc, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N)); bias = rng.standard_normal(N)
+    Ad = dev(A if a_kc else A.T); Bd = dev(B.T if b_kc else B); C = zeros(M, N)
+    L.call("sar_gemm_f32", Ad, Bd, C, dev(bias), M, N, K, Ad.shape[1], Bd.shape[1], N, a_kc, b_kc, 0, 0, 1)
+    check(C, A @ B + bias, name="gemm")
+    L.call("sar_gemm_f32", Ad, Bd, C, None, M, N, K, Ad.shape[1], Bd.shape[1], N, a_kc, b_kc, 1, 0, 1)
+    check(C, np.tanh(A @ B), name="gemm tanh")
+    C0 = rng.standard_normal((M, N)); C = dev(C0)
+    L.call("sar_gemm_f32", Ad, Bd, C, None, M, N, K, Ad.shape[1], Bd.shape[1], N, a_kc, b_kc, 0, 1, 1)
+    check(C, C0 + A @ B, name="gemm accumulate")
+    C = zeros(M, N)
+    L.call("sar_gemm_f32", Ad, Bd, C, dev(bias), M, N, K, Ad.shape[1], Bd.shape[1], N, a_kc, b_kc, 0, 0, 4)
+    check(C, A @ B + bias, name="gemm splitk")
+
+
+def test_gemm_transpose_detecting(L):
+    # asymmetric B with A = I catches a swapped C write (guide rule 16)
+    n = 64
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n) / n
+    C = zeros(n, n)
+    L.call("sar_gemm_f32", dev(np.eye(n)), dev(B), C, None, n, n, n, n, n, n, 1, 0, 0, 0, 1)
+    check(C, B, 1e-6)
+
+
+# ------------------------------------------------------------------ conv
+CONV_CASES = [  # B,H,W,Cin,Cout,k,stride,pad,prologue,residual
+    (2, 10, 8, 16, 16, 3, 1, "same", True, True), (2, 10, 8, 32, 64, 3, 2, "same", True, False),
+    (2, 13, 5, 16, 32, 3, 2, "same", False, False), (3, 25, 5, 64, 128, 1, 2, "valid", False, False),
+    (2, 12, 6, 64, 32, 1, 1, "valid", False, False), (1, 20, 20, 32, 32, 3, 1, "same", True, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(L, case):
+    B, H, W, Cin, Cout, k, s, pad, pro, res = case
+    rng = np.random.default_rng(sum(case[:7]))
+    x = rng.standard_normal((B, H, W, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) * 0.1; b = rng.standard_normal(Cout)
+    scale = rng.uniform(0.5, 1.5, Cin); shift = rng.standard_normal(Cin) * 0.3
+    act = np.maximum(x * scale + shift, 0) if pro else x
+    y_ref, cache = O.conv2d_fwd(act, w, b, (s, s), pad)
+    _, Ho, Wo, _ = y_ref.shape
+    if pad == "same":
+        pt = O.same_pads(H, k, s)[1]; pl = O.same_pads(W, k, s)[1]
+    else:
+        pt = pl = 0
+    r = rng.standard_normal(y_ref.shape) if res else None
+    xd, wd = dev(x), dev(w)
+    scd, shd = (dev(scale), dev(shift)) if pro else (None, None)
+    y = zeros(B, Ho, Wo, Cout)
+    L.call("sar_conv2d_fwd_f32", xd, wd, dev(b), scd, shd, dev(r) if res else None, y, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
+    check(y, y_ref + (r if res else 0), name="conv fwd")
+    dy = rng.standard_normal(y_ref.shape)
+    dact_ref, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+    dyd = dev(dy)
+    dx = zeros(B, H, W, Cin)
+    L.call("sar_conv2d_dgrad_f32", dyd, wd, dx, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 0)
+    check(dx, dact_ref, name="conv dgrad")
+    L.call("sar_conv2d_dgrad_f32", dyd, wd, dx, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 1)
+    check(dx, 2 * dact_ref, name="conv dgrad accumulate")
+    dw = zeros(k, k, Cin, Cout)
+    L.call("sar_conv2d_wgrad_f32", xd, dyd, scd, shd, dw, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
+    check(dw, dw_ref, name="conv wgrad")
+    db = zeros(Cout)
+    L.call("sar_colsum_f32", dyd, db, B * Ho * Wo, Cout)
+    check(db, db_ref, name="conv dbias")
+
+
+@pytest.mark.parametrize("B,T,D,C0", [(2, 100, 80, 64), (2, 37, 21, 8), (1, 64, 80, 32)])
+def test_stem_and_fused_maxpool(L, B, T, D, C0):
+    rng = np.random.default_rng(T)
+    x = rng.random((B, T, D, 1)); w = rng.standard_normal((7, 7, 1, C0)) * 0.2; b = rng.standard_normal(C0) * 0.1
+    y_ref, cache = O.conv2d_fwd(x, w, b, (2, 2), "same")
+    Ho, pt, _ = O.same_pads(T, 7, 2); Wo, pl, _ = O.same_pads(D, 7, 2)
+    xd = dev(x); y = zeros(B, Ho, Wo, C0)
+    L.call("sar_stem_conv7x7_fwd_f32", xd, dev(w), dev(b), y, B, T, D, Ho, Wo, C0, pt, pl)
+    check(y, y_ref, name="stem fwd")
+    # BN(train) + ReLU + MaxPool fused
+    gamma = rng.uniform(0.5, 1.5, C0); beta = rng.standard_normal(C0) * 0.2
+    bn_ref, bnc = O.batchnorm_fwd(y_ref, gamma, beta)
+    a_ref = O.relu_fwd(bn_ref)
+    p_ref, pc = O.maxpool_fwd(a_ref)
+    Hp, ppt, _ = O.same_pads(Ho, 3, 2); Wp, ppl, _ = O.same_pads(Wo, 3, 2)
+    sums = zeros(2 * C0, dtype=torch.float64)
+    mean, rstd, scale, shift = zeros(C0), zeros(C0), zeros(C0), zeros(C0)
+    mm, mv = zeros(C0), torch.ones(C0, device="cuda")
+    yd = dev(y_ref)
+    L.call("sar_bn_stats_f32", yd, dev(gamma), dev(beta), sums, mean, rstd, scale, shift, mm, mv, B * Ho * Wo, C0, 1e-3, 0.99, 1)
+    check(mean, bnc[4], name="bn mean"); check(rstd, bnc[1], name="bn rstd")
+    pooled = zeros(B, Hp, Wp, C0); idx = zeros(B, Hp, Wp, C0, dtype=torch.uint8)
+    L.call("sar_bn_relu_maxpool_fwd_f32", yd, scale, shift, pooled, idx, B, Ho, Wo, C0, Hp, Wp, ppt, ppl)
+    check(pooled, p_ref, name="bn+relu+maxpool fwd")
+    dpool = rng.standard_normal(p_ref.shape)
+    da = O.maxpool_bwd(dpool, pc)
+    dbn = O.relu_bwd(da, a_ref)
+    dy_ref, dg_ref, dbeta_ref = O.batchnorm_bwd(dbn, bnc)
+    dyd = zeros(B, Ho, Wo, C0)
+    L.call("sar_maxpool_bn_relu_bwd_f32", dev(dpool), pooled, idx, yd, mean, rstd, scale, sums, dyd, B, Ho, Wo, C0, Hp, Wp, ppt, ppl)
+    check(dyd, dy_ref, name="maxpool+bn+relu bwd")
+    dg, dbt = zeros(C0), zeros(C0)
+    L.call("sar_bn_param_grads_f32", sums, dg, dbt, C0)
+    check(dg, dg_ref, name="stem dgamma"); check(dbt, dbeta_ref, name="stem dbeta")
+    # stem wgrad
+    _, dw_ref, db_ref = O.conv2d_bwd(dy_ref, cache)
+    dw, db = zeros(7, 7, 1, C0), zeros(C0)
+    L.call("sar_stem_conv7x7_wgrad_f32", xd, dev(dy_ref), dw, db, B, T, D, Ho, Wo, C0, pt, pl)
+    check(dw, dw_ref, name="stem wgrad")
+    # the BN-backward gradient sums to exactly zero per channel, so scale by the summed magnitudes instead
+    check(db, db_ref, name="stem dbias", scale=np.abs(dy_ref).sum((0, 1, 2)).max())
+
+
+# ------------------------------------------------------------------ normalisation
+@pytest.mark.parametrize("R,C,relu", [(200, 32, 1), (999, 64, 1), (77, 256, 0), (64, 8, 1)])
+def test_batchnorm_4d(L, R, C, relu):
+    rng = np.random.default_rng(R + C)
+    x = rng.standard_normal((R, C)) * 2 + 0.5; gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C) * 0.3
+    y_ref, cache = O.batchnorm_fwd(x, gamma, beta)
+    a_ref = O.relu_fwd(y_ref) if relu else y_ref
+    xd = dev(x); sums = zeros(2 * C, dtype=torch.float64)
+    mean, rstd, scale, shift = zeros(C), zeros(C), zeros(C), zeros(C)
+    L.call("sar_bn_stats_f32", xd, dev(gamma), dev(beta), sums, mean, rstd, scale, shift, None, None, R, C, 1e-3, 0.99, 1)
+    y = zeros(R, C)
+    L.call("sar_bn_apply_f32", xd, scale, shift, y, R, C, relu)
+    check(y, a_ref, name="bn apply")
+    dact = rng.standard_normal((R, C)); add = rng.standard_normal((R, C))
+    dz = O.relu_bwd(dact, a_ref) if relu else dact
+    dx_ref, dg_ref, db_ref = O.batchnorm_bwd(dz, cache)
+    dx, dg, db = zeros(R, C), zeros(C), zeros(C)
+    L.call("sar_bn_bwd_f32", dev(dact), xd, scale, shift, mean, rstd, sums, dev(add), dx, dg, db, R, C, relu)
+    check(dx, dx_ref + add, name="bn bwd dx"); check(dg, dg_ref, name="bn dgamma"); check(db, db_ref, name="bn dbeta")
+
+
+@pytest.mark.parametrize("B,C", [(64, 2048), (5, 130), (64, 256)])
+def test_batchnorm_2d(L, B, C):
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal((B, C)); gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C)
+    y_ref, cache = O.batchnorm_fwd(x, gamma, beta)
+    xd, gd = dev(x), dev(gamma); y, mean, rstd = zeros(B, C), zeros(C), zeros(C)
+    L.call("sar_bn1d_fwd_f32", xd, gd, dev(beta), y, mean, rstd, None, None, B, C, 1e-3, 0.99)
+    check(y, y_ref, name="bn1d fwd")
+    dy = rng.standard_normal((B, C)); dx_ref, dg_ref, db_ref = O.batchnorm_bwd(dy, cache)
+    dx, dg, db = zeros(B, C), zeros(C), zeros(C)
+    L.call("sar_bn1d_bwd_f32", dev(dy), xd, gd, mean, rstd, dx, dg, db, B, C)
+    check(dx, dx_ref, name="bn1d dx"); check(dg, dg_ref, name="bn1d dgamma"); check(db, db_ref, name="bn1d dbeta")
+
+
+@pytest.mark.parametrize("R,C", [(2496, 256), (100, 512), (7, 16), (33, 2048)])
+def test_layernorm(L, R, C):
+    rng = np.random.default_rng(R)
+    x = rng.standard_normal((R, C)); gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C)
+    y_ref, cache = O.layernorm_fwd(x, gamma, beta)
+    xd, gd = dev(x), dev(gamma); y, mean, rstd = zeros(R, C), zeros(R), zeros(R)
+    L.call("sar_layernorm_fwd_f32", xd, gd, dev(beta), y, mean, rstd, R, C, 1e-14)
+    check(y, y_ref, name="ln fwd")
+    dy = rng.standard_normal((R, C)); dx_ref, dg_ref, db_ref = O.layernorm_bwd(dy, cache)
+    dx, dg, db = zeros(R, C), zeros(C), zeros(C)
+    L.call("sar_layernorm_bwd_f32", dev(dy), xd, gd, mean, rstd, dx, dg, db, R, C, 0)
+    check(dx, dx_ref, name="ln dx"); check(dg, dg_ref, name="ln dgamma"); check(db, db_ref, name="ln dbeta")
+    L.call("sar_layernorm_bwd_f32", dev(dy), xd, gd, mean, rstd, dx, dg, db, R, C, 1)
+    check(dx, 2 * dx_ref, name="ln dx accumulate")
+
+
+# ------------------------------------------------------------------ BiGRU
+@pytest.mark.parametrize("B,Lq,I,H", [(5, 7, 12, 64), (64, 39, 256, 256), (3, 12, 40, 20)])
+def test_bigru(L, B, Lq, I, H):
+    rng = np.random.default_rng(B * Lq)
+    x = rng.standard_normal((B, Lq, I))
+    mk = lambda: (rng.standard_normal((I, 3 * H)) / np.sqrt(I), rng.standard_normal((H, 3 * H)) / np.sqrt(H), rng.standard_normal(6 * H) * 0.1)
+    pf, pb = mk(), mk()
+    y_ref, cache = O.bigru_fwd(x, pf, pb, True)
+    xd = dev(x)
+    xa = [zeros(B * Lq, 3 * H), zeros(B * Lq, 3 * H)]
+    W = [dev(pf[0]), dev(pb[0])]; U = [dev(pf[1]), dev(pb[1])]; bias = [dev(pf[2]), dev(pb[2])]
+    for d in range(2):
+        L.call("sar_gemm_f32", xd, W[d], xa[d], bias[d], B * Lq, 3 * H, I, I, 3 * H, 3 * H, 1, 0, 0, 0, 1)
+    out = zeros(B, Lq, 2 * H); gates = zeros(2, B, Lq, 4, H); hprev = zeros(2, B, Lq, H)
+    L.call("sar_bigru_fwd_f32", xa[0], xa[1], U[0], U[1], bias[0][3 * H:], bias[1][3 * H:], out, gates, hprev, B, Lq, H)
+    check(out, y_ref, name="bigru fwd")
+    dy = rng.standard_normal(y_ref.shape)
+    dx_ref, gf, gb = O.bigru_bwd(dy, cache)
+    UT = [zeros(3 * H, H), zeros(3 * H, H)]
+    for d in range(2):
+        L.call("sar_transpose_f32", U[d], UT[d], H, 3 * H)
+    check(UT[0], pf[1].T, 1e-7, "transpose")
+    dai = zeros(2, B, Lq, 3 * H); dah = zeros(2, B, Lq, 3 * H)
+    L.call("sar_bigru_bwd_f32", dev(dy), gates, hprev, UT[0], UT[1], dai, dah, B, Lq, H)
+    dx = zeros(B * Lq, I)
+    for d, g in ((0, gf), (1, gb)):
+        L.call("sar_gemm_f32", dai[d], W[d], dx, None, B * Lq, I, 3 * H, 3 * H, 3 * H, I, 1, 1, 0, d, 1)      # dx (+)= dai W^T
+        dW = zeros(I, 3 * H); dU = zeros(H, 3 * H); db = zeros(6 * H)
+        L.call("sar_gemm_f32", xd, dai[d], dW, None, I, 3 * H, B * Lq, I, 3 * H, 3 * H, 0, 0, 0, 0, 1)          # x^T dai
+        L.call("sar_gemm_f32", hprev[d], dah[d], dU, None, H, 3 * H, B * Lq, H, 3 * H, 3 * H, 0, 0, 0, 0, 1)    # hprev^T dah
+        L.call("sar_colsum_f32", dai[d], db[:3 * H], B * Lq, 3 * H); L.call("sar_colsum_f32", dah[d], db[3 * H:], B * Lq, 3 * H)
+        check(dW, g[0], name="gru dW"); check(dU, g[1], name="gru dU"); check(db, g[2], name="gru db")
+    check(dx.view(B, Lq, I), dx_ref, name="bigru dx")
+    # seq=False helper
+    yl = zeros(B, 2 * H); L.call("sar_bigru_last_fwd_f32", out, yl, B, Lq, H)
+    check(yl, O.bigru_fwd(x, pf, pb, False)[0], name="bigru last")
+    dl = rng.standard_normal((B, 2 * H)); dout = zeros(B, Lq, 2 * H)
+    L.call("sar_bigru_last_bwd_f32", dev(dl), dout, B, Lq, H)
+    ref = np.zeros((B, Lq, 2 * H)); ref[:, -1, :H] = dl[:, :H]; ref[:, 0, H:] = dl[:, H:]
+    check(dout, ref, 1e-7, "bigru last bwd")
+
+
+# ------------------------------------------------------------------ CTC
+def _ctc_inputs(B, Lq, V, maxU, rng, Umax):
+    p = O.softmax(rng.standard_normal((B, Lq, V)) * 2)
+    lab = np.full((B, maxU), 2.0, np.float32); ll = np.zeros((B, 1), np.int32)
+    for b in range(B):
+        u = int(rng.integers(1, Umax + 1)); ll[b] = u
+        lab[b, :u] = rng.integers(0, V - 1, u)
+    il = np.full((B, 1), Lq, np.int32)
+    return p, lab, il, ll
+
+
+@pytest.mark.parametrize("B,Lq,V,maxU,Umax", [(4, 12, 9, 8, 4), (64, 39, 1000, 72, 16), (3, 189, 50, 72, 60)])
+def test_ctc(L, B, Lq, V, maxU, Umax):
+    rng = np.random.default_rng(V)
+    p, lab, il, ll = _ctc_inputs(B, Lq, V, maxU, rng, Umax)
+    lab[0, 1] = lab[0, 0]; ll[0] = max(ll[0], 2)            # a repeated label
+    il[1] = Lq - 3                                           # a shorter input
+    if B > 2:
+        ll[2] = min(maxU, Lq + 1); lab[2, :ll[2, 0]] = rng.integers(0, V - 1, ll[2, 0])   # infeasible: U > T
+    loss_ref, grad_ref = O.ctc_batch_cost_fwd_bwd(p, lab, il, ll)
+    pd, labd, ild, lld = dev(p), dev(lab), dev(il.ravel(), torch.int32), dev(ll.ravel(), torch.int32)
+    wsb = L.ctc_workspace_bytes(B, Lq, maxU); ws = zeros(wsb // 4)
+    loss = zeros(B)
+    L.call("sar_ctc_batch_cost_fwd_f32", pd, labd, ild, lld, loss, ws, wsb, B, Lq, V, maxU)
+    got = loss.cpu().numpy(); fin = np.isfinite(loss_ref[:, 0])
+    assert np.array_equal(np.isfinite(got), fin)
+    np.testing.assert_allclose(got[fin], loss_ref[fin, 0], rtol=1e-4, atol=1e-4)
+    dloss = rng.uniform(0.5, 1.5, B); dp = torch.full((B, Lq, V), 7.0, device="cuda")
+    L.call("sar_ctc_batch_cost_bwd_f32", pd, labd, ild, lld, loss, dev(dloss), ws, wsb, dp, B, Lq, V, maxU)
+    check(dp, grad_ref * dloss[:, None, None], 5e-4, "ctc grad")
+    dec = zeros(B, Lq, dtype=torch.int32); dl = zeros(B, dtype=torch.int32)
+    L.call("sar_ctc_greedy_decode_f32", pd, ild, dec, dl, B, Lq, V)
+    ref = O.ctc_greedy_decode(p, il)
+    for b in range(B):
+        assert dec[b, :int(dl[b])].cpu().tolist() == ref[b]
+
+
+# ------------------------------------------------------------------ VLAD / heads
+@pytest.mark.parametrize("B,Lq,D,K,G", [(3, 6, 20, 4, 0), (64, 39, 256, 32, 2), (4, 189, 256, 64, 2), (5, 12, 64, 8, 2)])
+def test_vlad(L, B, Lq, D, K, G):
+    rng = np.random.default_rng(K + D)
+    f = rng.standard_normal((B, 1, Lq, D)); s = rng.standard_normal((B, 1, Lq, K + G)) * 2; c = rng.standard_normal((K + G, D))
+    y_ref, cache = O.vlad_fwd(f, s, c, K, "gvlad" if G else "vlad")
+    fd, cd = dev(f), dev(c)
+    out, A, inv = zeros(B, K * D), zeros(B, Lq, K + G), zeros(B, K)
+    L.call("sar_vlad_fwd_f32", fd, dev(s), cd, out, A, inv, B, Lq, D, K, G)
+    check(out, y_ref, name="vlad fwd")
+    dy = rng.standard_normal(y_ref.shape)
+    df_ref, ds_ref, dc_ref = O.vlad_bwd(dy, cache)
+    df, ds, dc = zeros(B, Lq, D), zeros(B, Lq, K + G), zeros(K + G, D)
+    L.call("sar_vlad_bwd_f32", dev(dy), fd, A, cd, out, inv, df, ds, dc, B, Lq, D, K, G, 0)
+    check(df, df_ref.reshape(B, Lq, D), name="vlad dfeat"); check(ds, ds_ref.reshape(B, Lq, K + G), name="vlad dscore")
+    check(dc, dc_ref, name="vlad dcenters")
+
+
+@pytest.mark.parametrize("mode,name,m", [(0, "sphereface", 1.35), (1, "cosface", 0.3), (2, "arcface", 0.3)])
+def test_margin_heads(L, mode, name, m):
+    rng = np.random.default_rng(mode)
+    B, D, A = 64, 256, 8
+    x = rng.standard_normal((B, D)); W = rng.standard_normal((D, A)) * 0.1; y = np.eye(A)[rng.integers(0, A, B)]
+    p_ref, cache = O.margin_head_fwd(x, y, W, name, 30.0, m)
+    xd, yd, Wd = dev(x), dev(y), dev(W)
+    p, cosv, ix, iw = zeros(B, A), zeros(B, A), zeros(B), zeros(A)
+    L.call("sar_margin_head_fwd_f32", xd, yd, Wd, p, cosv, ix, iw, B, D, A, mode, 30.0, m)
+    check(p, p_ref, name=name + " fwd")
+    dp = rng.standard_normal((B, A))
+    dx_ref, dW_ref = O.margin_head_bwd(dp, cache)
+    dx, dW, ws = zeros(B, D), zeros(D, A), zeros(D, A)
+    L.call("sar_margin_head_bwd_f32", dev(dp), p, cosv, xd, yd, Wd, ix, iw, dx, dW, ws, B, D, A, mode, 30.0, m, 0)
+    check(dx, dx_ref, 1e-3, name + " dx"); check(dW, dW_ref, 1e-3, name + " dW")
+
+
+def test_circle_cce_softmax_misc(L):
+    rng = np.random.default_rng(11)
+    B, A = 64, 8
+    s = np.tanh(rng.standard_normal((B, A))); y = np.eye(A)[rng.integers(0, A, B)]
+    loss_ref, ds_ref = O.circle_loss_fwd_bwd(y, s, 256.0, 0.3)
+    sd, yd = dev(s), dev(y); loss = zeros(B)
+    L.call("sar_circle_loss_fwd_f32", yd, sd, loss, B, A, 256.0, 0.3)
+    check(loss, loss_ref, name="circle fwd")
+    g = rng.uniform(0.5, 2, B); ds = zeros(B, A)
+    L.call("sar_circle_loss_bwd_f32", yd, sd, dev(g), ds, B, A, 256.0, 0.3)
+    check(ds, ds_ref * g[:, None], name="circle bwd")
+    p = O.softmax(rng.standard_normal((B, A)) * 6); p[0] = [1 - 7e-9] + [1e-9] * 7
+    l_ref, dp_ref = O.categorical_crossentropy_fwd_bwd(y, p)
+    pd = dev(p); L.call("sar_cce_fwd_f32", yd, pd, loss, B, A)
+    check(loss, l_ref, name="cce fwd")
+    dp = zeros(B, A); L.call("sar_cce_bwd_f32", yd, pd, dev(g), dp, B, A)
+    check(dp, dp_ref * g[:, None], name="cce bwd")
+    for N in (8, 1000):
+        z = rng.standard_normal((70, N)) * 3; zd = dev(z); q = zeros(70, N)
+        L.call("sar_softmax_fwd_f32", zd, q, 70, N); check(q, O.softmax(z), name="softmax fwd")
+        dq = rng.standard_normal((70, N)); sm = O.softmax(z); dz = zeros(70, N)
+        L.call("sar_softmax_bwd_f32", dev(dq), q, dz, 70, N)
+        check(dz, sm * (dq - (dq * sm).sum(-1, keepdims=True)), name="softmax bwd")
+    x = rng.standard_normal((64, 256)); x[3] = 0
+    v_ref, cache = O.l2_normalize_fwd(x, 1); v, inv = zeros(64, 256), zeros(64)
+    L.call("sar_l2norm_rows_fwd_f32", dev(x), v, inv, 64, 256); check(v, v_ref, name="l2n fwd")
+    dv = rng.standard_normal((64, 256)); dx = zeros(64, 256)
+    L.call("sar_l2norm_rows_bwd_f32", dev(dv), v, inv, dx, 64, 256, 0)
+    ref = O.l2_normalize_bwd(dv, cache); ref[3] = 0; got = dx.clone(); got[3] = 0      # row 3 is the clamped branch (1e6 scale)
+    check(got, ref, name="l2n bwd")
+    x3 = rng.standard_normal((5, 12, 16)); y2 = zeros(5, 16)
+    L.call("sar_avgpool1d_fwd_f32", dev(x3), y2, 5, 12, 16); check(y2, x3.mean(1), name="avgpool")
+    dy2 = rng.standard_normal((5, 16)); dx3 = zeros(5, 12, 16)
+    L.call("sar_avgpool1d_bwd_f32", dev(dy2), dx3, 5, 12, 16, 0); check(dx3, O.global_avg_pool_bwd(dy2, 12), name="avgpool bwd")
+    yv = dev(np.ones(1000)); L.call("sar_axpy_f32", dev(np.arange(1000.0)), yv, 0.5, 1000); check(yv, 1 + 0.5 * np.arange(1000.0), 1e-7)
+    L.call("sar_fill_f32", yv, 3.0, 1000); check(yv, np.full(1000, 3.0), 1e-7)
+    dz = zeros(100); yy = rng.standard_normal(100); gg = rng.standard_normal(100)
+    L.call("sar_act_bwd_f32", dev(gg), dev(yy), dz, 100, 1); check(dz, gg * (1 - yy * yy), name="tanh bwd")
+    L.call("sar_act_bwd_f32", dev(gg), dev(yy), dz, 100, 2); check(dz, gg * (yy > 0), name="relu bwd")
+
+
+def test_adam_l2_unitnorm(L):
+    rng = np.random.default_rng(5)
+    n = 256 * 40
+    p0 = rng.standard_normal(n); g = rng.standard_normal(n) * 0.1
+    l2 = np.where(np.arange(40) % 2 == 0, 1e-4, 0.0)
+    st = torch.zeros(8, dtype=torch.float32, device="cuda")
+    st[:5] = torch.tensor([0.01, 2e-4, 0.9, 0.999, 1e-7]); st[7] = 0.5
+    st.view(torch.int32)[6] = 0
+    p, m, v = dev(p0), zeros(n), zeros(n); l2l = zeros(1)
+    pr, mr, vr = p0.copy(), np.zeros(n), np.zeros(n)
+    l2e = np.repeat(l2, 256)
+    for it in range(3):
+        l2l.zero_()
+        L.call("sar_adam_prepare", st)
+        L.call("sar_adam_l2_step_f32", p, dev(g), m, v, dev(l2), st, l2l, n)
+        ref_l2 = (l2e * pr * pr).sum()
+        pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, it, lr=0.01)
+        check(p, pr, 1e-5, "adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
+    assert int(st.view(torch.int32)[6]) == 3
+    w = rng.standard_normal((256, 8)); wd = dev(w)
+    L.call("sar_unit_norm_f32", wd, 256, 8); check(wd, O.unit_norm(w), 1e-5, "unit_norm")
