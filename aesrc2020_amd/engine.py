@@ -35,9 +35,21 @@ class ParamStore:
     Parameters are laid out in creation (= forward) order, so the tail of the gradient buffer (heads, GRUs)
     is complete first during backward and the head (conv stack) last -- the two all-reduce buckets of parallel.py."""
 
-    def __init__(self):
+    def __init__(self, seed=0, device="cuda"):
         self.refs = []; self.by_name = {}; self.finalized = False
         self.state_refs = []          # non-trainable (BN moving statistics)
+        self.rng = np.random.default_rng(seed)
+        self.bufs = Buffers(device)
+        self.layers = []              # construction order; drives summary()/get_layer()
+
+    def register_layer(self, layer):
+        self.layers.append(layer)
+
+    def auto_name(self, base):
+        """Keras-style auto names (conv2d_1, batch_normalization_1, ...) in construction order."""
+        self._auto = getattr(self, "_auto", {})
+        self._auto[base] = self._auto.get(base, 0) + 1
+        return "%s_%d" % (base, self._auto[base])
 
     def add(self, name, shape, init, l2=0.0, constraint=None):
         assert not self.finalized, "ParamStore already finalized"

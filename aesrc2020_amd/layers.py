@@ -1,0 +1,232 @@
+"""Eager layer objects for the SAR-Net hot path.  Each mirrors a Keras layer the reference instantiates
+(/root/reference/model.py:23-53) and owns an explicit backward: forward/backward are sequences of C-ABI kernel
+launches on the current HIP stream (no torch autograd, no torch math).  Weight names/layouts follow Keras so that
+by-name checkpoints map 1:1."""
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import ACT, current_store, gemm, pick_splitk, he_normal, glorot_uniform, orthogonal
+
+_call = _lib.call
+BN_EPS, BN_MOMENTUM, LN_EPS = 1e-3, 0.99, 1e-14
+
+
+class Layer:
+    def __init__(self, name):
+        self.name = name
+        self.store = current_store()
+        self.store.register_layer(self)
+
+    def buf(self, key, shape, dtype=torch.float32):
+        return self.store.bufs.get(self.name + "/" + key, shape, dtype)
+
+    def scratch(self, key, shape, dtype=torch.float32):
+        return self.store.bufs.get("scratch/" + key, shape, dtype)
+
+    def count_params(self):
+        return sum(r.size for r in self.params())
+
+    def params(self):
+        return [r for r in self.store.refs if r.name.startswith(self.name + "/")]
+
+
+class Dense(Layer):
+    """keras Dense via DS() (model.py:35-42): y = act(x W + b), he_normal kernel, l2(1e-4) on kernel and bias."""
+
+    def __init__(self, in_dim, units, activation=None, use_bias=True, name=None, l2=1e-4, init="he_normal",
+                 constraint=None):
+        super().__init__(name)
+        rng = self.store.rng
+        w = he_normal(rng, (in_dim, units), in_dim) if init == "he_normal" else glorot_uniform(rng, (in_dim, units), in_dim, units)
+        self.kernel = self.store.add(name + "/kernel", (in_dim, units), w, l2, constraint)
+        self.bias = self.store.add(name + "/bias", (units,), np.zeros(units), l2) if use_bias else None
+        self.in_dim, self.units, self.activation = in_dim, units, activation
+        self.output_shape = (None, units)
+
+    def forward(self, x):
+        R = x.numel() // self.in_dim
+        self.x, self.R = x, R
+        y = self.buf("y", (R, self.units))
+        b = self.bias.w if self.bias is not None else None
+        if self.activation == "softmax":
+            z = self.buf("z", (R, self.units))
+            gemm(x, self.kernel.w, z, b, R, self.units, self.in_dim, self.in_dim, self.units, self.units, 1, 0)
+            _call("sar_softmax_fwd_f32", z, y, R, self.units)
+        else:
+            sk = pick_splitk(R, self.units, self.in_dim) if ACT[self.activation] == 0 else 1
+            if sk > 1:
+                _call("sar_fill_f32", y, 0.0, y.numel())
+            gemm(x, self.kernel.w, y, b, R, self.units, self.in_dim, self.in_dim, self.units, self.units, 1, 0,
+                 ACT[self.activation], 0, sk)
+        self.y = y
+        return y
+
+    def backward(self, dy, need_dx=True, accumulate_dx=False, dx_out=None):
+        R = self.R
+        if self.activation == "softmax":
+            dz = self.scratch("dz%dx%d" % (R, self.units), (R, self.units))
+            _call("sar_softmax_bwd_f32", dy, self.y, dz, R, self.units)
+        elif ACT[self.activation] != 0:
+            dz = self.scratch("dz%dx%d" % (R, self.units), (R, self.units))
+            _call("sar_act_bwd_f32", dy, self.y, dz, R * self.units, ACT[self.activation])
+        else:
+            dz = dy
+        sk = pick_splitk(self.in_dim, self.units, R)
+        gemm(self.x, dz, self.kernel.g, None, self.in_dim, self.units, R, self.in_dim, self.units, self.units, 0, 0, 0, 1, sk)
+        if self.bias is not None:
+            _call("sar_colsum_f32", dz, self.bias.g, R, self.units)
+        if not need_dx:
+            return None
+        dx = dx_out if dx_out is not None else self.buf("dx", (R, self.in_dim))
+        gemm(dz, self.kernel.w, dx, None, R, self.in_dim, self.units, self.units, self.units, self.in_dim, 1, 1, 0,
+             1 if accumulate_dx else 0)
+        return dx
+
+
+class LayerNorm(Layer):
+    """keras_layer_normalization.LayerNormalization() (model.py:32-33): last-axis, eps = 1e-14."""
+
+    def __init__(self, dim, name=None):
+        super().__init__(name)
+        self.gamma = self.store.add(name + "/gamma", (dim,), np.ones(dim))
+        self.beta = self.store.add(name + "/beta", (dim,), np.zeros(dim))
+        self.dim = dim; self.output_shape = (None, dim)
+
+    def forward(self, x):
+        R = x.numel() // self.dim
+        self.x, self.R = x, R
+        y = self.buf("y", (R, self.dim)); self.mean = self.buf("mean", (R,)); self.rstd = self.buf("rstd", (R,))
+        _call("sar_layernorm_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, R, self.dim, LN_EPS)
+        return y
+
+    def backward(self, dy, accumulate_dx=False, dx_out=None):
+        dx = dx_out if dx_out is not None else self.buf("dx", (self.R, self.dim))
+        _call("sar_layernorm_bwd_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g,
+              self.R, self.dim, 1 if accumulate_dx else 0)
+        return dx
+
+
+class BiGRU(Layer):
+    """Bidirectional(CuDNNGRU(hidden, return_sequences=seq), merge_mode='concat') (model.py:44-50)."""
+
+    def __init__(self, in_dim, hidden, seq=True, name=None, l2=1e-4):
+        super().__init__(name)
+        rng = self.store.rng
+        H = hidden
+        self.p = {}
+        for d in ("forward", "backward"):
+            k = self.store.add("%s/%s/kernel" % (name, d), (in_dim, 3 * H), glorot_uniform(rng, (in_dim, 3 * H), in_dim, 3 * H), l2)
+            u = self.store.add("%s/%s/recurrent_kernel" % (name, d), (H, 3 * H),
+                               np.concatenate([orthogonal(rng, (H, H)) for _ in range(3)], 1))
+            b = self.store.add("%s/%s/bias" % (name, d), (6 * H,), np.zeros(6 * H), l2)
+            self.p[d] = (k, u, b)
+        self.in_dim, self.H, self.seq = in_dim, H, seq
+        self.output_shape = (None, None, 2 * H) if seq else (None, 2 * H)
+
+    def forward(self, x, B, L):
+        H, I = self.H, self.in_dim
+        self.x, self.B, self.L = x, B, L
+        R = B * L
+        xa = [self.buf("xa_f", (R, 3 * H)), self.buf("xa_b", (R, 3 * H))]
+        for i, d in enumerate(("forward", "backward")):
+            k, u, b = self.p[d]
+            gemm(x, k.w, xa[i], b.w, R, 3 * H, I, I, 3 * H, 3 * H, 1, 0)
+        self.out = self.buf("out", (B, L, 2 * H)); self.gates = self.buf("gates", (2, B, L, 4, H)); self.hprev = self.buf("hprev", (2, B, L, H))
+        (kf, uf, bf), (kb, ub, bb) = self.p["forward"], self.p["backward"]
+        _call("sar_bigru_fwd_f32", xa[0], xa[1], uf.w, ub.w, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
+        if self.seq:
+            return self.out
+        y = self.buf("last", (B, 2 * H))
+        _call("sar_bigru_last_fwd_f32", self.out, y, B, L, H)
+        return y
+
+    def backward(self, dy, need_dx=True, accumulate_dx=False, dx_out=None):
+        H, I, B, L = self.H, self.in_dim, self.B, self.L
+        R = B * L
+        if not self.seq:
+            dout = self.scratch("gru_dout%d_%d_%d" % (B, L, H), (B, L, 2 * H))
+            _call("sar_bigru_last_bwd_f32", dy, dout, B, L, H)
+        else:
+            dout = dy
+        UT = [self.scratch("gru_UT0_%d" % H, (3 * H, H)), self.scratch("gru_UT1_%d" % H, (3 * H, H))]
+        for i, d in enumerate(("forward", "backward")):
+            _call("sar_transpose_f32", self.p[d][1].w, UT[i], H, 3 * H)
+        dai = self.scratch("gru_dai%d_%d_%d" % (B, L, H), (2, B, L, 3 * H)); dah = self.scratch("gru_dah%d_%d_%d" % (B, L, H), (2, B, L, 3 * H))
+        _call("sar_bigru_bwd_f32", dout, self.gates, self.hprev, UT[0], UT[1], dai, dah, B, L, H)
+        dx = None
+        if need_dx:
+            dx = dx_out if dx_out is not None else self.buf("dx", (R, I))
+        sk = pick_splitk(I, 3 * H, R)
+        sku = pick_splitk(H, 3 * H, R)
+        for i, d in enumerate(("forward", "backward")):
+            k, u, b = self.p[d]
+            gemm(self.x, dai[i], k.g, None, I, 3 * H, R, I, 3 * H, 3 * H, 0, 0, 0, 1, sk)
+            gemm(self.hprev[i], dah[i], u.g, None, H, 3 * H, R, H, 3 * H, 3 * H, 0, 0, 0, 1, sku)
+            _call("sar_colsum_f32", dai[i], b.g[:3 * H], R, 3 * H)
+            _call("sar_colsum_f32", dah[i], b.g[3 * H:], R, 3 * H)
+            if need_dx:
+                gemm(dai[i], k.w, dx, None, R, I, 3 * H, 3 * H, 3 * H, I, 1, 1, 0, 1 if (accumulate_dx or i == 1) else 0)
+        return dx
+
+
+class BatchNorm1d(Layer):
+    """BatchNormalization() on a 2-D (B, C) tensor, training mode (model.py:286,289)."""
+
+    def __init__(self, dim, name=None):
+        super().__init__(name)
+        self.gamma = self.store.add(name + "/gamma", (dim,), np.ones(dim))
+        self.beta = self.store.add(name + "/beta", (dim,), np.zeros(dim))
+        self.moving_mean = self.store.add_state(name + "/moving_mean", (dim,), np.zeros(dim))
+        self.moving_var = self.store.add_state(name + "/moving_variance", (dim,), np.ones(dim))
+        self.dim = dim; self.output_shape = (None, dim)
+
+    def forward(self, x, B):
+        self.x, self.B = x, B
+        y = self.buf("y", (B, self.dim)); self.mean = self.buf("mean", (self.dim,)); self.rstd = self.buf("rstd", (self.dim,))
+        _call("sar_bn1d_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, self.moving_mean.w,
+              self.moving_var.w, B, self.dim, BN_EPS, BN_MOMENTUM)
+        return y
+
+    def backward(self, dy):
+        dx = self.buf("dx", (self.B, self.dim))
+        _call("sar_bn1d_bwd_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g, self.B, self.dim)
+        return dx
+
+
+class GlobalAveragePooling1D(Layer):
+    """model.py:125."""
+
+    def __init__(self, dim, name=None):
+        super().__init__(name)
+        self.dim = dim; self.output_shape = (None, dim)
+
+    def forward(self, x, B, L):
+        self.B, self.L = B, L
+        y = self.buf("y", (B, self.dim))
+        _call("sar_avgpool1d_fwd_f32", x, y, B, L, self.dim)
+        return y
+
+    def backward(self, dy, accumulate_dx=False, dx_out=None):
+        dx = dx_out if dx_out is not None else self.buf("dx", (self.B * self.L, self.dim))
+        _call("sar_avgpool1d_bwd_f32", dy, dx, self.B, self.L, self.dim, 1 if accumulate_dx else 0)
+        return dx
+
+
+class L2Normalize(Layer):
+    """Lambda(lambda x: K.l2_normalize(x, 1)) (model.py:162)."""
+
+    def __init__(self, dim, name=None):
+        super().__init__(name)
+        self.dim = dim; self.output_shape = (None, dim)
+
+    def forward(self, x, B):
+        self.B = B
+        self.v = self.buf("v", (B, self.dim)); self.inv = self.buf("inv", (B,))
+        _call("sar_l2norm_rows_fwd_f32", x, self.v, self.inv, B, self.dim)
+        return self.v
+
+    def backward(self, dv, accumulate_dx=False, dx_out=None):
+        dx = dx_out if dx_out is not None else self.buf("dx", (self.B, self.dim))
+        _call("sar_l2norm_rows_bwd_f32", dv, self.v, self.inv, dx, self.B, self.dim, 1 if accumulate_dx else 0)
+        return dx

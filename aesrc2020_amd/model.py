@@ -1,0 +1,538 @@
+"""SAR_Net: the multi-task speech-accent-recognition graph of /root/reference/model.py:204-371, MI355X-native.
+
+`SAR_Net(**kw) -> (model, train_model)` keeps the reference signature, layer names, weight layouts, batch-dict
+format (utils.py:102-116), loss assembly (model.py:344-369 incl. the weight overwrite at line 361) and the Keras
+model methods train.py uses (fit_generator / train_on_batch / save / load_weights / summary / get_layer / predict).
+The step itself is a static plan of hand-written HIP kernel launches (forward, explicit backward, fused L2+Adam)
+captured into one HIP graph; data parallelism is one process per GPU with an RCCL all-reduce of the flat gradient
+buffer (parallel.py) instead of keras.utils.multi_gpu_model (model.py:193-194)."""
+import numpy as np
+import torch
+
+from . import _lib
+from . import losses as ls
+from . import VLAD as vd
+from .engine import ParamStore, store_scope, orthogonal, glorot_uniform
+from .layers import Dense, LayerNorm, BiGRU, BatchNorm1d, GlobalAveragePooling1D, L2Normalize, Layer
+from .resnet import resnet18_, resnet34_, resnet50_, resnet101_, resnet152_
+from .parallel import DataParallel
+
+_call = _lib.call
+
+
+class Input:
+    """Shape holder standing in for keras Input (model.py:230-235)."""
+
+    def __init__(self, shape, name=None, dtype="float32"):
+        self.shape, self.name, self.dtype = tuple(shape), name, dtype
+
+
+# ---- layer helpers with the reference's names (model.py:29-53) -------------------------------------------------
+def BN(dim, name=None):
+    return BatchNorm1d(dim, name=name)
+
+
+def LN(dim, name=None):
+    return LayerNorm(dim, name=name)
+
+
+def DS(in_dim, hidden, activation, rgr=1e-4, use_bias=True, name=None):
+    return Dense(in_dim, hidden, activation=activation, use_bias=use_bias, name=name, l2=rgr, init="he_normal")
+
+
+def BIGRU(in_dim, hidden, seq=True, rgr=1e-4, name=None):
+    return BiGRU(in_dim, hidden, seq=seq, name=name, l2=rgr)
+
+
+class _AssignConv(Dense):
+    """1x1 Conv2D cluster assignment (model.py:89-95 / 99-105): orthogonal init, l2(1e-4) on kernel+bias.
+    Stored with the Keras kernel shape (1,1,H,K+G); computed as a GEMM over the (B*L, H) rows."""
+
+    def __init__(self, in_dim, units, name):
+        Layer.__init__(self, name)
+        rng = self.store.rng
+        w = orthogonal(rng, (in_dim, units)) if in_dim >= units else orthogonal(rng, (units, in_dim)).T
+        self.kernel = self.store.add(name + "/kernel", (1, 1, in_dim, units), w, 1e-4)
+        self.bias = self.store.add(name + "/bias", (units,), np.zeros(units), 1e-4)
+        self.in_dim, self.units, self.activation = in_dim, units, None
+        self.output_shape = (None, units)
+
+
+class _VladBlock:
+    """vlad() of model.py:82-109: assignment conv + VladPooling."""
+
+    def __init__(self, hidden, aggregation, vlad_clusters, ghost_clusters):
+        g = ghost_clusters if aggregation == "gvlad" else 0
+        self.assign = _AssignConv(hidden, vlad_clusters + g, aggregation + "_center_assignment")
+        self.pool = vd.VladPooling(k_centers=vlad_clusters, g_centers=g, mode=aggregation, name=aggregation + "_pool", feat_dim=hidden)
+        self.out_dim = vlad_clusters * hidden
+
+    def forward(self, x, B, L):
+        score = self.assign.forward(x)
+        return self.pool.forward(x.view(B, L, -1), score.view(B, L, -1))
+
+    def backward(self, dout):
+        dfeat, dscore = self.pool.backward(dout)
+        self.assign.backward(dscore, dx_out=dfeat.view(-1, dfeat.shape[-1]), accumulate_dx=True)
+        return dfeat.view(-1, dfeat.shape[-1])
+
+
+class SARNetModel:
+    """The object SAR_Net returns (both as `model` and `train_model`)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        c = cfg
+        self.store = ParamStore(seed=c["seed"])
+        self.name = c["name"] or "model"
+        T, D, _ = c["input_shape"]
+        H, A = c["hidden_dim"], c["accent_classes"]
+        with store_scope(self.store):
+            inputs = Input(shape=c["input_shape"], name="x_data")
+            fn = {"res18": resnet18_, "res34": resnet34_, "res50": resnet50_, "res101": resnet101_, "res152": resnet152_}
+            if c["res_type"] not in fn:
+                # the reference only prints here (model.py:250-251) and then fails on the undefined `cnn`
+                print("======= ERROR: please specify cnn in res-[18,34,50,101,152] ======")
+                raise ValueError("res_type")
+            self.trunk = fn[c["res_type"]](inputs, filters=c["res_filters"])
+            Tp, Dp = self.trunk.out_hw
+            self.L = Tp * Dp
+            C = self.trunk.out_c
+            self.CNN_LIN = DS(C, H, "tanh", name="CNN_LIN"); self.CNN_LIN_LN = LN(H, name="CNN_LIN_LN")
+            self.CRNN = BIGRU(H, H, name="CRNN"); self.CRNN_LN = LN(2 * H, name="CRNN_LN")
+            if c["ctc_enable"]:
+                self.CTC_BIGRU = BIGRU(2 * H, H, name="CTC_BIGRU"); self.CTC_BIGRU_LN = LN(2 * H, name="CTC_BIGRU_LN")
+                self.CTC_DS = DS(2 * H, H, "tanh", name="CTC_DS"); self.CTC_DS_LN = LN(H, name="CTC_DS_LN")
+                self.ctc_pred = DS(H, c["bpe_classes"], "softmax", name="ctc_pred")
+            if c["ar_enable"]:
+                self.AR_DS = DS(2 * H, H, "tanh", name="AR_DS"); self.AR_DS_LN = LN(H, name="AR_DS_LN")
+                mto = c["mto"]
+                if mto == "avg":
+                    self.merge = GlobalAveragePooling1D(H, name="AR_MERGE"); pooled = H
+                elif mto == "bigru":
+                    self.merge = BIGRU(H, H, seq=False, name="AR_MERGE"); pooled = 2 * H
+                elif mto in ("vlad", "gvlad"):
+                    self.merge = _VladBlock(H, mto, c["vlad_clusters"], c["ghost_clusters"]); pooled = self.merge.out_dim
+                else:
+                    print("Please specify avg/bigru/vlad/gvlad ..")           # model.py:137-138 (exit(1) there)
+                    raise SystemExit(1)
+                self.AR_BN1 = BN(pooled, name="AR_BN1")
+                self.AR_EMBEDDING = DS(pooled, H, None, name="AR_EMBEDDING")
+                self.AR_BN2 = BN(H, name="AR_BN2")
+                self.AR_CF_DS1 = DS(H, 64, "relu", name="AR_CF_DS1"); self.AR_CF_DS2 = DS(64, 64, "relu", name="AR_CF_DS2")
+                self.y_accent = DS(64, A, "softmax", name="y_accent")
+                self.disc = None
+                if c["disc_enable"]:
+                    ml = c["metric_loss"]
+                    if ml == "softmax":
+                        self.disc = DS(H, A, "softmax", use_bias=False, name="y_disc")
+                    elif ml in ("sphereface", "cosface", "arcface"):
+                        cls = {"sphereface": ls.SphereFace, "cosface": ls.CosFace, "arcface": ls.ArcFace}[ml]
+                        self.disc = cls(n_classes=A, m=c["margin"], name="y_disc", in_dim=H)
+                    elif ml == "circleloss":
+                        self.disc_norm = L2Normalize(H, name="y_disc_l2norm")
+                        self.disc = Dense(H, A, activation=None, use_bias=False, name="y_disc", l2=0.0, init="glorot_uniform",
+                                          constraint="unit_norm")
+                    else:
+                        raise ValueError("unknown metric_loss %r (the reference's disc_loss returns None, model.py:164-165)" % ml)
+                if c["disc_enable"] and c["bn_dim"]:
+                    raise NotImplementedError("bn_dim bottleneck head (model.py:312-322) is not built yet")
+        self.store.finalize()
+        self.dp = DataParallel(self.store)
+        self.store.set_adam(c["lr"], grad_scale=1.0 / self.dp.world)
+        self.bufs = self.store.bufs
+        self._loss_weights()
+        self.cce_accent = ls.CategoricalCrossentropy(self.bufs, "loss_y_accent")
+        self.cce_disc = ls.CategoricalCrossentropy(self.bufs, "loss_y_disc")
+        self.circle = ls.CircleLoss(self.bufs, "loss_circle")
+        self.graph = None; self.graph_B = None; self.use_graph = c["use_graph"]; self._eager_done = 0
+        self.stop_training = False
+        print(self.loss_weights)                                               # model.py:370
+
+    # ------------------------------------------------------------------ loss assembly (model.py:344-369)
+    def _loss_weights(self):
+        c = self.cfg
+        alpha, beta = 0.4, 0.01
+        lw = {}
+        if c["ar_enable"]:
+            lw["y_accent"] = beta if c["disc_enable"] else 1.0
+            if c["disc_enable"]:
+                lw["y_disc"] = 1 - alpha if c["ctc_enable"] else 1.0
+        if c["ctc_enable"]:
+            lw["y_ctc_loss"] = alpha if c["disc_enable"] else 1.0
+            lw["y_ctc_loss"] = 1 - alpha if not c["disc_enable"] else beta      # the reference's overwrite (line 361)
+        self.loss_weights = lw
+        self.output_names = [n for n in ("y_accent", "y_disc", "y_ctc_loss") if n in lw]
+        self.metrics_names = ["loss"] + [n + "_loss" for n in self.output_names] + \
+                             [n + "_acc" for n in self.output_names if n != "y_ctc_loss"]
+
+    # ------------------------------------------------------------------ inputs
+    def _bind_inputs(self, B):
+        c = self.cfg
+        T, D, _ = c["input_shape"]
+        b = self.bufs
+        self.B = B
+        self.in_x = b.get("in/x_data", (B, T, D, 1))
+        A = c["accent_classes"]
+        self.in_y_accent = b.get("in/y_accent", (B, A))
+        if c["disc_enable"]:
+            self.in_x_accent = b.get("in/x_accent", (B, A)); self.in_y_disc = b.get("in/y_disc", (B, A))
+        if c["ctc_enable"]:
+            self.in_ctc_label = b.get("in/x_ctc_label", (B, c["max_ctc_len"]))
+            self.in_ctc_in_len = b.get("in/x_ctc_in_len", (B,), torch.int32)
+            self.in_ctc_out_len = b.get("in/x_ctc_out_len", (B,), torch.int32)
+            self.ctc_ws_bytes = _lib.ctc_workspace_bytes(B, self.L, c["max_ctc_len"])
+            self.ctc_ws = b.get("ctc/ws", (self.ctc_ws_bytes // 4,))
+            self.ctc_loss = b.get("ctc/loss", (B,)); self.ctc_dprobs = b.get("ctc/dprobs", (B * self.L, c["bpe_classes"]))
+        # constant seed gradients: d(total)/d(per-sample loss) = weight / B (Keras batch-mean)
+        self.seed = {}
+        for k, w in self.loss_weights.items():
+            t = b.get("seed/" + k, (B,)); t.fill_(w / B); self.seed[k] = t
+
+    def _upload(self, inputs, targets):
+        c = self.cfg
+        x = np.asarray(inputs["x_data"], np.float32)
+        B = x.shape[0]
+        if getattr(self, "B", None) != B:
+            self._bind_inputs(B)
+            self.graph = None; self._eager_done = 0
+        self.in_x.copy_(torch.from_numpy(np.ascontiguousarray(x)).view(self.in_x.shape))
+        tg = targets or {}
+        A = c["accent_classes"]
+        zeros_a = np.zeros((B, A), np.float32)                                # predict(): labels may be absent
+        if c["ar_enable"]:
+            ya = tg.get("y_accent", inputs.get("x_accent", zeros_a))
+            self.in_y_accent.copy_(torch.from_numpy(np.asarray(ya, np.float32)))
+        if c["disc_enable"]:
+            xa = inputs.get("x_accent", zeros_a)
+            self.in_x_accent.copy_(torch.from_numpy(np.asarray(xa, np.float32)))
+            self.in_y_disc.copy_(torch.from_numpy(np.asarray(tg.get("y_disc", xa), np.float32)))
+        if c["ctc_enable"]:
+            if "x_ctc_label" in inputs:
+                lab = np.asarray(inputs["x_ctc_label"], np.float32)
+                il = np.asarray(inputs["x_ctc_in_len"]).reshape(-1).astype(np.int32)
+                ol = np.asarray(inputs["x_ctc_out_len"]).reshape(-1).astype(np.int32)
+            else:                                                             # predict(): dummy 1-symbol targets
+                lab = np.zeros((B, c["max_ctc_len"]), np.float32)
+                il = np.full(B, self.L, np.int32); ol = np.ones(B, np.int32)
+            self._check_ctc_feasible(lab, il, ol)
+            self.in_ctc_label.copy_(torch.from_numpy(np.ascontiguousarray(lab)))
+            self.in_ctc_in_len.copy_(torch.from_numpy(il)); self.in_ctc_out_len.copy_(torch.from_numpy(ol))
+
+    @staticmethod
+    def _check_ctc_feasible(lab, il, ol):
+        """tf.nn.ctc_loss raises 'Not enough time for target transition sequence' (SURVEY App. A); so do we."""
+        for b in range(lab.shape[0]):
+            u = int(min(ol[b], lab.shape[1])); l = lab[b, :u].astype(np.int64)
+            need = u + int((l[1:] == l[:-1]).sum())
+            if need > il[b]:
+                raise ValueError("Not enough time for target transition sequence (required: %d, available: %d) in batch item %d"
+                                 % (need, il[b], b))
+
+    def set_device_batch(self, dev):
+        """Device-resident batch (dict of torch tensors, same keys as the host batch dict): D2D copies only."""
+        B = dev["x_data"].shape[0]
+        if getattr(self, "B", None) != B:
+            self._bind_inputs(B); self.graph = None; self._eager_done = 0
+        self.in_x.copy_(dev["x_data"].view(self.in_x.shape))
+        c = self.cfg
+        if c["ar_enable"]:
+            self.in_y_accent.copy_(dev["y_accent"])
+        if c["disc_enable"]:
+            self.in_x_accent.copy_(dev["x_accent"]); self.in_y_disc.copy_(dev["y_disc"])
+        if c["ctc_enable"]:
+            self.in_ctc_label.copy_(dev["x_ctc_label"]); self.in_ctc_in_len.copy_(dev["x_ctc_in_len"].view(-1))
+            self.in_ctc_out_len.copy_(dev["x_ctc_out_len"].view(-1))
+
+    # ------------------------------------------------------------------ forward / backward plans
+    def _forward(self):
+        c = self.cfg
+        B, L = self.B, self.L
+        cnn = self.trunk.forward(self.in_x, B)
+        x = self.CNN_LIN.forward(cnn.view(B * L, -1))                         # CNN2SEQ (model.py:252) is a view
+        x = self.CNN_LIN_LN.forward(x)
+        x = self.CRNN.forward(x, B, L)
+        crnn = self.CRNN_LN.forward(x.view(B * L, -1))
+        self.out = {}
+        if c["ctc_enable"]:
+            a = self.CTC_BIGRU.forward(crnn, B, L)
+            a = self.CTC_BIGRU_LN.forward(a.view(B * L, -1))
+            a = self.CTC_DS_LN.forward(self.CTC_DS.forward(a))
+            pred = self.ctc_pred.forward(a)
+            self.out["ctc_pred"] = pred
+            _call("sar_ctc_batch_cost_fwd_f32", pred, self.in_ctc_label, self.in_ctc_in_len, self.in_ctc_out_len, self.ctc_loss,
+                  self.ctc_ws, self.ctc_ws_bytes, B, L, c["bpe_classes"], c["max_ctc_len"])
+            self.out["y_ctc_loss"] = self.ctc_loss
+        if c["ar_enable"]:
+            ar = self.AR_DS_LN.forward(self.AR_DS.forward(crnn))
+            if c["mto"] == "avg":
+                ar = self.merge.forward(ar, B, L)
+            else:
+                ar = self.merge.forward(ar, B, L)
+            ar = self.AR_BN1.forward(ar, B)
+            ar = self.AR_EMBEDDING.forward(ar)
+            ar = self.AR_BN2.forward(ar, B)
+            self.out["ar"] = ar
+            a1 = self.AR_CF_DS2.forward(self.AR_CF_DS1.forward(ar))
+            self.out["y_accent"] = self.y_accent.forward(a1)
+            if c["disc_enable"]:
+                ml = c["metric_loss"]
+                if ml == "softmax":
+                    self.out["y_disc"] = self.disc.forward(ar)
+                elif ml == "circleloss":
+                    self.out["y_disc"] = self.disc.forward(self.disc_norm.forward(ar, B))
+                else:
+                    self.out["y_disc"] = self.disc.forward(ar, self.in_x_accent)
+        return self.out
+
+    def _losses_forward(self):
+        c = self.cfg
+        self.loss_vec = {}
+        if "y_accent" in self.loss_weights:
+            self.loss_vec["y_accent"] = self.cce_accent.forward(self.in_y_accent, self.out["y_accent"])
+        if "y_disc" in self.loss_weights:
+            if c["metric_loss"] == "circleloss":
+                self.loss_vec["y_disc"] = self.circle.forward(self.in_y_disc, self.out["y_disc"], gamma=256, margin=c["margin"])
+            else:
+                self.loss_vec["y_disc"] = self.cce_disc.forward(self.in_y_disc, self.out["y_disc"])
+        if "y_ctc_loss" in self.loss_weights:
+            self.loss_vec["y_ctc_loss"] = self.out["y_ctc_loss"]
+
+    def _backward(self):
+        c = self.cfg
+        B, L = self.B, self.L
+        d_crnn = None
+        if c["ctc_enable"]:
+            _call("sar_ctc_batch_cost_bwd_f32", self.out["ctc_pred"], self.in_ctc_label, self.in_ctc_in_len, self.in_ctc_out_len,
+                  self.ctc_loss, self.seed["y_ctc_loss"], self.ctc_ws, self.ctc_ws_bytes, self.ctc_dprobs, B, L, c["bpe_classes"],
+                  c["max_ctc_len"])
+            g = self.ctc_pred.backward(self.ctc_dprobs)
+            g = self.CTC_DS.backward(self.CTC_DS_LN.backward(g))
+            g = self.CTC_BIGRU_LN.backward(g)
+            d_crnn = self.CTC_BIGRU.backward(g.view(B, L, -1))
+        if c["ar_enable"]:
+            dp = self.cce_accent.backward(self.seed["y_accent"])
+            g = self.y_accent.backward(dp)
+            g = self.AR_CF_DS1.backward(self.AR_CF_DS2.backward(g))           # -> d(ar) buffer of AR_CF_DS1
+            d_ar = g
+            if c["disc_enable"]:
+                ml = c["metric_loss"]
+                if ml == "circleloss":
+                    ds = self.circle.backward(self.seed["y_disc"])
+                    dv = self.disc.backward(ds)
+                    self.disc_norm.backward(dv, accumulate_dx=True, dx_out=d_ar)
+                elif ml == "softmax":
+                    dpd = self.cce_disc.backward(self.seed["y_disc"])
+                    self.disc.backward(dpd, accumulate_dx=True, dx_out=d_ar)
+                else:
+                    dpd = self.cce_disc.backward(self.seed["y_disc"])
+                    self.disc.backward(dpd, dx_out=d_ar, accumulate_dx=True)
+            g = self.AR_BN2.backward(d_ar)
+            g = self.AR_EMBEDDING.backward(g)
+            g = self.AR_BN1.backward(g)
+            if c["mto"] == "avg":
+                g = self.merge.backward(g)
+            elif c["mto"] == "bigru":
+                g = self.merge.backward(g)
+            else:
+                g = self.merge.backward(g)
+            g = self.AR_DS_LN.backward(g)
+            if d_crnn is not None:
+                self.AR_DS.backward(g, dx_out=d_crnn, accumulate_dx=True)
+            else:
+                d_crnn = self.AR_DS.backward(g)
+        g = self.CRNN_LN.backward(d_crnn)
+        g = self.CRNN.backward(g.view(B, L, -1))
+        g = self.CNN_LIN_LN.backward(g)
+        g = self.CNN_LIN.backward(g)
+        self.trunk.backward(g.view(B, self.trunk.out_hw[0], self.trunk.out_hw[1], -1))
+
+    def _device_step(self, update=True):
+        self.store.zero_grads()
+        self._forward(); self._losses_forward(); self._backward()
+        if update and self.dp.world == 1:
+            self.store.adam_step()
+
+    # ------------------------------------------------------------------ public step API
+    def train_step_device(self):
+        """One optimisation step on the batch currently bound in the static input buffers (no host sync)."""
+        if self.use_graph and self._eager_done >= 1:
+            if self.graph is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._device_step()
+                self.graph = g
+            self.graph.replay()
+        else:
+            self._device_step(); self._eager_done += 1
+        if self.dp.world > 1:
+            self.dp.allreduce_grads()
+            self.store.adam_step()
+
+    def train_on_batch(self, x, y=None, return_dict=True, sync=True):
+        self._upload(x, y)
+        self.train_step_device()
+        if not sync:
+            return None
+        return self._logs()
+
+    def _logs(self):
+        """Host-side scalars (forces a device sync): Keras-style loss / per-output losses / accuracies."""
+        logs = {}
+        total = float(self.store.l2_loss.item())
+        for k in self.output_names:
+            v = float(self.loss_vec[k].mean().item())
+            logs[k + "_loss"] = v; total += self.loss_weights[k] * v
+        logs["loss"] = total
+        for k in self.output_names:
+            if k == "y_ctc_loss":
+                continue
+            tgt = self.in_y_accent if k == "y_accent" else self.in_y_disc
+            logs[k + "_acc"] = float((self.out[k].argmax(1) == tgt.argmax(1)).float().mean().item())
+        return logs
+
+    def forward_backward_only(self, x, y=None):
+        """For tests: forward + losses + backward without the optimizer update; grads stay in store.grads."""
+        self._upload(x, y)
+        self.store.zero_grads()
+        self._forward(); self._losses_forward(); self._backward()
+        return self._logs_no_l2()
+
+    def _logs_no_l2(self):
+        return {k: self.loss_vec[k].detach().cpu().numpy().copy() for k in self.output_names}
+
+    # ------------------------------------------------------------------ Keras-like conveniences
+    def summary(self):
+        print('Model: "%s"' % self.name); print("_" * 72)
+        print("%-40s %-18s %12s" % ("Layer", "Output shape", "Param #")); print("=" * 72)
+        for l in self.store.layers:
+            print("%-40s %-18s %12d" % (l.name, str(getattr(l, "output_shape", "")), l.count_params()))
+        print("=" * 72); print("Total params: {:,}".format(self.store.n_params()))
+
+    def get_layer(self, name=None):
+        for l in self.store.layers:
+            if l.name == name:
+                return l
+        raise ValueError("No such layer: " + str(name))
+
+    def count_params(self):
+        return self.store.n_params()
+
+    def get_weights_dict(self):
+        return self.store.state_dict()
+
+    def save_weights(self, path):
+        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **self.store.state_dict())
+
+    def save(self, path):
+        """model.save (train.py:35).  No h5py in this image: an .npz of Keras-layout tensors + optimizer state."""
+        d = self.store.state_dict()
+        d["__adam_m__"] = self.store.m.cpu().numpy(); d["__adam_v__"] = self.store.v.cpu().numpy()
+        d["__adam_state__"] = self.store.adam_state.cpu().numpy()
+        np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **d)
+
+    def load_weights(self, path, by_name=True, skip_mismatch=True):
+        p = path if str(path).endswith(".npz") else str(path) + ".npz"
+        d = dict(np.load(p))
+        loaded, skipped = self.store.load_state_dict(d, by_name, skip_mismatch)
+        self.dp.broadcast_params()
+        return loaded, skipped
+
+    def set_weights_dict(self, d):
+        self.store.load_state_dict(d, True, False)
+
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, callbacks=None, initial_epoch=0, validation_data=None,
+                      max_queue_size=10, verbose=1, log_every=50):
+        """Keras fit_generator subset used by train.py:38-44 (single feeding thread; callbacks get Keras-style logs)."""
+        from .callbacks import CallbackList
+        cbs = CallbackList(callbacks or [], self)
+        cbs.on_train_begin()
+        history = []
+        for epoch in range(initial_epoch, epochs):
+            cbs.on_epoch_begin(epoch)
+            agg = {}
+            for step in range(steps_per_epoch):
+                x, y = next(generator)
+                want = (step % log_every == 0) or step == steps_per_epoch - 1
+                logs = self.train_on_batch(x, y, sync=want)
+                if logs:
+                    for k, v in logs.items():
+                        agg.setdefault(k, []).append(v)
+            logs = {k: float(np.mean(v)) for k, v in agg.items()}
+            if validation_data is not None:
+                vl = self.evaluate(validation_data[0], validation_data[1])
+                logs.update({"val_" + k: v for k, v in vl.items()})
+            logs["lr"] = self.store.get_lr()
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in sorted(logs.items())))
+            history.append(logs)
+            cbs.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        cbs.on_train_end()
+        return history
+
+    def evaluate(self, x, y=None, batch_size=32):
+        """Loss/accuracy over a dataset dict.  NOTE: runs the training-mode graph without the update
+        (BatchNorm uses batch statistics); the moving-average inference graph is the next scope row."""
+        n = len(x["x_data"]); agg = {}
+        for s in range(0, n - batch_size + 1, batch_size) if n >= batch_size else [0]:
+            sl = slice(s, min(n, s + batch_size))
+            xb = {k: v[sl] for k, v in x.items()}; yb = {k: v[sl] for k, v in (y or {}).items()}
+            self._upload(xb, yb)
+            self._forward(); self._losses_forward()
+            logs = self._logs()
+            for k, v in logs.items():
+                agg.setdefault(k, []).append(v)
+        return {k: float(np.mean(v)) for k, v in agg.items()}
+
+    def predict(self, x, batch_size=32):
+        """Outputs in the reference's order [y_accent, y_disc, y_ctc_loss] (model.py:327-338), training-mode BN (see evaluate)."""
+        x = x if isinstance(x, dict) else {"x_data": x}
+        n = len(x["x_data"]); outs = {k: [] for k in self.output_names}
+        for s in range(0, n, batch_size):
+            xb = {k: v[s:s + batch_size] for k, v in x.items()}
+            self._upload(xb, None); self._forward()
+            for k in self.output_names:
+                outs[k].append(self.out[k].detach().cpu().numpy().copy())
+        res = [np.concatenate(outs[k]) for k in self.output_names]
+        return res if len(res) > 1 else res[0]
+
+
+def SAR_Net(input_shape, ctc_enable=False, ar_enable=True, disc_enable=False, res_type="res18", res_filters=64,
+            hidden_dim=256, bn_dim=0, bpe_classes=1000, accent_classes=8, max_ctc_len=72, mto=None, vlad_clusters=8,
+            ghost_clusters=2, metric_loss="cosface", margin=0.3, raw_model=None, lr=0.01, gpus=1, mode="train", name=None,
+            seed=0, use_graph=True):
+    """model.py:204-371.  Returns (model, train_model); with one process per GPU both are the same object -- the
+    data-parallel wrapper of the reference (multi_gpu_model, model.py:193-194) is replaced by torch.distributed/RCCL
+    initialised by the launcher (`gpus` is informational)."""
+    cfg = dict(locals())
+    model = SARNetModel(cfg)
+    model.summary()                                                         # model.py:180
+    if raw_model:
+        print("===== init weights from:%s =====" % raw_model)             # model.py:181-183
+        model.load_weights(raw_model, by_name=True, skip_mismatch=True)
+    return model, model
+
+
+def sub_model(model, input_name, output_name):
+    """model.py:380-383 (layer lookup by name; the eager engine exposes the layer objects directly)."""
+    return model.get_layer(output_name)
+
+
+def ctc_pred(model, x, batch_size, input_len):
+    """model.py:385-389: greedy CTC decode of the ctc_pred probabilities."""
+    x = x if isinstance(x, dict) else {"x_data": x}
+    res = []
+    n = len(x["x_data"])
+    for s in range(0, n, batch_size):
+        xb = {k: v[s:s + batch_size] for k, v in x.items()}
+        model._upload(xb, None); model._forward()
+        B, L, V = model.B, model.L, model.cfg["bpe_classes"]
+        il = torch.full((B,), int(input_len), dtype=torch.int32, device="cuda")
+        dec = torch.empty(B, L, dtype=torch.int32, device="cuda"); dl = torch.empty(B, dtype=torch.int32, device="cuda")
+        _call("sar_ctc_greedy_decode_f32", model.out["ctc_pred"], il, dec, dl, B, L, V)
+        dec, dl = dec.cpu().numpy(), dl.cpu().numpy()
+        res += [dec[b, :dl[b]].tolist() for b in range(B)]
+    return res

@@ -1,0 +1,78 @@
+"""Data parallelism for the SAR-Net step: one process per GPU, RCCL over xGMI via torch.distributed.
+
+Replaces keras.utils.multi_gpu_model (model.py:193-194): each rank owns a full replica and a contiguous slice of
+the global batch (same slicing as multi_gpu_model); BatchNorm statistics stay per-GPU (per-tower in the reference);
+the flat fp32 gradient buffer (engine.ParamStore.grads) is summed across ranks and the mean is taken by the Adam
+kernel's grad_scale = 1/world.  The buffer is reduced in two contiguous buckets: parameters are laid out in
+forward order, so the tail (heads + GRUs) is complete early in backward and the head (conv stack) last.
+Everything here is device-agnostic torch.distributed code so the N>1 path is covered by gloo tests on CPU."""
+import os
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(batch, rank, world):
+    """Contiguous equal slices of the global batch (what multi_gpu_model does with its Lambda slices)."""
+    out = {}
+    for k, v in batch.items():
+        n = len(v); per = n // world
+        out[k] = v[rank * per:(rank + 1) * per]
+    return out
+
+
+def bucket_bounds(n, split):
+    """Two buckets over a flat buffer of n elements: [split, n) first (ready early), then [0, split)."""
+    split = max(0, min(n, int(split)))
+    return [(split, n), (0, split)] if 0 < split < n else [(0, n)]
+
+
+def allreduce_flat(flat, bounds, group=None, async_op=False):
+    """Sum-all-reduce the given [lo, hi) ranges of a flat tensor in place.  Returns the work handles."""
+    works = []
+    for lo, hi in bounds:
+        if hi > lo:
+            works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+    return works
+
+
+def broadcast_flat(flat, src=0, group=None):
+    dist.broadcast(flat, src=src, group=group)
+
+
+class DataParallel:
+    def __init__(self, store, split_name_prefix="CNN_LIN"):
+        self.store = store
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.rank = dist.get_rank() if self.enabled else 0
+        # bucket boundary = first parameter after the conv trunk
+        split = store.n
+        for r in store.refs:
+            if r.name.startswith(split_name_prefix):
+                split = r.offset; break
+        self.bounds = bucket_bounds(store.n, split)
+        if self.enabled:
+            self.broadcast_params()
+
+    def broadcast_params(self):
+        if self.enabled:
+            broadcast_flat(self.store.params, 0)
+            for r in self.store.state_refs:
+                dist.broadcast(r.w, src=0)
+
+    def allreduce_grads(self):
+        if self.enabled:
+            allreduce_flat(self.store.grads, self.bounds)

@@ -1,0 +1,243 @@
+"""Pre-activation ResNet-18/34 trunk of SAR-Net, MI355X-native (mirrors /root/reference/resnet.py).
+
+Same public names as the reference (`resnet18_`, `resnet34_`, ... resnet.py:170-249), same topology:
+7x7/2 stem -> BN -> ReLU -> MaxPool 3x3/2 'same' -> 4 stages of basic_block ([2,2,2,2] / [3,4,6,3]) with filters
+F,2F,4F,8F, stride 2 at the first block of stages 1-3 (resnet.py:96-98), 1x1 'valid' conv shortcuts where the shape
+changes (resnet.py:75-87; res34 hard-codes a 64-channel stem, resnet.py:191, so stage0/block0 gets one too),
+final BN+ReLU, no global pooling (resnet.py:178-181).
+
+Execution plan (what is different from the reference): BatchNormalization+ReLU in front of a conv is never
+materialised -- batch statistics are reduced once (sar_bn_stats), folded to per-channel scale/shift, and applied
+inside the conv's operand load (fwd and wgrad); the residual Add is the conv epilogue; the stem's BN+ReLU is fused
+with the max-pool.  Backward mirrors it: dgrad -> (BN+ReLU backward reduce, apply [+ shortcut gradient]) -> wgrad.
+Layers are auto-named conv2d_N / batch_normalization_N in construction order like Keras does for the unnamed
+reference layers (checkpoint row).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import current_store, he_normal, same_pads
+from .layers import Layer, BN_EPS, BN_MOMENTUM
+
+_call = _lib.call
+
+
+class _BN:
+    """BatchNormalization(axis=3) parameters + batch-statistics state for one use site (resnet.py:22-26)."""
+
+    def __init__(self, store, name, C):
+        self.name, self.C, self.store = name, C, store
+        self.gamma = store.add(name + "/gamma", (C,), np.ones(C))
+        self.beta = store.add(name + "/beta", (C,), np.zeros(C))
+        self.moving_mean = store.add_state(name + "/moving_mean", (C,), np.zeros(C))
+        self.moving_var = store.add_state(name + "/moving_variance", (C,), np.ones(C))
+
+    def _b(self, key, shape, dtype=torch.float32):
+        return self.store.bufs.get(self.name + "/" + key, shape, dtype)
+
+    def stats(self, x, R):
+        C = self.C
+        self.mean, self.rstd, self.scale, self.shift = (self._b(k, (C,)) for k in ("mean", "rstd", "scale", "shift"))
+        self.sums = self._b("sums", (2 * C,), torch.float64)
+        _call("sar_bn_stats_f32", x, self.gamma.w, self.beta.w, self.sums, self.mean, self.rstd, self.scale, self.shift,
+              self.moving_mean.w, self.moving_var.w, R, C, BN_EPS, BN_MOMENTUM, 1)
+
+    def bwd(self, dact, x, add, dx, R, relu=1):
+        """dx = d/dx [relu](bn(x)) given dact; (+ add).  Parameter gradients accumulate."""
+        _call("sar_bn_bwd_f32", dact, x, self.scale, self.shift, self.mean, self.rstd, self.sums, add, dx,
+              self.gamma.g, self.beta.g, R, self.C, relu)
+
+
+class _Conv:
+    """Conv2D(he_normal, l2(1e-4) on the kernel only, bias present) (resnet.py:39-42, 60-63, 82-87, 113-117)."""
+
+    def __init__(self, store, name, k, cin, cout, stride, padding):
+        self.name, self.k, self.cin, self.cout, self.stride, self.padding = name, k, cin, cout, stride, padding
+        self.kernel = store.add(name + "/kernel", (k, k, cin, cout), he_normal(store.rng, (k, k, cin, cout), k * k * cin), 1e-4)
+        self.bias = store.add(name + "/bias", (cout,), np.zeros(cout))
+
+    def out_hw(self, H, W):
+        if self.padding == "same":
+            (ho, self.pt), (wo, self.pl) = same_pads(H, self.k, self.stride), same_pads(W, self.k, self.stride)
+        else:
+            ho, wo = (H - self.k) // self.stride + 1, (W - self.k) // self.stride + 1
+            self.pt = self.pl = 0
+        self.H, self.W, self.Ho, self.Wo = H, W, ho, wo
+        return ho, wo
+
+    def fwd(self, x, y, B, bn=None, residual=None):
+        _call("sar_conv2d_fwd_f32", x, self.kernel.w, self.bias.w, bn.scale if bn else None, bn.shift if bn else None,
+              residual, y, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+
+    def dgrad(self, dy, dx, B, accumulate=0):
+        _call("sar_conv2d_dgrad_f32", dy, self.kernel.w, dx, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+              self.k, self.k, self.stride, self.pt, self.pl, accumulate)
+
+    def wgrad(self, x, dy, B, bn=None):
+        _call("sar_conv2d_wgrad_f32", x, dy, bn.scale if bn else None, bn.shift if bn else None, self.kernel.g, B, self.H,
+              self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+        _call("sar_colsum_f32", dy, self.bias.g, B * self.Ho * self.Wo, self.cout)
+
+
+class ResNetTrunk(Layer):
+    REPS = {"res18": [2, 2, 2, 2], "res34": [3, 4, 6, 3]}
+
+    def __init__(self, res_type, filters, input_hw, name="resnet"):
+        super().__init__(name)
+        st = self.store
+        if res_type not in self.REPS:
+            raise NotImplementedError("%s: the reference's resnet50_/101_/152_ return a keras Model, not a tensor "
+                                      "(resnet.py:217,233,249), so SAR_Net cannot use them; only res18/res34 are built" % res_type)
+        if filters % 16:
+            raise ValueError("res_filters must be a multiple of 16 for the gfx950 implicit-GEMM kernels (got %d)" % filters)
+        T, D = input_hw
+        stem_c = filters if res_type == "res18" else 64                      # resnet.py:173 vs 191
+        if stem_c > 64 or stem_c % 4:
+            raise ValueError("stem width %d unsupported (<= 64, multiple of 4)" % stem_c)
+        self.stem = _Conv(st, st.auto_name("conv2d"), 7, 1, stem_c, 2, "same")
+        self.stem_bn = _BN(st, st.auto_name("batch_normalization"), stem_c)
+        self.in_hw = (T, D)
+        H, W = self.stem.out_hw(T, D)
+        self.stem_hw = (H, W)
+        (H, self.pool_pt), (W, self.pool_pl) = same_pads(H, 3, 2), same_pads(W, 3, 2)
+        self.pool_hw = (H, W)
+        self.blocks = []
+        cin, f = stem_c, filters
+        for i, r in enumerate(self.REPS[res_type]):
+            for j in range(r):
+                stride = 2 if (j == 0 and i != 0) else 1
+                first = (i == 0 and j == 0)
+                blk = {"in_hw": (H, W), "cin": cin, "cout": f}
+                blk["bn1"] = None if first else _BN(st, st.auto_name("batch_normalization"), cin)     # resnet.py:111-120
+                blk["conv1"] = _Conv(st, st.auto_name("conv2d"), 3, cin, f, stride, "same")
+                H2, W2 = blk["conv1"].out_hw(H, W)
+                blk["bn2"] = _BN(st, st.auto_name("batch_normalization"), f)
+                blk["conv2"] = _Conv(st, st.auto_name("conv2d"), 3, f, f, 1, "same")
+                blk["conv2"].out_hw(H2, W2)
+                blk["sc"] = None
+                if stride > 1 or cin != f:                                   # resnet.py:75-87
+                    blk["sc"] = _Conv(st, st.auto_name("conv2d"), 1, cin, f, stride, "valid")
+                    assert blk["sc"].out_hw(H, W) == (H2, W2)
+                blk["out_hw"] = (H2, W2)
+                self.blocks.append(blk)
+                H, W, cin = H2, W2, f
+            f *= 2
+        self.final_bn = _BN(st, st.auto_name("batch_normalization"), cin)
+        self.out_hw, self.out_c = (H, W), cin
+        self.output_shape = (None, H, W, cin)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, B):
+        self.B, self.x = B, x
+        T, D = self.in_hw
+        H, W = self.stem_hw
+        c0 = self.stem.cout
+        self.stem_out = self.buf("stem_out", (B, H, W, c0))
+        _call("sar_stem_conv7x7_fwd_f32", x, self.stem.kernel.w, self.stem.bias.w, self.stem_out, B, T, D, H, W, c0, self.stem.pt, self.stem.pl)
+        self.stem_bn.stats(self.stem_out, B * H * W)
+        Hp, Wp = self.pool_hw
+        self.pooled = self.buf("pooled", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
+        _call("sar_bn_relu_maxpool_fwd_f32", self.stem_out, self.stem_bn.scale, self.stem_bn.shift, self.pooled, self.pool_idx,
+              B, H, W, c0, Hp, Wp, self.pool_pt, self.pool_pl)
+        cur = self.pooled
+        for n, blk in enumerate(self.blocks):
+            H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
+            blk["x"] = cur
+            if blk["bn1"] is not None:
+                blk["bn1"].stats(cur, B * H * W)
+            c1 = self.buf("b%d_c1" % n, (B, H2, W2, blk["cout"]))
+            blk["conv1"].fwd(cur, c1, B, bn=blk["bn1"])
+            blk["bn2"].stats(c1, B * H2 * W2)
+            if blk["sc"] is not None:
+                sc = self.buf("b%d_sc" % n, (B, H2, W2, blk["cout"]))
+                blk["sc"].fwd(cur, sc, B)
+            else:
+                sc = cur
+            y = self.buf("b%d_y" % n, (B, H2, W2, blk["cout"]))
+            blk["conv2"].fwd(c1, y, B, bn=blk["bn2"], residual=sc)
+            blk["c1"] = c1
+            cur = y
+        H, W = self.out_hw
+        self.pre_final = cur
+        self.final_bn.stats(cur, B * H * W)
+        out = self.buf("out", (B, H, W, self.out_c))
+        _call("sar_bn_apply_f32", cur, self.final_bn.scale, self.final_bn.shift, out, B * H * W, self.out_c, 1)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dy):
+        B = self.B
+        H, W = self.out_hw
+        g = self.scratch("res_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c))
+        self.final_bn.bwd(dy, self.pre_final, None, g, B * H * W, relu=1)
+        for n in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[n]
+            H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
+            cin, cout = blk["cin"], blk["cout"]
+            R2 = B * H2 * W2
+            # conv2: operand = relu(bn2(c1))
+            da2 = self.scratch("res_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout))
+            blk["conv2"].dgrad(g, da2, B)
+            blk["conv2"].wgrad(blk["c1"], g, B, bn=blk["bn2"])
+            dc1 = da2                                                      # in place: BN+ReLU backward
+            blk["bn2"].bwd(da2, blk["c1"], None, dc1, R2, relu=1)
+            blk["conv1"].wgrad(blk["x"], dc1, B, bn=blk["bn1"])
+            gin = self.scratch("res_gin%d_%dx%dx%d" % (n & 1, H, W, cin), (B, H, W, cin))   # ping-pong: never aliases g
+            if blk["bn1"] is not None:
+                # shortcut gradient first (raw block input), then the main path folds it in via `add`
+                if blk["sc"] is not None:
+                    dsc = self.scratch("res_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin))
+                    blk["sc"].dgrad(g, dsc, B); blk["sc"].wgrad(blk["x"], g, B)
+                else:
+                    dsc = g
+                da1 = self.scratch("res_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin))
+                blk["conv1"].dgrad(dc1, da1, B)
+                blk["bn1"].bwd(da1, blk["x"], dsc, gin, B * H * W, relu=1)
+            else:
+                # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
+                if blk["sc"] is not None:
+                    blk["sc"].dgrad(g, gin, B); blk["sc"].wgrad(blk["x"], g, B)
+                    blk["conv1"].dgrad(dc1, gin, B, accumulate=1)
+                else:
+                    blk["conv1"].dgrad(dc1, gin, B)
+                    _call("sar_axpy_f32", g, gin, 1.0, gin.numel())
+            g = gin
+        # stem: maxpool + BN + ReLU backward, then the 7x7 weight gradient (no input gradient needed)
+        Hs, Ws = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
+        dstem = self.scratch("res_dstem", (B, Hs, Ws, c0))
+        sb = self.stem_bn
+        _call("sar_maxpool_bn_relu_bwd_f32", g, self.pooled, self.pool_idx, self.stem_out, sb.mean, sb.rstd, sb.scale, sb.sums,
+              dstem, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
+        _call("sar_bn_param_grads_f32", sb.sums, sb.gamma.g, sb.beta.g, c0)
+        T, D = self.in_hw
+        _call("sar_stem_conv7x7_wgrad_f32", self.x, dstem, self.stem.kernel.g, self.stem.bias.g, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl)
+        return None
+
+
+def _make(res_type, input, filters):
+    shape = getattr(input, "shape", input)
+    T, D = int(shape[-3]), int(shape[-2])
+    return ResNetTrunk(res_type, filters, (T, D))
+
+
+def resnet18_(input, filters=64):
+    """resnet.py:170-182.  `input`: an InputSpec / shape (T, D, 1).  Returns the trunk layer (call .forward)."""
+    return _make("res18", input, filters)
+
+
+def resnet34_(input, filters=64):
+    """resnet.py:188-201 (64-channel stem regardless of `filters`)."""
+    return _make("res34", input, filters)
+
+
+def resnet50_(input, filters=64):
+    return _make("res50", input, filters)
+
+
+def resnet101_(input, filters=64):
+    return _make("res101", input, filters)
+
+
+def resnet152_(input, filters=64):
+    return _make("res152", input, filters)
