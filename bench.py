@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py -- train-step throughput of the MI355X-native SAR-Net hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
+
+A step = forward + backward + (RCCL gradient all-reduce when N>1) + fused L2/Adam update over one synthetic batch of
+400-frame x 80-dim fbank utterances already resident in HBM.  Default workload = BASELINE.json configs[1]
+(ResNet-34/F=32 + GhostVLAD(32+2 ghost) + ArcFace, B=64 per GPU); `--workload cfg3` = the full multi-task graph
+(CTC bpe1k + circle loss).  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel class, measured live with
+HIP events) and `cpu_baseline` (the torch-CPU restatement of the same graph timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    "cfg2": dict(desc="cfg2: ResNet34(F=32)+BiGRU encoder, GhostVLAD(32+2 ghost), ArcFace m=0.3, 8 accents, 400x80 fbank",
+                 kw=dict(res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=32, ghost_clusters=2,
+                         disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)),
+    "cfg3": dict(desc="cfg3: ResNet34(F=32)+BiGRU encoder, CTC bpe1k branch + GhostVLAD(8+2) + Circle-Loss AR head, 400x80 fbank",
+                 kw=dict(res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8, ghost_clusters=2,
+                         disc_enable=True, ctc_enable=True, metric_loss="circleloss", margin=0.3, bpe_classes=1000, max_ctc_len=72)),
+    "cfg5": dict(desc="cfg5: long utterance 2000x80, ResNet34(F=32), GhostVLAD(64+2), ArcFace",
+                 kw=dict(res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=64, ghost_clusters=2,
+                         disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)),
+}
+
+
+def conv_roofline(model, B, iters=10):
+    """Time every conv launch class of the ResNet trunk in isolation (HIP events on the launch stream) and return the
+    dominant class: achieved = algorithmic FLOPs per launch / average launch duration."""
+    from aesrc2020_amd import _lib
+    tr = model.trunk
+    classes = {}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(iters):
+            fn()
+        ev1.record(); torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) * 1e-3 / iters
+
+    def add(cls, secs, flops, nbytes):
+        c = classes.setdefault(cls, dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
+        c["time"] += secs; c["flops"] += flops; c["bytes"] += nbytes; c["launches"] += 1
+
+    for n, blk in enumerate(tr.blocks):
+        for cname, bn in (("conv1", blk["bn1"]), ("conv2", blk["bn2"]), ("sc", None)):
+            cv = blk[cname]
+            if cv is None:
+                continue
+            x = blk["x"] if cname != "conv2" else blk["c1"]
+            y = torch.randn(B, cv.Ho, cv.Wo, cv.cout, device="cuda"); dx = torch.empty(B, cv.H, cv.W, cv.cin, device="cuda")
+            flops = 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k
+            act_b = 4.0 * B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + 4.0 * cv.k * cv.k * cv.cin * cv.cout
+            tile = "n32" if cv.cout <= 32 else "n64"
+            add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd(x, y, B, bn=bn)), flops, act_b)
+            add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.wgrad(x, y, B, bn=bn)), flops, act_b)
+            tile_d = "n32" if cv.cin <= 32 else "n64"
+            add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad(y, dx, B)), flops, act_b)
+    total = sum(c["time"] for c in classes.values())
+    name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
+    ach = dom["flops"] / dom["time"] / 1e12
+    return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=dom["launches"],
+                avg_launch_us=round(dom["time"] / dom["launches"] * 1e6, 2),
+                conv_classes={k: dict(us_per_step=round(v["time"] * 1e6, 1), tflops=round(v["flops"] / v["time"] / 1e12, 2),
+                                      launches=v["launches"]) for k, v in sorted(classes.items())},
+                conv_total_us_per_step=round(total * 1e6, 1))
+
+
+def cpu_baseline(kw, input_shape, B, budget_s=20.0):
+    """torch-CPU restatement (oracle/model_torch.py, fp32) of the same graph on this box's host cores, bounded sample:
+    one warm-up step, then whole train steps at B=16 until ~budget_s of wall-clock is spent (at most 4).  Threads are
+    capped at 16: the graph's small sequential ops (GRU steps, heads) get slower, not faster, with more threads."""
+    from oracle import model_torch as MT
+    threads = max(1, min(os.cpu_count() or 1, 16))
+    torch.set_num_threads(threads)
+    Bc = min(B, 16)
+    cfg = MT.Cfg(input_shape, **kw)
+    net = MT.TorchSARNet(cfg, dtype=torch.float32)
+    b = MT.synthetic_batch(cfg, Bc)
+    net.train_on_batch(b)
+    t0 = time.time(); n = 0
+    while n < 4 and (n == 0 or time.time() - t0 < budget_s):
+        net.train_on_batch(b); n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=round(Bc / dt, 2), unit="utterances/sec", cores=threads, kind="port",
+                sample="%d train steps (after 1 warm-up) of the same graph at B=%d x %d frames, torch-CPU fp32 restatement "
+                       "(not TF-Keras), %d threads" % (n, Bc, input_shape[0], threads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64; cfg5: 32)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from aesrc2020_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    from aesrc2020_amd.model import SAR_Net
+    from aesrc2020_amd.utils import synthetic_batch
+    import torch.distributed as dist
+
+    wl = WORKLOADS[args.workload]
+    T = args.frames or (2000 if args.workload == "cfg5" else 400)
+    B = args.batch or (32 if args.workload == "cfg5" else 64)
+    input_shape = [T, 80, 1]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, train_model = SAR_Net(input_shape, lr=0.01, gpus=world, seed=0, use_graph=not args.no_graph, **wl["kw"])
+    kw = wl["kw"]
+    # a few synthetic batches, uploaded once; the timed loop only does D2D copies into the static input buffers
+    nb = 4
+    dev_batches = []
+    for i in range(nb):
+        xi, yi = synthetic_batch(input_shape, B, kw.get("ctc_enable", False), kw.get("disc_enable", False),
+                                 bpe_classes=kw.get("bpe_classes", 1000), max_ctc_len=kw.get("max_ctc_len", 72), seed=1234 + rank + 100 * i)
+        d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in {**xi, **yi}.items()}
+        dev_batches.append(d)
+    if dev_batches and "x_ctc_label" in dev_batches[0]:
+        for d in dev_batches:   # host-side feasibility check once (the device path never syncs)
+            model._check_ctc_feasible(d["x_ctc_label"].cpu().numpy(), d["x_ctc_in_len"].cpu().numpy().ravel(), d["x_ctc_out_len"].cpu().numpy().ravel())
+
+    def step(i):
+        train_model.set_device_batch(dev_batches[i % nb])
+        train_model.train_step_device()
+
+    for i in range(max(args.warmup, 2)):           # >= 2: first step is eager (allocations), second captures the graph
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    logs = train_model._logs()
+    assert np.isfinite(logs["loss"]), logs
+
+    if rank == 0:
+        res = {
+            "metric": "utterances/sec train step, 400-frame x 80-dim fbank", "value": round(world * B * args.steps / dt, 2),
+            "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "batch_per_gpu": B, "global_batch": B * world, "frames": T, "feat_dim": 80,
+                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "params": model.count_params(),
+                       "final_loss": round(logs["loss"], 4)},
+        }
+        if not args.no_roofline:
+            res["roofline"] = conv_roofline(model, B)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(kw, input_shape, B)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
