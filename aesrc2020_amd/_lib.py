@@ -73,5 +73,10 @@ def call(name, *args, stream=None):
         raise RuntimeError("%s failed with status %d (args=%r)" % (name, rc, [getattr(a, "shape", a) for a in args]))
 
 
+def bn_workspace_doubles(C):
+    """Length (in float64 elements) of the BatchNorm reduction workspace for C channels."""
+    return (lib().fn["sar_bn_workspace_bytes"](C) + 7) // 8
+
+
 def ctc_workspace_bytes(B, L, max_label_len):
     return lib().fn["sar_ctc_workspace_bytes"](B, L, max_label_len)

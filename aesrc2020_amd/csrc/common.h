@@ -66,5 +66,19 @@ __device__ __forceinline__ float lse2(float a, float b) {
     return m + logf(expf(a - m) + expf(b - m));
 }
 
+// Zero-fill as a kernel node.  hipMemsetAsync nodes inside a captured HIP graph were observed (ROCm 7.2, gfx950) to
+// corrupt split-K accumulation on replay, so the library never uses memset on the launch path.
+__global__ static void sar_zero_kernel(uint32_t* __restrict__ p, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t sar_zero_async(void* p, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;                 // all buffers here are multiples of 4 bytes
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(sar_zero_kernel, dim3((unsigned)nb), dim3(256), 0, stream, static_cast<uint32_t*>(p), n);
+    return hipGetLastError();
+}
+
 // activation codes shared by host and device (include/sarnet.h mirrors them)
 enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2 };

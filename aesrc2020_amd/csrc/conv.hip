@@ -7,13 +7,14 @@
 // SURVEY.md App. A.  The 7x7/2 Cin=1 stem (resnet.py:173/191) is a direct LDS-patch kernel; MaxPooling2D
 // (resnet.py:174) is fused with the stem's BN+ReLU.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 struct ConvP {
     const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
     float* y;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk;
 };
 
 constexpr int CK = 16;  // k-tile
@@ -96,9 +97,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nkt = K / CK;
-    load(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // split-K: slice z owns k-tiles [kt0, kt1); small-M layers (stages 2-3) need it to fill 256 CUs
+    const int nkt_all = K / CK, per = (nkt_all + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
+    if (kt0 < nkt) load(kt0);
+    for (int kt = kt0; kt < nkt; ++kt) {
         store();
         __syncthreads();
         if (kt + 1 < nkt) load(kt + 1);
@@ -112,21 +115,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= p.Cout) return;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+    const bool lead = blockIdx.z == 0;
+    const float bv = (p.bias && lead) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= M) continue;
         float v = acc[r] + bv;
-        if (p.res) v += p.res[row * p.Cout + col];
-        p.y[row * p.Cout + col] = v;
+        if (p.res && lead) v += p.res[row * p.Cout + col];
+        if (p.splitk > 1) atomicAdd(p.y + row * p.Cout + col, v);       // y was zeroed by the launcher
+        else p.y[row * p.Cout + col] = v;
     }
 }
 
 // ------------------------------------------------------------------ dgrad
 struct DgradP {
     const float* dy; const float* w; float* dx;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, accumulate;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, accumulate, splitk;
 };
 
 template <int WM, int WN>
@@ -200,9 +205,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nkt = K / CK;
-    load(0);
-    for (int kt = 0; kt < nkt; ++kt) {
+    const int nkt_all = K / CK, per = (nkt_all + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
+    if (kt0 < nkt) load(kt0);
+    for (int kt = kt0; kt < nkt; ++kt) {
         store();
         __syncthreads();
         if (kt + 1 < nkt) load(kt + 1);
@@ -221,7 +227,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
         const long row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= M) continue;
         float* d = p.dx + row * p.Cin + col;
-        *d = p.accumulate ? (*d + acc[r]) : acc[r];
+        if (p.splitk > 1) atomicAdd(d, acc[r]);                         // dx zeroed by the launcher unless accumulating
+        else *d = p.accumulate ? (*d + acc[r]) : acc[r];
     }
 }
 
@@ -464,7 +471,7 @@ __global__ void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, const fl
 __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
     const float* __restrict__ dpool, const float* __restrict__ out, const uint8_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-    double* __restrict__ sums, int B, int H, int W, int C, int Ho, int Wo, int pt, int pl) {
+    float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int pt, int pl) {
     // thread -> channel c = tid % C (C <= 256 and 256 % C == 0 assumed by the host), pixel group = tid / C
     const int c = threadIdx.x % C, pg = threadIdx.x / C, npg = blockDim.x / C;
     const long npix = (long)B * Ho * Wo;
@@ -487,10 +494,19 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
     __syncthreads();
     if (threadIdx.x < C) {
-        double a1 = 0, a2 = 0;
+        float a1 = 0.f, a2 = 0.f;
         for (int g = 0; g < npg; ++g) { a1 += r1[g * C + threadIdx.x]; a2 += r2[g * C + threadIdx.x]; }
-        atomicAdd(sums + c, a1); atomicAdd(sums + C + c, a2);
+        part[(long)blockIdx.x * 2 * C + c] = a1; part[(long)blockIdx.x * 2 * C + C + c] = a2;
     }
+}
+
+__global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restrict__ part, int nb, double* __restrict__ totals, int C2) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;     // one wave per column
+    if (c >= C2) return;
+    double s = 0;
+    for (int b = lane; b < nb; b += 64) s += (double)part[(long)b * C2 + c];
+    s = wave_sum_d(s);
+    if (lane == 0) totals[c] = s;
 }
 
 // Backward pass 2: dx = scale * (dz - s1/R - xhat*s2/R) at full resolution.
@@ -528,18 +544,32 @@ __global__ void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool
 
 static bool conv_args_ok(int Cin, int Cout) { return (Cin % 16 == 0) && (Cout % 16 == 0); }
 
+// Blocks are 256 threads with ~9-11 KB of LDS: aim for >= 4 blocks per CU (1024 blocks) so that global-load latency of
+// one block's k-tile hides behind the MFMA phase of another; each slice keeps >= 4 k-tiles.
+static int pick_conv_splitk(int tiles, int nkt) {
+    static const bool off = getenv("SAR_NO_SPLITK") != nullptr;      // debugging aid
+    if (off || tiles >= 768) return 1;
+    int s = (1024 + tiles - 1) / tiles;
+    if (s > nkt / 4) s = nkt / 4;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
 extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale,
                                   const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
                                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
                                   hipStream_t stream) {
     if (!x || !w || !y || !conv_args_ok(Cin, Cout) || (scale && !shift)) return SAR_EINVAL;
-    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left};
+    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1};
     const long M = (long)B * Ho * Wo;
+    const int tiles = Cout <= 32 ? cdiv(M, 128) * cdiv(Cout, 32) : cdiv(M, 64) * cdiv(Cout, 64);
+    p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / CK);
+    if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
     if (Cout <= 32) {
-        dim3 grid(cdiv(M, 128), cdiv(Cout, 32));
+        dim3 grid(cdiv(M, 128), cdiv(Cout, 32), p.splitk);
         hipLaunchKernelGGL((conv_fwd_kernel<4, 1>), grid, dim3(256), 0, stream, p);
     } else {
-        dim3 grid(cdiv(M, 64), cdiv(Cout, 64));
+        dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
         hipLaunchKernelGGL((conv_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, p);
     }
     SAR_CHECK_LAUNCH();
@@ -550,13 +580,16 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
                                     int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
                                     int accumulate, hipStream_t stream) {
     if (!dy || !w || !dx || !conv_args_ok(Cin, Cout)) return SAR_EINVAL;
-    DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate};
+    DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, 1};
     const long M = (long)B * H * W;
+    const int tiles = Cin <= 32 ? cdiv(M, 128) * cdiv(Cin, 32) : cdiv(M, 64) * cdiv(Cin, 64);
+    p.splitk = pick_conv_splitk(tiles, KH * KW * Cout / CK);
+    if (p.splitk > 1 && !accumulate && sar_zero_async(dx, sizeof(float) * M * Cin, stream) != hipSuccess) return SAR_ELAUNCH;
     if (Cin <= 32) {
-        dim3 grid(cdiv(M, 128), cdiv(Cin, 32));
+        dim3 grid(cdiv(M, 128), cdiv(Cin, 32), p.splitk);
         hipLaunchKernelGGL((conv_dgrad_kernel<4, 1>), grid, dim3(256), 0, stream, p);
     } else {
-        dim3 grid(cdiv(M, 64), cdiv(Cin, 64));
+        dim3 grid(cdiv(M, 64), cdiv(Cin, 64), p.splitk);
         hipLaunchKernelGGL((conv_dgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p);
     }
     SAR_CHECK_LAUNCH();
@@ -618,14 +651,15 @@ extern "C" int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, c
     return SAR_OK;
 }
 
-// sums: double[2C] workspace (zeroed here). dx may not alias x.
+// sums: the stem BN workspace (sar_bn_workspace_bytes(C)). dx may not alias x.
 extern "C" int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint8_t* idx, const float* x,
                                            const float* mean, const float* rstd, const float* scale, double* sums,
                                            float* dx, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
                                            int pad_left, hipStream_t stream) {
     if (!dpool || !out || !idx || !x || !mean || !rstd || !scale || !sums || !dx || C > 256 || (256 % C)) return SAR_EINVAL;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return SAR_ELAUNCH;
-    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(1024), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, sums, B, H, W, C, Ho, Wo, pad_top, pad_left);
+    float* part = reinterpret_cast<float*>(sums + 2 * C);          // workspace layout of sar_bn_workspace_bytes(C)
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, part, B, H, W, C, Ho, Wo, pad_top, pad_left);
+    hipLaunchKernelGGL(pool_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, 256, sums, 2 * C);
     const long total = (long)B * H * W * C;
     const int nblk = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3(nblk), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, sums, dx, B, H, W, C, Ho, Wo, pad_top, pad_left);

@@ -38,7 +38,31 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int i = threadIdx.x; i < N; i += blockDim.x) dz[o + i] = p[o + i] * (dp[o + i] - s);
 }
 
-// out[c] += sum_r x[r][c]; block handles a row chunk, 256 threads over columns (loop), atomics per block
+// out[c] += sum_r x[r][c].  C % 4 == 0: float4 lanes over channel-vectors x row-groups (coalesced), <= 128 blocks,
+// one fp32 atomic per column per block.  Otherwise (tiny C such as the 8 accents): thread-per-column fallback.
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, long R,
+                                                         int C, int tpr) {
+    __shared__ float4 s1[256];
+    const int nrg = 256 / tpr, rg = threadIdx.x / tpr;
+    for (int cv0 = 0; cv0 * 4 < C; cv0 += tpr) {            // C > 1024: several passes over column groups
+        const int cv = cv0 + threadIdx.x % tpr;
+        float4 a = make_float4(0, 0, 0, 0);
+        if (cv * 4 < C)
+            for (long r = (long)blockIdx.x * nrg + rg; r < R; r += (long)gridDim.x * nrg) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * C + cv * 4);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        __syncthreads();
+        s1[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < tpr && cv * 4 < C) {
+            float4 d = make_float4(0, 0, 0, 0);
+            for (int g = 0; g < nrg; ++g) { const float4 u = s1[g * tpr + threadIdx.x]; d.x += u.x; d.y += u.y; d.z += u.z; d.w += u.w; }
+            atomicAdd(out + cv * 4 + 0, d.x); atomicAdd(out + cv * 4 + 1, d.y);
+            atomicAdd(out + cv * 4 + 2, d.z); atomicAdd(out + cv * 4 + 3, d.w);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long R, int C,
                                                      int rows_per_block) {
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
@@ -142,8 +166,17 @@ extern "C" int sar_softmax_bwd_f32(const float* dp, const float* p, float* dz, i
 }
 extern "C" int sar_colsum_f32(const float* x, float* out, long R, int C, hipStream_t stream) {
     if (!x || !out || R <= 0 || C <= 0) return SAR_EINVAL;
-    int rpb = (int)((R + 511) / 512); if (rpb < 8) rpb = 8;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(R, rpb)), dim3(256), 0, stream, x, out, R, C, rpb);
+    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        int tpr = 1; while (tpr < C / 4 && tpr < 256) tpr <<= 1;
+        const int nrg = 256 / tpr;
+        long nb = (R + nrg * 8 - 1) / (nrg * 8);
+        if (nb > 128) nb = 128;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3((int)nb), dim3(256), 0, stream, x, out, R, C, tpr);
+    } else {
+        int rpb = (int)((R + 511) / 512); if (rpb < 8) rpb = 8;
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(R, rpb)), dim3(256), 0, stream, x, out, R, C, rpb);
+    }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -223,7 +223,7 @@ extern "C" int sar_margin_head_bwd_f32(const float* dprobs, const float* probs, 
                                        float* dx, float* dW, float* dwn_ws, int B, int D, int A, int mode, float s,
                                        float m, int accumulate_dx, hipStream_t stream) {
     if (!dprobs || !probs || !cosv || !x || !y || !W || !inv_x || !inv_w || !dx || !dW || !dwn_ws || A > 64 || D > 512) return SAR_EINVAL;
-    if (hipMemsetAsync(dwn_ws, 0, sizeof(float) * D * A, stream) != hipSuccess) return SAR_ELAUNCH;
+    if (sar_zero_async(dwn_ws, sizeof(float) * D * A, stream) != hipSuccess) return SAR_ELAUNCH;
     hipLaunchKernelGGL(margin_bwd_kernel, dim3(B), dim3(64), 0, stream, dprobs, probs, cosv, x, y, W, inv_x, inv_w, dx, dwn_ws, D, A, mode, s, m, accumulate_dx);
     hipLaunchKernelGGL(margin_wbwd_kernel, dim3(A), dim3(64), 0, stream, dwn_ws, W, inv_w, dW, D, A);
     SAR_CHECK_LAUNCH();

@@ -9,10 +9,10 @@
 
 namespace {
 
-__device__ __forceinline__ int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+constexpr int BN_MAX_BLOCKS = 256;
 
 // ---- per-channel sum / sum-of-squares of x (R, C), C % 4 == 0, C <= 1024 -----------------------------
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, double* __restrict__ sums, long R,
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long R,
                                                        int C, int tpr /* pow2 >= C/4, <= 256 */) {
     __shared__ float4 s1[256], s2[256];
     const int cv = threadIdx.x % tpr, rg = threadIdx.x / tpr, nrg = 256 / tpr;
@@ -26,29 +26,46 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
-    if (threadIdx.x < tpr && threadIdx.x * 4 < C) {
-        double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+    if (threadIdx.x < tpr && threadIdx.x * 4 < C) {      // per-block partials, combined in fp64 by the next kernel
+        float4 d1 = make_float4(0, 0, 0, 0), d2 = d1;
         for (int g = 0; g < nrg; ++g) {
             const float4 u = s1[g * tpr + threadIdx.x], w = s2[g * tpr + threadIdx.x];
-            d1[0] += u.x; d1[1] += u.y; d1[2] += u.z; d1[3] += u.w;
-            d2[0] += w.x; d2[1] += w.y; d2[2] += w.z; d2[3] += w.w;
+            d1.x += u.x; d1.y += u.y; d1.z += u.z; d1.w += u.w;
+            d2.x += w.x; d2.y += w.y; d2.z += w.z; d2.w += w.w;
         }
-        for (int j = 0; j < 4; ++j) {
-            atomicAdd(sums + threadIdx.x * 4 + j, d1[j]);
-            atomicAdd(sums + C + threadIdx.x * 4 + j, d2[j]);
-        }
+        float* o = part + (long)blockIdx.x * 2 * C;
+        *reinterpret_cast<float4*>(o + threadIdx.x * 4) = d1;
+        *reinterpret_cast<float4*>(o + C + threadIdx.x * 4) = d2;
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+// One wave per column: lanes stride over the per-block partials (independent loads in flight), fp64 wave reduction.
+__device__ __forceinline__ double combine_column(const float* __restrict__ part, int nb, int stride, int c, int lane) {
+    double s = 0;
+    for (int b = lane; b < nb; b += 64) s += (double)part[(long)b * stride + c];
+    return wave_sum_d(s);
+}
+
+// totals[c] = sum over blocks of part[b][c], c < C2 (fp64).  grid = ceil(C2/4), block = 256 (4 waves = 4 columns)
+__global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ part, int nb, double* __restrict__ totals, int C2) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C2) return;
+    const double s = combine_column(part, nb, C2, c, lane);
+    if (lane == 0) totals[c] = s;
+}
+
+// combines the per-block partials in fp64 and folds gamma/beta into scale/shift (one launch; one wave per channel)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nb, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
                                    float* __restrict__ mov_var, long R, int C, float eps, float momentum,
                                    int unbiased_moving_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
-    const double mu = sums[c] / (double)R;
-    double var = sums[C + c] / (double)R - mu * mu;
+    const double s1 = combine_column(part, nb, 2 * C, c, lane), s2 = combine_column(part, nb, 2 * C, C + c, lane);
+    if (lane != 0) return;
+    const double mu = s1 / (double)R;
+    double var = s2 / (double)R - mu * mu;
     if (var < 0) var = 0;
     const double rs = 1.0 / sqrt(var + (double)eps);
     mean[c] = (float)mu; rstd[c] = (float)rs;
@@ -78,7 +95,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dact, const float* __restrict__ x,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            double* __restrict__ sums, long R, int C, int tpr, int relu) {
+                                                            float* __restrict__ part, long R, int C, int tpr, int relu) {
     __shared__ float4 s1[256], s2[256];
     const int cv = threadIdx.x % tpr, rg = threadIdx.x / tpr, nrg = 256 / tpr;
     float4 a = make_float4(0, 0, 0, 0), b = a;
@@ -101,17 +118,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
-    if (threadIdx.x < tpr && threadIdx.x * 4 < C) {
-        double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+    if (threadIdx.x < tpr && threadIdx.x * 4 < C) {      // per-block partials, combined in fp64 by the next kernel
+        float4 d1 = make_float4(0, 0, 0, 0), d2 = d1;
         for (int g = 0; g < nrg; ++g) {
             const float4 u = s1[g * tpr + threadIdx.x], w = s2[g * tpr + threadIdx.x];
-            d1[0] += u.x; d1[1] += u.y; d1[2] += u.z; d1[3] += u.w;
-            d2[0] += w.x; d2[1] += w.y; d2[2] += w.z; d2[3] += w.w;
+            d1.x += u.x; d1.y += u.y; d1.z += u.z; d1.w += u.w;
+            d2.x += w.x; d2.y += w.y; d2.z += w.z; d2.w += w.w;
         }
-        for (int j = 0; j < 4; ++j) {
-            atomicAdd(sums + threadIdx.x * 4 + j, d1[j]);
-            atomicAdd(sums + C + threadIdx.x * 4 + j, d2[j]);
-        }
+        float* o = part + (long)blockIdx.x * 2 * C;
+        *reinterpret_cast<float4*>(o + threadIdx.x * 4) = d1;
+        *reinterpret_cast<float4*>(o + C + threadIdx.x * 4) = d2;
     }
 }
 
@@ -304,20 +320,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 }  // namespace
 
+// BN reduction workspace: double totals[2C] followed by float partials[BN_MAX_BLOCKS][2C]
+extern "C" size_t sar_bn_workspace_bytes(int C) { return sizeof(double) * 2 * C + sizeof(float) * (size_t)BN_MAX_BLOCKS * 2 * C; }
+
 static int pow2_tpr(int C) { int v = C / 4, p = 1; while (p < v) p <<= 1; return p; }
 
-// sums: double[2C] workspace. Computes batch statistics of x (R,C) and the folded scale/shift.
+// sums: workspace of sar_bn_workspace_bytes(C) (fp64 totals + per-block partials; no zeroing, no atomics).
+// Computes batch statistics of x (R,C) and the folded scale/shift.
 extern "C" int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, double* sums, float* mean,
                                 float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
                                 int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream) {
     if (!x || !gamma || !beta || !sums || !mean || !rstd || !scale || !shift || C % 4 || C > 1024 || R <= 0) return SAR_EINVAL;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return SAR_ELAUNCH;
     const int tpr = pow2_tpr(C), nrg = 256 / tpr;
-    long nb = (R + nrg * 8 - 1) / (nrg * 8);
-    if (nb > 2048) nb = 2048;
+    long nb = (R + nrg * 4 - 1) / (nrg * 4);
+    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((int)nb), dim3(256), 0, stream, x, sums, R, C, tpr);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, sums, gamma, beta, mean, rstd, scale,
+    float* part = reinterpret_cast<float*>(sums + 2 * C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((int)nb), dim3(256), 0, stream, x, part, R, C, tpr);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, part, (int)nb, gamma, beta, mean, rstd, scale,
                        shift, moving_mean, moving_var, R, C, eps, momentum, unbiased_moving_var);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -339,12 +359,13 @@ extern "C" int sar_bn_bwd_f32(const float* dact, const float* x, const float* sc
                               const float* mean, const float* rstd, double* sums, const float* add, float* dx,
                               float* dgamma, float* dbeta, long R, int C, int relu, hipStream_t stream) {
     if (!dact || !x || !scale || !shift || !mean || !rstd || !sums || !dx || C % 4 || C > 1024) return SAR_EINVAL;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, stream) != hipSuccess) return SAR_ELAUNCH;
     const int tpr = pow2_tpr(C), nrg = 256 / tpr;
-    long nb = (R + nrg * 8 - 1) / (nrg * 8);
-    if (nb > 2048) nb = 2048;
+    long nb = (R + nrg * 4 - 1) / (nrg * 4);
+    if (nb > BN_MAX_BLOCKS) nb = BN_MAX_BLOCKS;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)nb), dim3(256), 0, stream, dact, x, scale, shift, mean, rstd, sums, R, C, tpr, relu);
+    float* part = reinterpret_cast<float*>(sums + 2 * C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)nb), dim3(256), 0, stream, dact, x, scale, shift, mean, rstd, part, R, C, tpr, relu);
+    hipLaunchKernelGGL(bn_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, (int)nb, sums, 2 * C);
     const long n4 = R * (C / 4);
     const int nb2 = (int)(n4 / 256 + 1 < 8192 ? n4 / 256 + 1 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb2), dim3(256), 0, stream, dact, x, scale, shift, mean, rstd, sums, add, dx, dgamma, dbeta, R, C, relu);

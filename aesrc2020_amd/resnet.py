@@ -39,7 +39,7 @@ class _BN:
     def stats(self, x, R):
         C = self.C
         self.mean, self.rstd, self.scale, self.shift = (self._b(k, (C,)) for k in ("mean", "rstd", "scale", "shift"))
-        self.sums = self._b("sums", (2 * C,), torch.float64)
+        self.sums = self._b("sums", (_lib.bn_workspace_doubles(C),), torch.float64)
         _call("sar_bn_stats_f32", x, self.gamma.w, self.beta.w, self.sums, self.mean, self.rstd, self.scale, self.shift,
               self.moving_mean.w, self.moving_var.w, R, C, BN_EPS, BN_MOMENTUM, 1)
 
@@ -74,10 +74,13 @@ class _Conv:
         _call("sar_conv2d_dgrad_f32", dy, self.kernel.w, dx, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
               self.k, self.k, self.stride, self.pt, self.pl, accumulate)
 
-    def wgrad(self, x, dy, B, bn=None):
+    def wgrad(self, x, dy, B, bn=None, bias_grad=True):
+        """Kernel gradient (+ bias gradient).  A conv whose output feeds a BatchNorm directly has an exactly-zero bias
+        gradient (BN backward outputs sum to zero per channel), so callers pass bias_grad=False there."""
         _call("sar_conv2d_wgrad_f32", x, dy, bn.scale if bn else None, bn.shift if bn else None, self.kernel.g, B, self.H,
               self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
-        _call("sar_colsum_f32", dy, self.bias.g, B * self.Ho * self.Wo, self.cout)
+        if bias_grad:
+            _call("sar_colsum_f32", dy, self.bias.g, B * self.Ho * self.Wo, self.cout)
 
 
 class ResNetTrunk(Layer):
@@ -182,13 +185,14 @@ class ResNetTrunk(Layer):
             blk["conv2"].wgrad(blk["c1"], g, B, bn=blk["bn2"])
             dc1 = da2                                                      # in place: BN+ReLU backward
             blk["bn2"].bwd(da2, blk["c1"], None, dc1, R2, relu=1)
-            blk["conv1"].wgrad(blk["x"], dc1, B, bn=blk["bn1"])
+            blk["conv1"].wgrad(blk["x"], dc1, B, bn=blk["bn1"], bias_grad=False)   # feeds bn2
             gin = self.scratch("res_gin%d_%dx%dx%d" % (n & 1, H, W, cin), (B, H, W, cin))   # ping-pong: never aliases g
             if blk["bn1"] is not None:
                 # shortcut gradient first (raw block input), then the main path folds it in via `add`
                 if blk["sc"] is not None:
                     dsc = self.scratch("res_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin))
-                    blk["sc"].dgrad(g, dsc, B); blk["sc"].wgrad(blk["x"], g, B)
+                    blk["sc"].dgrad(g, dsc, B); blk["sc"].wgrad(blk["x"], g, B, bias_grad=False)
+                    _call("sar_axpy_f32", blk["conv2"].bias.g, blk["sc"].bias.g, 1.0, cout)   # same column sums of g
                 else:
                     dsc = g
                 da1 = self.scratch("res_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin))
@@ -197,7 +201,8 @@ class ResNetTrunk(Layer):
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
                 if blk["sc"] is not None:
-                    blk["sc"].dgrad(g, gin, B); blk["sc"].wgrad(blk["x"], g, B)
+                    blk["sc"].dgrad(g, gin, B); blk["sc"].wgrad(blk["x"], g, B, bias_grad=False)
+                    _call("sar_axpy_f32", blk["conv2"].bias.g, blk["sc"].bias.g, 1.0, cout)
                     blk["conv1"].dgrad(dc1, gin, B, accumulate=1)
                 else:
                     blk["conv1"].dgrad(dc1, gin, B)
@@ -211,7 +216,8 @@ class ResNetTrunk(Layer):
               dstem, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
         _call("sar_bn_param_grads_f32", sb.sums, sb.gamma.g, sb.beta.g, c0)
         T, D = self.in_hw
-        _call("sar_stem_conv7x7_wgrad_f32", self.x, dstem, self.stem.kernel.g, self.stem.bias.g, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl)
+        # the stem bias feeds a BatchNorm: its gradient is exactly zero, so db is not computed (None)
+        _call("sar_stem_conv7x7_wgrad_f32", self.x, dstem, self.stem.kernel.g, None, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl)
         return None
 
 

@@ -62,7 +62,9 @@ int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint
                                 sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
- * x is viewed (R, C).  sums = double[2C] scratch. */
+ * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a
+ * backward) followed by per-block fp32 partials; two-stage reduction, no atomics, no zeroing required. */
+size_t sar_bn_workspace_bytes(int C);
 int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, double* sums, float* mean, float* rstd,
                      float* scale, float* shift, float* moving_mean, float* moving_var, long R, int C, float eps,
                      float momentum, int unbiased_moving_var, sarStream_t stream);

@@ -85,25 +85,44 @@ def test_forward_backward_parity(case):
     assert set(r.name for r in model.store.refs if r.l2 > 0) == set(ref.reg)
 
 
+def grad_mismatches(model, ref, G, tol=2e-3):
+    """Per-tensor gradient comparison (see test_forward_backward_parity for the zero-gradient rule)."""
+    ref_g = {r.name: G[r.name].numpy() - (2 * MT.L2 * ref.P[r.name].numpy() if r.name in ref.reg else 0.0) for r in model.store.refs}
+    med = float(np.median([np.abs(v).max() for v in ref_g.values()]))
+    bad = []
+    for r in model.store.refs:
+        g = r.g.cpu().numpy(); gr = ref_g[r.name]
+        if np.abs(gr).max() < 1e-9 * med:
+            if not np.abs(g).max() < 1e-4 * med:
+                bad.append((r.name, "zero-grad tensor", float(np.abs(g).max())))
+            continue
+        e = np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-3 * med)
+        if not e < tol:
+            bad.append((r.name, float(e), float(np.abs(gr).max())))
+    return bad
+
+
 @pytest.mark.parametrize("case", ["cfg3_ctc_circle", "cfg2_gvlad_arcface", "cfg1_ar_only"])
 def test_three_train_steps_with_graph_replay(case):
-    """(a) the loss trajectory follows the oracle's for 3 optimizer steps (steps 2-3 replayed from the HIP graph);
-    (b) each fused L2+Adam(+unit_norm) update equals Keras-Adam (oracle/ops_np.adam_step, float64) applied to the
-    gradients the device produced in that step.  Weights are not compared with the oracle's directly: Adam's first steps
-    are +-lr per element whatever the gradient's magnitude, so rounding noise on near-zero gradient elements flips steps."""
+    """Three optimizer steps (steps 2-3 replayed from the captured HIP graph).  At every step the oracle is re-synchronised to
+    the device's current weights, then: (a) total loss and every gradient of that step match the oracle; (b) the fused
+    L2+Adam(+unit_norm) update equals Keras-Adam (oracle/ops_np.adam_step, float64) applied to the device's gradients.
+    (Trajectories are not compared open-loop: Adam's first steps are +-lr per element whatever the gradient magnitude, so
+    rounding noise on near-zero gradient elements flips steps and gamma=256 circle loss amplifies it.)"""
     from oracle import ops_np as O
     cfg, ref, model, batch = build_pair(CASES[case])
     batches = [batch, MT.synthetic_batch(cfg, CASES[case]["B"], seed=78), MT.synthetic_batch(cfg, CASES[case]["B"], seed=79)]
     st = model.store
     m = {r.name: np.zeros(r.shape) for r in st.refs}; v = {r.name: np.zeros(r.shape) for r in st.refs}
     for i, b in enumerate(batches):
-        out, total, parts, G = ref.train_on_batch(b)
         p0 = {r.name: r.w.cpu().double().numpy() for r in st.refs}
+        for k in ref.P:
+            ref.P[k] = torch.tensor(p0[k], dtype=torch.float64)
+        out, total, parts, G = ref.forward_backward(b)
         logs = model.train_on_batch(b, b)
-        if i == 0:          # identical weights -> identical loss; later steps drift by the Adam noise described above
-            assert abs(logs["loss"] - float(total)) <= 1e-3 * abs(float(total)) + 1e-3, (case, i, logs["loss"], float(total))
-        else:
-            assert abs(logs["loss"] - float(total)) <= 0.05 * abs(float(total)) + 1e-2, (case, i, logs["loss"], float(total))
+        assert abs(logs["loss"] - float(total)) <= 1e-3 * abs(float(total)) + 1e-3, (case, i, logs["loss"], float(total))
+        bad = grad_mismatches(model, ref, G, tol=2e-3 if i == 0 else 1e-2)
+        assert not bad, (case, i, bad[:8])
         for r in st.refs:
             g = r.g.cpu().double().numpy() + 2 * r.l2 * p0[r.name]
             want, m[r.name], v[r.name] = O.adam_step(p0[r.name], g, m[r.name], v[r.name], i, lr=cfg.lr)

@@ -123,9 +123,9 @@ def test_stem_and_fused_maxpool(L, B, T, D, C0):
     a_ref = O.relu_fwd(bn_ref)
     p_ref, pc = O.maxpool_fwd(a_ref)
     Hp, ppt, _ = O.same_pads(Ho, 3, 2); Wp, ppl, _ = O.same_pads(Wo, 3, 2)
-    sums = zeros(2 * C0, dtype=torch.float64)
+    sums = zeros(L.bn_workspace_doubles(C0), dtype=torch.float64)
     mean, rstd, scale, shift = zeros(C0), zeros(C0), zeros(C0), zeros(C0)
-    mm, mv = zeros(C0), torch.ones(C0, device="cuda")
+    mm, mv = zeros(C0), torch.ones(C0, device="cuda", dtype=torch.float32)
     yd = dev(y_ref)
     L.call("sar_bn_stats_f32", yd, dev(gamma), dev(beta), sums, mean, rstd, scale, shift, mm, mv, B * Ho * Wo, C0, 1e-3, 0.99, 1)
     check(mean, bnc[4], name="bn mean"); check(rstd, bnc[1], name="bn rstd")
@@ -158,7 +158,7 @@ def test_batchnorm_4d(L, R, C, relu):
     x = rng.standard_normal((R, C)) * 2 + 0.5; gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C) * 0.3
     y_ref, cache = O.batchnorm_fwd(x, gamma, beta)
     a_ref = O.relu_fwd(y_ref) if relu else y_ref
-    xd = dev(x); sums = zeros(2 * C, dtype=torch.float64)
+    xd = dev(x); sums = zeros(L.bn_workspace_doubles(C), dtype=torch.float64)
     mean, rstd, scale, shift = zeros(C), zeros(C), zeros(C), zeros(C)
     L.call("sar_bn_stats_f32", xd, dev(gamma), dev(beta), sums, mean, rstd, scale, shift, None, None, R, C, 1e-3, 0.99, 1)
     y = zeros(R, C)
@@ -271,7 +271,7 @@ def test_ctc(L, B, Lq, V, maxU, Umax):
     got = loss.cpu().numpy(); fin = np.isfinite(loss_ref[:, 0])
     assert np.array_equal(np.isfinite(got), fin)
     np.testing.assert_allclose(got[fin], loss_ref[fin, 0], rtol=1e-4, atol=1e-4)
-    dloss = rng.uniform(0.5, 1.5, B); dp = torch.full((B, Lq, V), 7.0, device="cuda")
+    dloss = rng.uniform(0.5, 1.5, B); dp = torch.full((B, Lq, V), 7.0, device="cuda", dtype=torch.float32)
     L.call("sar_ctc_batch_cost_bwd_f32", pd, labd, ild, lld, loss, dev(dloss), ws, wsb, dp, B, Lq, V, maxU)
     check(dp, grad_ref * dloss[:, None, None], 5e-4, "ctc grad")
     dec = zeros(B, Lq, dtype=torch.int32); dl = zeros(B, dtype=torch.int32)

@@ -10,7 +10,6 @@ import torch.nn.functional as F
 from oracle import ops_np as O
 from oracle import model_torch as MT
 
-torch.set_default_dtype(torch.float64)
 RNG = np.random.default_rng(7)
 
 
@@ -112,7 +111,7 @@ def test_bigru_vs_torch_nn_gru(seq):
     pf = (RNG.standard_normal((I, 3 * H)) * .5, RNG.standard_normal((H, 3 * H)) * .5, RNG.standard_normal(6 * H) * .5)
     pb = (RNG.standard_normal((I, 3 * H)) * .5, RNG.standard_normal((H, 3 * H)) * .5, RNG.standard_normal(6 * H) * .5)
     y, cache = O.bigru_fwd(x, pf, pb, seq)
-    gru = torch.nn.GRU(I, H, batch_first=True, bidirectional=True)
+    gru = torch.nn.GRU(I, H, batch_first=True, bidirectional=True).double()
     with torch.no_grad():
         for sfx, p in (("", pf), ("_reverse", pb)):
             wi, wh, bi, bh = _keras_to_torch_gru(*p, H)
