@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Generates the committed golden vectors under tests/golden/ from the CPU oracle (oracle/ops_np.py, oracle/model_torch.py).
+
+The reference (pika-online/AESRC2020) ships no golden vectors and TensorFlow/Keras cannot be imported in the build
+container, so these fixtures pin *our restatement* ("parity unpinned" w.r.t. the real Keras path): they freeze
+the oracle's numbers so that (a) the oracle cannot drift silently (CPU test) and (b) the GPU parity tests have
+data-only expectations that travel to the GPU box.      Usage: python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import ops_np as O          # noqa: E402
+from oracle import model_torch as MT    # noqa: E402
+
+MODEL_KW = dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="gvlad", vlad_clusters=4,
+                ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=20, max_ctc_len=6, metric_loss="circleloss")
+
+
+def ops_vectors():
+    rng = np.random.default_rng(2020)
+    d = {}
+    # K.ctc_batch_cost: repeated label, short input, infeasible item
+    B, L, V, U = 4, 10, 7, 5
+    p = O.softmax(rng.standard_normal((B, L, V)) * 2)
+    lab = np.array([[1, 1, 3, 2, 2], [0, 5, 2, 2, 2], [4, 2, 2, 2, 2], [3, 3, 3, 3, 3]], np.float32)
+    il = np.array([[10], [7], [10], [6]], np.int32); ll = np.array([[3], [2], [1], [5]], np.int32)
+    loss, grad = O.ctc_batch_cost_fwd_bwd(p, lab, il, ll)
+    d.update(ctc_probs=p, ctc_labels=lab, ctc_in_len=il, ctc_lab_len=ll, ctc_loss=loss, ctc_grad=grad)
+    # VladPooling (gvlad)
+    f = rng.standard_normal((3, 1, 9, 16)); s = rng.standard_normal((3, 1, 9, 6)) * 2; c = rng.standard_normal((6, 16))
+    y, cache = O.vlad_fwd(f, s, c, 4, "gvlad"); dy = rng.standard_normal(y.shape)
+    df, ds, dc = O.vlad_bwd(dy, cache)
+    d.update(vlad_feat=f, vlad_score=s, vlad_centers=c, vlad_out=y, vlad_dout=dy, vlad_dfeat=df, vlad_dscore=ds, vlad_dcenters=dc)
+    # margin heads
+    x = rng.standard_normal((6, 16)); W = rng.standard_normal((16, 5)) * 0.3; yh = np.eye(5)[rng.integers(0, 5, 6)]; dp = rng.standard_normal((6, 5))
+    d.update(head_x=x, head_W=W, head_y=yh, head_dp=dp)
+    for mode, m in (("sphereface", 1.35), ("cosface", 0.3), ("arcface", 0.3)):
+        pr, cache = O.margin_head_fwd(x, yh, W, mode, 30.0, m)
+        dx, dW = O.margin_head_bwd(dp, cache)
+        d.update({mode + "_probs": pr, mode + "_dx": dx, mode + "_dW": dW})
+    sc = np.tanh(rng.standard_normal((6, 5)))
+    cl, cds = O.circle_loss_fwd_bwd(yh, sc, 256.0, 0.3)
+    pq = O.softmax(rng.standard_normal((6, 5)) * 5)
+    ce, cdp = O.categorical_crossentropy_fwd_bwd(yh, pq)
+    d.update(circle_s=sc, circle_loss=cl, circle_ds=cds, cce_p=pq, cce_loss=ce, cce_dp=cdp)
+    return d
+
+
+def model_vectors():
+    cfg = MT.Cfg(**MODEL_KW)
+    net = MT.TorchSARNet(cfg, seed=0)
+    batch = MT.synthetic_batch(cfg, 3, seed=11)
+    out, total, parts, G = net.forward_backward(batch)
+    # the weights are regenerated from the seed by oracle init (numpy PCG64 streams are version-stable); the fixture keeps a
+    # per-tensor checksum so RNG/initialiser drift is detected instead of silently changing the expectations
+    d = {"seed": np.array(0), "param_names": np.array(list(net.P)),
+         "param_checksum": np.array([[float(v.sum()), float((v * v).sum())] for v in net.P.values()])}
+    d.update({"batch/" + k: np.asarray(v) for k, v in batch.items()})
+    d["out/y_accent"] = out["y_accent"].detach().numpy(); d["out/y_disc"] = out["y_disc"].detach().numpy()
+    d["out/y_ctc_loss"] = out["y_ctc_loss"].detach().numpy(); d["out/ar"] = out["ar"].detach().numpy()
+    d["loss/total"] = np.array(float(total))
+    for k, v in parts.items():
+        d["loss/" + k] = np.array(float(v))
+    # gradients are stored for a spread of layers (first conv ... heads), minus the L2 term
+    for k in ("conv2d_1/kernel", "conv2d_5/kernel", "batch_normalization_3/gamma", "CNN_LIN/kernel", "CRNN/forward/recurrent_kernel",
+              "CTC_BIGRU/backward/kernel", "ctc_pred/kernel", "gvlad_center_assignment/kernel", "gvlad_pool/centers",
+              "AR_EMBEDDING/kernel", "y_accent/kernel", "y_disc/kernel"):
+        g = G[k].numpy() - (2 * MT.L2 * net.P[k].numpy() if k in net.reg else 0.0)
+        d["grad/" + k] = g
+    return d
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "ops_golden.npz"), **ops_vectors())
+    np.savez_compressed(os.path.join(HERE, "model_golden.npz"), **model_vectors())
+    for f in ("ops_golden.npz", "model_golden.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -1,0 +1,115 @@
+"""CPU tests of the host side: the C-ABI library loads and exports exactly what include/sarnet.h declares (no compute
+calls), loud failure without a GPU, utils / callbacks logic, and the data-parallel path over gloo with world_size 2."""
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from aesrc2020_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    L = _lib.lib()                                        # dlopen + bind every prototype parsed from the header
+    protos = _lib.parse_header()
+    assert len(protos) >= 45 and set(L.fn) == set(protos)
+    out = subprocess.check_output(["nm", "-D", _lib.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T sar_" in l}
+    assert exported == set(protos), (exported ^ set(protos))
+    # every entry point takes the stream last and returns int (or size_t for workspace queries)
+    for name, (ret, at) in protos.items():
+        if name.endswith("_bytes"):
+            continue
+        assert at[-1].__name__ == "c_void_p", name
+    assert _lib.ctc_workspace_bytes(64, 39, 72) == 4 * (64 * 39 * 145 + 64 * 39)    # host-only query, no GPU needed
+    assert _lib.bn_workspace_doubles(32) == 258 * 32
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from aesrc2020_amd.model import SAR_Net
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SAR_Net([100, 80, 1], mto="avg", res_filters=16)
+    import aesrc2020_amd, inspect
+    src = "".join(open(os.path.join(ROOT, "aesrc2020_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "aesrc2020_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src, "the product must never import the oracle"
+
+
+def test_utils_match_reference_semantics():
+    from aesrc2020_amd import utils as U
+    assert [U.cal_descriptors(t, 80) for t in (1200, 400, 100, 2000)] == [114, 39, 12, 189]     # utils.py:156-159
+    assert U.text_ids_norm([5, 6, 7], 5) == [5, 6, 7, 2, 2] and U.text_ids_norm(list(range(9)), 4) == [0, 1, 2, 3]
+    f = np.ones((3, 4)); assert U.feat_reshape(f, 5).shape == (5, 4) and U.feat_reshape(f, 5)[3:].sum() == 0 and U.feat_reshape(f, 2).shape == (2, 4)
+    x, y = U.synthetic_batch([400, 80, 1], 8, True, True)
+    assert x["x_data"].shape == (8, 400, 80, 1) and x["x_data"].dtype == np.float32 and 0 <= x["x_data"].min() and x["x_data"].max() < 1
+    assert x["x_ctc_label"].shape == (8, 72) and x["x_ctc_label"].dtype == np.float32          # float labels, utils.py:107
+    assert x["x_ctc_in_len"].shape == (8, 1) and (x["x_ctc_in_len"] == 39).all() and x["x_ctc_out_len"].max() <= 16
+    assert (x["x_ctc_label"][0, int(x["x_ctc_out_len"][0, 0]):] == 2).all() and x["x_ctc_label"].max() <= 998
+    assert y["y_accent"].shape == (8, 8) and (y["y_accent"].sum(1) == 1).all() and y["y_ctc_loss"].shape == (8,)
+    from aesrc2020_amd.model import SARNetModel
+    SARNetModel._check_ctc_feasible(x["x_ctc_label"], x["x_ctc_in_len"].ravel(), x["x_ctc_out_len"].ravel())
+    with pytest.raises(ValueError, match="Not enough time"):
+        SARNetModel._check_ctc_feasible(np.full((1, 8), 3.0, np.float32), np.array([10]), np.array([8]))
+
+
+def test_callbacks():
+    from aesrc2020_amd.callbacks import ReduceLROnPlateau, EarlyStopping, CSVLogger, CallbackList
+
+    class FakeStore:
+        lr = 0.01
+        def get_lr(self): return self.lr
+        def set_lr(self, v): self.lr = v
+
+    class FakeModel:
+        store = FakeStore(); stop_training = False
+    m = FakeModel()
+    import tempfile
+    path = os.path.join(tempfile.mkdtemp(), "log.csv")
+    cbs = CallbackList([ReduceLROnPlateau(factor=0.3, patience=2, min_lr=1e-5, monitor="val_y_accent_acc", mode="max", min_delta=0.001),
+                        EarlyStopping(patience=3, monitor="val_y_accent_acc", mode="max", min_delta=0.001), CSVLogger(path)], m)
+    accs = [0.5, 0.6, 0.6, 0.6, 0.6, 0.6]
+    for e, a in enumerate(accs):
+        cbs.on_epoch_end(e, {"val_y_accent_acc": a, "loss": 1.0})
+    assert abs(m.store.lr - 0.0009) < 1e-12 and m.stop_training           # x0.3 after every 2 flat epochs (e3, e5); stop flagged at e4
+    assert len(open(path).read().strip().splitlines()) == 1 + len(accs)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    from aesrc2020_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    n = 1000
+    flat = torch.full((n,), float(rank + 1)); flat[:10] = torch.arange(10.0) * (rank + 1)
+    bounds = parallel.bucket_bounds(n, 300)
+    parallel.allreduce_flat(flat, bounds)
+    params = torch.full((7,), float(rank)); parallel.broadcast_flat(params, 0)
+    batch = {"x": np.arange(8 * 3).reshape(8, 3), "y": np.arange(8)}
+    sh = parallel.shard_batch(batch, r, w)
+    q.put((rank, flat.numpy().copy(), params.numpy().copy(), sh["y"].tolist(), bounds))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = 29000 + os.getpid() % 2000
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    for rank, flat, params, ys, bounds in res:
+        assert bounds == [(300, 1000), (0, 300)]                            # tail bucket (heads/GRU) first, conv trunk last
+        assert np.all(flat[10:] == 3.0) and np.allclose(flat[:10], np.arange(10.0) * 3)   # sum over ranks 1+2; Adam applies 1/world
+        assert np.all(params == 0.0)                                        # rank-0 weights everywhere
+        assert ys == list(range(rank * 4, rank * 4 + 4))                    # contiguous slices like multi_gpu_model
+    from aesrc2020_amd.parallel import bucket_bounds
+    assert bucket_bounds(10, 0) == [(0, 10)] and bucket_bounds(10, 10) == [(0, 10)]
