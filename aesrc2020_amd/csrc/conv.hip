@@ -11,328 +11,6 @@
 
 namespace {
 
-struct ConvP {
-    const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
-    float* y;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk;
-};
-
-constexpr int CK = 16;  // k-tile
-
-// ------------------------------------------------------------------ forward
-template <int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
-    constexpr int BMt = 32 * WM, BNt = 32 * WN, NT = 64 * WM * WN;
-    constexpr int NA = (BMt * 4 + NT - 1) / NT;   // float4 per thread for the A tile
-    constexpr int NB = (BNt * 4 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float As[CK][BMt + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[CK][BNt + 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const long M = (long)p.B * p.Ho * p.Wo;
-    const int K = p.KH * p.KW * p.Cin;
-    const long m0 = (long)blockIdx.x * BMt;
-    const int n0 = blockIdx.y * BNt;
-
-    // per-thread A rows (fixed across the k loop)
-    int an[NA], ah[NA], aw[NA];
-    const int kq = (tid & 3) * 4;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int q = tid + i * NT;
-        const long m = m0 + (q >> 2);
-        if (q < BMt * 4 && m < M) {
-            const int wo = (int)(m % p.Wo); const long t = m / p.Wo;
-            const int ho = (int)(t % p.Ho); an[i] = (int)(t / p.Ho);
-            ah[i] = ho * p.stride - p.pt; aw[i] = wo * p.stride - p.pl;
-        } else {
-            an[i] = -1; ah[i] = 0; aw[i] = 0;
-        }
-    }
-    float4 ra[NA], rb[NB];
-    auto load = [&](int kt) {
-        const int k0 = kt * CK;
-        const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin + kq;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
-        if (p.scale) { sc = *reinterpret_cast<const float4*>(p.scale + ci); sh = *reinterpret_cast<const float4*>(p.shift + ci); }
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            float4 v = make_float4(0, 0, 0, 0);
-            const int hi = ah[i] + kh, wi = aw[i] + kw;
-            if (an[i] >= 0 && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
-                v = *reinterpret_cast<const float4*>(p.x + (((long)an[i] * p.H + hi) * p.W + wi) * p.Cin + ci);
-                if (p.scale) {
-                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * NT;
-            const int k = q / (BNt / 4), n4 = (q % (BNt / 4)) * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (q < BNt * 4 && n0 + n4 < p.Cout) v = *reinterpret_cast<const float4*>(p.w + (long)(k0 + k) * p.Cout + n0 + n4);
-            rb[i] = v;
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int q = tid + i * NT;
-            if (q < BMt * 4) {
-                const int r = q >> 2;
-                As[kq + 0][r] = ra[i].x; As[kq + 1][r] = ra[i].y; As[kq + 2][r] = ra[i].z; As[kq + 3][r] = ra[i].w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * NT;
-            if (q < BNt * 4) *reinterpret_cast<float4*>(&Bs[q / (BNt / 4)][(q % (BNt / 4)) * 4]) = rb[i];
-        }
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // split-K: slice z owns k-tiles [kt0, kt1); small-M layers (stages 2-3) need it to fill 256 CUs
-    const int nkt_all = K / CK, per = (nkt_all + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
-    if (kt0 < nkt) load(kt0);
-    for (int kt = kt0; kt < nkt; ++kt) {
-        store();
-        __syncthreads();
-        if (kt + 1 < nkt) load(kt + 1);
-#pragma unroll
-        for (int k = 0; k < CK; k += 2) {
-            const float a = As[k + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[k + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cout) return;
-    const bool lead = blockIdx.z == 0;
-    const float bv = (p.bias && lead) ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        float v = acc[r] + bv;
-        if (p.res && lead) v += p.res[row * p.Cout + col];
-        if (p.splitk > 1) atomicAdd(p.y + row * p.Cout + col, v);       // y was zeroed by the launcher
-        else p.y[row * p.Cout + col] = v;
-    }
-}
-
-// ------------------------------------------------------------------ dgrad
-struct DgradP {
-    const float* dy; const float* w; float* dx;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, accumulate, splitk;
-};
-
-template <int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
-    constexpr int BMt = 32 * WM, BNt = 32 * WN, NT = 64 * WM * WN;
-    constexpr int NA = (BMt * 4 + NT - 1) / NT;
-    constexpr int NB = (BNt * 4 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float As[CK][BMt + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[CK][BNt + 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const long M = (long)p.B * p.H * p.W;           // input pixels
-    const int K = p.KH * p.KW * p.Cout;
-    const long m0 = (long)blockIdx.x * BMt;
-    const int n0 = blockIdx.y * BNt;                // ci tile
-    int an[NA], ah[NA], aw[NA];
-    const int kq = (tid & 3) * 4;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int q = tid + i * NT;
-        const long m = m0 + (q >> 2);
-        if (q < BMt * 4 && m < M) {
-            const int w_ = (int)(m % p.W); const long t = m / p.W;
-            an[i] = (int)(t / p.H); ah[i] = (int)(t % p.H) + p.pt; aw[i] = w_ + p.pl;
-        } else { an[i] = -1; ah[i] = 0; aw[i] = 0; }
-    }
-    float4 ra[NA], rb[NB];
-    auto load = [&](int kt) {
-        const int k0 = kt * CK;
-        const int tap = k0 / p.Cout, co = k0 - tap * p.Cout + kq;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            float4 v = make_float4(0, 0, 0, 0);
-            const int hn = ah[i] - kh, wn_ = aw[i] - kw;
-            if (an[i] >= 0 && hn >= 0 && wn_ >= 0 && (hn % p.stride) == 0 && (wn_ % p.stride) == 0) {
-                const int ho = hn / p.stride, wo = wn_ / p.stride;
-                if (ho < p.Ho && wo < p.Wo)
-                    v = *reinterpret_cast<const float4*>(p.dy + (((long)an[i] * p.Ho + ho) * p.Wo + wo) * p.Cout + co);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {   // B[k=co][n=ci] = w[tap][ci][co]  (k contiguous)
-            const int q = tid + i * NT;
-            const int n = q >> 2, kk = (q & 3) * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (q < BNt * 4 && n0 + n < p.Cin)
-                v = *reinterpret_cast<const float4*>(p.w + ((long)tap * p.Cin + n0 + n) * p.Cout + (k0 - tap * p.Cout) + kk);
-            rb[i] = v;
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int q = tid + i * NT;
-            if (q < BMt * 4) {
-                const int r = q >> 2;
-                As[kq + 0][r] = ra[i].x; As[kq + 1][r] = ra[i].y; As[kq + 2][r] = ra[i].z; As[kq + 3][r] = ra[i].w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * NT;
-            if (q < BNt * 4) {
-                const int n = q >> 2, kk = (q & 3) * 4;
-                Bs[kk + 0][n] = rb[i].x; Bs[kk + 1][n] = rb[i].y; Bs[kk + 2][n] = rb[i].z; Bs[kk + 3][n] = rb[i].w;
-            }
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int nkt_all = K / CK, per = (nkt_all + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
-    if (kt0 < nkt) load(kt0);
-    for (int kt = kt0; kt < nkt; ++kt) {
-        store();
-        __syncthreads();
-        if (kt + 1 < nkt) load(kt + 1);
-#pragma unroll
-        for (int k = 0; k < CK; k += 2) {
-            const float a = As[k + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[k + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cin) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= M) continue;
-        float* d = p.dx + row * p.Cin + col;
-        if (p.splitk > 1) atomicAdd(d, acc[r]);                         // dx zeroed by the launcher unless accumulating
-        else *d = p.accumulate ? (*d + acc[r]) : acc[r];
-    }
-}
-
-// ------------------------------------------------------------------ wgrad
-struct WgradP {
-    const float* x; const float* dy; const float* scale; const float* shift; float* dw;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, rows_per_slice;
-};
-
-template <int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
-    constexpr int BMt = 32 * WM, BNt = 32 * WN, NT = 64 * WM * WN;
-    constexpr int NA = (BMt * 4 + NT - 1) / NT;
-    constexpr int NB = (BNt * 4 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float As[CK][BMt + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[CK][BNt + 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const long R = (long)p.B * p.Ho * p.Wo;
-    const int Mp = p.KH * p.KW * p.Cin;
-    const int m0 = blockIdx.x * BMt, n0 = blockIdx.y * BNt;
-    const long r_begin = (long)blockIdx.z * p.rows_per_slice;
-    const long r_end = min(R, r_begin + p.rows_per_slice);
-    // per-thread A columns (m' = (tap, ci)) are fixed; rows move
-    int a_kh[NA], a_kw[NA], a_ci[NA], a_r[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int q = tid + i * NT;
-        const int mp = m0 + (q % (BMt / 4)) * 4;
-        a_r[i] = q / (BMt / 4);
-        if (q < BMt * 4 && mp < Mp) {
-            const int tap = mp / p.Cin; a_ci[i] = mp - tap * p.Cin;
-            a_kh[i] = tap / p.KW; a_kw[i] = tap - a_kh[i] * p.KW;
-        } else { a_ci[i] = -1; a_kh[i] = 0; a_kw[i] = 0; }
-    }
-    float4 ra[NA], rb[NB];
-    auto load = [&](long r0) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            float4 v = make_float4(0, 0, 0, 0);
-            const long m = r0 + a_r[i];
-            if (a_ci[i] >= 0 && m < r_end) {
-                const int wo = (int)(m % p.Wo); const long t = m / p.Wo;
-                const int ho = (int)(t % p.Ho); const int n = (int)(t / p.Ho);
-                const int hi = ho * p.stride - p.pt + a_kh[i], wi = wo * p.stride - p.pl + a_kw[i];
-                if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
-                    v = *reinterpret_cast<const float4*>(p.x + (((long)n * p.H + hi) * p.W + wi) * p.Cin + a_ci[i]);
-                    if (p.scale) {
-                        const float4 sc = *reinterpret_cast<const float4*>(p.scale + a_ci[i]);
-                        const float4 sh = *reinterpret_cast<const float4*>(p.shift + a_ci[i]);
-                        v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                        v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-                    }
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * NT;
-            const int r = q / (BNt / 4), n4 = (q % (BNt / 4)) * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (q < BNt * 4 && r0 + r < r_end && n0 + n4 < p.Cout)
-                v = *reinterpret_cast<const float4*>(p.dy + (r0 + r) * p.Cout + n0 + n4);
-            rb[i] = v;
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int q = tid + i * NT;
-            if (q < BMt * 4) *reinterpret_cast<float4*>(&As[q / (BMt / 4)][(q % (BMt / 4)) * 4]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int q = tid + i * NT;
-            if (q < BNt * 4) *reinterpret_cast<float4*>(&Bs[q / (BNt / 4)][(q % (BNt / 4)) * 4]) = rb[i];
-        }
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (r_begin < r_end) load(r_begin);
-    for (long r0 = r_begin; r0 < r_end; r0 += CK) {
-        store();
-        __syncthreads();
-        if (r0 + CK < r_end) load(r0 + CK);
-#pragma unroll
-        for (int k = 0; k < CK; k += 2) {
-            const float a = As[k + (lane >> 5)][wm * 32 + (lane & 31)];
-            const float b = Bs[k + (lane >> 5)][wn * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cout) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < Mp) atomicAdd(p.dw + (long)row * p.Cout + col, acc[r]);
-    }
-}
-
 // ------------------------------------------------------------------ stem 7x7/2, Cin = 1
 constexpr int ST_TH = 4, ST_TW = 16;                 // output tile 4 x 16
 constexpr int ST_PH = (ST_TH - 1) * 2 + 7, ST_PW = (ST_TW - 1) * 2 + 7;   // 13 x 37 input patch
@@ -541,85 +219,6 @@ __global__ void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool
 }
 
 }  // namespace
-
-static bool conv_args_ok(int Cin, int Cout) { return (Cin % 16 == 0) && (Cout % 16 == 0); }
-
-// Blocks are 256 threads with ~9-11 KB of LDS: aim for >= 4 blocks per CU (1024 blocks) so that global-load latency of
-// one block's k-tile hides behind the MFMA phase of another; each slice keeps >= 4 k-tiles.
-static int pick_conv_splitk(int tiles, int nkt) {
-    static const bool off = getenv("SAR_NO_SPLITK") != nullptr;      // debugging aid
-    if (off || tiles >= 768) return 1;
-    int s = (1024 + tiles - 1) / tiles;
-    if (s > nkt / 4) s = nkt / 4;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
-}
-
-extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale,
-                                  const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
-                                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
-                                  hipStream_t stream) {
-    if (!x || !w || !y || !conv_args_ok(Cin, Cout) || (scale && !shift)) return SAR_EINVAL;
-    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1};
-    const long M = (long)B * Ho * Wo;
-    const int tiles = Cout <= 32 ? cdiv(M, 128) * cdiv(Cout, 32) : cdiv(M, 64) * cdiv(Cout, 64);
-    p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / CK);
-    if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
-    if (Cout <= 32) {
-        dim3 grid(cdiv(M, 128), cdiv(Cout, 32), p.splitk);
-        hipLaunchKernelGGL((conv_fwd_kernel<4, 1>), grid, dim3(256), 0, stream, p);
-    } else {
-        dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
-        hipLaunchKernelGGL((conv_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, p);
-    }
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
-}
-
-extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho,
-                                    int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
-                                    int accumulate, hipStream_t stream) {
-    if (!dy || !w || !dx || !conv_args_ok(Cin, Cout)) return SAR_EINVAL;
-    DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, 1};
-    const long M = (long)B * H * W;
-    const int tiles = Cin <= 32 ? cdiv(M, 128) * cdiv(Cin, 32) : cdiv(M, 64) * cdiv(Cin, 64);
-    p.splitk = pick_conv_splitk(tiles, KH * KW * Cout / CK);
-    if (p.splitk > 1 && !accumulate && sar_zero_async(dx, sizeof(float) * M * Cin, stream) != hipSuccess) return SAR_ELAUNCH;
-    if (Cin <= 32) {
-        dim3 grid(cdiv(M, 128), cdiv(Cin, 32), p.splitk);
-        hipLaunchKernelGGL((conv_dgrad_kernel<4, 1>), grid, dim3(256), 0, stream, p);
-    } else {
-        dim3 grid(cdiv(M, 64), cdiv(Cin, 64), p.splitk);
-        hipLaunchKernelGGL((conv_dgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p);
-    }
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
-}
-
-extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift,
-                                    float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
-                                    int stride, int pad_top, int pad_left, hipStream_t stream) {
-    if (!x || !dy || !dw || !conv_args_ok(Cin, Cout) || (scale && !shift)) return SAR_EINVAL;
-    const long R = (long)B * Ho * Wo;
-    const int Mp = KH * KW * Cin;
-    // split the reduction so the grid fills 256 CUs a few times over
-    const int tiles = cdiv(Mp, 64) * cdiv(Cout, Cout <= 32 ? 32 : 64);
-    int splits = (int)((1024 + tiles - 1) / tiles);
-    int rows = (int)((R + splits - 1) / splits);
-    rows = ((rows + CK - 1) / CK) * CK;
-    if (rows < 256) rows = 256;
-    splits = cdiv(R, rows);
-    WgradP p{x, dy, scale, shift, dw, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, rows};
-    if (Cout <= 32) {
-        dim3 grid(cdiv(Mp, 64), cdiv(Cout, 32), splits);
-        hipLaunchKernelGGL((conv_wgrad_kernel<2, 1>), grid, dim3(128), 0, stream, p);
-    } else {
-        dim3 grid(cdiv(Mp, 64), cdiv(Cout, 64), splits);
-        hipLaunchKernelGGL((conv_wgrad_kernel<2, 2>), grid, dim3(256), 0, stream, p);
-    }
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
-}
 
 extern "C" int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H,
                                         int W, int Ho, int Wo, int C0, int pad_top, int pad_left, hipStream_t stream) {

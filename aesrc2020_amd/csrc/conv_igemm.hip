@@ -1,0 +1,483 @@
+// ResNet 3x3 / 1x1 convolutions of SAR-Net on gfx950: NHWC fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.
+//   fwd  : y = conv(P(x), w) + bias [+ residual]          P(x) = relu(x*scale[c]+shift[c]): the preceding
+//   dgrad: dP = conv_transpose(dy, w)                            BatchNorm+ReLU folded into the A-operand path;
+//   wgrad: dw += P(x)^T (*) dy   (split over output rows,        zero padding is applied AFTER P, as Keras does
+//                                  fp32 atomics into the flat gradient buffer)
+// Reference: resnet.py:22-125 (_bn_relu / _bn_relu_conv / basic_block / _shortcut), TF-SAME padding per SURVEY App. A.
+//
+// Structure (v3).  Block tile (32*WM*TM) x (32*WN) x BK, WM x WN waves, TM stacked 32x32 accumulators per wave.
+// Lessons from the v1/v2 ISA + ablation:
+//  * the im2col address of a row is  base[row] + tapoff(tap)  with a per-row 32-bit base and a per-row bitmask of valid
+//    taps, both computed ONCE before the k loop; the prefetch of the next tile is then ~6 instructions per 16-byte load
+//    (v1/v2 spent ~100 instructions and 4 branches per load on runtime div/mod and bounds tests, serialised in front of
+//    the MFMA phase of the same wave);
+//  * loads are branch-free (invalid lanes read offset 0 and are zeroed by the mask at LDS-store time) and the BN+ReLU
+//    prologue runs at LDS-store time, so nothing touches the in-flight registers before the MFMA phase;
+//  * the MFMA phase prefetches the LDS operands of step k+1 before issuing the MFMAs of step k;
+//  * wgrad decodes its moving rows with a precomputed magic-number division.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct ConvP {
+    const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
+    float* y;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk;
+};
+struct DgradP {
+    const float* dy; const float* w; float* dx;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, accumulate, splitk;
+};
+struct WgradP {
+    const float* x; const float* dy; const float* scale; const float* shift; float* dw;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, rows_per_slice;
+    unsigned magic_wo, magic_ho;        // ceil(2^32 / Wo), ceil(2^32 / Ho): q = umulhi(m, magic) exact for m < 2^32 / d
+};
+
+template <int WM, int WN, int TM, int BK>
+struct Tile {
+    static constexpr int BMt = 32 * WM * TM, BNt = 32 * WN, NT = 64 * WM * WN;
+    static constexpr int LDA = BMt + 1;          // odd stride: transposed b32 stores spread over banks
+    static constexpr int LDB = BNt + 4;          // keeps float4 stores 16-B aligned
+    static constexpr int KQ = BK / 4;            // float4 per k-row segment
+};
+
+__device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
+    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+    return v;
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// MFMA over one staged k-tile with the LDS operands of step k+1 prefetched ahead of the MFMAs of step k.
+template <int WM, int WN, int TM, int BK, int LDA, int LDB>
+__device__ __forceinline__ void mma_tile(f32x16 (&acc)[TM], const float (*As)[LDA], const float (*Bs)[LDB], int wm, int wn, int lane) {
+    const int kr = lane >> 5, c = lane & 31;
+    float a[TM], b, an[TM], bn;
+    b = Bs[kr][wn * 32 + c];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) a[tm] = As[kr][(wm * TM + tm) * 32 + c];
+#pragma unroll
+    for (int k = 0; k < BK; k += 2) {
+        if (k + 2 < BK) {
+            bn = Bs[k + 2 + kr][wn * 32 + c];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) an[tm] = As[k + 2 + kr][(wm * TM + tm) * 32 + c];
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b, acc[tm], 0, 0, 0);
+        if (k + 2 < BK) {
+            b = bn;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm] = an[tm];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ forward
+template <int WM, int WN, int TM, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
+    using T = Tile<WM, WN, TM, BK>;
+    constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
+    constexpr int NA = (BMt * KQ + NT - 1) / NT, NB = (BK * BNt / 4 + NT - 1) / NT;
+    static_assert(NT % KQ == 0 && (BMt * KQ) % NT == 0, "A-tile mapping");
+    __shared__ float As[BK][T::LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][T::LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned M = (unsigned)(p.B * p.Ho * p.Wo);
+    const int K = p.KH * p.KW * p.Cin;
+    const unsigned m0 = blockIdx.x * BMt;
+    const int n0 = blockIdx.y * BNt;
+    const int kq = (tid % KQ) * 4;                 // channel sub-offset of this thread's float4 (fixed)
+    // per-row im2col state: element offset of tap (0,0) (may be "negative": only used when valid) + valid-tap bits
+    int abase[NA]; unsigned avalid[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const unsigned m = m0 + (tid + i * NT) / KQ;
+        abase[i] = 0; avalid[i] = 0;
+        if (m < M) {
+            const unsigned wo = m % (unsigned)p.Wo, t = m / (unsigned)p.Wo;
+            const unsigned ho = t % (unsigned)p.Ho, n = t / (unsigned)p.Ho;
+            const int h0 = (int)ho * p.stride - p.pt, w0 = (int)wo * p.stride - p.pl;
+            abase[i] = (((int)n * p.H + h0) * p.W + w0) * p.Cin + kq;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if (h0 + kh >= 0 && h0 + kh < p.H && w0 + kw >= 0 && w0 + kw < p.W) avalid[i] |= 1u << (kh * p.KW + kw);
+        }
+    }
+    // B tile: rows k0+k of w (K, Cout), float4 along n
+    constexpr int BROWS = NT / (BNt / 4);
+    const int bk_row = tid / (BNt / 4), bn4 = (tid % (BNt / 4)) * 4;      // the i-th pass adds i * BROWS rows
+    const bool bcol_ok = n0 + bn4 < p.Cout;
+    float4 ra[NA], rb[NB];
+    float4 sc = make_float4(1, 1, 1, 1), sh = zero4();
+    unsigned vmask = 0;
+    auto load = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int tapoff = (kh * p.W + kw) * p.Cin + ci0;
+        if (p.scale) { sc = *reinterpret_cast<const float4*>(p.scale + ci0 + kq); sh = *reinterpret_cast<const float4*>(p.shift + ci0 + kq); }
+        vmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned ok = (avalid[i] >> tap) & 1u;
+            const int off = ok ? abase[i] + tapoff : 0;              // branch-free: invalid lanes read element 0
+            ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+            vmask |= ok << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = bk_row + i * BROWS;
+            const int off = (bcol_ok && k < BK) ? (k0 + k) * p.Cout + n0 + bn4 : 0;
+            rb[i] = *reinterpret_cast<const float4*>(p.w + off);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = (tid + i * NT) / KQ;
+            float4 v = zero4();
+            if ((vmask >> i) & 1u) v = p.scale ? bn_relu4(ra[i], sc, sh) : ra[i];      // padding stays exactly zero
+            As[kq + 0][r] = v.x; As[kq + 1][r] = v.y; As[kq + 2][r] = v.z; As[kq + 3][r] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = bk_row + i * BROWS;
+            if (k < BK) *reinterpret_cast<float4*>(&Bs[k][bn4]) = bcol_ok ? rb[i] : zero4();
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    // split-K: slice z owns k-tiles [kt0, nkt)
+    const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
+    if (kt0 < nkt) load(kt0);
+    for (int kt = kt0; kt < nkt; ++kt) {
+        store();
+        __syncthreads();
+        if (kt + 1 < nkt) load(kt + 1);
+        mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As, Bs, wm, wn, lane);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.Cout) return;
+    const bool lead = blockIdx.z == 0;
+    const float bv = (p.bias && lead) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= M) continue;
+            const long o = (long)row * p.Cout + col;
+            float v = acc[tm][r] + bv;
+            if (p.res && lead) v += p.res[o];
+            if (p.splitk > 1) atomicAdd(p.y + o, v);       // y zeroed by the launcher
+            else p.y[o] = v;
+        }
+}
+
+// ------------------------------------------------------------------ dgrad
+template <int WM, int WN, int TM, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
+    using T = Tile<WM, WN, TM, BK>;
+    constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
+    constexpr int NA = (BMt * KQ + NT - 1) / NT, NB = (BNt * KQ + NT - 1) / NT;
+    static_assert(NT % KQ == 0 && (BMt * KQ) % NT == 0, "A-tile mapping");
+    __shared__ float As[BK][T::LDA];
+    __shared__ float Bs[BK][T::LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned M = (unsigned)(p.B * p.H * p.W);           // input pixels
+    const int K = p.KH * p.KW * p.Cout;
+    const unsigned m0 = blockIdx.x * BMt;
+    const int n0 = blockIdx.y * BNt;                // ci tile
+    const int kq = (tid % KQ) * 4;
+    // dy element offset for tap (0,0) per row; for stride 2 the tap offset depends on the row's parity (ph, pw)
+    int abase[NA]; unsigned avalid[NA]; int aph[NA], apw[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const unsigned m = m0 + (tid + i * NT) / KQ;
+        abase[i] = 0; avalid[i] = 0; aph[i] = 0; apw[i] = 0;
+        if (m < M) {
+            const unsigned w_ = m % (unsigned)p.W, t = m / (unsigned)p.W;
+            const unsigned h = t % (unsigned)p.H, n = t / (unsigned)p.H;
+            const int hq = (int)h + p.pt, wq = (int)w_ + p.pl;
+            if (p.stride == 1) {
+                abase[i] = (((int)n * p.Ho + hq) * p.Wo + wq) * p.Cout + kq;
+            } else {
+                aph[i] = hq & 1; apw[i] = wq & 1;
+                abase[i] = (((int)n * p.Ho + (hq >> 1)) * p.Wo + (wq >> 1)) * p.Cout + kq;
+            }
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw) {
+                    const int hn = hq - kh, wn_ = wq - kw;
+                    if (hn >= 0 && wn_ >= 0 && (hn % p.stride) == 0 && (wn_ % p.stride) == 0 && hn / p.stride < p.Ho && wn_ / p.stride < p.Wo)
+                        avalid[i] |= 1u << (kh * p.KW + kw);
+                }
+        }
+    }
+    // B[k=co][n=ci] = w[tap][ci][co] (k contiguous in memory): thread reads float4 along co for its ci rows
+    int bn_[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) bn_[i] = (tid + i * NT) / KQ;
+    float4 ra[NA], rb[NB];
+    unsigned vmask = 0;
+    auto load = [&](int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        vmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned ok = (avalid[i] >> tap) & 1u;
+            // stride 1: ho = hq - kh ; stride 2 (valid taps only): ho = (hq>>1) - ((kh - ph) >> 1)
+            const int dh = p.stride == 1 ? kh : ((kh - aph[i]) >> 1), dw = p.stride == 1 ? kw : ((kw - apw[i]) >> 1);
+            const int off = ok ? abase[i] - (dh * p.Wo + dw) * p.Cout + co0 : 0;
+            ra[i] = *reinterpret_cast<const float4*>(p.dy + off);
+            vmask |= ok << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const bool ok = bn_[i] < BNt && n0 + bn_[i] < p.Cin;
+            const int off = ok ? (tap * p.Cin + n0 + bn_[i]) * p.Cout + co0 + kq : 0;
+            rb[i] = *reinterpret_cast<const float4*>(p.w + off);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = (tid + i * NT) / KQ;
+            const float4 v = ((vmask >> i) & 1u) ? ra[i] : zero4();
+            As[kq + 0][r] = v.x; As[kq + 1][r] = v.y; As[kq + 2][r] = v.z; As[kq + 3][r] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (bn_[i] < BNt) {
+                const float4 v = (n0 + bn_[i] < p.Cin) ? rb[i] : zero4();
+                Bs[kq + 0][bn_[i]] = v.x; Bs[kq + 1][bn_[i]] = v.y; Bs[kq + 2][bn_[i]] = v.z; Bs[kq + 3][bn_[i]] = v.w;
+            }
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
+    if (kt0 < nkt) load(kt0);
+    for (int kt = kt0; kt < nkt; ++kt) {
+        store();
+        __syncthreads();
+        if (kt + 1 < nkt) load(kt + 1);
+        mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As, Bs, wm, wn, lane);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.Cin) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= M) continue;
+            float* d = p.dx + (long)row * p.Cin + col;
+            if (p.splitk > 1) atomicAdd(d, acc[tm][r]);                 // dx zeroed by the launcher unless accumulating
+            else *d = p.accumulate ? (*d + acc[tm][r]) : acc[tm][r];
+        }
+}
+
+// ------------------------------------------------------------------ wgrad
+template <int WM, int WN, int TM, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
+    using T = Tile<WM, WN, TM, BK>;
+    constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT;
+    constexpr int LDAw = BMt + 4;                                     // float4 stores along m'
+    constexpr int NA = (BK * BMt / 4 + NT - 1) / NT, NB = (BK * BNt / 4 + NT - 1) / NT;
+    constexpr int AROWS = NT / (BMt / 4), BROWS = NT / (BNt / 4);
+    static_assert(NT % (BMt / 4) == 0 && NT % (BNt / 4) == 0, "tile mapping");
+    __shared__ __attribute__((aligned(16))) float As[BK][LDAw];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][T::LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned R = (unsigned)(p.B * p.Ho * p.Wo);
+    const int Mp = p.KH * p.KW * p.Cin;
+    const int m0 = blockIdx.x * BMt, n0 = blockIdx.y * BNt;
+    const unsigned r_begin = blockIdx.z * (unsigned)p.rows_per_slice;
+    const unsigned r_end = min(R, r_begin + (unsigned)p.rows_per_slice);
+    // per-thread A column (m' = (tap, ci)) is fixed; rows move with the reduction
+    const int mp = m0 + (tid % (BMt / 4)) * 4;
+    const int a_row = tid / (BMt / 4);
+    int a_dh = 0, a_dw = 0, a_ci = -1, a_tapoff = 0;
+    if (mp < Mp) {
+        const int tap = mp / p.Cin; a_ci = mp - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        a_dh = kh - p.pt; a_dw = kw - p.pl;
+        a_tapoff = (a_dh * p.W + a_dw) * p.Cin + a_ci;
+    }
+    float4 asc = make_float4(1, 1, 1, 1), ash = zero4();
+    if (p.scale && a_ci >= 0) { asc = *reinterpret_cast<const float4*>(p.scale + a_ci); ash = *reinterpret_cast<const float4*>(p.shift + a_ci); }
+    const int b_row = tid / (BNt / 4), bn4 = (tid % (BNt / 4)) * 4;
+    const bool bcol_ok = n0 + bn4 < p.Cout;
+    float4 ra[NA], rb[NB];
+    unsigned vmask = 0;
+    auto load = [&](unsigned r0) {
+        vmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned m = r0 + a_row + i * AROWS;
+            const unsigned t = p.Wo == 1 ? m : __umulhi(m, p.magic_wo), wo = m - t * (unsigned)p.Wo;       // m / Wo, m % Wo
+            const unsigned n = p.Ho == 1 ? t : __umulhi(t, p.magic_ho), ho = t - n * (unsigned)p.Ho;
+            const int hi = (int)ho * p.stride + a_dh, wi = (int)wo * p.stride + a_dw;
+            const unsigned ok = (a_ci >= 0 && a_row + i * AROWS < BK && m < r_end && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) ? 1u : 0u;
+            const int off = ok ? (((int)n * p.H + (int)ho * p.stride) * p.W + (int)wo * p.stride) * p.Cin + a_tapoff : 0;
+            ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+            vmask |= ok << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const unsigned m = r0 + b_row + i * BROWS;
+            const bool ok = bcol_ok && b_row + i * BROWS < BK && m < r_end;
+            const long off = ok ? (long)m * p.Cout + n0 + bn4 : 0;
+            rb[i] = *reinterpret_cast<const float4*>(p.dy + off);
+            vmask |= (ok ? 1u : 0u) << (16 + i);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = a_row + i * AROWS;
+            if (r < BK) {
+                float4 v = zero4();
+                if ((vmask >> i) & 1u) v = p.scale ? bn_relu4(ra[i], asc, ash) : ra[i];
+                *reinterpret_cast<float4*>(&As[r][(tid % (BMt / 4)) * 4]) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = b_row + i * BROWS;
+            if (r < BK) *reinterpret_cast<float4*>(&Bs[r][bn4]) = ((vmask >> (16 + i)) & 1u) ? rb[i] : zero4();
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    if (r_begin < r_end) load(r_begin);
+    for (unsigned r0 = r_begin; r0 < r_end; r0 += BK) {
+        store();
+        __syncthreads();
+        if (r0 + BK < r_end) load(r0 + BK);
+        mma_tile<WM, WN, TM, BK, LDAw, T::LDB>(acc, As, Bs, wm, wn, lane);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.Cout) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < Mp) atomicAdd(p.dw + (long)row * p.Cout + col, acc[tm][r]);
+        }
+}
+
+}  // namespace
+
+// 32-bit element offsets and the magic-number division bound the supported sizes (far above the SAR-Net shapes).
+static bool conv_args_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
+    const long in_e = (long)B * H * W * Cin, out_e = (long)B * Ho * Wo * Cout;
+    return (Cin % 16 == 0) && (Cout % 16 == 0) && KH * KW <= 16 && in_e < (1L << 31) && out_e < (1L << 31) &&
+           (long)KH * KW * Cin * Cout < (1L << 31);
+}
+
+// Aim for >= ~3 resident blocks per CU so one block's global-load latency hides behind another's MFMA phase, but keep the
+// atomic traffic of the split-K epilogue low: at most 4 slices, each with >= 4 k-tiles.
+static int pick_conv_splitk(int tiles, int nkt) {
+    static const bool off = getenv("SAR_NO_SPLITK") != nullptr;      // debugging aid
+    static const int cap = getenv("SAR_SPLITK_CAP") ? atoi(getenv("SAR_SPLITK_CAP")) : 4;
+    if (off || tiles >= 512) return 1;
+    int s = (768 + tiles - 1) / tiles;
+    if (s > nkt / 4) s = nkt / 4;
+    if (s > cap) s = cap;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale,
+                                  const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
+                                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                  hipStream_t stream) {
+    if (!x || !w || !y || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
+    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1};
+    const long M = (long)B * Ho * Wo;
+    const int bk = (Cin % 32 == 0) ? 32 : 16;
+    const bool narrow = Cout <= 32;
+    const int tiles = cdiv(M, 128) * cdiv(Cout, narrow ? 32 : 64);
+    p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
+    if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
+    dim3 grid(cdiv(M, 128), cdiv(Cout, narrow ? 32 : 64), p.splitk);
+    if (narrow) {
+        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 16>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 16>), grid, dim3(256), 0, stream, p);
+    }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho,
+                                    int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                    int accumulate, hipStream_t stream) {
+    if (!dy || !w || !dx || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || stride < 1 || stride > 2) return SAR_EINVAL;
+    DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, 1};
+    const long M = (long)B * H * W;
+    const int bk = (Cout % 32 == 0) ? 32 : 16;
+    const bool narrow = Cin <= 32;
+    const int tiles = cdiv(M, 128) * cdiv(Cin, narrow ? 32 : 64);
+    p.splitk = pick_conv_splitk(tiles, KH * KW * Cout / bk);
+    if (p.splitk > 1 && !accumulate && sar_zero_async(dx, sizeof(float) * M * Cin, stream) != hipSuccess) return SAR_ELAUNCH;
+    dim3 grid(cdiv(M, 128), cdiv(Cin, narrow ? 32 : 64), p.splitk);
+    if (narrow) {
+        if (bk == 32) hipLaunchKernelGGL((conv_dgrad_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_dgrad_kernel<4, 1, 1, 16>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (bk == 32) hipLaunchKernelGGL((conv_dgrad_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_dgrad_kernel<2, 2, 2, 16>), grid, dim3(256), 0, stream, p);
+    }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift,
+                                    float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                    int stride, int pad_top, int pad_left, hipStream_t stream) {
+    if (!x || !dy || !dw || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
+    const long R = (long)B * Ho * Wo;
+    if (R * (Wo > Ho ? Wo : Ho) >= (1L << 32)) return SAR_EINVAL;          // magic-number division exactness bound
+    const int Mp = KH * KW * Cin;
+    const bool narrow = Cout <= 32;
+    // split the reduction so the grid fills 256 CUs a few times over
+    const int tiles = cdiv(Mp, 128) * cdiv(Cout, narrow ? 32 : 64);
+    int splits = (1024 + tiles - 1) / tiles;
+    long rows = (R + splits - 1) / splits;
+    rows = ((rows + 31) / 32) * 32;
+    if (rows < 128) rows = 128;
+    splits = cdiv(R, rows);
+    WgradP p{x, dy, scale, shift, dw, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, (int)rows,
+             (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
+    dim3 grid(cdiv(Mp, 128), cdiv(Cout, narrow ? 32 : 64), splits);
+    if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}

@@ -1,0 +1,34 @@
+"""Per-stage conv micro-benchmark (B=64, T=400 shapes of res34/F=32): fwd / dgrad / wgrad TFLOP/s via HIP events."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from aesrc2020_amd import _lib as L
+B = 64
+STAGES = [("s0 3x3 32->32", 100, 20, 32, 32, 3, 1), ("s0 3x3 64->32", 100, 20, 64, 32, 3, 1), ("s1 3x3 64->64", 50, 10, 64, 64, 3, 1),
+          ("s1 3x3/2 32->64", 100, 20, 32, 64, 3, 2), ("s2 3x3 128->128", 25, 5, 128, 128, 3, 1), ("s3 3x3 256->256", 13, 3, 256, 256, 3, 1),
+          ("s3 1x1/2 128->256", 25, 5, 128, 256, 1, 2)]
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+def timed(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); ev0.record()
+    for _ in range(iters): fn()
+    ev1.record(); torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / iters
+tot = {"fwd": 0, "dgrad": 0, "wgrad": 0}
+FILTER = sys.argv[1] if len(sys.argv) > 1 else ""
+for name, H, W, ci, co, k, s in STAGES:
+    if FILTER and not name.startswith(FILTER):
+        continue
+    if k == 3:
+        Ho, Wo = -(-H // s), -(-W // s); pt = max((Ho - 1) * s + k - H, 0) // 2; pl = max((Wo - 1) * s + k - W, 0) // 2
+    else:
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1; pt = pl = 0
+    x = torch.randn(B, H, W, ci, device="cuda"); w = torch.randn(k, k, ci, co, device="cuda") * 0.05; b = torch.zeros(co, device="cuda")
+    sc = torch.rand(ci, device="cuda") + 0.5; sh = torch.randn(ci, device="cuda") * 0.1
+    y = torch.empty(B, Ho, Wo, co, device="cuda"); dy = torch.randn(B, Ho, Wo, co, device="cuda"); dx = torch.empty_like(x); dw = torch.zeros_like(w)
+    fl = 2.0 * B * Ho * Wo * co * ci * k * k
+    t_f = timed(lambda: L.call("sar_conv2d_fwd_f32", x, w, b, sc, sh, None, y, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
+    t_d = timed(lambda: L.call("sar_conv2d_dgrad_f32", dy, w, dx, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl, 0))
+    t_w = timed(lambda: L.call("sar_conv2d_wgrad_f32", x, dy, sc, sh, dw, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
+    print("%-20s GF %.2f | fwd %6.1f us %5.1f TF | dgrad %6.1f us %5.1f TF | wgrad %6.1f us %5.1f TF" %
+          (name, fl / 1e9, t_f * 1e6, fl / t_f / 1e12, t_d * 1e6, fl / t_d / 1e12, t_w * 1e6, fl / t_w / 1e12), flush=True)
