@@ -15,98 +15,125 @@ namespace {
 constexpr int ST_TH = 4, ST_TW = 16;                 // output tile 4 x 16
 constexpr int ST_PH = (ST_TH - 1) * 2 + 7, ST_PW = (ST_TW - 1) * 2 + 7;   // 13 x 37 input patch
 
-__device__ __forceinline__ void stem_load_patch(float (*patch)[ST_PW + 1], const float* x, int n, int H, int W,
-                                                int hi0, int wi0) {
+constexpr int ST_PLD = ST_PW + 1;                    // 38: patch row stride
+constexpr int ST_ZSLOT = ST_PH * ST_PLD;             // one zero word after the patch (k = 49 padding / invalid taps)
+
+__device__ __forceinline__ void stem_load_patch_flat(float* patch, const float* x, int n, int H, int W, int hi0, int wi0) {
     for (int i = threadIdx.x; i < ST_PH * ST_PW; i += blockDim.x) {
         const int r = i / ST_PW, c = i - r * ST_PW;
         const int hi = hi0 + r, wi = wi0 + c;
-        patch[r][c] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((long)n * H + hi) * W + wi] : 0.f;
+        patch[r * ST_PLD + c] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((long)n * H + hi) * W + wi] : 0.f;
     }
+    if (threadIdx.x == 0) patch[ST_ZSLOT] = 0.f;
 }
 
-// y[n,ho,wo,c] = sum_{kh,kw} x[n,2ho-pt+kh,2wo-pl+kw] * w[kh,kw,0,c] + b[c];  C0 <= 64, C0 % 4 == 0
+// y[n,ho,wo,c] = sum_{kh,kw} x[n,2ho-pt+kh,2wo-pl+kw] * w[kh,kw,0,c] + b[c];  C0 <= 64, C0 % 4 == 0.
+// GEMM view per block: M = 64 output pixels (4 x 16 tile), N = 64 channels, K = 49 taps padded to 50; the A operand is
+// gathered from the 13 x 37 input patch in LDS, B = the 7x7xC0 kernel in LDS; 4 waves = 2 pixel blocks x 2 channel blocks
+// of v_mfma_f32_32x32x2_f32 (25 MFMAs per wave).
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y, int B,
                                                        int H, int W, int Ho, int Wo, int C0, int pt, int pl) {
-    __shared__ float patch[ST_PH][ST_PW + 1];
-    __shared__ __attribute__((aligned(16))) float ws[49 * 64];
+    __shared__ float patch[ST_ZSLOT + 2];
+    __shared__ float ws[50 * 64];
     const int tiles_w = (Wo + ST_TW - 1) / ST_TW, tiles_h = (Ho + ST_TH - 1) / ST_TH;
     int b = blockIdx.x;
     const int tw = b % tiles_w; b /= tiles_w;
     const int th = b % tiles_h; const int n = b / tiles_h;
-    for (int i = threadIdx.x; i < 49 * C0; i += 256) ws[i] = w[i];
-    stem_load_patch(patch, x, n, H, W, th * ST_TH * 2 - pt, tw * ST_TW * 2 - pl);
+    for (int i = threadIdx.x; i < 50 * 64; i += 256) {
+        const int k = i >> 6, c = i & 63;
+        ws[i] = (k < 49 && c < C0) ? w[k * C0 + c] : 0.f;
+    }
+    stem_load_patch_flat(patch, x, n, H, W, th * ST_TH * 2 - pt, tw * ST_TW * 2 - pl);
     __syncthreads();
-    const int pix = threadIdx.x & 63, cg = threadIdx.x >> 6;      // 4 channel groups, wave-uniform
-    const int cpg = C0 / 4;                                       // channels per group (<= 16)
-    const int pr = pix / ST_TW, pc = pix % ST_TW;
-    float acc[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mb = wave >> 1, nb = wave & 1, kr = lane >> 5, col = lane & 31;
+    if (nb * 32 >= C0) return;                                      // wave-uniform (no barriers below)
+    const int pix = mb * 32 + col;
+    const int pbase = ((pix >> 4) * 2) * ST_PLD + (pix & 15) * 2;
+    f32x16 acc;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-    for (int kh = 0; kh < 7; ++kh)
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int kw = 0; kw < 7; ++kw) {
-            const float xv = patch[pr * 2 + kh][pc * 2 + kw];
-            const float* wp = ws + (kh * 7 + kw) * C0 + cg * cpg;
+    for (int s2 = 0; s2 < 25; ++s2) {
+        constexpr int dummy = 0; (void)dummy;
+        const int k0 = 2 * s2, k1 = 2 * s2 + 1;
+        const int offA = (k0 / 7) * ST_PLD + (k0 % 7);
+        const int offB = (k1 / 7) * ST_PLD + (k1 % 7);
+        const int ia = kr ? (k1 < 49 ? pbase + offB : ST_ZSLOT) : pbase + offA;
+        const float a = patch[ia];
+        const float bv = ws[(k0 + kr) * 64 + nb * 32 + col];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    const int c = nb * 32 + col;
+    if (c >= C0) return;
+    const float bz = bias[c];
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (c < cpg) acc[c] = fmaf(xv, wp[c], acc[c]);
-        }
-    const int ho = th * ST_TH + pr, wo = tw * ST_TW + pc;
-    if (ho < Ho && wo < Wo) {
-        float* dst = y + (((long)n * Ho + ho) * Wo + wo) * C0 + cg * cpg;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c < cpg) dst[c] = acc[c] + bias[cg * cpg + c];
+    for (int r = 0; r < 16; ++r) {
+        const int prow = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kr;
+        const int ho = th * ST_TH + (prow >> 4), wo = tw * ST_TW + (prow & 15);
+        if (ho < Ho && wo < Wo) y[(((long)n * Ho + ho) * Wo + wo) * C0 + c] = acc[r] + bz;
     }
 }
 
-// dw[tap][c] += sum_pixels patch * dy ; db[c] += sum dy.  Persistent over tiles; one atomic flush per block.
+// dw[tap][c] += sum_pixels patch * dy ; db[c] += sum dy.  GEMM view: M = 49 taps (padded to 64), N = C0, K = pixels;
+// persistent blocks walk the 4 x 16 output tiles and keep the 32x32 accumulators in registers; one atomic flush at the end.
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ dw, float* __restrict__ db, int B, int H,
                                                          int W, int Ho, int Wo, int C0, int pt, int pl) {
-    __shared__ float patch[ST_PH][ST_PW + 1];
-    __shared__ float dys[ST_TH * ST_TW][64 + 1];
+    __shared__ float patch[ST_ZSLOT + 2];
+    __shared__ __attribute__((aligned(16))) float dys[64 * 64];
     const int tiles_w = (Wo + ST_TW - 1) / ST_TW, tiles_h = (Ho + ST_TH - 1) / ST_TH;
     const int ntiles = B * tiles_h * tiles_w;
-    const int nout = 49 * C0;
-    constexpr int MAXJ = 13;
-    float acc[MAXJ];
-    int o_tap[MAXJ], o_c[MAXJ];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mb = wave >> 1, nb = wave & 1, kr = lane >> 5, col = lane & 31;
+    const int tap = mb * 32 + col;
+    const bool tap_ok = tap < 49;
+    const int toff = tap_ok ? (tap / 7) * ST_PLD + (tap % 7) : 0;
+    const bool active = nb * 32 < C0;                               // wave-uniform
+    const int C4 = C0 / 4;
+    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        acc[j] = 0.f;
-        const int idx = threadIdx.x + j * 256;
-        o_tap[j] = idx < nout ? idx / C0 : -1; o_c[j] = idx < nout ? idx % C0 : 0;
-    }
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float accb = 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b = tile;
         const int tw = b % tiles_w; b /= tiles_w;
         const int th = b % tiles_h; const int n = b / tiles_h;
         __syncthreads();
-        stem_load_patch(patch, x, n, H, W, th * ST_TH * 2 - pt, tw * ST_TW * 2 - pl);
-        for (int i = threadIdx.x; i < ST_TH * ST_TW * C0; i += 256) {
-            const int pix = i / C0, c = i - pix * C0;
-            const int ho = th * ST_TH + pix / ST_TW, wo = tw * ST_TW + pix % ST_TW;
-            dys[pix][c] = (ho < Ho && wo < Wo) ? dy[(((long)n * Ho + ho) * Wo + wo) * C0 + c] : 0.f;
+        stem_load_patch_flat(patch, x, n, H, W, th * ST_TH * 2 - pt, tw * ST_TW * 2 - pl);
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {          // dys[pix][0..63], float4 lanes; columns >= C0 are zero
+            const int pixel = i >> 4, c4 = i & 15;
+            const int ho = th * ST_TH + (pixel >> 4), wo = tw * ST_TW + (pixel & 15);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c4 < C4 && ho < Ho && wo < Wo) v = *reinterpret_cast<const float4*>(dy + (((long)n * Ho + ho) * Wo + wo) * C0 + c4 * 4);
+            *reinterpret_cast<float4*>(&dys[pixel * 64 + c4 * 4]) = v;
         }
         __syncthreads();
-        for (int pix = 0; pix < ST_TH * ST_TW; ++pix) {
-            const int pr = pix / ST_TW, pc = pix % ST_TW;
+        if (active) {
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j)
-                if (o_tap[j] >= 0) {
-                    const int kh = o_tap[j] / 7, kw = o_tap[j] - kh * 7;
-                    acc[j] = fmaf(patch[pr * 2 + kh][pc * 2 + kw], dys[pix][o_c[j]], acc[j]);
-                }
-            if (threadIdx.x < C0) accb += dys[pix][threadIdx.x];
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const int p0 = 2 * s2, p1 = 2 * s2 + 1;
+                const int pbA = ((p0 >> 4) * 2) * ST_PLD + (p0 & 15) * 2, pbB = ((p1 >> 4) * 2) * ST_PLD + (p1 & 15) * 2;
+                const int ia = tap_ok ? (kr ? pbB : pbA) + toff : ST_ZSLOT;
+                const float a = patch[ia];
+                const float bv = dys[(p0 + kr) * 64 + nb * 32 + col];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+            }
+        }
+        if (db && threadIdx.x < C0) {
+            for (int pixel = 0; pixel < 64; ++pixel) accb += dys[pixel * 64 + threadIdx.x];
         }
     }
+    const int c = nb * 32 + col;
+    if (active && c < C0) {
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-        if (o_tap[j] >= 0) atomicAdd(dw + o_tap[j] * C0 + o_c[j], acc[j]);
-    if (threadIdx.x < C0 && db) atomicAdd(db + threadIdx.x, accb);
+        for (int r = 0; r < 16; ++r) {
+            const int t = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kr;
+            if (t < 49) atomicAdd(dw + t * C0 + c, acc[r]);
+        }
+    }
+    if (db && threadIdx.x < C0) atomicAdd(db + threadIdx.x, accb);
 }
 
 // ------------------------------------------------------------------ BN + ReLU + MaxPool 3x3/2 SAME (fused)
@@ -146,35 +173,41 @@ __global__ void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, const fl
 
 // Backward pass 1: per-channel sums of dz and dz*xhat over the full-resolution tensor, where
 // dz[n,h,w,c] = sum of dpool over windows whose argmax is (h,w) and whose max is > 0 (ReLU active).
+// float4 lanes over channel-vectors x pixel groups; per-block partials (combined in fp64 by pool_combine_kernel).
 __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
     const float* __restrict__ dpool, const float* __restrict__ out, const uint8_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int pt, int pl) {
-    // thread -> channel c = tid % C (C <= 256 and 256 % C == 0 assumed by the host), pixel group = tid / C
-    const int c = threadIdx.x % C, pg = threadIdx.x / C, npg = blockDim.x / C;
-    const long npix = (long)B * Ho * Wo;
-    float s1 = 0.f, s2 = 0.f;
-    const float mu = mean[c], rs = rstd[c];
-    for (long pix = (long)blockIdx.x * npg + pg; pix < npix; pix += (long)gridDim.x * npg) {
-        const long o = pix * C + c;
-        const float a = out[o];
-        if (a > 0.f) {
-            const float g = dpool[o];
-            const int k = idx[o];
-            const int wo = (int)(pix % Wo); const long t = pix / Wo;
-            const int ho = (int)(t % Ho); const int n = (int)(t / Ho);
-            const int hi = ho * 2 - pt + k / 3, wi = wo * 2 - pl + k % 3;
-            const float xh = (x[(((long)n * H + hi) * W + wi) * C + c] - mu) * rs;
-            s1 += g; s2 += g * xh;
-        }
+    __shared__ float4 r1[256], r2[256];
+    const int tpr = C / 4;                                    // C <= 256 and 256 % C == 0 (host-checked) -> tpr | 64
+    const int cv = threadIdx.x % tpr, pg = threadIdx.x / tpr, npg = 256 / tpr;
+    const int c = cv * 4;
+    const unsigned npix = (unsigned)(B * Ho * Wo);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
+        const long o = (long)pix * C + c;
+        const float4 a = *reinterpret_cast<const float4*>(out + o);
+        const float4 g = *reinterpret_cast<const float4*>(dpool + o);
+        const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
+        const unsigned wo = pix % (unsigned)Wo, t = pix / (unsigned)Wo;
+        const unsigned ho = t % (unsigned)Ho, n = t / (unsigned)Ho;
+        const long base = (((long)n * H + (int)ho * 2 - pt) * W + (int)wo * 2 - pl) * C + c;
+        if (a.x > 0.f) { const float xh = (x[base + ((k.x / 3) * W + (k.x % 3)) * C + 0] - mu.x) * rs.x; s1.x += g.x; s2.x = fmaf(g.x, xh, s2.x); }
+        if (a.y > 0.f) { const float xh = (x[base + ((k.y / 3) * W + (k.y % 3)) * C + 1] - mu.y) * rs.y; s1.y += g.y; s2.y = fmaf(g.y, xh, s2.y); }
+        if (a.z > 0.f) { const float xh = (x[base + ((k.z / 3) * W + (k.z % 3)) * C + 2] - mu.z) * rs.z; s1.z += g.z; s2.z = fmaf(g.z, xh, s2.z); }
+        if (a.w > 0.f) { const float xh = (x[base + ((k.w / 3) * W + (k.w % 3)) * C + 3] - mu.w) * rs.w; s1.w += g.w; s2.w = fmaf(g.w, xh, s2.w); }
     }
-    __shared__ float r1[256], r2[256];
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
     __syncthreads();
-    if (threadIdx.x < C) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int g = 0; g < npg; ++g) { a1 += r1[g * C + threadIdx.x]; a2 += r2[g * C + threadIdx.x]; }
-        part[(long)blockIdx.x * 2 * C + c] = a1; part[(long)blockIdx.x * 2 * C + C + c] = a2;
+    if (threadIdx.x < tpr) {
+        float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+        for (int g = 0; g < npg; ++g) {
+            const float4 u = r1[g * tpr + threadIdx.x], v = r2[g * tpr + threadIdx.x];
+            a1.x += u.x; a1.y += u.y; a1.z += u.z; a1.w += u.w; a2.x += v.x; a2.y += v.y; a2.z += v.z; a2.w += v.w;
+        }
+        float* o = part + (long)blockIdx.x * 2 * C;
+        *reinterpret_cast<float4*>(o + c) = a1; *reinterpret_cast<float4*>(o + C + c) = a2;
     }
 }
 
@@ -187,20 +220,21 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
     if (lane == 0) totals[c] = s;
 }
 
-// Backward pass 2: dx = scale * (dz - s1/R - xhat*s2/R) at full resolution.
+// Backward pass 2: dx = scale * (dz - s1/R - xhat*s2/R) at full resolution; 4 channels per thread (float4 / uchar4).
 __global__ void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool, const float* __restrict__ out,
                                                  const uint8_t* __restrict__ idx, const float* __restrict__ x,
                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                  const float* __restrict__ scale, const double* __restrict__ sums,
                                                  float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
                                                  int pt, int pl) {
-    const long total = (long)B * H * W * C;
+    const int C4 = C / 4;
+    const long total = (long)B * H * W * C4;
     const double invR = 1.0 / ((double)B * H * W);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C); long t = i / C;
+        const int c = (int)(i % C4) * 4; long t = i / C4;
         const int w_ = (int)(t % W); t /= W;
         const int h = (int)(t % H); const int n = (int)(t / H);
-        float dz = 0.f;
+        float dz[4] = {0.f, 0.f, 0.f, 0.f};
         const int ho_lo = max(0, (h + pt - 1) / 2), ho_hi = min(Ho - 1, (h + pt) / 2);
         const int wo_lo = max(0, (w_ + pl - 1) / 2), wo_hi = min(Wo - 1, (w_ + pl) / 2);
         for (int ho = ho_lo; ho <= ho_hi; ++ho) {
@@ -210,11 +244,25 @@ __global__ void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool
                 const int kw = w_ - (wo * 2 - pl);
                 if (kw < 0 || kw > 2) continue;
                 const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
-                if (idx[o] == kh * 3 + kw && out[o] > 0.f) dz += dpool[o];
+                const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o);
+                const float4 ov = *reinterpret_cast<const float4*>(out + o);
+                const float4 g = *reinterpret_cast<const float4*>(dpool + o);
+                const int slot = kh * 3 + kw;
+                if (id.x == slot && ov.x > 0.f) dz[0] += g.x;
+                if (id.y == slot && ov.y > 0.f) dz[1] += g.y;
+                if (id.z == slot && ov.z > 0.f) dz[2] += g.z;
+                if (id.w == slot && ov.w > 0.f) dz[3] += g.w;
             }
         }
-        const float xh = (x[i] - mean[c]) * rstd[c];
-        dx[i] = scale[c] * (dz - (float)(sums[c] * invR) - xh * (float)(sums[C + c] * invR));
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        float4 o4;
+        o4.x = sc.x * (dz[0] - (float)(sums[c + 0] * invR) - (xv.x - mu.x) * rs.x * (float)(sums[C + c + 0] * invR));
+        o4.y = sc.y * (dz[1] - (float)(sums[c + 1] * invR) - (xv.y - mu.y) * rs.y * (float)(sums[C + c + 1] * invR));
+        o4.z = sc.z * (dz[2] - (float)(sums[c + 2] * invR) - (xv.z - mu.z) * rs.z * (float)(sums[C + c + 2] * invR));
+        o4.w = sc.w * (dz[3] - (float)(sums[c + 3] * invR) - (xv.w - mu.w) * rs.w * (float)(sums[C + c + 3] * invR));
+        reinterpret_cast<float4*>(dx)[i] = o4;
     }
 }
 
@@ -259,7 +307,8 @@ extern "C" int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out,
     float* part = reinterpret_cast<float*>(sums + 2 * C);          // workspace layout of sar_bn_workspace_bytes(C)
     hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, part, B, H, W, C, Ho, Wo, pad_top, pad_left);
     hipLaunchKernelGGL(pool_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, 256, sums, 2 * C);
-    const long total = (long)B * H * W * C;
+    if (C % 4) return SAR_EINVAL;
+    const long total = (long)B * H * W * (C / 4);
     const int nblk = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
     hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3(nblk), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, sums, dx, B, H, W, C, Ho, Wo, pad_top, pad_left);
     SAR_CHECK_LAUNCH();

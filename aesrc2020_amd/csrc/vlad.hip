@@ -8,19 +8,27 @@
 
 namespace {
 
-constexpr int KC = 8;       // clusters accumulated per register pass
+constexpr int KC = 16;      // clusters accumulated per register pass
+constexpr int XB = 13;      // feature rows fetched per batch (independent loads in flight)
 
+// Stage the (L, K+G) score tile into LDS with coalesced loads, soft-max each row in LDS (one thread per row; rows are
+// short), then write the assignment matrix back coalesced.  (v1 read the scores with per-thread serial global loads:
+// ~100 dependent L2 round trips per row.)
 __device__ __forceinline__ void softmax_rows_to_lds(const float* __restrict__ score, float* __restrict__ A_s,
                                                     float* __restrict__ A_out, int L, int KG) {
+    for (int i = threadIdx.x; i < L * KG; i += blockDim.x) A_s[i] = score[i];
+    __syncthreads();
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
-        const float* s = score + (long)l * KG;
+        float* s = A_s + l * KG;
         float m = -INFINITY;
         for (int k = 0; k < KG; ++k) m = fmaxf(m, s[k]);
         float sum = 0.f;
-        for (int k = 0; k < KG; ++k) { const float e = expf(s[k] - m); A_s[l * KG + k] = e; sum += e; }
+        for (int k = 0; k < KG; ++k) { const float e = expf(s[k] - m); s[k] = e; sum += e; }
         const float inv = 1.f / sum;
-        for (int k = 0; k < KG; ++k) { const float a = A_s[l * KG + k] * inv; A_s[l * KG + k] = a; if (A_out) A_out[(long)l * KG + k] = a; }
+        for (int k = 0; k < KG; ++k) s[k] *= inv;
     }
+    __syncthreads();
+    if (A_out) for (int i = threadIdx.x; i < L * KG; i += blockDim.x) A_out[i] = A_s[i];
 }
 
 __global__ __launch_bounds__(256) void vlad_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ score,
@@ -31,6 +39,7 @@ __global__ __launch_bounds__(256) void vlad_fwd_kernel(const float* __restrict__
     float* A_s = sm;                   // [L][KG]
     float* asum = A_s + L * KG;        // [KG]
     float* ss = asum + KG;             // [K]
+    float* res_s = ss + K;             // [K][D] un-normalised residuals (written once to HBM after the norms are known)
     const int b = blockIdx.x;
     const float* x = feat + (long)b * L * D;
     softmax_rows_to_lds(score + (long)b * L * KG, A_s, A_out + (long)b * L * KG, L, KG);
@@ -44,23 +53,40 @@ __global__ __launch_bounds__(256) void vlad_fwd_kernel(const float* __restrict__
     __syncthreads();
     float* o = out + (long)b * K * D;
     for (int k0 = 0; k0 < K; k0 += KC) {
-        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        for (int d0 = 0; d0 < D; d0 += blockDim.x) {           // wave-uniform trip count (shuffles below)
+            const int d = d0 + threadIdx.x;
+            const bool d_ok = d < D;
             float acc[KC];
 #pragma unroll
             for (int i = 0; i < KC; ++i) acc[i] = 0.f;
-            for (int l = 0; l < L; ++l) {
-                const float xv = x[(long)l * D + d];
+            for (int l0 = 0; l0 < L; l0 += XB) {                 // XB independent loads in flight per batch
+                float xv[XB];
 #pragma unroll
-                for (int i = 0; i < KC; ++i)
-                    if (k0 + i < K) acc[i] = fmaf(A_s[l * KG + k0 + i], xv, acc[i]);
+                for (int j = 0; j < XB; ++j) xv[j] = (d_ok && l0 + j < L) ? x[(long)(l0 + j) * D + d] : 0.f;
+#pragma unroll
+                for (int j = 0; j < XB; ++j)
+                    if (l0 + j < L) {
+#pragma unroll
+                        for (int i = 0; i < KC; ++i)
+                            if (k0 + i < K) acc[i] = fmaf(A_s[(l0 + j) * KG + k0 + i], xv[j], acc[i]);
+                    }
             }
 #pragma unroll
             for (int i = 0; i < KC; ++i)
-                if (k0 + i < K) {
+                if (d_ok && k0 + i < K) {
                     const float r = acc[i] - asum[k0 + i] * centers[(long)(k0 + i) * D + d];
-                    o[(long)(k0 + i) * D + d] = r;
-                    atomicAdd(&ss[k0 + i], r * r);
-                }
+                    res_s[(k0 + i) * D + d] = r;
+                    acc[i] = r * r;
+                } else acc[i] = 0.f;
+            // one LDS atomic per wave and cluster (256 same-address float atomics per cluster serialise badly)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int i = 0; i < KC; ++i) acc[i] += __shfl_xor(acc[i], off, 64);
+            if ((threadIdx.x & 63) == 0)
+#pragma unroll
+                for (int i = 0; i < KC; ++i)
+                    if (k0 + i < K) atomicAdd(&ss[k0 + i], acc[i]);
         }
     }
     __syncthreads();
@@ -69,9 +95,9 @@ __global__ __launch_bounds__(256) void vlad_fwd_kernel(const float* __restrict__
         const float iv = 1.f / sqrtf(fmaxf(s, 1e-12f));
         inv_out[(long)b * K + k] = s >= 1e-12f ? iv : -iv;
     }
-    for (int k = 0; k < K; ++k) {
-        const float iv = 1.f / sqrtf(fmaxf(ss[k], 1e-12f));
-        for (int d = threadIdx.x; d < D; d += blockDim.x) o[(long)k * D + d] *= iv;   // same thread wrote it
+    for (int i = threadIdx.x; i < K * D; i += blockDim.x) {
+        const float iv = 1.f / sqrtf(fmaxf(ss[i / D], 1e-12f));
+        o[i] = res_s[i] * iv;
     }
 }
 
@@ -130,13 +156,28 @@ __global__ __launch_bounds__(256) void vlad_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const int d = lane + i * 64; xr[i] = d < D ? x[(long)l * D + d] : 0.f; }
         float dA0 = 0.f, dA1 = 0.f;
-        for (int k = 0; k < K; ++k) {
-            float s = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 16) {                        // 16 independent butterfly chains per batch
+            float part[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const int d = lane + i * 64; if (d < D) s = fmaf(dres[k * DP + d], xr[i], s); }
-            s = wave_sum(s) - cd[k];
-            if (k == lane) dA0 = s;
-            if (k == lane + 64) dA1 = s;
+            for (int j = 0; j < 16; ++j) {
+                float s = 0.f;
+                if (k0 + j < K) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const int d = lane + i * 64; if (d < D) s = fmaf(dres[(k0 + j) * DP + d], xr[i], s); }
+                }
+                part[j] = s;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) part[j] += __shfl_xor(part[j], off, 64);
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (k0 + j < K) {
+                    const float s = part[j] - cd[k0 + j];
+                    if (k0 + j == lane) dA0 = s;
+                    if (k0 + j == lane + 64) dA1 = s;
+                }
         }
         const float a0 = lane < KG ? A_s[l * KG + lane] : 0.f;
         const float a1 = lane + 64 < KG ? A_s[l * KG + lane + 64] : 0.f;
@@ -161,7 +202,7 @@ extern "C" int sar_vlad_fwd_f32(const float* feat, const float* score, const flo
                                 float* inv, int B, int L, int D, int K, int G, hipStream_t stream) {
     const int KG = K + G;
     if (!feat || !score || !centers || !out || !A || !inv || K < 1 || G < 0) return SAR_EINVAL;
-    const size_t lds = sizeof(float) * ((size_t)L * KG + KG + K);
+    const size_t lds = sizeof(float) * ((size_t)L * KG + KG + K + (size_t)K * D);
     if (lds > 160 * 1024) return SAR_EINVAL;
     static size_t lds_set = 0;     // raise the dynamic-LDS cap once per size (host-side attribute, not a stream op)
     if (lds > 48 * 1024 && lds > lds_set) {
