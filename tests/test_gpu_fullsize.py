@@ -1,0 +1,79 @@
+"""Full-size (BASELINE.json shapes) GPU tests through size-independent properties -- the float64 oracle is too slow here:
+ * duplicated half-batch: BatchNorm batch statistics of [X; X] equal those of X, so every per-utterance output of the
+   B=64 run must equal the B=32 run of the half, and both halves must agree with each other;
+ * CTC sum rule at B=64, L=39, V=1000: sum_k (p_k + 1e-7) * dL/dp_k = 0 for every frame (state posteriors sum to 1);
+ * GhostVLAD rows are unit vectors; head probabilities sum to 1; everything finite;
+ * cfg5 long-utterance stress (T=2000 -> L=189, GhostVLAD 64+2) runs one full step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG3 = dict(input_shape=[400, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8, ghost_clusters=2,
+            disc_enable=True, ctc_enable=True, metric_loss="circleloss", margin=0.3, bpe_classes=1000, max_ctc_len=72)
+
+
+def _batch(kw, B, seed):
+    from aesrc2020_amd.utils import synthetic_batch
+    x, y = synthetic_batch(kw["input_shape"], B, kw.get("ctc_enable", False), kw.get("disc_enable", False),
+                           bpe_classes=kw.get("bpe_classes", 1000), max_ctc_len=kw.get("max_ctc_len", 72), seed=seed)
+    return {**x, **y}
+
+
+def test_cfg3_duplicated_half_batch_invariance():
+    from aesrc2020_amd.model import SAR_Net
+    half = _batch(CFG3, 32, 5)
+    full = {k: np.concatenate([v, v]) for k, v in half.items()}
+    m64, _ = SAR_Net(seed=0, use_graph=False, **CFG3)
+    m32, _ = SAR_Net(seed=0, use_graph=False, **CFG3)
+    m32.set_weights_dict(m64.get_weights_dict())
+    m64.forward_backward_only(full, full); m32.forward_backward_only(half, half)
+    for k in ("y_accent", "y_disc", "y_ctc_loss"):
+        a = m64.out[k].cpu().numpy(); b = m32.out[k].cpu().numpy()
+        assert np.all(np.isfinite(a))
+        scale = np.abs(b).max() + 1e-6
+        assert np.abs(a[:32] - a[32:]).max() <= 2e-4 * scale, k       # split-K atomics reorder fp32 sums, hence not bitwise
+        assert np.abs(a[:32] - b).max() <= 2e-4 * scale, k
+    assert (m64.out["y_ctc_loss"].cpu().numpy() > 0).all()
+    # mean-loss gradients of the doubled batch equal those of the half (same per-sample gradients, batch-mean)
+    g64 = m64.store.grads.cpu().numpy(); g32 = m32.store.grads.cpu().numpy()
+    assert np.all(np.isfinite(g64))
+    assert np.abs(g64 - g32).max() <= 5e-3 * np.abs(g32).max()
+    pooled = m64.merge.pool.out.view(64, 8, 256)
+    assert torch.allclose(pooled.norm(dim=2), torch.ones(64, 8, device="cuda", dtype=torch.float32), atol=1e-4)
+    assert torch.allclose(m64.out["y_accent"].sum(1), torch.ones(64, device="cuda", dtype=torch.float32), atol=1e-5)
+
+
+def test_ctc_sum_rule_full_size():
+    from aesrc2020_amd import _lib as L
+    B, Lq, V, U = 64, 39, 1000, 72
+    g = torch.Generator(device="cuda").manual_seed(3)
+    p = torch.softmax(torch.randn(B, Lq, V, device="cuda", generator=g, dtype=torch.float32) * 3, -1).contiguous()
+    rng = np.random.default_rng(1)
+    lab = np.full((B, U), 2.0, np.float32); ll = rng.integers(4, 17, B).astype(np.int32)
+    for b in range(B):
+        lab[b, :ll[b]] = rng.integers(0, V - 1, ll[b])
+    il = np.full(B, Lq, np.int32); il[::7] = 30
+    labd = torch.tensor(lab, device="cuda"); ild = torch.tensor(il, device="cuda"); lld = torch.tensor(ll, device="cuda")
+    wsb = L.ctc_workspace_bytes(B, Lq, U); ws = torch.zeros(wsb // 4, device="cuda", dtype=torch.float32)
+    loss = torch.zeros(B, device="cuda", dtype=torch.float32); dp = torch.zeros(B, Lq, V, device="cuda", dtype=torch.float32)
+    L.call("sar_ctc_batch_cost_fwd_f32", p, labd, ild, lld, loss, ws, wsb, B, Lq, V, U)
+    L.call("sar_ctc_batch_cost_bwd_f32", p, labd, ild, lld, loss, torch.ones(B, device="cuda", dtype=torch.float32), ws, wsb, dp, B, Lq, V, U)
+    assert torch.isfinite(loss).all() and (loss > 0).all()
+    s = ((p.double() + 1e-7) * dp.double()).sum(-1)                 # (B, L)
+    assert s.abs().max().item() < 1e-3
+    for b in range(0, B, 7):
+        assert (dp[b, 30:] == 0).all()                              # frames beyond in_len get exactly zero gradient
+
+
+def test_cfg5_long_utterance_stress():
+    from aesrc2020_amd.model import SAR_Net
+    kw = dict(input_shape=[2000, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=64, ghost_clusters=2,
+              disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)
+    m, _ = SAR_Net(seed=0, **kw)
+    assert m.L == 189
+    b = _batch(kw, 8, 9)
+    logs = [m.train_on_batch(b, b) for _ in range(3)]
+    assert all(np.isfinite(l["loss"]) for l in logs) and m.graph is not None
+    assert m.merge.pool.out.shape == (8, 64 * 256)

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aesrc2020_amd import _lib as L
-B = 64
+B = int(os.environ.get("CB", "64"))
 STAGES = [("s0 3x3 32->32", 100, 20, 32, 32, 3, 1), ("s0 3x3 64->32", 100, 20, 64, 32, 3, 1), ("s1 3x3 64->64", 50, 10, 64, 64, 3, 1),
           ("s1 3x3/2 32->64", 100, 20, 32, 64, 3, 2), ("s2 3x3 128->128", 25, 5, 128, 128, 3, 1), ("s3 3x3 256->256", 13, 3, 256, 256, 3, 1),
           ("s3 1x1/2 128->256", 25, 5, 128, 256, 1, 2)]
