@@ -1,7 +1,7 @@
 // Bidirectional reset-after GRU (Keras CuDNNGRU semantics, model.py:44-50) on gfx950.
 // The input projection xa = x*W + b_i for all time steps is one MFMA GEMM outside this file (gemm.hip);
 // here: the sequential recurrence, one persistent workgroup per (direction, group of GR batch rows),
-// thread (j, kq) owns hidden unit j and a quarter of the reduction. h lives in LDS; the recurrent kernel U (H,3H) streams from L2 every step
+// lane owns 4 hidden units, wave owns a k-slice (v3, see below). h lives in LDS; the recurrent kernel U (H,3H) streams from L2 every step
 // (coalesced across j).  Gate order z, r, h; bias_h = bias[3H:6H].
 //   z = sig(xa_z + hU_z + b_hz); r = sig(xa_r + hU_r + b_hr); q = hU_h + b_hh
 //   hh = tanh(xa_h + r*q);  h' = z*h + (1-z)*hh
@@ -10,67 +10,82 @@
 
 namespace {
 
-constexpr int GR = 4;   // batch rows per workgroup
-constexpr int KS = 4;   // k-splits: the block is H x KS threads, thread (j, kq) covers a quarter of the reduction
-                        // (4x the loads in flight per CU: the recurrence is L2-latency-bound, not FLOP-bound)
+constexpr int GR = 2;    // batch rows per workgroup
+constexpr int NW = 16;   // waves per workgroup = k-slices of the reduction
+// v3 mapping (H % 4 == 0, H <= 256): lane owns 4 consecutive hidden units (float4 loads of U rows: 1 KB per wave
+// instruction instead of 256 B), wave w owns the k-slice [w*H/16, (w+1)*H/16).  The recurrence is bound by how fast one
+// CU can stream the 3*H*H recurrent kernel from L2 every step, so bytes per load instruction and loads in flight matter,
+// not FLOPs.  Partial sums go through LDS: part[NW][GR*12][64] -> red[GR][3][H] -> gate math -> hs[GR][H].
 
-// dynamic LDS: hs[GR][H] | part[KS][GR][3][H]
-__global__ void gru_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
+__device__ __forceinline__ void fma4(float4& a, float h, const float4& u) {
+    a.x = fmaf(h, u.x, a.x); a.y = fmaf(h, u.y, a.y); a.z = fmaf(h, u.z, a.z); a.w = fmaf(h, u.w, a.w);
+}
+
+// dynamic LDS: hs[GR][H] | red[GR][3][H] | part[NW][GR*12][64]
+__global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
                                const float* __restrict__ U_f, const float* __restrict__ U_b,
                                const float* __restrict__ bh_f, const float* __restrict__ bh_b,
                                float* __restrict__ out, float* __restrict__ gates, float* __restrict__ hprev, int B,
                                int L, int H) {
-    extern __shared__ float sm[];
-    float* hs = sm; float* part = sm + GR * H;
-    const int d = blockIdx.y, j = threadIdx.x % H, kq = threadIdx.x / H, b0 = blockIdx.x * GR;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* hs = sm; float* red = hs + GR * H; float* part = red + GR * 3 * H;
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b0 = blockIdx.x * GR;
     const float* xa = d ? xa_b : xa_f; const float* U = d ? U_b : U_f; const float* bh = d ? bh_b : bh_f;
-    const int H3 = 3 * H;
-    const int kper = (H + KS - 1) / KS, k0 = kq * kper, k1 = min(H, k0 + kper);
-    const float bz = bh[j], br = bh[H + j], bq = bh[2 * H + j];
-    for (int i = threadIdx.x; i < GR * H; i += blockDim.x) hs[i] = 0.f;
+    const int H3 = 3 * H, H4 = H / 4;
+    const int kper = (H + NW - 1) / NW, k0 = w * kper, k1 = min(H, k0 + kper);
+    const bool lane_ok = lane < H4;
+    for (int i = tid; i < GR * H; i += blockDim.x) hs[i] = 0.f;
     __syncthreads();
     float* g_d = gates + (long)d * B * L * 4 * H;
     float* hp_d = hprev + (long)d * B * L * H;
     for (int s = 0; s < L; ++s) {
         const int t = d ? (L - 1 - s) : s;
-        float az[GR], ar[GR], aq[GR];
+        float4 az[GR], ar[GR], aq[GR];
 #pragma unroll
-        for (int r = 0; r < GR; ++r) { az[r] = 0.f; ar[r] = 0.f; aq[r] = 0.f; }
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) {
-            const float u0 = U[(long)k * H3 + j], u1 = U[(long)k * H3 + H + j], u2 = U[(long)k * H3 + 2 * H + j];
+        for (int r = 0; r < GR; ++r) { az[r] = make_float4(0, 0, 0, 0); ar[r] = az[r]; aq[r] = az[r]; }
+        if (lane_ok) {
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) {
+                const float* ur = U + (long)k * H3 + lane * 4;
+                const float4 u0 = *reinterpret_cast<const float4*>(ur), u1 = *reinterpret_cast<const float4*>(ur + H),
+                             u2 = *reinterpret_cast<const float4*>(ur + 2 * H);
 #pragma unroll
-            for (int r = 0; r < GR; ++r) {
-                const float hv = hs[r * H + k];
-                az[r] = fmaf(hv, u0, az[r]); ar[r] = fmaf(hv, u1, ar[r]); aq[r] = fmaf(hv, u2, aq[r]);
+                for (int r = 0; r < GR; ++r) { const float hv = hs[r * H + k]; fma4(az[r], hv, u0); fma4(ar[r], hv, u1); fma4(aq[r], hv, u2); }
             }
         }
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
-            float* p = part + ((kq * GR + r) * 3) * H;
-            p[j] = az[r]; p[H + j] = ar[r]; p[2 * H + j] = aq[r];
+            float* p = part + ((w * GR + r) * 12) * 64 + lane;
+            p[0 * 64] = az[r].x; p[1 * 64] = az[r].y; p[2 * 64] = az[r].z; p[3 * 64] = az[r].w;
+            p[4 * 64] = ar[r].x; p[5 * 64] = ar[r].y; p[6 * 64] = ar[r].z; p[7 * 64] = ar[r].w;
+            p[8 * 64] = aq[r].x; p[9 * 64] = aq[r].y; p[10 * 64] = aq[r].z; p[11 * 64] = aq[r].w;
         }
-        __syncthreads();                               // partials complete; everyone is done reading hs
-        for (int r = kq; r < GR; r += KS) {            // thread (j, kq) finishes batch row r = kq
-            const int b = b0 + r;
-            float sz = bz, sr = br, sq = bq;
+        __syncthreads();
+        // cross-wave reduction: output o = (r, g, j); j = 4*l4 + e lives at part[*][r*12 + g*4 + e][l4]
+        for (int o = tid; o < GR * 3 * H; o += blockDim.x) {
+            const int r = o / H3, rem = o - r * H3, g = rem / H, jj = rem - g * H;
+            const float* p = part + ((r * 12) + g * 4 + (jj & 3)) * 64 + (jj >> 2);
+            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < KS; ++q) {
-                const float* p = part + ((q * GR + r) * 3) * H;
-                sz += p[j]; sr += p[H + j]; sq += p[2 * H + j];
-            }
+            for (int q = 0; q < NW; ++q) sum += p[q * GR * 12 * 64];
+            red[o] = sum + bh[g * H + jj];
+        }
+        __syncthreads();
+        for (int o = tid; o < GR * H; o += blockDim.x) {
+            const int r = o / H, jj = o - r * H, b = b0 + r;
             if (b < B) {
                 const long xo = ((long)b * L + t) * H3;
-                const float hold = hs[r * H + j];
-                const float z = sigmoidf_(xa[xo + j] + sz);
-                const float rr = sigmoidf_(xa[xo + H + j] + sr);
-                const float hh = tanhf(xa[xo + 2 * H + j] + rr * sq);
+                const float hold = hs[o];
+                const float q = red[r * H3 + 2 * H + jj];
+                const float z = sigmoidf_(xa[xo + jj] + red[r * H3 + jj]);
+                const float rr = sigmoidf_(xa[xo + H + jj] + red[r * H3 + H + jj]);
+                const float hh = tanhf(xa[xo + 2 * H + jj] + rr * q);
                 const float hn = z * hold + (1.f - z) * hh;
                 const long go = (((long)b * L + t) * 4) * H;
-                g_d[go + j] = z; g_d[go + H + j] = rr; g_d[go + 2 * H + j] = hh; g_d[go + 3 * H + j] = sq;
-                hp_d[((long)b * L + t) * H + j] = hold;
-                out[((long)b * L + t) * 2 * H + d * H + j] = hn;
-                hs[r * H + j] = hn;                      // only this thread touches hs[r][j] in this phase
+                g_d[go + jj] = z; g_d[go + H + jj] = rr; g_d[go + 2 * H + jj] = hh; g_d[go + 3 * H + jj] = q;
+                hp_d[((long)b * L + t) * H + jj] = hold;
+                out[((long)b * L + t) * 2 * H + d * H + jj] = hn;
+                hs[o] = hn;
             }
         }
         __syncthreads();
@@ -78,62 +93,70 @@ __global__ void gru_fwd_kernel(const float* __restrict__ xa_f, const float* __re
 }
 
 // BPTT.  UT = transpose(U): (3H, H).  dai/dah: (2, B, L, 3H) input-side / recurrent-side pre-activation grads.
-// dynamic LDS: ds[GR][3H] | dhs[GR][H] | zs[GR][H] | part[KS][GR][H]
-__global__ void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
+// dynamic LDS: ds[GR][3H] | dhs[GR][H] | zs[GR][H] | part[NW][GR*4][64]
+__global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
                                const float* __restrict__ hprev, const float* __restrict__ UT_f,
                                const float* __restrict__ UT_b, float* __restrict__ dai, float* __restrict__ dah, int B,
                                int L, int H) {
-    extern __shared__ float sm[];
-    const int H3 = 3 * H;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H3 = 3 * H, H4 = H / 4;
     float* ds = sm; float* dhs = ds + GR * H3; float* zs = dhs + GR * H; float* part = zs + GR * H;
-    const int d = blockIdx.y, j = threadIdx.x % H, kq = threadIdx.x / H, b0 = blockIdx.x * GR;
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b0 = blockIdx.x * GR;
     const float* UT = d ? UT_b : UT_f;
-    const int cper = (H3 + KS - 1) / KS, c0 = kq * cper, c1 = min(H3, c0 + cper);
+    const int cper = (H3 + NW - 1) / NW, c0 = w * cper, c1 = min(H3, c0 + cper);
+    const bool lane_ok = lane < H4;
     const float* g_d = gates + (long)d * B * L * 4 * H;
     const float* hp_d = hprev + (long)d * B * L * H;
     float* dai_d = dai + (long)d * B * L * H3; float* dah_d = dah + (long)d * B * L * H3;
-    for (int i = threadIdx.x; i < GR * H; i += blockDim.x) dhs[i] = 0.f;
+    for (int i = tid; i < GR * H; i += blockDim.x) dhs[i] = 0.f;
     __syncthreads();
     for (int s = L - 1; s >= 0; --s) {
         const int t = d ? (L - 1 - s) : s;
-        for (int r = kq; r < GR; r += KS) {            // gate backward for row r by thread (j, kq = r)
-            const int b = b0 + r;
+        for (int o = tid; o < GR * H; o += blockDim.x) {            // gate backward for (row r, unit jj)
+            const int r = o / H, jj = o - r * H, b = b0 + r;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, z = 0.f, g = 0.f;
             if (b < B) {
                 const long go = (((long)b * L + t) * 4) * H;
-                z = g_d[go + j];
-                const float rr = g_d[go + H + j], hh = g_d[go + 2 * H + j], q = g_d[go + 3 * H + j];
-                const float hp = hp_d[((long)b * L + t) * H + j];
-                g = dhs[r * H + j] + dout[((long)b * L + t) * 2 * H + d * H + j];
+                z = g_d[go + jj];
+                const float rr = g_d[go + H + jj], hh = g_d[go + 2 * H + jj], q = g_d[go + 3 * H + jj];
+                const float hp = hp_d[((long)b * L + t) * H + jj];
+                g = dhs[o] + dout[((long)b * L + t) * 2 * H + d * H + jj];
                 const float da_h = g * (1.f - z) * (1.f - hh * hh);
                 const float da_z = g * (hp - hh) * z * (1.f - z);
                 const float da_r = da_h * q * rr * (1.f - rr);
-                const long o = ((long)b * L + t) * H3;
-                dai_d[o + j] = da_z; dai_d[o + H + j] = da_r; dai_d[o + 2 * H + j] = da_h;
+                const long oo = ((long)b * L + t) * H3;
+                dai_d[oo + jj] = da_z; dai_d[oo + H + jj] = da_r; dai_d[oo + 2 * H + jj] = da_h;
                 a0 = da_z; a1 = da_r; a2 = da_h * rr;
-                dah_d[o + j] = a0; dah_d[o + H + j] = a1; dah_d[o + 2 * H + j] = a2;
+                dah_d[oo + jj] = a0; dah_d[oo + H + jj] = a1; dah_d[oo + 2 * H + jj] = a2;
             }
-            ds[r * H3 + j] = a0; ds[r * H3 + H + j] = a1; ds[r * H3 + 2 * H + j] = a2;
-            dhs[r * H + j] = g; zs[r * H + j] = z;
+            ds[r * H3 + jj] = a0; ds[r * H3 + H + jj] = a1; ds[r * H3 + 2 * H + jj] = a2;
+            dhs[o] = g; zs[o] = z;
         }
         __syncthreads();
-        float acc[GR];
+        float4 acc[GR];
 #pragma unroll
-        for (int r = 0; r < GR; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int c = c0; c < c1; ++c) {
-            const float u = UT[(long)c * H + j];
+        for (int r = 0; r < GR; ++r) acc[r] = make_float4(0, 0, 0, 0);
+        if (lane_ok) {
+#pragma unroll 4
+            for (int c = c0; c < c1; ++c) {
+                const float4 u = *reinterpret_cast<const float4*>(UT + (long)c * H + lane * 4);
 #pragma unroll
-            for (int r = 0; r < GR; ++r) acc[r] = fmaf(ds[r * H3 + c], u, acc[r]);
+                for (int r = 0; r < GR; ++r) fma4(acc[r], ds[r * H3 + c], u);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < GR; ++r) part[(kq * GR + r) * H + j] = acc[r];
+        for (int r = 0; r < GR; ++r) {
+            float* p = part + ((w * GR + r) * 4) * 64 + lane;
+            p[0] = acc[r].x; p[64] = acc[r].y; p[128] = acc[r].z; p[192] = acc[r].w;
+        }
         __syncthreads();
-        for (int r = kq; r < GR; r += KS) {
+        for (int o = tid; o < GR * H; o += blockDim.x) {
+            const int r = o / H, jj = o - r * H;
+            const float* p = part + (r * 4 + (jj & 3)) * 64 + (jj >> 2);
             float a = 0.f;
 #pragma unroll
-            for (int q = 0; q < KS; ++q) a += part[(q * GR + r) * H + j];
-            dhs[r * H + j] = dhs[r * H + j] * zs[r * H + j] + a;
+            for (int q = 0; q < NW; ++q) a += p[q * GR * 4 * 64];
+            dhs[o] = dhs[o] * zs[o] + a;
         }
         __syncthreads();
     }
@@ -164,8 +187,11 @@ extern "C" int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const
                                  int L, int H, hipStream_t stream) {
     if (!xa_fwd || !xa_bwd || !U_fwd || !U_bwd || !bh_fwd || !bh_bwd || !out || !gates || !hprev || H < 1 || H > 1024)
         return SAR_EINVAL;
-    if (H * KS > 1024) return SAR_EINVAL;
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(B, GR), 2), dim3(H * KS), sizeof(float) * (GR * H + KS * GR * 3 * H), stream,
+    if (H > 256 || H % 4) return SAR_EINVAL;
+    const size_t lds = sizeof(float) * (GR * H + GR * 3 * H + NW * GR * 12 * 64);
+    static bool attr_f = false;
+    if (!attr_f) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH; attr_f = true; }
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
                        xa_fwd, xa_bwd, U_fwd, U_bwd, bh_fwd, bh_bwd, out, gates, hprev, B, L, H);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -174,8 +200,9 @@ extern "C" int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const
 extern "C" int sar_bigru_bwd_f32(const float* dout, const float* gates, const float* hprev, const float* UT_fwd,
                                  const float* UT_bwd, float* dai, float* dah, int B, int L, int H, hipStream_t stream) {
     if (!dout || !gates || !hprev || !UT_fwd || !UT_bwd || !dai || !dah || H < 1 || H > 1024) return SAR_EINVAL;
-    if (H * KS > 1024) return SAR_EINVAL;
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(B, GR), 2), dim3(H * KS), sizeof(float) * (GR * 3 * H + 2 * GR * H + KS * GR * H), stream,
+    if (H > 256 || H % 4) return SAR_EINVAL;
+    const size_t lds = sizeof(float) * (GR * 3 * H + 2 * GR * H + NW * GR * 4 * 64);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
                        dout, gates, hprev, UT_fwd, UT_bwd, dai, dah, B, L, H);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
