@@ -23,11 +23,13 @@ namespace {
 struct ConvP {
     const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
     float* y;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk, dbg;
+    unsigned magic_a, magic_b;          // ceil(2^32/Wo), ceil(2^32/Ho)
 };
 struct DgradP {
     const float* dy; const float* w; float* dx;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, accumulate, splitk;
+    unsigned magic_a, magic_b;          // ceil(2^32/W), ceil(2^32/H)
 };
 struct WgradP {
     const float* x; const float* dy; const float* scale; const float* shift; float* dw;
@@ -49,6 +51,14 @@ __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
     return v;
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// q = m / d with magic = ceil(2^32 / d) (exact for m * d < 2^32; d == 1 handled explicitly)
+__device__ __forceinline__ unsigned fdiv(unsigned m, unsigned d, unsigned magic) { return d == 1 ? m : __umulhi(m, magic); }
+// bit t = kh*KW+kw set iff row bit kh of hm and column bit kw of wm are set
+__device__ __forceinline__ unsigned outer_mask(unsigned hm, unsigned wm, int KH, int KW) {
+    unsigned v = 0;
+    for (int kh = 0; kh < KH; ++kh) v |= ((hm >> kh) & 1u) ? (wm << (kh * KW)) : 0u;
+    return v;
+}
 
 // MFMA over one staged k-tile with the LDS operands of step k+1 prefetched ahead of the MFMAs of step k.
 template <int WM, int WN, int TM, int BK, int LDA, int LDB>
@@ -98,13 +108,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
         const unsigned m = m0 + (tid + i * NT) / KQ;
         abase[i] = 0; avalid[i] = 0;
         if (m < M) {
-            const unsigned wo = m % (unsigned)p.Wo, t = m / (unsigned)p.Wo;
-            const unsigned ho = t % (unsigned)p.Ho, n = t / (unsigned)p.Ho;
+            const unsigned t = fdiv(m, p.Wo, p.magic_a), wo = m - t * (unsigned)p.Wo;
+            const unsigned n = fdiv(t, p.Ho, p.magic_b), ho = t - n * (unsigned)p.Ho;
             const int h0 = (int)ho * p.stride - p.pt, w0 = (int)wo * p.stride - p.pl;
             abase[i] = (((int)n * p.H + h0) * p.W + w0) * p.Cin + kq;
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw)
-                    if (h0 + kh >= 0 && h0 + kh < p.H && w0 + kw >= 0 && w0 + kw < p.W) avalid[i] |= 1u << (kh * p.KW + kw);
+            unsigned hm = 0, wmk = 0;
+            for (int kk = 0; kk < p.KH; ++kk) hm |= (unsigned)(h0 + kk >= 0 && h0 + kk < p.H) << kk;
+            for (int kk = 0; kk < p.KW; ++kk) wmk |= (unsigned)(w0 + kk >= 0 && w0 + kk < p.W) << kk;
+            avalid[i] = outer_mask(hm, wmk, p.KH, p.KW);
         }
     }
     // B tile: rows k0+k of w (K, Cout), float4 along n
@@ -159,10 +170,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
     const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
     if (kt0 < nkt) load(kt0);
     for (int kt = kt0; kt < nkt; ++kt) {
-        store();
+        if (!(p.dbg & 4)) store();
         __syncthreads();
-        if (kt + 1 < nkt) load(kt + 1);
-        mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As, Bs, wm, wn, lane);
+        if (kt + 1 < nkt && !(p.dbg & 1)) load(kt + 1);
+        if (!(p.dbg & 2)) mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As, Bs, wm, wn, lane);
         __syncthreads();
     }
     const int col = n0 + wn * 32 + (lane & 31);
@@ -206,8 +217,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
         const unsigned m = m0 + (tid + i * NT) / KQ;
         abase[i] = 0; avalid[i] = 0; aph[i] = 0; apw[i] = 0;
         if (m < M) {
-            const unsigned w_ = m % (unsigned)p.W, t = m / (unsigned)p.W;
-            const unsigned h = t % (unsigned)p.H, n = t / (unsigned)p.H;
+            const unsigned t = fdiv(m, p.W, p.magic_a), w_ = m - t * (unsigned)p.W;
+            const unsigned n = fdiv(t, p.H, p.magic_b), h = t - n * (unsigned)p.H;
             const int hq = (int)h + p.pt, wq = (int)w_ + p.pl;
             if (p.stride == 1) {
                 abase[i] = (((int)n * p.Ho + hq) * p.Wo + wq) * p.Cout + kq;
@@ -215,12 +226,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
                 aph[i] = hq & 1; apw[i] = wq & 1;
                 abase[i] = (((int)n * p.Ho + (hq >> 1)) * p.Wo + (wq >> 1)) * p.Cout + kq;
             }
-            for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw) {
-                    const int hn = hq - kh, wn_ = wq - kw;
-                    if (hn >= 0 && wn_ >= 0 && (hn % p.stride) == 0 && (wn_ % p.stride) == 0 && hn / p.stride < p.Ho && wn_ / p.stride < p.Wo)
-                        avalid[i] |= 1u << (kh * p.KW + kw);
-                }
+            unsigned hm = 0, wmk = 0;                 // stride is 1 or 2 (launcher-checked): parity test + shift
+            const int sh_ = p.stride - 1;
+            for (int kk = 0; kk < p.KH; ++kk) { const int hn = hq - kk; hm |= (unsigned)(hn >= 0 && (hn & sh_) == 0 && (hn >> sh_) < p.Ho) << kk; }
+            for (int kk = 0; kk < p.KW; ++kk) { const int wn_ = wq - kk; wmk |= (unsigned)(wn_ >= 0 && (wn_ & sh_) == 0 && (wn_ >> sh_) < p.Wo) << kk; }
+            avalid[i] = outer_mask(hm, wmk, p.KH, p.KW);
         }
     }
     // B[k=co][n=ci] = w[tap][ci][co] (k contiguous in memory): thread reads float4 along co for its ci rows
@@ -404,7 +414,7 @@ static bool conv_args_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
 static int pick_conv_splitk(int tiles, int nkt) {
     static const bool off = getenv("SAR_NO_SPLITK") != nullptr;      // debugging aid
     static const int cap = getenv("SAR_SPLITK_CAP") ? atoi(getenv("SAR_SPLITK_CAP")) : 4;
-    if (off || tiles >= 512) return 1;
+    if (off || tiles >= 200) return 1;           // >= ~1 block per CU: the atomic epilogue costs more than it buys
     int s = (768 + tiles - 1) / tiles;
     if (s > nkt / 4) s = nkt / 4;
     if (s > cap) s = cap;
@@ -416,7 +426,10 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
                                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
                                   hipStream_t stream) {
     if (!x || !w || !y || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
-    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1};
+    static const int dbg = getenv("SAR_CONV_DBG") ? atoi(getenv("SAR_CONV_DBG")) : 0;
+    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1, dbg,
+            (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
+    if ((long)B * Ho * Wo * (Wo > Ho ? Wo : Ho) >= (1L << 32)) return SAR_EINVAL;
     const long M = (long)B * Ho * Wo;
     const int bk = (Cin % 32 == 0) ? 32 : 16;
     const bool narrow = Cout <= 32;
@@ -424,11 +437,13 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
     p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
     if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
     dim3 grid(cdiv(M, 128), cdiv(Cout, narrow ? 32 : 64), p.splitk);
+    static const bool bk64 = getenv("SAR_BK64") != nullptr;
     if (narrow) {
         if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 16>), grid, dim3(256), 0, stream, p);
     } else {
-        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
+        if (bk64 && Cin % 64 == 0) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 64>), grid, dim3(256), 0, stream, p);
+        else if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 16>), grid, dim3(256), 0, stream, p);
     }
     SAR_CHECK_LAUNCH();
@@ -439,7 +454,9 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
                                     int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
                                     int accumulate, hipStream_t stream) {
     if (!dy || !w || !dx || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || stride < 1 || stride > 2) return SAR_EINVAL;
-    DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, 1};
+    DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, 1,
+             (unsigned)(((1UL << 32) + W - 1) / W), (unsigned)(((1UL << 32) + H - 1) / H)};
+    if ((long)B * H * W * (W > H ? W : H) >= (1L << 32)) return SAR_EINVAL;
     const long M = (long)B * H * W;
     const int bk = (Cout % 32 == 0) ? 32 : 16;
     const bool narrow = Cin <= 32;
