@@ -32,7 +32,7 @@ struct DgradP {
     unsigned magic_a, magic_b;          // ceil(2^32/W), ceil(2^32/H)
 };
 struct WgradP {
-    const float* x; const float* dy; const float* scale; const float* shift; float* dw;
+    const float* x; const float* dy; const float* scale; const float* shift; float* dw; float* dbias;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, rows_per_slice;
     unsigned magic_wo, magic_ho;        // ceil(2^32 / Wo), ceil(2^32 / Ho): q = umulhi(m, magic) exact for m < 2^32 / d
 };
@@ -338,6 +338,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
     const bool bcol_ok = n0 + bn4 < p.Cout;
     float4 ra[NA], rb[NB];
     unsigned vmask = 0;
+    const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;       // bias gradient = column sums of dy, fused here
+    float4 bsum = zero4();
     auto load = [&](unsigned r0) {
         vmask = 0;
 #pragma unroll
@@ -373,7 +375,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int r = b_row + i * BROWS;
-            if (r < BK) *reinterpret_cast<float4*>(&Bs[r][bn4]) = ((vmask >> (16 + i)) & 1u) ? rb[i] : zero4();
+            if (r < BK) {
+                const float4 v = ((vmask >> (16 + i)) & 1u) ? rb[i] : zero4();
+                *reinterpret_cast<float4*>(&Bs[r][bn4]) = v;
+                if (do_bias) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+            }
         }
     };
     f32x16 acc[TM];
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
         __syncthreads();
     }
     const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cout) return;
+    if (col < p.Cout)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -398,6 +404,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
             const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < Mp) atomicAdd(p.dw + (long)row * p.Cout + col, acc[tm][r]);
         }
+    if (do_bias) {                                                   // block-uniform; Bs is free after the last barrier
+        static_assert(BROWS <= BK, "bias reduction reuses the B tile");
+        *reinterpret_cast<float4*>(&Bs[b_row][bn4]) = bsum;
+        __syncthreads();
+        if (tid < BNt && n0 + tid < p.Cout) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < BROWS; ++g) sum += Bs[g][tid];
+            atomicAdd(p.dbias + n0 + tid, sum);
+        }
+    }
 }
 
 }  // namespace
@@ -476,7 +493,7 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
 }
 
 extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift,
-                                    float* dw, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
+                                    float* dw, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                                     int stride, int pad_top, int pad_left, hipStream_t stream) {
     if (!x || !dy || !dw || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
     const long R = (long)B * Ho * Wo;
@@ -490,7 +507,7 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     rows = ((rows + 31) / 32) * 32;
     if (rows < 128) rows = 128;
     splits = cdiv(R, rows);
-    WgradP p{x, dy, scale, shift, dw, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, (int)rows,
+    WgradP p{x, dy, scale, shift, dw, dbias, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, (int)rows,
              (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
     dim3 grid(cdiv(Mp, 128), cdiv(Cout, narrow ? 32 : 64), splits);
     if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);

@@ -77,10 +77,9 @@ class _Conv:
     def wgrad(self, x, dy, B, bn=None, bias_grad=True):
         """Kernel gradient (+ bias gradient).  A conv whose output feeds a BatchNorm directly has an exactly-zero bias
         gradient (BN backward outputs sum to zero per channel), so callers pass bias_grad=False there."""
-        _call("sar_conv2d_wgrad_f32", x, dy, bn.scale if bn else None, bn.shift if bn else None, self.kernel.g, B, self.H,
-              self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
-        if bias_grad:
-            _call("sar_colsum_f32", dy, self.bias.g, B * self.Ho * self.Wo, self.cout)
+        _call("sar_conv2d_wgrad_f32", x, dy, bn.scale if bn else None, bn.shift if bn else None, self.kernel.g,
+              self.bias.g if bias_grad else None, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.k,
+              self.stride, self.pt, self.pl)
 
 
 class ResNetTrunk(Layer):
@@ -191,8 +190,7 @@ class ResNetTrunk(Layer):
                 # shortcut gradient first (raw block input), then the main path folds it in via `add`
                 if blk["sc"] is not None:
                     dsc = self.scratch("res_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin))
-                    blk["sc"].dgrad(g, dsc, B); blk["sc"].wgrad(blk["x"], g, B, bias_grad=False)
-                    _call("sar_axpy_f32", blk["conv2"].bias.g, blk["sc"].bias.g, 1.0, cout)   # same column sums of g
+                    blk["sc"].dgrad(g, dsc, B); blk["sc"].wgrad(blk["x"], g, B)
                 else:
                     dsc = g
                 da1 = self.scratch("res_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin))
@@ -201,8 +199,7 @@ class ResNetTrunk(Layer):
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
                 if blk["sc"] is not None:
-                    blk["sc"].dgrad(g, gin, B); blk["sc"].wgrad(blk["x"], g, B, bias_grad=False)
-                    _call("sar_axpy_f32", blk["conv2"].bias.g, blk["sc"].bias.g, 1.0, cout)
+                    blk["sc"].dgrad(g, gin, B); blk["sc"].wgrad(blk["x"], g, B)
                     blk["conv1"].dgrad(dc1, gin, B, accumulate=1)
                 else:
                     blk["conv1"].dgrad(dc1, gin, B)

@@ -44,8 +44,9 @@ int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const 
 int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
                          int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int accumulate,
                          sarStream_t stream);
-int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift, float* dw, int B,
-                         int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top,
+/* dbias (nullable): bias gradient = column sums of dy, accumulated by the same launch */
+int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift, float* dw,
+                         float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top,
                          int pad_left, sarStream_t stream);
 /* 7x7/2 stem on the 1-channel fbank image: resnet.py:173 / 191.  C0 <= 64, C0 % 4 == 0. */
 int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ho,

@@ -100,12 +100,15 @@ def test_conv_fwd_dgrad_wgrad(L, case):
     check(dx, dact_ref, name="conv dgrad")
     L.call("sar_conv2d_dgrad_f32", dyd, wd, dx, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 1)
     check(dx, 2 * dact_ref, name="conv dgrad accumulate")
-    dw = zeros(k, k, Cin, Cout)
-    L.call("sar_conv2d_wgrad_f32", xd, dyd, scd, shd, dw, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
-    check(dw, dw_ref, name="conv wgrad")
-    db = zeros(Cout)
-    L.call("sar_colsum_f32", dyd, db, B * Ho * Wo, Cout)
-    check(db, db_ref, name="conv dbias")
+    dw = zeros(k, k, Cin, Cout); db = zeros(Cout)
+    L.call("sar_conv2d_wgrad_f32", xd, dyd, scd, shd, dw, db, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
+    check(dw, dw_ref, name="conv wgrad"); check(db, db_ref, name="conv dbias (fused)")
+    dw2 = zeros(k, k, Cin, Cout)
+    L.call("sar_conv2d_wgrad_f32", xd, dyd, scd, shd, dw2, None, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
+    check(dw2, dw_ref, name="conv wgrad (no bias)")
+    db2 = zeros(Cout)
+    L.call("sar_colsum_f32", dyd, db2, B * Ho * Wo, Cout)
+    check(db2, db_ref, name="colsum")
 
 
 @pytest.mark.parametrize("B,T,D,C0", [(2, 100, 80, 64), (2, 37, 21, 8), (1, 64, 80, 32)])

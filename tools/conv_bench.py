@@ -29,6 +29,6 @@ for name, H, W, ci, co, k, s in STAGES:
     fl = 2.0 * B * Ho * Wo * co * ci * k * k
     t_f = timed(lambda: L.call("sar_conv2d_fwd_f32", x, w, b, sc, sh, None, y, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
     t_d = timed(lambda: L.call("sar_conv2d_dgrad_f32", dy, w, dx, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl, 0))
-    t_w = timed(lambda: L.call("sar_conv2d_wgrad_f32", x, dy, sc, sh, dw, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
+    t_w = timed(lambda: L.call("sar_conv2d_wgrad_f32", x, dy, sc, sh, dw, None, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
     print("%-20s GF %.2f | fwd %6.1f us %5.1f TF | dgrad %6.1f us %5.1f TF | wgrad %6.1f us %5.1f TF" %
           (name, fl / 1e9, t_f * 1e6, fl / t_f / 1e12, t_d * 1e6, fl / t_d / 1e12, t_w * 1e6, fl / t_w / 1e12), flush=True)

@@ -10,7 +10,7 @@ for name, H, W, ci, co in [("s0", 100, 20, 32, 32), ("s1", 50, 10, 64, 64), ("s2
     dy = torch.randn(B, H, W, co, device="cuda"); dx = torch.empty_like(x); dw = torch.zeros_like(w)
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     def dgrad(st): L.call("sar_conv2d_dgrad_f32", dy, w, dx, B, H, W, ci, H, W, co, k, k, s, pt, pl, 0, stream=st.cuda_stream)
-    def wgrad(st): L.call("sar_conv2d_wgrad_f32", x, dy, None, None, dw, B, H, W, ci, H, W, co, k, k, s, pt, pl, stream=st.cuda_stream)
+    def wgrad(st): L.call("sar_conv2d_wgrad_f32", x, dy, None, None, dw, None, B, H, W, ci, H, W, co, k, k, s, pt, pl, stream=st.cuda_stream)
     def run(conc, iters=30):
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
