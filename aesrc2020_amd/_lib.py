@@ -24,6 +24,8 @@ def parse_header(path=HEADER_PATH):
         at = []
         for a in args.split(","):
             a = a.strip()
+            if a in ("void", ""):
+                continue
             if "*" in a or "sarStream_t" in a:
                 at.append(ctypes.c_void_p)
             else:
@@ -71,6 +73,20 @@ def call(name, *args, stream=None):
     rc = L.fn[name](*conv, stream)
     if rc != 0:
         raise RuntimeError("%s failed with status %d (args=%r)" % (name, rc, [getattr(a, "shape", a) for a in args]))
+
+
+CONV_MATH = {"fp32": 0, "bf16x3": 1}
+
+
+def set_conv_math(mode):
+    """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision, default) for the wide conv layers; host-side, process-wide."""
+    rc = lib().fn["sar_set_conv_math"](CONV_MATH[mode])
+    if rc != 0:
+        raise RuntimeError("sar_set_conv_math failed")
+
+
+def get_conv_math():
+    return {v: k for k, v in CONV_MATH.items()}[lib().fn["sar_get_conv_math"]()]
 
 
 def bn_workspace_doubles(C):

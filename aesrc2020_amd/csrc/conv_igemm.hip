@@ -17,6 +17,7 @@
 //  * wgrad decodes its moving rows with a precomputed magic-number division.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -61,23 +62,23 @@ __device__ __forceinline__ unsigned outer_mask(unsigned hm, unsigned wm, int KH,
 }
 
 // MFMA over one staged k-tile with the LDS operands of step k+1 prefetched ahead of the MFMAs of step k.
-template <int WM, int WN, int TM, int BK, int LDA, int LDB>
+template <int WM, int WN, int TM, int BK, int LDA, int LDB, int K0 = 0, int K1 = BK>
 __device__ __forceinline__ void mma_tile(f32x16 (&acc)[TM], const float (*As)[LDA], const float (*Bs)[LDB], int wm, int wn, int lane) {
     const int kr = lane >> 5, c = lane & 31;
     float a[TM], b, an[TM], bn;
-    b = Bs[kr][wn * 32 + c];
+    b = Bs[K0 + kr][wn * 32 + c];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) a[tm] = As[kr][(wm * TM + tm) * 32 + c];
+    for (int tm = 0; tm < TM; ++tm) a[tm] = As[K0 + kr][(wm * TM + tm) * 32 + c];
 #pragma unroll
-    for (int k = 0; k < BK; k += 2) {
-        if (k + 2 < BK) {
+    for (int k = K0; k < K1; k += 2) {
+        if (k + 2 < K1) {
             bn = Bs[k + 2 + kr][wn * 32 + c];
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) an[tm] = As[k + 2 + kr][(wm * TM + tm) * 32 + c];
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b, acc[tm], 0, 0, 0);
-        if (k + 2 < BK) {
+        if (k + 2 < K1) {
             b = bn;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) a[tm] = an[tm];
@@ -85,15 +86,38 @@ __device__ __forceinline__ void mma_tile(f32x16 (&acc)[TM], const float (*As)[LD
     }
 }
 
+// Operand group = 4 k-steps (8 k values) worth of MFMA operands for one wave: a[j][tm], b[j].
+template <int TM> struct OpSet { float a[4][TM]; float b[4]; };
+
+template <int WM, int WN, int TM, int LDA, int LDB>
+__device__ __forceinline__ void rd_group(OpSet<TM>& o, const float (*As)[LDA], const float (*Bs)[LDB], int g, int wm, int wn, int lane) {
+    const int kr = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o.b[j] = Bs[g * 8 + 2 * j + kr][wn * 32 + c];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) o.a[j][tm] = As[g * 8 + 2 * j + kr][(wm * TM + tm) * 32 + c];
+    }
+}
+template <int TM>
+__device__ __forceinline__ void mm_group(f32x16 (&acc)[TM], const OpSet<TM>& o) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[j][tm], o.b[j], acc[tm], 0, 0, 0);
+}
+#define SAR_SB() __builtin_amdgcn_sched_barrier(0)
+
 // ------------------------------------------------------------------ forward
-template <int WM, int WN, int TM, int BK>
+template <int WM, int WN, int TM, int BK, bool DBUF>
 __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
     using T = Tile<WM, WN, TM, BK>;
     constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
     constexpr int NA = (BMt * KQ + NT - 1) / NT, NB = (BK * BNt / 4 + NT - 1) / NT;
     static_assert(NT % KQ == 0 && (BMt * KQ) % NT == 0, "A-tile mapping");
-    __shared__ float As[BK][T::LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][T::LDB];
+    constexpr int NBUF = DBUF ? 2 : 1;                                // DBUF: one barrier per k-tile, 2x LDS
+    __shared__ float As2[NBUF][BK][T::LDA];
+    __shared__ __attribute__((aligned(16))) float Bs2[NBUF][BK][T::LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const unsigned M = (unsigned)(p.B * p.Ho * p.Wo);
@@ -146,7 +170,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
             rb[i] = *reinterpret_cast<const float4*>(p.w + off);
         }
     };
-    auto store = [&]() {
+    auto store = [&](int buf) {
+        float (*As)[T::LDA] = As2[buf]; float (*Bs)[T::LDB] = Bs2[buf];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = (tid + i * NT) / KQ;
@@ -168,13 +193,45 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
     // split-K: slice z owns k-tiles [kt0, nkt)
     const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
     const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
-    if (kt0 < nkt) load(kt0);
-    for (int kt = kt0; kt < nkt; ++kt) {
-        if (!(p.dbg & 4)) store();
-        __syncthreads();
-        if (kt + 1 < nkt && !(p.dbg & 1)) load(kt + 1);
-        if (!(p.dbg & 2)) mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As, Bs, wm, wn, lane);
-        __syncthreads();
+    if constexpr (DBUF) {
+        // Software pipeline: while the MFMAs of tile kt run from LDS buffer `cur`, the registers holding tile kt+1 (loaded one
+        // iteration ago) are written to the other buffer and the loads of tile kt+2 are issued; one barrier per k-tile.
+        // Tail iterations re-load the last tile (clamped index) so the loop body stays branch-free.
+        if (kt0 < nkt) {
+            load(kt0); store(0);
+            load(min(kt0 + 1, nkt - 1));
+            __syncthreads();
+            constexpr int NG = BK / 8;                                   // operand groups per k-tile
+            OpSet<TM> s0, s1;
+            for (int kt = kt0; kt < nkt; ++kt) {
+                const int cur = (kt - kt0) & 1;
+                // pinned schedule (sched_barrier): LDS reads of group g+1 are in flight while the MFMAs of group g execute;
+                // the LDS stores of the next tile ride on the last group; hipcc otherwise sinks the reads next to their use
+                rd_group<WM, WN, TM, T::LDA, T::LDB>(s0, As2[cur], Bs2[cur], 0, wm, wn, lane);
+                SAR_SB();
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    OpSet<TM>& oc = (g & 1) ? s1 : s0;
+                    OpSet<TM>& on = (g & 1) ? s0 : s1;
+                    if (g + 1 < NG) rd_group<WM, WN, TM, T::LDA, T::LDB>(on, As2[cur], Bs2[cur], g + 1, wm, wn, lane);
+                    else store(cur ^ 1);
+                    SAR_SB();
+                    mm_group<TM>(acc, oc);
+                    SAR_SB();
+                }
+                load(min(kt + 2, nkt - 1));
+                __syncthreads();
+            }
+        }
+    } else {
+        if (kt0 < nkt) load(kt0);
+        for (int kt = kt0; kt < nkt; ++kt) {
+            store(0);
+            __syncthreads();
+            if (kt + 1 < nkt) load(kt + 1);
+            mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As2[0], Bs2[0], wm, wn, lane);
+            __syncthreads();
+        }
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= p.Cout) return;
@@ -190,6 +247,170 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
             float v = acc[tm][r] + bv;
             if (p.res && lead) v += p.res[o];
             if (p.splitk > 1) atomicAdd(p.y + o, v);       // y zeroed by the launcher
+            else p.y[o] = v;
+        }
+}
+
+// ------------------------------------------------------------------ forward, bf16x3 split-precision MFMA
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest): A*B ~= Ah*Bh + Ah*Bl + Al*Bh on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped Al*Bl term is ~2^-16 relative, i.e. fp32-class accuracy
+// at 3/16 of the fp32-MFMA pipe time.  LDS tiles are [row][k] bf16 (k contiguous, 80-byte rows: conflict-free
+// ds_read_b128 operand fetches); global memory stays fp32.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 h = (__bf16)f[j];
+        hi[j] = h; lo[j] = (__bf16)(f[j] - (float)h);
+    }
+}
+
+template <int WM, int WN, int TM, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
+    using T = Tile<WM, WN, TM, BK>;
+    constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
+    constexpr int NA = (BMt * KQ + NT - 1) / NT;
+    constexpr int KPT = BK * BNt / NT;                                // consecutive k values per thread for the B tile (8 or 4)
+    static_assert(NT % BNt == 0 && KPT * (NT / BNt) == BK && (KPT == 8 || KPT == 4), "B-tile mapping");
+    constexpr int BKP = BK + 8;                                       // padded row (elements): 80 B for BK = 32
+    static_assert(NT % KQ == 0 && (BMt * KQ) % NT == 0, "A-tile mapping");
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BMt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[2][BMt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BNt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bl[2][BNt][BKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned M = (unsigned)(p.B * p.Ho * p.Wo);
+    const int K = p.KH * p.KW * p.Cin;
+    const unsigned m0 = blockIdx.x * BMt;
+    const int n0 = blockIdx.y * BNt;
+    const int kq = (tid % KQ) * 4;
+    int abase[NA]; unsigned avalid[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const unsigned m = m0 + (tid + i * NT) / KQ;
+        abase[i] = 0; avalid[i] = 0;
+        if (m < M) {
+            const unsigned t = fdiv(m, p.Wo, p.magic_a), wo = m - t * (unsigned)p.Wo;
+            const unsigned n = fdiv(t, p.Ho, p.magic_b), ho = t - n * (unsigned)p.Ho;
+            const int h0 = (int)ho * p.stride - p.pt, w0 = (int)wo * p.stride - p.pl;
+            abase[i] = (((int)n * p.H + h0) * p.W + w0) * p.Cin + kq;
+            unsigned hm = 0, wmk = 0;
+            for (int kk = 0; kk < p.KH; ++kk) hm |= (unsigned)(h0 + kk >= 0 && h0 + kk < p.H) << kk;
+            for (int kk = 0; kk < p.KW; ++kk) wmk |= (unsigned)(w0 + kk >= 0 && w0 + kk < p.W) << kk;
+            avalid[i] = outer_mask(hm, wmk, p.KH, p.KW);
+        }
+    }
+    const int b_n = tid % BNt, b_k = (tid / BNt) * KPT;               // B: weights (k, n) in memory; lanes run along n (coalesced)
+    const bool bcol_ok = n0 + b_n < p.Cout;
+    struct Regs { float4 ra[NA]; float rb[KPT]; float4 sc, sh; unsigned vmask; };
+    Regs R0, R1;                                                      // two sets: prefetch distance of two k-tiles
+    R0.sc = R1.sc = make_float4(1, 1, 1, 1); R0.sh = R1.sh = zero4(); R0.vmask = R1.vmask = 0;
+    auto load = [&](Regs& R, int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int tapoff = (kh * p.W + kw) * p.Cin + ci0;
+        if (p.scale) { R.sc = *reinterpret_cast<const float4*>(p.scale + ci0 + kq); R.sh = *reinterpret_cast<const float4*>(p.shift + ci0 + kq); }
+        R.vmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned ok = (avalid[i] >> tap) & 1u;
+            const int off = ok ? abase[i] + tapoff : 0;
+            R.ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+            R.vmask |= ok << i;
+        }
+        const int boff = bcol_ok ? (k0 + b_k) * p.Cout + n0 + b_n : 0;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) R.rb[j] = p.w[boff + (bcol_ok ? j * p.Cout : 0)];
+    };
+    auto store = [&](const Regs& R, int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = (tid + i * NT) / KQ;
+            float4 v = zero4();
+            if ((R.vmask >> i) & 1u) v = p.scale ? bn_relu4(R.ra[i], R.sc, R.sh) : R.ra[i];
+            bf16x4 hi, lo; split4(v, hi, lo);
+            *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
+        }
+        {                                                            // B: KPT consecutive k of one column -> one row segment
+            __bf16 hi[KPT], lo[KPT];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const float f = bcol_ok ? R.rb[j] : 0.f;
+                const __bf16 h = (__bf16)f;
+                hi[j] = h; lo[j] = (__bf16)(f - (float)h);
+            }
+            if constexpr (KPT == 8) {
+                bf16x8 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { vh[j] = hi[j]; vl[j] = lo[j]; }
+                *reinterpret_cast<bf16x8*>(&Bh[buf][b_n][b_k]) = vh; *reinterpret_cast<bf16x8*>(&Bl[buf][b_n][b_k]) = vl;
+            } else {
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vh[j] = hi[j]; vl[j] = lo[j]; }
+                *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k]) = vh; *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k]) = vl;
+            }
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
+    const int kg = (lane >> 5) * 8, rc = lane & 31;
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int st = 0; st < BK / 16; ++st) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[cur][wn * 32 + rc][st * 16 + kg]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[cur][wn * 32 + rc][st * 16 + kg]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);      // small terms first
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tm], 0, 0, 0);
+            }
+        }
+    };
+    // Pipeline with a prefetch distance of TWO k-tiles: with the matrix phase this short (~400 cycles per tile) a
+    // one-tile-ahead prefetch is latency-bound.  Tile kt+1 sits in one register set (loaded two iterations ago) and is
+    // written to the idle LDS buffer, then that set is re-filled with tile kt+3.  Clamped tile indices keep the tail branch-free.
+    if (kt0 < nkt) {
+        const int last = nkt - 1;
+        load(R0, kt0); load(R1, min(kt0 + 1, last));
+        store(R0, 0); load(R0, min(kt0 + 2, last));
+        __syncthreads();
+        for (int kt = kt0; kt < nkt; kt += 2) {
+            mma(0); store(R1, 1); load(R1, min(kt + 3, last));
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                mma(1); store(R0, 0); load(R0, min(kt + 4, last));
+                __syncthreads();
+            }
+        }
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.Cout) return;
+    const bool lead = blockIdx.z == 0;
+    const float bv = (p.bias && lead) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= M) continue;
+            const long o = (long)row * p.Cout + col;
+            float v = acc[tm][r] + bv;
+            if (p.res && lead) v += p.res[o];
+            if (p.splitk > 1) atomicAdd(p.y + o, v);
             else p.y[o] = v;
         }
 }
@@ -300,6 +521,135 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
             if (row >= M) continue;
             float* d = p.dx + (long)row * p.Cin + col;
             if (p.splitk > 1) atomicAdd(d, acc[tm][r]);                 // dx zeroed by the launcher unless accumulating
+            else *d = p.accumulate ? (*d + acc[tm][r]) : acc[tm][r];
+        }
+}
+
+// ------------------------------------------------------------------ dgrad, bf16x3 split-precision MFMA (see conv_fwd_x3_kernel)
+template <int WM, int WN, int TM, int BK>
+__global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
+    using T = Tile<WM, WN, TM, BK>;
+    constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
+    constexpr int NA = (BMt * KQ + NT - 1) / NT;
+    constexpr int KPT = BK * BNt / NT;                                // consecutive k (= co) per thread for the B tile
+    static_assert(NT % KQ == 0 && (BMt * KQ) % NT == 0 && (KPT == 8 || KPT == 4), "tile mapping");
+    constexpr int BKP = BK + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BMt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[2][BMt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BNt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bl[2][BNt][BKP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned M = (unsigned)(p.B * p.H * p.W);
+    const int K = p.KH * p.KW * p.Cout;
+    const unsigned m0 = blockIdx.x * BMt;
+    const int n0 = blockIdx.y * BNt;
+    const int kq = (tid % KQ) * 4;
+    int abase[NA]; unsigned avalid[NA]; int aph[NA], apw[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const unsigned m = m0 + (tid + i * NT) / KQ;
+        abase[i] = 0; avalid[i] = 0; aph[i] = 0; apw[i] = 0;
+        if (m < M) {
+            const unsigned t = fdiv(m, p.W, p.magic_a), w_ = m - t * (unsigned)p.W;
+            const unsigned n = fdiv(t, p.H, p.magic_b), h = t - n * (unsigned)p.H;
+            const int hq = (int)h + p.pt, wq = (int)w_ + p.pl;
+            if (p.stride == 1) {
+                abase[i] = (((int)n * p.Ho + hq) * p.Wo + wq) * p.Cout + kq;
+            } else {
+                aph[i] = hq & 1; apw[i] = wq & 1;
+                abase[i] = (((int)n * p.Ho + (hq >> 1)) * p.Wo + (wq >> 1)) * p.Cout + kq;
+            }
+            unsigned hm = 0, wmk = 0;
+            const int sh_ = p.stride - 1;
+            for (int kk = 0; kk < p.KH; ++kk) { const int hn = hq - kk; hm |= (unsigned)(hn >= 0 && (hn & sh_) == 0 && (hn >> sh_) < p.Ho) << kk; }
+            for (int kk = 0; kk < p.KW; ++kk) { const int wn_ = wq - kk; wmk |= (unsigned)(wn_ >= 0 && (wn_ & sh_) == 0 && (wn_ >> sh_) < p.Wo) << kk; }
+            avalid[i] = outer_mask(hm, wmk, p.KH, p.KW);
+        }
+    }
+    // B[k = co][n = ci] = w[tap][ci][co]: co is contiguous in memory, so a thread reads KPT consecutive k of one row n
+    constexpr int GPR = BK / KPT;                                     // k-groups per row
+    const int b_n = tid / GPR, b_k = (tid % GPR) * KPT;
+    const bool brow_ok = n0 + b_n < p.Cin;
+    struct Regs { float4 ra[NA]; float4 rb[KPT / 4]; unsigned vmask; };
+    Regs R0, R1; R0.vmask = R1.vmask = 0;
+    auto load = [&](Regs& R, int kt) {
+        const int k0 = kt * BK;
+        const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        R.vmask = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const unsigned ok = (avalid[i] >> tap) & 1u;
+            const int dh = p.stride == 1 ? kh : ((kh - aph[i]) >> 1), dw = p.stride == 1 ? kw : ((kw - apw[i]) >> 1);
+            const int off = ok ? abase[i] - (dh * p.Wo + dw) * p.Cout + co0 : 0;
+            R.ra[i] = *reinterpret_cast<const float4*>(p.dy + off);
+            R.vmask |= ok << i;
+        }
+        const int boff = brow_ok ? (tap * p.Cin + n0 + b_n) * p.Cout + co0 + b_k : 0;
+#pragma unroll
+        for (int j = 0; j < KPT / 4; ++j) R.rb[j] = *reinterpret_cast<const float4*>(p.w + boff + (brow_ok ? 4 * j : 0));
+    };
+    auto store = [&](const Regs& R, int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = (tid + i * NT) / KQ;
+            bf16x4 hi, lo; split4(((R.vmask >> i) & 1u) ? R.ra[i] : zero4(), hi, lo);
+            *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < KPT / 4; ++j) {
+            bf16x4 hi, lo; split4(brow_ok ? R.rb[j] : zero4(), hi, lo);
+            *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k + 4 * j]) = hi; *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k + 4 * j]) = lo;
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
+    const int kg = (lane >> 5) * 8, rc = lane & 31;
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int st = 0; st < BK / 16; ++st) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[cur][wn * 32 + rc][st * 16 + kg]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[cur][wn * 32 + rc][st * 16 + kg]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tm], 0, 0, 0);
+            }
+        }
+    };
+    if (kt0 < nkt) {
+        const int last = nkt - 1;
+        load(R0, kt0); load(R1, min(kt0 + 1, last));
+        store(R0, 0); load(R0, min(kt0 + 2, last));
+        __syncthreads();
+        for (int kt = kt0; kt < nkt; kt += 2) {
+            mma(0); store(R1, 1); load(R1, min(kt + 3, last));
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                mma(1); store(R0, 0); load(R0, min(kt + 4, last));
+                __syncthreads();
+            }
+        }
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.Cin) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= M) continue;
+            float* d = p.dx + (long)row * p.Cin + col;
+            if (p.splitk > 1) atomicAdd(d, acc[tm][r]);
             else *d = p.accumulate ? (*d + acc[tm][r]) : acc[tm][r];
         }
 }
@@ -420,6 +770,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
 }  // namespace
 
 // 32-bit element offsets and the magic-number division bound the supported sizes (far above the SAR-Net shapes).
+// 0 = fp32 MFMA (exact fp32 fma chains), 1 = bf16x3 split precision (default; 2^-17 relative per product).
+static int g_conv_math = (getenv("SAR_CONV_MATH") && !strcmp(getenv("SAR_CONV_MATH"), "fp32")) ? 0 : 1;
+extern "C" int sar_set_conv_math(int mode) { if (mode < 0 || mode > 1) return SAR_EINVAL; g_conv_math = mode; return SAR_OK; }
+extern "C" int sar_get_conv_math(void) { return g_conv_math; }
+
 static bool conv_args_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW) {
     const long in_e = (long)B * H * W * Cin, out_e = (long)B * Ho * Wo * Cout;
     return (Cin % 16 == 0) && (Cout % 16 == 0) && KH * KW <= 16 && in_e < (1L << 31) && out_e < (1L << 31) &&
@@ -443,25 +798,48 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
                                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
                                   hipStream_t stream) {
     if (!x || !w || !y || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
-    static const int dbg = getenv("SAR_CONV_DBG") ? atoi(getenv("SAR_CONV_DBG")) : 0;
-    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1, dbg,
+    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1, 0,
             (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
     if ((long)B * Ho * Wo * (Wo > Ho ? Wo : Ho) >= (1L << 32)) return SAR_EINVAL;
     const long M = (long)B * Ho * Wo;
     const int bk = (Cin % 32 == 0) ? 32 : 16;
     const bool narrow = Cout <= 32;
-    const int tiles = cdiv(M, 128) * cdiv(Cout, narrow ? 32 : 64);
-    p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
-    if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
-    dim3 grid(cdiv(M, 128), cdiv(Cout, narrow ? 32 : 64), p.splitk);
-    static const bool bk64 = getenv("SAR_BK64") != nullptr;
+    const bool fp32_math = g_conv_math == 0;
+    if (!fp32_math && bk == 32 && !narrow) {                        // bf16x3 split-precision path (default for Cout >= 64;
+        if (false) {                                                // Cout = 32 keeps the fp32 kernel: its LDS footprint allows 7 blocks/CU)
+        } else if (cdiv(M, 128) * cdiv(Cout, 64) >= 300) {
+            dim3 grid(cdiv(M, 128), cdiv(Cout, 64), 1);
+            hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
+        } else {
+            const int tiles = cdiv(M, 64) * cdiv(Cout, 64);
+            p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
+            if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
+            dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
+            hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 1, 32>), grid, dim3(256), 0, stream, p);
+        }
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
+    // tile choice (measured, tools/conv_bench.py): Cout <= 32 -> 128x32 single-buffered (high occupancy, 1000 blocks);
+    // otherwise 128x64 double-buffered when that already gives >= 300 blocks, else 64x64 (two co-resident blocks per CU)
     if (narrow) {
-        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 16>), grid, dim3(256), 0, stream, p);
+        const int tiles = cdiv(M, 128) * cdiv(Cout, 32);
+        p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
+        if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
+        dim3 grid(cdiv(M, 128), cdiv(Cout, 32), p.splitk);
+        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 32, false>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 16, false>), grid, dim3(256), 0, stream, p);
+    } else if (cdiv(M, 128) * cdiv(Cout, 64) >= 300) {
+        dim3 grid(cdiv(M, 128), cdiv(Cout, 64), 1);
+        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 32, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 16, true>), grid, dim3(256), 0, stream, p);
     } else {
-        if (bk64 && Cin % 64 == 0) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 64>), grid, dim3(256), 0, stream, p);
-        else if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 16>), grid, dim3(256), 0, stream, p);
+        const int tiles = cdiv(M, 64) * cdiv(Cout, 64);
+        p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
+        if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
+        dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
+        if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 1, 32, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 1, 16, true>), grid, dim3(256), 0, stream, p);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -477,6 +855,19 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
     const long M = (long)B * H * W;
     const int bk = (Cout % 32 == 0) ? 32 : 16;
     const bool narrow = Cin <= 32;
+    const bool fp32_math = g_conv_math == 0;
+    if (!fp32_math && bk == 32 && !narrow) {                        // bf16x3 split-precision path
+        if (cdiv(M, 128) * cdiv(Cin, 64) >= 300) {
+            hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 2, 32>), dim3(cdiv(M, 128), cdiv(Cin, 64), 1), dim3(256), 0, stream, p);
+        } else {
+            const int tiles1 = cdiv(M, 64) * cdiv(Cin, 64);
+            p.splitk = pick_conv_splitk(tiles1, KH * KW * Cout / bk);
+            if (p.splitk > 1 && !accumulate && sar_zero_async(dx, sizeof(float) * M * Cin, stream) != hipSuccess) return SAR_ELAUNCH;
+            hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 1, 32>), dim3(cdiv(M, 64), cdiv(Cin, 64), p.splitk), dim3(256), 0, stream, p);
+        }
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     const int tiles = cdiv(M, 128) * cdiv(Cin, narrow ? 32 : 64);
     p.splitk = pick_conv_splitk(tiles, KH * KW * Cout / bk);
     if (p.splitk > 1 && !accumulate && sar_zero_async(dx, sizeof(float) * M * Cin, stream) != hipSuccess) return SAR_ELAUNCH;

@@ -48,6 +48,12 @@ int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int 
 int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift, float* dw,
                          float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top,
                          int pad_left, sarStream_t stream);
+/* Matrix-core math of the 3x3/1x1 convolutions with >= 64 output (fwd) / input (dgrad) channels:
+ * 0 = fp32 MFMA (bit-exact fp32 fma chains); 1 = bf16x3 split precision (default): x = hi + lo in bf16,
+ * A*B ~= Ah*Bh + Ah*Bl + Al*Bh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, ~2^-17 relative error per product.
+ * Process-wide host-side setting read at launch time (also: env SAR_CONV_MATH=fp32). */
+int sar_set_conv_math(int mode);
+int sar_get_conv_math(void);
 /* 7x7/2 stem on the 1-channel fbank image: resnet.py:173 / 191.  C0 <= 64, C0 % 4 == 0. */
 int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ho,
                              int Wo, int C0, int pad_top, int pad_left, sarStream_t stream);

@@ -24,11 +24,12 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(protos), (exported ^ set(protos))
     # every entry point takes the stream last and returns int (or size_t for workspace queries)
     for name, (ret, at) in protos.items():
-        if name.endswith("_bytes"):
+        if name.endswith("_bytes") or name.endswith("_conv_math"):
             continue
         assert at[-1].__name__ == "c_void_p", name
     assert _lib.ctc_workspace_bytes(64, 39, 72) == 4 * (64 * 39 * 145 + 64 * 39)    # host-only query, no GPU needed
     assert _lib.bn_workspace_doubles(32) == 258 * 32
+    assert _lib.get_conv_math() in ("fp32", "bf16x3")
 
 
 def test_no_cpu_fallback():
