@@ -767,6 +767,188 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_wgrad_kernel(WgradP p) {
     }
 }
 
+// ------------------------------------------------------------------ wgrad, bf16x3 split-precision MFMA
+// dw[m' = (tap, ci)][co] += sum_m P(x)[m][m'] * dy[m][co].  Both MFMA operands need the reduction index m contiguous per
+// lane, while memory has the channel index contiguous: every thread therefore stages a 4 (rows m) x 4 (channels)
+// micro-tile -- four coalesced float4 row loads, BN+ReLU prologue, hi/lo split, 4x4 transpose in registers -- and writes
+// four 8-byte LDS rows [channel][m..m+3].  Block tile 128 (m') x BNt (co) x 32 (m), 4 waves.
+// The im2col row decode (two divisions, bounds tests) is done ONCE per block into an LDS table {pixel offset, valid-tap
+// mask}; the steady-state loop is then a table read, a bit test and a select per row (the kernel is VALU-issue bound at
+// 1-2 waves per SIMD, not MFMA bound).
+constexpr int WG_MAX_ROWS = 1024;                                     // rows per reduction slice (launcher guarantees it)
+template <int BNt>
+__global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
+    constexpr int BMt = 128, BK = 32, BKP = BK + 8;
+    constexpr int WN = BNt / 32, WM = 4 / WN, TM = BMt / (32 * WM);   // BNt = 64: 2x2 waves, TM = 2 ; BNt = 32: 4x1 waves, TM = 1
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BMt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Al[2][BMt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BNt][BKP];
+    __shared__ __attribute__((aligned(16))) __bf16 Bl[2][BNt][BKP];
+    __shared__ __attribute__((aligned(16))) int2 rowinfo[WG_MAX_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const unsigned R = (unsigned)(p.B * p.Ho * p.Wo);
+    const int Mp = p.KH * p.KW * p.Cin;
+    const int m0 = blockIdx.x * BMt, n0 = blockIdx.y * BNt;
+    const unsigned r_begin = blockIdx.z * (unsigned)p.rows_per_slice;
+    const unsigned r_end = min(R, r_begin + (unsigned)p.rows_per_slice);
+    if (r_begin >= r_end) return;
+    const int ntile = (int)((r_end - r_begin + BK - 1) / BK);
+    for (int r = tid; r < ntile * BK; r += 256) {
+        const unsigned m = r_begin + r;
+        int2 info = make_int2(0, 0);
+        if (m < r_end) {
+            const unsigned t = fdiv(m, p.Wo, p.magic_wo), wo = m - t * (unsigned)p.Wo;
+            const unsigned n = fdiv(t, p.Ho, p.magic_ho), ho = t - n * (unsigned)p.Ho;
+            const int h0 = (int)ho * p.stride - p.pt, w0 = (int)wo * p.stride - p.pl;
+            unsigned hm = 0, wmk = 0;
+            for (int kk = 0; kk < p.KH; ++kk) hm |= (unsigned)(h0 + kk >= 0 && h0 + kk < p.H) << kk;
+            for (int kk = 0; kk < p.KW; ++kk) wmk |= (unsigned)(w0 + kk >= 0 && w0 + kk < p.W) << kk;
+            info.x = (((int)n * p.H + h0) * p.W + w0) * p.Cin;
+            info.y = (int)outer_mask(hm, wmk, p.KH, p.KW);
+        }
+        rowinfo[r] = info;
+    }
+    // A' micro-tile of this thread: channels mp..mp+3 (fixed), rows a_r..a_r+3 of the current k-tile
+    const int a_c4 = tid % (BMt / 4), a_r = (tid / (BMt / 4)) * 4;    // 32 column groups x 8 row groups
+    const int mp = m0 + a_c4 * 4;
+    int a_tap = 31, a_ci = 0, a_tapoff = 0;                            // tap 31 is never valid: columns beyond Mp load nothing
+    if (mp < Mp) {
+        a_tap = mp / p.Cin; a_ci = mp - a_tap * p.Cin;
+        const int kh = a_tap / p.KW, kw = a_tap - kh * p.KW;
+        a_tapoff = (kh * p.W + kw) * p.Cin + a_ci;
+    }
+    float4 asc = make_float4(1, 1, 1, 1), ash = zero4();
+    if (p.scale) { asc = *reinterpret_cast<const float4*>(p.scale + a_ci); ash = *reinterpret_cast<const float4*>(p.shift + a_ci); }
+    const float relu_lo = p.scale ? 0.f : -INFINITY;                  // no prologue: identity
+    // B' micro-tile: channels b_c4*4.. of dy, rows b_r..b_r+3 (threads beyond the tile idle)
+    const int b_c4 = tid % (BNt / 4), b_r = (tid / (BNt / 4)) * 4;
+    const bool b_act = b_r < BK;
+    const bool bcol_ok = n0 + b_c4 * 4 < p.Cout;
+    const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
+    const float* dyb = p.dy + (bcol_ok ? n0 + b_c4 * 4 : 0);
+    float4 bsum = zero4();
+    struct Regs { float4 ra[4], rb[4]; unsigned vmask; };
+    Regs R0, R1; R0.vmask = R1.vmask = 0;
+    auto load = [&](Regs& Rg, int t) {
+        const int rl = min(t, ntile - 1) * BK;                        // clamped tile: tail stays branch-free
+        Rg.vmask = 0;
+        const int4 i01 = *reinterpret_cast<const int4*>(&rowinfo[rl + a_r]);
+        const int4 i23 = *reinterpret_cast<const int4*>(&rowinfo[rl + a_r + 2]);
+        const int base[4] = {i01.x, i01.z, i23.x, i23.z};
+        const int mask[4] = {i01.y, i01.w, i23.y, i23.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ok = ((unsigned)mask[i] >> a_tap) & 1u;
+            const int off = ok ? base[i] + a_tapoff : 0;
+            Rg.ra[i] = *reinterpret_cast<const float4*>(p.x + off);
+            Rg.vmask |= ok << i;
+        }
+        if (b_act) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned m = r_begin + rl + b_r + i;
+                const unsigned ok = (bcol_ok && m < r_end) ? 1u : 0u;
+                const unsigned off = ok ? m * (unsigned)p.Cout : 0u;
+                Rg.rb[i] = *reinterpret_cast<const float4*>(dyb + off);
+                Rg.vmask |= ok << (8 + i);
+            }
+        }
+    };
+    auto split_store = [&](const float (&v)[4][4], __bf16 (*Hh)[BKP], __bf16 (*Ll)[BKP], int c0, int r0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                 // transpose: channel j gets its 4 consecutive rows
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const __bf16 h = (__bf16)v[i][j]; hi[i] = h; lo[i] = (__bf16)(v[i][j] - (float)h); }
+            *reinterpret_cast<bf16x4*>(&Hh[c0 + j][r0]) = hi; *reinterpret_cast<bf16x4*>(&Ll[c0 + j][r0]) = lo;
+        }
+    };
+    auto store = [&](const Regs& Rg, int buf) {
+        {
+            float v[4][4];                                            // [row i][channel j]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (Rg.vmask >> i) & 1u;                 // padding stays exactly zero (selects, no branches)
+                const float4 q = Rg.ra[i];
+                v[i][0] = ok ? fmaxf(fmaf(q.x, asc.x, ash.x), relu_lo) : 0.f; v[i][1] = ok ? fmaxf(fmaf(q.y, asc.y, ash.y), relu_lo) : 0.f;
+                v[i][2] = ok ? fmaxf(fmaf(q.z, asc.z, ash.z), relu_lo) : 0.f; v[i][3] = ok ? fmaxf(fmaf(q.w, asc.w, ash.w), relu_lo) : 0.f;
+            }
+            split_store(v, Ah[buf], Al[buf], a_c4 * 4, a_r);
+        }
+        if (b_act) {
+            float v[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (Rg.vmask >> (8 + i)) & 1u;
+                const float4 q = Rg.rb[i];
+                v[i][0] = ok ? q.x : 0.f; v[i][1] = ok ? q.y : 0.f; v[i][2] = ok ? q.z : 0.f; v[i][3] = ok ? q.w : 0.f;
+                if (do_bias) { bsum.x += v[i][0]; bsum.y += v[i][1]; bsum.z += v[i][2]; bsum.w += v[i][3]; }
+            }
+            split_store(v, Bh[buf], Bl[buf], b_c4 * 4, b_r);
+        }
+    };
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+    const int kg = (lane >> 5) * 8, rc = lane & 31;
+    auto mma = [&](int cur) {
+#pragma unroll
+        for (int st = 0; st < BK / 16; ++st) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bh[cur][wn * 32 + rc][st * 16 + kg]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bl[cur][wn * 32 + rc][st * 16 + kg]);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tm], 0, 0, 0);
+            }
+        }
+    };
+    __syncthreads();                                                 // row table complete
+    // same two-tile-ahead pipeline as the forward kernel
+    load(R0, 0); load(R1, 1);
+    store(R0, 0); load(R0, 2);
+    __syncthreads();
+    for (int t = 0; t < ntile; t += 2) {
+        mma(0);
+        if (t + 1 < ntile) store(R1, 1);                              // a clamped re-load of the last tile must not reach the bias sum
+        load(R1, t + 3);
+        __syncthreads();
+        if (t + 1 < ntile) {
+            mma(1);
+            if (t + 2 < ntile) store(R0, 0);
+            load(R0, t + 4);
+            __syncthreads();
+        }
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < p.Cout)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < Mp) atomicAdd(p.dw + (long)row * p.Cout + col, acc[tm][r]);
+        }
+    if (do_bias) {                                                   // block-uniform; the A tile is free after the last barrier
+        float* scr = reinterpret_cast<float*>(&Ah[0][0][0]);         // [8 row groups][BNt]
+        __syncthreads();
+        if (b_act) *reinterpret_cast<float4*>(&scr[(b_r / 4) * BNt + b_c4 * 4]) = bsum;
+        __syncthreads();
+        if (tid < BNt && n0 + tid < p.Cout) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < BK / 4; ++g) sum += scr[g * BNt + tid];
+            atomicAdd(p.dbias + n0 + tid, sum);
+        }
+    }
+}
+
 }  // namespace
 
 // 32-bit element offsets and the magic-number division bound the supported sizes (far above the SAR-Net shapes).
@@ -893,14 +1075,25 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     const bool narrow = Cout <= 32;
     // split the reduction so the grid fills 256 CUs a few times over
     const int tiles = cdiv(Mp, 128) * cdiv(Cout, narrow ? 32 : 64);
-    int splits = (1024 + tiles - 1) / tiles;
+    // measured (tools/conv_bench.py): the split-precision kernel (2 blocks/CU, atomic epilogue) is best at ~512 blocks,
+    // the fp32 kernel (6 blocks/CU) at ~1024; Cout <= 32 keeps the fp32 kernel
+    const bool x3 = g_conv_math == 1 && !narrow;
+    static const int target_env = getenv("SAR_WGRAD_BLOCKS") ? atoi(getenv("SAR_WGRAD_BLOCKS")) : 0;
+    const int target = target_env ? target_env : (x3 ? 512 : 1024);
+    int splits = (target + tiles - 1) / tiles;
     long rows = (R + splits - 1) / splits;
     rows = ((rows + 31) / 32) * 32;
     if (rows < 128) rows = 128;
+    if (rows > WG_MAX_ROWS) rows = WG_MAX_ROWS;                       // bound of the per-block row table (bf16x3 kernel)
     splits = cdiv(R, rows);
     WgradP p{x, dy, scale, shift, dw, dbias, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, (int)rows,
              (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
     dim3 grid(cdiv(Mp, 128), cdiv(Cout, narrow ? 32 : 64), splits);
+    if (x3) {                                                        // bf16x3 split-precision path
+        hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), grid, dim3(256), 0, stream, p);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     if (narrow) hipLaunchKernelGGL((conv_wgrad_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
     SAR_CHECK_LAUNCH();

@@ -21,6 +21,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (dense)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
+# bf16x3 split precision issues three bf16 MFMAs per algorithmic fp32 multiply-add block: its algorithmic ceiling
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -73,9 +76,17 @@ def conv_roofline(model, B, iters=10):
     total = sum(c["time"] for c in classes.values())
     name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
     ach = dom["flops"] / dom["time"] / 1e12
-    return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None, launches_per_step=dom["launches"],
+    x3 = _lib.get_conv_math() == "bf16x3"
+    # which MFMA pipe the dominant class runs on: Cout (Cin for dgrad) <= 32 tiles keep the fp32 kernels
+    dom_x3 = x3 and name.endswith("n64")
+    peak = PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_F32_MFMA_TFLOPS
+    return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
+                frac=round(ach / peak, 4), traffic=None, launches_per_step=dom["launches"],
                 avg_launch_us=round(dom["time"] / dom["launches"] * 1e6, 2),
+                math="bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate"
+                     if dom_x3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                frac_of_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                algorithmic_hbm_gbs=round(dom["bytes"] / dom["time"] / 1e9, 1),
                 conv_classes={k: dict(us_per_step=round(v["time"] * 1e6, 1), tflops=round(v["flops"] / v["time"] / 1e12, 2),
                                       launches=v["launches"]) for k, v in sorted(classes.items())},
                 conv_total_us_per_step=round(total * 1e6, 1))
@@ -120,6 +131,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
+    from aesrc2020_amd import _lib
     from aesrc2020_amd.model import SAR_Net
     from aesrc2020_amd.utils import synthetic_batch
     import torch.distributed as dist
@@ -176,6 +188,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": B, "global_batch": B * world, "frames": T, "feat_dim": 80,
                        "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "params": model.count_params(),
+                       "conv_math": _lib.get_conv_math() + (" (fp32 in HBM, fp32 accumulate, 2^-17 relative per product)"
+                                                            if _lib.get_conv_math() == "bf16x3" else ""),
                        "final_loss": round(logs["loss"], 4)},
         }
         if not args.no_roofline:
