@@ -343,6 +343,41 @@ extern "C" int sar_bn_stats_f32(const float* x, const float* gamma, const float*
     return SAR_OK;
 }
 
+// ---- inference mode (Keras learning_phase 0): moving averages instead of batch statistics
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mm, const float* mv, float* scale,
+                               float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(mv[c] + eps);
+    scale[c] = sc; shift[c] = beta[c] - mm[c] * sc;
+}
+__global__ void bn_infer_kernel(const float* x, const float* gamma, const float* beta, const float* mm, const float* mv,
+                                float* y, long n, int C, float eps, int relu) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float sc = gamma[c] * rsqrtf(mv[c] + eps);
+        float v = fmaf(x[i], sc, beta[c] - mm[c] * sc);
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+extern "C" int sar_bn_fold_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                               float* scale, float* shift, int C, float eps, hipStream_t stream) {
+    if (!gamma || !beta || !moving_mean || !moving_var || !scale || !shift || C < 1) return SAR_EINVAL;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 256)), dim3(256), 0, stream, gamma, beta, moving_mean, moving_var, scale, shift, C, eps);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+extern "C" int sar_bn_infer_f32(const float* x, const float* gamma, const float* beta, const float* moving_mean,
+                                const float* moving_var, float* y, long R, int C, float eps, int relu, hipStream_t stream) {
+    if (!x || !gamma || !beta || !moving_mean || !moving_var || !y || C < 1 || R < 0) return SAR_EINVAL;
+    if (R == 0) return SAR_OK;
+    const long n = R * C;
+    const int nb = (int)(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+    hipLaunchKernelGGL(bn_infer_kernel, dim3(nb), dim3(256), 0, stream, x, gamma, beta, moving_mean, moving_var, y, n, C, eps, relu);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
 extern "C" int sar_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, long R, int C, int relu,
                                 hipStream_t stream) {
     if (!x || !scale || !shift || !y || C % 4) return SAR_EINVAL;

@@ -47,6 +47,19 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
     }
 }
 
+// sum of the l2(1e-4) regularisers for the current weights, without an update (evaluate(): Keras adds them to `loss`)
+__global__ __launch_bounds__(256) void l2_penalty_kernel(const float* __restrict__ p, const float* __restrict__ chunk_l2,
+                                                         float* __restrict__ out, long nchunks) {
+    __shared__ float red[16];
+    float lacc = 0.f;
+    for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const float w = p[c * 256 + threadIdx.x];
+        lacc = fmaf(chunk_l2[c] * w, w, lacc);
+    }
+    lacc = block_sum(lacc, red);
+    if (threadIdx.x == 0) atomicAdd(out, lacc);
+}
+
 // w (D, A): w[:,a] /= (1e-7 + ||w[:,a]||)
 __global__ __launch_bounds__(64) void unit_norm_kernel(float* __restrict__ w, int D, int A) {
     const int a = blockIdx.x, lane = threadIdx.x;
@@ -74,6 +87,16 @@ extern "C" int sar_adam_l2_step_f32(float* params, const float* grads, float* m,
     const int nb = (int)(nchunks < 4096 ? nchunks : 4096);
     hipLaunchKernelGGL(adam_l2_kernel, dim3(nb), dim3(256), 0, stream, params, grads, m, v, chunk_l2,
                        static_cast<const SarAdamState*>(state), l2_loss, nchunks);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+extern "C" int sar_l2_penalty_f32(const float* params, const float* chunk_l2, float* out, long n, hipStream_t stream) {
+    if (!params || !chunk_l2 || !out || (n % 256)) return SAR_EINVAL;
+    const long nchunks = n / 256;
+    if (sar_zero_async(out, sizeof(float), stream) != hipSuccess) return SAR_ELAUNCH;
+    if (nchunks == 0) return SAR_OK;
+    hipLaunchKernelGGL(l2_penalty_kernel, dim3((int)(nchunks < 1024 ? nchunks : 1024)), dim3(256), 0, stream, params, chunk_l2, out, nchunks);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -41,6 +41,7 @@ class ParamStore:
         self.rng = np.random.default_rng(seed)
         self.bufs = Buffers(device)
         self.layers = []              # construction order; drives summary()/get_layer()
+        self.training = True          # Keras learning phase: False = BatchNorm uses its moving averages (predict/evaluate)
 
     def register_layer(self, layer):
         self.layers.append(layer)
@@ -117,6 +118,10 @@ class ParamStore:
         for r in self.refs:
             if r.constraint == "unit_norm":
                 _lib.call("sar_unit_norm_f32", r.w, r.shape[0], r.shape[1])
+
+    def l2_penalty(self):
+        """Recompute l2_loss for the current weights without an update (evaluate())."""
+        _lib.call("sar_l2_penalty_f32", self.params, self.chunk_l2, self.l2_loss, self.n)
 
     def n_params(self):
         return sum(r.size for r in self.refs)

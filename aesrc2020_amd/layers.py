@@ -171,7 +171,7 @@ class BiGRU(Layer):
 
 
 class BatchNorm1d(Layer):
-    """BatchNormalization() on a 2-D (B, C) tensor, training mode (model.py:286,289)."""
+    """BatchNormalization() on a 2-D (B, C) tensor (model.py:286,289): batch statistics when training, moving averages otherwise."""
 
     def __init__(self, dim, name=None):
         super().__init__(name)
@@ -184,6 +184,9 @@ class BatchNorm1d(Layer):
     def forward(self, x, B):
         self.x, self.B = x, B
         y = self.buf("y", (B, self.dim)); self.mean = self.buf("mean", (self.dim,)); self.rstd = self.buf("rstd", (self.dim,))
+        if not self.store.training:                                          # learning phase 0: moving averages
+            _call("sar_bn_infer_f32", x, self.gamma.w, self.beta.w, self.moving_mean.w, self.moving_var.w, y, B, self.dim, BN_EPS, 0)
+            return y
         _call("sar_bn1d_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, self.moving_mean.w,
               self.moving_var.w, B, self.dim, BN_EPS, BN_MOMENTUM)
         return y

@@ -135,8 +135,21 @@ class SARNetModel:
                                           constraint="unit_norm")
                     else:
                         raise ValueError("unknown metric_loss %r (the reference's disc_loss returns None, model.py:164-165)" % ml)
-                if c["disc_enable"] and c["bn_dim"]:
-                    raise NotImplementedError("bn_dim bottleneck head (model.py:312-322) is not built yet")
+                if c["bn_dim"] and not c["disc_enable"]:
+                    # model.py:337-338 appends the undefined `bn` to the outputs (NameError in the reference)
+                    raise ValueError("bn_dim requires disc_enable=True (model.py:312, 337-338)")
+                if c["disc_enable"] and c["bn_dim"]:                          # visual bottleneck head, model.py:312-322
+                    nb = c["bn_dim"]
+                    self.AR_BN_DS = DS(H, 64, "relu", name="AR_BN_DS"); self.AR_BN3 = BN(64, name="AR_BN3")
+                    self.bottleneck = DS(64, nb, None, name="bottleneck"); self.AR_BN4 = BN(nb, name="AR_BN4")
+                    if ml == "softmax":
+                        self.disc_bn = DS(nb, A, "softmax", use_bias=False, name="y_disc_bn")
+                    elif ml == "circleloss":
+                        self.disc_bn_norm = L2Normalize(nb, name="y_disc_bn_l2norm")
+                        self.disc_bn = Dense(nb, A, activation=None, use_bias=False, name="y_disc_bn", l2=0.0,
+                                             init="glorot_uniform", constraint="unit_norm")
+                    else:
+                        self.disc_bn = cls(n_classes=A, m=c["margin"], name="y_disc_bn", in_dim=nb)
         self.store.finalize()
         self.dp = DataParallel(self.store)
         self.store.set_adam(c["lr"], grad_scale=1.0 / self.dp.world)
@@ -145,6 +158,7 @@ class SARNetModel:
         self.cce_accent = ls.CategoricalCrossentropy(self.bufs, "loss_y_accent")
         self.cce_disc = ls.CategoricalCrossentropy(self.bufs, "loss_y_disc")
         self.circle = ls.CircleLoss(self.bufs, "loss_circle")
+        self.cce_disc_bn = ls.CategoricalCrossentropy(self.bufs, "loss_y_disc_bn")
         self.graph = None; self.graph_B = None; self.use_graph = c["use_graph"]; self._eager_done = 0
         self.stop_training = False
         print(self.loss_weights)                                               # model.py:370
@@ -161,22 +175,33 @@ class SARNetModel:
         if c["ctc_enable"]:
             lw["y_ctc_loss"] = alpha if c["disc_enable"] else 1.0
             lw["y_ctc_loss"] = 1 - alpha if not c["disc_enable"] else beta      # the reference's overwrite (line 361)
+        if c["bn_dim"]:
+            lw["y_disc_bn"] = 0.1                                               # model.py:363-366
         self.loss_weights = lw
-        self.output_names = [n for n in ("y_accent", "y_disc", "y_ctc_loss") if n in lw]
+        self.output_names = [n for n in ("y_accent", "y_disc", "y_ctc_loss", "y_disc_bn") if n in lw]   # model.py:327-338
         self.metrics_names = ["loss"] + [n + "_loss" for n in self.output_names] + \
                              [n + "_acc" for n in self.output_names if n != "y_ctc_loss"]
 
     # ------------------------------------------------------------------ inputs
-    def _bind_inputs(self, B):
+    def _bind_inputs(self, B, T=None):
         c = self.cfg
-        T, D, _ = c["input_shape"]
+        D = c["input_shape"][1]
+        T = int(T if T is not None else c["input_shape"][0])
+        if T != self.trunk.in_hw[0]:
+            if c["mode"] == "train":
+                raise ValueError("x_data has %d frames but the train-mode graph was built for %d (model.py:228-229); "
+                                 "build with mode != 'train' for a variable-length time axis" % (T, self.trunk.in_hw[0]))
+            Tp, Dp = self.trunk.plan(T, D)                                    # model.py:230-231: Input(shape=[None, D, 1])
+            self.L = Tp * Dp
         b = self.bufs
-        self.B = B
+        self.B = B; self.T = T
         self.in_x = b.get("in/x_data", (B, T, D, 1))
         A = c["accent_classes"]
         self.in_y_accent = b.get("in/y_accent", (B, A))
         if c["disc_enable"]:
             self.in_x_accent = b.get("in/x_accent", (B, A)); self.in_y_disc = b.get("in/y_disc", (B, A))
+            if c["bn_dim"]:
+                self.in_y_disc_bn = b.get("in/y_disc_bn", (B, A))
         if c["ctc_enable"]:
             self.in_ctc_label = b.get("in/x_ctc_label", (B, c["max_ctc_len"]))
             self.in_ctc_in_len = b.get("in/x_ctc_in_len", (B,), torch.int32)
@@ -192,9 +217,9 @@ class SARNetModel:
     def _upload(self, inputs, targets):
         c = self.cfg
         x = np.asarray(inputs["x_data"], np.float32)
-        B = x.shape[0]
-        if getattr(self, "B", None) != B:
-            self._bind_inputs(B)
+        B, T = x.shape[0], x.shape[1]
+        if getattr(self, "B", None) != B or getattr(self, "T", None) != T:
+            self._bind_inputs(B, T)
             self.graph = None; self._eager_done = 0
         self.in_x.copy_(torch.from_numpy(np.ascontiguousarray(x)).view(self.in_x.shape))
         tg = targets or {}
@@ -207,6 +232,8 @@ class SARNetModel:
             xa = inputs.get("x_accent", zeros_a)
             self.in_x_accent.copy_(torch.from_numpy(np.asarray(xa, np.float32)))
             self.in_y_disc.copy_(torch.from_numpy(np.asarray(tg.get("y_disc", xa), np.float32)))
+            if c["bn_dim"]:
+                self.in_y_disc_bn.copy_(torch.from_numpy(np.asarray(tg.get("y_disc_bn", xa), np.float32)))
         if c["ctc_enable"]:
             if "x_ctc_label" in inputs:
                 lab = np.asarray(inputs["x_ctc_label"], np.float32)
@@ -231,15 +258,17 @@ class SARNetModel:
 
     def set_device_batch(self, dev):
         """Device-resident batch (dict of torch tensors, same keys as the host batch dict): D2D copies only."""
-        B = dev["x_data"].shape[0]
-        if getattr(self, "B", None) != B:
-            self._bind_inputs(B); self.graph = None; self._eager_done = 0
+        B, T = dev["x_data"].shape[0], dev["x_data"].shape[1]
+        if getattr(self, "B", None) != B or getattr(self, "T", None) != T:
+            self._bind_inputs(B, T); self.graph = None; self._eager_done = 0
         self.in_x.copy_(dev["x_data"].view(self.in_x.shape))
         c = self.cfg
         if c["ar_enable"]:
             self.in_y_accent.copy_(dev["y_accent"])
         if c["disc_enable"]:
             self.in_x_accent.copy_(dev["x_accent"]); self.in_y_disc.copy_(dev["y_disc"])
+            if c["bn_dim"]:
+                self.in_y_disc_bn.copy_(dev.get("y_disc_bn", dev["y_disc"]))
         if c["ctc_enable"]:
             self.in_ctc_label.copy_(dev["x_ctc_label"]); self.in_ctc_in_len.copy_(dev["x_ctc_in_len"].view(-1))
             self.in_ctc_out_len.copy_(dev["x_ctc_out_len"].view(-1))
@@ -283,6 +312,16 @@ class SARNetModel:
                     self.out["y_disc"] = self.disc.forward(self.disc_norm.forward(ar, B))
                 else:
                     self.out["y_disc"] = self.disc.forward(ar, self.in_x_accent)
+                if c["bn_dim"]:
+                    v = self.AR_BN3.forward(self.AR_BN_DS.forward(ar), B)
+                    v = self.AR_BN4.forward(self.bottleneck.forward(v), B)
+                    self.out["bottleneck"] = v
+                    if ml == "softmax":
+                        self.out["y_disc_bn"] = self.disc_bn.forward(v)
+                    elif ml == "circleloss":
+                        self.out["y_disc_bn"] = self.disc_bn.forward(self.disc_bn_norm.forward(v, B))
+                    else:
+                        self.out["y_disc_bn"] = self.disc_bn.forward(v, self.in_x_accent)
         return self.out
 
     def _losses_forward(self):
@@ -297,6 +336,10 @@ class SARNetModel:
                 self.loss_vec["y_disc"] = self.cce_disc.forward(self.in_y_disc, self.out["y_disc"])
         if "y_ctc_loss" in self.loss_weights:
             self.loss_vec["y_ctc_loss"] = self.out["y_ctc_loss"]
+        if "y_disc_bn" in self.loss_weights:
+            # model.py:364 compares the `metrics` dict with 'circleloss': always unequal, so this output always gets
+            # categorical_crossentropy (for circleloss: on the re-normalised raw cosine logits).  Kept verbatim.
+            self.loss_vec["y_disc_bn"] = self.cce_disc_bn.forward(self.in_y_disc_bn, self.out["y_disc_bn"])
 
     def _backward(self):
         c = self.cfg
@@ -327,6 +370,14 @@ class SARNetModel:
                 else:
                     dpd = self.cce_disc.backward(self.seed["y_disc"])
                     self.disc.backward(dpd, dx_out=d_ar, accumulate_dx=True)
+                if c["bn_dim"]:
+                    dpb = self.cce_disc_bn.backward(self.seed["y_disc_bn"])
+                    if ml == "circleloss":
+                        gv = self.disc_bn_norm.backward(self.disc_bn.backward(dpb))
+                    else:
+                        gv = self.disc_bn.backward(dpb)
+                    gv = self.bottleneck.backward(self.AR_BN4.backward(gv))
+                    self.AR_BN_DS.backward(self.AR_BN3.backward(gv), dx_out=d_ar, accumulate_dx=True)
             g = self.AR_BN2.backward(d_ar)
             g = self.AR_EMBEDDING.backward(g)
             g = self.AR_BN1.backward(g)
@@ -388,7 +439,8 @@ class SARNetModel:
         for k in self.output_names:
             if k == "y_ctc_loss":
                 continue
-            tgt = self.in_y_accent if k == "y_accent" else self.in_y_disc
+            tgt = {"y_accent": self.in_y_accent, "y_disc": getattr(self, "in_y_disc", None),
+                   "y_disc_bn": getattr(self, "in_y_disc_bn", None)}[k]
             logs[k + "_acc"] = float((self.out[k].argmax(1) == tgt.argmax(1)).float().mean().item())
         return logs
 
@@ -473,29 +525,49 @@ class SARNetModel:
         cbs.on_train_end()
         return history
 
+    def _inference(self):
+        """Context: Keras learning phase 0 -- BatchNormalization uses its moving averages and does not update them."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = self.store.training
+            self.store.training = False
+            try:
+                yield
+            finally:
+                self.store.training = prev
+        return ctx()
+
     def evaluate(self, x, y=None, batch_size=32):
-        """Loss/accuracy over a dataset dict.  NOTE: runs the training-mode graph without the update
-        (BatchNorm uses batch statistics); the moving-average inference graph is the next scope row."""
-        n = len(x["x_data"]); agg = {}
-        for s in range(0, n - batch_size + 1, batch_size) if n >= batch_size else [0]:
-            sl = slice(s, min(n, s + batch_size))
-            xb = {k: v[sl] for k, v in x.items()}; yb = {k: v[sl] for k, v in (y or {}).items()}
-            self._upload(xb, yb)
-            self._forward(); self._losses_forward()
-            logs = self._logs()
-            for k, v in logs.items():
-                agg.setdefault(k, []).append(v)
-        return {k: float(np.mean(v)) for k, v in agg.items()}
+        """Keras `evaluate` (what fit_generator's validation_data runs, train.py:42): inference-mode forward (BN moving
+        averages), per-output losses / accuracies and the weighted total incl. the L2 penalties, sample-weighted means
+        over all batches (the last one may be smaller)."""
+        n = len(x["x_data"]); agg = {}; tot = 0
+        with self._inference():
+            for s in range(0, n, batch_size):
+                sl = slice(s, min(n, s + batch_size))
+                xb = {k: v[sl] for k, v in x.items()}; yb = {k: v[sl] for k, v in (y or {}).items()}
+                self._upload(xb, yb)
+                self._forward(); self._losses_forward()
+                self.store.l2_penalty()
+                logs = self._logs()
+                nb = sl.stop - sl.start; tot += nb
+                for k, v in logs.items():
+                    agg[k] = agg.get(k, 0.0) + v * nb
+        return {k: v / tot for k, v in agg.items()}
 
     def predict(self, x, batch_size=32):
-        """Outputs in the reference's order [y_accent, y_disc, y_ctc_loss] (model.py:327-338), training-mode BN (see evaluate)."""
+        """Outputs in the reference's order [y_accent, y_disc, y_ctc_loss] (model.py:327-338), inference mode
+        (BN moving averages).  With mode != "train" the time axis may differ from input_shape[0] (model.py:230-231)."""
         x = x if isinstance(x, dict) else {"x_data": x}
         n = len(x["x_data"]); outs = {k: [] for k in self.output_names}
-        for s in range(0, n, batch_size):
-            xb = {k: v[s:s + batch_size] for k, v in x.items()}
-            self._upload(xb, None); self._forward()
-            for k in self.output_names:
-                outs[k].append(self.out[k].detach().cpu().numpy().copy())
+        with self._inference():
+            for s in range(0, n, batch_size):
+                xb = {k: v[s:s + batch_size] for k, v in x.items()}
+                self._upload(xb, None); self._forward()
+                for k in self.output_names:
+                    outs[k].append(self.out[k].detach().cpu().numpy().copy())
         res = [np.concatenate(outs[k]) for k in self.output_names]
         return res if len(res) > 1 else res[0]
 

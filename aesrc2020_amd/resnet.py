@@ -40,6 +40,9 @@ class _BN:
         C = self.C
         self.mean, self.rstd, self.scale, self.shift = (self._b(k, (C,)) for k in ("mean", "rstd", "scale", "shift"))
         self.sums = self._b("sums", (_lib.bn_workspace_doubles(C),), torch.float64)
+        if not self.store.training:                                          # learning phase 0: fold the moving averages
+            _call("sar_bn_fold_f32", self.gamma.w, self.beta.w, self.moving_mean.w, self.moving_var.w, self.scale, self.shift, C, BN_EPS)
+            return
         _call("sar_bn_stats_f32", x, self.gamma.w, self.beta.w, self.sums, self.mean, self.rstd, self.scale, self.shift,
               self.moving_mean.w, self.moving_var.w, R, C, BN_EPS, BN_MOMENTUM, 1)
 
@@ -93,41 +96,51 @@ class ResNetTrunk(Layer):
                                       "(resnet.py:217,233,249), so SAR_Net cannot use them; only res18/res34 are built" % res_type)
         if filters % 16:
             raise ValueError("res_filters must be a multiple of 16 for the gfx950 implicit-GEMM kernels (got %d)" % filters)
-        T, D = input_hw
         stem_c = filters if res_type == "res18" else 64                      # resnet.py:173 vs 191
         if stem_c > 64 or stem_c % 4:
             raise ValueError("stem width %d unsupported (<= 64, multiple of 4)" % stem_c)
         self.stem = _Conv(st, st.auto_name("conv2d"), 7, 1, stem_c, 2, "same")
         self.stem_bn = _BN(st, st.auto_name("batch_normalization"), stem_c)
-        self.in_hw = (T, D)
-        H, W = self.stem.out_hw(T, D)
-        self.stem_hw = (H, W)
-        (H, self.pool_pt), (W, self.pool_pl) = same_pads(H, 3, 2), same_pads(W, 3, 2)
-        self.pool_hw = (H, W)
         self.blocks = []
         cin, f = stem_c, filters
         for i, r in enumerate(self.REPS[res_type]):
             for j in range(r):
                 stride = 2 if (j == 0 and i != 0) else 1
                 first = (i == 0 and j == 0)
-                blk = {"in_hw": (H, W), "cin": cin, "cout": f}
+                blk = {"cin": cin, "cout": f}
                 blk["bn1"] = None if first else _BN(st, st.auto_name("batch_normalization"), cin)     # resnet.py:111-120
                 blk["conv1"] = _Conv(st, st.auto_name("conv2d"), 3, cin, f, stride, "same")
-                H2, W2 = blk["conv1"].out_hw(H, W)
                 blk["bn2"] = _BN(st, st.auto_name("batch_normalization"), f)
                 blk["conv2"] = _Conv(st, st.auto_name("conv2d"), 3, f, f, 1, "same")
-                blk["conv2"].out_hw(H2, W2)
                 blk["sc"] = None
                 if stride > 1 or cin != f:                                   # resnet.py:75-87
                     blk["sc"] = _Conv(st, st.auto_name("conv2d"), 1, cin, f, stride, "valid")
-                    assert blk["sc"].out_hw(H, W) == (H2, W2)
-                blk["out_hw"] = (H2, W2)
                 self.blocks.append(blk)
-                H, W, cin = H2, W2, f
+                cin = f
             f *= 2
         self.final_bn = _BN(st, st.auto_name("batch_normalization"), cin)
-        self.out_hw, self.out_c = (H, W), cin
-        self.output_shape = (None, H, W, cin)
+        self.out_c = cin
+        self.plan(*input_hw)
+
+    def plan(self, T, D):
+        """Spatial sizes of every layer for a (T, D) input.  Parameters do not depend on them, so an inference model
+        (mode != "train": variable-length time axis, model.py:229-232) re-plans per utterance length."""
+        self.in_hw = (T, D)
+        H, W = self.stem.out_hw(T, D)
+        self.stem_hw = (H, W)
+        (H, self.pool_pt), (W, self.pool_pl) = same_pads(H, 3, 2), same_pads(W, 3, 2)
+        self.pool_hw = (H, W)
+        for blk in self.blocks:
+            blk["in_hw"] = (H, W)
+            H2, W2 = blk["conv1"].out_hw(H, W)
+            blk["conv2"].out_hw(H2, W2)
+            if blk["sc"] is not None:
+                assert blk["sc"].out_hw(H, W) == (H2, W2)
+            blk["out_hw"] = (H2, W2)
+            H, W = H2, W2
+        self.out_hw = (H, W)
+        self.output_shape = (None, H, W, self.out_c)
+        return self.out_hw
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, B):

@@ -77,6 +77,13 @@ int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, doub
                      float momentum, int unbiased_moving_var, sarStream_t stream);
 int sar_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, long R, int C, int relu,
                      sarStream_t stream);
+/* Inference mode (Keras learning phase 0, used by predict/evaluate: train.py:42 validation_data, model.py:386):
+ * y = gamma*(x-moving_mean)/sqrt(moving_var+eps)+beta.  _fold produces the per-channel scale/shift the conv prologues
+ * consume; _infer applies it to an (R, C) tensor of any C. */
+int sar_bn_fold_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                    float* scale, float* shift, int C, float eps, sarStream_t stream);
+int sar_bn_infer_f32(const float* x, const float* gamma, const float* beta, const float* moving_mean,
+                     const float* moving_var, float* y, long R, int C, float eps, int relu, sarStream_t stream);
 int sar_bn_bwd_f32(const float* dact, const float* x, const float* scale, const float* shift, const float* mean,
                    const float* rstd, double* sums, const float* add, float* dx, float* dgamma, float* dbeta, long R,
                    int C, int relu, sarStream_t stream);
@@ -152,6 +159,9 @@ int sar_transpose_f32(const float* x, float* y, int R, int C, sarStream_t stream
 int sar_adam_prepare(void* state, sarStream_t stream);
 int sar_adam_l2_step_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                          const void* state, float* l2_loss, long n, sarStream_t stream);
+/* out[0] = sum over the flat parameter buffer of chunk_l2[i/256] * p[i]^2: the kernel/bias_regularizer terms Keras adds
+ * to `loss` (model.py:35-48) for evaluate(), where no optimiser step runs. */
+int sar_l2_penalty_f32(const float* params, const float* chunk_l2, float* out, long n, sarStream_t stream);
 int sar_unit_norm_f32(float* w, int D, int A, sarStream_t stream);
 
 #ifdef __cplusplus

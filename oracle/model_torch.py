@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 K_EPS = 1e-7
 BN_EPS = 1e-3
+BN_MOMENTUM = 0.99
 LN_EPS = 1e-14
 L2 = 1e-4
 
@@ -162,7 +163,28 @@ def init_params(cfg, seed=0):
                 P["y_disc/W"] = _glorot(rng, (H, cfg.accent_classes), H, cfg.accent_classes)
             elif cfg.metric_loss == "circleloss":
                 dense("y_disc", H, cfg.accent_classes, bias=False, init="glorot", regd=False)
+            if cfg.bn_dim:                                                       # model.py:312-322
+                dense("AR_BN_DS", H, 64)
+                P["AR_BN3/gamma"] = np.ones(64); P["AR_BN3/beta"] = np.zeros(64)
+                dense("bottleneck", 64, cfg.bn_dim)
+                P["AR_BN4/gamma"] = np.ones(cfg.bn_dim); P["AR_BN4/beta"] = np.zeros(cfg.bn_dim)
+                if cfg.metric_loss == "softmax":
+                    dense("y_disc_bn", cfg.bn_dim, cfg.accent_classes, bias=False)
+                elif cfg.metric_loss in ("sphereface", "cosface", "arcface"):
+                    P["y_disc_bn/W"] = _glorot(rng, (cfg.bn_dim, cfg.accent_classes), cfg.bn_dim, cfg.accent_classes)
+                elif cfg.metric_loss == "circleloss":
+                    dense("y_disc_bn", cfg.bn_dim, cfg.accent_classes, bias=False, init="glorot", regd=False)
     return P, reg
+
+
+def init_state(P):
+    """BatchNormalization moving statistics (Keras: moving_mean 0, moving_variance 1) for every BN in P."""
+    st = OrderedDict()
+    for n in P:
+        if n.endswith("/gamma") and ("batch_normalization" in n or n.startswith("AR_BN")) and not n.startswith("AR_BN_DS"):
+            base = n[:-6]
+            st[base + "/moving_mean"] = np.zeros(P[n].shape[0]); st[base + "/moving_variance"] = np.ones(P[n].shape[0])
+    return st
 
 
 # --------------------------------------------------------------------------- torch ops
@@ -192,6 +214,27 @@ def bn_train(x, g, b):
     ax = tuple(range(x.dim() - 1))
     mu = x.mean(ax); var = x.var(ax, unbiased=False)
     return (x - mu) / torch.sqrt(var + BN_EPS) * g + b
+
+
+def bn(x, P, name, state=None, training=True):
+    """BatchNormalization().  training: batch statistics; when `state` is given its moving averages are
+    updated with momentum 0.99 (4-D fused path: Bessel-corrected variance; 2-D path: biased).  not training: the moving
+    averages normalise (Keras learning phase 0)."""
+    g, b = P[name + "/gamma"], P[name + "/beta"]
+    if not training:
+        mm = torch.as_tensor(state[name + "/moving_mean"]).to(x.dtype); mv = torch.as_tensor(state[name + "/moving_variance"]).to(x.dtype)
+        return (x - mm) / torch.sqrt(mv + BN_EPS) * g + b
+    if state is not None:
+        with torch.no_grad():
+            ax = tuple(range(x.dim() - 1))
+            n = x.numel() // x.shape[-1]
+            mu = x.mean(ax); var = x.var(ax, unbiased=False)
+            if x.dim() == 4 and n > 1:
+                var = var * n / (n - 1)
+            for key, val in ((name + "/moving_mean", mu), (name + "/moving_variance", var)):
+                old = torch.as_tensor(state[key]).to(x.dtype)
+                state[key] = (BN_MOMENTUM * old + (1 - BN_MOMENTUM) * val).detach().cpu().numpy()
+    return bn_train(x, g, b)
 
 
 def ln(x, g, b):
@@ -245,7 +288,7 @@ def ctc_batch_cost(labels, y_pred, in_len, lab_len):
 
 
 # --------------------------------------------------------------------------- graph
-def forward(P, batch, cfg, collect=None):
+def forward(P, batch, cfg, collect=None, state=None, training=True):
     """P: name->torch tensor.  batch: dict as built by utils.py:102-116.  Returns dict of outputs:
     y_accent, y_disc, y_ctc_loss (as in model.py:327-338) plus 'ar' embedding, 'ctc_pred', 'cnn'."""
     dt = next(iter(P.values())).dtype
@@ -258,7 +301,7 @@ def forward(P, batch, cfg, collect=None):
         elif op[0] == "shortcut_conv":
             saved = conv2d(saved, P[op[1] + "/kernel"], P[op[1] + "/bias"], op[6], op[7])
         elif op[0] == "bn":
-            x = bn_train(x, P[op[1] + "/gamma"], P[op[1] + "/beta"])
+            x = bn(x, P, op[1], state, training)
         elif op[0] == "relu":
             x = torch.relu(x)
         elif op[0] == "maxpool":
@@ -295,9 +338,9 @@ def forward(P, batch, cfg, collect=None):
             res = res[:, :cfg.vlad_clusters]
             ar = l2n(res, -1).reshape(B, -1)
         out["pooled"] = ar
-        ar = bn_train(ar, P["AR_BN1/gamma"], P["AR_BN1/beta"])
+        ar = bn(ar, P, "AR_BN1", state, training)
         ar = ar @ P["AR_EMBEDDING/kernel"] + P["AR_EMBEDDING/bias"]
-        ar = bn_train(ar, P["AR_BN2/gamma"], P["AR_BN2/beta"])
+        ar = bn(ar, P, "AR_BN2", state, training)
         out["ar"] = ar
         a1 = torch.relu(ar @ P["AR_CF_DS1/kernel"] + P["AR_CF_DS1/bias"])
         a1 = torch.relu(a1 @ P["AR_CF_DS2/kernel"] + P["AR_CF_DS2/bias"])
@@ -305,18 +348,28 @@ def forward(P, batch, cfg, collect=None):
         if cfg.disc_enable:
             y = torch.as_tensor(batch["x_accent"]).to(dt)
             ml = cfg.metric_loss
-            if ml == "softmax":
-                out["y_disc"] = torch.softmax(ar @ P["y_disc/kernel"], -1)
-            elif ml == "circleloss":
-                out["y_disc"] = l2n(ar, 1) @ P["y_disc/kernel"]
-            else:
-                c = l2n(ar, 1) @ l2n(P["y_disc/W"], 0)
+
+            def disc_loss(v, name):                                              # model.py:140-166
+                if ml == "softmax":
+                    return torch.softmax(v @ P[name + "/kernel"], -1)
+                if ml == "circleloss":
+                    return l2n(v, 1) @ P[name + "/kernel"]
+                c = l2n(v, 1) @ l2n(P[name + "/W"], 0)
                 if ml == "cosface":
                     t = c - cfg.margin
                 else:
                     th = torch.acos(torch.clamp(c, -1 + K_EPS, 1 - K_EPS))
                     t = torch.cos(th + cfg.margin) if ml == "arcface" else torch.cos(cfg.margin * th)
-                out["y_disc"] = torch.softmax((c * (1 - y) + t * y) * 30.0, -1)
+                return torch.softmax((c * (1 - y) + t * y) * 30.0, -1)
+
+            out["y_disc"] = disc_loss(ar, "y_disc")
+            if cfg.bn_dim:                                                       # model.py:312-322
+                v = torch.relu(ar @ P["AR_BN_DS/kernel"] + P["AR_BN_DS/bias"])
+                v = bn(v, P, "AR_BN3", state, training)
+                v = v @ P["bottleneck/kernel"] + P["bottleneck/bias"]
+                v = bn(v, P, "AR_BN4", state, training)
+                out["bottleneck"] = v
+                out["y_disc_bn"] = disc_loss(v, "y_disc_bn")
     return out
 
 
@@ -330,6 +383,8 @@ def loss_weights(cfg):
             w["y_disc"] = 1 - alpha if cfg.ctc_enable else 1.0
     if cfg.ctc_enable:
         w["y_ctc_loss"] = 1 - alpha if not cfg.disc_enable else beta
+    if cfg.bn_dim:
+        w["y_disc_bn"] = 0.1                                                     # model.py:363-366
     return w
 
 
@@ -347,6 +402,10 @@ def losses(P, reg, out, batch, cfg):
             parts["y_disc"] = cce(y, out["y_disc"]).mean()
     if "y_ctc_loss" in lw:
         parts["y_ctc_loss"] = out["y_ctc_loss"].mean()
+    if "y_disc_bn" in lw:
+        # model.py:364 tests `metrics != 'circleloss'` (a dict against a string): always true, so this output always gets
+        # categorical_crossentropy -- with circleloss that is CE on the re-normalised raw cosine logits.  Kept verbatim.
+        parts["y_disc_bn"] = cce(torch.as_tensor(batch["y_disc_bn"]).to(dt), out["y_disc_bn"]).mean()
     parts["l2"] = sum(L2 * (P[n] ** 2).sum() for n in P if n in reg)
     total = sum(lw[k] * parts[k] for k in lw) + parts["l2"]
     return total, parts
@@ -378,15 +437,27 @@ class TorchSARNet:
         self.M = {k: torch.zeros_like(v) for k, v in self.P.items()}
         self.V = {k: torch.zeros_like(v) for k, v in self.P.items()}
         self.it = 0
-        self.constrained = ("y_disc/kernel",) if (cfg.disc_enable and cfg.metric_loss == "circleloss") else ()
+        self.constrained = ("y_disc/kernel", "y_disc_bn/kernel") if (cfg.disc_enable and cfg.metric_loss == "circleloss") else ()
+        self.state = init_state(P)
 
     def forward_backward(self, batch):
         P = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in self.P.items())
-        out = forward(P, batch, self.cfg)
+        out = forward(P, batch, self.cfg, state=self.state, training=True)
         total, parts = losses(P, self.reg, out, batch, self.cfg)
         total.backward()
         G = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in P}
         return out, total.detach(), {k: v.detach() for k, v in parts.items()}, G
+
+    def predict(self, batch):
+        """Inference-mode forward (moving averages), no state update."""
+        with torch.no_grad():
+            return forward(self.P, batch, self.cfg, state=self.state, training=False)
+
+    def evaluate(self, batch):
+        with torch.no_grad():
+            out = forward(self.P, batch, self.cfg, state=self.state, training=False)
+            total, parts = losses(self.P, self.reg, out, batch, self.cfg)
+        return out, total, parts
 
     def train_on_batch(self, batch):
         out, total, parts, G = self.forward_backward(batch)
@@ -411,6 +482,8 @@ def synthetic_batch(cfg, B, seed=1234, full_len=False):
     batch = {"x_data": x, "y_accent": onehot}
     if cfg.disc_enable:
         batch["x_accent"] = onehot; batch["y_disc"] = onehot
+        if cfg.bn_dim:
+            batch["y_disc_bn"] = onehot
     if cfg.ctc_enable:
         def pool(v):
             for _ in range(5):

@@ -27,6 +27,11 @@ CASES = {
                               disc_enable=True, ctc_enable=True, bpe_classes=30, max_ctc_len=6, metric_loss="cosface", B=3),
     "vlad_sphereface": dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="vlad",
                             vlad_clusters=4, disc_enable=True, metric_loss="sphereface", margin=1.35, B=4),
+    # optional visual bottleneck head (model.py:312-322): bn_dim=2, circle-loss heads (y_disc_bn still gets CE, model.py:364)
+    "bottleneck_circle": dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="gvlad",
+                              vlad_clusters=4, ghost_clusters=1, disc_enable=True, metric_loss="circleloss", bn_dim=2, B=4),
+    "bottleneck_arcface": dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="avg",
+                               disc_enable=True, metric_loss="arcface", bn_dim=3, B=4),
     "softmax_disc_ctc_only_asr": dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="avg",
                                       disc_enable=True, ctc_enable=True, bpe_classes=20, max_ctc_len=6, metric_loss="softmax", B=4),
 }
@@ -58,7 +63,7 @@ def test_forward_backward_parity(case):
     model.forward_backward_only(batch, batch)
     torch.cuda.synchronize()
     # outputs
-    for k in ("y_accent", "y_disc"):
+    for k in ("y_accent", "y_disc", "y_disc_bn", "bottleneck"):
         if k in out and k in model.out:
             got = model.out[k].cpu().numpy(); want = out[k].detach().numpy()
             assert np.abs(got - want).max() < 1e-3, (case, k, np.abs(got - want).max())
@@ -173,3 +178,66 @@ def test_save_load_roundtrip_and_predict(tmp_path):
     dec = ctc_pred(model, {"x_data": batch["x_data"]}, 4, 12)
     assert len(dec) == 4 and all(isinstance(d, list) for d in dec)
     assert model.get_layer("CRNN").name == "CRNN" and model.count_params() == sum(v.numel() for v in ref.P.values())
+
+
+@pytest.mark.parametrize("case", ["cfg3_ctc_circle", "cfg2_gvlad_arcface", "bottleneck_arcface"])
+def test_inference_mode_moving_averages(case):
+    """Keras learning phase 0 (predict / evaluate / validation_data): BatchNormalization normalises with its moving
+    averages.  Two training-mode passes move the averages (momentum 0.99; 4-D: Bessel-corrected variance, 2-D: biased),
+    then the moving statistics, predict() outputs and evaluate() losses are compared with the oracle's inference graph."""
+    cfg, ref, model, batch = build_pair(CASES[case])
+    B = CASES[case]["B"]
+    b2 = MT.synthetic_batch(cfg, B, seed=91)
+    for b in (batch, b2):
+        ref.forward_backward(b)
+        model.forward_backward_only(b, b)
+    sd = model.store.state_dict()
+    assert set(ref.state) <= set(sd), set(ref.state) - set(sd)
+    for k, v in ref.state.items():
+        assert np.abs(sd[k] - v).max() < 1e-4 * max(1.0, np.abs(v).max()), (k, np.abs(sd[k] - v).max())
+    b3 = MT.synthetic_batch(cfg, B + 1, seed=92)            # another batch size: static buffers are re-bound
+    want = ref.predict(b3)
+    got = model.predict({k: v for k, v in b3.items() if k.startswith("x_")}, batch_size=B + 1)
+    got = dict(zip(model.output_names, got if isinstance(got, list) else [got]))
+    for k in ("y_accent", "y_disc", "y_disc_bn"):
+        if k in got:
+            assert np.abs(got[k] - want[k].numpy()).max() < 1e-3, (case, k, np.abs(got[k] - want[k].numpy()).max())
+    if cfg.ctc_enable:
+        assert relmax(model.out["ctc_pred"].cpu().numpy().reshape(want["ctc_pred"].shape), want["ctc_pred"].numpy()) < 1e-3
+    # evaluate(): two batches of different size, sample-weighted; total includes the L2 penalties
+    xs = {k: v for k, v in b3.items() if k.startswith("x_")}; ys = {k: v for k, v in b3.items() if k.startswith("y_")}
+    logs = model.evaluate(xs, ys, batch_size=3)
+    tot = 0.0; n = 0
+    for s0 in range(0, B + 1, 3):
+        sub = {k: v[s0:s0 + 3] for k, v in b3.items()}
+        _, t, parts = ref.evaluate(sub)
+        nb = len(sub["x_data"]); tot += float(t) * nb; n += nb
+    assert abs(logs["loss"] - tot / n) <= 1e-3 * abs(tot / n) + 1e-3, (logs, tot / n)
+    # the moving averages were not touched by predict/evaluate
+    sd2 = model.store.state_dict()
+    for k in ref.state:
+        assert np.array_equal(sd[k], sd2[k]), k
+    # and training resumes in training mode
+    assert model.store.training
+
+
+def test_variable_length_inference_model():
+    """mode != "train" builds the graph with a free time axis (model.py:229-232): predict() on utterances of another
+    length re-plans the spatial sizes; the train-mode graph refuses them."""
+    from aesrc2020_amd.model import SAR_Net
+    kw = dict(CASES["cfg2_gvlad_arcface"]); B = kw.pop("B")
+    cfg = MT.Cfg(**kw)
+    ref = MT.TorchSARNet(cfg, seed=3)
+    model, _ = SAR_Net(seed=4, mode="predict", **kw)
+    model.set_weights_dict({k: v.numpy() for k, v in ref.P.items()})
+    for T in (100, 157, 64):
+        cfg_t = MT.Cfg(**dict(kw, input_shape=[T, 80, 1]))
+        b = MT.synthetic_batch(cfg_t, B, seed=5 + T)
+        want = MT.forward(ref.P, b, cfg_t, state=ref.state, training=False)
+        got = model.predict({"x_data": b["x_data"], "x_accent": b["x_accent"]}, batch_size=B)
+        for k, g in zip(model.output_names, got):
+            assert np.abs(g - want[k].detach().numpy()).max() < 1e-3, (T, k)
+    tm, _ = SAR_Net(seed=4, **kw)
+    b = MT.synthetic_batch(MT.Cfg(**dict(kw, input_shape=[120, 80, 1])), B, seed=6)
+    with pytest.raises(ValueError):
+        tm.train_on_batch(b, b)

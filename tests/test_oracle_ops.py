@@ -269,3 +269,40 @@ def test_l2norm_gap_adam_unitnorm():
     assert np.all(np.isfinite(p2))
     w = RNG.standard_normal((5, 3)); np.testing.assert_allclose(np.linalg.norm(O.unit_norm(w), axis=0), 1.0, atol=1e-6)
     assert O.ctc_greedy_decode(np.eye(4)[[0, 0, 3, 0, 1, 1, 3]][None], [7]) == [[0, 0, 1]]
+
+
+def test_whole_graph_inference_mode_and_bottleneck_head():
+    """oracle/model_torch.py: (a) BatchNormalization moving averages follow m <- 0.99 m + 0.01 batch (2-D: biased variance);
+    (b) with the moving averages set to the batch statistics the inference graph equals the training graph;
+    (c) the bn_dim head adds y_disc_bn with weight 0.1 and always-CE loss (model.py:363-366)."""
+    import torch
+    from oracle import model_torch as MT
+    cfg = MT.Cfg([64, 80, 1], disc_enable=True, res_type="res18", res_filters=16, hidden_dim=32, mto="avg",
+                 metric_loss="cosface", bn_dim=2)
+    net = MT.TorchSARNet(cfg, seed=1)
+    b = MT.synthetic_batch(cfg, 5, seed=3)
+    assert MT.loss_weights(cfg) == {"y_accent": 0.01, "y_disc": 1.0, "y_disc_bn": 0.1}
+    out, total, parts, G = net.forward_backward(b)
+    assert set(parts) == {"y_accent", "y_disc", "y_disc_bn", "l2"} and out["y_disc_bn"].shape == (5, 8)
+    want = 0.01 * parts["y_accent"] + parts["y_disc"] + 0.1 * parts["y_disc_bn"] + parts["l2"]
+    assert abs(float(total) - float(want)) < 1e-12
+    # (a) 2-D BN (AR_BN4 on the bottleneck pre-activation)
+    with torch.no_grad():
+        P = net.P
+        v = torch.relu(out["ar"] @ P["AR_BN_DS/kernel"] + P["AR_BN_DS/bias"])
+        mu3 = v.mean(0); var3 = v.var(0, unbiased=False)
+    np.testing.assert_allclose(net.state["AR_BN3/moving_mean"], 0.01 * mu3.numpy(), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(net.state["AR_BN3/moving_variance"], 0.99 + 0.01 * var3.numpy(), rtol=1e-12)
+    # (b) with momentum 0 the state becomes the batch statistics of this pass; the inference graph then reproduces the
+    # training graph up to the n/(n-1) Bessel factor the 4-D layers store in moving_variance (n >= 5*2*3 here)
+    st = dict(net.state)
+    old_m = MT.BN_MOMENTUM
+    MT.BN_MOMENTUM = 0.0
+    try:
+        trn = MT.forward(net.P, b, cfg, state=st, training=True)
+    finally:
+        MT.BN_MOMENTUM = old_m
+    inf = MT.forward(net.P, b, cfg, state=st, training=False)
+    assert float((inf["y_accent"] - trn["y_accent"]).abs().max()) < 5e-2
+    assert float((inf["y_accent"] - trn["y_accent"]).abs().max()) > 0          # the Bessel factor is really there
+    assert np.isfinite(inf["y_disc_bn"].detach().numpy()).all()
