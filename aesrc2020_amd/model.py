@@ -342,6 +342,11 @@ class SARNetModel:
             self.loss_vec["y_disc_bn"] = self.cce_disc_bn.forward(self.in_y_disc_bn, self.out["y_disc_bn"])
 
     def _backward(self):
+        self._backward_trunk(self._backward_heads())
+
+    def _backward_heads(self):
+        """Backward of everything after the conv trunk (heads, pooling, GRUs, CNN_LIN): completes the tail bucket of the flat
+        gradient buffer.  Returns the gradient w.r.t. the trunk output."""
         c = self.cfg
         B, L = self.B, self.L
         d_crnn = None
@@ -396,30 +401,70 @@ class SARNetModel:
         g = self.CRNN.backward(g.view(B, L, -1))
         g = self.CNN_LIN_LN.backward(g)
         g = self.CNN_LIN.backward(g)
-        self.trunk.backward(g.view(B, self.trunk.out_hw[0], self.trunk.out_hw[1], -1))
+        self._g_trunk = g.view(B, self.trunk.out_hw[0], self.trunk.out_hw[1], -1)
+        return self._g_trunk
+
+    def _backward_trunk(self, g):
+        """Backward of the ResNet trunk: completes the head bucket (conv stack) of the flat gradient buffer."""
+        self.trunk.backward(g)
 
     def _device_step(self, update=True):
         self.store.zero_grads()
         self._forward(); self._losses_forward(); self._backward()
-        if update and self.dp.world == 1:
+        if update:
             self.store.adam_step()
 
-    # ------------------------------------------------------------------ public step API
-    def train_step_device(self):
-        """One optimisation step on the batch currently bound in the static input buffers (no host sync)."""
+    def _seg_heads(self):
+        self.store.zero_grads()
+        self._forward(); self._losses_forward(); self._backward_heads()
+
+    def _seg_trunk(self):
+        self._backward_trunk(self._g_trunk)
+
+    def _run_segments(self, segments):
+        """Run the step as a list of (name, fn, after) segments; `after` (or None) is called on the host between segments
+        (collective launches).  First call eager (allocations), second call captures one HIP graph per segment, later calls
+        replay them."""
         if self.use_graph and self._eager_done >= 1:
             if self.graph is None:
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._device_step()
-                self.graph = g
-            self.graph.replay()
+                graphs = {}
+                for name, fn, after in segments:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        fn()
+                    graphs[name] = g
+                    g.replay()
+                    if after:
+                        after()
+                self.graph = graphs
+                return
+            for name, fn, after in segments:
+                self.graph[name].replay()
+                if after:
+                    after()
         else:
-            self._device_step(); self._eager_done += 1
-        if self.dp.world > 1:
-            self.dp.allreduce_grads()
-            self.store.adam_step()
+            for name, fn, after in segments:
+                fn()
+                if after:
+                    after()
+            self._eager_done += 1
+
+    # ------------------------------------------------------------------ public step API
+    def train_step_device(self):
+        """One optimisation step on the batch currently bound in the static input buffers (no host sync).
+        world == 1: the whole step is one HIP graph.  world > 1: three graphs -- [forward + heads/GRU backward], [trunk
+        backward], [L2+Adam] -- with the RCCL all-reduce of the tail gradient bucket launched between the first two, so it
+        runs on RCCL's stream underneath the conv backward; the conv bucket follows, then Adam waits for both."""
+        if self.dp.world == 1:
+            self._run_segments([("step", self._device_step, None)])
+            return
+        works = []
+        self._run_segments([
+            ("heads", self._seg_heads, lambda: works.extend(self.dp.allreduce_bucket(0, async_op=True))),
+            ("trunk", self._seg_trunk, lambda: (works.extend(self.dp.allreduce_bucket(1, async_op=True)),
+                                                [w.wait() for w in works])),
+            ("adam", self.store.adam_step, None)])
 
     def train_on_batch(self, x, y=None, return_dict=True, sync=True):
         self._upload(x, y)

@@ -79,3 +79,12 @@ class DataParallel:
     def allreduce_grads(self):
         if self.enabled:
             allreduce_flat(self.store.grads, self.bounds)
+
+    def allreduce_bucket(self, i, async_op=True):
+        """Launch the sum-all-reduce of bucket i (0 = tail: heads/GRUs, complete first in backward; 1 = conv stack).
+        With RCCL the collective is enqueued on RCCL's stream behind the work already submitted to the current stream, so
+        it overlaps whatever the caller submits next; `work.wait()` makes the current stream wait for it (no host block).
+        A model without post-trunk parameters has a single bucket: index 1 is then empty."""
+        if not self.enabled or i >= len(self.bounds):
+            return []
+        return [w for w in allreduce_flat(self.store.grads, [self.bounds[i]], async_op=async_op) if w is not None]

@@ -1,0 +1,77 @@
+"""Data-parallel step on the GPU: two processes (one model replica each) share this box's single GPU and exchange gradients
+through torch.distributed (gloo here; the production launcher uses backend "nccl" = RCCL, one GPU per rank).  Checks the
+multi-segment step of model.train_step_device: [forward + heads backward] -> tail bucket all-reduce (async) ->
+[trunk backward] -> conv bucket all-reduce -> [L2+Adam], eager on the first step and replayed from HIP graphs afterwards."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KW = dict(input_shape=[100, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="gvlad", vlad_clusters=4,
+          ghost_clusters=1, disc_enable=True, ctc_enable=True, bpe_classes=30, max_ctc_len=6, metric_loss="arcface")
+GLOBAL_B = 6
+STEPS = 3
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SAR_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import contextlib, io
+    from aesrc2020_amd import parallel
+    from aesrc2020_amd.model import SAR_Net
+    from oracle import model_torch as MT                     # test infrastructure: synthetic batch generator only
+    parallel.init_from_env()
+    with contextlib.redirect_stdout(io.StringIO()):
+        model, tm = SAR_Net(seed=10 + rank, **KW)            # different seeds: rank 0's weights must win (broadcast)
+    cfg = MT.Cfg(**KW)
+    out = []
+    for i in range(STEPS):
+        gb = MT.synthetic_batch(cfg, GLOBAL_B, seed=300 + i)
+        sh = parallel.shard_batch(gb, rank, world)
+        p_before = model.store.params.detach().cpu().numpy().copy()
+        logs = tm.train_on_batch(sh, sh)
+        torch.cuda.synchronize()
+        out.append(dict(p_before=p_before, grads=model.store.grads.detach().cpu().numpy().copy(),
+                        p_after=model.store.params.detach().cpu().numpy().copy(), loss=logs["loss"]))
+    q.put((rank, out, isinstance(model.graph, dict) and sorted(model.graph)))
+    import torch.distributed as dist
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_mean_of_shard_gradients():
+    import torch.multiprocessing as mp
+    from aesrc2020_amd import parallel
+    from aesrc2020_amd.model import SAR_Net
+    from oracle import model_torch as MT
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = 31000 + os.getpid() % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
+    [p.join(120) for p in ps]
+    (_, r0, g0), (_, r1, g1) = res
+    assert g0 == ["adam", "heads", "trunk"] and g1 == g0                   # steps 2.. ran from the three captured graphs
+    single, _ = SAR_Net(seed=99, **KW)
+    cfg = MT.Cfg(**KW)
+    st = single.store
+    for i in range(STEPS):
+        a, b = r0[i], r1[i]
+        assert np.array_equal(a["p_before"], b["p_before"]) and np.array_equal(a["p_after"], b["p_after"])   # replicas stay identical
+        assert np.array_equal(a["grads"], b["grads"])                                                       # same reduced buffer
+        # reference: one process, the two shards one after the other, from the same weights
+        st.params.copy_(torch.from_numpy(a["p_before"]).cuda())
+        gb = MT.synthetic_batch(cfg, GLOBAL_B, seed=300 + i)
+        gsum = np.zeros_like(a["grads"])
+        for r in range(2):
+            sh = parallel.shard_batch(gb, r, 2)
+            single.forward_backward_only(sh, sh)
+            gsum += st.grads.detach().cpu().numpy()
+        scale = np.abs(gsum).max()
+        assert np.abs(a["grads"] - gsum).max() < 2e-4 * scale, (i, np.abs(a["grads"] - gsum).max(), scale)
+        assert not np.array_equal(a["p_before"], a["p_after"])

@@ -95,7 +95,23 @@ def _dp_worker(rank, world, port, q):
     params = torch.full((7,), float(rank)); parallel.broadcast_flat(params, 0)
     batch = {"x": np.arange(8 * 3).reshape(8, 3), "y": np.arange(8)}
     sh = parallel.shard_batch(batch, r, w)
-    q.put((rank, flat.numpy().copy(), params.numpy().copy(), sh["y"].tolist(), bounds))
+    # DataParallel over a stand-in store: broadcast of weights + BN state, two asynchronously launched buckets
+    class Ref:
+        def __init__(self, name, offset, w=None):
+            self.name, self.offset, self.w = name, offset, w
+    class Store:
+        pass
+    st = Store(); st.n = 512; st.refs = [Ref("conv2d_1/kernel", 0), Ref("CNN_LIN/kernel", 256), Ref("y_accent/kernel", 384)]
+    st.params = torch.full((512,), float(rank)); st.grads = torch.full((512,), float(rank + 1))
+    st.state_refs = [Ref("batch_normalization_1/moving_mean", 0, torch.full((4,), float(rank + 5)))]
+    dp = parallel.DataParallel(st)
+    works = dp.allreduce_bucket(0, async_op=True)
+    tail_done = None
+    works += dp.allreduce_bucket(1, async_op=True)
+    [wk.wait() for wk in works]
+    dpres = (dp.bounds, dp.world, st.params.numpy().copy(), st.grads.numpy().copy(), st.state_refs[0].w.numpy().copy(),
+             len(works), dp.allreduce_bucket(2))
+    q.put((rank, flat.numpy().copy(), params.numpy().copy(), sh["y"].tolist(), bounds, dpres))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -107,7 +123,11 @@ def test_data_parallel_gloo_world2():
     [p.start() for p in ps]
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
-    for rank, flat, params, ys, bounds in res:
+    for rank, flat, params, ys, bounds, dpres in res:
+        dbounds, dworld, dparams, dgrads, dstate, nworks, extra = dpres
+        assert dbounds == [(256, 512), (0, 256)] and dworld == 2 and nworks == 2 and extra == []
+        assert np.all(dparams == 0.0) and np.all(dstate == 5.0)            # rank-0 weights and BN moving statistics everywhere
+        assert np.all(dgrads == 3.0)                                       # both buckets summed exactly once
         assert bounds == [(300, 1000), (0, 300)]                            # tail bucket (heads/GRU) first, conv trunk last
         assert np.all(flat[10:] == 3.0) and np.allclose(flat[:10], np.arange(10.0) * 3)   # sum over ranks 1+2; Adam applies 1/world
         assert np.all(params == 0.0)                                        # rank-0 weights everywhere
