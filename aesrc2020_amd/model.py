@@ -216,12 +216,16 @@ class SARNetModel:
 
     def _upload(self, inputs, targets):
         c = self.cfg
-        x = np.asarray(inputs["x_data"], np.float32)
-        B, T = x.shape[0], x.shape[1]
+        x = inputs["x_data"]
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float32)))
+        B, T = int(x.shape[0]), int(x.shape[1])
         if getattr(self, "B", None) != B or getattr(self, "T", None) != T:
             self._bind_inputs(B, T)
             self.graph = None; self._eager_done = 0
-        self.in_x.copy_(torch.from_numpy(np.ascontiguousarray(x)).view(self.in_x.shape))
+        self.in_x.copy_(x.reshape(self.in_x.shape))                           # H2D, or D2D for the device feeder's x_data
+        if x.is_cuda:
+            x.record_stream(torch.cuda.current_stream())                      # produced on the feeder's stream (utils.Prefetcher)
         tg = targets or {}
         A = c["accent_classes"]
         zeros_a = np.zeros((B, A), np.float32)                                # predict(): labels may be absent
@@ -543,8 +547,19 @@ class SARNetModel:
                       max_queue_size=10, verbose=1, log_every=50):
         """Keras fit_generator subset used by train.py:38-44 (single feeding thread; callbacks get Keras-style logs)."""
         from .callbacks import CallbackList
+        from .utils import Prefetcher
         cbs = CallbackList(callbacks or [], self)
         cbs.on_train_begin()
+        history = []
+        feed = Prefetcher(generator, max_queue_size)                         # Keras: one feeding thread, bounded queue
+        try:
+            history = self._fit_loop(feed, steps_per_epoch, epochs, cbs, initial_epoch, validation_data, verbose, log_every)
+        finally:
+            feed.close()
+        cbs.on_train_end()
+        return history
+
+    def _fit_loop(self, generator, steps_per_epoch, epochs, cbs, initial_epoch, validation_data, verbose, log_every):
         history = []
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
@@ -567,7 +582,6 @@ class SARNetModel:
             cbs.on_epoch_end(epoch, logs)
             if self.stop_training:
                 break
-        cbs.on_train_end()
         return history
 
     def _inference(self):

@@ -1,7 +1,18 @@
-"""Host helpers mirroring the parts of /root/reference/utils.py the hot path's caller needs:
-cal_descriptors (utils.py:156-159), label padding (utils.py:57-63), feature pad/trunc (utils.py:39-46), and the
-synthetic batch used by bench.py / smoke in the exact dict format of utils.py:102-116."""
+"""Host side of the data-feeding boundary, mirroring /root/reference/utils.py: file helpers (utils.py:14-27), feature
+normalisation + padding (35-46), label padding (57-63), `data_loader` / `data_generator` (71-154) with the reference's
+signatures and batch-dict format (102-116), `cal_descriptors` (156-159), plus the synthetic batch used by bench.py / smoke
+(SURVEY 8d).
+
+What is different from the reference: the per-utterance MinMax scaling + zero padding -- the only arithmetic on this row --
+runs on the MI355X (csrc/feeder.hip, `sar_feat_minmax_pad_f32`) on the ragged batch uploaded through pinned memory, so
+`x_data` comes back as a device tensor that `train_on_batch` / `fit_generator` consume without another copy.  There is no
+host implementation of that arithmetic here: without the HIP library these functions raise."""
 import math
+import pickle
+import queue
+import threading
+from random import shuffle
+
 import numpy as np
 
 EOS_ID = 2
@@ -15,7 +26,57 @@ def cal_descriptors(T, D):
     return T * D
 
 
+# ---- FILE OPT (utils.py:14-27)
+def save(path, arr):
+    with open(path, "wb") as f:
+        pickle.dump(arr, f)
+
+
+def load(path):
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def read_lines(path):
+    with open(path, "rt") as f:
+        return [line.strip() for line in f.readlines()]
+
+
+def to_categorical(y, num_classes):
+    """keras.utils.np_utils.to_categorical for one integer label (utils.py:92)."""
+    out = np.zeros(num_classes, np.float32); out[int(y)] = 1.0
+    return out
+
+
+# ---- FEATURE OPT (utils.py:35-46), device side
+def feat_norm_pad(feats, max_len=1200, stream=None):
+    """feat_reshape(feat_norm(f), max_len) for a list of (n_i, D) utterances -> device tensor (B, max_len, D, 1) f32.
+    The ragged batch goes through one pinned staging buffer and one H2D copy; MinMax scaling (per utterance, per feature
+    column, over all its frames) and truncation / zero padding run in `sar_feat_minmax_pad_f32`."""
+    import torch
+    from . import _lib
+    B = len(feats)
+    lens = [int(np.shape(f)[0]) for f in feats]
+    if B == 0 or min(lens) == 0:
+        # sklearn's MinMaxScaler raises on an empty utterance (utils.py:36)
+        raise ValueError("Found array with 0 sample(s) while a minimum of 1 is required by MinMaxScaler.")
+    D = int(np.shape(feats[0])[1])
+    off = np.zeros(B + 1, np.int32); off[1:] = np.cumsum(lens)
+    host = torch.empty((int(off[-1]), D), dtype=torch.float32).pin_memory()
+    hv = host.numpy()
+    for i, f in enumerate(feats):
+        hv[off[i]:off[i + 1]] = f                                           # casts float64 pickles to f32
+    st = stream or torch.cuda.current_stream()
+    with torch.cuda.stream(st):
+        frames = host.cuda(non_blocking=True)
+        offs = torch.from_numpy(off).pin_memory().cuda(non_blocking=True)
+        out = torch.empty((B, max_len, D, 1), dtype=torch.float32, device="cuda")
+        _lib.call("sar_feat_minmax_pad_f32", frames, offs, out, B, max_len, D, stream=st.cuda_stream)
+    return out
+
+
 def feat_reshape(feat, max_len=1200):
+    """utils.py:39-46 (pure data movement; kept for callers that pad already-normalised features)."""
     h, w = feat.shape
     if h >= max_len:
         return feat[:max_len]
@@ -49,3 +110,111 @@ def synthetic_batch(input_shape, B, ctc_enable, disc_enable, accent_classes=8, b
         inputs["x_ctc_label"] = lab; inputs["x_ctc_out_len"] = ll
         inputs["x_ctc_in_len"] = np.full((B, 1), L, np.int32); targets["y_ctc_loss"] = np.zeros(B, np.float32)
     return inputs, targets
+
+
+# ---- Generator (utils.py:71-154)
+def data_loader(lst, ctc_enable=False, ar_enable=False, disc_enable=False, data_dct=None, accent_dct=None, trans_dct=None,
+                max_input_len=1200, max_ctc_len=72, encoder_len=100, accent_classes=8, bn=0, stream=None):
+    """utils.py:71-116, same arguments and the same (input_data, output_data) dicts; `x_data` is a device tensor produced by
+    feat_norm_pad, the (tiny) label arrays stay numpy.  `data_dct[utt]` is a pickle path (utils.py:84) or an array."""
+    feats = []
+    ctc_input_len, ctc_label_len, ctc_labels, accent_labels = [], [], [], []
+    for utt in lst:
+        f = data_dct[utt]
+        feats.append(load(f) if isinstance(f, str) else f)
+        if ctc_enable and trans_dct:
+            trans = trans_dct[utt]
+            ctc_input_len.append(encoder_len)
+            ctc_label_len.append(min(len(trans), max_ctc_len))
+            ctc_labels.append(text_ids_norm(trans, max_ctc_len))
+        if ar_enable and accent_dct:
+            accent_labels.append(to_categorical(int(accent_dct[utt]), num_classes=accent_classes))
+    input_data = {"x_data": feat_norm_pad(feats, max_input_len, stream=stream)}
+    output_data = {}
+    if ctc_enable:
+        input_data["x_ctc_in_len"] = np.int32(np.expand_dims(np.asarray(ctc_input_len), axis=1))
+        input_data["x_ctc_out_len"] = np.int32(np.expand_dims(np.asarray(ctc_label_len), axis=1))
+        input_data["x_ctc_label"] = np.float32(np.asarray(ctc_labels))
+        output_data["y_ctc_loss"] = np.zeros([len(lst)])
+    if ar_enable:
+        output_data["y_accent"] = np.asarray(accent_labels)
+    if disc_enable:
+        input_data["x_accent"] = np.asarray(accent_labels)
+        output_data["y_disc"] = np.asarray(accent_labels)
+        if bn:
+            output_data["y_disc_bn"] = np.asarray(accent_labels)
+    return input_data, output_data
+
+
+def data_generator(lst, ctc_enable=False, ar_enable=False, disc_enable=False, batch_size=32, data_dct=None, accent_dct=None,
+                   trans_dct=None, max_input_len=1200, max_ctc_len=72, encoder_len=100, accent_classes=8, bn=0, stream=None):
+    """utils.py:120-154: endless epochs; every epoch shuffles `lst` in place and yields len(lst)//batch_size batches."""
+    n_batchs = len(lst) // batch_size
+    while True:
+        shuffle(lst)
+        for i in range(n_batchs):
+            sub = lst[i * batch_size:(i + 1) * batch_size]
+            yield data_loader(sub, ctc_enable=ctc_enable, ar_enable=ar_enable, disc_enable=disc_enable, data_dct=data_dct,
+                              accent_dct=accent_dct, trans_dct=trans_dct, max_input_len=max_input_len,
+                              max_ctc_len=max_ctc_len, encoder_len=encoder_len, accent_classes=accent_classes, bn=bn,
+                              stream=stream)
+
+
+class Prefetcher:
+    """What Keras' GeneratorEnqueuer does for fit_generator(max_queue_size=20, workers=1) (train.py:38-44): one background
+    thread runs the generator ahead of the training loop.  The thread issues its H2D copy + feeder kernel on its own HIP
+    stream and hands over (batch, event); the consumer makes the training stream wait on the event -- the upload of batch
+    i+1 overlaps the (graph-replayed) step of batch i."""
+
+    def __init__(self, generator, max_queue_size=10):
+        import torch
+        self.q = queue.Queue(maxsize=max(1, int(max_queue_size)))
+        self.gen = generator
+        self.stop = threading.Event()
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        import torch
+        try:
+            ctx = torch.cuda.stream(self.stream) if self.stream is not None else None
+            if ctx:
+                ctx.__enter__()
+            while not self.stop.is_set():
+                item = next(self.gen)
+                ev = None
+                if self.stream is not None:
+                    ev = torch.cuda.Event(); ev.record(self.stream)
+                while not self.stop.is_set():
+                    try:
+                        self.q.put((item, ev), timeout=0.1); break
+                    except queue.Full:
+                        continue
+        except StopIteration:
+            self.q.put((None, None))
+        except BaseException as e:                                        # surface feeder errors in the training thread
+            self.q.put((e, None))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        import torch
+        item, ev = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        if item is None:
+            raise StopIteration
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return item
+
+    def close(self):
+        self.stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+        self.th.join(timeout=5)

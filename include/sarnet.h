@@ -159,6 +159,12 @@ int sar_transpose_f32(const float* x, float* y, int R, int C, sarStream_t stream
 int sar_adam_prepare(void* state, sarStream_t stream);
 int sar_adam_l2_step_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                          const void* state, float* l2_loss, long n, sarStream_t stream);
+/* ---- data feeder: utils.py:35-36 feat_norm (sklearn MinMaxScaler.fit_transform per utterance: every
+ * feature column scaled to [0,1] over ALL frames of the utterance; constant column -> 0) + utils.py:39-46 feat_reshape
+ * (truncate / zero-pad to T frames).  frames = the batch's utterances back to back (sum_n, D) f32; offsets (B+1) i32 frame
+ * offsets; out (B, T, D) f32 = x_data (utils.py:102).  Same float32 operation order as sklearn (bit-exact for f32 input). */
+int sar_feat_minmax_pad_f32(const float* frames, const int* offsets, float* out, int B, int T, int D, sarStream_t stream);
+
 /* out[0] = sum over the flat parameter buffer of chunk_l2[i/256] * p[i]^2: the kernel/bias_regularizer terms Keras adds
  * to `loss` (model.py:35-48) for evaluate(), where no optimiser step runs. */
 int sar_l2_penalty_f32(const float* params, const float* chunk_l2, float* out, long n, sarStream_t stream);

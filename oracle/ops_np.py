@@ -527,3 +527,68 @@ def ctc_greedy_decode(y_pred, in_len):
             prev = a
         out.append(seq)
     return out
+
+
+# --------------------------------------------------------------------------- data feeder (utils.py:35-116)
+# Third-party arithmetic on this row: sklearn.preprocessing.MinMaxScaler (utils.py:5-6,35-36; version unpinned by the
+# reference's README).  scikit-learn IS importable in this image, so tests/test_oracle_ops.py pins feat_norm against the
+# real MinMaxScaler().fit_transform -- this row's parity is pinned, unlike the TF/Keras rows.
+def feat_norm(feat):
+    """utils.py:35-36: MinMaxScaler(feature_range=(0,1)).fit_transform(feat) restated: per feature column over the
+    utterance's frames; scale_ = 1 / (max - min) with a zero range replaced by 1; X * scale_ + (0 - min * scale_), in the
+    input's float dtype and in sklearn's operation order (two roundings, no fma)."""
+    feat = np.asarray(feat)
+    if feat.dtype not in (np.float32, np.float64):
+        feat = feat.astype(np.float64)
+    if feat.shape[0] == 0:
+        raise ValueError("Found array with 0 sample(s) (shape=%s) while a minimum of 1 is required by MinMaxScaler." % (feat.shape,))
+    dt = feat.dtype.type
+    mn = feat.min(0); rng = feat.max(0) - mn
+    rng = np.where(rng == 0, dt(1), rng).astype(feat.dtype)
+    scale = (dt(1) / rng).astype(feat.dtype)
+    min_ = (dt(0) - mn * scale).astype(feat.dtype)
+    out = feat * scale
+    out = out + min_
+    return out
+
+
+def feat_reshape(feat, max_len=1200):
+    """utils.py:39-46: truncate to max_len frames or zero-pad (float64 zeros in the reference; cast to f32 at utils.py:102)."""
+    h, w = feat.shape
+    if h >= max_len:
+        return feat[:max_len]
+    out = np.zeros((max_len, w)); out[:h] = feat
+    return out
+
+
+EOS_ID = 2
+
+
+def text_ids_norm(ids, max_len):
+    """utils.py:57-63: truncate to max_len or pad with EOS (2)."""
+    ids = list(ids)[:max_len]
+    return ids + [EOS_ID] * (max_len - len(ids))
+
+
+def data_loader(lst, feats, ctc_enable=False, ar_enable=False, disc_enable=False, accent_dct=None, trans_dct=None,
+                max_input_len=1200, max_ctc_len=72, encoder_len=100, accent_classes=8, bn=0):
+    """utils.py:71-116 with the pickle loads replaced by `feats[utt]` arrays: returns (input_data, output_data)."""
+    inputs = [feat_reshape(feat_norm(feats[u]), max_input_len) for u in lst]
+    x = {"x_data": np.float32(np.expand_dims(np.asarray(inputs), 3))}
+    y = {}
+    if ctc_enable and trans_dct:
+        x["x_ctc_in_len"] = np.full((len(lst), 1), encoder_len, np.int32)
+        x["x_ctc_out_len"] = np.int32([[min(len(trans_dct[u]), max_ctc_len)] for u in lst])
+        x["x_ctc_label"] = np.float32([text_ids_norm(trans_dct[u], max_ctc_len) for u in lst])
+    if ctc_enable:
+        y["y_ctc_loss"] = np.zeros([len(lst)])
+    acc = None
+    if ar_enable and accent_dct:
+        acc = np.eye(accent_classes, dtype=np.float32)[[int(accent_dct[u]) for u in lst]]
+    if ar_enable:
+        y["y_accent"] = acc
+    if disc_enable:
+        x["x_accent"] = acc; y["y_disc"] = acc
+        if bn:
+            y["y_disc_bn"] = acc
+    return x, y

@@ -50,6 +50,26 @@ def ops_vectors():
     return d
 
 
+def feeder_vectors():
+    """PINNED by third-party reference code: the expected outputs come from the real sklearn.preprocessing.MinMaxScaler
+    (the class utils.py:5-6,35-36 calls; scikit-learn is importable in the build container), composed with the
+    truncate / zero-pad rule of utils.py:39-46 -- not from the oracle."""
+    from sklearn.preprocessing import MinMaxScaler
+    import sklearn
+    rng = np.random.default_rng(36)
+    lens = [23, 40, 1, 57, 31]                      # shorter, equal, single-frame (all columns constant), longer than max_len
+    max_len, D = 40, 80
+    feats = [(rng.standard_normal((n, D)) * rng.uniform(0.5, 8) + rng.uniform(-20, 5)).astype(np.float32) for n in lens]
+    feats[0][:, 3] = 1.25; feats[3][:, 79] = 0.0     # constant columns -> 0
+    out = np.zeros((len(lens), max_len, D, 1), np.float32)
+    for i, f in enumerate(feats):
+        z = MinMaxScaler().fit_transform(f.copy())
+        k = min(len(z), max_len)
+        out[i, :k, :, 0] = z[:k]
+    return dict(frames=np.concatenate(feats), lens=np.int32(lens), max_len=np.int32(max_len), x_data=out,
+                sklearn_version=np.array(sklearn.__version__))
+
+
 def model_vectors():
     cfg = MT.Cfg(**MODEL_KW)
     net = MT.TorchSARNet(cfg, seed=0)
@@ -77,5 +97,6 @@ def model_vectors():
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "ops_golden.npz"), **ops_vectors())
     np.savez_compressed(os.path.join(HERE, "model_golden.npz"), **model_vectors())
+    np.savez_compressed(os.path.join(HERE, "feeder_golden.npz"), **feeder_vectors())
     for f in ("ops_golden.npz", "model_golden.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
