@@ -21,6 +21,21 @@
 
 namespace {
 
+// In-kernel phase timing (tools/conv_timing.py; built only with -DSAR_TIMING into tools/libsarnet_timing.so, never part
+// of libsarnet_hip.so): thread 0 of every block stamps s_memtime (shader clock) / s_memrealtime (100 MHz, device-wide).
+#ifdef SAR_TIMING
+__device__ unsigned long long* g_tbuf = nullptr;
+#define TSTAMP(slot)                                                                                                   \
+    do {                                                                                                               \
+        if (g_tbuf && threadIdx.x == 0) {                                                                              \
+            const long bl = (long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);          \
+            g_tbuf[bl * 16 + (slot)] = ((slot) == 0 || (slot) == 15) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+        }                                                                                                              \
+    } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#endif
+
 struct ConvP {
     const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
     float* y;
@@ -281,6 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     __shared__ __attribute__((aligned(16))) __bf16 Al[2][BMt][BKP];
     __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BNt][BKP];
     __shared__ __attribute__((aligned(16))) __bf16 Bl[2][BNt][BKP];
+    TSTAMP(0); TSTAMP(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const unsigned M = (unsigned)(p.B * p.Ho * p.Wo);
@@ -306,6 +322,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     }
     const int b_n = tid % BNt, b_k = (tid / BNt) * KPT;               // B: weights (k, n) in memory; lanes run along n (coalesced)
     const bool bcol_ok = n0 + b_n < p.Cout;
+    const int b_col = min(n0 + b_n, p.Cout - 1);
+    const float relu_lo = p.scale ? 0.f : -INFINITY;                  // no BN+ReLU prologue: identity
     struct Regs { float4 ra[NA]; float rb[KPT]; float4 sc, sh; unsigned vmask; };
     Regs R0, R1;                                                      // two sets: prefetch distance of two k-tiles
     R0.sc = R1.sc = make_float4(1, 1, 1, 1); R0.sh = R1.sh = zero4(); R0.vmask = R1.vmask = 0;
@@ -323,16 +341,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
             R.ra[i] = *reinterpret_cast<const float4*>(p.x + off);
             R.vmask |= ok << i;
         }
-        const int boff = bcol_ok ? (k0 + b_k) * p.Cout + n0 + b_n : 0;
+        // always-valid, always-distinct addresses (column clamped; zeroed at store time): a select between "real" and
+        // "dummy" offsets makes the compiler load once and copy the loaded value, i.e. wait on a fresh load right here
+        const int boff = (k0 + b_k) * p.Cout + b_col;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) R.rb[j] = p.w[boff + (bcol_ok ? j * p.Cout : 0)];
+        for (int j = 0; j < KPT; ++j) R.rb[j] = p.w[boff + j * p.Cout];
     };
     auto store = [&](const Regs& R, int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = (tid + i * NT) / KQ;
-            float4 v = zero4();
-            if ((R.vmask >> i) & 1u) v = p.scale ? bn_relu4(R.ra[i], R.sc, R.sh) : R.ra[i];
+            const bool ok = (R.vmask >> i) & 1u;                      // selects, no branches; padding stays exactly zero
+            const float4 q = R.ra[i];
+            float4 v;
+            v.x = ok ? fmaxf(fmaf(q.x, R.sc.x, R.sh.x), relu_lo) : 0.f; v.y = ok ? fmaxf(fmaf(q.y, R.sc.y, R.sh.y), relu_lo) : 0.f;
+            v.z = ok ? fmaxf(fmaf(q.z, R.sc.z, R.sh.z), relu_lo) : 0.f; v.w = ok ? fmaxf(fmaf(q.w, R.sc.w, R.sh.w), relu_lo) : 0.f;
             bf16x4 hi, lo; split4(v, hi, lo);
             *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
@@ -383,20 +406,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     // Pipeline with a prefetch distance of TWO k-tiles: with the matrix phase this short (~400 cycles per tile) a
     // one-tile-ahead prefetch is latency-bound.  Tile kt+1 sits in one register set (loaded two iterations ago) and is
     // written to the idle LDS buffer, then that set is re-filled with tile kt+3.  Clamped tile indices keep the tail branch-free.
+    TSTAMP(2);
     if (kt0 < nkt) {
         const int last = nkt - 1;
         load(R0, kt0); load(R1, min(kt0 + 1, last));
+        TSTAMP(3);
         store(R0, 0); load(R0, min(kt0 + 2, last));
         __syncthreads();
-        for (int kt = kt0; kt < nkt; kt += 2) {
+        TSTAMP(4);
+        // two explicit exits (not `if (more) { second half }`): keeps the s_waitcnt counts of the first half from
+        // collapsing to vmcnt(0) on the phantom path first half -> first half
+        for (int kt = kt0;;) {
             mma(0); store(R1, 1); load(R1, min(kt + 3, last));
             __syncthreads();
-            if (kt + 1 < nkt) {
-                mma(1); store(R0, 0); load(R0, min(kt + 4, last));
-                __syncthreads();
-            }
+            if (kt + 1 >= nkt) break;
+            mma(1); store(R0, 0); load(R0, min(kt + 4, last));
+            __syncthreads();
+            kt += 2;
+            if (kt >= nkt) break;
         }
     }
+    TSTAMP(5);
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= p.Cout) return;
     const bool lead = blockIdx.z == 0;
@@ -413,6 +443,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
             if (p.splitk > 1) atomicAdd(p.y + o, v);
             else p.y[o] = v;
         }
+#ifdef SAR_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    TSTAMP(6); TSTAMP(15);
 }
 
 // ------------------------------------------------------------------ dgrad
@@ -571,6 +605,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
     constexpr int GPR = BK / KPT;                                     // k-groups per row
     const int b_n = tid / GPR, b_k = (tid % GPR) * KPT;
     const bool brow_ok = n0 + b_n < p.Cin;
+    const int b_row = min(n0 + b_n, p.Cin - 1);
     struct Regs { float4 ra[NA]; float4 rb[KPT / 4]; unsigned vmask; };
     Regs R0, R1; R0.vmask = R1.vmask = 0;
     auto load = [&](Regs& R, int kt) {
@@ -586,9 +621,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
             R.ra[i] = *reinterpret_cast<const float4*>(p.dy + off);
             R.vmask |= ok << i;
         }
-        const int boff = brow_ok ? (tap * p.Cin + n0 + b_n) * p.Cout + co0 + b_k : 0;
+        const int boff = (tap * p.Cin + b_row) * p.Cout + co0 + b_k;      // row clamped: always valid (see the forward kernel)
 #pragma unroll
-        for (int j = 0; j < KPT / 4; ++j) R.rb[j] = *reinterpret_cast<const float4*>(p.w + boff + (brow_ok ? 4 * j : 0));
+        for (int j = 0; j < KPT / 4; ++j) R.rb[j] = *reinterpret_cast<const float4*>(p.w + boff + 4 * j);
     };
     auto store = [&](const Regs& R, int buf) {
 #pragma unroll
@@ -631,13 +666,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
         load(R0, kt0); load(R1, min(kt0 + 1, last));
         store(R0, 0); load(R0, min(kt0 + 2, last));
         __syncthreads();
-        for (int kt = kt0; kt < nkt; kt += 2) {
+        for (int kt = kt0;;) {                                           // two explicit exits: see the forward kernel
             mma(0); store(R1, 1); load(R1, min(kt + 3, last));
             __syncthreads();
-            if (kt + 1 < nkt) {
-                mma(1); store(R0, 0); load(R0, min(kt + 4, last));
-                __syncthreads();
-            }
+            if (kt + 1 >= nkt) break;
+            mma(1); store(R0, 0); load(R0, min(kt + 4, last));
+            __syncthreads();
+            kt += 2;
+            if (kt >= nkt) break;
         }
     }
     const int col = n0 + wn * 32 + (lane & 31);
@@ -914,17 +950,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     load(R0, 0); load(R1, 1);
     store(R0, 0); load(R0, 2);
     __syncthreads();
-    for (int t = 0; t < ntile; t += 2) {
+    for (int t = 0;;) {                                               // two explicit exits: see the forward kernel
         mma(0);
-        if (t + 1 < ntile) store(R1, 1);                              // a clamped re-load of the last tile must not reach the bias sum
-        load(R1, t + 3);
+        if (t + 1 >= ntile) break;
+        store(R1, 1); load(R1, t + 3);
         __syncthreads();
-        if (t + 1 < ntile) {
-            mma(1);
-            if (t + 2 < ntile) store(R0, 0);
-            load(R0, t + 4);
-            __syncthreads();
-        }
+        mma(1);
+        t += 2;
+        if (t >= ntile) break;                                        // a clamped re-load of the last tile must not reach the bias sum
+        store(R0, 0); load(R0, t + 2);
+        __syncthreads();
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < p.Cout)
@@ -954,6 +989,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
 // 32-bit element offsets and the magic-number division bound the supported sizes (far above the SAR-Net shapes).
 // 0 = fp32 MFMA (exact fp32 fma chains), 1 = bf16x3 split precision (default; 2^-17 relative per product).
 static int g_conv_math = (getenv("SAR_CONV_MATH") && !strcmp(getenv("SAR_CONV_MATH"), "fp32")) ? 0 : 1;
+#ifdef SAR_TIMING
+extern "C" int sar_dbg_set_timing_buffer(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &buf, sizeof(buf)) == hipSuccess ? SAR_OK : SAR_ELAUNCH;
+}
+#endif
 extern "C" int sar_set_conv_math(int mode) { if (mode < 0 || mode > 1) return SAR_EINVAL; g_conv_math = mode; return SAR_OK; }
 extern "C" int sar_get_conv_math(void) { return g_conv_math; }
 
