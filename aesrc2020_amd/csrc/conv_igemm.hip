@@ -1027,8 +1027,14 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
     const int bk = (Cin % 32 == 0) ? 32 : 16;
     const bool narrow = Cout <= 32;
     const bool fp32_math = g_conv_math == 0;
-    if (!fp32_math && bk == 32 && !narrow) {                        // bf16x3 split-precision path (default for Cout >= 64;
-        if (false) {                                                // Cout = 32 keeps the fp32 kernel: its LDS footprint allows 7 blocks/CU)
+    // Off by default for the FORWARD of the 32-channel layers (stage 0): kernel-level accuracy is the same 2^-17, but a
+    // perturbation of the earliest activations flips ReLU / max-pool decisions throughout the net, which the parity tests
+    // (tiny tensors) see as percent-level gradient changes.  SAR_X3_NARROW bit 0 enables it (-5 us per stage-0 conv).
+    static const bool x3_narrow = getenv("SAR_X3_NARROW") ? (atoi(getenv("SAR_X3_NARROW")) & 1) != 0 : false;
+    if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
+        if (narrow) {                                               // Cout <= 32: 128 x 32 tile, 4 waves stacked along M
+            dim3 grid(cdiv(M, 128), cdiv(Cout, 32), 1);
+            hipLaunchKernelGGL((conv_fwd_x3_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
         } else if (cdiv(M, 128) * cdiv(Cout, 64) >= 300) {
             dim3 grid(cdiv(M, 128), cdiv(Cout, 64), 1);
             hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
@@ -1078,8 +1084,11 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
     const int bk = (Cout % 32 == 0) ? 32 : 16;
     const bool narrow = Cin <= 32;
     const bool fp32_math = g_conv_math == 0;
-    if (!fp32_math && bk == 32 && !narrow) {                        // bf16x3 split-precision path
-        if (cdiv(M, 128) * cdiv(Cin, 64) >= 300) {
+    static const bool x3_narrow = getenv("SAR_X3_NARROW") ? (atoi(getenv("SAR_X3_NARROW")) & 2) != 0 : true;
+    if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
+        if (narrow) {                                               // Cin <= 32: 128 x 32 tile
+            hipLaunchKernelGGL((conv_dgrad_x3_kernel<4, 1, 1, 32>), dim3(cdiv(M, 128), cdiv(Cin, 32), 1), dim3(256), 0, stream, p);
+        } else if (cdiv(M, 128) * cdiv(Cin, 64) >= 300) {
             hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 2, 32>), dim3(cdiv(M, 128), cdiv(Cin, 64), 1), dim3(256), 0, stream, p);
         } else {
             const int tiles1 = cdiv(M, 64) * cdiv(Cin, 64);

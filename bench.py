@@ -185,7 +185,10 @@ def main():
             "metric": "utterances/sec train step, 400-frame x 80-dim fbank", "value": round(world * B * args.steps / dt, 2),
             "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            # arithmetic type of the dominant (conv) path: "bf16x3" = fp32 operands split into bf16 hi+lo, three bf16 MFMAs
+            # per product block, fp32 accumulate, fp32 in HBM (16 significant bits per product: above the bf16 that
+            # BASELINE configs[1] names); "f32" = exact fp32 MFMA (SAR_CONV_MATH=fp32)
+            "dtype": "bf16x3" if _lib.get_conv_math() == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": B, "global_batch": B * world, "frames": T, "feat_dim": 80,
                        "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "params": model.count_params(),
                        "conv_math": _lib.get_conv_math() + (" (fp32 in HBM, fp32 accumulate, 2^-17 relative per product)"

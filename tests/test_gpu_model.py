@@ -56,8 +56,24 @@ def relmax(a, b):
     return np.abs(a - b).max() / (np.abs(b).max() + 1e-12)
 
 
+@pytest.fixture
+def conv_math(request):
+    from aesrc2020_amd import _lib
+    old = _lib.get_conv_math()
+    _lib.set_conv_math(request.param)
+    yield request.param
+    _lib.set_conv_math(old)
+
+
+# Gradient tolerance (fraction of each tensor's max-abs): 2e-3 for the exact-fp32 MFMA conv mode (measured deviation from the
+# float64 oracle: ~5e-6, tests/diag_oracle_diff.py), 5e-3 for the default bf16x3 split-precision mode (measured ~4e-5).
+# The bound is loose on purpose: the graph is piecewise linear (ReLU, max-pool), so a forward perturbation that moves one
+# pre-activation across zero changes the gradient discretely -- on these tiny tensors (140 rows in stage 2) one flipped
+# element shows up as a percent-level change of a whole gradient tensor (that is what enabling the split-precision forward
+# for the 32-channel layers too, SAR_X3_NARROW=3, does on this seed; hence it is not the default).
+@pytest.mark.parametrize("conv_math,gtol", [("fp32", 2e-3), ("bf16x3", 5e-3)], indirect=["conv_math"])
 @pytest.mark.parametrize("case", list(CASES))
-def test_forward_backward_parity(case):
+def test_forward_backward_parity(case, conv_math, gtol):
     cfg, ref, model, batch = build_pair(CASES[case])
     out, total, parts, G = ref.forward_backward(batch)
     model.forward_backward_only(batch, batch)
@@ -83,7 +99,7 @@ def test_forward_backward_parity(case):
                 bad.append((r.name, "zero-grad tensor", float(np.abs(g).max())))
             continue
         e = np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-3 * med)
-        if not e < 2e-3:
+        if not e < gtol:
             bad.append((r.name, float(e), float(np.abs(gr).max())))
     assert not bad, (case, med, bad[:12])
     # L2 flags agree with the oracle's regulariser set
@@ -105,15 +121,6 @@ def grad_mismatches(model, ref, G, tol=2e-3):
         if not e < tol:
             bad.append((r.name, float(e), float(np.abs(gr).max())))
     return bad
-
-
-@pytest.fixture
-def conv_math(request):
-    from aesrc2020_amd import _lib
-    old = _lib.get_conv_math()
-    _lib.set_conv_math(request.param)
-    yield request.param
-    _lib.set_conv_math(old)
 
 
 @pytest.mark.parametrize("conv_math", ["fp32", "bf16x3"], indirect=True)
@@ -138,11 +145,11 @@ def test_three_train_steps_with_graph_replay(case, conv_math):
         assert abs(logs["loss"] - float(total)) <= 1e-3 * abs(float(total)) + 1e-3, (case, i, logs["loss"], float(total))
         # step 0 is held to 2e-3; after Adam's O(lr) noise-amplified steps the nets are less well conditioned (34 BN backward
         # passes each subtract batch means), so later steps allow 3e-2 on the deepest tensors
-        # ... in fp32 conv math.  The bf16x3 split mode (2^-17 per product instead of 2^-24) is held to the same 2e-3 at step 0;
-        # at later steps (loss ~1e2, gamma=256 circle loss, saturated heads) that extra rounding is amplified past any
-        # useful bound, so there only the loss and the in-situ Adam update are checked
+        # ... in fp32 conv math.  The bf16x3 split mode (2^-17 per product instead of 2^-24) is held to 5e-3 at step 0 (see
+        # test_forward_backward_parity); at later steps (loss ~1e2, gamma=256 circle loss, saturated heads) that extra rounding
+        # is amplified past any useful bound, so there only the loss and the in-situ Adam update are checked
         if conv_math == "fp32" or i == 0:
-            bad = grad_mismatches(model, ref, G, tol=2e-3 if i == 0 else 3e-2)
+            bad = grad_mismatches(model, ref, G, tol=(2e-3 if conv_math == "fp32" else 5e-3) if i == 0 else 3e-2)
             assert not bad, (case, i, bad[:8])
         for r in st.refs:
             g = r.g.cpu().double().numpy() + 2 * r.l2 * p0[r.name]
