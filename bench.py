@@ -80,8 +80,18 @@ def conv_roofline(model, B, iters=10):
     # which MFMA pipe the dominant class runs on: Cout (Cin for dgrad) <= 32 tiles keep the fp32 kernels
     dom_x3 = x3 and name.endswith("n64")
     peak = PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_F32_MFMA_TFLOPS
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
+    # correction applied by tools/pmc_to_traffic.py); null when no measurement exists for this kernel class
+    traffic, tsrc = None, None
+    try:
+        pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+        if name in pj:
+            traffic, tsrc = pj[name]["traffic_bytes"], pj["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
-                frac=round(ach / peak, 4), traffic=None, launches_per_step=dom["launches"],
+                frac=round(ach / peak, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
+                algorithmic_bytes=int(dom["bytes"] / dom["launches"]), launches_per_step=dom["launches"],
                 avg_launch_us=round(dom["time"] / dom["launches"] * 1e6, 2),
                 math="bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate"
                      if dom_x3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""profiles/<tag>_pmc_hbm.txt (tools/pmc_summary.py output of the FETCH_SIZE and WRITE_SIZE passes) -> profiles/pmc_traffic.json:
+HBM-side bytes per launch for the conv kernel classes bench.py reports, with the gfx950 correction of MI355X_MICROARCH.md
+(FETCH_SIZE counts wide coalesced reads at half their size): traffic = 2 * FETCH_SIZE + WRITE_SIZE, counters in KB."""
+import json, re, sys
+src = sys.argv[1]
+sec, cur, vals = None, None, {}
+for line in open(src):
+    if line.startswith("## "):
+        sec = line[3:].strip(); continue
+    if line.startswith("#") or not line.strip():
+        continue
+    if not line.startswith(" "):
+        cur = line.strip(); continue
+    m = re.match(r"\s+(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", line)
+    if m and cur:
+        vals.setdefault(cur, {})[m.group(1)] = (float(m.group(2)), int(m.group(3)))
+CLASS = [("conv_wgrad_x3_kernel<64>", "conv_wgrad_3x3_n64"), ("conv_fwd_x3_kernel<2, 2, 1, 32>", "conv_fwd_3x3_n64"),
+         ("conv_dgrad_x3_kernel<2, 2, 1, 32>", "conv_dgrad_3x3_n64"), ("conv_wgrad_kernel<4, 1, 1, 32>", "conv_wgrad_3x3_n32"),
+         ("conv_fwd_kernel<4, 1, 1, 32, false>", "conv_fwd_3x3_n32"), ("conv_dgrad_x3_kernel<4, 1, 1, 32>", "conv_dgrad_3x3_n32")]
+out = {"source": src, "note": "per-launch average over all dispatches of the kernel in a step (3x3 and 1x1 launches of one template together); "
+       "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+for kname, cls in CLASS:
+    for k, d in vals.items():
+        if kname in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
+            out[cls] = {"kernel": kname, "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
