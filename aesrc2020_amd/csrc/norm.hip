@@ -172,44 +172,65 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __
     if (c < C) { dgamma[c] += (float)sums[C + c]; dbeta[c] += (float)sums[c]; }
 }
 
-// ---- 2-D BatchNorm: x (B, C), thread per channel ---------------------------------------------------------
-__global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// ---- 2-D BatchNorm: x (B, C).  Block = 32 channels x 8 row groups: coalesced 128-byte rows, B/8 sequential loads per
+//      thread (the tensors are tiny -- 64 x 8192 at most -- so the kernel is latency-bound: parallelism over rows matters)
+constexpr int BN1_CH = 32, BN1_RG = 8;
+__device__ __forceinline__ float bn1d_colsum(float v, float (*red)[BN1_CH], int rg, int cl) {
+    __syncthreads();                                  // protects `red` against the previous use
+    red[rg][cl] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < BN1_RG; ++g) t += red[g][cl];
+    return t;
+}
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
                                 float* __restrict__ rstd, float* __restrict__ mov_mean, float* __restrict__ mov_var,
                                 int B, int C, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float mu = 0.f;
-    for (int b = 0; b < B; ++b) mu += x[(long)b * C + c];
-    mu /= B;
-    float var = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = x[(long)b * C + c] - mu; var = fmaf(d, d, var); }
-    var /= B;
+    __shared__ float red[BN1_RG][BN1_CH];
+    const int cl = threadIdx.x % BN1_CH, rg = threadIdx.x / BN1_CH;
+    const int c = blockIdx.x * BN1_CH + cl;
+    const bool ok = c < C;
+    float s = 0.f;
+    if (ok) for (int b = rg; b < B; b += BN1_RG) s += x[(long)b * C + c];
+    const float mu = bn1d_colsum(s, red, rg, cl) / B;
+    float q = 0.f;
+    if (ok) for (int b = rg; b < B; b += BN1_RG) { const float d = x[(long)b * C + c] - mu; q = fmaf(d, d, q); }
+    const float var = bn1d_colsum(q, red, rg, cl) / B;
+    if (!ok) return;
     const float rs = 1.f / sqrtf(var + eps);
-    mean[c] = mu; rstd[c] = rs;
     const float g = gamma[c], be = beta[c];
-    for (int b = 0; b < B; ++b) y[(long)b * C + c] = (x[(long)b * C + c] - mu) * rs * g + be;
-    if (mov_mean) {
-        mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * mu;
-        mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * var;
+    for (int b = rg; b < B; b += BN1_RG) y[(long)b * C + c] = (x[(long)b * C + c] - mu) * rs * g + be;
+    if (rg == 0) {
+        mean[c] = mu; rstd[c] = rs;
+        if (mov_mean) {
+            mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * mu;
+            mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * var;
+        }
     }
 }
 
-__global__ void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                 const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
                                 float* __restrict__ dbeta, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float mu = mean[c], rs = rstd[c];
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float g = dy[(long)b * C + c];
-        s1 += g; s2 = fmaf(g, (x[(long)b * C + c] - mu) * rs, s2);
-    }
-    dgamma[c] += s2; dbeta[c] += s1;
+    __shared__ float red[BN1_RG][BN1_CH];
+    const int cl = threadIdx.x % BN1_CH, rg = threadIdx.x / BN1_CH;
+    const int c = blockIdx.x * BN1_CH + cl;
+    const bool ok = c < C;
+    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
+    float a1 = 0.f, a2 = 0.f;
+    if (ok)
+        for (int b = rg; b < B; b += BN1_RG) {
+            const float g = dy[(long)b * C + c];
+            a1 += g; a2 = fmaf(g, (x[(long)b * C + c] - mu) * rs, a2);
+        }
+    const float s1 = bn1d_colsum(a1, red, rg, cl), s2 = bn1d_colsum(a2, red, rg, cl);
+    if (!ok) return;
+    if (rg == 0) { dgamma[c] += s2; dbeta[c] += s1; }
     const float k = gamma[c] * rs, m1 = s1 / B, m2 = s2 / B;
-    for (int b = 0; b < B; ++b) {
+    for (int b = rg; b < B; b += BN1_RG) {
         const float xh = (x[(long)b * C + c] - mu) * rs;
         dx[(long)b * C + c] = k * (dy[(long)b * C + c] - m1 - xh * m2);
     }
@@ -419,7 +440,7 @@ extern "C" int sar_bn1d_fwd_f32(const float* x, const float* gamma, const float*
                                 float* moving_mean, float* moving_var, int B, int C, float eps, float momentum,
                                 hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || B <= 0) return SAR_EINVAL;
-    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, x, gamma, beta, y, mean, rstd, moving_mean, moving_var, B, C, eps, momentum);
+    hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, BN1_CH)), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, moving_mean, moving_var, B, C, eps, momentum);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -427,7 +448,7 @@ extern "C" int sar_bn1d_fwd_f32(const float* x, const float* gamma, const float*
 extern "C" int sar_bn1d_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                 float* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return SAR_EINVAL;
-    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, B, C);
+    hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, BN1_CH)), dim3(256), 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, B, C);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -68,20 +68,6 @@ int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint
                                 int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
                                 sarStream_t stream);
 
-/* ---- Split-precision convolution on pre-split operands (csrc/conv_split.hip): the same Conv2D sites as above
- * (resnet.py:39-42,60-63,82-87,113-117), with the fp32 -> (hi, lo) bf16 split done once per tensor instead of once per tile:
- *   sar_bn_apply_split_bf16     xh/xl = split([relu](x*scale+shift))   -- the _bn_relu in front of a conv (resnet.py:22-26)
- *   sar_conv_weight_split_bf16  one launch over a device table of {w, wt_h, wt_l, wd_h, wd_l, K, Cout, first_block} rows
- *                               (8 x int64 each): wt_* [Cout][K] for forward, wd_* [K][Cout] for dgrad; 32x64 tiles per block
- *   sar_conv2d_fwd_split_f32    y = conv(x planes, wt planes) + bias (+ residual), fp32 out; Cin % 32 == 0, Cout % 16 == 0
- * bf16 buffers are passed as void*. */
-int sar_bn_apply_split_bf16(const float* x, const float* scale, const float* shift, void* xh, void* xl, long n, int C,
-                            int relu, sarStream_t stream);
-int sar_conv_weight_split_bf16(const void* table, int n, int total_blocks, sarStream_t stream);
-int sar_conv2d_fwd_split_f32(const void* xh, const void* xl, const void* wth, const void* wtl, const float* bias,
-                             const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                             int KH, int KW, int stride, int pad_top, int pad_left, sarStream_t stream);
-
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a
  * backward) followed by per-block fp32 partials; two-stage reduction, no atomics, no zeroing required. */

@@ -115,59 +115,6 @@ def test_conv_fwd_dgrad_wgrad(L, case):
     check(db2, db_ref, name="colsum")
 
 
-SPLIT_CASES = [  # B,H,W,Cin,Cout,k,stride,pad,prologue,residual  (Cin % 32 == 0: the pre-split operand path, csrc/conv_split.hip)
-    (2, 10, 8, 64, 64, 3, 1, "same", True, True), (2, 13, 5, 64, 128, 3, 2, "same", True, False),
-    (3, 25, 5, 64, 128, 1, 2, "valid", False, False), (2, 7, 3, 128, 256, 3, 1, "same", True, True),
-    (2, 9, 4, 32, 80, 3, 1, "same", True, False), (64, 50, 12, 64, 64, 3, 1, "same", True, False),
-]
-
-
-def weight_split_table(ws):
-    """Device planes + descriptor table for sar_conv_weight_split_bf16: rows {w, wt_h, wt_l, wd_h, wd_l, K, Cout, blk0}."""
-    rows, planes, blk = [], [], 0
-    for w in ws:
-        K, Cout = w.numel() // w.shape[-1], w.shape[-1]
-        pl = [torch.empty(Cout, K, dtype=torch.bfloat16, device="cuda") for _ in range(2)] + \
-             [torch.empty(K, Cout, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
-        rows.append([w.data_ptr()] + [t.data_ptr() for t in pl] + [K, Cout, blk])
-        planes.append(pl); blk += (K // 32) * (Cout // 64)
-    return torch.tensor(rows, dtype=torch.int64, device="cuda"), planes, blk
-
-
-@pytest.mark.parametrize("case", SPLIT_CASES)
-def test_conv_split_operand_path(L, case):
-    B, H, W, Cin, Cout, k, s, pad, pro, res = case
-    rng = np.random.default_rng(sum(case[:7]) + 1)
-    x = rng.standard_normal((B, H, W, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) * 0.1; b = rng.standard_normal(Cout)
-    scale = rng.uniform(0.5, 1.5, Cin); shift = rng.standard_normal(Cin) * 0.3
-    act = np.maximum(x * scale + shift, 0) if pro else x
-    y_ref, cache = O.conv2d_fwd(act, w, b, (s, s), pad)
-    _, Ho, Wo, _ = y_ref.shape
-    pt, pl = (O.same_pads(H, k, s)[1], O.same_pads(W, k, s)[1]) if pad == "same" else (0, 0)
-    r = rng.standard_normal(y_ref.shape) if res else None
-    xd, wd = dev(x), dev(w)
-    # operand producers
-    xh = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device="cuda"); xl = torch.empty_like(xh)
-    L.call("sar_bn_apply_split_bf16", xd, dev(scale) if pro else None, dev(shift) if pro else None, xh, xl, xd.numel(), Cin, 1 if pro else 0)
-    rec = xh.double().cpu().numpy() + xl.double().cpu().numpy()
-    a32 = np.float32(np.maximum(np.float32(x) * np.float32(scale) + np.float32(shift), 0)) if pro else np.float32(x)
-    assert np.abs(rec - a32).max() <= 2.0 ** -16 * np.abs(a32).max() + 1e-30, "activation split"
-    if Cout % 64 == 0:
-        table, planes, nblk = weight_split_table([wd])
-        L.call("sar_conv_weight_split_bf16", table, 1, nblk)
-        wt_h, wt_l, wd_h, wd_l = planes[0]
-        w2 = np.float32(w).reshape(-1, Cout)
-        assert np.abs((wd_h.double() + wd_l.double()).cpu().numpy() - w2).max() <= 2.0 ** -16 * np.abs(w2).max()
-        assert torch.equal(wt_h, wd_h.t().contiguous()) and torch.equal(wt_l, wd_l.t().contiguous())
-        assert torch.equal(wd_h, wd.reshape(-1, Cout).to(torch.bfloat16))
-    else:                                            # Cout not a multiple of the 64-wide split tile: planes made on the host side
-        w2 = wd.reshape(-1, Cout); wd_h = w2.to(torch.bfloat16); wd_l = (w2 - wd_h.float()).to(torch.bfloat16)
-        wt_h, wt_l = wd_h.t().contiguous(), wd_l.t().contiguous()
-    y = zeros(B, Ho, Wo, Cout)
-    L.call("sar_conv2d_fwd_split_f32", xh, xl, wt_h, wt_l, dev(b), dev(r) if res else None, y, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
-    check(y, y_ref + (r if res else 0), name="conv fwd (pre-split operands)")
-
-
 @pytest.mark.parametrize("B,T,D,C0", [(2, 100, 80, 64), (2, 37, 21, 8), (1, 64, 80, 32)])
 def test_stem_and_fused_maxpool(L, B, T, D, C0):
     rng = np.random.default_rng(T)

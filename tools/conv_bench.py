@@ -28,13 +28,6 @@ for name, H, W, ci, co, k, s in STAGES:
     y = torch.empty(B, Ho, Wo, co, device="cuda"); dy = torch.randn(B, Ho, Wo, co, device="cuda"); dx = torch.empty_like(x); dw = torch.zeros_like(w)
     fl = 2.0 * B * Ho * Wo * co * ci * k * k
     t_f = timed(lambda: L.call("sar_conv2d_fwd_f32", x, w, b, sc, sh, None, y, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
-    t_fs = float("nan")
-    if ci % 32 == 0 and co % 64 == 0:                # pre-split operand path (csrc/conv_split.hip)
-        xh = torch.empty(B, H, W, ci, dtype=torch.bfloat16, device="cuda"); xl = torch.empty_like(xh)
-        w2 = w.reshape(-1, co); wth = w2.t().contiguous().to(torch.bfloat16); wtl = (w2.t().contiguous() - wth.float()).to(torch.bfloat16)
-        t_sp = timed(lambda: L.call("sar_bn_apply_split_bf16", x, sc, sh, xh, xl, x.numel(), ci, 1))
-        t_fs = timed(lambda: L.call("sar_conv2d_fwd_split_f32", xh, xl, wth, wtl, b, None, y, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
-        print("%-20s split pass %5.1f us | fwd on planes %6.1f us %5.1f TF" % (name, t_sp * 1e6, t_fs * 1e6, fl / t_fs / 1e12), flush=True)
     t_d = timed(lambda: L.call("sar_conv2d_dgrad_f32", dy, w, dx, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl, 0))
     t_w = timed(lambda: L.call("sar_conv2d_wgrad_f32", x, dy, sc, sh, dw, None, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
     print("%-20s GF %.2f | fwd %6.1f us %5.1f TF | dgrad %6.1f us %5.1f TF | wgrad %6.1f us %5.1f TF" %

@@ -18,10 +18,6 @@ lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.sar_conv2d_fwd_f32.argtypes = [vp] * 7 + [ci] * 12 + [vp]
 lib.sar_dbg_set_timing_buffer.argtypes = [vp]
-lib.sar_dbg_set_timing_buffer_split.argtypes = [vp]
-lib.sar_conv2d_fwd_split_f32.argtypes = [vp] * 7 + [ci] * 12 + [vp]
-lib.sar_bn_apply_split_bf16.argtypes = [vp] * 5 + [ctypes.c_long, ci, ci, vp]
-SPLIT = os.environ.get("SPLIT", "0") == "1"          # time the pre-split operand kernel (conv_split.hip) instead
 
 SHAPES = [("s1 3x3 64->64", 50, 10, 64, 64, 3, 1), ("s2 3x3 128->128", 25, 5, 128, 128, 3, 1), ("s3 3x3 256->256", 13, 3, 256, 256, 3, 1)]
 B = int(os.environ.get("CB", 64))
@@ -33,12 +29,6 @@ for name, H, W, Cin, Cout, k, stride in SHAPES:
     st = torch.cuda.current_stream().cuda_stream
     args = [x.data_ptr(), w.data_ptr(), bias.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(), B, H, W, Cin, H, W, Cout, k, k, stride, 1, 1, st]
     fwd, setbuf = lib.sar_conv2d_fwd_f32, lib.sar_dbg_set_timing_buffer
-    if SPLIT:
-        xh = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device="cuda"); xl = torch.empty_like(xh)
-        lib.sar_bn_apply_split_bf16(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), xh.data_ptr(), xl.data_ptr(), x.numel(), Cin, 1, st)
-        w2 = w.reshape(-1, Cout).t().contiguous(); wth = w2.to(torch.bfloat16); wtl = (w2 - wth.float()).to(torch.bfloat16)
-        args = [xh.data_ptr(), xl.data_ptr(), wth.data_ptr(), wtl.data_ptr(), bias.data_ptr(), None, y.data_ptr(), B, H, W, Cin, H, W, Cout, k, k, stride, 1, 1, st]
-        fwd, setbuf = lib.sar_conv2d_fwd_split_f32, lib.sar_dbg_set_timing_buffer_split
     for it in range(3):
         setbuf(None); torch.cuda.synchronize()
         y.zero_(); fwd(*args)
