@@ -821,6 +821,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     __shared__ __attribute__((aligned(16))) __bf16 Bh[2][BNt][BKP];
     __shared__ __attribute__((aligned(16))) __bf16 Bl[2][BNt][BKP];
     __shared__ __attribute__((aligned(16))) int2 rowinfo[WG_MAX_ROWS];
+    TSTAMP(0); TSTAMP(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const unsigned R = (unsigned)(p.B * p.Ho * p.Wo);
@@ -846,7 +847,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
         rowinfo[r] = info;
     }
     // A' micro-tile of this thread: channels mp..mp+3 (fixed), rows a_r..a_r+3 of the current k-tile
-    const int a_c4 = tid % (BMt / 4), a_r = (tid / (BMt / 4)) * 4;    // 32 column groups x 8 row groups
+    // Row group is the FAST thread index: the eight lanes of one channel group write one contiguous 64-byte LDS row segment
+    // and successive channel groups land 16 banks apart -- conflict-free.  (With the channel group fast, lanes were 4 LDS
+    // rows = 320 B apart: 16-way bank conflicts on every transposed ds_write_b64, which WAS the wgrad k-loop: 4700 cycles
+    // per k-tile in tools/conv_timing.py.)  Global loads stay coalesced: per row, eight lanes read 128 contiguous bytes.
+    const int a_r = (tid % (BK / 4)) * 4, a_c4 = tid / (BK / 4);      // 8 row groups x 32 column groups
     const int mp = m0 + a_c4 * 4;
     int a_tap = 31, a_ci = 0, a_tapoff = 0;                            // tap 31 is never valid: columns beyond Mp load nothing
     if (mp < Mp) {
@@ -858,8 +863,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     if (p.scale) { asc = *reinterpret_cast<const float4*>(p.scale + a_ci); ash = *reinterpret_cast<const float4*>(p.shift + a_ci); }
     const float relu_lo = p.scale ? 0.f : -INFINITY;                  // no prologue: identity
     // B' micro-tile: channels b_c4*4.. of dy, rows b_r..b_r+3 (threads beyond the tile idle)
-    const int b_c4 = tid % (BNt / 4), b_r = (tid / (BNt / 4)) * 4;
-    const bool b_act = b_r < BK;
+    const int b_r = (tid % (BK / 4)) * 4, b_c4 = tid / (BK / 4);
+    const bool b_act = b_c4 < BNt / 4;
     const bool bcol_ok = n0 + b_c4 * 4 < p.Cout;
     const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
     const float* dyb = p.dy + (bcol_ok ? n0 + b_c4 * 4 : 0);
@@ -946,21 +951,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
         }
     };
     __syncthreads();                                                 // row table complete
+    TSTAMP(2);
     // same two-tile-ahead pipeline as the forward kernel
     load(R0, 0); load(R1, 1);
-    store(R0, 0); load(R0, 2);
+    TSTAMP(3);
+    store(R0, 0);
+    if (ntile > 1) store(R1, 1);                                      // a clamped re-load of the last tile must not reach the bias sum
     __syncthreads();
-    for (int t = 0;;) {                                               // two explicit exits: see the forward kernel
+    TSTAMP(4);
+    // Two k-tiles per iteration; the loads of the NEXT two tiles are issued at the top and consumed at the bottom, behind both
+    // matrix phases.  (With loads carried across the back-edge the compiler drained the whole load queue, vmcnt(0), in every
+    // first half here -- tools/conv_timing.py: 4700 cycles per k-tile.)
+    for (int t = 0; t < ntile; t += 2) {
+        load(R0, t + 2); load(R1, t + 3);
         mma(0);
-        if (t + 1 >= ntile) break;
-        store(R1, 1); load(R1, t + 3);
+        if (t + 1 < ntile) mma(1);
         __syncthreads();
-        mma(1);
-        t += 2;
-        if (t >= ntile) break;                                        // a clamped re-load of the last tile must not reach the bias sum
-        store(R0, 0); load(R0, t + 2);
+        if (t + 2 < ntile) store(R0, 0);
+        if (t + 3 < ntile) store(R1, 1);
         __syncthreads();
     }
+    TSTAMP(5);
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < p.Cout)
 #pragma unroll
@@ -970,6 +981,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
             const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < Mp) atomicAdd(p.dw + (long)row * p.Cout + col, acc[tm][r]);
         }
+#ifdef SAR_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    TSTAMP(6); TSTAMP(15);
     if (do_bias) {                                                   // block-uniform; the A tile is free after the last barrier
         float* scr = reinterpret_cast<float*>(&Ah[0][0][0]);         // [8 row groups][BNt]
         __syncthreads();

@@ -29,6 +29,11 @@ for name, H, W, Cin, Cout, k, stride in SHAPES:
     st = torch.cuda.current_stream().cuda_stream
     args = [x.data_ptr(), w.data_ptr(), bias.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(), B, H, W, Cin, H, W, Cout, k, k, stride, 1, 1, st]
     fwd, setbuf = lib.sar_conv2d_fwd_f32, lib.sar_dbg_set_timing_buffer
+    if os.environ.get("KERNEL", "fwd") == "wgrad":    # weight-gradient kernel instead (phases: row table / first loads / fill / k-loop / atomics)
+        dy = torch.randn(B, H, W, Cout, device="cuda"); dw = torch.zeros_like(w)
+        lib.sar_conv2d_wgrad_f32.argtypes = [vp] * 6 + [ci] * 12 + [vp]
+        args = [x.data_ptr(), dy.data_ptr(), sc.data_ptr(), sh.data_ptr(), dw.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, k, stride, 1, 1, st]
+        fwd = lib.sar_conv2d_wgrad_f32
     for it in range(3):
         setbuf(None); torch.cuda.synchronize()
         y.zero_(); fwd(*args)
