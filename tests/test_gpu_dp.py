@@ -72,6 +72,8 @@ def test_two_rank_step_matches_mean_of_shard_gradients():
             sh = parallel.shard_batch(gb, r, 2)
             single.forward_backward_only(sh, sh)
             gsum += st.grads.detach().cpu().numpy()
-        scale = np.abs(gsum).max()
-        assert np.abs(a["grads"] - gsum).max() < 2e-4 * scale, (i, np.abs(a["grads"] - gsum).max(), scale)
+        # flat-vector L2 (not max-abs): the two computations differ only in fp32 summation order (split-K atomics), but a
+        # pre-activation within that noise of zero flips a ReLU and changes single gradient elements discretely
+        err = float(np.linalg.norm(a["grads"] - gsum) / np.linalg.norm(gsum))
+        assert err < 1e-3, (i, err)
         assert not np.array_equal(a["p_before"], a["p_after"])
