@@ -1139,11 +1139,11 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     const bool narrow = Cout <= 32;
     // split the reduction so the grid fills 256 CUs a few times over
     const int tiles = cdiv(Mp, 128) * cdiv(Cout, narrow ? 32 : 64);
-    // measured (tools/conv_bench.py): the split-precision kernel (2 blocks/CU, atomic epilogue) is best at ~512 blocks,
+    // measured (tools/conv_bench.py): the split-precision kernel (2 blocks/CU, atomic epilogue) is best at ~384 blocks,
     // the fp32 kernel (6 blocks/CU) at ~1024; Cout <= 32 keeps the fp32 kernel
     const bool x3 = g_conv_math == 1 && !narrow;
     static const int target_env = getenv("SAR_WGRAD_BLOCKS") ? atoi(getenv("SAR_WGRAD_BLOCKS")) : 0;
-    const int target = target_env ? target_env : (x3 ? 512 : 1024);
+    const int target = target_env ? target_env : (x3 ? 384 : 1024);
     int splits = (target + tiles - 1) / tiles;
     long rows = (R + splits - 1) / splits;
     rows = ((rows + 31) / 32) * 32;
