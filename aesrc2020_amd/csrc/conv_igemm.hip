@@ -1140,8 +1140,10 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     // split the reduction so the grid fills 256 CUs a few times over
     const int tiles = cdiv(Mp, 128) * cdiv(Cout, narrow ? 32 : 64);
     // measured (tools/conv_bench.py): the split-precision kernel (2 blocks/CU, atomic epilogue) is best at ~384 blocks,
-    // the fp32 kernel (6 blocks/CU) at ~1024; Cout <= 32 keeps the fp32 kernel
-    const bool x3 = g_conv_math == 1 && !narrow;
+    // the fp32 kernel (6 blocks/CU) at ~1024
+    // Cout <= 32 keeps the fp32 kernel (measured: 48 vs 55 us); SAR_X3_NARROW bit 2 switches it for experiments
+    static const bool x3_narrow = getenv("SAR_X3_NARROW") ? (atoi(getenv("SAR_X3_NARROW")) & 4) != 0 : false;
+    const bool x3 = g_conv_math == 1 && (!narrow || x3_narrow);
     static const int target_env = getenv("SAR_WGRAD_BLOCKS") ? atoi(getenv("SAR_WGRAD_BLOCKS")) : 0;
     const int target = target_env ? target_env : (x3 ? 384 : 1024);
     int splits = (target + tiles - 1) / tiles;
@@ -1154,7 +1156,8 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
              (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
     dim3 grid(cdiv(Mp, 128), cdiv(Cout, narrow ? 32 : 64), splits);
     if (x3) {                                                        // bf16x3 split-precision path
-        hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), grid, dim3(256), 0, stream, p);
+        if (narrow) hipLaunchKernelGGL((conv_wgrad_x3_kernel<32>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), grid, dim3(256), 0, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
