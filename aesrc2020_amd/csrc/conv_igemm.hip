@@ -1004,6 +1004,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
 // 32-bit element offsets and the magic-number division bound the supported sizes (far above the SAR-Net shapes).
 // 0 = fp32 MFMA (exact fp32 fma chains), 1 = bf16x3 split precision (default; 2^-17 relative per product).
 static int g_conv_math = (getenv("SAR_CONV_MATH") && !strcmp(getenv("SAR_CONV_MATH"), "fp32")) ? 0 : 1;
+
+// Launch-policy knobs for tools/conv_bench.py sweeps (read once; the defaults are the measured optima and what ships):
+//   SAR_NO_SPLITK        disable split-K in fwd/dgrad            SAR_SPLITK_CAP=n   at most n k-slices (default 4)
+//   SAR_WGRAD_BLOCKS=n   target grid size of the weight gradient (default 384 split-precision / 1024 fp32 kernel)
+//   SAR_X3_NARROW=mask   split-precision kernels for the 32-channel layers too: bit 0 forward (default off: perturbs the
+//                        earliest activations), bit 1 dgrad (default on), bit 2 wgrad (default off: slower)
+struct ConvKnobs { bool no_splitk; int splitk_cap, wgrad_blocks, x3_narrow; };
+static const ConvKnobs& conv_knobs() {
+    static const ConvKnobs k{getenv("SAR_NO_SPLITK") != nullptr, getenv("SAR_SPLITK_CAP") ? atoi(getenv("SAR_SPLITK_CAP")) : 4,
+                             getenv("SAR_WGRAD_BLOCKS") ? atoi(getenv("SAR_WGRAD_BLOCKS")) : 0,
+                             getenv("SAR_X3_NARROW") ? atoi(getenv("SAR_X3_NARROW")) : 2};
+    return k;
+}
 #ifdef SAR_TIMING
 extern "C" int sar_dbg_set_timing_buffer(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf), &buf, sizeof(buf)) == hipSuccess ? SAR_OK : SAR_ELAUNCH;
@@ -1021,9 +1034,8 @@ static bool conv_args_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
 // Aim for >= ~3 resident blocks per CU so one block's global-load latency hides behind another's MFMA phase, but keep the
 // atomic traffic of the split-K epilogue low: at most 4 slices, each with >= 4 k-tiles.
 static int pick_conv_splitk(int tiles, int nkt) {
-    static const bool off = getenv("SAR_NO_SPLITK") != nullptr;      // debugging aid
-    static const int cap = getenv("SAR_SPLITK_CAP") ? atoi(getenv("SAR_SPLITK_CAP")) : 4;
-    if (off || tiles >= 200) return 1;           // >= ~1 block per CU: the atomic epilogue costs more than it buys
+    const int cap = conv_knobs().splitk_cap;
+    if (conv_knobs().no_splitk || tiles >= 200) return 1;           // >= ~1 block per CU: the atomic epilogue costs more than it buys
     int s = (768 + tiles - 1) / tiles;
     if (s > nkt / 4) s = nkt / 4;
     if (s > cap) s = cap;
@@ -1045,7 +1057,7 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
     // Off by default for the FORWARD of the 32-channel layers (stage 0): kernel-level accuracy is the same 2^-17, but a
     // perturbation of the earliest activations flips ReLU / max-pool decisions throughout the net, which the parity tests
     // (tiny tensors) see as percent-level gradient changes.  SAR_X3_NARROW bit 0 enables it (-5 us per stage-0 conv).
-    static const bool x3_narrow = getenv("SAR_X3_NARROW") ? (atoi(getenv("SAR_X3_NARROW")) & 1) != 0 : false;
+    const bool x3_narrow = (conv_knobs().x3_narrow & 1) != 0;
     if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
         if (narrow) {                                               // Cout <= 32: 128 x 32 tile, 4 waves stacked along M
             dim3 grid(cdiv(M, 128), cdiv(Cout, 32), 1);
@@ -1099,7 +1111,7 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
     const int bk = (Cout % 32 == 0) ? 32 : 16;
     const bool narrow = Cin <= 32;
     const bool fp32_math = g_conv_math == 0;
-    static const bool x3_narrow = getenv("SAR_X3_NARROW") ? (atoi(getenv("SAR_X3_NARROW")) & 2) != 0 : true;
+    const bool x3_narrow = (conv_knobs().x3_narrow & 2) != 0;
     if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
         if (narrow) {                                               // Cin <= 32: 128 x 32 tile
             hipLaunchKernelGGL((conv_dgrad_x3_kernel<4, 1, 1, 32>), dim3(cdiv(M, 128), cdiv(Cin, 32), 1), dim3(256), 0, stream, p);
@@ -1142,10 +1154,9 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     // measured (tools/conv_bench.py): the split-precision kernel (2 blocks/CU, atomic epilogue) is best at ~384 blocks,
     // the fp32 kernel (6 blocks/CU) at ~1024
     // Cout <= 32 keeps the fp32 kernel (measured: 48 vs 55 us); SAR_X3_NARROW bit 2 switches it for experiments
-    static const bool x3_narrow = getenv("SAR_X3_NARROW") ? (atoi(getenv("SAR_X3_NARROW")) & 4) != 0 : false;
+    const bool x3_narrow = (conv_knobs().x3_narrow & 4) != 0;
     const bool x3 = g_conv_math == 1 && (!narrow || x3_narrow);
-    static const int target_env = getenv("SAR_WGRAD_BLOCKS") ? atoi(getenv("SAR_WGRAD_BLOCKS")) : 0;
-    const int target = target_env ? target_env : (x3 ? 384 : 1024);
+    const int target = conv_knobs().wgrad_blocks ? conv_knobs().wgrad_blocks : (x3 ? 384 : 1024);
     int splits = (target + tiles - 1) / tiles;
     long rows = (R + splits - 1) / splits;
     rows = ((rows + 31) / 32) * 32;

@@ -52,7 +52,7 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const float* __restrict__ bias, int M,
                                                        int N, int K, int lda, int ldb, int ldc, int act,
-                                                       int accumulate, int splitk) {
+                                                       int accumulate, int splitk, float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) float As[BK][LDP];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float ra[4], rb[4];
+    // colsum (weight-gradient GEMMs, B stored (K,N)): the first row of blocks also reduces its B tiles over k -- the bias
+    // gradient sum_rows dY comes for free with dW = X^T dY (B is dY) instead of a separate pass over dY
+    const bool do_colsum = !B_KC && colsum != nullptr && blockIdx.y == 0;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     if (kt0 < kt1) {
         load_tile<A_KC>(ra, A, lda, m0, kt0 * BK, M, K, tid, a_vec);
         load_tile<B_KC>(rb, B, ldb, n0, kt0 * BK, N, K, tid, b_vec);
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int kt = kt0; kt < kt1; ++kt) {
         store_tile<A_KC>(ra, As, tid);
         store_tile<B_KC>(rb, Bs, tid);
+        if (do_colsum) { cs[0] += rb[0]; cs[1] += rb[1]; cs[2] += rb[2]; cs[3] += rb[3]; }
         __syncthreads();
         if (kt + 1 < kt1) {
             load_tile<A_KC>(ra, A, lda, m0, (kt + 1) * BK, M, K, tid, a_vec);
@@ -88,6 +93,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (do_colsum) {                                  // block-uniform; Bs is free after the loop's last barrier
+        *reinterpret_cast<float4*>(&Bs[tid >> 4][(tid & 15) * 4]) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < BK; ++k) t += Bs[k][tid];
+            atomicAdd(colsum + n0 + tid, t);
+        }
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= N) return;
@@ -112,15 +127,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }  // namespace
 
 // C-ABI: see include/sarnet.h
-extern "C" int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
-                            int ldb, int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk,
-                            hipStream_t stream) {
+static int gemm_launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                       int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk, float* colsum, hipStream_t stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splitk < 1) return SAR_EINVAL;
     if (splitk > 1 && act != ACT_NONE) return SAR_EINVAL;  // split-K accumulates atomically: C must be pre-zeroed (or hold the addend)
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk), block(256);
 #define LAUNCH(AK, BK_)                                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, block, 0, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, \
-                       act, accumulate, splitk)
+                       act, accumulate, splitk, colsum)
     if (a_kc && b_kc) LAUNCH(true, true);
     else if (a_kc && !b_kc) LAUNCH(true, false);
     else if (!a_kc && b_kc) LAUNCH(false, true);
@@ -128,4 +142,17 @@ extern "C" int sar_gemm_f32(const float* A, const float* B, float* C, const floa
 #undef LAUNCH
     SAR_CHECK_LAUNCH();
     return SAR_OK;
+}
+
+extern "C" int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                            int ldb, int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk,
+                            hipStream_t stream) {
+    return gemm_launch(A, B, C, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, accumulate, splitk, nullptr, stream);
+}
+
+// Weight gradient of a Dense layer with its bias gradient: dW[in,out] += X^T[in,R] dY[R,out], db[out] += sum_R dY.
+// X is (R, in) row-major (lda), dY is (R, out) row-major (ldb); both results ACCUMULATE (split-K uses atomics).
+extern "C" int sar_gemm_wgrad_f32(const float* X, const float* dY, float* dW, float* db, int in_dim, int out_dim, int R,
+                                  int lda, int ldb, int ldc, int splitk, hipStream_t stream) {
+    return gemm_launch(X, dY, dW, nullptr, in_dim, out_dim, R, lda, ldb, ldc, 0, 0, ACT_NONE, 1, splitk, db, stream);
 }

@@ -73,9 +73,8 @@ class Dense(Layer):
         else:
             dz = dy
         sk = pick_splitk(self.in_dim, self.units, R)
-        gemm(self.x, dz, self.kernel.g, None, self.in_dim, self.units, R, self.in_dim, self.units, self.units, 0, 0, 0, 1, sk)
-        if self.bias is not None:
-            _call("sar_colsum_f32", dz, self.bias.g, R, self.units)
+        _call("sar_gemm_wgrad_f32", self.x, dz, self.kernel.g, self.bias.g if self.bias is not None else None, self.in_dim,
+              self.units, R, self.in_dim, self.units, self.units, sk)
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else self.buf("dx", (R, self.in_dim))
@@ -161,10 +160,8 @@ class BiGRU(Layer):
         sku = pick_splitk(H, 3 * H, R)
         for i, d in enumerate(("forward", "backward")):
             k, u, b = self.p[d]
-            gemm(self.x, dai[i], k.g, None, I, 3 * H, R, I, 3 * H, 3 * H, 0, 0, 0, 1, sk)
-            gemm(self.hprev[i], dah[i], u.g, None, H, 3 * H, R, H, 3 * H, 3 * H, 0, 0, 0, 1, sku)
-            _call("sar_colsum_f32", dai[i], b.g[:3 * H], R, 3 * H)
-            _call("sar_colsum_f32", dah[i], b.g[3 * H:], R, 3 * H)
+            _call("sar_gemm_wgrad_f32", self.x, dai[i], k.g, b.g[:3 * H], I, 3 * H, R, I, 3 * H, 3 * H, sk)
+            _call("sar_gemm_wgrad_f32", self.hprev[i], dah[i], u.g, b.g[3 * H:], H, 3 * H, R, H, 3 * H, 3 * H, sku)
             if need_dx:
                 gemm(dai[i], k.w, dx, None, R, I, 3 * H, 3 * H, 3 * H, I, 1, 1, 0, 1 if (accumulate_dx or i == 1) else 0)
         return dx

@@ -33,6 +33,10 @@ enum { SAR_HEAD_SPHEREFACE = 0, SAR_HEAD_COSFACE = 1, SAR_HEAD_ARCFACE = 2 };
  * b_kc: B is (N,K) row-major else (K,N).  splitk>1 accumulates atomically (act must be NONE). */
 int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                  int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk, sarStream_t stream);
+/* Backward of Dense w.r.t. its parameters in one launch: dW (in,out) += X^T dY and db (out) += column sums of dY
+ * (db nullable); X (R,in) row-major with stride lda, dY (R,out) with stride ldb.  Both accumulate. */
+int sar_gemm_wgrad_f32(const float* X, const float* dY, float* dW, float* db, int in_dim, int out_dim, int R, int lda,
+                       int ldb, int ldc, int splitk, sarStream_t stream);
 
 /* ---- ResNet convolutions: Conv2D at resnet.py:39-42, 60-63, 82-87, 113-117 (TF SAME / VALID padding given as
  * explicit pad_top/pad_left).  scale/shift (nullable) fold the preceding BatchNormalization+ReLU

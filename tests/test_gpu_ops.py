@@ -56,6 +56,20 @@ def test_gemm_layouts(L, a_kc, b_kc, M, N, K):
     check(C, A @ B + bias, name="gemm splitk")
 
 
+@pytest.mark.parametrize("R,I,N,sk", [(250, 64, 96, 1), (2496, 256, 768, 1), (77, 33, 10, 1), (2000, 48, 130, 4), (64, 8192, 256, 1)])
+def test_gemm_wgrad_with_fused_bias_gradient(L, R, I, N, sk):
+    """Dense backward w.r.t. parameters in one launch: dW += X^T dY and db += column sums of dY (both accumulate)."""
+    rng = np.random.default_rng(R + I + N)
+    X = rng.standard_normal((R, I)); dY = rng.standard_normal((R, N))
+    dW0 = rng.standard_normal((I, N)); db0 = rng.standard_normal(N)
+    dW = dev(dW0); db = dev(db0)
+    L.call("sar_gemm_wgrad_f32", dev(X), dev(dY), dW, db, I, N, R, I, N, N, sk)
+    check(dW, dW0 + X.T @ dY, name="dW"); check(db, db0 + dY.sum(0), name="db (fused colsum)")
+    dW2 = dev(dW0)
+    L.call("sar_gemm_wgrad_f32", dev(X), dev(dY), dW2, None, I, N, R, I, N, N, sk)
+    check(dW2, dW0 + X.T @ dY, name="dW without bias")
+
+
 def test_gemm_transpose_detecting(L):
     # asymmetric B with A = I catches a swapped C write (guide rule 16)
     n = 64
