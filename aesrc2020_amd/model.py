@@ -435,7 +435,8 @@ class SARNetModel:
                 graphs = {}
                 for name, fn, after in segments:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # thread_local: the feeder thread (utils.Prefetcher) may allocate / copy on its own stream meanwhile
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         fn()
                     graphs[name] = g
                     g.replay()
