@@ -39,8 +39,9 @@ __device__ unsigned long long* g_tbuf = nullptr;
 struct ConvP {
     const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
     float* y;
-    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk, dbg;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk;
     unsigned magic_a, magic_b;          // ceil(2^32/Wo), ceil(2^32/Ho)
+    float* stats;                       // nullable: per-row-tile BatchNorm partials [gridDim.x][2*Cout] of the OUTPUT (splitk == 1 only)
 };
 struct DgradP {
     const float* dy; const float* w; float* dx;
@@ -67,6 +68,49 @@ __device__ __forceinline__ float4 bn_relu4(float4 v, float4 sc, float4 sh) {
     return v;
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// Forward epilogue shared by the fp32 and the split-precision kernels: y = acc + bias (+ residual), plain stores or split-K
+// atomics -- and, when p.stats is set (never with split-K), the BatchNormalization batch statistics of y for the layer that
+// consumes it (resnet.py:22-26 _bn_relu in front of the next conv): per output channel sum and sum of squares over this
+// block's rows, written as one partial row per row-tile; sar_bn_finalize_f32 combines them.  Saves the separate statistics
+// pass over y.  `red` = at least 2 * WM * WN * 32 floats of LDS that is free after the k-loop's last barrier.
+template <int WM, int WN, int TM>
+__device__ __forceinline__ void fwd_epilogue(const f32x16 (&acc)[TM], const ConvP& p, unsigned M, unsigned m0, int n0, int wm,
+                                             int wn, int lane, float* red) {
+    constexpr int BNt = 32 * WN;
+    const int col = n0 + wn * 32 + (lane & 31);
+    const bool colok = col < p.Cout;
+    const bool lead = blockIdx.z == 0;
+    const float bv = (colok && p.bias && lead) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (colok) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                const long o = (long)row * p.Cout + col;
+                float v = acc[tm][r] + bv;
+                if (p.res && lead) v += p.res[o];
+                if (p.splitk > 1) atomicAdd(p.y + o, v);       // y zeroed by the launcher
+                else p.y[o] = v;
+                s1 += v; s2 = fmaf(v, v, s2);
+            }
+    }
+    if (p.stats == nullptr) return;                             // kernel-uniform
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); // the two half-waves hold the other rows of the same column
+    if (lane < 32) { red[wm * BNt + wn * 32 + lane] = s1; red[(WM + wm) * BNt + wn * 32 + lane] = s2; }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BNt && n0 + t < p.Cout) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int g = 0; g < WM; ++g) { a += red[g * BNt + t]; b += red[(WM + g) * BNt + t]; }
+        float* o = p.stats + (long)blockIdx.x * 2 * p.Cout;
+        o[n0 + t] = a; o[p.Cout + n0 + t] = b;
+    }
+}
 // q = m / d with magic = ceil(2^32 / d) (exact for m * d < 2^32; d == 1 handled explicitly)
 __device__ __forceinline__ unsigned fdiv(unsigned m, unsigned d, unsigned magic) { return d == 1 ? m : __umulhi(m, magic); }
 // bit t = kh*KW+kw set iff row bit kh of hm and column bit kw of wm are set
@@ -248,22 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
             __syncthreads();
         }
     }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cout) return;
-    const bool lead = blockIdx.z == 0;
-    const float bv = (p.bias && lead) ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= M) continue;
-            const long o = (long)row * p.Cout + col;
-            float v = acc[tm][r] + bv;
-            if (p.res && lead) v += p.res[o];
-            if (p.splitk > 1) atomicAdd(p.y + o, v);       // y zeroed by the launcher
-            else p.y[o] = v;
-        }
+    fwd_epilogue<WM, WN, TM>(acc, p, M, m0, n0, wm, wn, lane, &As2[0][0][0]);
 }
 
 // ------------------------------------------------------------------ forward, bf16x3 split-precision MFMA
@@ -427,22 +456,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
         }
     }
     TSTAMP(5);
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cout) return;
-    const bool lead = blockIdx.z == 0;
-    const float bv = (p.bias && lead) ? p.bias[col] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= M) continue;
-            const long o = (long)row * p.Cout + col;
-            float v = acc[tm][r] + bv;
-            if (p.res && lead) v += p.res[o];
-            if (p.splitk > 1) atomicAdd(p.y + o, v);
-            else p.y[o] = v;
-        }
+    fwd_epilogue<WM, WN, TM>(acc, p, M, m0, n0, wm, wn, lane, reinterpret_cast<float*>(&Ah[0][0][0]));
 #ifdef SAR_TIMING
     __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -1042,14 +1056,21 @@ static int pick_conv_splitk(int tiles, int nkt) {
     return s < 1 ? 1 : s;
 }
 
-extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale,
-                                  const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
-                                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
-                                  hipStream_t stream) {
+// stats_part (nullable) = room for stats_rows_cap rows of 2*Cout floats.  When the chosen launch has no split-K and at most
+// that many row tiles, the kernel's epilogue writes the BatchNorm partials of y there and *stats_rows = number of rows;
+// otherwise *stats_rows = 0 and the caller runs the separate statistics pass.
+static int conv_fwd_launch(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                           const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                           int KW, int stride, int pad_top, int pad_left, float* stats_part, int stats_rows_cap,
+                           int* stats_rows, hipStream_t stream) {
+    if (stats_rows) *stats_rows = 0;
     if (!x || !w || !y || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
-    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1, 0,
-            (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
+    ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1,
+            (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho), nullptr};
     if ((long)B * Ho * Wo * (Wo > Ho ? Wo : Ho) >= (1L << 32)) return SAR_EINVAL;
+    auto arm_stats = [&](const dim3& grid) {           // call after p.splitk is final, right before the launch
+        if (stats_part && p.splitk == 1 && (int)grid.x <= stats_rows_cap) { p.stats = stats_part; *stats_rows = (int)grid.x; }
+    };
     const long M = (long)B * Ho * Wo;
     const int bk = (Cin % 32 == 0) ? 32 : 16;
     const bool narrow = Cout <= 32;
@@ -1061,15 +1082,18 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
     if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
         if (narrow) {                                               // Cout <= 32: 128 x 32 tile, 4 waves stacked along M
             dim3 grid(cdiv(M, 128), cdiv(Cout, 32), 1);
+            arm_stats(grid);
             hipLaunchKernelGGL((conv_fwd_x3_kernel<4, 1, 1, 32>), grid, dim3(256), 0, stream, p);
         } else if (cdiv(M, 128) * cdiv(Cout, 64) >= 300) {
             dim3 grid(cdiv(M, 128), cdiv(Cout, 64), 1);
+            arm_stats(grid);
             hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
         } else {
             const int tiles = cdiv(M, 64) * cdiv(Cout, 64);
             p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
             if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
             dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
+            arm_stats(grid);
             hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 1, 32>), grid, dim3(256), 0, stream, p);
         }
         SAR_CHECK_LAUNCH();
@@ -1082,10 +1106,12 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
         p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
         if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
         dim3 grid(cdiv(M, 128), cdiv(Cout, 32), p.splitk);
+        arm_stats(grid);
         if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 32, false>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_fwd_kernel<4, 1, 1, 16, false>), grid, dim3(256), 0, stream, p);
     } else if (cdiv(M, 128) * cdiv(Cout, 64) >= 300) {
         dim3 grid(cdiv(M, 128), cdiv(Cout, 64), 1);
+        arm_stats(grid);
         if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 32, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 2, 16, true>), grid, dim3(256), 0, stream, p);
     } else {
@@ -1093,11 +1119,54 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
         p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
         if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
         dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
+        arm_stats(grid);
         if (bk == 32) hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 1, 32, true>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((conv_fwd_kernel<2, 2, 1, 16, true>), grid, dim3(256), 0, stream, p);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
+}
+
+extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale,
+                                  const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
+                                  int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                  hipStream_t stream) {
+    return conv_fwd_launch(x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left,
+                           nullptr, 0, nullptr, stream);
+}
+
+extern "C" size_t sar_bn_workspace_bytes(int C);
+extern "C" int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, double* sums, float* mean, float* rstd,
+                                float* scale, float* shift, float* moving_mean, float* moving_var, long R, int C, float eps,
+                                float momentum, int unbiased_moving_var, hipStream_t stream);
+extern "C" int sar_bn_finalize_f32(const float* part, int rows, const float* gamma, const float* beta, float* mean,
+                                   float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
+                                   int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream);
+
+// Conv2D followed by the training-mode BatchNormalization statistics of its OUTPUT (the _bn_relu in front of the next conv,
+// resnet.py:22-26,47-65): y as sar_conv2d_fwd_f32, then mean/rstd/scale/shift (+ moving averages) of y exactly as
+// sar_bn_stats_f32(y, gamma_o, ...) would produce.  Without split-K the sums come out of the conv epilogue (no second pass
+// over y); with split-K (small-M layers) the separate statistics kernel runs.  sums_o = BN workspace of the consumer.
+extern "C" int sar_conv2d_fwd_bnstats_f32(const float* x, const float* w, const float* bias, const float* scale,
+                                          const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
+                                          int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                          const float* gamma_o, const float* beta_o, double* sums_o, float* mean_o,
+                                          float* rstd_o, float* scale_o, float* shift_o, float* moving_mean_o,
+                                          float* moving_var_o, float eps, float momentum, int unbiased_moving_var,
+                                          hipStream_t stream) {
+    if (!gamma_o || !beta_o || !sums_o || !mean_o || !rstd_o || !scale_o || !shift_o) return SAR_EINVAL;
+    float* part = reinterpret_cast<float*>(sums_o + 2 * Cout);
+    const int cap = (int)((sar_bn_workspace_bytes(Cout) - sizeof(double) * 2 * Cout) / (sizeof(float) * 2 * Cout));
+    int rows = 0;
+    const int rc = conv_fwd_launch(x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top,
+                                   pad_left, part, cap, &rows, stream);
+    if (rc != SAR_OK) return rc;
+    const long R = (long)B * Ho * Wo;
+    if (rows > 0)
+        return sar_bn_finalize_f32(part, rows, gamma_o, beta_o, mean_o, rstd_o, scale_o, shift_o, moving_mean_o, moving_var_o, R,
+                                   Cout, eps, momentum, unbiased_moving_var, stream);
+    return sar_bn_stats_f32(y, gamma_o, beta_o, sums_o, mean_o, rstd_o, scale_o, shift_o, moving_mean_o, moving_var_o, R, Cout,
+                            eps, momentum, unbiased_moving_var, stream);
 }
 
 extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho,

@@ -9,7 +9,8 @@
 
 namespace {
 
-constexpr int BN_MAX_BLOCKS = 256;
+constexpr int BN_MAX_BLOCKS = 256;    // grid cap of the reduction kernels in this file
+constexpr int BN_PART_ROWS = 1024;    // partial rows the workspace holds (conv epilogues write one row per row tile)
 
 // ---- per-channel sum / sum-of-squares of x (R, C), C % 4 == 0, C <= 1024 -----------------------------
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long R,
@@ -341,8 +342,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 }  // namespace
 
-// BN reduction workspace: double totals[2C] followed by float partials[BN_MAX_BLOCKS][2C]
-extern "C" size_t sar_bn_workspace_bytes(int C) { return sizeof(double) * 2 * C + sizeof(float) * (size_t)BN_MAX_BLOCKS * 2 * C; }
+// BN reduction workspace: double totals[2C] followed by float partials[BN_PART_ROWS][2C]
+extern "C" size_t sar_bn_workspace_bytes(int C) { return sizeof(double) * 2 * C + sizeof(float) * (size_t)BN_PART_ROWS * 2 * C; }
 
 static int pow2_tpr(int C) { int v = C / 4, p = 1; while (p < v) p <<= 1; return p; }
 
@@ -359,6 +360,18 @@ extern "C" int sar_bn_stats_f32(const float* x, const float* gamma, const float*
     float* part = reinterpret_cast<float*>(sums + 2 * C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((int)nb), dim3(256), 0, stream, x, part, R, C, tpr);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, part, (int)nb, gamma, beta, mean, rstd, scale,
+                       shift, moving_mean, moving_var, R, C, eps, momentum, unbiased_moving_var);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// Second half of sar_bn_stats_f32 for producers that wrote the per-block partials themselves (conv epilogues):
+// part = [rows][2C] (sum | sum of squares); combines in fp64, folds gamma/beta, updates the moving averages.
+extern "C" int sar_bn_finalize_f32(const float* part, int rows, const float* gamma, const float* beta, float* mean,
+                                   float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
+                                   int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream) {
+    if (!part || rows < 1 || rows > BN_PART_ROWS || !gamma || !beta || !mean || !rstd || !scale || !shift || C < 1 || R <= 0) return SAR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, part, rows, gamma, beta, mean, rstd, scale,
                        shift, moving_mean, moving_var, R, C, eps, momentum, unbiased_moving_var);
     SAR_CHECK_LAUNCH();
     return SAR_OK;

@@ -36,10 +36,14 @@ class _BN:
     def _b(self, key, shape, dtype=torch.float32):
         return self.store.bufs.get(self.name + "/" + key, shape, dtype)
 
-    def stats(self, x, R):
+    def prepare(self):
         C = self.C
         self.mean, self.rstd, self.scale, self.shift = (self._b(k, (C,)) for k in ("mean", "rstd", "scale", "shift"))
         self.sums = self._b("sums", (_lib.bn_workspace_doubles(C),), torch.float64)
+
+    def stats(self, x, R):
+        C = self.C
+        self.prepare()
         if not self.store.training:                                          # learning phase 0: fold the moving averages
             _call("sar_bn_fold_f32", self.gamma.w, self.beta.w, self.moving_mean.w, self.moving_var.w, self.scale, self.shift, C, BN_EPS)
             return
@@ -69,9 +73,17 @@ class _Conv:
         self.H, self.W, self.Ho, self.Wo = H, W, ho, wo
         return ho, wo
 
-    def fwd(self, x, y, B, bn=None, residual=None):
-        _call("sar_conv2d_fwd_f32", x, self.kernel.w, self.bias.w, bn.scale if bn else None, bn.shift if bn else None,
-              residual, y, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+    def fwd(self, x, y, B, bn=None, residual=None, bn_out=None):
+        """y = conv(relu(bn(x))) + bias (+ residual).  bn_out: the BatchNorm that consumes y next -- its batch statistics are
+        produced by the same call (conv epilogue where the launch has no split-K), training mode only."""
+        args = (x, self.kernel.w, self.bias.w, bn.scale if bn else None, bn.shift if bn else None, residual, y, B, self.H, self.W,
+                self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+        if bn_out is None:
+            _call("sar_conv2d_fwd_f32", *args)
+        else:
+            bn_out.prepare()
+            _call("sar_conv2d_fwd_bnstats_f32", *args, bn_out.gamma.w, bn_out.beta.w, bn_out.sums, bn_out.mean, bn_out.rstd,
+                  bn_out.scale, bn_out.shift, bn_out.moving_mean.w, bn_out.moving_var.w, BN_EPS, BN_MOMENTUM, 1)
 
     def dgrad(self, dy, dx, B, accumulate=0):
         _call("sar_conv2d_dgrad_f32", dy, self.kernel.w, dx, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
@@ -156,26 +168,33 @@ class ResNetTrunk(Layer):
         _call("sar_bn_relu_maxpool_fwd_f32", self.stem_out, self.stem_bn.scale, self.stem_bn.shift, self.pooled, self.pool_idx,
               B, H, W, c0, Hp, Wp, self.pool_pt, self.pool_pl)
         cur = self.pooled
+        # training: every conv also produces the batch statistics of the BatchNorm that consumes its output (no separate
+        # pass over the activation); inference: the moving averages are folded instead (stats() does that)
+        fused = self.store.training
+        nblk = len(self.blocks)
         for n, blk in enumerate(self.blocks):
             H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
             blk["x"] = cur
-            if blk["bn1"] is not None:
+            if blk["bn1"] is not None and not (fused and n > 0):
                 blk["bn1"].stats(cur, B * H * W)
             c1 = self.buf("b%d_c1" % n, (B, H2, W2, blk["cout"]))
-            blk["conv1"].fwd(cur, c1, B, bn=blk["bn1"])
-            blk["bn2"].stats(c1, B * H2 * W2)
+            blk["conv1"].fwd(cur, c1, B, bn=blk["bn1"], bn_out=blk["bn2"] if fused else None)
+            if not fused:
+                blk["bn2"].stats(c1, B * H2 * W2)
             if blk["sc"] is not None:
                 sc = self.buf("b%d_sc" % n, (B, H2, W2, blk["cout"]))
                 blk["sc"].fwd(cur, sc, B)
             else:
                 sc = cur
             y = self.buf("b%d_y" % n, (B, H2, W2, blk["cout"]))
-            blk["conv2"].fwd(c1, y, B, bn=blk["bn2"], residual=sc)
+            nxt = self.blocks[n + 1]["bn1"] if n + 1 < nblk else self.final_bn
+            blk["conv2"].fwd(c1, y, B, bn=blk["bn2"], residual=sc, bn_out=nxt if fused else None)
             blk["c1"] = c1
             cur = y
         H, W = self.out_hw
         self.pre_final = cur
-        self.final_bn.stats(cur, B * H * W)
+        if not fused:
+            self.final_bn.stats(cur, B * H * W)
         out = self.buf("out", (B, H, W, self.out_c))
         _call("sar_bn_apply_f32", cur, self.final_bn.scale, self.final_bn.shift, out, B * H * W, self.out_c, 1)
         return out

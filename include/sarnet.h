@@ -45,6 +45,15 @@ int sar_gemm_wgrad_f32(const float* X, const float* dY, float* dW, float* db, in
 int sar_conv2d_fwd_f32(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
                        const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
                        int KW, int stride, int pad_top, int pad_left, sarStream_t stream);
+/* sar_conv2d_fwd_f32 followed by the training-mode BatchNormalization statistics of its OUTPUT for the _bn_relu that
+ * consumes it (resnet.py:22-26): identical results to sar_conv2d_fwd_f32 + sar_bn_stats_f32(y, gamma_o, ...).  Without
+ * split-K the sums come out of the conv epilogue (no second pass over y).  sums_o = that BatchNorm's workspace. */
+int sar_conv2d_fwd_bnstats_f32(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                               const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                               int KH, int KW, int stride, int pad_top, int pad_left, const float* gamma_o,
+                               const float* beta_o, double* sums_o, float* mean_o, float* rstd_o, float* scale_o,
+                               float* shift_o, float* moving_mean_o, float* moving_var_o, float eps, float momentum,
+                               int unbiased_moving_var, sarStream_t stream);
 int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
                          int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int accumulate,
                          sarStream_t stream);
@@ -79,6 +88,10 @@ size_t sar_bn_workspace_bytes(int C);
 int sar_bn_stats_f32(const float* x, const float* gamma, const float* beta, double* sums, float* mean, float* rstd,
                      float* scale, float* shift, float* moving_mean, float* moving_var, long R, int C, float eps,
                      float momentum, int unbiased_moving_var, sarStream_t stream);
+/* Second half of sar_bn_stats_f32 for a producer that wrote `rows` partial rows [2C] (sum | sum of squares) itself. */
+int sar_bn_finalize_f32(const float* part, int rows, const float* gamma, const float* beta, float* mean, float* rstd,
+                        float* scale, float* shift, float* moving_mean, float* moving_var, long R, int C, float eps,
+                        float momentum, int unbiased_moving_var, sarStream_t stream);
 int sar_bn_apply_f32(const float* x, const float* scale, const float* shift, float* y, long R, int C, int relu,
                      sarStream_t stream);
 /* Inference mode (Keras learning phase 0, used by predict/evaluate: train.py:42 validation_data, model.py:386):

@@ -129,6 +129,39 @@ def test_conv_fwd_dgrad_wgrad(L, case):
     check(db2, db_ref, name="colsum")
 
 
+@pytest.mark.parametrize("case", [  # B,H,W,Cin,Cout,k,stride,residual -- with / without split-K, narrow / wide, 1x1
+    (4, 25, 20, 64, 32, 3, 1, True), (16, 25, 10, 64, 64, 3, 1, True), (3, 13, 3, 128, 128, 3, 1, False),
+    (2, 9, 5, 32, 48, 3, 2, False), (64, 50, 10, 64, 64, 3, 1, True), (5, 25, 5, 64, 128, 1, 2, False)])
+def test_conv_with_fused_batchnorm_statistics(L, case):
+    """sar_conv2d_fwd_bnstats_f32 == sar_conv2d_fwd_f32 followed by sar_bn_stats_f32 on its output (oracle: batchnorm of the
+    float64 conv output): mean / rstd / folded scale+shift and the moving averages of the consuming BatchNorm."""
+    B, H, W, Cin, Cout, k, s, res = case
+    rng = np.random.default_rng(sum(case[:7]) + 7)
+    x = rng.standard_normal((B, H, W, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) * 0.1; b = rng.standard_normal(Cout)
+    sc = rng.uniform(0.5, 1.5, Cin); sh = rng.standard_normal(Cin) * 0.3
+    gamma = rng.uniform(0.5, 1.5, Cout); beta = rng.standard_normal(Cout)
+    pad = "same" if k == 3 else "valid"
+    y_ref, _ = O.conv2d_fwd(np.maximum(x * sc + sh, 0), w, b, (s, s), pad)
+    _, Ho, Wo, _ = y_ref.shape
+    pt, pl = (O.same_pads(H, k, s)[1], O.same_pads(W, k, s)[1]) if pad == "same" else (0, 0)
+    r = rng.standard_normal(y_ref.shape) if res else None
+    if res:
+        y_ref = y_ref + r
+    R = B * Ho * Wo
+    mu = y_ref.reshape(R, Cout).mean(0); var = y_ref.reshape(R, Cout).var(0)
+    y = zeros(B, Ho, Wo, Cout)
+    mean, rstd, scale, shift = (zeros(Cout) for _ in range(4))
+    mm = zeros(Cout); mv = dev(np.ones(Cout))
+    sums = zeros(L.bn_workspace_doubles(Cout), dtype=torch.float64)
+    L.call("sar_conv2d_fwd_bnstats_f32", dev(x), dev(w), dev(b), dev(sc), dev(sh), dev(r) if res else None, y, B, H, W, Cin, Ho, Wo,
+           Cout, k, k, s, pt, pl, dev(gamma), dev(beta), sums, mean, rstd, scale, shift, mm, mv, 1e-3, 0.99, 1)
+    check(y, y_ref, name="conv out")
+    check(mean, mu, name="bn mean", scale=np.abs(y_ref).max()); check(rstd, 1 / np.sqrt(var + 1e-3), name="bn rstd")
+    check(scale, gamma / np.sqrt(var + 1e-3), name="bn scale"); check(shift, beta - mu * gamma / np.sqrt(var + 1e-3), name="bn shift", scale=np.abs(y_ref).max())
+    check(mm, 0.01 * mu, name="moving mean", scale=np.abs(y_ref).max() * 0.01)
+    check(mv, 0.99 + 0.01 * var * R / (R - 1), name="moving var")
+
+
 @pytest.mark.parametrize("B,T,D,C0", [(2, 100, 80, 64), (2, 37, 21, 8), (1, 64, 80, 32)])
 def test_stem_and_fused_maxpool(L, B, T, D, C0):
     rng = np.random.default_rng(T)
