@@ -11,49 +11,74 @@ namespace {
 
 constexpr float CTC_EPS = 1e-7f;
 constexpr int CTC_SMAX = 512;      // 2*max_label_len+1 (reference: 2*72+1 = 145)
+constexpr size_t CTC_LDS_CAP = 56 * 1024;   // dynamic LDS for the e / alpha staging (with the static arrays: < 64 KB, no attribute needed)
 
 __device__ __forceinline__ int ext_label(const float* lab, int s, int blank) {
     return (s & 1) ? (int)lab[s >> 1] : blank;
 }
 
+// Both kernels split the work into a PARALLEL part (denominators, emission log-probabilities e[t][s] of the extended label,
+// the dense part of the gradient) and the inherently SEQUENTIAL alpha / beta recursion.  The recursion used to issue a
+// dependent global load of the 10 MB probability tensor and two block barriers per frame (~2 us x L of pure latency); now it
+// reads e (and alpha, backward) from LDS when T*S fits (always for the reference shapes: 39 x 33), else from the
+// L2-resident workspace.
+constexpr int CTC_NF = 4;           // frames a wave reduces at once (independent loads in flight)
+
+template <bool LDS_E>
 __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
                                                       const int* __restrict__ in_len, const int* __restrict__ lab_len,
                                                       float* __restrict__ loss, float* __restrict__ alpha_ws,
-                                                      float* __restrict__ logden_ws, int L, int V, int maxU, int Smax) {
-    __shared__ float red[16];
+                                                      float* __restrict__ logden_ws, float* __restrict__ e_ws, int L, int V,
+                                                      int maxU, int Smax) {
+    extern __shared__ float e_s[];               // LDS_E: [L][Smax]
     __shared__ float al[2][CTC_SMAX];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int T = in_len[b]; if (T > L) T = L;
     const int U = min(lab_len[b], maxU), S = 2 * U + 1, blank = V - 1;
     const float* p = probs + (long)b * L * V;
     const float* lab = labels + (long)b * maxU;
     float* aw = alpha_ws + (long)b * L * Smax;
+    float* ew = e_ws + (long)b * L * Smax;
     float* ld = logden_ws + (long)b * L;
-    // log denominators
-    for (int t = 0; t < T; ++t) {
-        float s = 0.f;
-        for (int v = tid; v < V; v += 256) s += p[(long)t * V + v] + CTC_EPS;
-        s = block_sum(s, red);
-        if (tid == 0) ld[t] = logf(s);
+    // (1) log denominators: each wave reduces CTC_NF frames at a time
+    for (int t0 = wave * CTC_NF; t0 < T; t0 += 4 * CTC_NF) {
+        float acc[CTC_NF];
+#pragma unroll
+        for (int j = 0; j < CTC_NF; ++j) acc[j] = 0.f;
+        for (int v = lane; v < V; v += 64) {
+#pragma unroll
+            for (int j = 0; j < CTC_NF; ++j) acc[j] += p[(long)min(t0 + j, T - 1) * V + v] + CTC_EPS;
+        }
+#pragma unroll
+        for (int j = 0; j < CTC_NF; ++j) {
+            const float sum = wave_sum(acc[j]);
+            if (lane == 0 && t0 + j < T) ld[t0 + j] = logf(sum);
+        }
     }
     __syncthreads();
-    // state-local constants (each thread owns states tid, tid+256)
-    for (int s = tid; s < S; s += 256) {
-        float a = -INFINITY;
-        if (s < 2 && T > 0) a = logf(p[ext_label(lab, s, blank)] + CTC_EPS) - ld[0];
-        al[0][s] = a; aw[s] = a;
+    // (2) emissions of the extended label: e[t][s] = log y_t(l'_s), all (t, s) in parallel
+    for (int i = tid; i < T * S; i += 256) {
+        const int t = i / S, s_ = i - t * S;
+        const float e = logf(p[(long)t * V + ext_label(lab, s_, blank)] + CTC_EPS) - ld[t];
+        ew[(long)t * Smax + s_] = e;                                  // backward reads it from the workspace
+        if (LDS_E) e_s[t * Smax + s_] = e;
+    }
+    __syncthreads();
+    // (3) alpha recursion
+    for (int s_ = tid; s_ < S; s_ += 256) {
+        const float a = (s_ < 2 && T > 0) ? (LDS_E ? e_s[s_] : ew[s_]) : -INFINITY;
+        al[0][s_] = a; aw[s_] = a;
     }
     __syncthreads();
     for (int t = 1; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
-        const float ldt = ld[t];
-        for (int s = tid; s < S; s += 256) {
-            const int k = ext_label(lab, s, blank);
-            float a = al[prv][s];
-            if (s >= 1) a = lse2(a, al[prv][s - 1]);
-            if (s >= 2 && k != blank && k != ext_label(lab, s - 2, blank)) a = lse2(a, al[prv][s - 2]);
-            a += logf(p[(long)t * V + k] + CTC_EPS) - ldt;
-            al[cur][s] = a; aw[(long)t * Smax + s] = a;
+        for (int s_ = tid; s_ < S; s_ += 256) {
+            const int k = ext_label(lab, s_, blank);
+            float a = al[prv][s_];
+            if (s_ >= 1) a = lse2(a, al[prv][s_ - 1]);
+            if (s_ >= 2 && k != blank && k != ext_label(lab, s_ - 2, blank)) a = lse2(a, al[prv][s_ - 2]);
+            a += LDS_E ? e_s[t * Smax + s_] : ew[(long)t * Smax + s_];
+            al[cur][s_] = a; aw[(long)t * Smax + s_] = a;
         }
         __syncthreads();
     }
@@ -68,58 +93,74 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     }
 }
 
+// dp[t][v] = g * (1/den_t - occ_t(v) / (p_t(v) + eps)); occ_t(v) = sum over states s with l'_s = v of exp(alpha+beta-ll).
+// Dense part g/den_t first (parallel), then per frame the few label symbols are corrected with atomics:
+// occ_t(l'_s)/(p+eps) = exp(alpha_t(s) + beta_t(s) - ll - e_t(s) - log den_t)   [beta excludes the emission at t].
+template <bool LDS_E>
 __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
                                                       const int* __restrict__ in_len, const int* __restrict__ lab_len,
                                                       const float* __restrict__ loss, const float* __restrict__ dloss,
                                                       const float* __restrict__ alpha_ws,
-                                                      const float* __restrict__ logden_ws, float* __restrict__ dprobs,
-                                                      int L, int V, int maxU, int Smax) {
-    extern __shared__ float occ[];               // [V]
+                                                      const float* __restrict__ logden_ws, const float* __restrict__ e_ws,
+                                                      float* __restrict__ dprobs, int L, int V, int maxU, int Smax) {
+    extern __shared__ float dyn[];               // LDS_E: e [L][Smax] | alpha - e - log den [L][Smax]
     __shared__ float be[2][CTC_SMAX];            // beta (excludes the emission at t)
     const int b = blockIdx.x, tid = threadIdx.x;
     int T = in_len[b]; if (T > L) T = L;
     const int U = min(lab_len[b], maxU), S = 2 * U + 1, blank = V - 1;
-    const float* p = probs + (long)b * L * V;
     const float* lab = labels + (long)b * maxU;
     const float* aw = alpha_ws + (long)b * L * Smax;
+    const float* ew = e_ws + (long)b * L * Smax;
     const float* ld = logden_ws + (long)b * L;
     float* dp = dprobs + (long)b * L * V;
+    float* e_s = dyn; float* c_s = dyn + (LDS_E ? L * Smax : 0);
     const float ll = -loss[b];
     const float g = dloss[b];
     const bool feasible = (ll > -INFINITY) && (ll < INFINITY);
-    // frames beyond the input length (and everything when infeasible) get zero gradient
-    for (long i = (long)(feasible ? T : 0) * V + tid; i < (long)L * V; i += 256) dp[i] = 0.f;
+    // dense part; frames beyond the input length (and everything when infeasible) get zero gradient
+    const int Tl = feasible ? T : 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool vec = (V & 3) == 0 && (reinterpret_cast<uintptr_t>(dp) & 15) == 0;
+    for (int t = wave; t < L; t += 4) {                               // one wave per frame row, 16-byte stores
+        const float val = t < Tl ? g * expf(-ld[t]) : 0.f;
+        float* row = dp + (long)t * V;
+        if (vec) {
+            const float4 v4 = make_float4(val, val, val, val);
+            for (int v = lane * 4; v < V; v += 256) *reinterpret_cast<float4*>(row + v) = v4;
+        } else {
+            for (int v = lane; v < V; v += 64) row[v] = val;
+        }
+    }
     if (!feasible) return;
+    if (LDS_E) {
+        for (int i = tid; i < T * S; i += 256) {
+            const int t = i / S, s_ = i - t * S;
+            const float e = ew[(long)t * Smax + s_];
+            e_s[t * Smax + s_] = e; c_s[t * Smax + s_] = aw[(long)t * Smax + s_] - e - ld[t] - ll;
+        }
+    }
+    __syncthreads();                                                  // dense rows written before the atomics below
     for (int t = T - 1; t >= 0; --t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        for (int v = tid; v < V; v += 256) occ[v] = 0.f;
-        for (int s = tid; s < S; s += 256) {
+        for (int s_ = tid; s_ < S; s_ += 256) {
             float bb;
             if (t == T - 1) {
-                bb = (s >= S - 2) ? 0.f : -INFINITY;
+                bb = (s_ >= S - 2) ? 0.f : -INFINITY;
             } else {
-                const float ldn = ld[t + 1];
-                const int k0 = ext_label(lab, s, blank);
-                bb = be[nxt][s] + logf(p[(long)(t + 1) * V + k0] + CTC_EPS) - ldn;
-                if (s + 1 < S) {
-                    const int k1 = ext_label(lab, s + 1, blank);
-                    bb = lse2(bb, be[nxt][s + 1] + logf(p[(long)(t + 1) * V + k1] + CTC_EPS) - ldn);
-                }
-                if (s + 2 < S) {
-                    const int k2 = ext_label(lab, s + 2, blank);
-                    if (k2 != blank && k2 != k0) bb = lse2(bb, be[nxt][s + 2] + logf(p[(long)(t + 1) * V + k2] + CTC_EPS) - ldn);
+                const int k0 = ext_label(lab, s_, blank);
+                const float e0 = LDS_E ? e_s[(t + 1) * Smax + s_] : ew[(long)(t + 1) * Smax + s_];
+                bb = be[nxt][s_] + e0;
+                if (s_ + 1 < S) bb = lse2(bb, be[nxt][s_ + 1] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 1] : ew[(long)(t + 1) * Smax + s_ + 1]));
+                if (s_ + 2 < S) {
+                    const int k2 = ext_label(lab, s_ + 2, blank);
+                    if (k2 != blank && k2 != k0) bb = lse2(bb, be[nxt][s_ + 2] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 2] : ew[(long)(t + 1) * Smax + s_ + 2]));
                 }
             }
-            be[cur][s] = bb;
+            be[cur][s_] = bb;
+            const float c = LDS_E ? c_s[t * Smax + s_] : (aw[(long)t * Smax + s_] - ew[(long)t * Smax + s_] - ld[t] - ll);
+            const float w = expf(c + bb);
+            if (w > 0.f) atomicAdd(&dp[(long)t * V + ext_label(lab, s_, blank)], -g * w);
         }
-        __syncthreads();                          // occ zeroed, beta[cur] complete
-        for (int s = tid; s < S; s += 256) {
-            const float w = expf(aw[(long)t * Smax + s] + be[cur][s] - ll);
-            if (w > 0.f) atomicAdd(&occ[ext_label(lab, s, blank)], w);
-        }
-        __syncthreads();
-        const float inv_den = expf(-ld[t]);
-        for (int v = tid; v < V; v += 256) dp[(long)t * V + v] = g * (inv_den - occ[v] / (p[(long)t * V + v] + CTC_EPS));
         __syncthreads();
     }
 }
@@ -148,7 +189,7 @@ __global__ void ctc_greedy_kernel(const float* __restrict__ probs, const int* __
 
 extern "C" size_t sar_ctc_workspace_bytes(int B, int L, int max_label_len) {
     const int Smax = 2 * max_label_len + 1;
-    return sizeof(float) * ((size_t)B * L * Smax + (size_t)B * L);
+    return sizeof(float) * (2 * (size_t)B * L * Smax + (size_t)B * L);       // alpha | emissions e | log denominators
 }
 
 extern "C" int sar_ctc_batch_cost_fwd_f32(const float* probs, const float* labels, const int* in_len, const int* lab_len,
@@ -159,8 +200,13 @@ extern "C" int sar_ctc_batch_cost_fwd_f32(const float* probs, const float* label
         workspace_bytes < sar_ctc_workspace_bytes(B, L, max_label_len))
         return SAR_EINVAL;
     float* alpha = static_cast<float*>(workspace);
-    float* logden = alpha + (size_t)B * L * Smax;
-    hipLaunchKernelGGL(ctc_fwd_kernel, dim3(B), dim3(256), 0, stream, probs, labels, in_len, lab_len, loss, alpha, logden, L, V, max_label_len, Smax);
+    float* ews = alpha + (size_t)B * L * Smax;
+    float* logden = ews + (size_t)B * L * Smax;
+    const size_t lds = sizeof(float) * (size_t)L * Smax;
+    if (lds <= CTC_LDS_CAP)
+        hipLaunchKernelGGL(ctc_fwd_kernel<true>, dim3(B), dim3(256), lds, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
+    else
+        hipLaunchKernelGGL(ctc_fwd_kernel<false>, dim3(B), dim3(256), 0, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -174,8 +220,13 @@ extern "C" int sar_ctc_batch_cost_bwd_f32(const float* probs, const float* label
         workspace_bytes < sar_ctc_workspace_bytes(B, L, max_label_len) || V > 8192)
         return SAR_EINVAL;
     const float* alpha = static_cast<const float*>(workspace);
-    const float* logden = alpha + (size_t)B * L * Smax;
-    hipLaunchKernelGGL(ctc_bwd_kernel, dim3(B), dim3(256), sizeof(float) * V, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, dprobs, L, V, max_label_len, Smax);
+    const float* ews = alpha + (size_t)B * L * Smax;
+    const float* logden = ews + (size_t)B * L * Smax;
+    const size_t lds = 2 * sizeof(float) * (size_t)L * Smax;
+    if (lds <= CTC_LDS_CAP)
+        hipLaunchKernelGGL(ctc_bwd_kernel<true>, dim3(B), dim3(256), lds, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
+    else
+        hipLaunchKernelGGL(ctc_bwd_kernel<false>, dim3(B), dim3(256), 0, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
