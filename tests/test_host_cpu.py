@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         if name.endswith("_bytes") or name.endswith("_conv_math"):
             continue
         assert at[-1].__name__ == "c_void_p", name
-    assert _lib.ctc_workspace_bytes(64, 39, 72) == 4 * (64 * 39 * 145 + 64 * 39)    # host-only query, no GPU needed
+    assert _lib.ctc_workspace_bytes(64, 39, 72) == 4 * (2 * 64 * 39 * 145 + 64 * 39)    # alpha + emissions + log denominators; host-only query
     assert _lib.bn_workspace_doubles(32) == 1026 * 32        # fp64 totals[2C] + 1024 fp32 partial rows
     assert _lib.get_conv_math() in ("fp32", "bf16x3")
 
