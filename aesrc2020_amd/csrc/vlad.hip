@@ -196,12 +196,264 @@ __global__ __launch_bounds__(256) void vlad_bwd_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ MFMA formulation (D <= 256, K <= 64)
+// The three contractions of the layer are small per-utterance GEMMs -- V = A^T X (K x L x D), dA = X dres^T (L x D x K),
+// dfeat = A dres (L x K x D) -- so they run on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains) from LDS tiles instead of scalar
+// FMA loops with one LDS read per FMA.  L is processed in chunks (softmax, A_out and the column sums are chunk-local), so
+// utterances of any length fit.  Operand conventions of the 32x32x2 MFMA: A-operand lane -> (row lane&31, k lane>>5),
+// B-operand lane -> (col lane&31, k lane>>5), acc[r] -> (row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31).
+constexpr int VF_LC = 64;           // rows of L per chunk, forward
+constexpr int VB_LC = 32;           // backward (two more LDS tiles live)
+
+__global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restrict__ feat, const float* __restrict__ score,
+                                                            const float* __restrict__ centers, float* __restrict__ out,
+                                                            float* __restrict__ A_out, float* __restrict__ inv_out, int L,
+                                                            int D, int K, int KG) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Kt = (K + 31) / 32, Dt = (D + 31) / 32, KGP = max(KG, Kt * 32), DP = Dt * 32;
+    float* A_c = sm;                     // [VF_LC][KGP]   soft assignments of the chunk (zero beyond L / KG)
+    float* X_c = A_c + VF_LC * KGP;      // [VF_LC][DP]    features of the chunk (zero beyond L / D)
+    float* asum = X_c + VF_LC * DP;      // [KGP]
+    float* ss = asum + KGP;              // [64]           squared norms of the residual rows
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = feat + (long)b * L * D;
+    const float* sc = score + (long)b * L * KG;
+    float* Ao = A_out + (long)b * L * KG;
+    for (int i = tid; i < KGP; i += 256) asum[i] = 0.f;
+    for (int i = tid; i < 64; i += 256) ss[i] = 0.f;
+    f32x16 acc[2][2];                    // [d-tile slot: wave, wave+4][k-tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.f;
+    for (int l0 = 0; l0 < L; l0 += VF_LC) {
+        const int rows = min(VF_LC, L - l0);
+        __syncthreads();                                             // previous chunk's tiles are no longer read
+        for (int i = tid; i < VF_LC * KGP; i += 256) {
+            const int r = i / KGP, k = i - r * KGP;
+            A_c[i] = (r < rows && k < KG) ? sc[(long)(l0 + r) * KG + k] : -INFINITY;
+        }
+        for (int i = tid; i < VF_LC * DP; i += 256) {
+            const int r = i / DP, d = i - r * DP;
+            X_c[i] = (r < rows && d < D) ? x[(long)(l0 + r) * D + d] : 0.f;
+        }
+        __syncthreads();
+        if (tid < VF_LC) {                                           // softmax of one row (rows are short)
+            float* srow = A_c + tid * KGP;
+            if (tid < rows) {
+                float m = -INFINITY;
+                for (int k = 0; k < KG; ++k) m = fmaxf(m, srow[k]);
+                float sum = 0.f;
+                for (int k = 0; k < KG; ++k) { const float e = expf(srow[k] - m); srow[k] = e; sum += e; }
+                const float inv = 1.f / sum;
+                for (int k = 0; k < KG; ++k) srow[k] *= inv;
+                for (int k = KG; k < KGP; ++k) srow[k] = 0.f;
+            } else {
+                for (int k = 0; k < KGP; ++k) srow[k] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < rows * KG; i += 256) { const int r = i / KG, k = i - r * KG; Ao[(long)(l0 + r) * KG + k] = A_c[r * KGP + k]; }
+        if (tid < KG) { float t = 0.f; for (int r = 0; r < rows; ++r) t += A_c[r * KGP + tid]; asum[tid] += t; }
+        const int i31 = lane & 31, kk = lane >> 5;
+        for (int r0 = 0; r0 < VF_LC; r0 += 2) {
+            if (r0 >= rows) break;                                    // block-uniform; further rows are zero
+            float av[2], bv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) av[c] = c < Kt ? A_c[(r0 + kk) * KGP + c * 32 + i31] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) bv[a] = (wave + 4 * a) < Dt ? X_c[(r0 + kk) * DP + (wave + 4 * a) * 32 + i31] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if ((wave + 4 * a) < Dt && c < Kt) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[a], acc[a][c], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                 // asum complete
+    // residuals in registers, squared row norms through one LDS atomic per (half-wave, row)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c >= Kt) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float sq = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int d = (wave + 4 * a) * 32 + (lane & 31);
+                float v = 0.f;
+                if ((wave + 4 * a) < Dt && d < D && k < K) v = acc[a][c][r] - asum[k] * centers[(long)k * D + d];
+                acc[a][c][r] = v; sq = fmaf(v, v, sq);
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            if ((lane & 31) == 0 && k < K) atomicAdd(&ss[k], sq);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        const float s2 = ss[k];
+        const float iv = 1.f / sqrtf(fmaxf(s2, 1e-12f));
+        inv_out[(long)b * K + k] = s2 >= 1e-12f ? iv : -iv;
+    }
+    float* o = out + (long)b * K * D;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c >= Kt) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (k >= K) continue;
+            const float iv = 1.f / sqrtf(fmaxf(ss[k], 1e-12f));
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int d = (wave + 4 * a) * 32 + (lane & 31);
+                if ((wave + 4 * a) < Dt && d < D) o[(long)k * D + d] = acc[a][c][r] * iv;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ feat,
+                                                            const float* __restrict__ A, const float* __restrict__ centers,
+                                                            const float* __restrict__ out, const float* __restrict__ inv,
+                                                            float* __restrict__ dfeat, float* __restrict__ dscore,
+                                                            float* __restrict__ dcenters, int L, int D, int K, int KG,
+                                                            int accumulate_dfeat) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Kt = (K + 31) / 32, Dt = (D + 31) / 32, KP = Kt * 32, DP1 = Dt * 32 + 1, KGP1 = max(KG, KP) | 1;
+    float* dres = sm;                     // [KP][DP1]       gradient w.r.t. the un-normalised residuals (zero beyond K / D)
+    float* X_c = dres + KP * DP1;         // [VB_LC][DP1]
+    float* A_c = X_c + VB_LC * DP1;       // [VB_LC][KGP1]
+    float* dA_s = A_c + VB_LC * KGP1;     // [VB_LC][KP + 1]
+    float* asum = dA_s + VB_LC * (KP + 1);  // [KG]
+    float* dot = asum + KG;               // [K]   n . dO
+    float* cd = dot + K;                  // [K]   dres . c
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = feat + (long)b * L * D;
+    const float* Ab = A + (long)b * L * KG;
+    const float* dO = dout + (long)b * K * D;
+    const float* n = out + (long)b * K * D;
+    for (int i = tid; i < KP * DP1; i += 256) dres[i] = 0.f;
+    for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments
+        float t = 0.f;
+        for (int l = 0; l < L; ++l) t += Ab[(long)l * KG + k];
+        asum[k] = t;
+    }
+    for (int k = wave; k < K; k += 4) {                              // n . dO per cluster (wave per cluster)
+        float t = 0.f;
+        for (int d = lane; d < D; d += 64) t = fmaf(n[(long)k * D + d], dO[(long)k * D + d], t);
+        t = wave_sum(t);
+        if (lane == 0) dot[k] = t;
+    }
+    __syncthreads();
+    for (int k = wave; k < K; k += 4) {                              // l2-normalise backward; dcenters; dres . c
+        const float iv = inv[(long)b * K + k];
+        const float aiv = fabsf(iv), dt = iv > 0.f ? dot[k] : 0.f;
+        float t = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            const float g = (dO[(long)k * D + d] - n[(long)k * D + d] * dt) * aiv;
+            dres[k * DP1 + d] = g;
+            t = fmaf(g, centers[(long)k * D + d], t);
+            atomicAdd(dcenters + (long)k * D + d, -asum[k] * g);
+        }
+        t = wave_sum(t);
+        if (lane == 0) cd[k] = t;
+    }
+    const int i31 = lane & 31, kk = lane >> 5;
+    for (int l0 = 0; l0 < L; l0 += VB_LC) {
+        const int rows = min(VB_LC, L - l0);
+        __syncthreads();                                             // dres complete / previous chunk consumed
+        for (int i = tid; i < VB_LC * DP1; i += 256) {
+            const int r = i / DP1, d = i - r * DP1;
+            X_c[i] = (r < rows && d < D) ? x[(long)(l0 + r) * D + d] : 0.f;
+        }
+        for (int i = tid; i < VB_LC * KGP1; i += 256) {
+            const int r = i / KGP1, k = i - r * KGP1;
+            A_c[i] = (r < rows && k < KG) ? Ab[(long)(l0 + r) * KG + k] : 0.f;
+        }
+        for (int i = tid; i < VB_LC * (KP + 1); i += 256) dA_s[i] = 0.f;
+        __syncthreads();
+        // dA[l][k] = sum_d X[l][d] dres[k][d]: each wave reduces a quarter of d, partial tiles meet in LDS
+        {
+            f32x16 pa[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pa[c][i] = 0.f;
+            const int dsteps = (Dt * 32) / 2, per = (dsteps + 3) / 4;
+            for (int st = wave * per; st < min(dsteps, (wave + 1) * per); ++st) {
+                const int d = st * 2 + kk;
+                const float av = X_c[i31 * DP1 + d];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (c < Kt) pa[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dres[(c * 32 + i31) * DP1 + d], pa[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < Kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        atomicAdd(&dA_s[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * (KP + 1) + c * 32 + (lane & 31)], pa[c][r]);
+        }
+        __syncthreads();
+        if (tid < rows) {                                            // softmax backward of one row -> dscore
+            const float* arow = A_c + tid * KGP1;
+            const float* drow = dA_s + tid * (KP + 1);
+            float t = 0.f;
+            for (int k = 0; k < K; ++k) t = fmaf(arow[k], drow[k] - cd[k], t);
+            float* ds = dscore + ((long)b * L + l0 + tid) * KG;
+            for (int k = 0; k < KG; ++k) ds[k] = arow[k] * ((k < K ? drow[k] - cd[k] : 0.f) - t);
+        }
+        // dfeat[l][d] = sum_k A[l][k] dres[k][d]: d-tiles wave, wave+4; reduction over the K (padded) clusters
+        {
+            f32x16 fa[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) fa[a][i] = 0.f;
+            for (int k0 = 0; k0 < KP; k0 += 2) {
+                const float av = (k0 + kk) < K ? A_c[i31 * KGP1 + k0 + kk] : 0.f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if ((wave + 4 * a) < Dt) fa[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dres[(k0 + kk) * DP1 + (wave + 4 * a) * 32 + i31], fa[a], 0, 0, 0);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                if ((wave + 4 * a) < Dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int l = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), d = (wave + 4 * a) * 32 + (lane & 31);
+                        if (l < rows && d < D) {
+                            float* dst = dfeat + ((long)b * L + l0 + l) * D + d;
+                            *dst = accumulate_dfeat ? *dst + fa[a][r] : fa[a][r];
+                        }
+                    }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sar_vlad_fwd_f32(const float* feat, const float* score, const float* centers, float* out, float* A,
                                 float* inv, int B, int L, int D, int K, int G, hipStream_t stream) {
     const int KG = K + G;
     if (!feat || !score || !centers || !out || !A || !inv || K < 1 || G < 0) return SAR_EINVAL;
+    if (D <= 256 && K <= 64 && KG <= 128) {             // MFMA formulation
+        const int Kt = (K + 31) / 32, Dt = (D + 31) / 32, KGP = KG > Kt * 32 ? KG : Kt * 32;
+        const size_t ldsm = sizeof(float) * ((size_t)VF_LC * KGP + (size_t)VF_LC * Dt * 32 + KGP + 64);
+        static bool attr_set = false;  // raise the dynamic-LDS cap once (host-side attribute, not a stream op)
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(vlad_fwd_mfma_kernel, dim3(B), dim3(256), ldsm, stream, feat, score, centers, out, A, inv, L, D, K, KG);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     const size_t lds = sizeof(float) * ((size_t)L * KG + KG + K + (size_t)K * D);
     if (lds > 160 * 1024) return SAR_EINVAL;
     static size_t lds_set = 0;     // raise the dynamic-LDS cap once per size (host-side attribute, not a stream op)
@@ -219,6 +471,18 @@ extern "C" int sar_vlad_bwd_f32(const float* dout, const float* feat, const floa
                                 int L, int D, int K, int G, int accumulate_dfeat, hipStream_t stream) {
     const int KG = K + G;
     if (!dout || !feat || !A || !centers || !out || !inv || !dfeat || !dscore || !dcenters || KG > 128 || D > 512) return SAR_EINVAL;
+    if (D <= 256 && K <= 64) {                          // MFMA formulation
+        const int Kt = (K + 31) / 32, Dt = (D + 31) / 32, KP = Kt * 32, DP1 = Dt * 32 + 1, KGP1 = (KG > KP ? KG : KP) | 1;
+        const size_t ldsm = sizeof(float) * ((size_t)KP * DP1 + (size_t)VB_LC * DP1 + (size_t)VB_LC * KGP1 + (size_t)VB_LC * (KP + 1) + KG + 2 * K);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(vlad_bwd_mfma_kernel, dim3(B), dim3(256), ldsm, stream, dout, feat, A, centers, out, inv, dfeat, dscore, dcenters, L, D, K, KG, accumulate_dfeat);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     const size_t lds = sizeof(float) * ((size_t)L * KG + (size_t)K * (D + 1) + KG + 2 * K);
     if (lds > 160 * 1024) return SAR_EINVAL;
     static size_t lds_set = 0;
