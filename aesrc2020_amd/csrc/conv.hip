@@ -177,7 +177,7 @@ __global__ void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, const fl
 __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
     const float* __restrict__ dpool, const float* __restrict__ out, const uint8_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-    float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int pt, int pl) {
+    float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int pt, int pl, unsigned magic_wo, unsigned magic_ho) {
     __shared__ float4 r1[256], r2[256];
     const int tpr = C / 4;                                    // C <= 256 and 256 % C == 0 (host-checked) -> tpr | 64
     const int cv = threadIdx.x % tpr, pg = threadIdx.x / tpr, npg = 256 / tpr;
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
         const float4 a = *reinterpret_cast<const float4*>(out + o);
         const float4 g = *reinterpret_cast<const float4*>(dpool + o);
         const uchar4 k = *reinterpret_cast<const uchar4*>(idx + o);
-        const unsigned wo = pix % (unsigned)Wo, t = pix / (unsigned)Wo;
-        const unsigned ho = t % (unsigned)Ho, n = t / (unsigned)Ho;
+        const unsigned t = Wo == 1 ? pix : __umulhi(pix, magic_wo), wo = pix - t * (unsigned)Wo;      // q = umulhi(m, ceil(2^32/d))
+        const unsigned n = Ho == 1 ? t : __umulhi(t, magic_ho), ho = t - n * (unsigned)Ho;
         const long base = (((long)n * H + (int)ho * 2 - pt) * W + (int)wo * 2 - pl) * C + c;
         if (a.x > 0.f) { const float xh = (x[base + ((k.x / 3) * W + (k.x % 3)) * C + 0] - mu.x) * rs.x; s1.x += g.x; s2.x = fmaf(g.x, xh, s2.x); }
         if (a.y > 0.f) { const float xh = (x[base + ((k.y / 3) * W + (k.y % 3)) * C + 1] - mu.y) * rs.y; s1.y += g.y; s2.y = fmaf(g.y, xh, s2.y); }
@@ -221,19 +221,26 @@ __global__ __launch_bounds__(256) void pool_combine_kernel(const float* __restri
 }
 
 // Backward pass 2: dx = scale * (dz - s1/R - xhat*s2/R) at full resolution; 4 channels per thread (float4 / uchar4).
-__global__ void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool, const float* __restrict__ out,
+// Thread = (pixel group, channel vector): the per-channel constants are hoisted out of the pixel loop and the pixel index is
+// decomposed with two magic-number divisions (the first version spent most of its time in five 64-bit divisions per element).
+__global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool, const float* __restrict__ out,
                                                  const uint8_t* __restrict__ idx, const float* __restrict__ x,
                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                  const float* __restrict__ scale, const double* __restrict__ sums,
                                                  float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
-                                                 int pt, int pl) {
-    const int C4 = C / 4;
-    const long total = (long)B * H * W * C4;
-    const double invR = 1.0 / ((double)B * H * W);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4; long t = i / C4;
-        const int w_ = (int)(t % W); t /= W;
-        const int h = (int)(t % H); const int n = (int)(t / H);
+                                                 int pt, int pl, unsigned magic_w, unsigned magic_h) {
+    const int tpr = C / 4;                                    // C <= 256 and 256 % C == 0 (host-checked)
+    const int cv = threadIdx.x % tpr, pg = threadIdx.x / tpr, npg = 256 / tpr;
+    const int c = cv * 4;
+    const unsigned npix = (unsigned)(B * H * W);
+    const double invR = 1.0 / (double)npix;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 m1 = make_float4((float)(sums[c] * invR), (float)(sums[c + 1] * invR), (float)(sums[c + 2] * invR), (float)(sums[c + 3] * invR));
+    const float4 m2 = make_float4((float)(sums[C + c] * invR), (float)(sums[C + c + 1] * invR), (float)(sums[C + c + 2] * invR), (float)(sums[C + c + 3] * invR));
+    for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
+        const unsigned t = W == 1 ? pix : __umulhi(pix, magic_w); const int w_ = (int)(pix - t * (unsigned)W);
+        const unsigned n = H == 1 ? t : __umulhi(t, magic_h); const int h = (int)(t - n * (unsigned)H);
         float dz[4] = {0.f, 0.f, 0.f, 0.f};
         const int ho_lo = max(0, (h + pt - 1) / 2), ho_hi = min(Ho - 1, (h + pt) / 2);
         const int wo_lo = max(0, (w_ + pl - 1) / 2), wo_hi = min(Wo - 1, (w_ + pl) / 2);
@@ -254,15 +261,14 @@ __global__ void maxpool_bn_relu_bwd_apply_kernel(const float* __restrict__ dpool
                 if (id.w == slot && ov.w > 0.f) dz[3] += g.w;
             }
         }
-        const float4 xv = reinterpret_cast<const float4*>(x)[i];
-        const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
-        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const long xo = (long)pix * C + c;
+        const float4 xv = *reinterpret_cast<const float4*>(x + xo);
         float4 o4;
-        o4.x = sc.x * (dz[0] - (float)(sums[c + 0] * invR) - (xv.x - mu.x) * rs.x * (float)(sums[C + c + 0] * invR));
-        o4.y = sc.y * (dz[1] - (float)(sums[c + 1] * invR) - (xv.y - mu.y) * rs.y * (float)(sums[C + c + 1] * invR));
-        o4.z = sc.z * (dz[2] - (float)(sums[c + 2] * invR) - (xv.z - mu.z) * rs.z * (float)(sums[C + c + 2] * invR));
-        o4.w = sc.w * (dz[3] - (float)(sums[c + 3] * invR) - (xv.w - mu.w) * rs.w * (float)(sums[C + c + 3] * invR));
-        reinterpret_cast<float4*>(dx)[i] = o4;
+        o4.x = sc.x * (dz[0] - m1.x - (xv.x - mu.x) * rs.x * m2.x);
+        o4.y = sc.y * (dz[1] - m1.y - (xv.y - mu.y) * rs.y * m2.y);
+        o4.z = sc.z * (dz[2] - m1.z - (xv.z - mu.z) * rs.z * m2.z);
+        o4.w = sc.w * (dz[3] - m1.w - (xv.w - mu.w) * rs.w * m2.w);
+        *reinterpret_cast<float4*>(dx + xo) = o4;
     }
 }
 
@@ -305,12 +311,14 @@ extern "C" int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out,
                                            int pad_left, hipStream_t stream) {
     if (!dpool || !out || !idx || !x || !mean || !rstd || !scale || !sums || !dx || C > 256 || (256 % C)) return SAR_EINVAL;
     float* part = reinterpret_cast<float*>(sums + 2 * C);          // workspace layout of sar_bn_workspace_bytes(C)
-    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, part, B, H, W, C, Ho, Wo, pad_top, pad_left);
+    if ((long)B * H * W * (W > H ? W : H) >= (1L << 32)) return SAR_EINVAL;         // magic-number division exactness bound
+    const auto magic = [](int d) { return (unsigned)(((1UL << 32) + d - 1) / d); };
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, part, B, H, W, C, Ho, Wo, pad_top, pad_left, magic(Wo), magic(Ho));
     hipLaunchKernelGGL(pool_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, 256, sums, 2 * C);
     if (C % 4) return SAR_EINVAL;
     const long total = (long)B * H * W * (C / 4);
     const int nblk = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
-    hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3(nblk), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, sums, dx, B, H, W, C, Ho, Wo, pad_top, pad_left);
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_apply_kernel, dim3(nblk), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, sums, dx, B, H, W, C, Ho, Wo, pad_top, pad_left, magic(W), magic(H));
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
