@@ -55,16 +55,32 @@ __global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict
     if (lane == 0) totals[c] = s;
 }
 
-// combines the per-block partials in fp64 and folds gamma/beta into scale/shift (one launch; one wave per channel)
+// combines the per-block partials in fp64 and folds gamma/beta into scale/shift (one launch)
+// Block = 16 channels x 16 row groups: each thread walks the partial rows of its group reading 16 consecutive channels
+// (64-byte segments; the first version's wave-per-channel walk read one float per cache line), fp64 accumulation, LDS reduce.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nb, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mov_mean,
                                    float* __restrict__ mov_var, long R, int C, float eps, float momentum,
                                    int unbiased_moving_var) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= C) return;
-    const double s1 = combine_column(part, nb, 2 * C, c, lane), s2 = combine_column(part, nb, 2 * C, C + c, lane);
-    if (lane != 0) return;
+    __shared__ double r1[16][17], r2[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+    if (c < C) {
+        int row = rg;
+        for (; row + 16 < nb; row += 32) {                            // two independent chains
+            a1 += (double)part[(long)row * 2 * C + c];        a2 += (double)part[(long)row * 2 * C + C + c];
+            b1 += (double)part[(long)(row + 16) * 2 * C + c]; b2 += (double)part[(long)(row + 16) * 2 * C + C + c];
+        }
+        for (; row < nb; row += 16) { a1 += (double)part[(long)row * 2 * C + c]; a2 += (double)part[(long)row * 2 * C + C + c]; }
+    }
+    r1[rg][cl] = a1 + b1; r2[rg][cl] = a2 + b2;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
     const double mu = s1 / (double)R;
     double var = s2 / (double)R - mu * mu;
     if (var < 0) var = 0;
@@ -359,7 +375,7 @@ extern "C" int sar_bn_stats_f32(const float* x, const float* gamma, const float*
     if (nb < 1) nb = 1;
     float* part = reinterpret_cast<float*>(sums + 2 * C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((int)nb), dim3(256), 0, stream, x, part, R, C, tpr);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, part, (int)nb, gamma, beta, mean, rstd, scale,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, part, (int)nb, gamma, beta, mean, rstd, scale,
                        shift, moving_mean, moving_var, R, C, eps, momentum, unbiased_moving_var);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -371,7 +387,7 @@ extern "C" int sar_bn_finalize_f32(const float* part, int rows, const float* gam
                                    float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
                                    int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream) {
     if (!part || rows < 1 || rows > BN_PART_ROWS || !gamma || !beta || !mean || !rstd || !scale || !shift || C < 1 || R <= 0) return SAR_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, stream, part, rows, gamma, beta, mean, rstd, scale,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, stream, part, rows, gamma, beta, mean, rstd, scale,
                        shift, moving_mean, moving_var, R, C, eps, momentum, unbiased_moving_var);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
