@@ -202,6 +202,26 @@ __global__ __launch_bounds__(256) void vlad_bwd_kernel(const float* __restrict__
 // FMA loops with one LDS read per FMA.  L is processed in chunks (softmax, A_out and the column sums are chunk-local), so
 // utterances of any length fit.  Operand conventions of the 32x32x2 MFMA: A-operand lane -> (row lane&31, k lane>>5),
 // B-operand lane -> (col lane&31, k lane>>5), acc[r] -> (row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31).
+// Stage `nrows` rows of a (rows, D) global matrix into an LDS tile [nrows_tile][ld] (ld >= round_up(D, 32)), zero-filling the
+// rows beyond `rows` and the columns beyond D: a wave per row, float4 global loads when the row is 16-byte aligned.
+__device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, const float* __restrict__ src, int D, int rows,
+                                           int nrows_tile, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int Dpad = ((D + 31) / 32) * 32;
+    const bool vec = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    for (int r = wave; r < nrows_tile; r += 4) {
+        float* dst = tile + r * ld;
+        if (r < rows && vec) {
+            for (int d = lane * 4; d < Dpad; d += 256) {
+                const float4 v = d < D ? *reinterpret_cast<const float4*>(src + (long)r * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[d] = v.x; dst[d + 1] = v.y; dst[d + 2] = v.z; dst[d + 3] = v.w;      // ld may be odd: scalar LDS stores
+            }
+        } else {
+            for (int d = lane; d < Dpad; d += 64) dst[d] = (r < rows && d < D) ? src[(long)r * D + d] : 0.f;
+        }
+    }
+}
+
 constexpr int VF_LC = 64;           // rows of L per chunk, forward
 constexpr int VB_LC = 32;           // backward (two more LDS tiles live)
 
@@ -235,10 +255,7 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
             const int r = i / KGP, k = i - r * KGP;
             A_c[i] = (r < rows && k < KG) ? sc[(long)(l0 + r) * KG + k] : -INFINITY;
         }
-        for (int i = tid; i < VF_LC * DP; i += 256) {
-            const int r = i / DP, d = i - r * DP;
-            X_c[i] = (r < rows && d < D) ? x[(long)(l0 + r) * D + d] : 0.f;
-        }
+        stage_rows(X_c, DP, x + (long)l0 * D, D, rows, VF_LC, tid);
         __syncthreads();
         if (tid < VF_LC) {                                           // softmax of one row (rows are short)
             float* srow = A_c + tid * KGP;
@@ -367,10 +384,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     for (int l0 = 0; l0 < L; l0 += VB_LC) {
         const int rows = min(VB_LC, L - l0);
         __syncthreads();                                             // dres complete / previous chunk consumed
-        for (int i = tid; i < VB_LC * DP1; i += 256) {
-            const int r = i / DP1, d = i - r * DP1;
-            X_c[i] = (r < rows && d < D) ? x[(long)(l0 + r) * D + d] : 0.f;
-        }
+        stage_rows(X_c, DP1, x + (long)l0 * D, D, rows, VB_LC, tid);
         for (int i = tid; i < VB_LC * KGP1; i += 256) {
             const int r = i / KGP1, k = i - r * KGP1;
             A_c[i] = (r < rows && k < KG) ? Ab[(long)(l0 + r) * KG + k] : 0.f;
