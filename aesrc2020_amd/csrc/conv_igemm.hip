@@ -42,11 +42,13 @@ struct ConvP {
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, splitk;
     unsigned magic_a, magic_b;          // ceil(2^32/Wo), ceil(2^32/Ho)
     float* stats;                       // nullable: per-row-tile BatchNorm partials [gridDim.x][2*Cout] of the OUTPUT (splitk == 1 only)
+    const __bf16* wth; const __bf16* wtl;   // nullable: the kernel pre-split into bf16 (hi, lo) planes [Cout][K] (k contiguous)
 };
 struct DgradP {
     const float* dy; const float* w; float* dx;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, accumulate, splitk;
     unsigned magic_a, magic_b;          // ceil(2^32/W), ceil(2^32/H)
+    const __bf16* wdh; const __bf16* wdl;   // nullable: the kernel pre-split into bf16 (hi, lo) planes in HWIO order [K][Cout]
 };
 struct WgradP {
     const float* x; const float* dy; const float* scale; const float* shift; float* dw; float* dbias;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_kernel(ConvP p) {
 // ds_read_b128 operand fetches); global memory stays fp32.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;       // 16-byte opaque copy (HIP's uint4 struct defeats SROA inside the register sets)
 
 __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
     const float f[4] = {v.x, v.y, v.z, v.w};
@@ -312,7 +315,9 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-template <int WM, int WN, int TM, int BK>
+// WP: the weights arrive pre-split (sar_conv_weight_split_bf16, once per step): the B tile is staged with two 16-byte copies
+// per thread instead of eight scalar loads + hi/lo splits -- every block used to redo that conversion of the same weights.
+template <int WM, int WN, int TM, int BK, bool WP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     using T = Tile<WM, WN, TM, BK>;
     constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
@@ -353,7 +358,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     const bool bcol_ok = n0 + b_n < p.Cout;
     const int b_col = min(n0 + b_n, p.Cout - 1);
     const float relu_lo = p.scale ? 0.f : -INFINITY;                  // no BN+ReLU prologue: identity
-    struct Regs { float4 ra[NA]; float rb[KPT]; float4 sc, sh; unsigned vmask; };
+    static_assert(!WP || (BNt == 64 && NT == 256 && BK == 32), "weight-plane staging: 64 columns x four 8-element chunks");
+    const long wp_off = (long)min(n0 + (tid >> 2), p.Cout - 1) * K + (tid & 3) * 8;   // WP: column tid>>2, chunk tid&3
+    const bool wp_ok = n0 + (tid >> 2) < p.Cout;
+    struct Regs { float4 ra[NA]; float rb[WP ? 1 : KPT]; u32x4 wh, wl; float4 sc, sh; unsigned vmask; };
     Regs R0, R1;                                                      // two sets: prefetch distance of two k-tiles
     R0.sc = R1.sc = make_float4(1, 1, 1, 1); R0.sh = R1.sh = zero4(); R0.vmask = R1.vmask = 0;
     auto load = [&](Regs& R, int kt) {
@@ -372,9 +380,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
         }
         // always-valid, always-distinct addresses (column clamped; zeroed at store time): a select between "real" and
         // "dummy" offsets makes the compiler load once and copy the loaded value, i.e. wait on a fresh load right here
-        const int boff = (k0 + b_k) * p.Cout + b_col;
+        if constexpr (WP) {
+            R.wh = *reinterpret_cast<const u32x4*>(p.wth + wp_off + k0);
+            R.wl = *reinterpret_cast<const u32x4*>(p.wtl + wp_off + k0);
+        } else {
+            const int boff = (k0 + b_k) * p.Cout + b_col;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) R.rb[j] = p.w[boff + j * p.Cout];
+            for (int j = 0; j < KPT; ++j) R.rb[j] = p.w[boff + j * p.Cout];
+        }
     };
     auto store = [&](const Regs& R, int buf) {
 #pragma unroll
@@ -388,7 +401,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
             bf16x4 hi, lo; split4(v, hi, lo);
             *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
-        {                                                            // B: KPT consecutive k of one column -> one row segment
+        if constexpr (WP) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wh : z;
+            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z;
+        } else {                                                     // B: KPT consecutive k of one column -> one row segment
             __bf16 hi[KPT], lo[KPT];
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
@@ -574,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
 }
 
 // ------------------------------------------------------------------ dgrad, bf16x3 split-precision MFMA (see conv_fwd_x3_kernel)
-template <int WM, int WN, int TM, int BK>
+template <int WM, int WN, int TM, int BK, bool WP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
     using T = Tile<WM, WN, TM, BK>;
     constexpr int BMt = T::BMt, BNt = T::BNt, NT = T::NT, KQ = T::KQ;
@@ -620,7 +637,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
     const int b_n = tid / GPR, b_k = (tid % GPR) * KPT;
     const bool brow_ok = n0 + b_n < p.Cin;
     const int b_row = min(n0 + b_n, p.Cin - 1);
-    struct Regs { float4 ra[NA]; float4 rb[KPT / 4]; unsigned vmask; };
+    static_assert(!WP || (BNt == 64 && NT == 256 && BK == 32), "weight-plane staging: 64 rows x four 8-element chunks");
+    const int wp_row = min(n0 + (tid >> 2), p.Cin - 1);
+    const bool wp_ok = n0 + (tid >> 2) < p.Cin;
+    struct Regs { float4 ra[NA]; float4 rb[WP ? 1 : KPT / 4]; u32x4 wh, wl; unsigned vmask; };
     Regs R0, R1; R0.vmask = R1.vmask = 0;
     auto load = [&](Regs& R, int kt) {
         const int k0 = kt * BK;
@@ -635,9 +655,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
             R.ra[i] = *reinterpret_cast<const float4*>(p.dy + off);
             R.vmask |= ok << i;
         }
-        const int boff = (tap * p.Cin + b_row) * p.Cout + co0 + b_k;      // row clamped: always valid (see the forward kernel)
+        if constexpr (WP) {
+            const long o = (long)(tap * p.Cin + wp_row) * p.Cout + co0 + (tid & 3) * 8;
+            R.wh = *reinterpret_cast<const u32x4*>(p.wdh + o); R.wl = *reinterpret_cast<const u32x4*>(p.wdl + o);
+        } else {
+            const int boff = (tap * p.Cin + b_row) * p.Cout + co0 + b_k;      // row clamped: always valid (see the forward kernel)
 #pragma unroll
-        for (int j = 0; j < KPT / 4; ++j) R.rb[j] = *reinterpret_cast<const float4*>(p.w + boff + 4 * j);
+            for (int j = 0; j < KPT / 4; ++j) R.rb[j] = *reinterpret_cast<const float4*>(p.w + boff + 4 * j);
+        }
     };
     auto store = [&](const Regs& R, int buf) {
 #pragma unroll
@@ -646,10 +671,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
             bf16x4 hi, lo; split4(((R.vmask >> i) & 1u) ? R.ra[i] : zero4(), hi, lo);
             *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
+        if constexpr (WP) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wh : z;
+            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z;
+        } else {
 #pragma unroll
-        for (int j = 0; j < KPT / 4; ++j) {
-            bf16x4 hi, lo; split4(brow_ok ? R.rb[j] : zero4(), hi, lo);
-            *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k + 4 * j]) = hi; *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k + 4 * j]) = lo;
+            for (int j = 0; j < KPT / 4; ++j) {
+                bf16x4 hi, lo; split4(brow_ok ? R.rb[j] : zero4(), hi, lo);
+                *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k + 4 * j]) = hi; *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k + 4 * j]) = lo;
+            }
         }
     };
     f32x16 acc[TM];
@@ -1013,6 +1044,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     }
 }
 
+// ------------------------------------------------------------------ weight planes
+// One launch splits the kernels of all convolutions of the trunk into bf16 (hi, lo) planes: table row =
+// {w, wt_h, wt_l, wd_h, wd_l, K, Cout, first block}; block = one 32 (k) x 64 (cout) tile.  wt_* = [Cout][K] (forward B operand,
+// k contiguous), wd_* = [K][Cout] (HWIO order: dgrad B operand).
+struct WSplitDesc { const float* w; __bf16* wt_h; __bf16* wt_l; __bf16* wd_h; __bf16* wd_l; long K, Cout, blk0; };
+
+__global__ __launch_bounds__(256) void weight_split_kernel(const WSplitDesc* __restrict__ table, int n) {
+    __shared__ __bf16 th[64][34], tl[64][34];                         // [cout][k] transposed tile (+2 pad)
+    __shared__ long first_blk[128];
+    __shared__ int s_d;
+    for (int i = threadIdx.x; i < n; i += 256) first_blk[i] = table[i].blk0;   // one coalesced read instead of a dependent walk
+    __syncthreads();
+    if (threadIdx.x < n) {                                            // exactly one row satisfies blk0 <= block < next blk0
+        const long nxt = threadIdx.x + 1 < n ? first_blk[threadIdx.x + 1] : (1L << 62);
+        if ((long)blockIdx.x >= first_blk[threadIdx.x] && (long)blockIdx.x < nxt) s_d = threadIdx.x;
+    }
+    __syncthreads();
+    const WSplitDesc ds = table[s_d];
+    const int K = (int)ds.K, Cout = (int)ds.Cout;
+    const int tiles_n = Cout / 64;
+    const int t = blockIdx.x - (int)ds.blk0, k0 = (t / tiles_n) * 32, n0 = (t % tiles_n) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                     // 32 x 64 fp32, coalesced along cout
+        const int kk = tid / 16 + h * 16, nn = (tid % 16) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(ds.w + (long)(k0 + kk) * Cout + n0 + nn);
+        bf16x4 hi, lo; split4(v, hi, lo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { th[nn + j][kk] = hi[j]; tl[nn + j][kk] = lo[j]; }
+        *reinterpret_cast<bf16x4*>(ds.wd_h + (long)(k0 + kk) * Cout + n0 + nn) = hi;
+        *reinterpret_cast<bf16x4*>(ds.wd_l + (long)(k0 + kk) * Cout + n0 + nn) = lo;
+    }
+    __syncthreads();
+    const int nn = tid / 4, kq = (tid % 4) * 8;                       // wt[cout][k0 .. k0+31]: 8 consecutive k per thread
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vh[j] = th[nn][kq + j]; vl[j] = tl[nn][kq + j]; }
+    *reinterpret_cast<bf16x8*>(ds.wt_h + (long)(n0 + nn) * K + k0 + kq) = vh;
+    *reinterpret_cast<bf16x8*>(ds.wt_l + (long)(n0 + nn) * K + k0 + kq) = vl;
+}
+
 }  // namespace
 
 // 32-bit element offsets and the magic-number division bound the supported sizes (far above the SAR-Net shapes).
@@ -1062,7 +1134,7 @@ static int pick_conv_splitk(int tiles, int nkt) {
 static int conv_fwd_launch(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
                            const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
                            int KW, int stride, int pad_top, int pad_left, float* stats_part, int stats_rows_cap,
-                           int* stats_rows, hipStream_t stream) {
+                           int* stats_rows, const void* wt_hi, const void* wt_lo, hipStream_t stream) {
     if (stats_rows) *stats_rows = 0;
     if (!x || !w || !y || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || (scale && !shift)) return SAR_EINVAL;
     ConvP p{x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, 1,
@@ -1079,6 +1151,8 @@ static int conv_fwd_launch(const float* x, const float* w, const float* bias, co
     // perturbation of the earliest activations flips ReLU / max-pool decisions throughout the net, which the parity tests
     // (tiny tensors) see as percent-level gradient changes.  SAR_X3_NARROW bit 0 enables it (-5 us per stage-0 conv).
     const bool x3_narrow = (conv_knobs().x3_narrow & 1) != 0;
+    const bool wp = wt_hi && wt_lo && !narrow;                      // pre-split kernel planes [Cout][K]
+    p.wth = static_cast<const __bf16*>(wt_hi); p.wtl = static_cast<const __bf16*>(wt_lo);
     if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
         if (narrow) {                                               // Cout <= 32: 128 x 32 tile, 4 waves stacked along M
             dim3 grid(cdiv(M, 128), cdiv(Cout, 32), 1);
@@ -1087,14 +1161,16 @@ static int conv_fwd_launch(const float* x, const float* w, const float* bias, co
         } else if (cdiv(M, 128) * cdiv(Cout, 64) >= 300) {
             dim3 grid(cdiv(M, 128), cdiv(Cout, 64), 1);
             arm_stats(grid);
-            hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
+            if (wp) hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 2, 32, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
         } else {
             const int tiles = cdiv(M, 64) * cdiv(Cout, 64);
             p.splitk = pick_conv_splitk(tiles, KH * KW * Cin / bk);
             if (p.splitk > 1 && sar_zero_async(y, sizeof(float) * M * Cout, stream) != hipSuccess) return SAR_ELAUNCH;
             dim3 grid(cdiv(M, 64), cdiv(Cout, 64), p.splitk);
             arm_stats(grid);
-            hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 1, 32>), grid, dim3(256), 0, stream, p);
+            if (wp) hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 1, 32, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_fwd_x3_kernel<2, 2, 1, 32>), grid, dim3(256), 0, stream, p);
         }
         SAR_CHECK_LAUNCH();
         return SAR_OK;
@@ -1132,7 +1208,7 @@ extern "C" int sar_conv2d_fwd_f32(const float* x, const float* w, const float* b
                                   int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
                                   hipStream_t stream) {
     return conv_fwd_launch(x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left,
-                           nullptr, 0, nullptr, stream);
+                           nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" size_t sar_bn_workspace_bytes(int C);
@@ -1143,23 +1219,28 @@ extern "C" int sar_bn_finalize_f32(const float* part, int rows, const float* gam
                                    float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
                                    int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream);
 
-// Conv2D followed by the training-mode BatchNormalization statistics of its OUTPUT (the _bn_relu in front of the next conv,
-// resnet.py:22-26,47-65): y as sar_conv2d_fwd_f32, then mean/rstd/scale/shift (+ moving averages) of y exactly as
-// sar_bn_stats_f32(y, gamma_o, ...) would produce.  Without split-K the sums come out of the conv epilogue (no second pass
-// over y); with split-K (small-M layers) the separate statistics kernel runs.  sums_o = BN workspace of the consumer.
-extern "C" int sar_conv2d_fwd_bnstats_f32(const float* x, const float* w, const float* bias, const float* scale,
-                                          const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
-                                          int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
-                                          const float* gamma_o, const float* beta_o, double* sums_o, float* mean_o,
-                                          float* rstd_o, float* scale_o, float* shift_o, float* moving_mean_o,
-                                          float* moving_var_o, float eps, float momentum, int unbiased_moving_var,
-                                          hipStream_t stream) {
-    if (!gamma_o || !beta_o || !sums_o || !mean_o || !rstd_o || !scale_o || !shift_o) return SAR_EINVAL;
+// The forward conv with its optional companions: wt_hi/wt_lo = the kernel pre-split into bf16 planes [Cout][K]
+// (sar_conv_weight_split_bf16; used by the split-precision kernels, ignored in fp32 mode and for Cout <= 32), and gamma_o ...
+// = the training-mode BatchNormalization that consumes y (the _bn_relu in front of the next conv, resnet.py:22-26,47-65):
+// mean/rstd/scale/shift (+ moving averages) of y exactly as sar_bn_stats_f32(y, gamma_o, ...) would produce.  Without split-K
+// the sums come out of the conv epilogue (no second pass over y); with split-K (small-M layers) the separate statistics
+// kernel runs.  sums_o = BN workspace of the consumer.  gamma_o == NULL: no statistics.
+extern "C" int sar_conv2d_fwd_ex_f32(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                                     const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                                     int KH, int KW, int stride, int pad_top, int pad_left, const void* wt_hi,
+                                     const void* wt_lo, const float* gamma_o, const float* beta_o, double* sums_o,
+                                     float* mean_o, float* rstd_o, float* scale_o, float* shift_o, float* moving_mean_o,
+                                     float* moving_var_o, float eps, float momentum, int unbiased_moving_var,
+                                     hipStream_t stream) {
+    if (!gamma_o)
+        return conv_fwd_launch(x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left,
+                               nullptr, 0, nullptr, wt_hi, wt_lo, stream);
+    if (!beta_o || !sums_o || !mean_o || !rstd_o || !scale_o || !shift_o) return SAR_EINVAL;
     float* part = reinterpret_cast<float*>(sums_o + 2 * Cout);
     const int cap = (int)((sar_bn_workspace_bytes(Cout) - sizeof(double) * 2 * Cout) / (sizeof(float) * 2 * Cout));
     int rows = 0;
     const int rc = conv_fwd_launch(x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top,
-                                   pad_left, part, cap, &rows, stream);
+                                   pad_left, part, cap, &rows, wt_hi, wt_lo, stream);
     if (rc != SAR_OK) return rc;
     const long R = (long)B * Ho * Wo;
     if (rows > 0)
@@ -1169,9 +1250,29 @@ extern "C" int sar_conv2d_fwd_bnstats_f32(const float* x, const float* w, const 
                             eps, momentum, unbiased_moving_var, stream);
 }
 
-extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho,
-                                    int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
-                                    int accumulate, hipStream_t stream) {
+extern "C" int sar_conv2d_fwd_bnstats_f32(const float* x, const float* w, const float* bias, const float* scale,
+                                          const float* shift, const float* residual, float* y, int B, int H, int W, int Cin,
+                                          int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                          const float* gamma_o, const float* beta_o, double* sums_o, float* mean_o,
+                                          float* rstd_o, float* scale_o, float* shift_o, float* moving_mean_o,
+                                          float* moving_var_o, float eps, float momentum, int unbiased_moving_var,
+                                          hipStream_t stream) {
+    if (!gamma_o) return SAR_EINVAL;
+    return sar_conv2d_fwd_ex_f32(x, w, bias, scale, shift, residual, y, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left,
+                                 nullptr, nullptr, gamma_o, beta_o, sums_o, mean_o, rstd_o, scale_o, shift_o, moving_mean_o,
+                                 moving_var_o, eps, momentum, unbiased_moving_var, stream);
+}
+
+extern "C" int sar_conv_weight_split_bf16(const void* table, int n, int total_blocks, hipStream_t stream) {
+    if (!table || n < 1 || n > 128 || total_blocks < 1) return SAR_EINVAL;
+    hipLaunchKernelGGL(weight_split_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const WSplitDesc*>(table), n);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+static int conv_dgrad_launch(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                             int KH, int KW, int stride, int pad_top, int pad_left, int accumulate, const void* wd_hi,
+                             const void* wd_lo, hipStream_t stream) {
     if (!dy || !w || !dx || !conv_args_ok(B, H, W, Cin, Ho, Wo, Cout, KH, KW) || stride < 1 || stride > 2) return SAR_EINVAL;
     DgradP p{dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, 1,
              (unsigned)(((1UL << 32) + W - 1) / W), (unsigned)(((1UL << 32) + H - 1) / H)};
@@ -1181,16 +1282,22 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
     const bool narrow = Cin <= 32;
     const bool fp32_math = g_conv_math == 0;
     const bool x3_narrow = (conv_knobs().x3_narrow & 2) != 0;
+    const bool wp = wd_hi && wd_lo && !narrow;                      // pre-split kernel planes in HWIO order [K][Cout]
+    p.wdh = static_cast<const __bf16*>(wd_hi); p.wdl = static_cast<const __bf16*>(wd_lo);
     if (!fp32_math && bk == 32 && (!narrow || x3_narrow)) {         // bf16x3 split-precision path
         if (narrow) {                                               // Cin <= 32: 128 x 32 tile
             hipLaunchKernelGGL((conv_dgrad_x3_kernel<4, 1, 1, 32>), dim3(cdiv(M, 128), cdiv(Cin, 32), 1), dim3(256), 0, stream, p);
         } else if (cdiv(M, 128) * cdiv(Cin, 64) >= 300) {
-            hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 2, 32>), dim3(cdiv(M, 128), cdiv(Cin, 64), 1), dim3(256), 0, stream, p);
+            const dim3 grid(cdiv(M, 128), cdiv(Cin, 64), 1);
+            if (wp) hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 2, 32, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 2, 32>), grid, dim3(256), 0, stream, p);
         } else {
             const int tiles1 = cdiv(M, 64) * cdiv(Cin, 64);
             p.splitk = pick_conv_splitk(tiles1, KH * KW * Cout / bk);
             if (p.splitk > 1 && !accumulate && sar_zero_async(dx, sizeof(float) * M * Cin, stream) != hipSuccess) return SAR_ELAUNCH;
-            hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 1, 32>), dim3(cdiv(M, 64), cdiv(Cin, 64), p.splitk), dim3(256), 0, stream, p);
+            const dim3 grid(cdiv(M, 64), cdiv(Cin, 64), p.splitk);
+            if (wp) hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 1, 32, true>), grid, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_dgrad_x3_kernel<2, 2, 1, 32>), grid, dim3(256), 0, stream, p);
         }
         SAR_CHECK_LAUNCH();
         return SAR_OK;
@@ -1208,6 +1315,20 @@ extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, 
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
+}
+
+extern "C" int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho,
+                                    int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                    int accumulate, hipStream_t stream) {
+    return conv_dgrad_launch(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, nullptr, nullptr, stream);
+}
+
+// dgrad with the kernel pre-split into bf16 planes in HWIO order [K][Cout] (sar_conv_weight_split_bf16's wd_*); NULL planes or
+// fp32 mode or Cin <= 32: same as sar_conv2d_dgrad_f32.
+extern "C" int sar_conv2d_dgrad_ex_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho,
+                                       int Wo, int Cout, int KH, int KW, int stride, int pad_top, int pad_left,
+                                       int accumulate, const void* wd_hi, const void* wd_lo, hipStream_t stream) {
+    return conv_dgrad_launch(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, wd_hi, wd_lo, stream);
 }
 
 extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift,

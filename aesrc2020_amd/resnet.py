@@ -63,6 +63,18 @@ class _Conv:
         self.name, self.k, self.cin, self.cout, self.stride, self.padding = name, k, cin, cout, stride, padding
         self.kernel = store.add(name + "/kernel", (k, k, cin, cout), he_normal(store.rng, (k, k, cin, cout), k * k * cin), 1e-4)
         self.bias = store.add(name + "/bias", (cout,), np.zeros(cout))
+        self.store = store
+        # bf16 (hi, lo) planes of the kernel for the split-precision kernels (ResNetTrunk.split_weights fills them once per step)
+        self.wp_ok = cin % 32 == 0 and cout % 64 == 0
+        self.wt = self.wd = (None, None)
+        self.use_planes = False
+
+    def planes(self):
+        K = self.k * self.k * self.cin
+        b = self.store.bufs
+        self.wt = tuple(b.get("%s/wt_%s" % (self.name, h), (self.cout, K), torch.bfloat16) for h in ("hi", "lo"))
+        self.wd = tuple(b.get("%s/wd_%s" % (self.name, h), (K, self.cout), torch.bfloat16) for h in ("hi", "lo"))
+        return [self.kernel.w.data_ptr()] + [t.data_ptr() for t in self.wt + self.wd] + [K, self.cout]
 
     def out_hw(self, H, W):
         if self.padding == "same":
@@ -78,16 +90,18 @@ class _Conv:
         produced by the same call (conv epilogue where the launch has no split-K), training mode only."""
         args = (x, self.kernel.w, self.bias.w, bn.scale if bn else None, bn.shift if bn else None, residual, y, B, self.H, self.W,
                 self.cin, self.Ho, self.Wo, self.cout, self.k, self.k, self.stride, self.pt, self.pl)
+        wt = self.wt if self.use_planes else (None, None)
         if bn_out is None:
-            _call("sar_conv2d_fwd_f32", *args)
+            _call("sar_conv2d_fwd_ex_f32", *args, wt[0], wt[1], None, None, None, None, None, None, None, None, None, BN_EPS, BN_MOMENTUM, 1)
         else:
             bn_out.prepare()
-            _call("sar_conv2d_fwd_bnstats_f32", *args, bn_out.gamma.w, bn_out.beta.w, bn_out.sums, bn_out.mean, bn_out.rstd,
+            _call("sar_conv2d_fwd_ex_f32", *args, wt[0], wt[1], bn_out.gamma.w, bn_out.beta.w, bn_out.sums, bn_out.mean, bn_out.rstd,
                   bn_out.scale, bn_out.shift, bn_out.moving_mean.w, bn_out.moving_var.w, BN_EPS, BN_MOMENTUM, 1)
 
     def dgrad(self, dy, dx, B, accumulate=0):
-        _call("sar_conv2d_dgrad_f32", dy, self.kernel.w, dx, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
-              self.k, self.k, self.stride, self.pt, self.pl, accumulate)
+        wd = self.wd if self.use_planes else (None, None)
+        _call("sar_conv2d_dgrad_ex_f32", dy, self.kernel.w, dx, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+              self.k, self.k, self.stride, self.pt, self.pl, accumulate, wd[0], wd[1])
 
     def wgrad(self, x, dy, B, bn=None, bias_grad=True):
         """Kernel gradient (+ bias gradient).  A conv whose output feeds a BatchNorm directly has an exactly-zero bias
@@ -154,9 +168,30 @@ class ResNetTrunk(Layer):
         self.output_shape = (None, H, W, self.out_c)
         return self.out_hw
 
+    def split_weights(self):
+        """bf16 (hi, lo) planes of every eligible conv kernel, one launch (the weights change every step).  Only in the
+        split-precision conv mode; the convs then stage their weight tiles with plain 16-byte copies."""
+        convs = [cv for blk in self.blocks for cv in (blk["conv1"], blk["conv2"], blk["sc"]) if cv is not None and cv.wp_ok]
+        on = _lib.get_conv_math() == "bf16x3" and bool(convs)
+        for blk in self.blocks:
+            for cv in (blk["conv1"], blk["conv2"], blk["sc"]):
+                if cv is not None:
+                    cv.use_planes = on and cv.wp_ok
+        if not on:
+            return
+        if getattr(self, "_wtable", None) is None:
+            rows, blk0 = [], 0
+            for cv in convs:
+                r = cv.planes()
+                rows.append(r + [blk0]); blk0 += (r[5] // 32) * (r[6] // 64)
+            self._wtable = torch.tensor(rows, dtype=torch.int64, device="cuda")
+            self._wblocks = blk0
+        _call("sar_conv_weight_split_bf16", self._wtable, self._wtable.shape[0], self._wblocks)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, B):
         self.B, self.x = B, x
+        self.split_weights()
         T, D = self.in_hw
         H, W = self.stem_hw
         c0 = self.stem.cout

@@ -54,6 +54,23 @@ int sar_conv2d_fwd_bnstats_f32(const float* x, const float* w, const float* bias
                                const float* beta_o, double* sums_o, float* mean_o, float* rstd_o, float* scale_o,
                                float* shift_o, float* moving_mean_o, float* moving_var_o, float eps, float momentum,
                                int unbiased_moving_var, sarStream_t stream);
+/* Weight planes for the split-precision kernels: one launch converts the kernels of many convolutions into bf16 (hi, lo)
+ * planes.  `table` = device array of n rows of 8 x int64: {w (fp32 HWIO), wt_hi, wt_lo, wd_hi, wd_lo, K = KH*KW*Cin, Cout,
+ * first_block}; wt_* = [Cout][K] (forward), wd_* = [K][Cout] (dgrad); K % 32 == 0, Cout % 64 == 0; first_block = running sum
+ * of (K/32)*(Cout/64); total_blocks = that sum over all rows.  Run once per optimiser step (the weights change). */
+int sar_conv_weight_split_bf16(const void* table, int n, int total_blocks, sarStream_t stream);
+/* sar_conv2d_fwd_f32 with optional companions: wt_hi/wt_lo (nullable) = the kernel's planes from the call above;
+ * gamma_o ... (nullable as a group) = the BatchNormalization consuming y, as in sar_conv2d_fwd_bnstats_f32. */
+int sar_conv2d_fwd_ex_f32(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                          const float* residual, float* y, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH,
+                          int KW, int stride, int pad_top, int pad_left, const void* wt_hi, const void* wt_lo,
+                          const float* gamma_o, const float* beta_o, double* sums_o, float* mean_o, float* rstd_o,
+                          float* scale_o, float* shift_o, float* moving_mean_o, float* moving_var_o, float eps,
+                          float momentum, int unbiased_moving_var, sarStream_t stream);
+/* sar_conv2d_dgrad_f32 with the kernel's wd_hi/wd_lo planes (nullable). */
+int sar_conv2d_dgrad_ex_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
+                            int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int accumulate,
+                            const void* wd_hi, const void* wd_lo, sarStream_t stream);
 int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int H, int W, int Cin, int Ho, int Wo,
                          int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int accumulate,
                          sarStream_t stream);

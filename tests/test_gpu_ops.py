@@ -129,6 +129,46 @@ def test_conv_fwd_dgrad_wgrad(L, case):
     check(db2, db_ref, name="colsum")
 
 
+@pytest.mark.parametrize("case", [  # B,H,W,Cin,Cout,k,stride -- kernels pre-split into bf16 planes (two convs in one table)
+    (2, 10, 8, 64, 64, 3, 1), (2, 13, 5, 64, 128, 3, 2), (3, 25, 5, 64, 128, 1, 2), (64, 50, 12, 64, 64, 3, 1), (2, 7, 3, 128, 256, 3, 1)])
+def test_conv_with_weight_planes(L, case):
+    """sar_conv_weight_split_bf16 + the *_ex conv entry points: planes reproduce the kernel to 2^-16, wt is the transpose of wd,
+    and forward / dgrad with planes match the oracle like the converting kernels do."""
+    B, H, W, Cin, Cout, k, s = case
+    rng = np.random.default_rng(sum(case) + 3)
+    x = rng.standard_normal((B, H, W, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) * 0.1; b = rng.standard_normal(Cout)
+    w_other = rng.standard_normal((1, 1, 32, 64))                 # a second row in the table
+    sc = rng.uniform(0.5, 1.5, Cin); sh = rng.standard_normal(Cin) * 0.3
+    pad = "same" if k == 3 else "valid"
+    y_ref, cache = O.conv2d_fwd(np.maximum(x * sc + sh, 0), w, b, (s, s), pad)
+    _, Ho, Wo, _ = y_ref.shape
+    pt, pl = (O.same_pads(H, k, s)[1], O.same_pads(W, k, s)[1]) if pad == "same" else (0, 0)
+    wd_, wo_ = dev(w), dev(w_other)
+    rows, planes, blk = [], [], 0
+    for t in (wo_, wd_):
+        K_, C_ = t.numel() // t.shape[-1], t.shape[-1]
+        pl_ = [torch.empty(C_, K_, dtype=torch.bfloat16, device="cuda") for _ in range(2)] + \
+              [torch.empty(K_, C_, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        rows.append([t.data_ptr()] + [q.data_ptr() for q in pl_] + [K_, C_, blk]); planes.append(pl_); blk += (K_ // 32) * (C_ // 64)
+    L.call("sar_conv_weight_split_bf16", torch.tensor(rows, dtype=torch.int64, device="cuda"), 2, blk)
+    for t, (wt_h, wt_l, wd_h, wd_l) in zip((wo_, wd_), planes):
+        w2 = t.reshape(-1, t.shape[-1])
+        assert float(((wd_h.float() + wd_l.float()) - w2).abs().max()) <= 2.0 ** -16 * float(w2.abs().max())
+        assert torch.equal(wd_h, w2.to(torch.bfloat16)) and torch.equal(wt_h, wd_h.t().contiguous()) and torch.equal(wt_l, wd_l.t().contiguous())
+    wt_h, wt_l, wd_h, wd_l = planes[1]
+    y = zeros(B, Ho, Wo, Cout)
+    L.call("sar_conv2d_fwd_ex_f32", dev(x), wd_, dev(b), dev(sc), dev(sh), None, y, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, wt_h, wt_l,
+           None, None, None, None, None, None, None, None, None, 1e-3, 0.99, 1)
+    check(y, y_ref, name="conv fwd (weight planes)")
+    dy = rng.standard_normal(y_ref.shape)
+    dact_ref, _, _ = O.conv2d_bwd(dy, cache)
+    dx = zeros(B, H, W, Cin)
+    L.call("sar_conv2d_dgrad_ex_f32", dev(dy), wd_, dx, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 0, wd_h, wd_l)
+    check(dx, dact_ref, name="conv dgrad (weight planes)")
+    L.call("sar_conv2d_dgrad_ex_f32", dev(dy), wd_, dx, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 1, wd_h, wd_l)
+    check(dx, 2 * dact_ref, name="conv dgrad (weight planes) accumulate")
+
+
 @pytest.mark.parametrize("case", [  # B,H,W,Cin,Cout,k,stride,residual -- with / without split-K, narrow / wide, 1x1
     (4, 25, 20, 64, 32, 3, 1, True), (16, 25, 10, 64, 64, 3, 1, True), (3, 13, 3, 128, 128, 3, 1, False),
     (2, 9, 5, 32, 48, 3, 2, False), (64, 50, 10, 64, 64, 3, 1, True), (5, 25, 5, 64, 128, 1, 2, False)])

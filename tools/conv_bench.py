@@ -28,6 +28,16 @@ for name, H, W, ci, co, k, s in STAGES:
     y = torch.empty(B, Ho, Wo, co, device="cuda"); dy = torch.randn(B, Ho, Wo, co, device="cuda"); dx = torch.empty_like(x); dw = torch.zeros_like(w)
     fl = 2.0 * B * Ho * Wo * co * ci * k * k
     t_f = timed(lambda: L.call("sar_conv2d_fwd_f32", x, w, b, sc, sh, None, y, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
+    if ci % 32 == 0 and co % 64 == 0:                # weight planes (sar_conv_weight_split_bf16)
+        K_ = k * k * ci
+        pl_ = [torch.empty(co, K_, dtype=torch.bfloat16, device="cuda") for _ in range(2)] + [torch.empty(K_, co, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        nblk = (K_ // 32) * (co // 64)
+        table = torch.tensor([[w.data_ptr()] + [t.data_ptr() for t in pl_] + [K_, co, 0]], dtype=torch.int64, device="cuda")
+        t_ws = timed(lambda: L.call("sar_conv_weight_split_bf16", table, 1, nblk))
+        t_fp = timed(lambda: L.call("sar_conv2d_fwd_ex_f32", x, w, b, sc, sh, None, y, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl, pl_[0], pl_[1],
+                                    None, None, None, None, None, None, None, None, None, 1e-3, 0.99, 1))
+        t_dp = timed(lambda: L.call("sar_conv2d_dgrad_ex_f32", dy, w, dx, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl, 0, pl_[2], pl_[3]))
+        print("%-20s weight split %5.1f us | with planes: fwd %6.1f us | dgrad %6.1f us" % (name, t_ws * 1e6, t_fp * 1e6, t_dp * 1e6), flush=True)
     t_d = timed(lambda: L.call("sar_conv2d_dgrad_f32", dy, w, dx, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl, 0))
     t_w = timed(lambda: L.call("sar_conv2d_wgrad_f32", x, dy, sc, sh, dw, None, B, H, W, ci, Ho, Wo, co, k, k, s, pt, pl))
     print("%-20s GF %.2f | fwd %6.1f us %5.1f TF | dgrad %6.1f us %5.1f TF | wgrad %6.1f us %5.1f TF" %
