@@ -1,3 +1,4 @@
+"""Diagnostic (not collected by pytest; lives under tests/ because only tests may import oracle/): CTC kernel vs oracle on one batch, including uninitialised workspace."""
 import os, sys, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,3 +1,4 @@
+"""Diagnostic (not collected by pytest; lives under tests/ because only tests may import oracle/): eager vs graph-replayed steps against the oracle (the tool that bisected the hipMemsetAsync-in-graph finding)."""
 import os, sys, io, contextlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
