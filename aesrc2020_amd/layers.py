@@ -18,6 +18,19 @@ class Layer:
         self.store = current_store()
         self.store.register_layer(self)
 
+    def __init_subclass__(cls, **kw):
+        """Every layer remembers the tensor its last forward() produced: `layer.output` is what keras' `layer.output`
+        evaluates to for the current batch (model.py:380-383 sub_model builds on it)."""
+        super().__init_subclass__(**kw)
+        fwd = cls.__dict__.get("forward")
+        if fwd is not None:
+            def forward(self, *a, _fwd=fwd, **k):
+                out = _fwd(self, *a, **k)
+                self.output = out
+                return out
+            forward.__doc__ = fwd.__doc__
+            cls.forward = forward
+
     def buf(self, key, shape, dtype=torch.float32):
         return self.store.bufs.get(self.name + "/" + key, shape, dtype)
 

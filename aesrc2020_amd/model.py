@@ -648,9 +648,36 @@ def SAR_Net(input_shape, ctc_enable=False, ar_enable=True, disc_enable=False, re
     return model, model
 
 
+class SubModel:
+    """What `Model(inputs=model.get_layer(input_name).input, outputs=model.get_layer(output_name).output)` gives the caller of
+    the reference's sub_model (model.py:380-383): an object whose predict() returns the named layer's output -- e.g. the
+    utterance embedding `AR_BN2`, the pooled vector `gvlad_pool`, or the encoder states `CRNN_LN` -- in inference mode."""
+
+    def __init__(self, model, input_name, output_name):
+        if input_name != "x_data":
+            raise ValueError("sub-models start at the spectrogram input 'x_data' (got %r)" % (input_name,))
+        self.model, self.layer = model, model.get_layer(output_name)
+        self.name = output_name
+
+    def predict(self, x, batch_size=32):
+        m = self.model
+        x = x if isinstance(x, dict) else {"x_data": x}
+        n = len(x["x_data"]); outs = []
+        with m._inference():
+            for s in range(0, n, batch_size):
+                xb = {k: v[s:s + batch_size] for k, v in x.items()}
+                m._upload(xb, None); m._forward()
+                o = self.layer.output
+                B = m.B
+                if o.dim() == 2 and o.shape[0] == B * m.L and m.L > 1:       # sequence tensors are (B*L, C) on the device
+                    o = o.view(B, m.L, -1)
+                outs.append(o.detach().cpu().numpy().copy())
+        return np.concatenate(outs)
+
+
 def sub_model(model, input_name, output_name):
-    """model.py:380-383 (layer lookup by name; the eager engine exposes the layer objects directly)."""
-    return model.get_layer(output_name)
+    """model.py:380-383."""
+    return SubModel(model, input_name, output_name)
 
 
 def ctc_pred(model, x, batch_size, input_len):
@@ -658,13 +685,14 @@ def ctc_pred(model, x, batch_size, input_len):
     x = x if isinstance(x, dict) else {"x_data": x}
     res = []
     n = len(x["x_data"])
-    for s in range(0, n, batch_size):
-        xb = {k: v[s:s + batch_size] for k, v in x.items()}
-        model._upload(xb, None); model._forward()
-        B, L, V = model.B, model.L, model.cfg["bpe_classes"]
-        il = torch.full((B,), int(input_len), dtype=torch.int32, device="cuda")
-        dec = torch.empty(B, L, dtype=torch.int32, device="cuda"); dl = torch.empty(B, dtype=torch.int32, device="cuda")
-        _call("sar_ctc_greedy_decode_f32", model.out["ctc_pred"], il, dec, dl, B, L, V)
-        dec, dl = dec.cpu().numpy(), dl.cpu().numpy()
-        res += [dec[b, :dl[b]].tolist() for b in range(B)]
+    with model._inference():                                                  # model.predict: Keras learning phase 0
+        for s in range(0, n, batch_size):
+            xb = {k: v[s:s + batch_size] for k, v in x.items()}
+            model._upload(xb, None); model._forward()
+            B, L, V = model.B, model.L, model.cfg["bpe_classes"]
+            il = torch.full((B,), int(input_len), dtype=torch.int32, device="cuda")
+            dec = torch.empty(B, L, dtype=torch.int32, device="cuda"); dl = torch.empty(B, dtype=torch.int32, device="cuda")
+            _call("sar_ctc_greedy_decode_f32", model.out["ctc_pred"], il, dec, dl, B, L, V)
+            dec, dl = dec.cpu().numpy(), dl.cpu().numpy()
+            res += [dec[b, :dl[b]].tolist() for b in range(B)]
     return res

@@ -254,3 +254,30 @@ def test_variable_length_inference_model():
     b = MT.synthetic_batch(MT.Cfg(**dict(kw, input_shape=[120, 80, 1])), B, seed=6)
     with pytest.raises(ValueError):
         tm.train_on_batch(b, b)
+
+
+def test_sub_model_and_ctc_pred_helpers():
+    """model.py:380-389: sub_model(model, 'x_data', name).predict(x) returns the named layer's output (inference mode), and
+    ctc_pred() the greedy CTC decoding of the ctc_pred probabilities."""
+    from aesrc2020_amd import model as mdl
+    from oracle import ops_np as O
+    cfg, ref, model, batch = build_pair(CASES["cfg3_ctc_circle"])
+    B = CASES["cfg3_ctc_circle"]["B"]
+    for b in (batch, MT.synthetic_batch(cfg, B, seed=5)):            # move the BN moving averages a little
+        ref.forward_backward(b); model.forward_backward_only(b, b)
+    x = {k: v for k, v in batch.items() if k.startswith("x_")}
+    want = ref.predict(batch)
+    emb = mdl.sub_model(model, "x_data", "AR_BN2").predict(x, batch_size=3)
+    assert emb.shape == tuple(want["ar"].shape) and np.abs(emb - want["ar"].numpy()).max() < 1e-3
+    enc = mdl.sub_model(model, "x_data", "CRNN_LN").predict(x, batch_size=B)
+    assert enc.shape == tuple(want["crnn"].shape) and np.abs(enc - want["crnn"].numpy()).max() < 1e-3
+    pooled = mdl.sub_model(model, "x_data", "gvlad_pool").predict(x)
+    assert np.abs(pooled - want["pooled"].numpy()).max() < 1e-3
+    with pytest.raises(ValueError):
+        mdl.sub_model(model, "x_data", "no_such_layer")
+    L = want["ctc_pred"].shape[1]
+    dec = mdl.ctc_pred(model, x, batch_size=B, input_len=L)
+    ref_dec = O.ctc_greedy_decode(want["ctc_pred"].numpy(), np.full((B, 1), L))
+    for b in range(B):
+        row = [int(t) for t in dec[b] if t >= 0]
+        assert row == ref_dec[b], (b, row, ref_dec[b])
