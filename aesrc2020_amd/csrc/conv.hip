@@ -177,6 +177,7 @@ __global__ void bn_relu_maxpool_fwd_kernel(const float* __restrict__ x, const fl
 __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
     const float* __restrict__ dpool, const float* __restrict__ out, const uint8_t* __restrict__ idx,
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ scale, const float* __restrict__ shift,
     float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int pt, int pl, unsigned magic_wo, unsigned magic_ho) {
     __shared__ float4 r1[256], r2[256];
     const int tpr = C / 4;                                    // C <= 256 and 256 % C == 0 (host-checked) -> tpr | 64
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
     const int c = cv * 4;
     const unsigned npix = (unsigned)(B * Ho * Wo);
     const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+    const float4 scv = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    struct B4 { bool x, y, z, w; };
+    const B4 ok = {fabsf(scv.x) > 1e-6f, fabsf(scv.y) > 1e-6f, fabsf(scv.z) > 1e-6f, fabsf(scv.w) > 1e-6f};
+    const float4 isc = make_float4(ok.x ? 1.f / scv.x : 0.f, ok.y ? 1.f / scv.y : 0.f, ok.z ? 1.f / scv.z : 0.f, ok.w ? 1.f / scv.w : 0.f);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
         const long o = (long)pix * C + c;
@@ -193,10 +198,13 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_reduce_kernel(
         const unsigned t = Wo == 1 ? pix : __umulhi(pix, magic_wo), wo = pix - t * (unsigned)Wo;      // q = umulhi(m, ceil(2^32/d))
         const unsigned n = Ho == 1 ? t : __umulhi(t, magic_ho), ho = t - n * (unsigned)Ho;
         const long base = (((long)n * H + (int)ho * 2 - pt) * W + (int)wo * 2 - pl) * C + c;
-        if (a.x > 0.f) { const float xh = (x[base + ((k.x / 3) * W + (k.x % 3)) * C + 0] - mu.x) * rs.x; s1.x += g.x; s2.x = fmaf(g.x, xh, s2.x); }
-        if (a.y > 0.f) { const float xh = (x[base + ((k.y / 3) * W + (k.y % 3)) * C + 1] - mu.y) * rs.y; s1.y += g.y; s2.y = fmaf(g.y, xh, s2.y); }
-        if (a.z > 0.f) { const float xh = (x[base + ((k.z / 3) * W + (k.z % 3)) * C + 2] - mu.z) * rs.z; s1.z += g.z; s2.z = fmaf(g.z, xh, s2.z); }
-        if (a.w > 0.f) { const float xh = (x[base + ((k.w / 3) * W + (k.w % 3)) * C + 3] - mu.w) * rs.w; s1.w += g.w; s2.w = fmaf(g.w, xh, s2.w); }
+        // xhat at the argmax.  Where ReLU is active the pooled value IS scale*x + shift, so x (and xhat) follow from it without
+        // touching the full-resolution tensor (the gather costs a 32-byte sector per element); only a degenerate channel
+        // (|scale| tiny) falls back to the gather.
+        if (a.x > 0.f) { const float xv = ok.x ? (a.x - sh.x) * isc.x : x[base + ((k.x / 3) * W + (k.x % 3)) * C + 0]; const float xh = (xv - mu.x) * rs.x; s1.x += g.x; s2.x = fmaf(g.x, xh, s2.x); }
+        if (a.y > 0.f) { const float xv = ok.y ? (a.y - sh.y) * isc.y : x[base + ((k.y / 3) * W + (k.y % 3)) * C + 1]; const float xh = (xv - mu.y) * rs.y; s1.y += g.y; s2.y = fmaf(g.y, xh, s2.y); }
+        if (a.z > 0.f) { const float xv = ok.z ? (a.z - sh.z) * isc.z : x[base + ((k.z / 3) * W + (k.z % 3)) * C + 2]; const float xh = (xv - mu.z) * rs.z; s1.z += g.z; s2.z = fmaf(g.z, xh, s2.z); }
+        if (a.w > 0.f) { const float xv = ok.w ? (a.w - sh.w) * isc.w : x[base + ((k.w / 3) * W + (k.w % 3)) * C + 3]; const float xh = (xv - mu.w) * rs.w; s1.w += g.w; s2.w = fmaf(g.w, xh, s2.w); }
     }
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
     __syncthreads();
@@ -306,14 +314,14 @@ extern "C" int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, c
 
 // sums: the stem BN workspace (sar_bn_workspace_bytes(C)). dx may not alias x.
 extern "C" int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint8_t* idx, const float* x,
-                                           const float* mean, const float* rstd, const float* scale, double* sums,
-                                           float* dx, int B, int H, int W, int C, int Ho, int Wo, int pad_top,
-                                           int pad_left, hipStream_t stream) {
-    if (!dpool || !out || !idx || !x || !mean || !rstd || !scale || !sums || !dx || C > 256 || (256 % C)) return SAR_EINVAL;
+                                           const float* mean, const float* rstd, const float* scale, const float* shift,
+                                           double* sums, float* dx, int B, int H, int W, int C, int Ho, int Wo,
+                                           int pad_top, int pad_left, hipStream_t stream) {
+    if (!dpool || !out || !idx || !x || !mean || !rstd || !scale || !shift || !sums || !dx || C > 256 || (256 % C)) return SAR_EINVAL;
     float* part = reinterpret_cast<float*>(sums + 2 * C);          // workspace layout of sar_bn_workspace_bytes(C)
     if ((long)B * H * W * (W > H ? W : H) >= (1L << 32)) return SAR_EINVAL;         // magic-number division exactness bound
     const auto magic = [](int d) { return (unsigned)(((1UL << 32) + d - 1) / d); };
-    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, part, B, H, W, C, Ho, Wo, pad_top, pad_left, magic(Wo), magic(Ho));
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, shift, part, B, H, W, C, Ho, Wo, pad_top, pad_left, magic(Wo), magic(Ho));
     hipLaunchKernelGGL(pool_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, 256, sums, 2 * C);
     if (C % 4) return SAR_EINVAL;
     const long total = (long)B * H * W * (C / 4);

@@ -276,7 +276,7 @@ class ResNetTrunk(Layer):
         Hs, Ws = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
         dstem = self.scratch("res_dstem", (B, Hs, Ws, c0))
         sb = self.stem_bn
-        _call("sar_maxpool_bn_relu_bwd_f32", g, self.pooled, self.pool_idx, self.stem_out, sb.mean, sb.rstd, sb.scale, sb.sums,
+        _call("sar_maxpool_bn_relu_bwd_f32", g, self.pooled, self.pool_idx, self.stem_out, sb.mean, sb.rstd, sb.scale, sb.shift, sb.sums,
               dstem, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
         _call("sar_bn_param_grads_f32", sb.sums, sb.gamma.g, sb.beta.g, c0)
         T, D = self.in_hw

@@ -94,8 +94,8 @@ int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, const float*
                                 int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
                                 sarStream_t stream);
 int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint8_t* idx, const float* x,
-                                const float* mean, const float* rstd, const float* scale, double* sums, float* dx,
-                                int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
+                                const float* mean, const float* rstd, const float* scale, const float* shift, double* sums,
+                                float* dx, int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
                                 sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.

@@ -231,7 +231,7 @@ def test_stem_and_fused_maxpool(L, B, T, D, C0):
     dbn = O.relu_bwd(da, a_ref)
     dy_ref, dg_ref, dbeta_ref = O.batchnorm_bwd(dbn, bnc)
     dyd = zeros(B, Ho, Wo, C0)
-    L.call("sar_maxpool_bn_relu_bwd_f32", dev(dpool), pooled, idx, yd, mean, rstd, scale, sums, dyd, B, Ho, Wo, C0, Hp, Wp, ppt, ppl)
+    L.call("sar_maxpool_bn_relu_bwd_f32", dev(dpool), pooled, idx, yd, mean, rstd, scale, shift, sums, dyd, B, Ho, Wo, C0, Hp, Wp, ppt, ppl)
     check(dyd, dy_ref, name="maxpool+bn+relu bwd")
     dg, dbt = zeros(C0), zeros(C0)
     L.call("sar_bn_param_grads_f32", sums, dg, dbt, C0)
