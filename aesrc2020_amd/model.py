@@ -151,7 +151,7 @@ class SARNetModel:
                     else:
                         self.disc_bn = cls(n_classes=A, m=c["margin"], name="y_disc_bn", in_dim=nb)
         self.store.finalize()
-        self.dp = DataParallel(self.store)
+        self.dp = DataParallel(self.store, trunk_splits=self.trunk.bucket_split_names())
         self.store.set_adam(c["lr"], grad_scale=1.0 / self.dp.world)
         self.bufs = self.store.bufs
         self._loss_weights()
@@ -422,8 +422,8 @@ class SARNetModel:
         self.store.zero_grads()
         self._forward(); self._losses_forward(); self._backward_heads()
 
-    def _seg_trunk(self):
-        self._backward_trunk(self._g_trunk)
+    def _seg_trunk(self, part):
+        self.trunk.backward(self._g_trunk, part=part)
 
     def _run_segments(self, segments):
         """Run the step as a list of (name, fn, after) segments; `after` (or None) is called on the host between segments
@@ -458,18 +458,23 @@ class SARNetModel:
     # ------------------------------------------------------------------ public step API
     def train_step_device(self):
         """One optimisation step on the batch currently bound in the static input buffers (no host sync).
-        world == 1: the whole step is one HIP graph.  world > 1: three graphs -- [forward + heads/GRU backward], [trunk
-        backward], [L2+Adam] -- with the RCCL all-reduce of the tail gradient bucket launched between the first two, so it
-        runs on RCCL's stream underneath the conv backward; the conv bucket follows, then Adam waits for both."""
+        world == 1: the whole step is one HIP graph.  world > 1: five graphs -- [forward + heads/GRU backward], [trunk
+        backward: stage 3], [stage 2], [stages 1-0 + stem], [L2+Adam] -- and after each backward graph the RCCL all-reduce
+        of the gradient bucket it completed is launched asynchronously, so it runs on RCCL's stream underneath the next
+        graph; only the last, small bucket (stages 1-0 + stem, 1.5 MB at F=32) is exposed before Adam waits for all."""
         if self.dp.world == 1:
             self._run_segments([("step", self._device_step, None)])
             return
         works = []
-        self._run_segments([
-            ("heads", self._seg_heads, lambda: works.extend(self.dp.allreduce_bucket(0, async_op=True))),
-            ("trunk", self._seg_trunk, lambda: (works.extend(self.dp.allreduce_bucket(1, async_op=True)),
-                                                [w.wait() for w in works])),
-            ("adam", self.store.adam_step, None)])
+        ar = lambda i: (lambda: works.extend(self.dp.allreduce_bucket(i, async_op=True)))
+        segs = [("heads", self._seg_heads, ar(0))]
+        nparts = self.trunk.N_PARTS
+        for part in range(nparts):
+            last = part == nparts - 1
+            after = (lambda i=part + 1: (works.extend(self.dp.allreduce_bucket(i, async_op=True)), [w.wait() for w in works])) if last else ar(part + 1)
+            segs.append(("trunk%d" % part, (lambda part=part: self._seg_trunk(part)), after))
+        segs.append(("adam", self.store.adam_step, None))
+        self._run_segments(segs)
 
     def train_on_batch(self, x, y=None, return_dict=True, sync=True):
         self._upload(x, y)

@@ -56,17 +56,27 @@ def broadcast_flat(flat, src=0, group=None):
 
 
 class DataParallel:
-    def __init__(self, store, split_name_prefix="CNN_LIN"):
+    def __init__(self, store, split_name_prefix="CNN_LIN", trunk_splits=()):
+        """Buckets of the flat gradient buffer in the order backward completes them: [first post-trunk parameter, n) (heads,
+        pooling, GRUs), then the conv trunk from its end towards its start, cut at the parameters named in `trunk_splits`
+        (ResNetTrunk.bucket_split_names(): stage 3, stage 2), the rest last."""
         self.store = store
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
-        # bucket boundary = first parameter after the conv trunk
         split = store.n
         for r in store.refs:
             if r.name.startswith(split_name_prefix):
                 split = r.offset; break
         self.bounds = bucket_bounds(store.n, split)
+        offs = {r.name: r.offset for r in store.refs}
+        cuts = sorted((offs[n] for n in trunk_splits if n in offs and 0 < offs[n] < split), reverse=True)
+        if cuts and len(self.bounds) == 2:
+            lo_hi, hi = [], split
+            for c in cuts:
+                lo_hi.append((c, hi)); hi = c
+            lo_hi.append((0, hi))
+            self.bounds = [self.bounds[0]] + lo_hi
         if self.enabled:
             self.broadcast_params()
 
@@ -81,7 +91,8 @@ class DataParallel:
             allreduce_flat(self.store.grads, self.bounds)
 
     def allreduce_bucket(self, i, async_op=True):
-        """Launch the sum-all-reduce of bucket i (0 = tail: heads/GRUs, complete first in backward; 1 = conv stack).
+        """Launch the sum-all-reduce of bucket i (0 = tail: heads/GRUs, complete first in backward; 1.. = conv stack, late
+        stages first).
         With RCCL the collective is enqueued on RCCL's stream behind the work already submitted to the current stream, so
         it overlaps whatever the caller submits next; `work.wait()` makes the current stream wait for it (no host block).
         A model without post-trunk parameters has a single bucket: index 1 is then empty."""

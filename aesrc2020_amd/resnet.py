@@ -133,7 +133,7 @@ class ResNetTrunk(Layer):
             for j in range(r):
                 stride = 2 if (j == 0 and i != 0) else 1
                 first = (i == 0 and j == 0)
-                blk = {"cin": cin, "cout": f}
+                blk = {"cin": cin, "cout": f, "stage": i}
                 blk["bn1"] = None if first else _BN(st, st.auto_name("batch_normalization"), cin)     # resnet.py:111-120
                 blk["conv1"] = _Conv(st, st.auto_name("conv2d"), 3, cin, f, stride, "same")
                 blk["bn2"] = _BN(st, st.auto_name("batch_normalization"), f)
@@ -235,13 +235,34 @@ class ResNetTrunk(Layer):
         return out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dy):
+    # Backward runs in parts so that a data-parallel step can all-reduce the gradients of the late stages (most of the
+    # parameters: stage 3 = 14 MB, stage 2 = 7 MB of the 21 MB conv bucket at F=32) underneath the backward of the early ones:
+    # part 0 = final BN + stage 3, part 1 = stage 2, part 2 = stages 1, 0 and the stem.  The flat parameter buffer is in
+    # forward order, so each part completes one contiguous range (bucket_split_names()).
+    N_PARTS = 3
+
+    def bucket_split_names(self):
+        """First parameter of stage 3 and of stage 2 (creation order = flat-buffer order)."""
+        names = []
+        for stage in (3, 2):
+            blk = next(b for b in self.blocks if b["stage"] == stage)
+            names.append((blk["bn1"].gamma if blk["bn1"] is not None else blk["conv1"].kernel).name)
+        return names
+
+    def backward(self, dy, part=None):
+        """part None: the whole backward; 0/1/2: one part (see above), dy only read by part 0."""
         B = self.B
-        H, W = self.out_hw
-        g = self.scratch("res_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c))
-        self.final_bn.bwd(dy, self.pre_final, None, g, B * H * W, relu=1)
+        if part in (None, 0):
+            H, W = self.out_hw
+            g = self.scratch("res_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c))
+            self.final_bn.bwd(dy, self.pre_final, None, g, B * H * W, relu=1)
+        else:
+            g = self._g_part
+        stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
+            if blk["stage"] not in stages:
+                continue
             H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
             cin, cout = blk["cin"], blk["cout"]
             R2 = B * H2 * W2
@@ -272,6 +293,9 @@ class ResNetTrunk(Layer):
                     blk["conv1"].dgrad(dc1, gin, B)
                     _call("sar_axpy_f32", g, gin, 1.0, gin.numel())
             g = gin
+        self._g_part = g
+        if part in (0, 1):
+            return None
         # stem: maxpool + BN + ReLU backward, then the 7x7 weight gradient (no input gradient needed)
         Hs, Ws = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
         dstem = self.scratch("res_dstem", (B, Hs, Ws, c0))

@@ -1,7 +1,8 @@
 """Data-parallel step on the GPU: two processes (one model replica each) share this box's single GPU and exchange gradients
 through torch.distributed (gloo here; the production launcher uses backend "nccl" = RCCL, one GPU per rank).  Checks the
-multi-segment step of model.train_step_device: [forward + heads backward] -> tail bucket all-reduce (async) ->
-[trunk backward] -> conv bucket all-reduce -> [L2+Adam], eager on the first step and replayed from HIP graphs afterwards."""
+multi-segment step of model.train_step_device: [forward + heads backward] -> tail bucket all-reduce (async) -> [trunk
+backward stage 3] -> its bucket -> [stage 2] -> its bucket -> [stages 1-0 + stem] -> last bucket -> wait -> [L2+Adam],
+eager on the first step and replayed from HIP graphs afterwards."""
 import os
 import sys
 
@@ -56,7 +57,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients():
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
     (_, r0, g0), (_, r1, g1) = res
-    assert g0 == ["adam", "heads", "trunk"] and g1 == g0                   # steps 2.. ran from the three captured graphs
+    assert g0 == ["adam", "heads", "trunk0", "trunk1", "trunk2"] and g1 == g0      # steps 2.. ran from the five captured graphs
     single, _ = SAR_Net(seed=99, **KW)
     cfg = MT.Cfg(**KW)
     st = single.store
@@ -74,6 +75,8 @@ def test_two_rank_step_matches_mean_of_shard_gradients():
             gsum += st.grads.detach().cpu().numpy()
         # flat-vector L2 (not max-abs): the two computations differ only in fp32 summation order (split-K atomics), but a
         # pre-activation within that noise of zero flips a ReLU and changes single gradient elements discretely
+        # (observed: 1e-6 typically, up to 5e-3 when a flip happens on these 3-utterance shards; a missed or doubled bucket
+        # would show as O(1))
         err = float(np.linalg.norm(a["grads"] - gsum) / np.linalg.norm(gsum))
-        assert err < 1e-3, (i, err)
+        assert err < 2e-2, (i, err)
         assert not np.array_equal(a["p_before"], a["p_after"])

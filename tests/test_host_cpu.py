@@ -134,3 +134,25 @@ def test_data_parallel_gloo_world2():
         assert ys == list(range(rank * 4, rank * 4 + 4))                    # contiguous slices like multi_gpu_model
     from aesrc2020_amd.parallel import bucket_bounds
     assert bucket_bounds(10, 0) == [(0, 10)] and bucket_bounds(10, 10) == [(0, 10)]
+
+
+def test_gradient_buckets_follow_backward_order():
+    """DataParallel buckets: tail (post-trunk) first, then the conv trunk from its last stage towards the stem; they tile the
+    flat buffer exactly once."""
+    from aesrc2020_amd import parallel
+
+    class Ref:
+        def __init__(self, name, offset):
+            self.name, self.offset = name, offset
+
+    class Store:
+        pass
+    st = Store(); st.n = 4096
+    st.refs = [Ref("conv2d_1/kernel", 0), Ref("batch_normalization_9/gamma", 768), Ref("conv2d_12/kernel", 1024),
+               Ref("batch_normalization_13/gamma", 2048), Ref("CNN_LIN/kernel", 3072), Ref("y_accent/kernel", 3840)]
+    st.params = st.grads = None; st.state_refs = []
+    dp = parallel.DataParallel(st, trunk_splits=["batch_normalization_13/gamma", "batch_normalization_9/gamma"])
+    assert dp.bounds == [(3072, 4096), (2048, 3072), (768, 2048), (0, 768)]
+    assert sorted(dp.bounds) == [(0, 768), (768, 2048), (2048, 3072), (3072, 4096)]
+    assert parallel.DataParallel(st).bounds == [(3072, 4096), (0, 3072)]
+    assert parallel.DataParallel(st, trunk_splits=["no_such_param"]).bounds == [(3072, 4096), (0, 3072)]
