@@ -3,7 +3,7 @@
 Replaces keras.utils.multi_gpu_model (model.py:193-194): each rank owns a full replica and a contiguous slice of
 the global batch (same slicing as multi_gpu_model); BatchNorm statistics stay per-GPU (per-tower in the reference);
 the flat fp32 gradient buffer (engine.ParamStore.grads) is summed across ranks and the mean is taken by the Adam
-kernel's grad_scale = 1/world.  The buffer is reduced in two contiguous buckets: parameters are laid out in
+kernel's grad_scale = 1/world.  The buffer is reduced in contiguous buckets: parameters are laid out in
 forward order, so the tail (heads + GRUs) is complete early in backward and the head (conv stack) last.
 Everything here is device-agnostic torch.distributed code so the N>1 path is covered by gloo tests on CPU."""
 import os
