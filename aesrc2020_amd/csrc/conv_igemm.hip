@@ -907,17 +907,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     float4 asc = make_float4(1, 1, 1, 1), ash = zero4();
     if (p.scale) { asc = *reinterpret_cast<const float4*>(p.scale + a_ci); ash = *reinterpret_cast<const float4*>(p.shift + a_ci); }
     const float relu_lo = p.scale ? 0.f : -INFINITY;                  // no prologue: identity
-    // B' micro-tile: channels b_c4*4.. of dy, rows b_r..b_r+3 (threads beyond the tile idle)
-    const int b_r = (tid % (BK / 4)) * 4, b_c4 = tid / (BK / 4);
-    const bool b_act = b_c4 < BNt / 4;
+    // B' micro-tile: channels b_c4*4.. of dy, rows b_r..b_r+BR-1: ALL threads stage an equal share (BR = 2 rows for the 64-wide
+    // tile).  With 4-row micro-tiles only half the threads had B work: waves 0-1 staged twice as much as waves 2-3, and
+    // the exec-masked loads made the compiler's wait counts assume the short path (a wait on a load issued moments before).
+    // LDS stores: the 16 lanes of a channel group write 64 contiguous bytes, groups land 16 banks apart -- conflict-free.
+    constexpr int BR = BNt / 32;
+    const int b_r = (tid % (BK / BR)) * BR, b_c4 = tid / (BK / BR);
     const bool bcol_ok = n0 + b_c4 * 4 < p.Cout;
     const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
     const float* dyb = p.dy + (bcol_ok ? n0 + b_c4 * 4 : 0);
     float4 bsum = zero4();
-    struct Regs { float4 ra[4], rb[4]; unsigned vmask; };
+    struct Regs { float4 ra[4], rb[BR]; unsigned vmask; };
     Regs R0, R1; R0.vmask = R1.vmask = 0;
+    // Tiles past the end of the slice stage an all-zero A' tile (`live`), so the loop body below has no conditional matrix
+    // phase: a conditional second half made the compiler round-trip the 32 accumulator registers through VGPR copies in
+    // every iteration.  dy rows are NOT masked: a row outside the slice always meets a zero row of A' (its rowinfo mask is
+    // 0), so a clamped, finite row is as good as zeros; only the fused bias sum looks at the row bits (8..11).
     auto load = [&](Regs& Rg, int t) {
         const int rl = min(t, ntile - 1) * BK;                        // clamped tile: tail stays branch-free
+        const unsigned live = t < ntile ? 1u : 0u;
         Rg.vmask = 0;
         const int4 i01 = *reinterpret_cast<const int4*>(&rowinfo[rl + a_r]);
         const int4 i23 = *reinterpret_cast<const int4*>(&rowinfo[rl + a_r + 2]);
@@ -925,20 +933,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
         const int mask[4] = {i01.y, i01.w, i23.y, i23.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned ok = ((unsigned)mask[i] >> a_tap) & 1u;
+            const unsigned ok = ((unsigned)mask[i] >> a_tap) & live;
             const int off = ok ? base[i] + a_tapoff : 0;
             Rg.ra[i] = *reinterpret_cast<const float4*>(p.x + off);
             Rg.vmask |= ok << i;
         }
-        if (b_act) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned m = r_begin + rl + b_r + i;
-                const unsigned ok = (bcol_ok && m < r_end) ? 1u : 0u;
-                const unsigned off = ok ? m * (unsigned)p.Cout : 0u;
-                Rg.rb[i] = *reinterpret_cast<const float4*>(dyb + off);
-                Rg.vmask |= ok << (8 + i);
-            }
+        for (int i = 0; i < BR; ++i) {
+            const unsigned m = r_begin + rl + b_r + i;
+            Rg.rb[i] = *reinterpret_cast<const float4*>(dyb + min(m, r_end - 1) * (unsigned)p.Cout);
+            Rg.vmask |= ((m < r_end ? 1u : 0u) & live) << (8 + i);
         }
     };
     auto split_store = [&](const float (&v)[4][4], __bf16 (*Hh)[BKP], __bf16 (*Ll)[BKP], int c0, int r0) {
@@ -950,28 +954,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
             *reinterpret_cast<bf16x4*>(&Hh[c0 + j][r0]) = hi; *reinterpret_cast<bf16x4*>(&Ll[c0 + j][r0]) = lo;
         }
     };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 sc01 = {asc.x, asc.y}, sc23 = {asc.z, asc.w}, sh01 = {ash.x, ash.y}, sh23 = {ash.z, ash.w};
     auto store = [&](const Regs& Rg, int buf) {
         {
             float v[4][4];                                            // [row i][channel j]
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool ok = (Rg.vmask >> i) & 1u;                 // padding stays exactly zero (selects, no branches)
+                // packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two channels per instruction); padding rows are multiplied
+                // by 0 after the ReLU, so they stay exactly zero
+                const float okf = ((Rg.vmask >> i) & 1u) ? 1.f : 0.f;
                 const float4 q = Rg.ra[i];
-                v[i][0] = ok ? fmaxf(fmaf(q.x, asc.x, ash.x), relu_lo) : 0.f; v[i][1] = ok ? fmaxf(fmaf(q.y, asc.y, ash.y), relu_lo) : 0.f;
-                v[i][2] = ok ? fmaxf(fmaf(q.z, asc.z, ash.z), relu_lo) : 0.f; v[i][3] = ok ? fmaxf(fmaf(q.w, asc.w, ash.w), relu_lo) : 0.f;
+                f32x2 u01 = {q.x, q.y}, u23 = {q.z, q.w};
+                u01 = __builtin_elementwise_fma(u01, sc01, sh01); u23 = __builtin_elementwise_fma(u23, sc23, sh23);
+                v[i][0] = fmaxf(u01.x, relu_lo); v[i][1] = fmaxf(u01.y, relu_lo);
+                v[i][2] = fmaxf(u23.x, relu_lo); v[i][3] = fmaxf(u23.y, relu_lo);
+                f32x2 w01 = {v[i][0], v[i][1]}, w23 = {v[i][2], v[i][3]};
+                const f32x2 ok2 = {okf, okf};
+                w01 *= ok2; w23 *= ok2;
+                v[i][0] = w01.x; v[i][1] = w01.y; v[i][2] = w23.x; v[i][3] = w23.y;
             }
             split_store(v, Ah[buf], Al[buf], a_c4 * 4, a_r);
         }
-        if (b_act) {
-            float v[4][4];
+        {
+            float v[BR][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = (Rg.vmask >> (8 + i)) & 1u;
+            for (int i = 0; i < BR; ++i) {
                 const float4 q = Rg.rb[i];
-                v[i][0] = ok ? q.x : 0.f; v[i][1] = ok ? q.y : 0.f; v[i][2] = ok ? q.z : 0.f; v[i][3] = ok ? q.w : 0.f;
-                if (do_bias) { bsum.x += v[i][0]; bsum.y += v[i][1]; bsum.z += v[i][2]; bsum.w += v[i][3]; }
+                v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
             }
-            split_store(v, Bh[buf], Bl[buf], b_c4 * 4, b_r);
+            if (do_bias) {                                            // block-uniform
+#pragma unroll
+                for (int i = 0; i < BR; ++i)
+                    if ((Rg.vmask >> (8 + i)) & 1u) { bsum.x += v[i][0]; bsum.y += v[i][1]; bsum.z += v[i][2]; bsum.w += v[i][3]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                             // channel j gets its BR consecutive rows
+                typedef __bf16 bf16xr __attribute__((ext_vector_type(BR)));
+                bf16xr hi, lo;
+#pragma unroll
+                for (int i = 0; i < BR; ++i) { const __bf16 h = (__bf16)v[i][j]; hi[i] = h; lo[i] = (__bf16)(v[i][j] - (float)h); }
+                *reinterpret_cast<bf16xr*>(&Bh[buf][b_c4 * 4 + j][b_r]) = hi; *reinterpret_cast<bf16xr*>(&Bl[buf][b_c4 * 4 + j][b_r]) = lo;
+            }
         }
     };
     f32x16 acc[TM];
@@ -997,23 +1021,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     };
     __syncthreads();                                                 // row table complete
     TSTAMP(2);
-    // same two-tile-ahead pipeline as the forward kernel
+    // Double buffering at k-tile granularity: while the matrix pipe works on the tile in one LDS buffer, the same wave's VALU
+    // stages the next tile (BN+ReLU, hi/lo split, transposed stores) into the other -- both sit in one basic block, so the
+    // MFMAs run in the shadow of the staging code instead of in a phase of their own.  The raw loads for the tile after that are
+    // issued at the top of each half and are consumed one half later (two register sets, two halves per iteration).
     load(R0, 0); load(R1, 1);
     TSTAMP(3);
     store(R0, 0);
-    if (ntile > 1) store(R1, 1);                                      // a clamped re-load of the last tile must not reach the bias sum
     __syncthreads();
     TSTAMP(4);
-    // Two k-tiles per iteration; the loads of the NEXT two tiles are issued at the top and consumed at the bottom, behind both
-    // matrix phases.  (With loads carried across the back-edge the compiler drained the whole load queue, vmcnt(0), in every
-    // first half here -- tools/conv_timing.py: 4700 cycles per k-tile.)
     for (int t = 0; t < ntile; t += 2) {
-        load(R0, t + 2); load(R1, t + 3);
-        mma(0);
-        if (t + 1 < ntile) mma(1);
+        load(R0, t + 2);
+        mma(0); store(R1, 1);
         __syncthreads();
-        if (t + 2 < ntile) store(R0, 0);
-        if (t + 3 < ntile) store(R1, 1);
+        load(R1, t + 3);
+        mma(1); store(R0, 0);
         __syncthreads();
     }
     TSTAMP(5);
@@ -1031,14 +1053,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
 #endif
     TSTAMP(6); TSTAMP(15);
     if (do_bias) {                                                   // block-uniform; the A tile is free after the last barrier
-        float* scr = reinterpret_cast<float*>(&Ah[0][0][0]);         // [8 row groups][BNt]
+        float* scr = reinterpret_cast<float*>(&Ah[0][0][0]);         // [BK/BR row groups][BNt]
         __syncthreads();
-        if (b_act) *reinterpret_cast<float4*>(&scr[(b_r / 4) * BNt + b_c4 * 4]) = bsum;
+        *reinterpret_cast<float4*>(&scr[(b_r / BR) * BNt + b_c4 * 4]) = bsum;
         __syncthreads();
         if (tid < BNt && n0 + tid < p.Cout) {
             float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < BK / 4; ++g) sum += scr[g * BNt + tid];
+            for (int g = 0; g < BK / BR; ++g) sum += scr[g * BNt + tid];
             atomicAdd(p.dbias + n0 + tid, sum);
         }
     }
@@ -1349,7 +1371,7 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     const int target = conv_knobs().wgrad_blocks ? conv_knobs().wgrad_blocks : (x3 ? 384 : 1024);
     int splits = (target + tiles - 1) / tiles;
     long rows = (R + splits - 1) / splits;
-    rows = ((rows + 31) / 32) * 32;
+    rows = ((rows + 63) / 64) * 64;                                    // whole pairs of k-tiles: the bf16x3 loop does two per iteration
     if (rows < 128) rows = 128;
     if (rows > WG_MAX_ROWS) rows = WG_MAX_ROWS;                       // bound of the per-block row table (bf16x3 kernel)
     splits = cdiv(R, rows);
