@@ -85,20 +85,32 @@ __device__ __forceinline__ void fwd_epilogue(const f32x16 (&acc)[TM], const Conv
     const bool lead = blockIdx.z == 0;
     const float bv = (colok && p.bias && lead) ? p.bias[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    if (colok) {
+    // Branch-free over the 16 accumulator rows: the residual values are fetched first, as 16 independent loads from clamped
+    // addresses (with a per-row `continue` in front of it, every residual load was followed by its own wait -- 16 serialized
+    // memory latencies per wave in the epilogue of every second conv of a residual block).
+    const bool use_res = p.res != nullptr && lead;                  // kernel-uniform
+    const int colc = min(col, p.Cout - 1);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
+        float rv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= M) continue;
-                const long o = (long)row * p.Cout + col;
-                float v = acc[tm][r] + bv;
-                if (p.res && lead) v += p.res[o];
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            rv[r] = use_res ? p.res[(long)min(row, M - 1) * p.Cout + colc] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const bool ok = colok && row < M;
+            const long o = (long)row * p.Cout + col;
+            float v = acc[tm][r] + bv;
+            if (use_res) v += rv[r];
+            if (ok) {
                 if (p.splitk > 1) atomicAdd(p.y + o, v);       // y zeroed by the launcher
                 else p.y[o] = v;
-                s1 += v; s2 = fmaf(v, v, s2);
             }
+            s1 += ok ? v : 0.f; s2 += ok ? v * v : 0.f;
+        }
     }
     if (p.stats == nullptr) return;                             // kernel-uniform
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); // the two half-waves hold the other rows of the same column
@@ -111,6 +123,32 @@ __device__ __forceinline__ void fwd_epilogue(const f32x16 (&acc)[TM], const Conv
         for (int g = 0; g < WM; ++g) { a += red[g * BNt + t]; b += red[(WM + g) * BNt + t]; }
         float* o = p.stats + (long)blockIdx.x * 2 * p.Cout;
         o[n0 + t] = a; o[p.Cout + n0 + t] = b;
+    }
+}
+// dgrad epilogue: dx = acc, dx += acc (accumulate: the old values are fetched first, 16 independent loads) or split-K atomics
+// (dx zeroed by the launcher unless accumulating).
+template <int WM, int WN, int TM>
+__device__ __forceinline__ void dgrad_epilogue(const f32x16 (&acc)[TM], const DgradP& p, unsigned M, unsigned m0, int n0, int wm,
+                                               int wn, int lane) {
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col >= p.Cin) return;
+    const bool rmw = p.accumulate && p.splitk <= 1;                 // kernel-uniform
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            old[r] = rmw ? p.dx[(long)min(row, M - 1) * p.Cin + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row >= M) continue;
+            float* d = p.dx + (long)row * p.Cin + col;
+            if (p.splitk > 1) atomicAdd(d, acc[tm][r]);
+            else *d = rmw ? old[r] + acc[tm][r] : acc[tm][r];
+        }
     }
 }
 // q = m / d with magic = ceil(2^32 / d) (exact for m * d < 2^32; d == 1 handled explicitly)
@@ -576,18 +614,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_kernel(DgradP p) {
         mma_tile<WM, WN, TM, BK, T::LDA, T::LDB>(acc, As, Bs, wm, wn, lane);
         __syncthreads();
     }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cin) return;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= M) continue;
-            float* d = p.dx + (long)row * p.Cin + col;
-            if (p.splitk > 1) atomicAdd(d, acc[tm][r]);                 // dx zeroed by the launcher unless accumulating
-            else *d = p.accumulate ? (*d + acc[tm][r]) : acc[tm][r];
-        }
+    dgrad_epilogue<WM, WN, TM>(acc, p, M, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------ dgrad, bf16x3 split-precision MFMA (see conv_fwd_x3_kernel)
@@ -721,18 +748,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
             if (kt >= nkt) break;
         }
     }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col >= p.Cin) return;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row >= M) continue;
-            float* d = p.dx + (long)row * p.Cin + col;
-            if (p.splitk > 1) atomicAdd(d, acc[tm][r]);
-            else *d = p.accumulate ? (*d + acc[tm][r]) : acc[tm][r];
-        }
+    dgrad_epilogue<WM, WN, TM>(acc, p, M, m0, n0, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------ wgrad
