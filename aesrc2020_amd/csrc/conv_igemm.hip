@@ -344,13 +344,28 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;       // 16-byte opaque copy (HIP's uint4 struct defeats SROA inside the register sets)
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// x = hi + lo on register pairs: v_cvt_pk_bf16_f32 (RNE), two bit operations to widen hi again, v_pk_add_f32, v_cvt_pk_bf16_f32
+// -- 2.5 instructions per value (element-wise code compiled to one conversion per value plus packing moves: ~4)
+__device__ __forceinline__ void split2(const f32x2 v, bf16x2& hi, bf16x2& lo) {
+    hi = __builtin_convertvector(v, bf16x2);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), bf16x2);
+}
 __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
-    const float f[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 h = (__bf16)f[j];
-        hi[j] = h; lo[j] = (__bf16)(f[j] - (float)h);
-    }
+    bf16x2 h0, l0, h1, l1;
+    split2(f32x2{v.x, v.y}, h0, l0); split2(f32x2{v.z, v.w}, h1, l1);
+    hi = bf16x4{h0[0], h0[1], h1[0], h1[1]}; lo = bf16x4{l0[0], l0[1], l1[0], l1[1]};
+}
+// BN+ReLU prologue of one float4 with the padding mask folded in as a multiplication by 0 / 1 (packed fp32 math: v_pk_fma_f32,
+// v_pk_mul_f32 handle two channels per instruction); relu_lo = -inf makes it the identity
+__device__ __forceinline__ float4 bn_relu_mask4(const float4 q, const float4 sc, const float4 sh, float relu_lo, bool ok) {
+    const float okf = ok ? 1.f : 0.f;
+    f32x2 a = __builtin_elementwise_fma(f32x2{q.x, q.y}, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});
+    f32x2 b = __builtin_elementwise_fma(f32x2{q.z, q.w}, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
+    a = f32x2{fmaxf(a.x, relu_lo), fmaxf(a.y, relu_lo)} * f32x2{okf, okf};
+    b = f32x2{fmaxf(b.x, relu_lo), fmaxf(b.y, relu_lo)} * f32x2{okf, okf};
+    return make_float4(a.x, a.y, b.x, b.y);
 }
 
 // WP: the weights arrive pre-split (sar_conv_weight_split_bf16, once per step): the B tile is staged with two 16-byte copies
@@ -431,11 +446,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int r = (tid + i * NT) / KQ;
-            const bool ok = (R.vmask >> i) & 1u;                      // selects, no branches; padding stays exactly zero
-            const float4 q = R.ra[i];
-            float4 v;
-            v.x = ok ? fmaxf(fmaf(q.x, R.sc.x, R.sh.x), relu_lo) : 0.f; v.y = ok ? fmaxf(fmaf(q.y, R.sc.y, R.sh.y), relu_lo) : 0.f;
-            v.z = ok ? fmaxf(fmaf(q.z, R.sc.z, R.sh.z), relu_lo) : 0.f; v.w = ok ? fmaxf(fmaf(q.w, R.sc.w, R.sh.w), relu_lo) : 0.f;
+            // no branches; padding is multiplied by 0 after the ReLU and stays exactly zero
+            const float4 v = bn_relu_mask4(R.ra[i], R.sc, R.sh, relu_lo, (R.vmask >> i) & 1u);
             bf16x4 hi, lo; split4(v, hi, lo);
             *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
@@ -961,36 +973,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
             Rg.vmask |= ((m < r_end ? 1u : 0u) & live) << (8 + i);
         }
     };
-    auto split_store = [&](const float (&v)[4][4], __bf16 (*Hh)[BKP], __bf16 (*Ll)[BKP], int c0, int r0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                                 // transpose: channel j gets its 4 consecutive rows
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const __bf16 h = (__bf16)v[i][j]; hi[i] = h; lo[i] = (__bf16)(v[i][j] - (float)h); }
-            *reinterpret_cast<bf16x4*>(&Hh[c0 + j][r0]) = hi; *reinterpret_cast<bf16x4*>(&Ll[c0 + j][r0]) = lo;
-        }
-    };
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 sc01 = {asc.x, asc.y}, sc23 = {asc.z, asc.w}, sh01 = {ash.x, ash.y}, sh23 = {ash.z, ash.w};
     auto store = [&](const Regs& Rg, int buf) {
         {
+            // packed fp32 math throughout: BN on channel pairs (v_pk_fma_f32), ReLU, then ROW pairs of one channel -- the unit of
+            // the transposed LDS layout -- are masked (x 0/1: padding stays exactly zero) and split (split2) two values at a time
             float v[4][4];                                            // [row i][channel j]
+            float okf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32: two channels per instruction); padding rows are multiplied
-                // by 0 after the ReLU, so they stay exactly zero
-                const float okf = ((Rg.vmask >> i) & 1u) ? 1.f : 0.f;
+                okf[i] = ((Rg.vmask >> i) & 1u) ? 1.f : 0.f;
                 const float4 q = Rg.ra[i];
-                f32x2 u01 = {q.x, q.y}, u23 = {q.z, q.w};
-                u01 = __builtin_elementwise_fma(u01, sc01, sh01); u23 = __builtin_elementwise_fma(u23, sc23, sh23);
+                const f32x2 u01 = __builtin_elementwise_fma(f32x2{q.x, q.y}, sc01, sh01);
+                const f32x2 u23 = __builtin_elementwise_fma(f32x2{q.z, q.w}, sc23, sh23);
                 v[i][0] = fmaxf(u01.x, relu_lo); v[i][1] = fmaxf(u01.y, relu_lo);
                 v[i][2] = fmaxf(u23.x, relu_lo); v[i][3] = fmaxf(u23.y, relu_lo);
-                f32x2 w01 = {v[i][0], v[i][1]}, w23 = {v[i][2], v[i][3]};
-                const f32x2 ok2 = {okf, okf};
-                w01 *= ok2; w23 *= ok2;
-                v[i][0] = w01.x; v[i][1] = w01.y; v[i][2] = w23.x; v[i][3] = w23.y;
             }
-            split_store(v, Ah[buf], Al[buf], a_c4 * 4, a_r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                             // channel j gets its 4 consecutive rows
+                bf16x2 h01, l01, h23, l23;
+                split2(f32x2{v[0][j], v[1][j]} * f32x2{okf[0], okf[1]}, h01, l01);
+                split2(f32x2{v[2][j], v[3][j]} * f32x2{okf[2], okf[3]}, h23, l23);
+                *reinterpret_cast<bf16x4*>(&Ah[buf][a_c4 * 4 + j][a_r]) = bf16x4{h01[0], h01[1], h23[0], h23[1]};
+                *reinterpret_cast<bf16x4*>(&Al[buf][a_c4 * 4 + j][a_r]) = bf16x4{l01[0], l01[1], l23[0], l23[1]};
+            }
         }
         {
             float v[BR][4];
@@ -1006,11 +1012,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                             // channel j gets its BR consecutive rows
-                typedef __bf16 bf16xr __attribute__((ext_vector_type(BR)));
-                bf16xr hi, lo;
-#pragma unroll
-                for (int i = 0; i < BR; ++i) { const __bf16 h = (__bf16)v[i][j]; hi[i] = h; lo[i] = (__bf16)(v[i][j] - (float)h); }
-                *reinterpret_cast<bf16xr*>(&Bh[buf][b_c4 * 4 + j][b_r]) = hi; *reinterpret_cast<bf16xr*>(&Bl[buf][b_c4 * 4 + j][b_r]) = lo;
+                if constexpr (BR == 2) {
+                    bf16x2 hi, lo; split2(f32x2{v[0][j], v[1][j]}, hi, lo);
+                    *reinterpret_cast<bf16x2*>(&Bh[buf][b_c4 * 4 + j][b_r]) = hi; *reinterpret_cast<bf16x2*>(&Bl[buf][b_c4 * 4 + j][b_r]) = lo;
+                } else {
+                    const __bf16 h = (__bf16)v[0][j];
+                    Bh[buf][b_c4 * 4 + j][b_r] = h; Bl[buf][b_c4 * 4 + j][b_r] = (__bf16)(v[0][j] - (float)h);
+                }
             }
         }
     };
