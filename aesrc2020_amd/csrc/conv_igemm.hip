@@ -417,8 +417,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     struct Regs { float4 ra[NA]; float rb[WP ? 1 : KPT]; u32x4 wh, wl; float4 sc, sh; unsigned vmask; };
     Regs R0, R1;                                                      // two sets: prefetch distance of two k-tiles
     R0.sc = R1.sc = make_float4(1, 1, 1, 1); R0.sh = R1.sh = zero4(); R0.vmask = R1.vmask = 0;
+    const int nkt_all = K / BK, per = ((nkt_all + p.splitk - 1) / p.splitk + 1) & ~1;   // split-K slices of whole tile pairs
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per), last = nkt - 1;
+    // kt may run past the block's last k-tile: such a tile re-reads the last one (clamped, branch-free) and stages an
+    // all-zero A tile (`live`), so the loop below needs no conditional half
     auto load = [&](Regs& R, int kt) {
-        const int k0 = kt * BK;
+        const unsigned live = kt <= last ? 1u : 0u;
+        const int k0 = min(kt, last) * BK;
         const int tap = k0 / p.Cin, ci0 = k0 - tap * p.Cin;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int tapoff = (kh * p.W + kw) * p.Cin + ci0;
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
         R.vmask = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const unsigned ok = (avalid[i] >> tap) & 1u;
+            const unsigned ok = (avalid[i] >> tap) & live;
             const int off = ok ? abase[i] + tapoff : 0;
             R.ra[i] = *reinterpret_cast<const float4*>(p.x + off);
             R.vmask |= ok << i;
@@ -481,8 +486,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
-    const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
     const int kg = (lane >> 5) * 8, rc = lane & 31;
     auto mma = [&](int cur) {
 #pragma unroll
@@ -504,22 +507,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     // written to the idle LDS buffer, then that set is re-filled with tile kt+3.  Clamped tile indices keep the tail branch-free.
     TSTAMP(2);
     if (kt0 < nkt) {
-        const int last = nkt - 1;
-        load(R0, kt0); load(R1, min(kt0 + 1, last));
+        load(R0, kt0); load(R1, kt0 + 1);
         TSTAMP(3);
-        store(R0, 0); load(R0, min(kt0 + 2, last));
+        store(R0, 0); load(R0, kt0 + 2);
         __syncthreads();
         TSTAMP(4);
-        // two explicit exits (not `if (more) { second half }`): keeps the s_waitcnt counts of the first half from
-        // collapsing to vmcnt(0) on the phantom path first half -> first half
-        for (int kt = kt0;;) {
-            mma(0); store(R1, 1); load(R1, min(kt + 3, last));
+        // Straight-line two-half body, no exit between the halves (an odd tile count runs one all-zero half): any conditional
+        // half leaves a structurizer edge first half -> first half in the CFG, and on that phantom path the register set
+        // consumed by the first half holds the NEWEST loads -- its waits became vmcnt(3..0), draining the prefetch of the
+        // other set in every iteration.
+        for (int kt = kt0; kt < nkt; kt += 2) {
+            mma(0); store(R1, 1); load(R1, kt + 3);
             __syncthreads();
-            if (kt + 1 >= nkt) break;
-            mma(1); store(R0, 0); load(R0, min(kt + 4, last));
+            mma(1); store(R0, 0); load(R0, kt + 4);
             __syncthreads();
-            kt += 2;
-            if (kt >= nkt) break;
         }
     }
     TSTAMP(5);
@@ -681,14 +682,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
     const bool wp_ok = n0 + (tid >> 2) < p.Cin;
     struct Regs { float4 ra[NA]; float4 rb[WP ? 1 : KPT / 4]; u32x4 wh, wl; unsigned vmask; };
     Regs R0, R1; R0.vmask = R1.vmask = 0;
-    auto load = [&](Regs& R, int kt) {
-        const int k0 = kt * BK;
+    const int nkt_all = K / BK, per = ((nkt_all + p.splitk - 1) / p.splitk + 1) & ~1;   // split-K slices of whole tile pairs
+    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per), last = nkt - 1;
+    auto load = [&](Regs& R, int kt) {                               // kt past the last tile: zero A tile (see the forward kernel)
+        const unsigned live = kt <= last ? 1u : 0u;
+        const int k0 = min(kt, last) * BK;
         const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         R.vmask = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const unsigned ok = (avalid[i] >> tap) & 1u;
+            const unsigned ok = (avalid[i] >> tap) & live;
             const int dh = p.stride == 1 ? kh : ((kh - aph[i]) >> 1), dw = p.stride == 1 ? kw : ((kw - apw[i]) >> 1);
             const int off = ok ? abase[i] - (dh * p.Wo + dw) * p.Cout + co0 : 0;
             R.ra[i] = *reinterpret_cast<const float4*>(p.dy + off);
@@ -727,8 +731,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
-    const int nkt_all = K / BK, per = (nkt_all + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.z * per, nkt = min(nkt_all, kt0 + per);
     const int kg = (lane >> 5) * 8, rc = lane & 31;
     auto mma = [&](int cur) {
 #pragma unroll
@@ -746,18 +748,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
         }
     };
     if (kt0 < nkt) {
-        const int last = nkt - 1;
-        load(R0, kt0); load(R1, min(kt0 + 1, last));
-        store(R0, 0); load(R0, min(kt0 + 2, last));
+        load(R0, kt0); load(R1, kt0 + 1);
+        store(R0, 0); load(R0, kt0 + 2);
         __syncthreads();
-        for (int kt = kt0;;) {                                           // two explicit exits: see the forward kernel
-            mma(0); store(R1, 1); load(R1, min(kt + 3, last));
+        for (int kt = kt0; kt < nkt; kt += 2) {                        // straight-line halves: see the forward kernel
+            mma(0); store(R1, 1); load(R1, kt + 3);
             __syncthreads();
-            if (kt + 1 >= nkt) break;
-            mma(1); store(R0, 0); load(R0, min(kt + 4, last));
+            mma(1); store(R0, 0); load(R0, kt + 4);
             __syncthreads();
-            kt += 2;
-            if (kt >= nkt) break;
         }
     }
     dgrad_epilogue<WM, WN, TM>(acc, p, M, m0, n0, wm, wn, lane);
@@ -1146,7 +1144,7 @@ struct ConvKnobs { bool no_splitk; int splitk_cap, wgrad_blocks, x3_narrow; };
 static const ConvKnobs& conv_knobs() {
     static const ConvKnobs k{getenv("SAR_NO_SPLITK") != nullptr, getenv("SAR_SPLITK_CAP") ? atoi(getenv("SAR_SPLITK_CAP")) : 4,
                              getenv("SAR_WGRAD_BLOCKS") ? atoi(getenv("SAR_WGRAD_BLOCKS")) : 0,
-                             getenv("SAR_X3_NARROW") ? atoi(getenv("SAR_X3_NARROW")) : 2};
+                             getenv("SAR_X3_NARROW") ? atoi(getenv("SAR_X3_NARROW")) : 6};
     return k;
 }
 #ifdef SAR_TIMING
@@ -1389,7 +1387,7 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     const int tiles = cdiv(Mp, 128) * cdiv(Cout, narrow ? 32 : 64);
     // measured (tools/conv_bench.py): the split-precision kernel (2 blocks/CU, atomic epilogue) is best at ~384 blocks,
     // the fp32 kernel (6 blocks/CU) at ~1024
-    // Cout <= 32 keeps the fp32 kernel (measured: 48 vs 55 us); SAR_X3_NARROW bit 2 switches it for experiments
+    // Cout <= 32: the split-precision kernel too since its k-tile double buffering (SAR_X3_NARROW bit 2; default on)
     const bool x3_narrow = (conv_knobs().x3_narrow & 4) != 0;
     const bool x3 = g_conv_math == 1 && (!narrow || x3_narrow);
     const int target = conv_knobs().wgrad_blocks ? conv_knobs().wgrad_blocks : (x3 ? 384 : 1024);
