@@ -11,39 +11,73 @@
 namespace {
 
 constexpr int GR = 2;    // batch rows per workgroup
-constexpr int NW = 16;   // waves per workgroup = k-slices of the reduction
+constexpr int NW = 8;    // waves per workgroup = k-slices of the reduction (512 threads: 256 VGPRs per thread)
 // v3 mapping (H % 4 == 0, H <= 256): lane owns 4 consecutive hidden units (float4 loads of U rows: 1 KB per wave
 // instruction instead of 256 B), wave w owns the k-slice [w*H/16, (w+1)*H/16).  The recurrence is bound by how fast one
 // CU can stream the 3*H*H recurrent kernel from L2 every step, so bytes per load instruction and loads in flight matter,
 // not FLOPs.  Partial sums go through LDS: part[NW][GR*12][64] -> red[GR][3][H] -> gate math -> hs[GR][H].
+// v4: one third of that stream is taken out of the loop -- every thread keeps the candidate-gate rows of its k-slice
+// (forward: U[k][2H + 4*lane ..], backward: the first KRES rows of its UT slice) in registers for all L steps: KRES float4 =
+// 128 of the 256 VGPRs a 512-thread workgroup allows, 256 KB of the 786 KB per CU (with 1024 threads and a 128-register
+// budget the compiler spilled).  The operands of the gate math that do not depend on the recurrence (xa; gates / hprev /
+// dout in BPTT) are fetched ahead of the streaming phase instead of after it.
+constexpr int KRES = 32;  // resident rows per thread (= H/NW at H = 256)
 
 __device__ __forceinline__ void fma4(float4& a, float h, const float4& u) {
     a.x = fmaf(h, u.x, a.x); a.y = fmaf(h, u.y, a.y); a.z = fmaf(h, u.z, a.z); a.w = fmaf(h, u.w, a.w);
 }
 
 // dynamic LDS: hs[GR][H] | red[GR][3][H] | part[NW][GR*12][64]
-__global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
+template <bool RES>                                                // RES: H == KRES * NW, the k-slices are exactly KRES rows
+__global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
                                const float* __restrict__ U_f, const float* __restrict__ U_b,
                                const float* __restrict__ bh_f, const float* __restrict__ bh_b,
                                float* __restrict__ out, float* __restrict__ gates, float* __restrict__ hprev, int B,
                                int L, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* hs = sm; float* red = hs + GR * H; float* part = red + GR * 3 * H;
-    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b0 = blockIdx.x * GR;
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, b0 = blockIdx.x * GR;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: row addresses of the U stream stay in SGPRs
     const float* xa = d ? xa_b : xa_f; const float* U = d ? U_b : U_f; const float* bh = d ? bh_b : bh_f;
     const int H3 = 3 * H, H4 = H / 4;
     const int kper = (H + NW - 1) / NW, k0 = w * kper, k1 = min(H, k0 + kper);
     const bool lane_ok = lane < H4;
     for (int i = tid; i < GR * H; i += blockDim.x) hs[i] = 0.f;
+    float4 uq[RES ? KRES : 1];                                        // resident candidate-gate rows
+    if constexpr (RES) {
+#pragma unroll
+        for (int kk = 0; kk < KRES; ++kk) uq[kk] = *reinterpret_cast<const float4*>(U + (long)(k0 + kk) * H3 + 2 * H + lane * 4);
+    }
     __syncthreads();
     float* g_d = gates + (long)d * B * L * 4 * H;
     float* hp_d = hprev + (long)d * B * L * H;
+    // gate-math ownership: thread tid < GR*H handles (row gr, unit gj) -- one output per thread (GR*H <= blockDim)
+    const int gr = tid / H, gj = tid - gr * H, gb = b0 + gr;
+    const bool gate_thread = tid < GR * H && gb < B;
     for (int s = 0; s < L; ++s) {
         const int t = d ? (L - 1 - s) : s;
+        float xz = 0.f, xr = 0.f, xh = 0.f;                           // input projections of this step: in flight under the stream
+        if (gate_thread) {
+            const long xo = ((long)gb * L + t) * H3;
+            xz = xa[xo + gj]; xr = xa[xo + H + gj]; xh = xa[xo + 2 * H + gj];
+        }
         float4 az[GR], ar[GR], aq[GR];
 #pragma unroll
         for (int r = 0; r < GR; ++r) { az[r] = make_float4(0, 0, 0, 0); ar[r] = az[r]; aq[r] = az[r]; }
-        if (lane_ok) {
+        if constexpr (RES) {                                         // H == 256: every lane owns 4 units, every slice is KRES rows
+            int opq = 0;
+            asm volatile("" : "+s"(opq));                             // opaque 0: keeps the 64 row addresses of the unrolled loop from
+            const float* Us = U + opq;                                // being hoisted out of the time loop as 128 live (spilled) VGPRs
+#pragma unroll
+            for (int kk = 0; kk < KRES; ++kk) {                       // fully unrolled (uq[] must stay in registers) ...
+                if (kk % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // ... but loads are batched four rows at a time, not all 64
+                const int k = k0 + kk;
+                const float* ur = Us + (long)k * H3 + lane * 4;
+                const float4 u0 = *reinterpret_cast<const float4*>(ur), u1 = *reinterpret_cast<const float4*>(ur + H);
+#pragma unroll
+                for (int r = 0; r < GR; ++r) { const float hv = hs[r * H + k]; fma4(az[r], hv, u0); fma4(ar[r], hv, u1); fma4(aq[r], hv, uq[kk]); }
+            }
+        } else if (lane_ok) {
 #pragma unroll 4
             for (int k = k0; k < k1; ++k) {
                 const float* ur = U + (long)k * H3 + lane * 4;
@@ -71,22 +105,19 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
             red[o] = sum + bh[g * H + jj];
         }
         __syncthreads();
-        for (int o = tid; o < GR * H; o += blockDim.x) {
-            const int r = o / H, jj = o - r * H, b = b0 + r;
-            if (b < B) {
-                const long xo = ((long)b * L + t) * H3;
-                const float hold = hs[o];
-                const float q = red[r * H3 + 2 * H + jj];
-                const float z = sigmoidf_(xa[xo + jj] + red[r * H3 + jj]);
-                const float rr = sigmoidf_(xa[xo + H + jj] + red[r * H3 + H + jj]);
-                const float hh = tanhf(xa[xo + 2 * H + jj] + rr * q);
-                const float hn = z * hold + (1.f - z) * hh;
-                const long go = (((long)b * L + t) * 4) * H;
-                g_d[go + jj] = z; g_d[go + H + jj] = rr; g_d[go + 2 * H + jj] = hh; g_d[go + 3 * H + jj] = q;
-                hp_d[((long)b * L + t) * H + jj] = hold;
-                out[((long)b * L + t) * 2 * H + d * H + jj] = hn;
-                hs[o] = hn;
-            }
+        if (gate_thread) {
+            const int r = gr, jj = gj, o = tid, b = gb;
+            const float hold = hs[o];
+            const float q = red[r * H3 + 2 * H + jj];
+            const float z = sigmoidf_(xz + red[r * H3 + jj]);
+            const float rr = sigmoidf_(xr + red[r * H3 + H + jj]);
+            const float hh = tanhf(xh + rr * q);
+            const float hn = z * hold + (1.f - z) * hh;
+            const long go = (((long)b * L + t) * 4) * H;
+            g_d[go + jj] = z; g_d[go + H + jj] = rr; g_d[go + 2 * H + jj] = hh; g_d[go + 3 * H + jj] = q;
+            hp_d[((long)b * L + t) * H + jj] = hold;
+            out[((long)b * L + t) * 2 * H + d * H + jj] = hn;
+            hs[o] = hn;
         }
         __syncthreads();
     }
@@ -94,14 +125,16 @@ __global__ __launch_bounds__(1024) void gru_fwd_kernel(const float* __restrict__
 
 // BPTT.  UT = transpose(U): (3H, H).  dai/dah: (2, B, L, 3H) input-side / recurrent-side pre-activation grads.
 // dynamic LDS: ds[GR][3H] | dhs[GR][H] | zs[GR][H] | part[NW][GR*4][64]
-__global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
+template <bool RES>                                                // RES: H == 256, UT slices of 3 * KRES rows
+__global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
                                const float* __restrict__ hprev, const float* __restrict__ UT_f,
                                const float* __restrict__ UT_b, float* __restrict__ dai, float* __restrict__ dah, int B,
                                int L, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H3 = 3 * H, H4 = H / 4;
     float* ds = sm; float* dhs = ds + GR * H3; float* zs = dhs + GR * H; float* part = zs + GR * H;
-    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b0 = blockIdx.x * GR;
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, b0 = blockIdx.x * GR;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: row addresses of the U stream stay in SGPRs
     const float* UT = d ? UT_b : UT_f;
     const int cper = (H3 + NW - 1) / NW, c0 = w * cper, c1 = min(H3, c0 + cper);
     const bool lane_ok = lane < H4;
@@ -109,18 +142,39 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
     const float* hp_d = hprev + (long)d * B * L * H;
     float* dai_d = dai + (long)d * B * L * H3; float* dah_d = dah + (long)d * B * L * H3;
     for (int i = tid; i < GR * H; i += blockDim.x) dhs[i] = 0.f;
+    float4 ures[RES ? KRES : 1];                                      // resident: the first KRES rows of this wave's UT slice
+    if constexpr (RES) {
+#pragma unroll
+        for (int cc = 0; cc < KRES; ++cc) ures[cc] = *reinterpret_cast<const float4*>(UT + (long)(c0 + cc) * H + lane * 4);
+    }
     __syncthreads();
+    // gate backward ownership: thread tid < GR*H handles (row gr, unit gj); its saved activations for step s-1 are fetched
+    // while step s streams UT
+    const int gr = tid / H, gj = tid - gr * H, gb = b0 + gr;
+    const bool gate_thread = tid < GR * H && gb < B;
+    struct Saved { float z, rr, hh, q, hp, dy; };
+    auto fetch = [&](int s) {
+        Saved v{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (gate_thread && s >= 0) {
+            const int t = d ? (L - 1 - s) : s;
+            const long go = (((long)gb * L + t) * 4) * H;
+            v.z = g_d[go + gj]; v.rr = g_d[go + H + gj]; v.hh = g_d[go + 2 * H + gj]; v.q = g_d[go + 3 * H + gj];
+            v.hp = hp_d[((long)gb * L + t) * H + gj];
+            v.dy = dout[((long)gb * L + t) * 2 * H + d * H + gj];
+        }
+        return v;
+    };
+    Saved nxt = fetch(L - 1);
     for (int s = L - 1; s >= 0; --s) {
         const int t = d ? (L - 1 - s) : s;
-        for (int o = tid; o < GR * H; o += blockDim.x) {            // gate backward for (row r, unit jj)
-            const int r = o / H, jj = o - r * H, b = b0 + r;
+        const Saved cur = nxt;
+        if (tid < GR * H) {                                          // gate backward for (row r, unit jj)
+            const int r = gr, jj = gj, o = tid, b = gb;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, z = 0.f, g = 0.f;
             if (b < B) {
-                const long go = (((long)b * L + t) * 4) * H;
-                z = g_d[go + jj];
-                const float rr = g_d[go + H + jj], hh = g_d[go + 2 * H + jj], q = g_d[go + 3 * H + jj];
-                const float hp = hp_d[((long)b * L + t) * H + jj];
-                g = dhs[o] + dout[((long)b * L + t) * 2 * H + d * H + jj];
+                z = cur.z;
+                const float rr = cur.rr, hh = cur.hh, q = cur.q, hp = cur.hp;
+                g = dhs[o] + cur.dy;
                 const float da_h = g * (1.f - z) * (1.f - hh * hh);
                 const float da_z = g * (hp - hh) * z * (1.f - z);
                 const float da_r = da_h * q * rr * (1.f - rr);
@@ -133,15 +187,24 @@ __global__ __launch_bounds__(1024) void gru_bwd_kernel(const float* __restrict__
             dhs[o] = g; zs[o] = z;
         }
         __syncthreads();
+        nxt = fetch(s - 1);
         float4 acc[GR];
 #pragma unroll
         for (int r = 0; r < GR; ++r) acc[r] = make_float4(0, 0, 0, 0);
         if (lane_ok) {
 #pragma unroll 4
-            for (int c = c0; c < c1; ++c) {
+            for (int c = c0 + (RES ? KRES : 0); c < c1; ++c) {        // streamed rows
                 const float4 u = *reinterpret_cast<const float4*>(UT + (long)c * H + lane * 4);
 #pragma unroll
                 for (int r = 0; r < GR; ++r) fma4(acc[r], ds[r * H3 + c], u);
+            }
+            if constexpr (RES) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < KRES; ++cc) {                   // resident rows
+#pragma unroll
+                    for (int r = 0; r < GR; ++r) fma4(acc[r], ds[r * H3 + c0 + cc], ures[cc]);
+                }
             }
         }
 #pragma unroll
@@ -190,9 +253,18 @@ extern "C" int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const
     if (H > 256 || H % 4) return SAR_EINVAL;
     const size_t lds = sizeof(float) * (GR * H + GR * 3 * H + NW * GR * 12 * 64);
     static bool attr_f = false;
-    if (!attr_f) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH; attr_f = true; }
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
-                       xa_fwd, xa_bwd, U_fwd, U_bwd, bh_fwd, bh_bwd, out, gates, hprev, B, L, H);
+    if (!attr_f) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return SAR_ELAUNCH;
+        attr_f = true;
+    }
+    if (H == KRES * NW)
+        hipLaunchKernelGGL(gru_fwd_kernel<true>, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
+                           xa_fwd, xa_bwd, U_fwd, U_bwd, bh_fwd, bh_bwd, out, gates, hprev, B, L, H);
+    else
+        hipLaunchKernelGGL(gru_fwd_kernel<false>, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
+                           xa_fwd, xa_bwd, U_fwd, U_bwd, bh_fwd, bh_bwd, out, gates, hprev, B, L, H);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -202,8 +274,12 @@ extern "C" int sar_bigru_bwd_f32(const float* dout, const float* gates, const fl
     if (!dout || !gates || !hprev || !UT_fwd || !UT_bwd || !dai || !dah || H < 1 || H > 1024) return SAR_EINVAL;
     if (H > 256 || H % 4) return SAR_EINVAL;
     const size_t lds = sizeof(float) * (GR * 3 * H + 2 * GR * H + NW * GR * 4 * 64);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
-                       dout, gates, hprev, UT_fwd, UT_bwd, dai, dah, B, L, H);
+    if (H == KRES * NW)
+        hipLaunchKernelGGL(gru_bwd_kernel<true>, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
+                           dout, gates, hprev, UT_fwd, UT_bwd, dai, dah, B, L, H);
+    else
+        hipLaunchKernelGGL(gru_bwd_kernel<false>, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
+                           dout, gates, hprev, UT_fwd, UT_bwd, dai, dah, B, L, H);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
