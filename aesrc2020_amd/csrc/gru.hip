@@ -22,6 +22,7 @@ constexpr int NW = 8;    // waves per workgroup = k-slices of the reduction (512
 // budget the compiler spilled).  The operands of the gate math that do not depend on the recurrence (xa; gates / hprev /
 // dout in BPTT) are fetched ahead of the streaming phase instead of after it.
 constexpr int KRES = 32;  // resident rows per thread (= H/NW at H = 256)
+constexpr int XRES = 12;  // further resident rows (forward: of the reset gate; backward: rows KRES.. of the slice): what is left of 256 VGPRs
 
 __device__ __forceinline__ void fma4(float4& a, float h, const float4& u) {
     a.x = fmaf(h, u.x, a.x); a.y = fmaf(h, u.y, a.y); a.z = fmaf(h, u.z, a.z); a.w = fmaf(h, u.w, a.w);
@@ -43,10 +44,12 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     const int kper = (H + NW - 1) / NW, k0 = w * kper, k1 = min(H, k0 + kper);
     const bool lane_ok = lane < H4;
     for (int i = tid; i < GR * H; i += blockDim.x) hs[i] = 0.f;
-    float4 uq[RES ? KRES : 1];                                        // resident candidate-gate rows
+    float4 uq[RES ? KRES : 1], ux[RES ? XRES : 1];                    // resident candidate-gate rows (+ XRES reset-gate rows)
     if constexpr (RES) {
 #pragma unroll
         for (int kk = 0; kk < KRES; ++kk) uq[kk] = *reinterpret_cast<const float4*>(U + (long)(k0 + kk) * H3 + 2 * H + lane * 4);
+#pragma unroll
+        for (int kk = 0; kk < XRES; ++kk) ux[kk] = *reinterpret_cast<const float4*>(U + (long)(k0 + kk) * H3 + H + lane * 4);
     }
     __syncthreads();
     float* g_d = gates + (long)d * B * L * 4 * H;
@@ -73,7 +76,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                 if (kk % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // ... but loads are batched four rows at a time, not all 64
                 const int k = k0 + kk;
                 const float* ur = Us + (long)k * H3 + lane * 4;
-                const float4 u0 = *reinterpret_cast<const float4*>(ur), u1 = *reinterpret_cast<const float4*>(ur + H);
+                const float4 u0 = *reinterpret_cast<const float4*>(ur);
+                float4 u1;
+                if (kk < XRES) u1 = ux[kk < XRES ? kk : 0]; else u1 = *reinterpret_cast<const float4*>(ur + H);
 #pragma unroll
                 for (int r = 0; r < GR; ++r) { const float hv = hs[r * H + k]; fma4(az[r], hv, u0); fma4(ar[r], hv, u1); fma4(aq[r], hv, uq[kk]); }
             }
@@ -142,10 +147,11 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     const float* hp_d = hprev + (long)d * B * L * H;
     float* dai_d = dai + (long)d * B * L * H3; float* dah_d = dah + (long)d * B * L * H3;
     for (int i = tid; i < GR * H; i += blockDim.x) dhs[i] = 0.f;
-    float4 ures[RES ? KRES : 1];                                      // resident: the first KRES rows of this wave's UT slice
+    constexpr int BRES = KRES + XRES;
+    float4 ures[RES ? BRES : 1];                                      // resident: the first BRES rows of this wave's UT slice
     if constexpr (RES) {
 #pragma unroll
-        for (int cc = 0; cc < KRES; ++cc) ures[cc] = *reinterpret_cast<const float4*>(UT + (long)(c0 + cc) * H + lane * 4);
+        for (int cc = 0; cc < BRES; ++cc) ures[cc] = *reinterpret_cast<const float4*>(UT + (long)(c0 + cc) * H + lane * 4);
     }
     __syncthreads();
     // gate backward ownership: thread tid < GR*H handles (row gr, unit gj); its saved activations for step s-1 are fetched
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         for (int r = 0; r < GR; ++r) acc[r] = make_float4(0, 0, 0, 0);
         if (lane_ok) {
 #pragma unroll 4
-            for (int c = c0 + (RES ? KRES : 0); c < c1; ++c) {        // streamed rows
+            for (int c = c0 + (RES ? BRES : 0); c < c1; ++c) {        // streamed rows
                 const float4 u = *reinterpret_cast<const float4*>(UT + (long)c * H + lane * 4);
 #pragma unroll
                 for (int r = 0; r < GR; ++r) fma4(acc[r], ds[r * H3 + c], u);
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
             if constexpr (RES) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int cc = 0; cc < KRES; ++cc) {                   // resident rows
+                for (int cc = 0; cc < BRES; ++cc) {                   // resident rows
 #pragma unroll
                     for (int r = 0; r < GR; ++r) fma4(acc[r], ds[r * H3 + c0 + cc], ures[cc]);
                 }
