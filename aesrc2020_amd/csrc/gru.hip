@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
 }
 
 // BPTT.  UT = transpose(U): (3H, H).  dai/dah: (2, B, L, 3H) input-side / recurrent-side pre-activation grads.
-// dynamic LDS: ds[GR][3H] | dhs[GR][H] | zs[GR][H] | part[NW][GR*4][64]
+// dynamic LDS: ds[GR][3H] | part[NW][GR][H]
 template <bool RES>                                                // RES: H == 256, UT slices of 3 * KRES rows
 __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
                                const float* __restrict__ hprev, const float* __restrict__ UT_f,
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                                int L, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H3 = 3 * H, H4 = H / 4;
-    float* ds = sm; float* dhs = ds + GR * H3; float* zs = dhs + GR * H; float* part = zs + GR * H;
+    float* ds = sm; float* part = ds + GR * H3;
     const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, b0 = blockIdx.x * GR;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: row addresses of the U stream stay in SGPRs
     const float* UT = d ? UT_b : UT_f;
@@ -146,7 +146,6 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
     const float* g_d = gates + (long)d * B * L * 4 * H;
     const float* hp_d = hprev + (long)d * B * L * H;
     float* dai_d = dai + (long)d * B * L * H3; float* dah_d = dah + (long)d * B * L * H3;
-    for (int i = tid; i < GR * H; i += blockDim.x) dhs[i] = 0.f;
     constexpr int BRES = KRES + XRES;
     float4 ures[RES ? BRES : 1];                                      // resident: the first BRES rows of this wave's UT slice
     if constexpr (RES) {
@@ -171,16 +170,18 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
         return v;
     };
     Saved nxt = fetch(L - 1);
+    float dh = 0.f;                                                   // dL/dh carried to the previous step, of this thread's (row, unit)
     for (int s = L - 1; s >= 0; --s) {
         const int t = d ? (L - 1 - s) : s;
         const Saved cur = nxt;
         if (tid < GR * H) {                                          // gate backward for (row r, unit jj)
-            const int r = gr, jj = gj, o = tid, b = gb;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, z = 0.f, g = 0.f;
+            const int r = gr, jj = gj, b = gb;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             if (b < B) {
-                z = cur.z;
+                const float z = cur.z;
                 const float rr = cur.rr, hh = cur.hh, q = cur.q, hp = cur.hp;
-                g = dhs[o] + cur.dy;
+                const float g = dh + cur.dy;
+                dh = g * z;                                           // the direct path; the recurrent-kernel path is added below
                 const float da_h = g * (1.f - z) * (1.f - hh * hh);
                 const float da_z = g * (hp - hh) * z * (1.f - z);
                 const float da_r = da_h * q * rr * (1.f - rr);
@@ -190,7 +191,6 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 dah_d[oo + jj] = a0; dah_d[oo + H + jj] = a1; dah_d[oo + 2 * H + jj] = a2;
             }
             ds[r * H3 + jj] = a0; ds[r * H3 + H + jj] = a1; ds[r * H3 + 2 * H + jj] = a2;
-            dhs[o] = g; zs[o] = z;
         }
         __syncthreads();
         nxt = fetch(s - 1);
@@ -213,21 +213,18 @@ __global__ __launch_bounds__(512) void gru_bwd_kernel(const float* __restrict__ 
                 }
             }
         }
+        // each wave's partial sums as float4 per lane (unit j at float index j: conflict-free 16-byte stores, consecutive-lane reads)
+        if (lane_ok) {
 #pragma unroll
-        for (int r = 0; r < GR; ++r) {
-            float* p = part + ((w * GR + r) * 4) * 64 + lane;
-            p[0] = acc[r].x; p[64] = acc[r].y; p[128] = acc[r].z; p[192] = acc[r].w;
+            for (int r = 0; r < GR; ++r) *reinterpret_cast<float4*>(part + (w * GR + r) * H + lane * 4) = acc[r];
         }
         __syncthreads();
-        for (int o = tid; o < GR * H; o += blockDim.x) {
-            const int r = o / H, jj = o - r * H;
-            const float* p = part + (r * 4 + (jj & 3)) * 64 + (jj >> 2);
-            float a = 0.f;
+        if (tid < GR * H) {                                          // same thread as the gate phase: dh stays in a register, and the
+            float a = 0.f;                                            // next gate phase needs no barrier in between
 #pragma unroll
-            for (int q = 0; q < NW; ++q) a += p[q * GR * 4 * 64];
-            dhs[o] = dhs[o] * zs[o] + a;
+            for (int q = 0; q < NW; ++q) a += part[(q * GR + gr) * H + gj];
+            dh += a;
         }
-        __syncthreads();
     }
 }
 
@@ -279,7 +276,7 @@ extern "C" int sar_bigru_bwd_f32(const float* dout, const float* gates, const fl
                                  const float* UT_bwd, float* dai, float* dah, int B, int L, int H, hipStream_t stream) {
     if (!dout || !gates || !hprev || !UT_fwd || !UT_bwd || !dai || !dah || H < 1 || H > 1024) return SAR_EINVAL;
     if (H > 256 || H % 4) return SAR_EINVAL;
-    const size_t lds = sizeof(float) * (GR * 3 * H + 2 * GR * H + NW * GR * 4 * 64);
+    const size_t lds = sizeof(float) * (GR * 3 * H + NW * GR * H);
     if (H == KRES * NW)
         hipLaunchKernelGGL(gru_bwd_kernel<true>, dim3(cdiv(B, GR), 2), dim3(64 * NW), lds, stream,
                            dout, gates, hprev, UT_fwd, UT_bwd, dai, dah, B, L, H);
