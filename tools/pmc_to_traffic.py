@@ -15,9 +15,9 @@ for line in open(src):
     m = re.match(r"\s+(\w+)\s+([0-9.]+)\s+\(n=(\d+)\)", line)
     if m and cur:
         vals.setdefault(cur, {})[m.group(1)] = (float(m.group(2)), int(m.group(3)))
-CLASS = [("conv_wgrad_x3_kernel<64>", "conv_wgrad_3x3_n64"), ("conv_fwd_x3_kernel<2, 2, 1, 32>", "conv_fwd_3x3_n64"),
-         ("conv_dgrad_x3_kernel<2, 2, 1, 32>", "conv_dgrad_3x3_n64"), ("conv_wgrad_kernel<4, 1, 1, 32>", "conv_wgrad_3x3_n32"),
-         ("conv_fwd_kernel<4, 1, 1, 32, false>", "conv_fwd_3x3_n32"), ("conv_dgrad_x3_kernel<4, 1, 1, 32>", "conv_dgrad_3x3_n32")]
+CLASS = [("conv_wgrad_x3_kernel<64>", "conv_wgrad_3x3_n64"), ("conv_fwd_x3_kernel<2, 2, 1, 32, true>", "conv_fwd_3x3_n64"),
+         ("conv_dgrad_x3_kernel<2, 2, 1, 32, true>", "conv_dgrad_3x3_n64"), ("conv_wgrad_x3_kernel<32>", "conv_wgrad_3x3_n32"),
+         ("conv_fwd_kernel<4, 1, 1, 32, false>", "conv_fwd_3x3_n32"), ("conv_dgrad_x3_kernel<4, 1, 1, 32, false>", "conv_dgrad_3x3_n32")]
 out = {"source": src, "note": "per-launch average over all dispatches of the kernel in a step (3x3 and 1x1 launches of one template together); "
        "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 for kname, cls in CLASS:
