@@ -249,28 +249,38 @@ __global__ __launch_bounds__(256) void maxpool_bn_relu_bwd_apply_kernel(const fl
     for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
         const unsigned t = W == 1 ? pix : __umulhi(pix, magic_w); const int w_ = (int)(pix - t * (unsigned)W);
         const unsigned n = H == 1 ? t : __umulhi(t, magic_h); const int h = (int)(t - n * (unsigned)H);
-        float dz[4] = {0.f, 0.f, 0.f, 0.f};
-        const int ho_lo = max(0, (h + pt - 1) / 2), ho_hi = min(Ho - 1, (h + pt) / 2);
-        const int wo_lo = max(0, (w_ + pl - 1) / 2), wo_hi = min(Wo - 1, (w_ + pl) / 2);
-        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
-            const int kh = h - (ho * 2 - pt);
-            if (kh < 0 || kh > 2) continue;
-            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-                const int kw = w_ - (wo * 2 - pl);
-                if (kw < 0 || kw > 2) continue;
-                const long o = (((long)n * Ho + ho) * Wo + wo) * C + c;
-                const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o);
-                const float4 ov = *reinterpret_cast<const float4*>(out + o);
-                const float4 g = *reinterpret_cast<const float4*>(dpool + o);
-                const int slot = kh * 3 + kw;
-                if (id.x == slot && ov.x > 0.f) dz[0] += g.x;
-                if (id.y == slot && ov.y > 0.f) dz[1] += g.y;
-                if (id.z == slot && ov.z > 0.f) dz[2] += g.z;
-                if (id.w == slot && ov.w > 0.f) dz[3] += g.w;
-            }
-        }
+        // A pixel lies in at most 2 x 2 pooling windows (3x3, stride 2): with a = h + pt, window a>>1 sees it at row a&1 and, when a
+        // is even, window (a>>1)-1 sees it at row 2.  All four candidates are fetched unconditionally from clamped addresses
+        // (twelve independent loads in flight next to the x load) and masked afterwards -- the first version looped over the
+        // candidates with data-dependent bounds, one dependent load group after the other.
         const long xo = (long)pix * C + c;
         const float4 xv = *reinterpret_cast<const float4*>(x + xo);
+        const int a = h + pt, b = w_ + pl;
+        const int ho1 = a >> 1, wo1 = b >> 1;
+        const int hos[2] = {ho1, ho1 - 1}, khs[2] = {a & 1, 2}, wos[2] = {wo1, wo1 - 1}, kws[2] = {b & 1, 2};
+        const bool vh[2] = {ho1 < Ho, (a & 1) == 0 && ho1 >= 1 && ho1 - 1 < Ho}, vw[2] = {wo1 < Wo, (b & 1) == 0 && wo1 >= 1 && wo1 - 1 < Wo};
+        uchar4 id[4]; float4 ov[4], g[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int hoc = min(max(hos[i], 0), Ho - 1), woc = min(max(wos[j], 0), Wo - 1);
+                const long o = (((long)n * Ho + hoc) * Wo + woc) * C + c;
+                id[i * 2 + j] = *reinterpret_cast<const uchar4*>(idx + o);
+                ov[i * 2 + j] = *reinterpret_cast<const float4*>(out + o);
+                g[i * 2 + j] = *reinterpret_cast<const float4*>(dpool + o);
+            }
+        float dz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = i * 2 + j, slot = vh[i] && vw[j] ? khs[i] * 3 + kws[j] : 255;      // 255: never an argmax slot
+                if (id[q].x == slot && ov[q].x > 0.f) dz[0] += g[q].x;
+                if (id[q].y == slot && ov[q].y > 0.f) dz[1] += g[q].y;
+                if (id[q].z == slot && ov[q].z > 0.f) dz[2] += g[q].z;
+                if (id[q].w == slot && ov[q].w > 0.f) dz[3] += g[q].w;
+            }
         float4 o4;
         o4.x = sc.x * (dz[0] - m1.x - (xv.x - mu.x) * rs.x * m2.x);
         o4.y = sc.y * (dz[1] - m1.y - (xv.y - mu.y) * rs.y * m2.y);
