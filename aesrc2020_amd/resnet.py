@@ -298,14 +298,16 @@ class ResNetTrunk(Layer):
             return None
         # stem: maxpool + BN + ReLU backward, then the 7x7 weight gradient (no input gradient needed)
         Hs, Ws = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
-        dstem = self.scratch("res_dstem", (B, Hs, Ws, c0))
         sb = self.stem_bn
+        # the full-resolution gradient (131 MB at B=64) is never written: the two BatchNorm sums first (dx = None), then the
+        # weight gradient evaluates the pooling/BatchNorm backward tile by tile
         _call("sar_maxpool_bn_relu_bwd_f32", g, self.pooled, self.pool_idx, self.stem_out, sb.mean, sb.rstd, sb.scale, sb.shift, sb.sums,
-              dstem, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
+              None, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
         _call("sar_bn_param_grads_f32", sb.sums, sb.gamma.g, sb.beta.g, c0)
         T, D = self.in_hw
         # the stem bias feeds a BatchNorm: its gradient is exactly zero, so db is not computed (None)
-        _call("sar_stem_conv7x7_wgrad_f32", self.x, dstem, self.stem.kernel.g, None, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl)
+        _call("sar_stem_conv7x7_wgrad_poolbwd_f32", self.x, self.stem_out, g, self.pooled, self.pool_idx, sb.mean, sb.rstd, sb.scale,
+              sb.sums, self.stem.kernel.g, None, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl, Hp, Wp, self.pool_pt, self.pool_pl)
         return None
 
 

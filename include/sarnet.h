@@ -97,6 +97,15 @@ int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint
                                 const float* mean, const float* rstd, const float* scale, const float* shift, double* sums,
                                 float* dx, int B, int H, int W, int C, int Ho, int Wo, int pad_top, int pad_left,
                                 sarStream_t stream);
+/* Stem weight gradient without the full-resolution gradient tensor: dw += patches(x)^T * d/dy[maxpool(relu(bn(y)))], the
+ * pooling/BatchNorm backward evaluated per tile inside the kernel (resnet.py:173-174; nothing but this weight gradient reads
+ * that tensor: the stem is the first layer).  Call sar_maxpool_bn_relu_bwd_f32 with dx = NULL first: it leaves the two
+ * BatchNorm sums in `sums`. */
+int sar_stem_conv7x7_wgrad_poolbwd_f32(const float* x, const float* y, const float* dpool, const float* out,
+                                       const uint8_t* idx, const float* mean, const float* rstd, const float* scale,
+                                       const double* sums, float* dw, float* db, int B, int H, int W, int Ho, int Wo, int C0,
+                                       int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left,
+                                       sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a

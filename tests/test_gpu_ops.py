@@ -243,6 +243,17 @@ def test_stem_and_fused_maxpool(L, B, T, D, C0):
     check(dw, dw_ref, name="stem wgrad")
     # the BN-backward gradient sums to exactly zero per channel, so scale by the summed magnitudes instead
     check(db, db_ref, name="stem dbias", scale=np.abs(dy_ref).sum((0, 1, 2)).max())
+    # fused form: sums only (dx = NULL), then the weight gradient evaluates the pooling/BatchNorm backward per tile
+    sums2 = zeros(L.bn_workspace_doubles(C0), dtype=torch.float64)
+    L.call("sar_maxpool_bn_relu_bwd_f32", dev(dpool), pooled, idx, yd, mean, rstd, scale, shift, sums2, None, B, Ho, Wo, C0, Hp, Wp, ppt, ppl)
+    dg2, dbt2 = zeros(C0), zeros(C0)
+    L.call("sar_bn_param_grads_f32", sums2, dg2, dbt2, C0)
+    check(dg2, dg_ref, name="stem dgamma (sums only)"); check(dbt2, dbeta_ref, name="stem dbeta (sums only)")
+    dw2, db2 = zeros(7, 7, 1, C0), zeros(C0)
+    L.call("sar_stem_conv7x7_wgrad_poolbwd_f32", xd, yd, dev(dpool), pooled, idx, mean, rstd, scale, sums2, dw2, db2, B, T, D, Ho, Wo, C0,
+           pt, pl, Hp, Wp, ppt, ppl)
+    check(dw2, dw_ref, name="stem wgrad (fused pool/BN backward)")
+    check(db2, db_ref, name="stem dbias (fused)", scale=np.abs(dy_ref).sum((0, 1, 2)).max())
 
 
 # ------------------------------------------------------------------ normalisation
