@@ -31,9 +31,13 @@ __device__ __forceinline__ void stem_load_patch_flat(float* patch, const float* 
 // GEMM view per block: M = 64 output pixels (4 x 16 tile), N = 64 channels, K = 49 taps padded to 50; the A operand is
 // gathered from the 13 x 37 input patch in LDS, B = the 7x7xC0 kernel in LDS; 4 waves = 2 pixel blocks x 2 channel blocks
 // of v_mfma_f32_32x32x2_f32 (25 MFMAs per wave).
+// stats (nullable): [stat_rows][2*C0] fp32, zeroed by the launcher -- per-channel sum and sum of squares of y, added with
+// atomics to row blockIdx % stat_rows (a few adds per address); sar_bn_finalize_f32 turns them into the batch statistics of
+// the BatchNorm behind the stem, which saves the separate statistics pass over the 131 MB map (B=64).
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                       int H, int W, int Ho, int Wo, int C0, int pt, int pl) {
+                                                       int H, int W, int Ho, int Wo, int C0, int pt, int pl,
+                                                       float* __restrict__ stats, int stat_rows) {
     __shared__ float patch[ST_ZSLOT + 2];
     __shared__ float ws[50 * 64];
     const int tiles_w = (Wo + ST_TW - 1) / ST_TW, tiles_h = (Ho + ST_TH - 1) / ST_TH;
@@ -68,11 +72,23 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     const int c = nb * 32 + col;
     if (c >= C0) return;
     const float bz = bias[c];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int prow = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kr;
         const int ho = th * ST_TH + (prow >> 4), wo = tw * ST_TW + (prow & 15);
-        if (ho < Ho && wo < Wo) y[(((long)n * Ho + ho) * Wo + wo) * C0 + c] = acc[r] + bz;
+        if (ho < Ho && wo < Wo) {
+            const float v = acc[r] + bz;
+            y[(((long)n * Ho + ho) * Wo + wo) * C0 + c] = v;
+            s1 += v; s2 = fmaf(v, v, s2);
+        }
+    }
+    if (stats) {                                                    // kernel-uniform; lanes col and col+32 hold the same channel
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (kr == 0) {
+            float* o = stats + (long)(blockIdx.x % stat_rows) * 2 * C0;
+            atomicAdd(o + c, s1); atomicAdd(o + C0 + c, s2);
+        }
     }
 }
 
@@ -387,9 +403,34 @@ extern "C" int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const fl
                                         int W, int Ho, int Wo, int C0, int pad_top, int pad_left, hipStream_t stream) {
     if (!x || !w || !bias || !y || C0 > 64 || C0 % 4) return SAR_EINVAL;
     const int nblk = B * cdiv(Ho, ST_TH) * cdiv(Wo, ST_TW);
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(nblk), dim3(256), 0, stream, x, w, bias, y, B, H, W, Ho, Wo, C0, pad_top, pad_left);
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(nblk), dim3(256), 0, stream, x, w, bias, y, B, H, W, Ho, Wo, C0, pad_top, pad_left, nullptr, 1);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
+}
+
+extern "C" size_t sar_bn_workspace_bytes(int C);
+extern "C" int sar_bn_finalize_f32(const float* part, int rows, const float* gamma, const float* beta, float* mean,
+                                   float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, long R,
+                                   int C, float eps, float momentum, int unbiased_moving_var, hipStream_t stream);
+
+// The stem conv together with the training-mode statistics of the BatchNormalization behind it (resnet.py:173,43): y as
+// sar_stem_conv7x7_fwd_f32, mean/rstd/scale/shift (+ moving averages) as sar_bn_stats_f32(y, ...) -- the sums come out of the
+// conv epilogue (fp32 atomics into 512 partial rows of the workspace, cleared here first, combined in fp64).
+extern "C" int sar_stem_conv7x7_fwd_bnstats_f32(const float* x, const float* w, const float* bias, float* y, int B, int H,
+                                                int W, int Ho, int Wo, int C0, int pad_top, int pad_left, const float* gamma,
+                                                const float* beta, double* sums, float* mean, float* rstd, float* scale,
+                                                float* shift, float* moving_mean, float* moving_var, float eps,
+                                                float momentum, int unbiased_moving_var, hipStream_t stream) {
+    if (!x || !w || !bias || !y || C0 > 64 || C0 % 4 || !gamma || !beta || !sums || !mean || !rstd || !scale || !shift) return SAR_EINVAL;
+    constexpr int ROWS = 512;
+    if (sar_bn_workspace_bytes(C0) < sizeof(double) * 2 * C0 + sizeof(float) * (size_t)ROWS * 2 * C0) return SAR_EINVAL;
+    float* part = reinterpret_cast<float*>(sums + 2 * C0);
+    if (sar_zero_async(part, sizeof(float) * (size_t)ROWS * 2 * C0, stream) != hipSuccess) return SAR_ELAUNCH;
+    const int nblk = B * cdiv(Ho, ST_TH) * cdiv(Wo, ST_TW);
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(nblk), dim3(256), 0, stream, x, w, bias, y, B, H, W, Ho, Wo, C0, pad_top, pad_left, part, ROWS);
+    SAR_CHECK_LAUNCH();
+    return sar_bn_finalize_f32(part, ROWS, gamma, beta, mean, rstd, scale, shift, moving_mean, moving_var, (long)B * Ho * Wo, C0, eps,
+                               momentum, unbiased_moving_var, stream);
 }
 
 extern "C" int sar_stem_conv7x7_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int B, int H, int W,

@@ -196,8 +196,15 @@ class ResNetTrunk(Layer):
         H, W = self.stem_hw
         c0 = self.stem.cout
         self.stem_out = self.buf("stem_out", (B, H, W, c0))
-        _call("sar_stem_conv7x7_fwd_f32", x, self.stem.kernel.w, self.stem.bias.w, self.stem_out, B, T, D, H, W, c0, self.stem.pt, self.stem.pl)
-        self.stem_bn.stats(self.stem_out, B * H * W)
+        sb = self.stem_bn
+        if self.store.training:                                              # statistics out of the conv epilogue
+            sb.prepare()
+            _call("sar_stem_conv7x7_fwd_bnstats_f32", x, self.stem.kernel.w, self.stem.bias.w, self.stem_out, B, T, D, H, W, c0,
+                  self.stem.pt, self.stem.pl, sb.gamma.w, sb.beta.w, sb.sums, sb.mean, sb.rstd, sb.scale, sb.shift,
+                  sb.moving_mean.w, sb.moving_var.w, BN_EPS, BN_MOMENTUM, 1)
+        else:
+            _call("sar_stem_conv7x7_fwd_f32", x, self.stem.kernel.w, self.stem.bias.w, self.stem_out, B, T, D, H, W, c0, self.stem.pt, self.stem.pl)
+            sb.stats(self.stem_out, B * H * W)
         Hp, Wp = self.pool_hw
         self.pooled = self.buf("pooled", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
         _call("sar_bn_relu_maxpool_fwd_f32", self.stem_out, self.stem_bn.scale, self.stem_bn.shift, self.pooled, self.pool_idx,

@@ -87,6 +87,13 @@ int sar_get_conv_math(void);
 /* 7x7/2 stem on the 1-channel fbank image: resnet.py:173 / 191.  C0 <= 64, C0 % 4 == 0. */
 int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ho,
                              int Wo, int C0, int pad_top, int pad_left, sarStream_t stream);
+/* sar_stem_conv7x7_fwd_f32 + sar_bn_stats_f32 of its output in one call: the per-channel sums come out of the conv epilogue
+ * (sums = the BatchNorm workspace), so the 131 MB stem map (B=64) is not read a second time for its statistics. */
+int sar_stem_conv7x7_fwd_bnstats_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W,
+                                     int Ho, int Wo, int C0, int pad_top, int pad_left, const float* gamma,
+                                     const float* beta, double* sums, float* mean, float* rstd, float* scale, float* shift,
+                                     float* moving_mean, float* moving_var, float eps, float momentum,
+                                     int unbiased_moving_var, sarStream_t stream);
 int sar_stem_conv7x7_wgrad_f32(const float* x, const float* dy, float* dw, float* db, int B, int H, int W, int Ho,
                                int Wo, int C0, int pad_top, int pad_left, sarStream_t stream);
 /* BN+ReLU (resnet.py:43) fused with MaxPooling2D 3x3/2 'same' (resnet.py:174,192). idx = argmax window slot. */

@@ -223,6 +223,15 @@ def test_stem_and_fused_maxpool(L, B, T, D, C0):
     yd = dev(y_ref)
     L.call("sar_bn_stats_f32", yd, dev(gamma), dev(beta), sums, mean, rstd, scale, shift, mm, mv, B * Ho * Wo, C0, 1e-3, 0.99, 1)
     check(mean, bnc[4], name="bn mean"); check(rstd, bnc[1], name="bn rstd")
+    # the same statistics out of the stem conv's epilogue (twice: the partial rows are cleared by every call)
+    for rep in range(2):
+        y2, sums_f = zeros(B, Ho, Wo, C0), torch.full((L.bn_workspace_doubles(C0),), 7.0, device="cuda", dtype=torch.float64)
+        m2, r2, sc2, sh2 = zeros(C0), zeros(C0), zeros(C0), zeros(C0)
+        mm2, mv2 = zeros(C0), torch.ones(C0, device="cuda", dtype=torch.float32)
+        L.call("sar_stem_conv7x7_fwd_bnstats_f32", xd, dev(w), dev(b), y2, B, T, D, Ho, Wo, C0, pt, pl, dev(gamma), dev(beta), sums_f,
+               m2, r2, sc2, sh2, mm2, mv2, 1e-3, 0.99, 1)
+        check(y2, y_ref, name="stem fwd (bnstats)"); check(m2, bnc[4], name="stem bn mean (epilogue)"); check(r2, bnc[1], name="stem bn rstd (epilogue)")
+        check(sc2, scale.cpu().numpy(), name="stem bn scale (epilogue)"); check(mv2, mv.cpu().numpy(), name="stem moving var (epilogue)")
     pooled = zeros(B, Hp, Wp, C0); idx = zeros(B, Hp, Wp, C0, dtype=torch.uint8)
     L.call("sar_bn_relu_maxpool_fwd_f32", yd, scale, shift, pooled, idx, B, Ho, Wo, C0, Hp, Wp, ppt, ppl)
     check(pooled, p_ref, name="bn+relu+maxpool fwd")
