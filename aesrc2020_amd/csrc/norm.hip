@@ -126,9 +126,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (cv * 4 < C) {
         const float4 sc = *reinterpret_cast<const float4*>(scale + cv * 4), sh = *reinterpret_cast<const float4*>(shift + cv * 4);
         const float4 mu = *reinterpret_cast<const float4*>(mean + cv * 4), rs = *reinterpret_cast<const float4*>(rstd + cv * 4);
-        for (long r = (long)blockIdx.x * nrg + rg; r < R; r += (long)gridDim.x * nrg) {
-            const float4 v = *reinterpret_cast<const float4*>(x + r * C + cv * 4);
-            float4 g = *reinterpret_cast<const float4*>(dact + r * C + cv * 4);
+        auto step = [&](const float4 v, float4 g) {
             if (relu) {
                 if (fmaf(v.x, sc.x, sh.x) <= 0.f) g.x = 0.f;
                 if (fmaf(v.y, sc.y, sh.y) <= 0.f) g.y = 0.f;
@@ -138,7 +136,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
             b.x = fmaf(g.x, (v.x - mu.x) * rs.x, b.x); b.y = fmaf(g.y, (v.y - mu.y) * rs.y, b.y);
             b.z = fmaf(g.z, (v.z - mu.z) * rs.z, b.z); b.w = fmaf(g.w, (v.w - mu.w) * rs.w, b.w);
+        };
+        // four rows per trip, all eight loads issued before the first use: the kernel is a handful of memory round trips per
+        // thread (4-16 rows), so loads in flight are what counts
+        const long S = (long)gridDim.x * nrg;
+        long r = (long)blockIdx.x * nrg + rg;
+        const float* xp = x + cv * 4; const float* gp = dact + cv * 4;
+        for (; r + 3 * S < R; r += 4 * S) {
+            float4 v[4], g[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = *reinterpret_cast<const float4*>(xp + (r + j * S) * C); g[j] = *reinterpret_cast<const float4*>(gp + (r + j * S) * C); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) step(v[j], g[j]);
         }
+        for (; r < R; r += S) step(*reinterpret_cast<const float4*>(xp + r * C), *reinterpret_cast<const float4*>(gp + r * C));
     }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
