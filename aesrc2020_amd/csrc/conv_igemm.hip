@@ -54,7 +54,22 @@ struct WgradP {
     const float* x; const float* dy; const float* scale; const float* shift; float* dw; float* dbias;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pt, pl, rows_per_slice;
     unsigned magic_wo, magic_ho;        // ceil(2^32 / Wo), ceil(2^32 / Ho): q = umulhi(m, magic) exact for m < 2^32 / d
+    int gx, gy, gz;                     // logical grid (m' tiles, co tiles, row slices) of the 1-D XCD-aware launch (bf16x3 kernel)
+    int xcd;                            // 1: slices grouped per XCD; 0: plain x-fastest order
 };
+
+// Logical block coordinates for a 1-D launch in which all tiles of one row slice land on the same XCD (blocks are dealt to the
+// 8 XCDs round-robin by linear index -- observed, not promised; only speed depends on it): the gx*gy tiles of a slice all read
+// the same rows of x and dy, so they should share one L2 instead of fetching those rows into up to five.  Block b: XCD
+// k = b % 8, position j = b / 8 within it; XCD k owns slices k, k+8, ...; j walks (slice, tile).  false: past the last slice.
+__device__ __forceinline__ bool xcd_slice_coords(int gx, int gy, int gz, int xcd, int& bx, int& by, int& bz) {
+    if (!xcd) { const int b = blockIdx.x, tps = gx * gy; bz = b / tps; const int t = b - bz * tps; by = t / gx; bx = t - by * gx; return bz < gz; }
+    const int b = blockIdx.x, k = b & 7, j = b >> 3, nsl = (gz + 7) / 8;
+    const int t = j / nsl, sl = j - t * nsl;                          // tile-major within the XCD
+    bz = k + 8 * sl; by = t / gx; bx = t - by * gx;
+    return bz < gz;
+}
+static inline int xcd_slice_blocks(int gx, int gy, int gz) { return 8 * gx * gy * ((gz + 7) / 8); }
 
 template <int WM, int WN, int TM, int BK>
 struct Tile {
@@ -897,8 +912,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     const int wm = wave / WN, wn = wave % WN;
     const unsigned R = (unsigned)(p.B * p.Ho * p.Wo);
     const int Mp = p.KH * p.KW * p.Cin;
-    const int m0 = blockIdx.x * BMt, n0 = blockIdx.y * BNt;
-    const unsigned r_begin = blockIdx.z * (unsigned)p.rows_per_slice;
+    int bx, by, bz;
+    if (!xcd_slice_coords(p.gx, p.gy, p.gz, p.xcd, bx, by, bz)) return;
+    const int m0 = bx * BMt, n0 = by * BNt;
+    const unsigned r_begin = bz * (unsigned)p.rows_per_slice;
     const unsigned r_end = min(R, r_begin + (unsigned)p.rows_per_slice);
     if (r_begin >= r_end) return;
     const int ntile = (int)((r_end - r_begin + BK - 1) / BK);
@@ -940,7 +957,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
     constexpr int BR = BNt / 32;
     const int b_r = (tid % (BK / BR)) * BR, b_c4 = tid / (BK / BR);
     const bool bcol_ok = n0 + b_c4 * 4 < p.Cout;
-    const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
+    const bool do_bias = p.dbias != nullptr && bx == 0;
     const float* dyb = p.dy + (bcol_ok ? n0 + b_c4 * 4 : 0);
     float4 bsum = zero4();
     struct Regs { float4 ra[4], rb[BR]; unsigned vmask; };
@@ -1397,12 +1414,21 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     if (rows < 128) rows = 128;
     if (rows > WG_MAX_ROWS) rows = WG_MAX_ROWS;                       // bound of the per-block row table (bf16x3 kernel)
     splits = cdiv(R, rows);
-    WgradP p{x, dy, scale, shift, dw, dbias, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, (int)rows,
-             (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho)};
+    if (x3 && splits > 8 && (splits & 7)) {                           // XCD-aware launch: a multiple of 8 slices loads the 8 XCDs evenly
+        const int s8 = (splits + 7) & ~7;
+        long r8 = (((R + s8 - 1) / s8 + 63) / 64) * 64;
+        if (r8 >= 128 && r8 <= WG_MAX_ROWS && (cdiv(R, r8) & 7) == 0) { rows = r8; splits = cdiv(R, rows); }
+    }
     dim3 grid(cdiv(Mp, 128), cdiv(Cout, narrow ? 32 : 64), splits);
-    if (x3) {                                                        // bf16x3 split-precision path
-        if (narrow) hipLaunchKernelGGL((conv_wgrad_x3_kernel<32>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), grid, dim3(256), 0, stream, p);
+    WgradP p{x, dy, scale, shift, dw, dbias, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, (int)rows,
+             (unsigned)(((1UL << 32) + Wo - 1) / Wo), (unsigned)(((1UL << 32) + Ho - 1) / Ho), (int)grid.x, (int)grid.y, (int)grid.z, 0};
+    // group the slices per XCD only when that loads the 8 XCDs evenly (with 6 slices of 72 tiles -- stage 3 -- two XCDs would idle)
+    static const int xcd_knob = getenv("SAR_WGRAD_XCD") ? atoi(getenv("SAR_WGRAD_XCD")) : 1;
+    p.xcd = xcd_knob && (splits & 7) == 0;
+    if (x3) {                                                        // bf16x3 split-precision path, XCD-aware 1-D grid
+        const dim3 g1(p.xcd ? xcd_slice_blocks(p.gx, p.gy, p.gz) : p.gx * p.gy * p.gz);
+        if (narrow) hipLaunchKernelGGL((conv_wgrad_x3_kernel<32>), g1, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_x3_kernel<64>), g1, dim3(256), 0, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
