@@ -57,6 +57,10 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     // gate-math ownership: thread tid < GR*H handles (row gr, unit gj) -- one output per thread (GR*H <= blockDim)
     const int gr = tid / H, gj = tid - gr * H, gb = b0 + gr;
     const bool gate_thread = tid < GR * H && gb < B;
+    // recurrent bias of the (up to three) reduction outputs of this thread: loaded once, not in every step's critical path
+    float bhr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int o = tid + i * 64 * NW; if (o < GR * H3) bhr[i] = bh[o % H3]; }
     for (int s = 0; s < L; ++s) {
         const int t = d ? (L - 1 - s) : s;
         float xz = 0.f, xr = 0.f, xh = 0.f;                           // input projections of this step: in flight under the stream
@@ -101,13 +105,17 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
         }
         __syncthreads();
         // cross-wave reduction: output o = (r, g, j); j = 4*l4 + e lives at part[*][r*12 + g*4 + e][l4]
-        for (int o = tid; o < GR * 3 * H; o += blockDim.x) {
-            const int r = o / H3, rem = o - r * H3, g = rem / H, jj = rem - g * H;
-            const float* p = part + ((r * 12) + g * 4 + (jj & 3)) * 64 + (jj >> 2);
-            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < NW; ++q) sum += p[q * GR * 12 * 64];
-            red[o] = sum + bh[g * H + jj];
+        for (int i = 0; i < 3; ++i) {                                // GR*3*H <= 3 * blockDim (H <= 256)
+            const int o = tid + i * 64 * NW;
+            if (o < GR * 3 * H) {
+                const int r = o / H3, rem = o - r * H3, g = rem / H, jj = rem - g * H;
+                const float* p = part + ((r * 12) + g * 4 + (jj & 3)) * 64 + (jj >> 2);
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) sum += p[q * GR * 12 * 64];
+                red[o] = sum + bhr[i];
+            }
         }
         __syncthreads();
         if (gate_thread) {
