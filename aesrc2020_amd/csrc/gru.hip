@@ -15,7 +15,7 @@ constexpr int NW = 8;    // waves per workgroup = k-slices of the reduction (512
 // v3 mapping (H % 4 == 0, H <= 256): lane owns 4 consecutive hidden units (float4 loads of U rows: 1 KB per wave
 // instruction instead of 256 B), wave w owns the k-slice [w*H/16, (w+1)*H/16).  The recurrence is bound by how fast one
 // CU can stream the 3*H*H recurrent kernel from L2 every step, so bytes per load instruction and loads in flight matter,
-// not FLOPs.  Partial sums go through LDS: part[NW][GR*12][64] -> red[GR][3][H] -> gate math -> hs[GR][H].
+// not FLOPs.  Partial sums go through LDS: part[NW][GR*12][64] -> summed by the gate thread of each unit -> hs[GR][H].
 // v4: one third of that stream is taken out of the loop -- every thread keeps the candidate-gate rows of its k-slice
 // (forward: U[k][2H + 4*lane ..], backward: the first KRES rows of its UT slice) in registers for all L steps: KRES float4 =
 // 128 of the 256 VGPRs a 512-thread workgroup allows, 256 KB of the 786 KB per CU (with 1024 threads and a 128-register
@@ -28,7 +28,7 @@ __device__ __forceinline__ void fma4(float4& a, float h, const float4& u) {
     a.x = fmaf(h, u.x, a.x); a.y = fmaf(h, u.y, a.y); a.z = fmaf(h, u.z, a.z); a.w = fmaf(h, u.w, a.w);
 }
 
-// dynamic LDS: hs[GR][H] | red[GR][3][H] | part[NW][GR*12][64]
+// dynamic LDS: hs[GR][H] | part[NW][GR*12][64]
 template <bool RES>                                                // RES: H == KRES * NW, the k-slices are exactly KRES rows
 __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
                                const float* __restrict__ U_f, const float* __restrict__ U_b,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
                                float* __restrict__ out, float* __restrict__ gates, float* __restrict__ hprev, int B,
                                int L, int H) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* hs = sm; float* red = hs + GR * H; float* part = red + GR * 3 * H;
+    float* hs = sm; float* part = hs + GR * H;
     const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, b0 = blockIdx.x * GR;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: row addresses of the U stream stay in SGPRs
     const float* xa = d ? xa_b : xa_f; const float* U = d ? U_b : U_f; const float* bh = d ? bh_b : bh_f;
@@ -57,10 +57,9 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
     // gate-math ownership: thread tid < GR*H handles (row gr, unit gj) -- one output per thread (GR*H <= blockDim)
     const int gr = tid / H, gj = tid - gr * H, gb = b0 + gr;
     const bool gate_thread = tid < GR * H && gb < B;
-    // recurrent bias of the (up to three) reduction outputs of this thread: loaded once, not in every step's critical path
-    float bhr[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const int o = tid + i * 64 * NW; if (o < GR * H3) bhr[i] = bh[o % H3]; }
+    // recurrent bias of this thread's unit: loaded once, not in every step's critical path
+    float bz = 0.f, br = 0.f, bq = 0.f;
+    if (gate_thread) { bz = bh[gj]; br = bh[H + gj]; bq = bh[2 * H + gj]; }
     for (int s = 0; s < L; ++s) {
         const int t = d ? (L - 1 - s) : s;
         float xz = 0.f, xr = 0.f, xh = 0.f;                           // input projections of this step: in flight under the stream
@@ -105,25 +104,18 @@ __global__ __launch_bounds__(512) void gru_fwd_kernel(const float* __restrict__ 
         }
         __syncthreads();
         // cross-wave reduction: output o = (r, g, j); j = 4*l4 + e lives at part[*][r*12 + g*4 + e][l4]
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                                // GR*3*H <= 3 * blockDim (H <= 256)
-            const int o = tid + i * 64 * NW;
-            if (o < GR * 3 * H) {
-                const int r = o / H3, rem = o - r * H3, g = rem / H, jj = rem - g * H;
-                const float* p = part + ((r * 12) + g * 4 + (jj & 3)) * 64 + (jj >> 2);
-                float sum = 0.f;
-#pragma unroll
-                for (int q = 0; q < NW; ++q) sum += p[q * GR * 12 * 64];
-                red[o] = sum + bhr[i];
-            }
-        }
-        __syncthreads();
+        // the gate thread of (row, unit) sums the NW partials of its three pre-activations itself: no separate reduction phase,
+        // one barrier and one LDS round trip fewer per step.  Unit j = 4*l4 + e lives at part[q][r*12 + g*4 + e][l4].
         if (gate_thread) {
             const int r = gr, jj = gj, o = tid, b = gb;
+            const float* p = part + (r * 12 + (jj & 3)) * 64 + (jj >> 2);
+            float sz = 0.f, sr = 0.f, sq = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { sz += p[q * GR * 12 * 64]; sr += p[q * GR * 12 * 64 + 4 * 64]; sq += p[q * GR * 12 * 64 + 8 * 64]; }
             const float hold = hs[o];
-            const float q = red[r * H3 + 2 * H + jj];
-            const float z = sigmoidf_(xz + red[r * H3 + jj]);
-            const float rr = sigmoidf_(xr + red[r * H3 + H + jj]);
+            const float q = sq + bq;
+            const float z = sigmoidf_(xz + (sz + bz));
+            const float rr = sigmoidf_(xr + (sr + br));
             const float hh = tanhf(xh + rr * q);
             const float hn = z * hold + (1.f - z) * hh;
             const long go = (((long)b * L + t) * 4) * H;
@@ -262,7 +254,7 @@ extern "C" int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const
     if (!xa_fwd || !xa_bwd || !U_fwd || !U_bwd || !bh_fwd || !bh_bwd || !out || !gates || !hprev || H < 1 || H > 1024)
         return SAR_EINVAL;
     if (H > 256 || H % 4) return SAR_EINVAL;
-    const size_t lds = sizeof(float) * (GR * H + GR * 3 * H + NW * GR * 12 * 64);
+    const size_t lds = sizeof(float) * (GR * H + NW * GR * 12 * 64);
     static bool attr_f = false;
     if (!attr_f) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
