@@ -19,9 +19,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifndef SAR_X3_TERMS
-#define SAR_X3_TERMS 3
-#endif
 namespace {
 
 // In-kernel phase timing (tools/conv_timing.py; built only with -DSAR_TIMING into tools/libsarnet_timing.so, never part
@@ -472,13 +469,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
             // no branches; padding is multiplied by 0 after the ReLU and stays exactly zero
             const float4 v = bn_relu_mask4(R.ra[i], R.sc, R.sh, relu_lo, (R.vmask >> i) & 1u);
             bf16x4 hi, lo; split4(v, hi, lo);
-            *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi;
-            if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo; }
+            *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
         if constexpr (WP) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wh : z;
-            if (SAR_X3_TERMS == 3) { *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z; }
+            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z;
         } else {                                                     // B: KPT consecutive k of one column -> one row segment
             __bf16 hi[KPT], lo[KPT];
 #pragma unroll
@@ -491,14 +487,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
                 bf16x8 vh, vl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { vh[j] = hi[j]; vl[j] = lo[j]; }
-                *reinterpret_cast<bf16x8*>(&Bh[buf][b_n][b_k]) = vh;
-                if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x8*>(&Bl[buf][b_n][b_k]) = vl; }
+                *reinterpret_cast<bf16x8*>(&Bh[buf][b_n][b_k]) = vh; *reinterpret_cast<bf16x8*>(&Bl[buf][b_n][b_k]) = vl;
             } else {
                 bf16x4 vh, vl;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { vh[j] = hi[j]; vl[j] = lo[j]; }
-                *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k]) = vh;
-                if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k]) = vl; }
+                *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k]) = vh; *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k]) = vl;
             }
         }
     };
@@ -517,8 +511,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
             for (int tm = 0; tm < TM; ++tm) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
-                if (SAR_X3_TERMS == 3) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);      // small terms first
-                if (SAR_X3_TERMS == 3) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);      // small terms first
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tm], 0, 0, 0);
             }
         }
@@ -733,19 +727,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
         for (int i = 0; i < NA; ++i) {
             const int r = (tid + i * NT) / KQ;
             bf16x4 hi, lo; split4(((R.vmask >> i) & 1u) ? R.ra[i] : zero4(), hi, lo);
-            *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi;
-            if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo; }
+            *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
         if constexpr (WP) {
             const u32x4 z = {0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wh : z;
-            if (SAR_X3_TERMS == 3) { *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z; }
+            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z;
         } else {
 #pragma unroll
             for (int j = 0; j < KPT / 4; ++j) {
                 bf16x4 hi, lo; split4(brow_ok ? R.rb[j] : zero4(), hi, lo);
-                *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k + 4 * j]) = hi;
-                if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k + 4 * j]) = lo; }
+                *reinterpret_cast<bf16x4*>(&Bh[buf][b_n][b_k + 4 * j]) = hi; *reinterpret_cast<bf16x4*>(&Bl[buf][b_n][b_k + 4 * j]) = lo;
             }
         }
     };
@@ -764,8 +756,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
             for (int tm = 0; tm < TM; ++tm) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
-                if (SAR_X3_TERMS == 3) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);
-                if (SAR_X3_TERMS == 3) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tm], 0, 0, 0);
             }
         }
@@ -1018,7 +1010,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
                 split2(f32x2{v[0][j], v[1][j]} * f32x2{okf[0], okf[1]}, h01, l01);
                 split2(f32x2{v[2][j], v[3][j]} * f32x2{okf[2], okf[3]}, h23, l23);
                 *reinterpret_cast<bf16x4*>(&Ah[buf][a_c4 * 4 + j][a_r]) = bf16x4{h01[0], h01[1], h23[0], h23[1]};
-                if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x4*>(&Al[buf][a_c4 * 4 + j][a_r]) = bf16x4{l01[0], l01[1], l23[0], l23[1]}; }
+                *reinterpret_cast<bf16x4*>(&Al[buf][a_c4 * 4 + j][a_r]) = bf16x4{l01[0], l01[1], l23[0], l23[1]};
             }
         }
         {
@@ -1037,12 +1029,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
             for (int j = 0; j < 4; ++j) {                             // channel j gets its BR consecutive rows
                 if constexpr (BR == 2) {
                     bf16x2 hi, lo; split2(f32x2{v[0][j], v[1][j]}, hi, lo);
-                    *reinterpret_cast<bf16x2*>(&Bh[buf][b_c4 * 4 + j][b_r]) = hi;
-                    if (SAR_X3_TERMS == 3) { *reinterpret_cast<bf16x2*>(&Bl[buf][b_c4 * 4 + j][b_r]) = lo; }
+                    *reinterpret_cast<bf16x2*>(&Bh[buf][b_c4 * 4 + j][b_r]) = hi; *reinterpret_cast<bf16x2*>(&Bl[buf][b_c4 * 4 + j][b_r]) = lo;
                 } else {
                     const __bf16 h = (__bf16)v[0][j];
-                    Bh[buf][b_c4 * 4 + j][b_r] = h;
-                    if (SAR_X3_TERMS == 3) { Bl[buf][b_c4 * 4 + j][b_r] = (__bf16)(v[0][j] - (float)h); }
+                    Bh[buf][b_c4 * 4 + j][b_r] = h; Bl[buf][b_c4 * 4 + j][b_r] = (__bf16)(v[0][j] - (float)h);
                 }
             }
         }
@@ -1062,8 +1052,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(WgradP p) {
             for (int tm = 0; tm < TM; ++tm) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ah[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Al[cur][(wm * TM + tm) * 32 + rc][st * 16 + kg]);
-                if (SAR_X3_TERMS == 3) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);
-                if (SAR_X3_TERMS == 3) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[tm], 0, 0, 0);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[tm], 0, 0, 0);
                 acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[tm], 0, 0, 0);
             }
         }
