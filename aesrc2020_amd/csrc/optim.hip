@@ -30,16 +30,37 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
     __shared__ float red[16];
     const float lr_t = st->lr_t, b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
     float lacc = 0.f;
-    for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const float l2 = chunk_l2[c];
-        const long i = c * 256 + threadIdx.x;
-        const float w = p[i];
-        const float gr = fmaf(2.f * l2, w, g[i] * gs);
+    // one wave per 256-element chunk, float4 per lane (16-byte accesses: the scalar version ran at 3.4 TB/s), two chunks per
+    // trip so that 14 loads are in flight per lane
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto upd = [&](float w, float gi, float& mi, float& vi, float l2) {
+        const float gr = fmaf(2.f * l2, w, gi * gs);
         lacc = fmaf(l2 * w, w, lacc);
-        const float mm = b1 * m[i] + (1.f - b1) * gr;
-        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
-        m[i] = mm; v[i] = vv;
-        p[i] = w - lr_t * mm / (sqrtf(vv) + eps);
+        mi = b1 * mi + (1.f - b1) * gr;
+        vi = b2 * vi + (1.f - b2) * gr * gr;
+        return w - lr_t * mi / (sqrtf(vi) + eps);
+    };
+    auto one = [&](long c, float4 w, float4 gg, float4 mm, float4 vv, float l2) {
+        w.x = upd(w.x, gg.x, mm.x, vv.x, l2); w.y = upd(w.y, gg.y, mm.y, vv.y, l2);
+        w.z = upd(w.z, gg.z, mm.z, vv.z, l2); w.w = upd(w.w, gg.w, mm.w, vv.w, l2);
+        const long i = c * 256 + lane * 4;
+        *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv; *reinterpret_cast<float4*>(p + i) = w;
+    };
+    const long stride = (long)gridDim.x * 4;
+    long c = (long)blockIdx.x * 4 + wv;
+    for (; c + stride < nchunks; c += 2 * stride) {
+        const long i0 = c * 256 + lane * 4, i1 = (c + stride) * 256 + lane * 4;
+        const float4 w0 = *reinterpret_cast<const float4*>(p + i0), g0 = *reinterpret_cast<const float4*>(g + i0);
+        const float4 m0 = *reinterpret_cast<const float4*>(m + i0), v0 = *reinterpret_cast<const float4*>(v + i0);
+        const float4 w1 = *reinterpret_cast<const float4*>(p + i1), g1 = *reinterpret_cast<const float4*>(g + i1);
+        const float4 m1 = *reinterpret_cast<const float4*>(m + i1), v1 = *reinterpret_cast<const float4*>(v + i1);
+        const float l20 = chunk_l2[c], l21 = chunk_l2[c + stride];
+        one(c, w0, g0, m0, v0, l20); one(c + stride, w1, g1, m1, v1, l21);
+    }
+    for (; c < nchunks; c += stride) {
+        const long i0 = c * 256 + lane * 4;
+        one(c, *reinterpret_cast<const float4*>(p + i0), *reinterpret_cast<const float4*>(g + i0), *reinterpret_cast<const float4*>(m + i0),
+            *reinterpret_cast<const float4*>(v + i0), chunk_l2[c]);
     }
     if (l2_loss) {
         lacc = block_sum(lacc, red);
@@ -84,7 +105,8 @@ extern "C" int sar_adam_l2_step_f32(float* params, const float* grads, float* m,
                                     const void* state, float* l2_loss, long n, hipStream_t stream) {
     if (!params || !grads || !m || !v || !chunk_l2 || !state || (n % 256)) return SAR_EINVAL;
     const long nchunks = n / 256;
-    const int nb = (int)(nchunks < 4096 ? nchunks : 4096);
+    const long nb4 = (nchunks + 3) / 4;                                // a block = 4 waves = 4 chunks per trip
+    const int nb = (int)(nb4 < 2048 ? nb4 : 2048);
     hipLaunchKernelGGL(adam_l2_kernel, dim3(nb), dim3(256), 0, stream, params, grads, m, v, chunk_l2,
                        static_cast<const SarAdamState*>(state), l2_loss, nchunks);
     SAR_CHECK_LAUNCH();
