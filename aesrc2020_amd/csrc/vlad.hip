@@ -355,13 +355,17 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     const float* dO = dout + (long)b * K * D;
     const float* n = out + (long)b * K * D;
     for (int i = tid; i < KP * DP1; i += 256) dres[i] = 0.f;
+    // The prologue loops are chains of memory round trips (a workgroup per utterance: nothing else hides them), so they are
+    // unrolled to keep independent loads in flight (as plain loops: 82 us for the kernel, unrolled 71 us)
     for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments
         float t = 0.f;
+#pragma unroll 13
         for (int l = 0; l < L; ++l) t += Ab[(long)l * KG + k];
         asum[k] = t;
     }
     for (int k = wave; k < K; k += 4) {                              // n . dO per cluster (wave per cluster)
         float t = 0.f;
+#pragma unroll 4
         for (int d = lane; d < D; d += 64) t = fmaf(n[(long)k * D + d], dO[(long)k * D + d], t);
         t = wave_sum(t);
         if (lane == 0) dot[k] = t;
@@ -371,6 +375,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
         const float iv = inv[(long)b * K + k];
         const float aiv = fabsf(iv), dt = iv > 0.f ? dot[k] : 0.f;
         float t = 0.f;
+#pragma unroll 4
         for (int d = lane; d < D; d += 64) {
             const float g = (dO[(long)k * D + d] - n[(long)k * D + d] * dt) * aiv;
             dres[k * DP1 + d] = g;
