@@ -44,9 +44,20 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     int b = blockIdx.x;
     const int tw = b % tiles_w; b /= tiles_w;
     const int th = b % tiles_h; const int n = b / tiles_h;
-    for (int i = threadIdx.x; i < 50 * 64; i += 256) {
-        const int k = i >> 6, c = i & 63;
-        ws[i] = (k < 49 && c < C0) ? w[k * C0 + c] : 0.f;
+    // all 13 kernel loads of a thread are issued before the first LDS store (clamped addresses, select afterwards): as a plain
+    // loop this was 13 L2 round trips in front of every block's 25 MFMAs
+    {
+        float wv[13];
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const int i = threadIdx.x + 256 * j, k = i >> 6, c = i & 63;
+            wv[j] = w[min(k, 48) * C0 + min(c, C0 - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 13; ++j) {
+            const int i = threadIdx.x + 256 * j, k = i >> 6, c = i & 63;
+            if (i < 50 * 64) ws[i] = (k < 49 && c < C0) ? wv[j] : 0.f;
+        }
     }
     stem_load_patch_flat(patch, x, n, H, W, th * ST_TH * 2 - pt, tw * ST_TW * 2 - pl);
     __syncthreads();
