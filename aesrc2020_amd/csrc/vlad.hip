@@ -209,6 +209,25 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, con
     const int lane = tid & 63, wave = tid >> 6;
     const int Dpad = ((D + 31) / 32) * 32;
     const bool vec = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    if (vec && Dpad <= 256) {                                         // one float4 per lane and row: eight rows per trip, loads first
+        const int d = lane * 4;                                       // (row by row this was 8-16 dependent L2 round trips per chunk)
+        for (int r0 = wave; r0 < nrows_tile; r0 += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + 4 * j;
+                const bool ok = r < rows && d < D;
+                v[j] = *reinterpret_cast<const float4*>(src + (ok ? (long)r * D + d : 0));
+                if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + 4 * j;
+                if (r < nrows_tile && d < Dpad) { float* dst = tile + r * ld + d; dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w; }
+            }
+        }
+        return;
+    }
     for (int r = wave; r < nrows_tile; r += 4) {
         float* dst = tile + r * ld;
         if (r < rows && vec) {
