@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     const int U = min(lab_len[b], maxU), S = 2 * U + 1, blank = V - 1;
     const float* p = probs + (long)b * L * V;
     const float* lab = labels + (long)b * maxU;
+    // the extended label sequence l' (blank, l1, blank, l2, ...) once into LDS: the recursion below reads it every frame, and a
+    // global (even L1-resident) load per frame sits in its critical path
+    __shared__ int xl[CTC_SMAX];
+    for (int s_ = threadIdx.x; s_ < 2 * min(lab_len[b], maxU) + 1; s_ += 256) xl[s_] = ext_label(lab, s_, V - 1);
     float* aw = alpha_ws + (long)b * L * Smax;
     float* ew = e_ws + (long)b * L * Smax;
     float* ld = logden_ws + (long)b * L;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     // (2) emissions of the extended label: e[t][s] = log y_t(l'_s), all (t, s) in parallel
     for (int i = tid; i < T * S; i += 256) {
         const int t = i / S, s_ = i - t * S;
-        const float e = logf(p[(long)t * V + ext_label(lab, s_, blank)] + CTC_EPS) - ld[t];
+        const float e = logf(p[(long)t * V + xl[s_]] + CTC_EPS) - ld[t];
         ew[(long)t * Smax + s_] = e;                                  // backward reads it from the workspace
         if (LDS_E) e_s[t * Smax + s_] = e;
     }
@@ -73,10 +77,10 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     for (int t = 1; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
         for (int s_ = tid; s_ < S; s_ += 256) {
-            const int k = ext_label(lab, s_, blank);
+            const int k = xl[s_];
             float a = al[prv][s_];
             if (s_ >= 1) a = lse2(a, al[prv][s_ - 1]);
-            if (s_ >= 2 && k != blank && k != ext_label(lab, s_ - 2, blank)) a = lse2(a, al[prv][s_ - 2]);
+            if (s_ >= 2 && k != blank && k != xl[s_ - 2]) a = lse2(a, al[prv][s_ - 2]);
             a += LDS_E ? e_s[t * Smax + s_] : ew[(long)t * Smax + s_];
             al[cur][s_] = a; aw[(long)t * Smax + s_] = a;
         }
@@ -109,6 +113,10 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
     int T = in_len[b]; if (T > L) T = L;
     const int U = min(lab_len[b], maxU), S = 2 * U + 1, blank = V - 1;
     const float* lab = labels + (long)b * maxU;
+    // the extended label sequence l' (blank, l1, blank, l2, ...) once into LDS: the recursion below reads it every frame, and a
+    // global (even L1-resident) load per frame sits in its critical path
+    __shared__ int xl[CTC_SMAX];
+    for (int s_ = threadIdx.x; s_ < 2 * min(lab_len[b], maxU) + 1; s_ += 256) xl[s_] = ext_label(lab, s_, V - 1);
     const float* aw = alpha_ws + (long)b * L * Smax;
     const float* ew = e_ws + (long)b * L * Smax;
     const float* ld = logden_ws + (long)b * L;
@@ -147,19 +155,19 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
             if (t == T - 1) {
                 bb = (s_ >= S - 2) ? 0.f : -INFINITY;
             } else {
-                const int k0 = ext_label(lab, s_, blank);
+                const int k0 = xl[s_];
                 const float e0 = LDS_E ? e_s[(t + 1) * Smax + s_] : ew[(long)(t + 1) * Smax + s_];
                 bb = be[nxt][s_] + e0;
                 if (s_ + 1 < S) bb = lse2(bb, be[nxt][s_ + 1] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 1] : ew[(long)(t + 1) * Smax + s_ + 1]));
                 if (s_ + 2 < S) {
-                    const int k2 = ext_label(lab, s_ + 2, blank);
+                    const int k2 = xl[s_ + 2];
                     if (k2 != blank && k2 != k0) bb = lse2(bb, be[nxt][s_ + 2] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 2] : ew[(long)(t + 1) * Smax + s_ + 2]));
                 }
             }
             be[cur][s_] = bb;
             const float c = LDS_E ? c_s[t * Smax + s_] : (aw[(long)t * Smax + s_] - ew[(long)t * Smax + s_] - ld[t] - ll);
             const float w = expf(c + bb);
-            if (w > 0.f) atomicAdd(&dp[(long)t * V + ext_label(lab, s_, blank)], -g * w);
+            if (w > 0.f) atomicAdd(&dp[(long)t * V + xl[s_]], -g * w);
         }
         __syncthreads();
     }
