@@ -61,11 +61,23 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     // (2) emissions of the extended label: e[t][s] = log y_t(l'_s), all (t, s) in parallel
-    for (int i = tid; i < T * S; i += 256) {
-        const int t = i / S, s_ = i - t * S;
-        const float e = logf(p[(long)t * V + xl[s_]] + CTC_EPS) - ld[t];
-        ew[(long)t * Smax + s_] = e;                                  // backward reads it from the workspace
-        if (LDS_E) e_s[t * Smax + s_] = e;
+    for (int i0 = tid; i0 < T * S; i0 += 4 * 256) {                   // four gathers in flight per thread
+        float pv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min(i0 + 256 * j, T * S - 1), t = i / S, s_ = i - t * S;
+            pv[j] = p[(long)t * V + xl[s_]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + 256 * j;
+            if (i < T * S) {
+                const int t = i / S, s_ = i - t * S;
+                const float e = logf(pv[j] + CTC_EPS) - ld[t];
+                ew[(long)t * Smax + s_] = e;                          // backward reads it from the workspace
+                if (LDS_E) e_s[t * Smax + s_] = e;
+            }
+        }
     }
     __syncthreads();
     // (3) alpha recursion
@@ -141,10 +153,21 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
     }
     if (!feasible) return;
     if (LDS_E) {
-        for (int i = tid; i < T * S; i += 256) {
-            const int t = i / S, s_ = i - t * S;
-            const float e = ew[(long)t * Smax + s_];
-            e_s[t * Smax + s_] = e; c_s[t * Smax + s_] = aw[(long)t * Smax + s_] - e - ld[t] - ll;
+        for (int i0 = tid; i0 < T * S; i0 += 4 * 256) {               // eight loads in flight per thread
+            float ev[4], av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = min(i0 + 256 * j, T * S - 1), t = i / S, s_ = i - t * S;
+                ev[j] = ew[(long)t * Smax + s_]; av[j] = aw[(long)t * Smax + s_];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + 256 * j;
+                if (i < T * S) {
+                    const int t = i / S, s_ = i - t * S;
+                    e_s[t * Smax + s_] = ev[j]; c_s[t * Smax + s_] = av[j] - ev[j] - ld[t] - ll;
+                }
+            }
         }
     }
     __syncthreads();                                                  // dense rows written before the atomics below
