@@ -53,8 +53,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        float* __restrict__ C, const float* __restrict__ bias, int M,
                                                        int N, int K, int lda, int ldb, int ldc, int act,
                                                        int accumulate, int splitk, float* __restrict__ colsum) {
-    __shared__ __attribute__((aligned(16))) float As[BK][LDP];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];
+    __shared__ __attribute__((aligned(16))) float As2[2][BK][LDP];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LDP];
+    float (*As)[LDP] = As2[0];
+    float (*Bs)[LDP] = Bs2[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -73,11 +75,52 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // gradient sum_rows dY comes for free with dW = X^T dY (B is dY) instead of a separate pass over dY
     const bool do_colsum = !B_KC && colsum != nullptr && blockIdx.y == 0;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (kt0 < kt1) {
+    // Interior blocks of aligned problems (every Dense / GRU-projection GEMM of the model): branch-free float4 loads, two
+    // register sets (a tile is loaded two tiles before its MFMAs), two LDS buffers and ONE barrier per k-tile, the staging of
+    // tile t+1 in the same basic block as the MFMAs of tile t; k-tiles past the end are staged as zeros so that the two-half
+    // loop has no conditional half.  (The generic loop below issues its loads 8 MFMAs = 512 cycles ahead of their use and
+    // waits on them with vmcnt(0) every tile.)
+    const bool fast = a_vec && b_vec && m0 + BM <= M && n0 + BN <= N && (K % BK) == 0 && kt0 < kt1;   // block-uniform
+    if (fast) {
+        const int last = kt1 - 1;
+        float4 fa[2], fb[2];
+        auto fload = [&](int set, int kt) {
+            const int k0 = min(kt, last) * BK;
+            if (A_KC) fa[set] = *reinterpret_cast<const float4*>(A + (long)(m0 + (tid >> 2)) * lda + k0 + (tid & 3) * 4);
+            else      fa[set] = *reinterpret_cast<const float4*>(A + (long)(k0 + (tid >> 4)) * lda + m0 + (tid & 15) * 4);
+            if (B_KC) fb[set] = *reinterpret_cast<const float4*>(B + (long)(n0 + (tid >> 2)) * ldb + k0 + (tid & 3) * 4);
+            else      fb[set] = *reinterpret_cast<const float4*>(B + (long)(k0 + (tid >> 4)) * ldb + n0 + (tid & 15) * 4);
+        };
+        auto fstore = [&](int set, int buf, int kt) {
+            const float live = kt <= last ? 1.f : 0.f;
+            const float4 a = fa[set], b = fb[set];
+            const float va[4] = {a.x * live, a.y * live, a.z * live, a.w * live}, vb[4] = {b.x * live, b.y * live, b.z * live, b.w * live};
+            store_tile<A_KC>(va, As2[buf], tid);
+            store_tile<B_KC>(vb, Bs2[buf], tid);
+            if (do_colsum) { cs[0] += vb[0]; cs[1] += vb[1]; cs[2] += vb[2]; cs[3] += vb[3]; }
+        };
+        auto fmma = [&](int buf) {
+#pragma unroll
+            for (int k = 0; k < BK; k += 2) {
+                const float a = As2[buf][k + (lane >> 5)][wm * 32 + (lane & 31)];
+                const float b = Bs2[buf][k + (lane >> 5)][wn * 32 + (lane & 31)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+        };
+        fload(0, kt0); fload(1, kt0 + 1);
+        fstore(0, 0, kt0); fload(0, kt0 + 2);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            fmma(0); fstore(1, 1, kt + 1); fload(1, kt + 3);
+            __syncthreads();
+            fmma(1); fstore(0, 0, kt + 2); fload(0, kt + 4);
+            __syncthreads();
+        }
+    } else if (kt0 < kt1) {
         load_tile<A_KC>(ra, A, lda, m0, kt0 * BK, M, K, tid, a_vec);
         load_tile<B_KC>(rb, B, ldb, n0, kt0 * BK, N, K, tid, b_vec);
     }
-    for (int kt = kt0; kt < kt1; ++kt) {
+    for (int kt = fast ? kt1 : kt0; kt < kt1; ++kt) {
         store_tile<A_KC>(ra, As, tid);
         store_tile<B_KC>(rb, Bs, tid);
         if (do_colsum) { cs[0] += rb[0]; cs[1] += rb[1]; cs[2] += rb[2]; cs[3] += rb[3]; }
