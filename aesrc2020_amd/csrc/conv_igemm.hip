@@ -428,7 +428,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
     const float relu_lo = p.scale ? 0.f : -INFINITY;                  // no BN+ReLU prologue: identity
     static_assert(!WP || (BNt == 64 && NT == 256 && BK == 32), "weight-plane staging: 64 columns x four 8-element chunks");
     const long wp_off = (long)min(n0 + (tid >> 2), p.Cout - 1) * K + (tid & 3) * 8;   // WP: column tid>>2, chunk tid&3
-    const bool wp_ok = n0 + (tid >> 2) < p.Cout;
     struct Regs { float4 ra[NA]; float rb[WP ? 1 : KPT]; u32x4 wh, wl; float4 sc, sh; unsigned vmask; };
     Regs R0, R1;                                                      // two sets: prefetch distance of two k-tiles
     R0.sc = R1.sc = make_float4(1, 1, 1, 1); R0.sh = R1.sh = zero4(); R0.vmask = R1.vmask = 0;
@@ -472,9 +471,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fwd_x3_kernel(ConvP p) {
             *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
         if constexpr (WP) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wh : z;
-            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z;
+            // a column past Cout / Cin re-reads the last valid one (clamped address): its products land in output columns the
+            // epilogue discards, so no zeroing select here (8 v_cndmask per k-tile)
+            *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = R.wh;
+            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = R.wl;
         } else {                                                     // B: KPT consecutive k of one column -> one row segment
             __bf16 hi[KPT], lo[KPT];
 #pragma unroll
@@ -694,7 +694,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
     const int b_row = min(n0 + b_n, p.Cin - 1);
     static_assert(!WP || (BNt == 64 && NT == 256 && BK == 32), "weight-plane staging: 64 rows x four 8-element chunks");
     const int wp_row = min(n0 + (tid >> 2), p.Cin - 1);
-    const bool wp_ok = n0 + (tid >> 2) < p.Cin;
     struct Regs { float4 ra[NA]; float4 rb[WP ? 1 : KPT / 4]; u32x4 wh, wl; unsigned vmask; };
     Regs R0, R1; R0.vmask = R1.vmask = 0;
     const int nkt_all = K / BK, per = ((nkt_all + p.splitk - 1) / p.splitk + 1) & ~1;   // split-K slices of whole tile pairs
@@ -730,9 +729,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dgrad_x3_kernel(DgradP p) {
             *reinterpret_cast<bf16x4*>(&Ah[buf][r][kq]) = hi; *reinterpret_cast<bf16x4*>(&Al[buf][r][kq]) = lo;
         }
         if constexpr (WP) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wh : z;
-            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = wp_ok ? R.wl : z;
+            // a column past Cout / Cin re-reads the last valid one (clamped address): its products land in output columns the
+            // epilogue discards, so no zeroing select here (8 v_cndmask per k-tile)
+            *reinterpret_cast<u32x4*>(&Bh[buf][tid >> 2][(tid & 3) * 8]) = R.wh;
+            *reinterpret_cast<u32x4*>(&Bl[buf][tid >> 2][(tid & 3) * 8]) = R.wl;
         } else {
 #pragma unroll
             for (int j = 0; j < KPT / 4; ++j) {
