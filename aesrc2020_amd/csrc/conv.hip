@@ -484,6 +484,7 @@ extern "C" int sar_bn_relu_maxpool_fwd_f32(const float* x, const float* scale, c
     return SAR_OK;
 }
 
+constexpr int POOL_RED_BLOCKS = 1024;   // partial rows of the reduction (= the rows a BN workspace holds): 4 blocks per CU for a bandwidth-bound pass
 // sums: the stem BN workspace (sar_bn_workspace_bytes(C)). dx may not alias x.  dx == NULL: only the two sums (the BatchNorm
 // parameter gradients; sar_stem_conv7x7_wgrad_poolbwd_f32 consumes them and never materialises dx).
 extern "C" int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out, const uint8_t* idx, const float* x,
@@ -494,8 +495,8 @@ extern "C" int sar_maxpool_bn_relu_bwd_f32(const float* dpool, const float* out,
     float* part = reinterpret_cast<float*>(sums + 2 * C);          // workspace layout of sar_bn_workspace_bytes(C)
     if ((long)B * H * W * (W > H ? W : H) >= (1L << 32)) return SAR_EINVAL;         // magic-number division exactness bound
     const auto magic = [](int d) { return (unsigned)(((1UL << 32) + d - 1) / d); };
-    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(256), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, shift, part, B, H, W, C, Ho, Wo, pad_top, pad_left, magic(Wo), magic(Ho));
-    hipLaunchKernelGGL(pool_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, 256, sums, 2 * C);
+    hipLaunchKernelGGL(maxpool_bn_relu_bwd_reduce_kernel, dim3(POOL_RED_BLOCKS), dim3(256), 0, stream, dpool, out, idx, x, mean, rstd, scale, shift, part, B, H, W, C, Ho, Wo, pad_top, pad_left, magic(Wo), magic(Ho));
+    hipLaunchKernelGGL(pool_combine_kernel, dim3(cdiv(2 * C, 4)), dim3(256), 0, stream, part, POOL_RED_BLOCKS, sums, 2 * C);
     if (C % 4) return SAR_EINVAL;
     if (!dx) { SAR_CHECK_LAUNCH(); return SAR_OK; }
     const long total = (long)B * H * W * (C / 4);
