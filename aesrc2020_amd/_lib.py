@@ -69,7 +69,7 @@ def call(name, *args, stream=None):
     L = lib()
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
-    conv = [a.data_ptr() if hasattr(a, "data_ptr") else a for a in args]
+    conv = [a.data_ptr() if hasattr(a, "data_ptr") else (ctypes.byref(a) if isinstance(a, ctypes.Structure) else a) for a in args]
     rc = L.fn[name](*conv, stream)
     if rc != 0:
         raise RuntimeError("%s failed with status %d (args=%r)" % (name, rc, [getattr(a, "shape", a) for a in args]))
@@ -87,6 +87,31 @@ def set_conv_math(mode):
 
 def get_conv_math():
     return {v: k for k, v in CONV_MATH.items()}[lib().fn["sar_get_conv_math"]()]
+
+
+# ---- activation storage of the conv trunk: "fp32" (round-1 kernels, conv math per set_conv_math) or "bf16" (conv_bf16.hip:
+# 2-byte activations / activation gradients, single-pass bf16 MFMA, fp32 statistics and weights).  Read when a model is built.
+_TRUNK_DTYPE = [os.environ.get("SAR_TRUNK_DTYPE", "fp32")]
+
+
+def set_trunk_dtype(dtype):
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError("trunk dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+    _TRUNK_DTYPE[0] = dtype
+
+
+def get_trunk_dtype():
+    return _TRUNK_DTYPE[0]
+
+
+class BnRef(ctypes.Structure):
+    """include/sarnet.h: sarBnRef."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("gamma", "beta", "bins", "bbins", "saved", "moving_mean", "moving_var", "dgamma", "dbeta")] + \
+               [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+def bn_bins():
+    return lib().fn["sar_bn_bins"]()
 
 
 def bn_workspace_doubles(C):

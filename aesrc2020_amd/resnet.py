@@ -50,6 +50,31 @@ class _BN:
         _call("sar_bn_stats_f32", x, self.gamma.w, self.beta.w, self.sums, self.mean, self.rstd, self.scale, self.shift,
               self.moving_mean.w, self.moving_var.w, R, C, BN_EPS, BN_MOMENTUM, 1)
 
+    # ---- bf16 trunk (csrc/conv_bf16.hip): statistics through bins of fp32 atomics, constants recomputed by every consumer
+    def prepare16(self, arena, off):
+        """Claim this BatchNorm's forward / backward bins in the trunk's statistics arena (zeroed once per step)."""
+        n = _lib.bn_bins() * 2 * self.C
+        self.bins, self.bbins = arena[off:off + n], arena[off + n:off + 2 * n]
+        self.saved = self._b("saved", (4, self.C))
+        return off + 2 * n
+
+    def ref(self, R, stats, write):
+        """sarBnRef for a consumer kernel.  stats: 'fwd' = batch statistics from the bins (training forward), 'saved' = the
+        saved mean/rstd/scale/shift (backward consumers; inference after fold16), 'bwd' = saved + backward sums."""
+        r = _lib.BnRef()
+        r.gamma, r.beta, r.saved = self.gamma.w.data_ptr(), self.beta.w.data_ptr(), self.saved.data_ptr()
+        r.bins = self.bins.data_ptr() if stats == "fwd" else None
+        r.bbins = self.bbins.data_ptr() if stats == "bwd" else None
+        r.moving_mean, r.moving_var = self.moving_mean.w.data_ptr(), self.moving_var.w.data_ptr()
+        r.dgamma, r.dbeta = self.gamma.g.data_ptr(), self.beta.g.data_ptr()
+        r.inv_n, r.unbias, r.eps, r.momentum = 1.0 / R, R / max(R - 1.0, 1.0), BN_EPS, BN_MOMENTUM
+        r.write = int(write)
+        return r
+
+    def fold16(self):
+        """Inference: moving averages -> saved scale/shift (rows 2, 3); consumers then run with stats='saved'."""
+        _call("sar_bn_fold_f32", self.gamma.w, self.beta.w, self.moving_mean.w, self.moving_var.w, self.saved[2], self.saved[3], self.C, BN_EPS)
+
     def bwd(self, dact, x, add, dx, R, relu=1):
         """dx = d/dx [relu](bn(x)) given dact; (+ add).  Parameter gradients accumulate."""
         _call("sar_bn_bwd_f32", dact, x, self.scale, self.shift, self.mean, self.rstd, self.sums, add, dx,
@@ -75,6 +100,32 @@ class _Conv:
         self.wt = tuple(b.get("%s/wt_%s" % (self.name, h), (self.cout, K), torch.bfloat16) for h in ("hi", "lo"))
         self.wd = tuple(b.get("%s/wd_%s" % (self.name, h), (K, self.cout), torch.bfloat16) for h in ("hi", "lo"))
         return [self.kernel.w.data_ptr()] + [t.data_ptr() for t in self.wt + self.wd] + [K, self.cout]
+
+    # ---- bf16 trunk
+    def streams16(self):
+        """Packed bf16 weight streams (forward, input gradient) + this conv's row of the pack table."""
+        taps = self.k * self.k
+        nf = (self.cout // 32) * (taps * self.cin // 16 + 8) * 512          # bf16 elements
+        nd = (self.cin // 32) * (taps * self.cout // 16 + 8) * 512
+        b = self.store.bufs
+        self.wf = b.get(self.name + "/wf16", (nf,), torch.bfloat16)
+        self.wd = b.get(self.name + "/wd16", (nd,), torch.bfloat16)
+        return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
+
+    def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None):
+        _call("sar_conv2d_bf16", x, None, self.wf, self.bias.w, res, y, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+              self.k, self.stride, 1, self.pt, self.pl, fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
+
+    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None):
+        """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2; the epilogue
+        leaves the backward sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
+        _call("sar_conv2d_bf16", dy, dy2, self.wd, None, res, dx, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
+              self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
+              e_bins, e_y, e_saved)
+
+    def wgrad16(self, x, a_fill, abn, dy, dy2, d_fill, dbn, B, bias_grad):
+        _call("sar_conv2d_wgrad_bf16", x, a_fill, abn, dy, dy2, d_fill, dbn, self.kernel.g, self.bias.g if bias_grad else None,
+              B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.stride, self.pt, self.pl)
 
     def out_hw(self, H, W):
         if self.padding == "same":
@@ -125,6 +176,10 @@ class ResNetTrunk(Layer):
         stem_c = filters if res_type == "res18" else 64                      # resnet.py:173 vs 191
         if stem_c > 64 or stem_c % 4:
             raise ValueError("stem width %d unsupported (<= 64, multiple of 4)" % stem_c)
+        self.bf16 = _lib.get_trunk_dtype() == "bf16"
+        if self.bf16 and (filters != 32 or stem_c not in (32, 64)):
+            raise ValueError("bf16 trunk: res_filters must be 32 (the reference's train.py:54 default; channel counts are powers of two "
+                             "in [32, 256], the 512-channel stage of F=64 does not fit the LDS patch); got %d" % filters)
         self.stem = _Conv(st, st.auto_name("conv2d"), 7, 1, stem_c, 2, "same")
         self.stem_bn = _BN(st, st.auto_name("batch_normalization"), stem_c)
         self.blocks = []
@@ -188,10 +243,127 @@ class ResNetTrunk(Layer):
             self._wblocks = blk0
         _call("sar_conv_weight_split_bf16", self._wtable, self._wtable.shape[0], self._wblocks)
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, x, B):
-        self.B, self.x = B, x
-        self.split_weights()
+    # ------------------------------------------------------------------ bf16 trunk (csrc/conv_bf16.hip)
+    def _all_convs(self):
+        return [cv for blk in self.blocks for cv in (blk["conv1"], blk["conv2"], blk["sc"]) if cv is not None]
+
+    def _all_bns(self):
+        return [bn for blk in self.blocks for bn in (blk["bn1"], blk["bn2"]) if bn is not None] + [self.final_bn]
+
+    def _setup16(self):
+        if getattr(self, "_pack_table", None) is not None:
+            return
+        rows, blk0 = [], 0
+        for cv in self._all_convs():
+            r, nb = cv.streams16()
+            rows.append(r + [blk0, 0]); blk0 += nb
+        self._pack_table = torch.tensor(rows, dtype=torch.int64, device="cuda")
+        self._pack_blocks = blk0
+        bns = self._all_bns()
+        n = sum(4 * _lib.bn_bins() * bn.C for bn in bns)
+        self._arena = self.store.bufs.get(self.name + "/bn_arena", (n,))
+        off = 0
+        for bn in bns:
+            off = bn.prepare16(self._arena, off)
+
+    def _buf16(self, key, shape):
+        return self.buf(key, shape, torch.bfloat16)
+
+    def _forward16(self, x, B):
+        """Same graph as forward() on bf16 activations: one launch per conv (BN+ReLU of the producer evaluated in the conv's
+        patch fill from the statistic bins; statistics of the consumer BN out of the epilogue), stem on the fp32 kernels."""
+        self._setup16()
+        training = self.store.training
+        _call("sar_conv_pack_weights_bf16", self._pack_table, self._pack_table.shape[0], self._pack_blocks)
+        if training:
+            _call("sar_fill_f32", self._arena, 0.0, self._arena.numel())
+        else:
+            for bn in self._all_bns():
+                bn.fold16()
+        pooled = self._stem_forward(x, B)
+        Hp, Wp = self.pool_hw
+        c0 = self.stem.cout
+        cur = self._buf16("pooled16", (B, Hp, Wp, c0))
+        _call("sar_cast_f32_bf16", pooled, cur, pooled.numel())
+        st = "fwd" if training else "saved"
+        nblk = len(self.blocks)
+        for n, blk in enumerate(self.blocks):
+            H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
+            cout = blk["cout"]
+            blk["x"] = cur
+            bn1, bn2 = blk["bn1"], blk["bn2"]
+            c1 = self._buf16("b%d_c1" % n, (B, H2, W2, cout))
+            blk["conv1"].fwd16(cur, c1, B, fill=1 if bn1 is not None else 0, fbn=bn1.ref(B * H * W, st, training) if bn1 is not None else None,
+                               e_bins=bn2.bins if training else None)
+            if blk["sc"] is not None:
+                sc = self._buf16("b%d_sc" % n, (B, H2, W2, cout))
+                blk["sc"].fwd16(cur, sc, B)
+            else:
+                sc = cur
+            y = self._buf16("b%d_y" % n, (B, H2, W2, cout))
+            nxt = self.blocks[n + 1]["bn1"] if n + 1 < nblk else self.final_bn
+            blk["conv2"].fwd16(c1, y, B, fill=1, fbn=bn2.ref(B * H2 * W2, st, training), res=sc, e_bins=nxt.bins if training else None)
+            blk["c1"] = c1
+            cur = y
+        H, W = self.out_hw
+        self.pre_final = cur
+        out = self.buf("out", (B, H, W, self.out_c))
+        _call("sar_bn_apply_bf16_f32", cur, self.final_bn.ref(B * H * W, st, training), out, B * H * W, self.out_c, 1)
+        return out
+
+    def _backward16(self, dy, part):
+        B = self.B
+        if part in (None, 0):
+            H, W = self.out_hw
+            fb = self.final_bn
+            R = B * H * W
+            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), torch.bfloat16)
+            _call("sar_bn_bwd_reduce_bf16", dy, 1, self.pre_final, fb.saved, fb.bbins, R, self.out_c, 1)
+            _call("sar_bn_bwd_apply_bf16", dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1)
+        else:
+            g = self._g_part
+        stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
+        bf = torch.bfloat16
+        for n in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[n]
+            if blk["stage"] not in stages:
+                continue
+            H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
+            cin, cout = blk["cin"], blk["cout"]
+            R1, R2 = B * H * W, B * H2 * W2
+            bn1, bn2, c1, x = blk["bn1"], blk["bn2"], blk["c1"], blk["x"]
+            # conv2: operand relu(bn2(c1)); its input gradient da2 leaves the two sums of bn2's backward in bn2.bbins
+            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
+            blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
+            blk["conv2"].wgrad16(c1, 1, bn2.ref(R2, "saved", False), g, None, 0, None, B, bias_grad=True)
+            # conv1's output gradient dc1 = BN+ReLU backward of (da2, c1) is never materialised: both consumers evaluate it in
+            # their fills; the weight-gradient launch owns bn2's parameter gradients
+            blk["conv1"].wgrad16(x, 1 if bn1 is not None else 0, bn1.ref(R1, "saved", False) if bn1 is not None else None,
+                                 da2, c1, 2, bn2.ref(R2, "bwd", True), B, bias_grad=False)
+            gin = self.scratch("res16_gin%d_%dx%dx%d" % (n & 1, H, W, cin), (B, H, W, cin), bf)       # ping-pong: never aliases g
+            if blk["sc"] is not None:
+                dsc = gin if bn1 is None else self.scratch("res16_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
+                blk["sc"].dgrad16(g, None, dsc, B)
+                blk["sc"].wgrad16(x, 0, None, g, None, 0, None, B, bias_grad=True)
+            else:
+                dsc = g
+            if bn1 is not None:
+                da1 = self.scratch("res16_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
+                blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved)
+                _call("sar_bn_bwd_apply_bf16", da1, 0, x, bn1.ref(R1, "bwd", True), dsc, gin, R1, cin, 1)
+            else:
+                # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
+                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=dsc)
+            g = gin
+        self._g_part = g
+        if part in (0, 1):
+            return None
+        g32 = self.scratch("res16_g32", tuple(g.shape))
+        _call("sar_cast_bf16_f32", g, g32, g.numel())
+        self._stem_backward(g32, B)
+        return None
+
+    def _stem_forward(self, x, B):
         T, D = self.in_hw
         H, W = self.stem_hw
         c0 = self.stem.cout
@@ -209,6 +381,30 @@ class ResNetTrunk(Layer):
         self.pooled = self.buf("pooled", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
         _call("sar_bn_relu_maxpool_fwd_f32", self.stem_out, self.stem_bn.scale, self.stem_bn.shift, self.pooled, self.pool_idx,
               B, H, W, c0, Hp, Wp, self.pool_pt, self.pool_pl)
+        return self.pooled
+
+    def _stem_backward(self, g, B):
+        """maxpool + BN + ReLU backward, then the 7x7 weight gradient (no input gradient needed); g fp32 (B,Hp,Wp,c0)."""
+        Hs, Ws = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
+        sb = self.stem_bn
+        # the full-resolution gradient (131 MB at B=64) is never written: the two BatchNorm sums first (dx = None), then the
+        # weight gradient evaluates the pooling/BatchNorm backward tile by tile
+        _call("sar_maxpool_bn_relu_bwd_f32", g, self.pooled, self.pool_idx, self.stem_out, sb.mean, sb.rstd, sb.scale, sb.shift, sb.sums,
+              None, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
+        _call("sar_bn_param_grads_f32", sb.sums, sb.gamma.g, sb.beta.g, c0)
+        T, D = self.in_hw
+        # the stem bias feeds a BatchNorm: its gradient is exactly zero, so db is not computed (None)
+        _call("sar_stem_conv7x7_wgrad_poolbwd_f32", self.x, self.stem_out, g, self.pooled, self.pool_idx, sb.mean, sb.rstd, sb.scale,
+              sb.sums, self.stem.kernel.g, None, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl, Hp, Wp, self.pool_pt, self.pool_pl)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, B):
+        self.B, self.x = B, x
+        if self.bf16:
+            return self._forward16(x, B)
+        self.split_weights()
+        self._stem_forward(x, B)
+        c0 = self.stem.cout
         cur = self.pooled
         # training: every conv also produces the batch statistics of the BatchNorm that consumes its output (no separate
         # pass over the activation); inference: the moving averages are folded instead (stats() does that)
@@ -258,6 +454,8 @@ class ResNetTrunk(Layer):
 
     def backward(self, dy, part=None):
         """part None: the whole backward; 0/1/2: one part (see above), dy only read by part 0."""
+        if self.bf16:
+            return self._backward16(dy, part)
         B = self.B
         if part in (None, 0):
             H, W = self.out_hw
@@ -303,18 +501,7 @@ class ResNetTrunk(Layer):
         self._g_part = g
         if part in (0, 1):
             return None
-        # stem: maxpool + BN + ReLU backward, then the 7x7 weight gradient (no input gradient needed)
-        Hs, Ws = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
-        sb = self.stem_bn
-        # the full-resolution gradient (131 MB at B=64) is never written: the two BatchNorm sums first (dx = None), then the
-        # weight gradient evaluates the pooling/BatchNorm backward tile by tile
-        _call("sar_maxpool_bn_relu_bwd_f32", g, self.pooled, self.pool_idx, self.stem_out, sb.mean, sb.rstd, sb.scale, sb.shift, sb.sums,
-              None, B, Hs, Ws, c0, Hp, Wp, self.pool_pt, self.pool_pl)
-        _call("sar_bn_param_grads_f32", sb.sums, sb.gamma.g, sb.beta.g, c0)
-        T, D = self.in_hw
-        # the stem bias feeds a BatchNorm: its gradient is exactly zero, so db is not computed (None)
-        _call("sar_stem_conv7x7_wgrad_poolbwd_f32", self.x, self.stem_out, g, self.pooled, self.pool_idx, sb.mean, sb.rstd, sb.scale,
-              sb.sums, self.stem.kernel.g, None, B, T, D, Hs, Ws, c0, self.stem.pt, self.stem.pl, Hp, Wp, self.pool_pt, self.pool_pl)
+        self._stem_backward(g, B)
         return None
 
 

@@ -114,6 +114,56 @@ int sar_stem_conv7x7_wgrad_poolbwd_f32(const float* x, const float* y, const flo
                                        int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left,
                                        sarStream_t stream);
 
+/* ---- bf16 trunk (BASELINE configs[1] "bf16"): the same ResNet layers (resnet.py:22-125) on 2-byte NHWC activations and
+ * activation gradients; fp32 master weights, BatchNorm statistics and MFMA accumulation.  `void*` tensors are bf16.
+ * BatchNorm statistics travel through per-layer bins of fp32 atomics: NB = sar_bn_bins() rows of [sum | sum of squares]
+ * (forward) or [sum dz | sum dz*xhat] (backward), zeroed by the caller once per step; every consumer sums the rows itself,
+ * so there are no finalize / combine / apply launches. */
+typedef struct sarBnRef {      /* one BatchNormalization (resnet.py:25) as a consumer kernel sees it; host struct of device pointers */
+    const float* gamma; const float* beta;
+    const float* bins;         /* forward sums [NB][2][C] of the BN input, or NULL: take mean/rstd/scale/shift from `saved` */
+    const float* bbins;        /* backward sums [NB][2][C] */
+    float* saved;              /* [4][C]: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale */
+    float* moving_mean; float* moving_var;   /* updated (momentum, Bessel-corrected variance) when `write` and bins != NULL */
+    float* dgamma; float* dbeta;             /* += when `write` in a backward consumer (nullable) */
+    float inv_n, unbias, eps, momentum;      /* 1/rows, rows/(rows-1) */
+    int write;                 /* this launch owns the side effects (block 0 performs them) */
+    int pad_;
+} sarBnRef;
+int sar_bn_bins(void);
+/* Kernels of many convolutions (fp32 HWIO) -> the bf16 fragment streams sar_conv2d_bf16 reads, one launch.  table = device
+ * array of n rows of 8 x int64: {w, wf (forward stream), wd (input-gradient stream: transposed, taps flipped), KH*KW, Cin,
+ * Cout, first_block, 0}; stream sizes: wf = (Cout/32)*(KH*KW*Cin/16 + 8)*1024 bytes, wd = (Cin/32)*(KH*KW*Cout/16 + 8)*1024;
+ * blocks per row = ceil((wf + wd bytes)/16/256), first_block = running sum.  Once per optimiser step. */
+int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarStream_t stream);
+/* Generic bf16 convolution, forward (resnet.py:39-42, 60-63, 82-87, 113-117) and input gradient in one kernel:
+ *   y[B*Ho*Wo][Cout] = sum_taps T(src)[padded position] * wpk (+ bias) (+ res)
+ * fill 0: T = identity; 1: T = relu(bn(.)) of fbn (statistics from fbn->bins, or fbn->saved when bins is NULL: inference /
+ * recompute); 2: T = BatchNorm+ReLU backward of (da = src, y = src2) through fbn (sums from fbn->bbins).
+ * epi 0: none; 1: sum and sum of squares of y into e_bins (the statistics of the BatchNorm that consumes y); 2: the two
+ * BatchNorm-backward sums of y (= da) against (e_y = that BN's input, e_saved) into e_bins.
+ * Forward: d = 1, s = stride, pt/pl = TF pads, wpk = wf.  Input gradient: src = dy, Hs/Ws = its size, d = stride, s = 1,
+ * Ho/Wo = the forward INPUT size, pt = K-1-pad_top, pl = K-1-pad_left, wpk = wd.  K in {1,3}; Cin, Cout powers of two in
+ * [32, 512]. */
+int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, int B,
+                    int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
+/* Kernel gradient dw[K][K][Cin][Cout] += T_a(x)^T (*) T_d(dy) (fp32 atomics), dbias (nullable) += column sums of T_d(dy).
+ * a_fill 0 | 1 (relu(bn(x)) with abn->saved); d_fill 0 | 2 (BatchNorm+ReLU backward of (da = dy, y = dy2) through dbn). */
+int sar_conv2d_wgrad_bf16(const void* x, int a_fill, const sarBnRef* abn, const void* dy, const void* dy2, int d_fill,
+                          const sarBnRef* dbn, float* dw, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                          int K, int s, int pt, int pl, sarStream_t stream);
+/* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
+int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
+                          int C, int relu, sarStream_t stream);
+/* bbins += the two BatchNorm(+ReLU) backward sums for a gradient that does not come out of a conv epilogue (the final BN) */
+int sar_bn_bwd_reduce_bf16(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
+                           sarStream_t stream);
+/* out (fp32) = [relu](bn(x)) for bf16 x: the trunk's final BN+ReLU (resnet.py:178-181) feeding the fp32 sequence layers */
+int sar_bn_apply_bf16_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, sarStream_t stream);
+int sar_cast_f32_bf16(const float* x, void* y, long n, sarStream_t stream);   /* n % 8 == 0 */
+int sar_cast_bf16_f32(const void* x, float* y, long n, sarStream_t stream);
+
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a
  * backward) followed by per-block fp32 partials; two-stage reduction, no atomics, no zeroing required. */

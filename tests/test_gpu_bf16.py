@@ -1,0 +1,349 @@
+"""GPU parity tests of the bf16 trunk kernels (csrc/conv_bf16.hip) against the CPU oracle (oracle/ops_np.py, float64).
+
+Inputs are drawn on the bf16 grid (activations, gradients) or rounded to it exactly as the kernels do (weights, the
+BatchNorm+ReLU / BatchNorm-backward transforms evaluated in the patch fill), so products are exact in fp32 and the only
+differences left are fp32 accumulation order and the final bf16 rounding of stored tensors:
+  stored bf16 tensors : |err| <= 4e-3 of the reference's max-abs (half an ulp is 2^-9 = 2e-3 relative)
+  fp32 outputs        : weight gradients, statistics  <= 1e-3 / 1e-4 of max-abs
+Every distinct conv shape of the bench configuration (res34, F=32, 400x80, B=64) is covered, fwd + dgrad + wgrad.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_np as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+TOL_BF, TOL_F32 = 4e-3, 1e-3
+
+
+@pytest.fixture(scope="module")
+def L():
+    from aesrc2020_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    _lib.lib()
+    return _lib
+
+
+def rbf(a):
+    """numpy -> values rounded to the bf16 grid (float64)."""
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).to(BF).double().numpy()
+
+
+def dbf(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).to(BF).cuda()
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+
+
+def val(t):
+    return t.detach().float().cpu().double().numpy()
+
+
+def check(got, ref, tol, name):
+    got = val(got) if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert np.all(np.isfinite(got)), name
+    err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-9)
+    assert err <= tol, "%s: rel-to-max error %.3e > %.1e" % (name, err, tol)
+
+
+class Conv:
+    """Host mirror of one conv layer: packs the weight streams with the library and knows the TF geometry."""
+
+    def __init__(self, L, w, stride, padding):
+        self.L, self.w, self.s = L, np.asarray(w, np.float32), stride
+        self.k, _, self.cin, self.cout = w.shape
+        self.padding = padding
+        taps = self.k * self.k
+        nf = (self.cout // 32) * (taps * self.cin // 16 + 8) * 512
+        nd = (self.cin // 32) * (taps * self.cout // 16 + 8) * 512
+        self.wdev = dev(self.w)
+        self.wf = torch.zeros(nf, dtype=BF, device="cuda"); self.wd = torch.zeros(nd, dtype=BF, device="cuda")
+        nb = -(-(nf + nd) // 8 // 256)
+        tab = torch.tensor([[self.wdev.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout, 0, 0]],
+                           dtype=torch.int64, device="cuda")
+        L.call("sar_conv_pack_weights_bf16", tab, 1, nb)
+        self.wq = rbf(self.w)                                   # what the kernels multiply with
+
+    def geo(self, H, W):
+        if self.padding == "same":
+            (ho, pt, _), (wo, pl, _) = O.same_pads(H, self.k, self.s), O.same_pads(W, self.k, self.s)
+        else:
+            ho, wo, pt, pl = O.valid_out(H, self.k, self.s), O.valid_out(W, self.k, self.s), 0, 0
+        return ho, wo, pt, pl
+
+    def fwd(self, x, bias=None, res=None, fill=0, fbn=None, e_bins=None):
+        B, H, W, _ = x.shape
+        ho, wo, pt, pl = self.geo(H, W)
+        y = torch.empty(B, ho, wo, self.cout, dtype=BF, device="cuda")
+        self.L.call("sar_conv2d_bf16", x, None, self.wf, bias, res, y, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, 1, pt, pl,
+                    fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
+        return y
+
+    def dgrad(self, dy, H, W, dy2=None, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None):
+        B, ho, wo, _ = dy.shape
+        _, _, pt, pl = self.geo(H, W)
+        dx = torch.empty(B, H, W, self.cin, dtype=BF, device="cuda")
+        self.L.call("sar_conv2d_bf16", dy, dy2, self.wd, None, res, dx, B, ho, wo, self.cout, H, W, self.cin, self.k, 1, self.s,
+                    self.k - 1 - pt, self.k - 1 - pl, fill, fbn, 2 if e_bins is not None else 0, e_bins, e_y, e_saved)
+        return dx
+
+    def wgrad(self, x, dy, a_fill=0, abn=None, dy2=None, d_fill=0, dbn=None, bias=True):
+        B, H, W, _ = x.shape
+        ho, wo, pt, pl = self.geo(H, W)
+        dw = torch.zeros(self.k, self.k, self.cin, self.cout, device="cuda"); db = torch.zeros(self.cout, device="cuda")
+        self.L.call("sar_conv2d_wgrad_bf16", x, a_fill, abn, dy, dy2, d_fill, dbn, dw, db if bias else None, B, H, W, self.cin, ho, wo,
+                    self.cout, self.k, self.s, pt, pl)
+        return dw, db
+
+
+class BN:
+    """Host mirror of one BatchNorm: device state + float64 reference of the constants the kernels derive."""
+    EPS, MOM = 1e-3, 0.99
+
+    def __init__(self, L, C, rng):
+        self.L, self.C = L, C
+        self.NB = L.bn_bins()
+        self.gamma = rng.uniform(0.5, 1.5, C).astype(np.float32); self.beta = (0.3 * rng.standard_normal(C)).astype(np.float32)
+        self.d = dict(gamma=dev(self.gamma), beta=dev(self.beta), bins=torch.zeros(self.NB, 2, C, device="cuda"),
+                      bbins=torch.zeros(self.NB, 2, C, device="cuda"), saved=torch.zeros(4, C, device="cuda"),
+                      mm=torch.zeros(C, device="cuda"), mv=torch.ones(C, device="cuda"), dg=torch.zeros(C, device="cuda"),
+                      db=torch.zeros(C, device="cuda"))
+
+    def ref(self, R, stats, write):
+        r = self.L.BnRef()
+        d = self.d
+        r.gamma, r.beta, r.saved = d["gamma"].data_ptr(), d["beta"].data_ptr(), d["saved"].data_ptr()
+        r.bins = d["bins"].data_ptr() if stats == "fwd" else None
+        r.bbins = d["bbins"].data_ptr() if stats == "bwd" else None
+        r.moving_mean, r.moving_var, r.dgamma, r.dbeta = d["mm"].data_ptr(), d["mv"].data_ptr(), d["dg"].data_ptr(), d["db"].data_ptr()
+        r.inv_n, r.unbias, r.eps, r.momentum, r.write = 1.0 / R, R / max(R - 1.0, 1.0), self.EPS, self.MOM, int(write)
+        return r
+
+    def set_fwd_stats(self, x):
+        """Fill the forward bins as a producer conv's epilogue would (split over two bins) and the f64 constants."""
+        x2 = x.reshape(-1, self.C)
+        s1, s2 = x2.sum(0), (x2 * x2).sum(0)
+        bins = np.zeros((self.NB, 2, self.C), np.float32)
+        bins[3, 0], bins[3, 1] = 0.25 * s1, 0.25 * s2
+        bins[11, 0], bins[11, 1] = s1 - bins[3, 0].astype(np.float64), s2 - bins[3, 1].astype(np.float64)
+        self.d["bins"].copy_(dev(bins))
+        n = x2.shape[0]
+        self.mean = s1 / n; self.var = np.maximum(s2 / n - self.mean ** 2, 0.0)
+        self.rstd = 1.0 / np.sqrt(self.var + self.EPS)
+        self.scale = self.gamma * self.rstd; self.shift = self.beta - self.mean * self.scale
+        self.n = n
+
+    def set_saved(self):
+        self.d["saved"].copy_(dev(np.stack([self.mean, self.rstd, self.scale, self.shift])))
+
+    def act(self, x):
+        """relu(bn(x)) as the fill computes it, on the bf16 grid."""
+        s, h = self.scale.astype(np.float32).astype(np.float64), self.shift.astype(np.float32).astype(np.float64)
+        return rbf(np.maximum(x * s + h, 0.0))
+
+    def bwd_sums(self, da, y):
+        y2, d2 = y.reshape(-1, self.C), da.reshape(-1, self.C)
+        s, h = self.scale.astype(np.float32).astype(np.float64), self.shift.astype(np.float32).astype(np.float64)
+        dz = np.where(y2 * s + h > 0, d2, 0.0)
+        xh = (y2 - self.mean.astype(np.float32)) * self.rstd.astype(np.float32)
+        return dz.sum(0), (dz * xh).sum(0), dz, xh
+
+    def set_bwd_stats(self, da, y):
+        S1, S2, dz, xh = self.bwd_sums(da, y)
+        bb = np.zeros((self.NB, 2, self.C), np.float32)
+        bb[5, 0], bb[5, 1] = S1, S2
+        self.d["bbins"].copy_(dev(bb))
+        self.S1, self.S2 = S1, S2
+        return dz, xh
+
+    def dx(self, da, y):
+        """BatchNorm+ReLU backward as the fills / apply pass compute it (float64 on the same constants)."""
+        S1, S2, dz, xh = self.bwd_sums(da, y)
+        n = dz.shape[0]
+        out = self.scale.astype(np.float32).astype(np.float64) * (dz - np.float32(S1 / n) - xh * np.float32(S2 / n))
+        return out.reshape(da.shape)
+
+
+# every distinct 3x3 / 1x1 conv of the bench trunk (res34, F=32, T=400: pooled map 100x20x64) + small ragged cases
+SHAPES = [
+    # B, H, W, Cin, Cout, k, stride, padding
+    (2, 9, 7, 32, 32, 3, 1, "same"),
+    (3, 13, 3, 64, 64, 3, 1, "same"),                # several images per pixel tile
+    (5, 13, 3, 256, 256, 3, 1, "same"),
+    (2, 11, 20, 32, 64, 3, 2, "same"),               # odd height, stride 2
+    (2, 10, 6, 64, 128, 1, 2, "valid"),
+    (1, 4, 4, 512, 512, 3, 1, "same"),               # two channel halves per tap
+    (64, 100, 20, 64, 32, 3, 1, "same"),             # stage 0, block 0 conv1
+    (64, 100, 20, 64, 32, 1, 1, "valid"),            # stage 0 shortcut
+    (64, 100, 20, 32, 32, 3, 1, "same"),             # stage 0
+    (64, 100, 20, 32, 64, 3, 2, "same"),             # stage 1 entry
+    (64, 100, 20, 32, 64, 1, 2, "valid"),
+    (64, 50, 10, 64, 64, 3, 1, "same"),              # stage 1
+    (64, 50, 10, 64, 128, 3, 2, "same"),             # stage 2 entry
+    (64, 50, 10, 64, 128, 1, 2, "valid"),
+    (64, 25, 5, 128, 128, 3, 1, "same"),             # stage 2
+    (64, 25, 5, 128, 256, 3, 2, "same"),             # stage 3 entry
+    (64, 25, 5, 128, 256, 1, 2, "valid"),
+    (64, 13, 3, 256, 256, 3, 1, "same"),             # stage 3
+]
+def _ids(shapes):
+    return ["%dx%dx%dx%d-%d_k%d_s%d" % s[:7] for s in shapes]
+
+
+IDS = _ids(SHAPES)
+SOME = SHAPES[:6] + SHAPES[6::4]                  # the fill variants: all small cases + every fourth bench shape
+IDS_SOME = _ids(SOME)
+
+
+def grid(rng, shape, scale=1.0):
+    return rbf(scale * rng.standard_normal(shape))
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_conv_fwd_plain_residual_and_statistics(L, shape):
+    B, H, W, Cin, Cout, k, s, pad = shape
+    rng = np.random.default_rng(sum(shape[:7]))
+    x = grid(rng, (B, H, W, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    cv = Conv(L, w, s, pad)
+    ref, _ = O.conv2d_fwd(x, cv.wq, bias, (s, s), pad)
+    res = grid(rng, ref.shape)
+    bins = torch.zeros(L.bn_bins(), 2, Cout, device="cuda")
+    y = cv.fwd(dbf(x), dev(bias), dbf(res), e_bins=bins)
+    check(y, ref + res, TOL_BF, "y")
+    yv = val(y).reshape(-1, Cout)
+    tot = val(bins).sum(0)
+    check(tot[0], yv.sum(0), 1e-4, "sum(y)"); check(tot[1], (yv * yv).sum(0), 1e-4, "sum(y^2)")
+    y2 = cv.fwd(dbf(x), None, None)
+    check(y2, ref - bias, TOL_BF, "y (no bias / residual)")
+
+
+@pytest.mark.parametrize("shape", SOME, ids=IDS_SOME)
+def test_conv_fwd_with_batchnorm_relu_in_the_fill(L, shape):
+    B, H, W, Cin, Cout, k, s, pad = shape
+    rng = np.random.default_rng(1 + sum(shape[:7]))
+    x = grid(rng, (B, H, W, Cin)) + rbf(0.5 * rng.standard_normal(Cin))
+    x = rbf(x)
+    w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+    cv = Conv(L, w, s, pad); bn = BN(L, Cin, rng)
+    bn.set_fwd_stats(x)
+    ref, _ = O.conv2d_fwd(bn.act(x), cv.wq, None, (s, s), pad)
+    y = cv.fwd(dbf(x), None, None, fill=1, fbn=bn.ref(bn.n, "fwd", True))
+    check(y, ref, TOL_BF, "y")
+    check(bn.d["saved"], np.stack([bn.mean, bn.rstd, bn.scale, bn.shift]), 1e-5, "saved mean/rstd/scale/shift")
+    check(bn.d["mm"], (1 - BN.MOM) * bn.mean, 1e-5, "moving mean")
+    check(bn.d["mv"], BN.MOM + (1 - BN.MOM) * bn.var * bn.n / (bn.n - 1.0), 1e-5, "moving variance (Bessel)")
+    # the same through the saved constants (backward consumers, inference): no further side effects
+    y2 = cv.fwd(dbf(x), None, None, fill=1, fbn=bn.ref(bn.n, "saved", False))
+    assert torch.equal(y, y2)
+    check(bn.d["mm"], (1 - BN.MOM) * bn.mean, 1e-5, "moving mean untouched")
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_conv_dgrad_plain_and_batchnorm_sums(L, shape):
+    B, H, W, Cin, Cout, k, s, pad = shape
+    rng = np.random.default_rng(2 + sum(shape[:7]))
+    w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cout)
+    cv = Conv(L, w, s, pad)
+    ho, wo, _, _ = cv.geo(H, W)
+    x0 = np.zeros((B, H, W, Cin))
+    _, cache = O.conv2d_fwd(x0, cv.wq, None, (s, s), pad)
+    dy = grid(rng, (B, ho, wo, Cout))
+    ref = O.conv2d_bwd(dy, cache)[0]
+    res = grid(rng, ref.shape)
+    dx = cv.dgrad(dbf(dy), H, W, res=dbf(res))
+    check(dx, ref + res, TOL_BF, "dx + res")
+    # epilogue sums of the BatchNorm in front of the conv (input xin), against the stored dx
+    bn = BN(L, Cin, rng)
+    xin = rbf(grid(rng, (B, H, W, Cin)) + 0.3)
+    bn.set_fwd_stats(xin); bn.set_saved()
+    dx2 = cv.dgrad(dbf(dy), H, W, e_bins=bn.d["bbins"], e_y=dbf(xin), e_saved=bn.d["saved"])
+    check(dx2, ref, TOL_BF, "dx")
+    S1, S2, _, _ = bn.bwd_sums(val(dx2), xin)
+    tot = val(bn.d["bbins"]).sum(0)
+    check(tot[0], S1, 2e-4, "sum dz"); check(tot[1], S2, 2e-4, "sum dz*xhat")
+
+
+@pytest.mark.parametrize("shape", SOME, ids=IDS_SOME)
+def test_conv_dgrad_with_batchnorm_backward_in_the_fill(L, shape):
+    B, H, W, Cin, Cout, k, s, pad = shape
+    rng = np.random.default_rng(3 + sum(shape[:7]))
+    w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cout)
+    cv = Conv(L, w, s, pad)
+    ho, wo, _, _ = cv.geo(H, W)
+    _, cache = O.conv2d_fwd(np.zeros((B, H, W, Cin)), cv.wq, None, (s, s), pad)
+    da = grid(rng, (B, ho, wo, Cout)); yb = rbf(grid(rng, (B, ho, wo, Cout)) + 0.2)
+    bn = BN(L, Cout, rng)
+    bn.set_fwd_stats(yb); bn.set_saved(); bn.set_bwd_stats(da, yb)
+    dyq = rbf(bn.dx(da, yb))                                    # what the fill writes to LDS
+    ref = O.conv2d_bwd(dyq, cache)[0]
+    dx = cv.dgrad(dbf(da), H, W, dy2=dbf(yb), fill=2, fbn=bn.ref(bn.n, "bwd", True))
+    check(dx, ref, TOL_BF, "dx")
+    check(bn.d["dg"], bn.S2, 1e-5, "dgamma"); check(bn.d["db"], bn.S1, 1e-5, "dbeta")
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_conv_wgrad_all_fills(L, shape):
+    B, H, W, Cin, Cout, k, s, pad = shape
+    rng = np.random.default_rng(4 + sum(shape[:7]))
+    w = rng.standard_normal((k, k, Cin, Cout))
+    cv = Conv(L, w, s, pad)
+    ho, wo, _, _ = cv.geo(H, W)
+    x = rbf(grid(rng, (B, H, W, Cin)) + 0.4); dy = grid(rng, (B, ho, wo, Cout))
+    _, cache = O.conv2d_fwd(x, cv.wq, np.zeros(Cout), (s, s), pad)
+    _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+    dw, db = cv.wgrad(dbf(x), dbf(dy))
+    check(dw, dw_ref, TOL_F32, "dw plain"); check(db, db_ref, TOL_F32, "db plain")
+    # activation side through BN+ReLU, gradient side through the BatchNorm backward
+    bna = BN(L, Cin, rng); bna.set_fwd_stats(x); bna.set_saved()
+    yb = rbf(grid(rng, dy.shape) - 0.1)
+    bnd = BN(L, Cout, rng); bnd.set_fwd_stats(yb); bnd.set_saved(); bnd.set_bwd_stats(dy, yb)
+    _, cache = O.conv2d_fwd(bna.act(x), cv.wq, np.zeros(Cout), (s, s), pad)
+    _, dw_ref, db_ref = O.conv2d_bwd(rbf(bnd.dx(dy, yb)), cache)
+    dw, db = cv.wgrad(dbf(x), dbf(dy), a_fill=1, abn=bna.ref(bna.n, "saved", False), dy2=dbf(yb), d_fill=2, dbn=bnd.ref(bnd.n, "bwd", True))
+    check(dw, dw_ref, TOL_F32, "dw bn/bn-bwd"); check(db, db_ref, TOL_F32, "db bn-bwd", )
+    check(bnd.d["dg"], bnd.S2, 1e-5, "dgamma"); check(bnd.d["db"], bnd.S1, 1e-5, "dbeta")
+    dw2, _ = cv.wgrad(dbf(x), dbf(dy), a_fill=1, abn=bna.ref(bna.n, "saved", False), bias=False)
+    _, dw_ref2, _ = O.conv2d_bwd(dy, cache)
+    check(dw2, dw_ref2, TOL_F32, "dw bn/plain")
+
+
+@pytest.mark.parametrize("R,C", [(2496, 256), (77, 32), (128000, 32), (8000, 128), (5, 512)])
+def test_batchnorm_passes(L, R, C):
+    rng = np.random.default_rng(R + C)
+    x = rbf(grid(rng, (R, C)) + 0.3 * rng.standard_normal(C)); da = grid(rng, (R, C)); add = grid(rng, (R, C))
+    bn = BN(L, C, rng)
+    bn.set_fwd_stats(x)
+    out = torch.empty(R, C, device="cuda")
+    L.call("sar_bn_apply_bf16_f32", dbf(x), bn.ref(R, "fwd", True), out, R, C, 1)
+    s, h = bn.scale.astype(np.float32).astype(np.float64), bn.shift.astype(np.float32).astype(np.float64)
+    check(out, np.maximum(x * s + h, 0), 1e-5, "final bn+relu")
+    check(bn.d["saved"], np.stack([bn.mean, bn.rstd, bn.scale, bn.shift]), 1e-5, "saved")
+    for f32 in (1, 0):
+        bn.d["bbins"].zero_(); bn.d["dg"].zero_(); bn.d["db"].zero_()
+        dd = dev(da) if f32 else dbf(da)
+        L.call("sar_bn_bwd_reduce_bf16", dd, f32, dbf(x), bn.d["saved"], bn.d["bbins"], R, C, 1)
+        S1, S2, _, _ = bn.bwd_sums(da, x)
+        tot = val(bn.d["bbins"]).sum(0)
+        check(tot[0], S1, 2e-4, "S1"); check(tot[1], S2, 2e-4, "S2")
+        g = torch.empty(R, C, dtype=BF, device="cuda")
+        L.call("sar_bn_bwd_apply_bf16", dd, f32, dbf(x), bn.ref(R, "bwd", True), dbf(add), g, R, C, 1)
+        check(g, bn.dx(da, x) + add, TOL_BF, "bn bwd apply")
+        check(bn.d["dg"], S2, 2e-4, "dgamma"); check(bn.d["db"], S1, 2e-4, "dbeta")
+
+
+def test_casts(L):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(8 * 1000 + 8).astype(np.float32)
+    y = torch.empty(a.size, dtype=BF, device="cuda")
+    L.call("sar_cast_f32_bf16", dev(a), y, a.size)
+    assert torch.equal(y.cpu(), torch.tensor(a).to(BF))
+    z = torch.empty(a.size, device="cuda")
+    L.call("sar_cast_bf16_f32", y, z, a.size)
+    assert torch.equal(z.cpu(), torch.tensor(a).to(BF).float())
