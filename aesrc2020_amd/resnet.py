@@ -354,6 +354,8 @@ class ResNetTrunk(Layer):
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
                 blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=dsc)
+            if getattr(self, "debug_tap", None) is not None:          # tests/test_gpu_bf16_trunk.py: per-block tensors before reuse
+                self.debug_tap(n, g, da2, gin)
             g = gin
         self._g_part = g
         if part in (0, 1):

@@ -59,96 +59,114 @@ def conv_roofline(model, B, iters=10):
         c = classes.setdefault(cls, dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
         c["time"] += secs; c["flops"] += flops; c["bytes"] += nbytes; c["launches"] += 1
 
+    bf16 = getattr(tr, "bf16", False)
+    eb = 2.0 if bf16 else 4.0
     for n, blk in enumerate(tr.blocks):
         for cname, bn in (("conv1", blk["bn1"]), ("conv2", blk["bn2"]), ("sc", None)):
             cv = blk[cname]
             if cv is None:
                 continue
             x = blk["x"] if cname != "conv2" else blk["c1"]
-            y = torch.randn(B, cv.Ho, cv.Wo, cv.cout, device="cuda"); dx = torch.empty(B, cv.H, cv.W, cv.cin, device="cuda")
+            dt = torch.bfloat16 if bf16 else torch.float32
+            y = torch.randn(B, cv.Ho, cv.Wo, cv.cout, device="cuda").to(dt); dx = torch.empty(B, cv.H, cv.W, cv.cin, device="cuda", dtype=dt)
             flops = 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k
-            act_b = 4.0 * B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + 4.0 * cv.k * cv.k * cv.cin * cv.cout
+            act_b = eb * B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + eb * cv.k * cv.k * cv.cin * cv.cout
             tile = "n32" if cv.cout <= 32 else "n64"
+            tile_d = "n32" if cv.cin <= 32 else "n64"
+            if bf16:
+                # the launches of the train step: BN+ReLU in the forward / weight-gradient fills (saved constants), plain gradient
+                fb = bn.ref(B * cv.H * cv.W, "saved", False) if bn is not None else None
+                fl = 1 if bn is not None else 0
+                dw = torch.zeros_like(cv.kernel.g)
+                add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd16(x, y, B, fill=fl, fbn=fb)), flops, act_b)
+                add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: _lib.call(
+                    "sar_conv2d_wgrad_bf16", x, fl, fb, y, None, 0, None, dw, None, B, cv.H, cv.W, cv.cin, cv.Ho, cv.Wo, cv.cout, cv.k,
+                    cv.stride, cv.pt, cv.pl)), flops, act_b)
+                add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad16(y, None, dx, B)), flops, act_b)
+                continue
             add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd(x, y, B, bn=bn)), flops, act_b)
             add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.wgrad(x, y, B, bn=bn)), flops, act_b)
-            tile_d = "n32" if cv.cin <= 32 else "n64"
             add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad(y, dx, B)), flops, act_b)
     total = sum(c["time"] for c in classes.values())
     name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
     ach = dom["flops"] / dom["time"] / 1e12
-    x3 = _lib.get_conv_math() == "bf16x3"
-    # which MFMA pipe the dominant class runs on: Cout (Cin for dgrad) <= 32 tiles keep the fp32 kernels
+    x3 = (not bf16) and _lib.get_conv_math() == "bf16x3"
+    # which MFMA pipe the dominant class runs on: bf16 trunk = single-pass bf16 MFMA; fp32 storage: Cout (Cin for dgrad) <= 32
+    # tiles keep the fp32 kernels, the rest run bf16x3
     dom_x3 = x3 and name.endswith("n64")
-    peak = PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_F32_MFMA_TFLOPS)
+    # bound of the dominant class on this chip: time its algorithmic FLOPs need on the pipe vs its algorithmic bytes on HBM
+    t_mfma, t_hbm = dom["flops"] / (peak * 1e12), dom["bytes"] / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
     # correction applied by tools/pmc_to_traffic.py); null when no measurement exists for this kernel class
     traffic, tsrc = None, None
     try:
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-        if name in pj:
-            traffic, tsrc = pj[name]["traffic_bytes"], pj["source"]
+        key = ("bf16:" if bf16 else "") + name
+        if key in pj:
+            traffic, tsrc = pj[key]["traffic_bytes"], pj["source"]
     except (OSError, ValueError, KeyError):
         pass
-    return dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s",
-                frac=round(ach / peak, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
+    math = ("single-pass bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM, fp32 accumulate" if bf16 else
+            "bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate" if dom_x3 else
+            "fp32 MFMA (v_mfma_f32_32x32x2_f32)")
+    if bound == "hbm":
+        ach_v, peak_v, unit = dom["bytes"] / dom["time"] / 1e9, PEAK_HBM_GBS, "GB/s"
+    else:
+        ach_v, peak_v, unit = ach, peak, "TFLOP/s"
+    # T_roof of the 36 non-stem convs = 3 x (52.9 - 8.7) us per train step at B=64, T=400 (bf16 activations, 2.5 PFLOP/s,
+    # 8 TB/s); scaled by this workload's conv FLOPs (1.2263 GFLOP/utt forward for those 36 layers)
+    all_flops = sum(c["flops"] for c in classes.values())
+    t_roof_us = 132.6 * all_flops / (3 * 64 * 1.2263e9) if all_flops else None
+    return dict(bound=bound, kernel=name, achieved=round(ach_v, 2), peak=round(peak_v, 1), unit=unit,
+                frac=round(ach_v / peak_v, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
                 algorithmic_bytes=int(dom["bytes"] / dom["launches"]), launches_per_step=dom["launches"],
-                avg_launch_us=round(dom["time"] / dom["launches"] * 1e6, 2),
-                math="bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate"
-                     if dom_x3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                avg_launch_us=round(dom["time"] / dom["launches"] * 1e6, 2), math=math,
+                achieved_tflops=round(ach, 2), frac_of_bf16_dense_peak=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                 frac_of_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                 algorithmic_hbm_gbs=round(dom["bytes"] / dom["time"] / 1e9, 1),
                 conv_classes={k: dict(us_per_step=round(v["time"] * 1e6, 1), tflops=round(v["flops"] / v["time"] / 1e12, 2),
                                       launches=v["launches"]) for k, v in sorted(classes.items())},
-                conv_total_us_per_step=round(total * 1e6, 1))
+                conv_total_us_per_step=round(total * 1e6, 1),
+                conv_t_roof_over_t_measured=round(t_roof_us / (total * 1e6), 4) if t_roof_us else None)
 
 
-def cpu_baseline(kw, input_shape, B, budget_s=20.0):
-    """torch-CPU restatement (oracle/model_torch.py, fp32) of the same graph on this box's host cores, bounded sample:
-    one warm-up step, then whole train steps at B=16 until ~budget_s of wall-clock is spent (at most 4).  Threads are
-    capped at 16: the graph's small sequential ops (GRU steps, heads) get slower, not faster, with more threads."""
+def cpu_baseline(kw, input_shape, B, warm=3, steps=10):
+    """torch-CPU restatement (oracle/model_torch.py, fp32) of the same graph on this box's host cores, as BASELINE.md
+    section 4 states it: B=64 (the bench batch), 3 warm-up + 10 timed train steps (~10-25 s).  Threads are capped at 16: the
+    graph's small sequential ops (GRU steps, heads) get slower, not faster, with more threads."""
     from oracle import model_torch as MT
     threads = max(1, min(os.cpu_count() or 1, 16))
     torch.set_num_threads(threads)
-    Bc = min(B, 16)
     cfg = MT.Cfg(input_shape, **kw)
     net = MT.TorchSARNet(cfg, dtype=torch.float32)
-    b = MT.synthetic_batch(cfg, Bc)
+    b = MT.synthetic_batch(cfg, B)
+    t0 = time.time()
     net.train_on_batch(b)
-    t0 = time.time(); n = 0
-    while n < 4 and (n == 0 or time.time() - t0 < budget_s):
-        net.train_on_batch(b); n += 1
-    dt = (time.time() - t0) / n
-    return dict(value=round(Bc / dt, 2), unit="utterances/sec", cores=threads, kind="port",
-                sample="%d train steps (after 1 warm-up) of the same graph at B=%d x %d frames, torch-CPU fp32 restatement "
-                       "(not TF-Keras), %d threads" % (n, Bc, input_shape[0], threads))
+    one = time.time() - t0
+    if one * (warm + steps) > 90.0:                   # slow host: keep the default run within minutes, say so in `sample`
+        warm, steps = 1, max(2, int(30.0 / one))
+    for _ in range(warm - 1):
+        net.train_on_batch(b)
+    t0 = time.time()
+    for _ in range(steps):
+        net.train_on_batch(b)
+    dt = (time.time() - t0) / steps
+    return dict(value=round(B / dt, 2), unit="utterances/sec", cores=threads, kind="port",
+                sample="%d timed train steps (after %d warm-up) of the same graph at B=%d x %d frames, torch-CPU fp32 restatement "
+                       "(not TF-Keras), %d threads" % (steps, warm, B, input_shape[0], threads))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64; cfg5: 32)")
-    ap.add_argument("--frames", type=int, default=None)
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
-    from aesrc2020_amd import parallel
-    rank, world, local = parallel.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local)
+def run_workload(name, args, rank, world, with_extras):
+    """Build the model of one workload, time `args.steps` train steps; returns (result dict, model)."""
     from aesrc2020_amd import _lib
     from aesrc2020_amd.model import SAR_Net
     from aesrc2020_amd.utils import synthetic_batch
     import torch.distributed as dist
-
-    wl = WORKLOADS[args.workload]
-    T = args.frames or (2000 if args.workload == "cfg5" else 400)
-    B = args.batch or (32 if args.workload == "cfg5" else 64)
+    wl = WORKLOADS[name]
+    T = args.frames or (2000 if name == "cfg5" else 400)
+    B = args.batch or (32 if name == "cfg5" else 64)
     input_shape = [T, 80, 1]
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -189,26 +207,74 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     logs = train_model._logs()
     assert np.isfinite(logs["loss"]), logs
+    res = dict(value=round(world * B * args.steps / dt, 2), ms_per_step=round(dt / args.steps * 1e3, 4), workload=wl["desc"], B=B, T=T,
+               params=model.count_params(), final_loss=round(logs["loss"], 4), kw=kw, input_shape=input_shape)
+    return res, model
 
+
+DTYPES = {
+    # --dtype: (trunk storage, conv math, what the JSON line says)
+    "bf16": ("bf16", "bf16x3", "bf16 activations / activation gradients in HBM, single-pass bf16 MFMA, fp32 accumulate, statistics and master weights"),
+    "bf16x3": ("fp32", "bf16x3", "fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),
+    "f32": ("fp32", "fp32", "fp32 in HBM, fp32 MFMA"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
+    ap.add_argument("--dtype", default=os.environ.get("SAR_BENCH_DTYPE", "bf16"), choices=list(DTYPES),
+                    help="arithmetic of the conv trunk: bf16 (BASELINE configs[1]), bf16x3 (fp32-class), f32")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64; cfg5: 32)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra cfg3 / cfg5 timings of the default 1-GPU run")
+    args = ap.parse_args()
+
+    from aesrc2020_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    from aesrc2020_amd import _lib
+    import torch.distributed as dist
+    trunk, math, dtype_desc = DTYPES[args.dtype]
+    _lib.set_trunk_dtype(trunk); _lib.set_conv_math(math)
+
+    r, model = run_workload(args.workload, args, rank, world, True)
     if rank == 0:
         res = {
-            "metric": "utterances/sec train step, 400-frame x 80-dim fbank", "value": round(world * B * args.steps / dt, 2),
+            "metric": "utterances/sec train step, 400-frame x 80-dim fbank", "value": r["value"],
             "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            # arithmetic type of the dominant (conv) path: "bf16x3" = fp32 operands split into bf16 hi+lo, three bf16 MFMAs
-            # per product block, fp32 accumulate, fp32 in HBM (16 significant bits per product: above the bf16 that
-            # BASELINE configs[1] names); "f32" = exact fp32 MFMA (SAR_CONV_MATH=fp32)
-            "dtype": "bf16x3" if _lib.get_conv_math() == "bf16x3" else "f32", "data": "synthetic",
-            "config": {"workload": wl["desc"], "batch_per_gpu": B, "global_batch": B * world, "frames": T, "feat_dim": 80,
-                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "params": model.count_params(),
-                       "conv_math": _lib.get_conv_math() + (" (fp32 in HBM, fp32 accumulate, 2^-17 relative per product)"
-                                                            if _lib.get_conv_math() == "bf16x3" else ""),
-                       "final_loss": round(logs["loss"], 4)},
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # arithmetic type of the dominant (conv) path, see DTYPES
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": r["workload"], "batch_per_gpu": r["B"], "global_batch": r["B"] * world, "frames": r["T"], "feat_dim": 80,
+                       "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "params": r["params"],
+                       "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"]},
         }
         if not args.no_roofline:
-            res["roofline"] = conv_roofline(model, B)
+            res["roofline"] = conv_roofline(model, r["B"])
+    del model
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not args.no_also and args.workload == "cfg2" and args.batch is None and args.frames is None:
+            # the other single-GPU configurations of BASELINE.json, same build, same dtype: cfg3 is the N=1 base of the cfg4 curve
+            also = {}
+            for name in ("cfg3", "cfg5"):
+                ra, m2 = run_workload(name, args, rank, world, False)
+                also[name] = {"value": ra["value"], "unit": "utterances/sec", "ms_per_step": ra["ms_per_step"], "batch_per_gpu": ra["B"],
+                              "frames": ra["T"], "workload": ra["workload"], "final_loss": ra["final_loss"]}
+                del m2
+                torch.cuda.empty_cache()
+            res["also"] = also
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(kw, input_shape, B)
+            res["cpu_baseline"] = cpu_baseline(r["kw"], r["input_shape"], r["B"])
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -305,9 +305,12 @@ def test_conv_wgrad_all_fills(L, shape):
     yb = rbf(grid(rng, dy.shape) - 0.1)
     bnd = BN(L, Cout, rng); bnd.set_fwd_stats(yb); bnd.set_saved(); bnd.set_bwd_stats(dy, yb)
     _, cache = O.conv2d_fwd(bna.act(x), cv.wq, np.zeros(Cout), (s, s), pad)
-    _, dw_ref, db_ref = O.conv2d_bwd(rbf(bnd.dx(dy, yb)), cache)
+    dyq = rbf(bnd.dx(dy, yb))
+    _, dw_ref, db_ref = O.conv2d_bwd(dyq, cache)
     dw, db = cv.wgrad(dbf(x), dbf(dy), a_fill=1, abn=bna.ref(bna.n, "saved", False), dy2=dbf(yb), d_fill=2, dbn=bnd.ref(bnd.n, "bwd", True))
-    check(dw, dw_ref, TOL_F32, "dw bn/bn-bwd"); check(db, db_ref, TOL_F32, "db bn-bwd", )
+    check(dw, dw_ref, TOL_F32, "dw bn/bn-bwd")
+    # a BatchNorm backward sums to zero per channel: db is rounding residue, so its error is measured against sum |dy|
+    assert np.abs(val(db) - db_ref).max() <= 1e-5 * np.abs(dyq).reshape(-1, Cout).sum(0).max(), "db bn-bwd"
     check(bnd.d["dg"], bnd.S2, 1e-5, "dgamma"); check(bnd.d["db"], bnd.S1, 1e-5, "dbeta")
     dw2, _ = cv.wgrad(dbf(x), dbf(dy), a_fill=1, abn=bna.ref(bna.n, "saved", False), bias=False)
     _, dw_ref2, _ = O.conv2d_bwd(dy, cache)

@@ -1,0 +1,158 @@
+"""Block-by-block parity of the bf16 trunk (resnet.py _forward16 / _backward16) against the CPU oracle.
+
+Every stored tensor of the bf16 trunk is on the bf16 grid.  Two runs that differ in ONE last bit (fp32 vs float64 accumulation
+order) decorrelate within a few layers -- a 2^-9 input perturbation moves a quarter of the next layer's outputs across a
+rounding boundary -- so an end-to-end "rounding-aware" reference only agrees to the bf16 noise level (measured: 2 % on the
+trunk output, 10-20 % on gradients, tests/test_gpu_bf16_model.py).  Wiring errors are found one block at a time instead: the
+reference takes the tensors the HIP path itself stored as the block's INPUTS (block input x, conv1 output c1, incoming
+gradient g -- tapped through ResNetTrunk.debug_tap before the scratch buffers are reused) and recomputes that block's
+outputs with the float64 oracle (oracle/ops_np.py conv2d / BatchNorm algebra, resnet.py:96-125 wiring), rounding to bf16
+exactly where the kernels store a tensor or write a fill operand to LDS.  One block deep, a wrong BatchNorm in a fill, a
+missing shortcut gradient or a wrong stride-2 padding is an O(1) error; correct wiring leaves isolated last-bit flips.
+Bounds: 1e-2 of each tensor's max-abs (parameter gradients: 5e-3).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops_np as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+EPS = 1e-3
+
+
+def rbf(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).to(BF).double().numpy()
+
+
+def f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+class RefBN:
+    """Constants exactly as bn_prologue derives them from the statistics of the STORED (bf16) tensor."""
+
+    def __init__(self, x, gamma, beta):
+        x2 = x.reshape(-1, x.shape[-1])
+        self.n = x2.shape[0]
+        self.mean = f32(x2.mean(0)); var = np.maximum((x2 * x2).mean(0) - x2.mean(0) ** 2, 0.0)
+        self.rstd = f32(1.0 / np.sqrt(f32(var) + EPS))
+        self.scale = f32(gamma * self.rstd); self.shift = f32(beta - self.mean * self.scale)
+        self.x = x
+
+    def act(self):
+        return rbf(np.maximum(self.x * self.scale + self.shift, 0.0))
+
+    def bwd(self, da):
+        """-> (dx unrounded, dgamma, dbeta): BatchNorm+ReLU backward with the kernel's operation order."""
+        dz = np.where(self.x * self.scale + self.shift > 0, da, 0.0)
+        xh = (self.x - self.mean) * self.rstd
+        ax = tuple(range(da.ndim - 1))
+        S1, S2 = dz.sum(ax), (dz * xh).sum(ax)
+        dx = self.scale * (dz - f32(S1 / self.n) - xh * f32(S2 / self.n))
+        return dx, S2, S1
+
+
+def relerr(got, ref):
+    got = got.detach().float().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+
+
+@pytest.mark.parametrize("res_type,B,T", [("res34", 3, 72), ("res18", 2, 40), ("res34", 4, 200)])
+def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T):
+    from aesrc2020_amd import _lib
+    from aesrc2020_amd.engine import ParamStore, store_scope
+    from aesrc2020_amd.resnet import ResNetTrunk
+    old = _lib.get_trunk_dtype()
+    _lib.set_trunk_dtype("bf16")
+    try:
+        store = ParamStore(seed=3)
+        with store_scope(store):
+            tr = ResNetTrunk(res_type, 32, (T, 80))
+        store.finalize()
+    finally:
+        _lib.set_trunk_dtype(old)
+    rng = np.random.default_rng(11)
+    for r in store.refs:                                            # non-trivial BatchNorm parameters and biases
+        if r.name.endswith("/gamma"):
+            r.w.copy_(torch.tensor(rng.uniform(0.6, 1.4, r.shape), dtype=torch.float32))
+        elif r.name.endswith("/beta") or r.name.endswith("/bias"):
+            r.w.copy_(torch.tensor(0.2 * rng.standard_normal(r.shape), dtype=torch.float32))
+    x = torch.tensor(rng.uniform(0, 1, (B, T, 80, 1)), dtype=torch.float32, device="cuda")
+    store.zero_grads()
+    out = tr.forward(x, B)
+    dy_np = f32(rng.standard_normal(tuple(out.shape)))
+    taps = {}
+    tr.debug_tap = lambda n, g, da2, gin: taps.__setitem__(n, (g.clone(), da2.clone(), gin.clone()))
+    g_final = None
+    tr.backward(torch.tensor(dy_np, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    P = {r.name: r.w.detach().cpu().double().numpy() for r in store.refs}
+    G = {r.name: r.g.detach().cpu().double().numpy() for r in store.refs}
+    val = lambda t: t.detach().float().cpu().double().numpy()
+    errs = {}
+
+    def chk(name, got, ref, tol):
+        e = relerr(got, ref) if not isinstance(got, np.ndarray) else float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+        errs[name] = e
+        assert e < tol, (name, e)
+
+    nblk = len(tr.blocks)
+    cache = []
+    # ---- forward, one block at a time from the stored inputs
+    for n, blk in enumerate(tr.blocks):
+        c1v, c2v, scv = blk["conv1"], blk["conv2"], blk["sc"]
+        xin, c1 = val(blk["x"]), val(blk["c1"])
+        bn1 = RefBN(xin, P[blk["bn1"].gamma.name], P[blk["bn1"].beta.name]) if blk["bn1"] is not None else None
+        a = bn1.act() if bn1 is not None else xin
+        y1, cache1 = O.conv2d_fwd(a, rbf(P[c1v.kernel.name]), P[c1v.bias.name], (c1v.stride,) * 2, c1v.padding)
+        chk("b%d c1" % n, c1, rbf(y1), 1e-2)
+        bn2 = RefBN(c1, P[blk["bn2"].gamma.name], P[blk["bn2"].beta.name])
+        y2, cache2 = O.conv2d_fwd(bn2.act(), rbf(P[c2v.kernel.name]), P[c2v.bias.name], (1, 1), "same")
+        if scv is not None:
+            ys, caches = O.conv2d_fwd(xin, rbf(P[scv.kernel.name]), P[scv.bias.name], (scv.stride,) * 2, scv.padding)
+            sc = rbf(ys)
+        else:
+            sc, caches = xin, None
+        ynext = val(tr.blocks[n + 1]["x"]) if n + 1 < nblk else val(tr.pre_final)
+        chk("b%d y" % n, ynext, rbf(y2 + sc), 1e-2)
+        cache.append((bn1, bn2, cache1, cache2, caches))
+    fb = RefBN(val(tr.pre_final), P[tr.final_bn.gamma.name], P[tr.final_bn.beta.name])
+    chk("trunk out", val(out), np.maximum(fb.x * fb.scale + fb.shift, 0.0), 1e-4)
+    # ---- backward: final BatchNorm, then every block from its tapped incoming gradient
+    dx, dgam, dbet = fb.bwd(dy_np)
+    chk("final bn -> g", val(taps[nblk - 1][0]), rbf(dx), 1e-2)
+    chk("final bn dgamma", G[tr.final_bn.gamma.name], dgam, 5e-3); chk("final bn dbeta", G[tr.final_bn.beta.name], dbet, 5e-3)
+    for n in range(nblk - 1, -1, -1):
+        blk = tr.blocks[n]
+        bn1, bn2, cache1, cache2, caches = cache[n]
+        c1v, c2v, scv = blk["conv1"], blk["conv2"], blk["sc"]
+        g, da2_dev, gin_dev = (val(t) for t in taps[n])
+        if n + 1 < nblk:                                            # the chain: this block's g is the next block's gin
+            assert torch.equal(taps[n][0], taps[n + 1][2])
+        da2, dw2, db2 = O.conv2d_bwd(g, cache2)
+        chk("b%d da2" % n, da2_dev, rbf(da2), 1e-2)
+        chk("b%d conv2 dw" % n, G[c2v.kernel.name], dw2, 5e-3)
+        assert np.abs(G[c2v.bias.name] - db2).max() < 1e-4 * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6, "b%d conv2 db" % n
+        dc1, dg2, dbt2 = bn2.bwd(da2_dev)                            # from the STORED da2, as the fills read it
+        chk("b%d bn2 dgamma" % n, G[blk["bn2"].gamma.name], dg2, 5e-3); chk("b%d bn2 dbeta" % n, G[blk["bn2"].beta.name], dbt2, 5e-3)
+        dc1 = rbf(dc1)
+        da1, dw1, _ = O.conv2d_bwd(dc1, cache1)
+        chk("b%d conv1 dw" % n, G[c1v.kernel.name], dw1, 5e-3)
+        assert np.abs(G[c1v.bias.name]).max() == 0.0                 # feeds a BatchNorm: exactly zero, not computed
+        if scv is not None:
+            dsc, dws, dbs = O.conv2d_bwd(g, caches)
+            chk("b%d shortcut dw" % n, G[scv.kernel.name], dws, 5e-3)
+            assert np.abs(G[scv.bias.name] - dbs).max() < 1e-4 * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6
+            dsc = rbf(dsc)
+        else:
+            dsc = g
+        if bn1 is not None:
+            dxb, dg1, dbt1 = bn1.bwd(rbf(da1))
+            chk("b%d gin" % n, gin_dev, rbf(dxb + dsc), 1e-2)
+            chk("b%d bn1 dgamma" % n, G[blk["bn1"].gamma.name], dg1, 1e-2); chk("b%d bn1 dbeta" % n, G[blk["bn1"].beta.name], dbt1, 1e-2)
+        else:
+            chk("b%d gin" % n, gin_dev, rbf(da1 + dsc), 1e-2)
+    chk("gradient handed to the stem", val(store.bufs.d["scratch/res16_g32"]), val(taps[0][2]), 1e-9)
+    print("bf16 trunk %s B=%d T=%d: worst block-local error %.3e (%s)" % (res_type, B, T, max(errs.values()), max(errs, key=errs.get)))
