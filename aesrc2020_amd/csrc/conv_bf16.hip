@@ -27,6 +27,21 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// In-kernel phase timing (tools/conv16_timing.py; built only with -DSAR_TIMING into tools/libsarnet_timing16.so, never part
+// of libsarnet_hip.so): thread 0 of every block stamps s_memtime (shader clock) / s_memrealtime (100 MHz, device-wide).
+#ifdef SAR_TIMING
+__device__ unsigned long long* g_tbuf16 = nullptr;
+#define TSTAMP(slot)                                                                                                   \
+    do {                                                                                                               \
+        if (g_tbuf16 && threadIdx.x == 0) {                                                                            \
+            const long bl = (long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);          \
+            g_tbuf16[bl * 16 + (slot)] = ((slot) == 0 || (slot) == 15) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+        }                                                                                                              \
+    } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#endif
+
 constexpr int NB = 16;          // statistic bins per BatchNorm (fp32 atomics; contention = blocks / 16 per address)
 constexpr int CMAX = 512;       // max channels of a BatchNorm / conv side
 constexpr int CST_BYTES = 6 * CMAX * 4;
@@ -165,31 +180,62 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const Cst8
 struct ConvP {
     Geo g; int Cout;
     const u16* x; const u16* x2; const bf16x8* wpk; const float* bias; const u16* res; u16* y;
+    u16* side;                  // nullable: the fill transform T(x) written back to HBM (same shape as x) for the weight gradient
     int fill; BnP fb;
     int epi; float* e_bins; const u16* e_y; const float* e_saved;
     int lg_pc;                  // log2(Cin/8): 16-byte pieces per position
     int rs;                     // LDS row stride in bytes = Cin*2 + 16 (conflict-free ds_read_b128 across rows)
     int Fs;                     // fragment stride of the weight stream per 32 output channels: K*K*Cin/16 + 8 (zero tail)
     int cap_rows;               // patch rows the LDS allocation holds
+    int patch_bytes;            // LDS bytes of the patch region (incl. the 1 KiB scratch slot); the weight ring follows
 };
+constexpr int ROWTAB_BYTES = 1024;   // per patch row {source row base offset | NONE, owner pixel of the row's first column}
 
-template <int MODE>
-__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, int lg_pc, int rs,
-                                           unsigned char* patch, const float* cst, unsigned Rp_lo, unsigned nrows, int tid) {
+// asm-issued LDS-DMA (hidden from hipcc's vmcnt bookkeeping: the waits below are counted by hand; guide section 5.7)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0, 16]
+    switch (n) {
+        case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;   case 3: wait_vm<3>(); break;
+        case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;   case 6: wait_vm<6>(); break;   case 7: wait_vm<7>(); break;
+        case 8: wait_vm<8>(); break;   case 9: wait_vm<9>(); break;   case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
+        case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break; case 15: wait_vm<15>(); break;
+        default: wait_vm<16>(); break;
+    }
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+
+// Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
+// per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
+// source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
+template <int MODE, int TM>
+__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, u16* __restrict__ side,
+                                           int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
+                                           unsigned nrows, unsigned m0, int tid) {
     const unsigned pc = 1u << lg_pc, total = (nrows * g.Wp) << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
     const unsigned c8 = tid & (pc - 1);                            // 256 % pc == 0: a thread keeps its channel group
+    const int dm = g.d - 1, ssh = g.s - 1;
+    const bool do_side = side != nullptr && blockIdx.y == 0;       // block-uniform
     Cst8 k;
     if constexpr (MODE != 0) load_cst8(cst, c8 * 8, MODE, k);
     for (unsigned i0 = tid; i0 < total; i0 += 4 * 256) {
-        uint4 q[4], q2[4]; unsigned off[4], lo[4];
+        uint4 q[4], q2[4]; unsigned off[4], lo[4], own[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned i = i0 + 256 * j, pos = i >> lg_pc;
-            const unsigned prow = udiv(pos, g.mg_wp, (unsigned)g.Wp), wp = pos - prow * g.Wp;
-            off[j] = src_off(g, Rp_lo + prow, wp, i < total);
+            const unsigned prow = min(udiv(pos, g.mg_wp, (unsigned)g.Wp), nrows - 1), wp = pos - prow * g.Wp;
+            const uint2 rt = rowtab[prow];
+            const int v = (int)wp - g.pl, vs = v >> dm;
+            const bool ok = (i < total) & (rt.x != NONE) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
+            off[j] = ok ? rt.x + (unsigned)vs * g.Cin + c8 * 8 : NONE;
+            own[j] = rt.y + (dm ? 2u * vs : (unsigned)vs >> ssh) - m0;   // < TM: this block owns the source pixel
             lo[j] = pos * rs + c8 * 16;
-            const unsigned o = off[j] == NONE ? 0u : off[j] + c8 * 8;
+            const unsigned o = ok ? off[j] : 0u;
             q[j] = *reinterpret_cast<const uint4*>(x + o);
             if constexpr (MODE == 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
         }
@@ -197,6 +243,7 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
         for (int j = 0; j < 4; ++j) {
             const uint4 r = xform<MODE>(q[j], q2[j], k);                 // branch-free: pieces past the end land in a scratch slot
             *reinterpret_cast<uint4*>(patch + (i0 + 256 * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
+            if (do_side && off[j] != NONE && own[j] < (unsigned)TM) *reinterpret_cast<uint4*>(side + off[j]) = r;
         }
     }
 }
@@ -206,97 +253,33 @@ __device__ __forceinline__ void load_afrags(bf16x8 (&a)[NKC], const unsigned cha
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) a[kc] = *reinterpret_cast<const bf16x8*>(patch + addr + kc * 32);
 }
-// One (virtual) tap: NKC MFMAs on the fragments in `a`; bpt = this tap's first weight fragment; the weight ring bq
-// (depth 8, this tap starts at slot s0 -- a constant after unrolling) is refilled 8 fragments ahead.
-template <int NKC>
-__device__ __forceinline__ void tap_mma(f32x16& acc, const bf16x8 (&a)[NKC], bf16x8 (&bq)[8], const bf16x8* bpt, const int s0) {
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {
-        const int slot = (s0 + kc) & 7;
-        const bf16x8 Bv = bq[slot];
-        bq[slot] = bpt[(size_t)(kc + 8) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kc], Bv, acc, 0, 0, 0);
-    }
-}
 
-// WN: waves along the output channels (tile 32*(4/WN) pixels x 32*WN channels); NKC: 16-channel blocks per virtual tap;
-// VT: virtual taps = K*K x channel halves (a tap of Cin <= 256 channels is one virtual tap, Cin = 512 is two): 1, 2, 9, 18.
+// WN: waves along the output channels (tile 32*(4/WN) pixels x 32*WN channels); NKC: 16-channel blocks per virtual tap
+// (2, 4, 8); VT: virtual taps = K*K x channel parts of 128 (Cin = 256: two parts per tap, 512: four): 1, 2, 4, 9, 18, 36.
+// Weights: the packed fragment stream of this block's channels is brought into a 3-deep LDS ring by LDS-DMA in stages of 8
+// fragments per channel tile (one barrier per stage, two stages in flight behind the one being multiplied), so all four
+// waves share one copy and no VGPR or VALU instruction is spent on the B operand.
 template <int WN, int NKC, int VT>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
     constexpr int WM = 4 / WN, TM = 32 * WM, TN = 32 * WN;
     constexpr int CP = TN / 2, RG = 256 / CP, RPT = TM / RG;       // epilogue: column pairs, row groups, rows per thread
-    constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel halves
+    constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
+    constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
+    constexpr int SJ = WN * 8, PW = SJ / 4;                        // DMA wave-instructions per stage: block / per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cst = reinterpret_cast<float*>(smem);
-    unsigned char* patch = smem + CST_BYTES;
+    uint2* rowtab = reinterpret_cast<uint2*>(smem + CST_BYTES);
+    unsigned char* patch = smem + CST_BYTES + ROWTAB_BYTES;
+    unsigned char* bring = patch + p.patch_bytes;                  // [3][WN][8][1 KiB]
     const Geo& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WN, wn = w % WN;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WN, wn = w % WN;
     const unsigned m0 = blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
     const unsigned M = (unsigned)g.M;
+    TSTAMP(0); TSTAMP(1);
 
-    if (p.fill) {
-        bn_prologue(p.fb, p.fill, g.Cin, 0, g.Cin, cst, blockIdx.x == 0 && blockIdx.y == 0, 256);
-        __syncthreads();
-    }
-    unsigned Rp_lo, Rp_hi, wtmp;
-    pix_rp(g, m0, Rp_lo, wtmp);
-    pix_rp(g, min(m0 + TM - 1, M - 1), Rp_hi, wtmp);
-    Rp_hi += g.K - 1;
-    unsigned nrows = Rp_hi - Rp_lo + 1;
-    if (nrows > (unsigned)p.cap_rows) nrows = p.cap_rows;          // never taken: the launcher sizes cap_rows as an upper bound
-
-    // ---- weight stream of this wave's 32 output channels: first 8 fragments in flight before the fill
-    const bf16x8* bp = p.wpk + ((size_t)(blockIdx.y * WN + wn) * p.Fs) * 64 + lane;
-    bf16x8 bq[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bq[j] = bp[(size_t)j * 64];
-
-    // ---- fill: the padded patch, all input channels, transformed once
-    if (p.fill == 0) fill_patch<0>(g, p.x, p.x2, p.lg_pc, p.rs, patch, cst, Rp_lo, nrows, tid);
-    else if (p.fill == 1) fill_patch<1>(g, p.x, p.x2, p.lg_pc, p.rs, patch, cst, Rp_lo, nrows, tid);
-    else fill_patch<2>(g, p.x, p.x2, p.lg_pc, p.rs, patch, cst, Rp_lo, nrows, tid);
-    // ---- per-lane A address
-    unsigned a_lane;
-    {
-        unsigned Rp, wq;
-        pix_rp(g, min(m0 + wm * 32 + (lane & 31), M - 1), Rp, wq);
-        unsigned prow = Rp - Rp_lo;
-        if (prow + g.K > nrows) prow = 0;                          // only with the clamp above
-        a_lane = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16;
-    }
-    __syncthreads();
-
-    // ---- k-phase, straight-line (no loop-carried register rings for the compiler to copy around): virtual taps in stream
-    // order; the A fragments of the NEXT virtual tap are read from LDS while the MFMAs of the current one issue (two register
-    // sets), weight fragments arrive 8 MFMAs ahead.
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    bf16x8 afr[2][NKC];
-    load_afrags<NKC>(afr[0], patch, a_lane);
-#pragma unroll
-    for (int v = 0; v < VT; ++v) {
-        if (v + 1 < VT) {
-            const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
-            load_afrags<NKC>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
-        }
-        tap_mma<NKC>(acc, afr[v & 1], bq, bp + (size_t)(v * NKC) * 64, (v * NKC) & 7);
-    }
-    __syncthreads();                                               // the patch is dead: reuse it as the output staging tile
-
-    // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), bf16 stores, statistics
-    float* ot = reinterpret_cast<float*>(patch);                   // [TM][TN]
-    float* part = ot + TM * TN;                                    // [RG][TN][2]
-    {
-        const int col = wn * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            ot[row * TN + col] = acc[r];
-        }
-    }
-    __syncthreads();
+    // ---- epilogue operands that do not depend on the accumulators (bias, residual, BatchNorm constants and input of the
+    // backward sums): requested first, consumed ~10 us later
     const int cp = tid % CP, rg = tid / CP;
     const int c = n0 + 2 * cp;
     const float b0 = p.bias ? p.bias[c] : 0.f, b1 = p.bias ? p.bias[c + 1] : 0.f;
@@ -314,6 +297,105 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
         rv[i] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
         yv[i] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
     }
+    // ---- weight ring: stages 0 and 1 on their way before anything else
+    const bf16x8* wsrc = p.wpk + (size_t)(blockIdx.y * WN) * p.Fs * 64 + lane;
+    const unsigned ring0 = lds_addr(bring);
+    auto issue_stage = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int j = w + 4 * i, nt = j >> 3, f8 = j & 7;
+            dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)(((st % 3) * SJ + j) * 1024));
+        }
+    };
+    issue_stage(0);
+    if (NST > 1) issue_stage(1);
+
+
+    if (p.fill) bn_prologue(p.fb, p.fill, g.Cin, 0, g.Cin, cst, blockIdx.x == 0 && blockIdx.y == 0, 256);
+    unsigned Rp_lo, Rp_hi, wtmp;
+    pix_rp(g, m0, Rp_lo, wtmp);
+    pix_rp(g, min(m0 + TM - 1, M - 1), Rp_hi, wtmp);
+    Rp_hi += g.K - 1;
+    unsigned nrows = Rp_hi - Rp_lo + 1;
+    if (nrows > (unsigned)p.cap_rows) nrows = p.cap_rows;          // never taken: the launcher sizes cap_rows as an upper bound
+    if ((unsigned)tid < nrows) {                                   // row table
+        const unsigned Rp = Rp_lo + tid, b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
+        const int dm = g.d - 1, u = (int)hp - g.pt, us = u >> dm;
+        const bool ok = (u >= 0) & ((u & dm) == 0) & (us < g.Hs) & (b < (unsigned)g.B);
+        uint2 rt;
+        rt.x = ok ? ((b * g.Hs + us) * g.Ws) * g.Cin : NONE;
+        rt.y = b * (unsigned)(g.Ho * g.Wo) + (dm ? 2u * us : (unsigned)us >> (g.s - 1)) * g.Wo;
+        rowtab[tid] = rt;
+    }
+    // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TSTAMP(2);
+
+    // ---- fill: the padded patch, all input channels, transformed once
+    if (p.fill == 0) fill_patch<0, TM>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else if (p.fill == 1) fill_patch<1, TM>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else fill_patch<2, TM>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    // ---- per-lane A address
+    unsigned a_lane;
+    {
+        unsigned Rp, wq;
+        pix_rp(g, min(m0 + wm * 32 + (lane & 31), M - 1), Rp, wq);
+        unsigned prow = Rp - Rp_lo;
+        if (prow + g.K > nrows) prow = 0;                          // only with the clamp above
+        a_lane = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16;
+    }
+    TSTAMP(3);
+
+    // ---- k-phase, straight-line.  Per stage: wait for its fragments, barrier (also: every wave is done with the ring slot
+    // refilled next; on stage 0: the patch is complete), start the DMA of stage + 2, read the stage's 8 B fragments, then 8
+    // MFMAs; the A fragments of the NEXT virtual tap are read from the patch while the current tap's MFMAs issue.
+    // two accumulators (even / odd fragments): an instruction between two MFMAs on the SAME accumulator costs ~43 cycles, on
+    // different ones ~6 (MI355X_MICROARCH.md, per-instruction constants) -- and every MFMA here has LDS reads next to it
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+    bf16x8 afr[2][NKC], bfr[8];
+    const unsigned char* bmine = bring + wn * 8 * 1024 + lane * 16;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const int f = v * NKC + kc;
+            if (f % 8 == 0) {
+                const int st = f / 8;
+                if (st + 1 < NST) wait_vm<PW>(); else wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                if (st == 0) { TSTAMP(4); load_afrags<NKC>(afr[0], patch, a_lane); }
+                if (st + 2 < NST) issue_stage(st + 2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + ((st % 3) * SJ + i) * 1024);
+            }
+            if (kc == 0 && v + 1 < VT) {
+                const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
+                load_afrags<NKC>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
+            }
+            if (f & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[v & 1][kc], bfr[f % 8], acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[v & 1][kc], bfr[f % 8], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    TSTAMP(5);
+    __syncthreads();                                               // the patch is dead: reuse it as the output staging tile
+
+    // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), bf16 stores, statistics
+    float* ot = reinterpret_cast<float*>(patch);                   // [TM][TN]
+    float* part = ot + TM * TN;                                    // [RG][TN][2]
+    {
+        const int col = wn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ot[row * TN + col] = acc[r];
+        }
+    }
+    __syncthreads();
     float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -324,8 +406,9 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
         const unsigned pk = pack2(v0, v1);
         if (m < M) {
             *reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c) = pk;
-            v0 = bf_lo(pk); v1 = bf_hi(pk);                        // statistics of what was stored
-            if (p.epi == 1) { s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
+            // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
+            // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
+            if (p.epi == 1) { v0 = bf_lo(pk); v1 = bf_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
             if (p.epi == 2) {
                 const float y0 = bf_lo(yv[i]), y1 = bf_hi(yv[i]);
                 const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
@@ -333,7 +416,8 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
             }
         }
     }
-    if (p.epi == 0) return;                                        // kernel-uniform
+    TSTAMP(6);
+    if (p.epi == 0) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
     part[(rg * TN + 2 * cp) * 2 + 0] = s10; part[(rg * TN + 2 * cp) * 2 + 1] = s20;
     part[(rg * TN + 2 * cp + 1) * 2 + 0] = s11; part[(rg * TN + 2 * cp + 1) * 2 + 1] = s21;
     __syncthreads();
@@ -344,122 +428,129 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
         for (int r = 0; r < RG; ++r) s += part[(r * TN + cc) * 2 + which];
         atomicAdd(p.e_bins + ((blockIdx.x % NB) * 2 + which) * p.Cout + n0 + cc, s);
     }
+    TSTAMP(7); TSTAMP(15);
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
+// dw[tap][ci][co] = sum over pixels of A[pixel + tap][ci] * dY[pixel][co] on PLAIN bf16 operands: A = the activated tensor the
+// forward conv's fill wrote back (ConvP::side; the raw tensor for shortcuts / the first conv), dY = the gradient tensor (for
+// conv1 of a block: the BatchNorm-backward the input-gradient conv's fill wrote back).  Both arrive by LDS-DMA, four 64-pixel
+// chunks in flight, and feed the MFMA through ds_read_b64_tr_b16; no VALU work on the data at all.
+// Block = KK waves (one per tap) x one (32 input, 32 output channel) pair x a slice of the pixels.  Every block writes its
+// partial 32x32 tiles with plain stores into part[slice][tap][ci][co]; wgrad_reduce_kernel sums the slices into the gradient
+// (fp32 atomics at this volume -- ~9 MB per launch -- ran at ~1 TB/s and cost more than the whole k-loop).
 struct WgP {
     Geo g; int Cout;
-    const u16* x; int a_fill; BnP ab;
-    const u16* dy; const u16* dy2; int d_fill; BnP db;
-    float* dw; float* dbias;
+    const u16* x; const u16* dy;
+    float* part; float* dbias;
+    const uint4* zero;          // >= 1 KiB of zeros in HBM: DMA source of halo / out-of-range pieces
     int nchunks, cpb;           // 64-pixel chunks in total / per block
-    int cap_pos;                // patch positions one LDS buffer holds
+    int cap_pos;                // patch positions one LDS buffer holds (multiple of 16)
 };
-constexpr int WG_MAXA = 4;      // 16-byte patch pieces per thread and chunk (9-wave blocks)
+__device__ uint4 g_zero_page[64];
+constexpr int WG_NBUF = 4;
 
 __device__ __forceinline__ s16x4 lds_tr(const unsigned char* base, unsigned off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
 }
 
-// KK = taps = waves per block; AF / DF = fill modes of the activation patch (0, 1) and of dY (0, 2).
-// grid (pixel slices, Cin/32, Cout/32).
-template <int KK, int AF, int DF>
+constexpr int WG_MAXNI = 4;     // DMA wave-instructions per wave and chunk, 9-wave blocks (8 for the single-wave 1x1 blocks; launcher checks)
+constexpr int WG_ROWS = 64;     // patch rows per chunk the row table holds (launcher checks)
+
+template <int KK>
 __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
-    constexpr int NT = KK * 64;
-    constexpr int MAXA = KK == 1 ? 4 : WG_MAXA;
-    constexpr int ND = (256 + NT - 1) / NT;                        // dY pieces (64 pixels x 4) per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* cstA = reinterpret_cast<float*>(smem);                  // [6][CMAX] layout, 32 channels used
-    float* cstD = cstA + 6 * CMAX;
-    unsigned char* bufs = smem + 2 * CST_BYTES;
     const Geo& g = p.g;
-    const unsigned buf_bytes = 256 + 64 * 64 + (unsigned)p.cap_pos * 64 + 1024;   // qtab | dY [64][32] | patch [pos][32] | scratch
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
     const unsigned M = (unsigned)g.M;
-    const int c_first = blockIdx.x * p.cpb, c_end = min(c_first + p.cpb, p.nchunks);
+    const int c_first = blockIdx.x * p.cpb, c_end = min(c_first + p.cpb, p.nchunks), nmine = c_end - c_first;
+    unsigned* qtabs = reinterpret_cast<unsigned*>(smem);                          // [cpb][64]: patch byte offset of every pixel
+    unsigned* rowt = qtabs + (size_t)p.cpb * 64;                                  // [cpb][WG_ROWS]: source offset of every patch row
+    unsigned char* bufs = smem + (size_t)p.cpb * (256 + WG_ROWS * 4);
+    const unsigned buf_bytes = 64 * 64 + (unsigned)p.cap_pos * 64;               // dY [64][32] | patch [pos][32]
+    const unsigned bufs0 = lds_addr(bufs);
+    // DMA wave-instructions per chunk: 4 (dY) + cap_pos/16 (patch), dealt to the KK waves; every wave issues the same count
+    // NI (the surplus ones repeat the block's last instruction: same source, same destination)
+    const int nblk_i = 4 + p.cap_pos / 16, NI = (nblk_i + KK - 1) / KK;
+    TSTAMP(0); TSTAMP(1);
 
-    if constexpr (AF != 0) bn_prologue(p.ab, 1, g.Cin, ci0, 32, cstA, false, NT);
-    if constexpr (DF != 0) bn_prologue(p.db, 2, p.Cout, co0, 32, cstD, blockIdx.x == 0 && blockIdx.y == 0, NT);
-    if constexpr (AF != 0 || DF != 0) __syncthreads();
-    const int c8 = tid & 3;                                        // NT % 4 == 0: fixed channel group per thread
-    Cst8 kA, kD;
-    if constexpr (AF != 0) load_cst8(cstA, c8 * 8, 1, kA);
-    if constexpr (DF != 0) load_cst8(cstD, c8 * 8, 2, kD);
-
-    uint4 qa[MAXA]; unsigned offa[MAXA];
-    uint4 qd[ND], qd2[ND];
-    unsigned Rp_lo = 0, npos = 0;
-    const u16* __restrict__ xs = p.x + ci0 + c8 * 8;
-    const u16* __restrict__ dys = p.dy + co0 + c8 * 8;
-    const u16* __restrict__ dy2s = p.dy2 + co0 + c8 * 8;
-
-    auto issue = [&](int ch) {
-        const unsigned mc0 = (unsigned)ch * 64;
-        if constexpr (KK == 1) {                                   // 1x1: the "patch" is the 64 pixels themselves
-            npos = 64;
-#pragma unroll
-            for (int j = 0; j < MAXA; ++j) {
-                const unsigned pos = (tid + NT * j) >> 2;
-                unsigned Rp, wq;
-                pix_rp(g, min(mc0 + pos, M - 1), Rp, wq);
-                offa[j] = src_off(g, Rp, wq, mc0 + pos < M);
-                qa[j] = *reinterpret_cast<const uint4*>(xs + (offa[j] == NONE ? 0u : offa[j]));
-            }
-        } else {
-            unsigned Rp_hi, wtmp;
+    // ---- geometry tables for all of this block's chunks: patch offset of every pixel, source offset of every patch row
+    for (int i = tid; i < nmine * 64; i += KK * 64) {
+        const int lc = i >> 6, px = i & 63;
+        const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+        unsigned q = px * 64;
+        if constexpr (KK != 1) {
+            unsigned Rp_lo, Rp, wq, wtmp;
             pix_rp(g, mc0, Rp_lo, wtmp);
-            pix_rp(g, min(mc0 + 63, M - 1), Rp_hi, wtmp);
-            npos = min((Rp_hi + g.K - Rp_lo) * g.Wp, (unsigned)p.cap_pos);
+            pix_rp(g, min(mc0 + px, M - 1), Rp, wq);
+            q = ((Rp - Rp_lo) * g.Wp + wq) * 64;
+            if (mc0 + px >= M || q + ((g.K - 1) * g.Wp + g.K) * 64 > (unsigned)p.cap_pos * 64) q = 0;   // past the batch: its dY row is zero
+        }
+        qtabs[i] = q;
+    }
+    if constexpr (KK != 1) {
+        for (int i = tid; i < nmine * WG_ROWS; i += KK * 64) {
+            const int lc = i / WG_ROWS, pr = i % WG_ROWS;
+            unsigned Rp_lo, wtmp;
+            pix_rp(g, (unsigned)(c_first + lc) * 64, Rp_lo, wtmp);
+            const unsigned Rp = Rp_lo + pr, b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
+            const int u = (int)hp - g.pt;
+            rowt[i] = (u >= 0 && u < g.Hs && b < (unsigned)g.B) ? ((b * g.Hs + u) * g.Ws) * g.Cin : NONE;
+        }
+    }
+    // ---- per-lane, chunk-independent part of every DMA piece this wave issues
+    constexpr int MAXNI = KK == 1 ? 8 : WG_MAXNI;
+    int jj[MAXNI]; unsigned prow_i[MAXNI], col_i[MAXNI], row_i[MAXNI];
 #pragma unroll
-            for (int j = 0; j < MAXA; ++j) {
-                const unsigned pos = (tid + NT * j) >> 2;
-                const unsigned prow = udiv(pos, g.mg_wp, (unsigned)g.Wp), wp = pos - prow * g.Wp;
-                offa[j] = src_off(g, Rp_lo + prow, wp, pos < npos);
-                qa[j] = *reinterpret_cast<const uint4*>(xs + (offa[j] == NONE ? 0u : offa[j]));
-            }
+    for (int i = 0; i < MAXNI; ++i) {
+        const int j = min(w + KK * i, nblk_i - 1);
+        jj[i] = j;
+        const unsigned piece = (j < 4 ? j : j - 4) * 64 + lane, c8 = piece & 3, row = piece >> 2;
+        row_i[i] = row;
+        if (j < 4) { prow_i[i] = 0; col_i[i] = co0 + c8 * 8; }
+        else if constexpr (KK == 1) { prow_i[i] = 0; col_i[i] = ci0 + c8 * 8; }
+        else {
+            const unsigned prow = udiv(row, g.mg_wp, (unsigned)g.Wp), wp = row - prow * g.Wp;
+            const int v = (int)wp - g.pl;
+            prow_i[i] = min(prow, (unsigned)WG_ROWS - 1);
+            col_i[i] = (v >= 0 && v < g.Ws && prow < (unsigned)WG_ROWS) ? (unsigned)v * g.Cin + ci0 + c8 * 8 : NONE;
         }
-#pragma unroll
-        for (int j = 0; j < ND; ++j) {
-            const unsigned m = mc0 + ((tid + NT * j) >> 2);
-            const size_t o = (size_t)min(m, M - 1) * p.Cout;
-            qd[j] = *reinterpret_cast<const uint4*>(dys + o);
-            if constexpr (DF != 0) qd2[j] = *reinterpret_cast<const uint4*>(dy2s + o); else qd2[j] = qd[j];
-        }
-    };
-    auto store = [&](int ch, unsigned char* buf) {
-        const unsigned mc0 = (unsigned)ch * 64;
-        unsigned* qtab = reinterpret_cast<unsigned*>(buf);
-        unsigned char* dyt = buf + 256;
-        unsigned char* ap = buf + 256 + 64 * 64;
-        unsigned char* dump = ap + (unsigned)p.cap_pos * 64 + (tid & 63) * 16;
-#pragma unroll
-        for (int j = 0; j < MAXA; ++j) {
-            const unsigned pos = (tid + NT * j) >> 2;
-            const uint4 r = xform<AF>(qa[j], qa[j], kA);                // branch-free: unused pieces land in a scratch slot
-            *reinterpret_cast<uint4*>(pos < npos ? ap + pos * 64 + c8 * 16 : dump) = offa[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
-        }
-#pragma unroll
-        for (int j = 0; j < ND; ++j) {
-            const unsigned i = tid + NT * j, m = mc0 + (i >> 2);
-            const uint4 r = xform<DF>(qd[j], qd2[j], kD);
-            *reinterpret_cast<uint4*>(i < 256 ? dyt + (i >> 2) * 64 + c8 * 16 : dump) = m < M ? r : make_uint4(0, 0, 0, 0);
-        }
-        if (tid < 64) {
-            unsigned q = tid * 64;
-            if constexpr (KK != 1) {
-                unsigned Rp, wq;
-                pix_rp(g, min(mc0 + tid, M - 1), Rp, wq);
-                q = ((Rp - Rp_lo) * g.Wp + wq) * 64;
-                if (mc0 + tid >= M || q + ((g.K - 1) * g.Wp + g.K) * 64 > npos * 64) q = 0;   // past the batch (dY row is zero) / cap_pos clamp
-            }
-            qtab[tid] = q;
-        }
-    };
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    TSTAMP(2);
 
-    f32x16 acc;
+    auto issue = [&](int lc) {
+        const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+        const unsigned dst0 = bufs0 + (unsigned)(lc % WG_NBUF) * buf_bytes;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int i = 0; i < MAXNI; ++i) {
+            if (i < NI) {
+                const int j = jj[i];
+                const void* src;
+                if (j < 4) {                                       // dY rows
+                    const unsigned m = mc0 + row_i[i];
+                    src = m < M ? (const void*)(p.dy + (size_t)m * p.Cout + col_i[i]) : (const void*)(p.zero + lane);
+                } else if constexpr (KK == 1) {                    // 1x1: the "patch" is the 64 pixels themselves
+                    unsigned Rp, wq;
+                    pix_rp(g, min(mc0 + row_i[i], M - 1), Rp, wq);
+                    const unsigned off = src_off(g, Rp, wq, mc0 + row_i[i] < M);
+                    src = off != NONE ? (const void*)(p.x + off + col_i[i]) : (const void*)(p.zero + lane);
+                } else {
+                    const unsigned rb = rowt[lc * WG_ROWS + prow_i[i]];
+                    src = (rb != NONE && col_i[i] != NONE) ? (const void*)(p.x + rb + col_i[i]) : (const void*)(p.zero + lane);
+                }
+                dma16(src, dst0 + (unsigned)j * 1024);
+            }
+        }
+    };
+    for (int k = 0; k < WG_NBUF - 1 && k < nmine; ++k) issue(k);
+    TSTAMP(3);
+
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     float bsum = 0.f;
     const bool do_bias = p.dbias != nullptr && w == 0 && blockIdx.y == 0;
     const unsigned toff = KK == 1 ? 0u : (unsigned)(((w / g.K) * g.Wp + (w % g.K)) * 64);
@@ -467,50 +558,96 @@ __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
     const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2;
     const unsigned prb = 8 * kh + (gi >> 2);
 
-    if (c_first < c_end) issue(c_first);
-    for (int ch = c_first; ch < c_end; ++ch) {
-        unsigned char* buf = bufs + ((ch - c_first) & 1) * buf_bytes;
-        store(ch, buf);
-        __syncthreads();
-        if (ch + 1 < c_end) issue(ch + 1);
-        const unsigned* qtab = reinterpret_cast<const unsigned*>(buf);
-        const unsigned char* dyt = buf + 256;
-        const unsigned char* ap = buf + 256 + 64 * 64;
-        unsigned q0[4], q1[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { q0[ks] = qtab[16 * ks + prb]; q1[ks] = qtab[16 * ks + prb + 4]; }
-        bf16x8 Af[4], Bf[4];
+    // Chunk loop, software-pipelined by one chunk: iteration lc waits for chunk lc's DMA, passes the barrier, starts the DMA
+    // of chunk lc+3, ISSUES the transpose-reads of chunk lc -- and multiplies chunk lc-1, whose operands were read one
+    // iteration earlier (LDS latency is hidden behind MFMAs and DMA issue instead of sitting between barrier and MFMA).
+    bf16x8 Af[2][4], Bf[2][4];
+    auto read_ops = [&](int lc, bf16x8 (&A)[4], bf16x8 (&Bm)[4]) {
+        const unsigned char* buf = bufs + (size_t)(lc % WG_NBUF) * buf_bytes;
+        const unsigned* qtab = qtabs + lc * 64;
+        const unsigned char* dyt = buf;
+        const unsigned char* ap = buf + 64 * 64;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const unsigned pr0 = 16 * ks + prb, pr1 = pr0 + 4;
+            const unsigned q0 = qtab[pr0], q1 = qtab[pr1];
             const s16x4 b_lo = lds_tr(dyt, pr0 * 64 + colb), b_hi = lds_tr(dyt, pr1 * 64 + colb);
-            const s16x4 a_lo = lds_tr(ap, q0[ks] + toff + colb), a_hi = lds_tr(ap, q1[ks] + toff + colb);
-            Af[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            Bf[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            const s16x4 a_lo = lds_tr(ap, q0 + toff + colb), a_hi = lds_tr(ap, q1 + toff + colb);
+            A[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            Bm[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[ks], Bf[ks], acc, 0, 0, 0);
+    };
+    auto mma = [&](const bf16x8 (&A)[4], const bf16x8 (&Bm)[4]) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bm[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bm[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bm[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], Bm[3], acc2, 0, 0, 0);
         if (do_bias) {                                             // wave-uniform (scalar branch)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += (float)Bf[ks][j];
+                for (int j = 0; j < 8; ++j) bsum += (float)Bm[ks][j];
         }
+    };
+    auto step = [&](int lc, bf16x8 (&An)[4], bf16x8 (&Bn)[4], const bf16x8 (&Ao)[4], const bf16x8 (&Bo)[4]) {
+        // chunk lc has landed once at most min(nmine-1-lc, NBUF-2) younger chunks of this wave are still in flight
+        wait_vm_n(NI * min(nmine - 1 - lc, WG_NBUF - 2));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's transpose-reads of chunk lc-1 are done
+        __builtin_amdgcn_s_barrier();                              // everyone's pieces landed; everyone has read chunk lc-1
+        if (lc + WG_NBUF - 1 < nmine) issue(lc + WG_NBUF - 1);     // into the slot chunk lc-1 just left
+        read_ops(lc, An, Bn);
+        if (lc > 0) mma(Ao, Bo);
+    };
+    int lc = 0;
+    for (; lc + 1 < nmine; lc += 2) {
+        step(lc, Af[0], Bf[0], Af[1], Bf[1]);
+        step(lc + 1, Af[1], Bf[1], Af[0], Bf[0]);
     }
-    // ---- flush: dw[tap][ci0+row][co0+col] += acc
+    if (lc < nmine) { step(lc, Af[0], Bf[0], Af[1], Bf[1]); mma(Af[0], Bf[0]); }
+    else if (nmine > 0) mma(Af[1], Bf[1]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    TSTAMP(4);
+    // ---- flush: part[slice][tap][ci0+row][co0+col] = acc (plain coalesced stores; slices with no chunk write zeros)
     {
         const int col = lane & 31;
-        float* o = p.dw + ((size_t)w * g.Cin + ci0) * p.Cout + co0 + col;
+        float* o = p.part + ((size_t)blockIdx.x * KK + w) * g.Cin * p.Cout + (size_t)ci0 * p.Cout + co0 + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(o + (size_t)row * p.Cout, acc[r]);
+            o[(size_t)row * p.Cout] = acc[r];
         }
         if (do_bias) {
             bsum += __shfl_xor(bsum, 32, 64);
             if (lane < 32) atomicAdd(p.dbias + co0 + lane, bsum);
         }
     }
+    TSTAMP(5); TSTAMP(15);
+}
+
+// dw[e] += sum over slices of part[slice][e], many convolutions per launch.  Rows of 8 x int64: {part, dw, slices, n elements,
+// first_block, 0, 0, 0}; 1024 elements per block (n is a multiple of 1024: 32x32 tiles).
+struct RedRow { const float* part; float* dw; long slices, n, first_block, pad0_, pad1_, pad2_; };
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedRow* __restrict__ tab, int nrows) {
+    int r = 0;
+    while (r + 1 < nrows && (long)blockIdx.x >= tab[r + 1].first_block) ++r;
+    const RedRow row = tab[r];
+    const long e = (((long)blockIdx.x - row.first_block) * 256 + threadIdx.x) * 4;
+    if (e >= row.n) return;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    long sl = 0;
+    for (; sl + 1 < row.slices; sl += 2) {                         // two independent chains: loads in flight
+        const float4 a = *reinterpret_cast<const float4*>(row.part + sl * row.n + e);
+        const float4 b = *reinterpret_cast<const float4*>(row.part + (sl + 1) * row.n + e);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (sl < row.slices) {
+        const float4 a = *reinterpret_cast<const float4*>(row.part + sl * row.n + e);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    float4 d = *reinterpret_cast<const float4*>(row.dw + e);
+    d.x += s0.x + s1.x; d.y += s0.y + s1.y; d.z += s0.z + s1.z; d.w += s0.w + s1.w;
+    *reinterpret_cast<float4*>(row.dw + e) = d;
 }
 
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
@@ -705,10 +842,11 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, hipSt
 // Generic bf16 convolution: y[M][Cout] = sum over taps, channels of T(src)[padded position] * wpk (+ bias) (+ res), with
 //   fill 0: T = identity; 1: T = relu(bn(.)) of `fbn` (forward statistics from fbn->bins, or fbn->saved when bins is null);
 //        2: T = BatchNorm(+ReLU) backward of (da = src, y = src2) through `fbn`.
+//   side (nullable): T(src) written back to HBM (shape of src) -- the plain operand of the matching weight gradient.
 //   epi  0: none; 1: sum / sum of squares of y into e_bins; 2: BatchNorm-backward sums of y (= da) against (e_y, e_saved).
 // Forward: d = 1, s = stride, pads as TF.  Input gradient: src = dy, d = stride, s = 1, pt = K-1-pad_top, wpk = dgrad stream.
-int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, int B,
-                    int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, hipStream_t stream) {
     ConvP p;
     memset(&p, 0, sizeof(p));
@@ -720,22 +858,28 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
     if ((long)B * Hs * Ws * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
     p.Cout = Cout;
     p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.wpk = static_cast<const bf16x8*>(wpk);
-    p.bias = bias; p.res = static_cast<const u16*>(res); p.y = static_cast<u16*>(y);
+    p.bias = bias; p.res = static_cast<const u16*>(res); p.y = static_cast<u16*>(y); p.side = static_cast<u16*>(side);
     p.fill = fill; if (fbn) p.fb = *fbn;
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;
     p.lg_pc = ilog2(Cin / 8); p.rs = Cin * 2 + 16;
     p.Fs = K * K * Cin / 16 + 8;
     const int WN = Cout >= 64 ? 2 : 1, TM = 32 * (4 / WN), TN = 32 * WN;
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
-    const size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024, stage_bytes = (size_t)TM * TN * 4 + 256 / (TN / 2) * TN * 2 * 4;
-    const size_t lds = CST_BYTES + (patch_bytes > stage_bytes ? patch_bytes : stage_bytes);
+    if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
+    const size_t ring_bytes = (size_t)3 * WN * 8 * 1024;
+    size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
+    const size_t stage_bytes = (size_t)TM * TN * 4 + 256 / (TN / 2) * TN * 2 * 4;
+    if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
+    patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
+    p.patch_bytes = (int)patch_bytes;
+    const size_t lds = CST_BYTES + ROWTAB_BYTES + patch_bytes + ring_bytes;
     if (lds > 160 * 1024) return SAR_EINVAL;
     const dim3 grid((unsigned)cdiv(p.g.M, TM), (unsigned)(Cout / TN));
-    // instantiations: [WN][log2(NKC)-1][K == 3]; Cin = 512 runs NKC = 16 with two channel halves per tap
+    // instantiations: [WN][NKC in {2,4,8}][K == 3]; Cin = 256 / 512 run NKC = 8 with 2 / 4 channel parts per tap
     typedef void (*kern_t)(const ConvP);
-#define CV(WN_, NKC_) {conv_bf16_kernel<WN_, NKC_, 1>, conv_bf16_kernel<WN_, NKC_, 9>}
-    static const kern_t kerns[2][5][2] = {{CV(1, 2), CV(1, 4), CV(1, 8), CV(1, 16), {conv_bf16_kernel<1, 16, 2>, conv_bf16_kernel<1, 16, 18>}},
-                                          {CV(2, 2), CV(2, 4), CV(2, 8), CV(2, 16), {conv_bf16_kernel<2, 16, 2>, conv_bf16_kernel<2, 16, 18>}}};
+#define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
+    static const kern_t kerns[2][5][2] = {{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
+                                          {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}};
 #undef CV
     static bool attr[2][5][2];
     const int ki = ilog2(Cin / 16) - 1, k3 = K == 3 ? 1 : 0;
@@ -746,40 +890,63 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
     return SAR_OK;
 }
 
-// Kernel gradient dw[K][K][Cin][Cout] += T_a(x)^T (*) T_d(dy) (+ dbias += column sums of T_d(dy), nullable).
-//   a_fill 0: x as stored; 1: relu(bn(x)) with abn->saved.   d_fill 0: dy as stored; 2: BatchNorm(+ReLU) backward of
-//   (da = dy, y = dy2) through dbn (sums from dbn->bbins).  Geometry as the forward conv (s = stride, pads as TF).
-int sar_conv2d_wgrad_bf16(const void* x, int a_fill, const sarBnRef* abn, const void* dy, const void* dy2, int d_fill,
-                          const sarBnRef* dbn, float* dw, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                          int K, int s, int pt, int pl, hipStream_t stream) {
+// Pixel slices of the weight gradient of one convolution (the first dimension of its partial buffer).
+static int wgrad_slices(int M, int Cin, int Cout, int* cpb_out) {
+    const int nchunks = cdiv(M, 64), pairs = (Cin / 32) * (Cout / 32);
+    int P = 256 / pairs; if (P < 1) P = 1; if (P > nchunks) P = nchunks;
+    const int cpb = cdiv(nchunks, P);
+    if (cpb_out) *cpb_out = cpb;
+    return cdiv(nchunks, cpb);
+}
+int sar_conv2d_wgrad_slices_bf16(int B, int Ho, int Wo, int Cin, int Cout) {
+    if (B < 1 || Ho < 1 || Wo < 1 || Cin < 32 || Cout < 32 || (long)B * Ho * Wo >= (1L << 31)) return SAR_EINVAL;
+    return wgrad_slices(B * Ho * Wo, Cin, Cout, nullptr);
+}
+
+// Kernel-gradient partials: part[slices][K][K][Cin][Cout] = per-slice x^T (*) dy on plain bf16 operands (slices =
+// sar_conv2d_wgrad_slices_bf16; every element is written), dbias (nullable) += column sums of dy (fp32 atomics).
+// Geometry as the forward conv (s = stride, pads as TF).  sar_wgrad_reduce_f32 then adds the slices into the gradient.
+int sar_conv2d_wgrad_bf16(const void* x, const void* dy, float* part, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo,
+                          int Cout, int K, int s, int pt, int pl, hipStream_t stream) {
     WgP p;
     memset(&p, 0, sizeof(p));
     if (!make_geo(p.g, B, H, W, Cin, Ho, Wo, K, s, 1, pt, pl)) return SAR_EINVAL;
-    if (!pow2(Cin) || !pow2(Cout) || Cin < 32 || Cout < 32 || Cin > CMAX || Cout > CMAX) return SAR_EINVAL;
-    if ((a_fill != 0 && a_fill != 1) || (d_fill != 0 && d_fill != 2) || (a_fill && abn == nullptr) || (d_fill && (dbn == nullptr || dy2 == nullptr))) return SAR_EINVAL;
+    if (!pow2(Cin) || !pow2(Cout) || Cin < 32 || Cout < 32 || Cin > CMAX || Cout > CMAX || part == nullptr) return SAR_EINVAL;
     if ((long)B * H * W * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
     p.Cout = Cout;
-    p.x = static_cast<const u16*>(x); p.a_fill = a_fill; if (abn) p.ab = *abn;
-    p.dy = static_cast<const u16*>(dy); p.dy2 = static_cast<const u16*>(dy2); p.d_fill = d_fill; if (dbn) p.db = *dbn;
-    p.dw = dw; p.dbias = dbias;
+    p.x = static_cast<const u16*>(x); p.dy = static_cast<const u16*>(dy); p.part = part; p.dbias = dbias;
+    static const uint4* zero_page = nullptr;
+    if (zero_page == nullptr) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return SAR_ELAUNCH;
+        zero_page = static_cast<const uint4*>(zp);
+    }
+    p.zero = zero_page;
     p.nchunks = cdiv(p.g.M, 64);
-    const int pairs = (Cin / 32) * (Cout / 32);
-    int P = 256 / pairs; if (P < 1) P = 1; if (P > p.nchunks) P = p.nchunks;
-    p.cpb = cdiv(p.nchunks, P); P = cdiv(p.nchunks, p.cpb);
+    const int P = wgrad_slices(p.g.M, Cin, Cout, &p.cpb);
     const int NT = K == 3 ? 576 : 64;
     p.cap_pos = K == 3 ? patch_rows_bound(p.g, 64 < p.g.M ? 64 : p.g.M) * p.g.Wp : 64;
-    if (K == 3 && p.cap_pos > WG_MAXA * NT / 4) return SAR_EINVAL;    // a chunk's patch must fit the per-thread prefetch registers
-    const size_t lds = 2 * CST_BYTES + 2 * (size_t)(256 + 64 * 64 + p.cap_pos * 64 + 1024);
-    if (lds > 160 * 1024) return SAR_EINVAL;
+    p.cap_pos = (p.cap_pos + 15) & ~15;
+    const size_t lds = (size_t)p.cpb * (256 + WG_ROWS * 4) + (size_t)WG_NBUF * (64 * 64 + (size_t)p.cap_pos * 64);
+    const int ni = cdiv(4 + p.cap_pos / 16, K == 3 ? 9 : 1);
+    if (K == 3 && p.cap_pos / p.g.Wp > WG_ROWS) return SAR_EINVAL;
+    if (lds > 160 * 1024 || ni > (K == 3 ? WG_MAXNI : 8) || ni * (WG_NBUF - 2) > 16 || ni * (WG_NBUF - 1) > 60) return SAR_EINVAL;   // vmcnt is a 6-bit counter
     const dim3 grid((unsigned)P, (unsigned)(Cin / 32), (unsigned)(Cout / 32));
-    typedef void (*kern_t)(const WgP);
-    static const kern_t kerns[2][2][2] = {{{wgrad_bf16_kernel<9, 0, 0>, wgrad_bf16_kernel<9, 0, 2>}, {wgrad_bf16_kernel<9, 1, 0>, wgrad_bf16_kernel<9, 1, 2>}},
-                                          {{wgrad_bf16_kernel<1, 0, 0>, wgrad_bf16_kernel<1, 0, 2>}, {wgrad_bf16_kernel<1, 1, 0>, wgrad_bf16_kernel<1, 1, 2>}}};
-    static bool attr[2][2][2] = {{{false, false}, {false, false}}, {{false, false}, {false, false}}};
-    const int i0 = K == 3 ? 0 : 1, i1 = a_fill ? 1 : 0, i2 = d_fill ? 1 : 0;
-    const kern_t kern = kerns[i0][i1][i2];
-    if (!attr[i0][i1][i2]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[i0][i1][i2] = true; }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, p);
+    static bool attr9 = false, attr1 = false;
+    if (K == 3) {
+        if (!attr9) { if (!allow_lds(wgrad_bf16_kernel<9>, 160 * 1024)) return SAR_ELAUNCH; attr9 = true; }
+        hipLaunchKernelGGL(wgrad_bf16_kernel<9>, grid, dim3(NT), lds, stream, p);
+    } else {
+        if (!attr1) { if (!allow_lds(wgrad_bf16_kernel<1>, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
+        hipLaunchKernelGGL(wgrad_bf16_kernel<1>, grid, dim3(NT), lds, stream, p);
+    }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+int sar_wgrad_reduce_f32(const void* table, int n, int total_blocks, hipStream_t stream) {
+    if (table == nullptr || n < 1 || total_blocks < 1) return SAR_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const RedRow*>(table), n);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -841,5 +1008,11 @@ int sar_cast_bf16_f32(const void* x, float* y, long n, hipStream_t stream) {
 }
 
 int sar_bn_bins(void) { return NB; }
+
+#ifdef SAR_TIMING
+int sar_dbg_set_timing_buffer16(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf16), &buf, sizeof(buf)) == hipSuccess ? SAR_OK : SAR_ELAUNCH;
+}
+#endif
 
 }  // extern "C"

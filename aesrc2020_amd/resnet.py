@@ -112,20 +112,26 @@ class _Conv:
         self.wd = b.get(self.name + "/wd16", (nd,), torch.bfloat16)
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
-    def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None):
-        _call("sar_conv2d_bf16", x, None, self.wf, self.bias.w, res, y, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+    def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
+        _call("sar_conv2d_bf16", x, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
               self.k, self.stride, 1, self.pt, self.pl, fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
 
-    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None):
-        """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2; the epilogue
-        leaves the backward sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
-        _call("sar_conv2d_bf16", dy, dy2, self.wd, None, res, dx, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
+    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None):
+        """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2 (written back to
+        `side` for the weight gradient); the epilogue leaves the backward sums of the BatchNorm in FRONT of this conv (input
+        e_y) in e_bins."""
+        _call("sar_conv2d_bf16", dy, dy2, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
               self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
               e_bins, e_y, e_saved)
 
-    def wgrad16(self, x, a_fill, abn, dy, dy2, d_fill, dbn, B, bias_grad):
-        _call("sar_conv2d_wgrad_bf16", x, a_fill, abn, dy, dy2, d_fill, dbn, self.kernel.g, self.bias.g if bias_grad else None,
+    def wgrad16(self, x, dy, B, bias_grad):
+        """Partial kernel gradients of this conv (plain operands); ResNetTrunk._reduce16 adds the slices into kernel.g."""
+        P = _lib.lib().fn["sar_conv2d_wgrad_slices_bf16"](B, self.Ho, self.Wo, self.cin, self.cout)
+        n = self.k * self.k * self.cin * self.cout
+        self.part = self.store.bufs.get(self.name + "/wgrad_part", (P, n))
+        _call("sar_conv2d_wgrad_bf16", x, dy, self.part, self.bias.g if bias_grad else None,
               B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.stride, self.pt, self.pl)
+        return [self.part.data_ptr(), self.kernel.g.data_ptr(), P, n]
 
     def out_hw(self, H, W):
         if self.padding == "same":
@@ -293,8 +299,11 @@ class ResNetTrunk(Layer):
             blk["x"] = cur
             bn1, bn2 = blk["bn1"], blk["bn2"]
             c1 = self._buf16("b%d_c1" % n, (B, H2, W2, cout))
+            # training: the activated operands relu(bn(.)) the fills compute are written back (a, a1) for the weight gradients
+            blk["a"] = self._buf16("b%d_a" % n, tuple(cur.shape)) if (training and bn1 is not None) else None
+            blk["a1"] = self._buf16("b%d_a1" % n, (B, H2, W2, cout)) if training else None
             blk["conv1"].fwd16(cur, c1, B, fill=1 if bn1 is not None else 0, fbn=bn1.ref(B * H * W, st, training) if bn1 is not None else None,
-                               e_bins=bn2.bins if training else None)
+                               e_bins=bn2.bins if training else None, side=blk["a"])
             if blk["sc"] is not None:
                 sc = self._buf16("b%d_sc" % n, (B, H2, W2, cout))
                 blk["sc"].fwd16(cur, sc, B)
@@ -302,7 +311,8 @@ class ResNetTrunk(Layer):
                 sc = cur
             y = self._buf16("b%d_y" % n, (B, H2, W2, cout))
             nxt = self.blocks[n + 1]["bn1"] if n + 1 < nblk else self.final_bn
-            blk["conv2"].fwd16(c1, y, B, fill=1, fbn=bn2.ref(B * H2 * W2, st, training), res=sc, e_bins=nxt.bins if training else None)
+            blk["conv2"].fwd16(c1, y, B, fill=1, fbn=bn2.ref(B * H2 * W2, st, training), res=sc, e_bins=nxt.bins if training else None,
+                               side=blk["a1"])
             blk["c1"] = c1
             cur = y
         H, W = self.out_hw
@@ -324,6 +334,7 @@ class ResNetTrunk(Layer):
             g = self._g_part
         stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
         bf = torch.bfloat16
+        self._red16 = []
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
             if blk["stage"] not in stages:
@@ -332,38 +343,54 @@ class ResNetTrunk(Layer):
             cin, cout = blk["cin"], blk["cout"]
             R1, R2 = B * H * W, B * H2 * W2
             bn1, bn2, c1, x = blk["bn1"], blk["bn2"], blk["c1"], blk["x"]
-            # conv2: operand relu(bn2(c1)); its input gradient da2 leaves the two sums of bn2's backward in bn2.bbins
+            # conv2: operand a1 = relu(bn2(c1)) (written back by the forward fill); its input gradient da2 leaves the two sums of
+            # bn2's backward in bn2.bbins
+            red = []
             da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
             blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
-            blk["conv2"].wgrad16(c1, 1, bn2.ref(R2, "saved", False), g, None, 0, None, B, bias_grad=True)
-            # conv1's output gradient dc1 = BN+ReLU backward of (da2, c1) is never materialised: both consumers evaluate it in
-            # their fills; the weight-gradient launch owns bn2's parameter gradients
-            blk["conv1"].wgrad16(x, 1 if bn1 is not None else 0, bn1.ref(R1, "saved", False) if bn1 is not None else None,
-                                 da2, c1, 2, bn2.ref(R2, "bwd", True), B, bias_grad=False)
+            red.append(blk["conv2"].wgrad16(blk["a1"], g, B, bias_grad=True))
             gin = self.scratch("res16_gin%d_%dx%dx%d" % (n & 1, H, W, cin), (B, H, W, cin), bf)       # ping-pong: never aliases g
             if blk["sc"] is not None:
                 dsc = gin if bn1 is None else self.scratch("res16_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
                 blk["sc"].dgrad16(g, None, dsc, B)
-                blk["sc"].wgrad16(x, 0, None, g, None, 0, None, B, bias_grad=True)
+                red.append(blk["sc"].wgrad16(x, g, B, bias_grad=True))
             else:
                 dsc = g
+            # conv1's output gradient dc1 = BN+ReLU backward of (da2, c1): evaluated in the fill of conv1's input-gradient launch
+            # (which owns bn2's parameter gradients) and written back for the weight gradient
+            dc1 = self.scratch("res16_dc1_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
             if bn1 is not None:
                 da1 = self.scratch("res16_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
-                blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved)
+                blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
                 _call("sar_bn_bwd_apply_bf16", da1, 0, x, bn1.ref(R1, "bwd", True), dsc, gin, R1, cin, 1)
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
-                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=dsc)
+                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True), res=dsc, side=dc1)
+            red.append(blk["conv1"].wgrad16(blk["a"] if bn1 is not None else x, dc1, B, bias_grad=False))
+            self._red16.extend(red)
             if getattr(self, "debug_tap", None) is not None:          # tests/test_gpu_bf16_trunk.py: per-block tensors before reuse
                 self.debug_tap(n, g, da2, gin)
             g = gin
         self._g_part = g
+        self._reduce16(part)
         if part in (0, 1):
             return None
         g32 = self.scratch("res16_g32", tuple(g.shape))
         _call("sar_cast_bf16_f32", g, g32, g.numel())
         self._stem_backward(g32, B)
         return None
+
+    def _reduce16(self, part):
+        """One launch adds the per-slice partial weight gradients of every conv of this backward part into the flat gradient."""
+        key = "_redtab_%s" % (part,)
+        rows, blk0 = [], 0
+        for pp, gg, P, n in self._red16:
+            rows.append([pp, gg, P, n, blk0, 0, 0, 0]); blk0 += n // 1024
+        tab = getattr(self, key, None)
+        if tab is None or tab[2] != rows:                           # pointers and shapes are static per (B, T): upload once
+            tab = (torch.tensor(rows, dtype=torch.int64, device="cuda"), blk0, rows)
+            setattr(self, key, tab)
+        _call("sar_wgrad_reduce_f32", tab[0], tab[0].shape[0], tab[1])
 
     def _stem_forward(self, x, B):
         T, D = self.in_hw

@@ -77,11 +77,8 @@ def conv_roofline(model, B, iters=10):
                 # the launches of the train step: BN+ReLU in the forward / weight-gradient fills (saved constants), plain gradient
                 fb = bn.ref(B * cv.H * cv.W, "saved", False) if bn is not None else None
                 fl = 1 if bn is not None else 0
-                dw = torch.zeros_like(cv.kernel.g)
                 add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd16(x, y, B, fill=fl, fbn=fb)), flops, act_b)
-                add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: _lib.call(
-                    "sar_conv2d_wgrad_bf16", x, fl, fb, y, None, 0, None, dw, None, B, cv.H, cv.W, cv.cin, cv.Ho, cv.Wo, cv.cout, cv.k,
-                    cv.stride, cv.pt, cv.pl)), flops, act_b)
+                add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.wgrad16(x, y, B, False)), flops, act_b)
                 add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad16(y, None, dx, B)), flops, act_b)
                 continue
             add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd(x, y, B, bn=bn)), flops, act_b)

@@ -140,19 +140,25 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarSt
  *   y[B*Ho*Wo][Cout] = sum_taps T(src)[padded position] * wpk (+ bias) (+ res)
  * fill 0: T = identity; 1: T = relu(bn(.)) of fbn (statistics from fbn->bins, or fbn->saved when bins is NULL: inference /
  * recompute); 2: T = BatchNorm+ReLU backward of (da = src, y = src2) through fbn (sums from fbn->bbins).
+ * side (nullable, shape of src): T(src) written back to HBM -- the plain operand of the matching weight gradient.
  * epi 0: none; 1: sum and sum of squares of y into e_bins (the statistics of the BatchNorm that consumes y); 2: the two
  * BatchNorm-backward sums of y (= da) against (e_y = that BN's input, e_saved) into e_bins.
  * Forward: d = 1, s = stride, pt/pl = TF pads, wpk = wf.  Input gradient: src = dy, Hs/Ws = its size, d = stride, s = 1,
  * Ho/Wo = the forward INPUT size, pt = K-1-pad_top, pl = K-1-pad_left, wpk = wd.  K in {1,3}; Cin, Cout powers of two in
  * [32, 512]. */
-int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, int B,
-                    int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
-/* Kernel gradient dw[K][K][Cin][Cout] += T_a(x)^T (*) T_d(dy) (fp32 atomics), dbias (nullable) += column sums of T_d(dy).
- * a_fill 0 | 1 (relu(bn(x)) with abn->saved); d_fill 0 | 2 (BatchNorm+ReLU backward of (da = dy, y = dy2) through dbn). */
-int sar_conv2d_wgrad_bf16(const void* x, int a_fill, const sarBnRef* abn, const void* dy, const void* dy2, int d_fill,
-                          const sarBnRef* dbn, float* dw, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout,
-                          int K, int s, int pt, int pl, sarStream_t stream);
+/* Kernel gradient in two steps.  (1) part[slices][K][K][Cin][Cout] = per-pixel-slice x^T (*) dy on PLAIN bf16 operands (x: the
+ * `side` tensor of the forward conv, or the raw input of a shortcut / first conv; dy: the gradient tensor, for a conv that
+ * feeds a BatchNorm the `side` tensor of its input-gradient launch); slices = sar_conv2d_wgrad_slices_bf16(B, Ho, Wo, Cin, Cout);
+ * every element of part is written.  dbias (nullable) += column sums of dy.  (2) sar_wgrad_reduce_f32: dw += sum of the slices,
+ * many convolutions per launch: table = device array of n rows of 8 x int64 {part, dw, slices, K*K*Cin*Cout, first_block, 0, 0, 0},
+ * blocks per row = K*K*Cin*Cout/1024, first_block = running sum. */
+int sar_conv2d_wgrad_slices_bf16(int B, int Ho, int Wo, int Cin, int Cout);
+int sar_conv2d_wgrad_bf16(const void* x, const void* dy, float* part, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo,
+                          int Cout, int K, int s, int pt, int pl, sarStream_t stream);
+int sar_wgrad_reduce_f32(const void* table, int n, int total_blocks, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
 int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
                           int C, int relu, sarStream_t stream);

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""In-kernel phase timing of the bf16 trunk kernels (developer tool).
+
+    make -C aesrc2020_amd/csrc timing && python tools/conv16_timing.py [fwd|dgrad|wgrad]
+
+Loads tools/libsarnet_timing16.so (conv_bf16.hip built with -DSAR_TIMING): thread 0 of every block stamps the shader clock
+at phase boundaries.  Per layer shape: distribution over blocks of the phases (cycles) and the device-wide timeline of block
+starts / ends (us, 100 MHz real-time counter)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing16.so"))
+vp, ci = ctypes.c_void_p, ctypes.c_int
+lib.sar_conv2d_bf16.argtypes = [vp] * 7 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
+lib.sar_conv2d_wgrad_bf16.argtypes = [vp] * 4 + [ci] * 11 + [vp]
+lib.sar_conv2d_wgrad_slices_bf16.argtypes = [ci] * 5
+lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
+lib.sar_dbg_set_timing_buffer16.argtypes = [vp]
+BF = torch.bfloat16
+mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+B = int(os.environ.get("CB", 64))
+SHAPES = [("s0 3x3 32->32", 100, 20, 32, 32, 3), ("s1 3x3 64->64", 50, 10, 64, 64, 3), ("s2 3x3 128->128", 25, 5, 128, 128, 3),
+          ("s3 3x3 256->256", 13, 3, 256, 256, 3)]
+st = torch.cuda.current_stream().cuda_stream
+for name, H, W, Cin, Cout, k in SHAPES:
+    x = torch.randn(B, H, W, Cin, device="cuda").to(BF); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
+    y = torch.zeros(B, H, W, Cout, device="cuda", dtype=BF); dw = torch.zeros_like(w)
+    taps = k * k
+    nf = (Cout // 32) * (taps * Cin // 16 + 8) * 512; nd = (Cin // 32) * (taps * Cout // 16 + 8) * 512
+    wf = torch.zeros(nf, dtype=BF, device="cuda"); wd = torch.zeros(nd, dtype=BF, device="cuda")
+    tab = torch.tensor([[w.data_ptr(), wf.data_ptr(), wd.data_ptr(), taps, Cin, Cout, 0, 0]], dtype=torch.int64, device="cuda")
+    lib.sar_conv_pack_weights_bf16(tab.data_ptr(), 1, -(-(nf + nd) // 8 // 256), st)
+    bins = torch.zeros(16, 2, Cout, device="cuda")
+    if mode == "wgrad":
+        P = lib.sar_conv2d_wgrad_slices_bf16(B, H, W, Cin, Cout)
+        part = torch.zeros(P, k * k * Cin * Cout, device="cuda")
+        fn = lambda: lib.sar_conv2d_wgrad_bf16(x.data_ptr(), y.data_ptr(), part.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, st)
+        names = {"prologue": (1, 2), "first issue": (2, 3), "chunk loop": (3, 4), "flush": (4, 5), "total": (1, 5)}
+    else:
+        wp = wf if mode == "fwd" else wd
+        fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
+                                         0, None, 1, bins.data_ptr(), None, None, st)
+        names = {"prologue": (1, 2), "fill": (2, 3), "fill sync": (3, 4), "k-phase": (4, 5), "epilogue": (5, 6), "stats": (6, 7), "total": (1, 7)}
+    tb = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
+    for it in range(3):
+        lib.sar_dbg_set_timing_buffer16(None); torch.cuda.synchronize(); fn()
+    torch.cuda.synchronize()
+    lib.sar_dbg_set_timing_buffer16(tb.data_ptr()); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); rc = fn(); e1.record(); torch.cuda.synchronize()
+    assert rc == 0, rc
+    t = tb.cpu().numpy().astype(np.int64)
+    t = t[t[:, 0] != 0]
+    rt0 = t[:, 0].min()
+    start_us = (t[:, 0] - rt0) / 100.0; end_us = (t[:, 15] - rt0) / 100.0
+    print("== %s %s B=%d blocks=%d event %.1f us; block starts p50 %.1f max %.1f us; ends p10 %.1f p50 %.1f max %.1f us; block life p50 %.1f us"
+          % (mode, name, B, len(t), e0.elapsed_time(e1) * 1e3, np.percentile(start_us, 50), start_us.max(), np.percentile(end_us, 10),
+             np.percentile(end_us, 50), end_us.max(), np.percentile(end_us - start_us, 50)))
+    if mode == "wgrad":
+        for nm, sl in (("loop: wait", 8), ("loop: barrier", 9), ("loop: issue", 10), ("loop: compute", 11)):
+            v = t[:, sl]
+            print("   %-12s cycles: p10 %7d  p50 %7d  p90 %7d  max %7d (sum over the block's chunks, wave 0)" % (nm, np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
+    for k_, (a, b) in names.items():
+        v = t[:, b] - t[:, a]
+        print("   %-12s cycles: p10 %7d  p50 %7d  p90 %7d  max %7d" % (k_, np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
