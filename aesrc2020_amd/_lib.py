@@ -110,6 +110,48 @@ class BnRef(ctypes.Structure):
                [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
+class WgradConv(ctypes.Structure):
+    """include/sarnet.h: sarWgradConv."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dy", "dw", "dbias")] + \
+               [(n, ctypes.c_int) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl", "pad_")]
+
+
+class WgradPlan:
+    """Device tables of one batched weight-gradient launch (sar_wgrad_plan_bf16 runs on the host; uploaded once)."""
+    MAX_ITEMS = 16384
+
+    @staticmethod
+    def plan_host(descs, target_blocks, max_items=MAX_ITEMS):
+        """descs: dicts with the sarWgradConv fields (pointers: tensors, ints or None), all of equal K.
+        -> (convs table bytes, items table bytes, n_items, lds_bytes); no device access."""
+        n = len(descs)
+        arr = (WgradConv * n)()
+        for a, d in zip(arr, descs):
+            for k in ("x", "dy", "dw", "dbias"):
+                t = d[k]
+                setattr(a, k, t.data_ptr() if hasattr(t, "data_ptr") else t)
+            for k in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl"):
+                setattr(a, k, int(d[k]))
+        cbuf = ctypes.create_string_buffer(n * 128)
+        ibuf = ctypes.create_string_buffer(max_items * 32)
+        ni, lds = ctypes.c_int(0), ctypes.c_int(0)
+        rc = lib().fn["sar_wgrad_plan_bf16"](arr, n, int(target_blocks), cbuf, ibuf, max_items, ctypes.byref(ni), ctypes.byref(lds))
+        if rc != 0:
+            raise RuntimeError("sar_wgrad_plan_bf16 failed with status %d" % rc)
+        return cbuf.raw, ibuf.raw[:ni.value * 32], ni.value, lds.value
+
+    def __init__(self, descs, target_blocks):
+        import torch
+        self.keep = [d[k] for d in descs for k in ("x", "dy", "dw", "dbias")]      # the tensors whose addresses the tables hold
+        self.K = int(descs[0]["K"])
+        convs, items, self.n_items, self.lds = self.plan_host(descs, target_blocks)
+        self.convs = torch.frombuffer(bytearray(convs), dtype=torch.uint8).cuda()
+        self.items = torch.frombuffer(bytearray(items), dtype=torch.uint8).cuda()
+
+    def launch(self):
+        call("sar_conv2d_wgrad_batch_bf16", self.convs, self.items, self.n_items, self.K, self.lds)
+
+
 def bn_bins():
     return lib().fn["sar_bn_bins"]()
 

@@ -432,73 +432,88 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
-// dw[tap][ci][co] = sum over pixels of A[pixel + tap][ci] * dY[pixel][co] on PLAIN bf16 operands: A = the activated tensor the
+// dw[tap][ci][co] += sum over pixels of A[pixel + tap][ci] * dY[pixel][co] on PLAIN bf16 operands: A = the activated tensor the
 // forward conv's fill wrote back (ConvP::side; the raw tensor for shortcuts / the first conv), dY = the gradient tensor (for
-// conv1 of a block: the BatchNorm-backward the input-gradient conv's fill wrote back).  Both arrive by LDS-DMA, four 64-pixel
-// chunks in flight, and feed the MFMA through ds_read_b64_tr_b16; no VALU work on the data at all.
-// Block = KK waves (one per tap) x one (32 input, 32 output channel) pair x a slice of the pixels.  Every block writes its
-// partial 32x32 tiles with plain stores into part[slice][tap][ci][co]; wgrad_reduce_kernel sums the slices into the gradient
-// (fp32 atomics at this volume -- ~9 MB per launch -- ran at ~1 TB/s and cost more than the whole k-loop).
-struct WgP {
+// conv1 of a block: the BatchNorm-backward the input-gradient conv's fill wrote back).  Both arrive by LDS-DMA, 64-pixel chunks,
+// three chunks in flight, and feed the MFMA through ds_read_b64_tr_b16; no VALU work on the data at all.
+// ONE launch computes the weight gradients of MANY convolutions (they are off the critical path of the backward pass, so the
+// trunk runs them at the end of each backward part): a block takes one work item = (convolution, 32 input x 32 output
+// channels, a run of pixel chunks) from a table the host planned (sar_wgrad_plan_bf16: longest items first, runs sized so the
+// whole launch is ~3 blocks per CU), KK waves = one per tap, and adds its 32x32 tiles into the gradient (fp32 atomics when the
+// convolution's pixels are split over several items, plain read-add-write otherwise).
+struct WgConv {                 // device table row, written by sar_wgrad_plan_bf16 (128 bytes)
     Geo g; int Cout;
-    const u16* x; const u16* dy;
-    float* part; float* dbias;
-    const uint4* zero;          // >= 1 KiB of zeros in HBM: DMA source of halo / out-of-range pieces
-    int nchunks, cpb;           // 64-pixel chunks in total / per block
-    int cap_pos;                // patch positions one LDS buffer holds (multiple of 16)
+    const u16* x; const u16* dy; float* dw; float* dbias;
+    int nchunks;                // 64-pixel chunks
+    int cap_pos;                // patch positions of one chunk (multiple of 16)
+    int pad_[2];
 };
+static_assert(sizeof(WgConv) <= 128, "WgConv must fit its 128-byte table row");
+struct WgItem { int conv, ci0, co0, c_first, c_count, single, pad0_, pad1_; };   // 32 bytes
 __device__ uint4 g_zero_page[64];
-constexpr int WG_NBUF = 4;
+constexpr int WG_NBUF = 4;      // chunk buffers (three chunks in flight behind the one being multiplied)
+constexpr int WG_TR = 6;        // geometry-table ring: a chunk's tables are written four steps before its operands are read
+constexpr int WG_MAXNI = 4;     // DMA wave-instructions per wave and chunk, 9-wave blocks (8 for the single-wave 1x1 blocks; planner checks)
+constexpr int WG_ROWS = 64;     // patch rows per chunk the row table holds (planner checks)
+constexpr int WG_TAB_BYTES = WG_TR * (64 + WG_ROWS) * 4;
 
 __device__ __forceinline__ s16x4 lds_tr(const unsigned char* base, unsigned off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
 }
 
-constexpr int WG_MAXNI = 4;     // DMA wave-instructions per wave and chunk, 9-wave blocks (8 for the single-wave 1x1 blocks; launcher checks)
-constexpr int WG_ROWS = 64;     // patch rows per chunk the row table holds (launcher checks)
+constexpr int WG_NW1 = 4;       // 1x1: independent waves per block, each on its own share of the item's chunks (merged in LDS at the end)
 
 template <int KK>
-__global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
+__global__ __launch_bounds__(KK == 1 ? WG_NW1 * 64 : KK * 64) void wgrad_bf16_kernel(const unsigned char* __restrict__ convs, const WgItem* __restrict__ items,
+                                                             const uint4* __restrict__ zero, const unsigned buf_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Geo& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const WgItem it = items[blockIdx.x];
+    const WgConv* cvp = reinterpret_cast<const WgConv*>(convs + (size_t)it.conv * 128);
+    const Geo g = cvp->g;                                                          // by value: scalar registers for the whole kernel
+    const int Cout = cvp->Cout, cap_pos = cvp->cap_pos;
+    const u16* __restrict__ xp = cvp->x; const u16* __restrict__ dyp = cvp->dy;
+    float* dwp = cvp->dw; float* dbp = cvp->dbias;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = KK == 1 ? 0 : wv;                                                // tap of this wave
+    const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M;
-    const int c_first = blockIdx.x * p.cpb, c_end = min(c_first + p.cpb, p.nchunks), nmine = c_end - c_first;
-    unsigned* qtabs = reinterpret_cast<unsigned*>(smem);                          // [cpb][64]: patch byte offset of every pixel
-    unsigned* rowt = qtabs + (size_t)p.cpb * 64;                                  // [cpb][WG_ROWS]: source offset of every patch row
-    unsigned char* bufs = smem + (size_t)p.cpb * (256 + WG_ROWS * 4);
-    const unsigned buf_bytes = 64 * 64 + (unsigned)p.cap_pos * 64;               // dY [64][32] | patch [pos][32]
+    // 3x3: the KK waves share every chunk (one tap each).  1x1: the block's WG_NW1 waves split the item's chunks and never
+    // synchronise inside the loop
+    const int cw = KK == 1 ? (it.c_count + WG_NW1 - 1) / WG_NW1 : it.c_count;
+    const int c_first = it.c_first + (KK == 1 ? wv * cw : 0);
+    const int nmine = KK == 1 ? max(0, min(cw, it.c_count - wv * cw)) : it.c_count;
+    unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [WG_TR][64]: patch byte offset of every pixel
+    unsigned* rring = qring + WG_TR * 64;                                         // [WG_TR][WG_ROWS]: source offset of every patch row
+    unsigned char* bufs = smem + (KK == 1 ? (size_t)wv * WG_NBUF * buf_bytes : (size_t)WG_TAB_BYTES);   // [WG_NBUF]: dY [64][32] | patch [pos][32]
     const unsigned bufs0 = lds_addr(bufs);
     // DMA wave-instructions per chunk: 4 (dY) + cap_pos/16 (patch), dealt to the KK waves; every wave issues the same count
     // NI (the surplus ones repeat the block's last instruction: same source, same destination)
-    const int nblk_i = 4 + p.cap_pos / 16, NI = (nblk_i + KK - 1) / KK;
+    const int nblk_i = 4 + cap_pos / 16, NI = (nblk_i + KK - 1) / KK;
     TSTAMP(0); TSTAMP(1);
 
-    // ---- geometry tables for all of this block's chunks: patch offset of every pixel, source offset of every patch row
-    for (int i = tid; i < nmine * 64; i += KK * 64) {
-        const int lc = i >> 6, px = i & 63;
-        const unsigned mc0 = (unsigned)(c_first + lc) * 64;
-        unsigned q = px * 64;
+    // ---- geometry tables of one chunk (3x3 only): 64 threads the pixel offsets, 64 threads the patch rows
+    auto tables = [&](int lc) __attribute__((always_inline)) {
         if constexpr (KK != 1) {
-            unsigned Rp_lo, Rp, wq, wtmp;
-            pix_rp(g, mc0, Rp_lo, wtmp);
-            pix_rp(g, min(mc0 + px, M - 1), Rp, wq);
-            q = ((Rp - Rp_lo) * g.Wp + wq) * 64;
-            if (mc0 + px >= M || q + ((g.K - 1) * g.Wp + g.K) * 64 > (unsigned)p.cap_pos * 64) q = 0;   // past the batch: its dY row is zero
+            if (tid < 128) {
+                const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+                const int slot = lc % WG_TR;
+                unsigned Rp_lo, wtmp;
+                pix_rp(g, mc0, Rp_lo, wtmp);
+                if (tid < 64) {
+                    unsigned Rp, wq;
+                    pix_rp(g, min(mc0 + tid, M - 1), Rp, wq);
+                    unsigned q = ((Rp - Rp_lo) * g.Wp + wq) * 64;
+                    if (mc0 + tid >= M || q + ((g.K - 1) * g.Wp + g.K) * 64 > (unsigned)cap_pos * 64) q = 0;   // past the batch: its dY row is zero
+                    qring[slot * 64 + tid] = q;
+                } else {
+                    const unsigned Rp = Rp_lo + (tid - 64), b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
+                    const int u = (int)hp - g.pt;
+                    rring[slot * WG_ROWS + tid - 64] = (u >= 0 && u < g.Hs && b < (unsigned)g.B) ? ((b * g.Hs + u) * g.Ws) * g.Cin : NONE;
+                }
+            }
         }
-        qtabs[i] = q;
-    }
-    if constexpr (KK != 1) {
-        for (int i = tid; i < nmine * WG_ROWS; i += KK * 64) {
-            const int lc = i / WG_ROWS, pr = i % WG_ROWS;
-            unsigned Rp_lo, wtmp;
-            pix_rp(g, (unsigned)(c_first + lc) * 64, Rp_lo, wtmp);
-            const unsigned Rp = Rp_lo + pr, b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
-            const int u = (int)hp - g.pt;
-            rowt[i] = (u >= 0 && u < g.Hs && b < (unsigned)g.B) ? ((b * g.Hs + u) * g.Ws) * g.Cin : NONE;
-        }
-    }
+    };
+    for (int k = 0; k < WG_NBUF && k < nmine; ++k) tables(k);
     // ---- per-lane, chunk-independent part of every DMA piece this wave issues
     constexpr int MAXNI = KK == 1 ? 8 : WG_MAXNI;
     int jj[MAXNI]; unsigned prow_i[MAXNI], col_i[MAXNI], row_i[MAXNI];
@@ -518,10 +533,10 @@ __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (KK != 1) __builtin_amdgcn_s_barrier();
     TSTAMP(2);
 
-    auto issue = [&](int lc) {
+    auto issue = [&](int lc) __attribute__((always_inline)) {
         const unsigned mc0 = (unsigned)(c_first + lc) * 64;
         const unsigned dst0 = bufs0 + (unsigned)(lc % WG_NBUF) * buf_bytes;
 #pragma unroll
@@ -531,15 +546,15 @@ __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
                 const void* src;
                 if (j < 4) {                                       // dY rows
                     const unsigned m = mc0 + row_i[i];
-                    src = m < M ? (const void*)(p.dy + (size_t)m * p.Cout + col_i[i]) : (const void*)(p.zero + lane);
+                    src = m < M ? (const void*)(dyp + (size_t)m * Cout + col_i[i]) : (const void*)(zero + lane);
                 } else if constexpr (KK == 1) {                    // 1x1: the "patch" is the 64 pixels themselves
                     unsigned Rp, wq;
                     pix_rp(g, min(mc0 + row_i[i], M - 1), Rp, wq);
                     const unsigned off = src_off(g, Rp, wq, mc0 + row_i[i] < M);
-                    src = off != NONE ? (const void*)(p.x + off + col_i[i]) : (const void*)(p.zero + lane);
+                    src = off != NONE ? (const void*)(xp + off + col_i[i]) : (const void*)(zero + lane);
                 } else {
-                    const unsigned rb = rowt[lc * WG_ROWS + prow_i[i]];
-                    src = (rb != NONE && col_i[i] != NONE) ? (const void*)(p.x + rb + col_i[i]) : (const void*)(p.zero + lane);
+                    const unsigned rb = rring[(lc % WG_TR) * WG_ROWS + prow_i[i]];
+                    src = (rb != NONE && col_i[i] != NONE) ? (const void*)(xp + rb + col_i[i]) : (const void*)(zero + lane);
                 }
                 dma16(src, dst0 + (unsigned)j * 1024);
             }
@@ -552,32 +567,32 @@ __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     float bsum = 0.f;
-    const bool do_bias = p.dbias != nullptr && w == 0 && blockIdx.y == 0;
+    const bool do_bias = dbp != nullptr && w == 0 && ci0 == 0;
     const unsigned toff = KK == 1 ? 0u : (unsigned)(((w / g.K) * g.Wp + (w % g.K)) * 64);
     const int gi = lane & 15, gg = lane >> 4, cb = gg & 1, kh = gg >> 1;
     const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2;
     const unsigned prb = 8 * kh + (gi >> 2);
 
     // Chunk loop, software-pipelined by one chunk: iteration lc waits for chunk lc's DMA, passes the barrier, starts the DMA
-    // of chunk lc+3, ISSUES the transpose-reads of chunk lc -- and multiplies chunk lc-1, whose operands were read one
-    // iteration earlier (LDS latency is hidden behind MFMAs and DMA issue instead of sitting between barrier and MFMA).
+    // of chunk lc+3, writes the tables of chunk lc+4, ISSUES the transpose-reads of chunk lc -- and multiplies chunk lc-1, whose
+    // operands were read one iteration earlier (LDS latency is hidden behind MFMAs and DMA issue).
     bf16x8 Af[2][4], Bf[2][4];
-    auto read_ops = [&](int lc, bf16x8 (&A)[4], bf16x8 (&Bm)[4]) {
+    auto read_ops = [&](int lc, bf16x8 (&A)[4], bf16x8 (&Bm)[4]) __attribute__((always_inline)) {
         const unsigned char* buf = bufs + (size_t)(lc % WG_NBUF) * buf_bytes;
-        const unsigned* qtab = qtabs + lc * 64;
+        const unsigned* qtab = qring + (lc % WG_TR) * 64;
         const unsigned char* dyt = buf;
         const unsigned char* ap = buf + 64 * 64;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const unsigned pr0 = 16 * ks + prb, pr1 = pr0 + 4;
-            const unsigned q0 = qtab[pr0], q1 = qtab[pr1];
+            const unsigned q0 = KK == 1 ? pr0 * 64 : qtab[pr0], q1 = KK == 1 ? pr1 * 64 : qtab[pr1];
             const s16x4 b_lo = lds_tr(dyt, pr0 * 64 + colb), b_hi = lds_tr(dyt, pr1 * 64 + colb);
             const s16x4 a_lo = lds_tr(ap, q0 + toff + colb), a_hi = lds_tr(ap, q1 + toff + colb);
             A[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
             Bm[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
     };
-    auto mma = [&](const bf16x8 (&A)[4], const bf16x8 (&Bm)[4]) {
+    auto mma = [&](const bf16x8 (&A)[4], const bf16x8 (&Bm)[4]) __attribute__((always_inline)) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bm[0], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bm[1], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bm[2], acc, 0, 0, 0);
@@ -589,12 +604,13 @@ __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
                 for (int j = 0; j < 8; ++j) bsum += (float)Bm[ks][j];
         }
     };
-    auto step = [&](int lc, bf16x8 (&An)[4], bf16x8 (&Bn)[4], const bf16x8 (&Ao)[4], const bf16x8 (&Bo)[4]) {
+    auto step = [&](int lc, bf16x8 (&An)[4], bf16x8 (&Bn)[4], const bf16x8 (&Ao)[4], const bf16x8 (&Bo)[4]) __attribute__((always_inline)) {
         // chunk lc has landed once at most min(nmine-1-lc, NBUF-2) younger chunks of this wave are still in flight
         wait_vm_n(NI * min(nmine - 1 - lc, WG_NBUF - 2));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's transpose-reads of chunk lc-1 are done
-        __builtin_amdgcn_s_barrier();                              // everyone's pieces landed; everyone has read chunk lc-1
+        if constexpr (KK != 1) __builtin_amdgcn_s_barrier();       // everyone's pieces landed; everyone has read chunk lc-1
         if (lc + WG_NBUF - 1 < nmine) issue(lc + WG_NBUF - 1);     // into the slot chunk lc-1 just left
+        if (lc + WG_NBUF < nmine) tables(lc + WG_NBUF);            // ring slot of chunk lc-2: last read two barriers ago
         read_ops(lc, An, Bn);
         if (lc > 0) mma(Ao, Bo);
     };
@@ -608,46 +624,45 @@ __global__ __launch_bounds__(KK * 64) void wgrad_bf16_kernel(const WgP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     TSTAMP(4);
-    // ---- flush: part[slice][tap][ci0+row][co0+col] = acc (plain coalesced stores; slices with no chunk write zeros)
-    {
-        const int col = lane & 31;
-        float* o = p.part + ((size_t)blockIdx.x * KK + w) * g.Cin * p.Cout + (size_t)ci0 * p.Cout + co0 + col;
+    // ---- flush: dw[tap][ci0+row][co0+col] += acc
+    if constexpr (KK == 1) {
+        // merge the waves' tiles in LDS (each wave's own first buffer: its transpose-reads are done), then one add per element
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        float* mine = reinterpret_cast<float*>(bufs);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            o[(size_t)row * p.Cout] = acc[r];
+        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[r];
+        __syncthreads();
+#pragma unroll
+        for (int e = tid; e < 1024; e += WG_NW1 * 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < WG_NW1; ++k) s += reinterpret_cast<const float*>(smem + (size_t)k * WG_NBUF * buf_bytes)[e];
+            float* o = dwp + (size_t)(ci0 + (e >> 5)) * Cout + co0 + (e & 31);
+            if (it.single) *o += s; else atomicAdd(o, s);
         }
         if (do_bias) {
             bsum += __shfl_xor(bsum, 32, 64);
-            if (lane < 32) atomicAdd(p.dbias + co0 + lane, bsum);
+            if (lane < 32) atomicAdd(dbp + co0 + lane, bsum);
+        }
+    } else {
+        const int col = lane & 31;
+        float* o = dwp + ((size_t)w * g.Cin + ci0) * Cout + co0 + col;
+        if (it.single) {                                           // block-uniform: this item owns the tile
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout, acc[r]);
+        }
+        if (do_bias) {
+            bsum += __shfl_xor(bsum, 32, 64);
+            if (lane < 32) atomicAdd(dbp + co0 + lane, bsum);
         }
     }
     TSTAMP(5); TSTAMP(15);
-}
-
-// dw[e] += sum over slices of part[slice][e], many convolutions per launch.  Rows of 8 x int64: {part, dw, slices, n elements,
-// first_block, 0, 0, 0}; 1024 elements per block (n is a multiple of 1024: 32x32 tiles).
-struct RedRow { const float* part; float* dw; long slices, n, first_block, pad0_, pad1_, pad2_; };
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedRow* __restrict__ tab, int nrows) {
-    int r = 0;
-    while (r + 1 < nrows && (long)blockIdx.x >= tab[r + 1].first_block) ++r;
-    const RedRow row = tab[r];
-    const long e = (((long)blockIdx.x - row.first_block) * 256 + threadIdx.x) * 4;
-    if (e >= row.n) return;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    long sl = 0;
-    for (; sl + 1 < row.slices; sl += 2) {                         // two independent chains: loads in flight
-        const float4 a = *reinterpret_cast<const float4*>(row.part + sl * row.n + e);
-        const float4 b = *reinterpret_cast<const float4*>(row.part + (sl + 1) * row.n + e);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-    }
-    if (sl < row.slices) {
-        const float4 a = *reinterpret_cast<const float4*>(row.part + sl * row.n + e);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-    }
-    float4 d = *reinterpret_cast<const float4*>(row.dw + e);
-    d.x += s0.x + s1.x; d.y += s0.y + s1.y; d.z += s0.z + s1.z; d.w += s0.w + s1.w;
-    *reinterpret_cast<float4*>(row.dw + e) = d;
 }
 
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
@@ -890,63 +905,98 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
     return SAR_OK;
 }
 
-// Pixel slices of the weight gradient of one convolution (the first dimension of its partial buffer).
-static int wgrad_slices(int M, int Cin, int Cout, int* cpb_out) {
-    const int nchunks = cdiv(M, 64), pairs = (Cin / 32) * (Cout / 32);
-    int P = 256 / pairs; if (P < 1) P = 1; if (P > nchunks) P = nchunks;
-    const int cpb = cdiv(nchunks, P);
-    if (cpb_out) *cpb_out = cpb;
-    return cdiv(nchunks, cpb);
-}
-int sar_conv2d_wgrad_slices_bf16(int B, int Ho, int Wo, int Cin, int Cout) {
-    if (B < 1 || Ho < 1 || Wo < 1 || Cin < 32 || Cout < 32 || (long)B * Ho * Wo >= (1L << 31)) return SAR_EINVAL;
-    return wgrad_slices(B * Ho * Wo, Cin, Cout, nullptr);
+// One convolution of a batched weight-gradient launch as the caller describes it (include/sarnet.h: sarWgradConv).
+struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl, pad_; };
+
+// Host-only planning (no device access): the device tables of ONE launch over `n` convolutions of equal K (1 or 3) --
+// convs_out: n rows of 128 bytes, items_out: up to max_items rows of 32 bytes, longest first -- plus the launch's dynamic
+// LDS size.  Runs of chunks are cut so that the launch has about `target_blocks` items.
+int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, void* convs_out, void* items_out, int max_items,
+                        int* n_items, int* lds_bytes) {
+    if (convs == nullptr || n < 1 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || lds_bytes == nullptr)
+        return SAR_EINVAL;
+    const int K = convs[0].K;
+    if (K != 1 && K != 3) return SAR_EINVAL;
+    WgConv tmp;
+    unsigned char* co = static_cast<unsigned char*>(convs_out);
+    long total = 0;
+    int cap_max = 0;
+    for (int i = 0; i < n; ++i) {
+        const sarWgradConv& c = convs[i];
+        memset(&tmp, 0, sizeof(tmp));
+        if (c.K != K || !make_geo(tmp.g, c.B, c.H, c.W, c.Cin, c.Ho, c.Wo, c.K, c.s, 1, c.pt, c.pl)) return SAR_EINVAL;
+        if (!pow2(c.Cin) || !pow2(c.Cout) || c.Cin < 32 || c.Cout < 32 || c.Cin > CMAX || c.Cout > CMAX) return SAR_EINVAL;
+        if (c.x == nullptr || c.dy == nullptr || c.dw == nullptr) return SAR_EINVAL;
+        if ((long)c.B * c.H * c.W * c.Cin >= (1L << 31) || (long)tmp.g.M * c.Cout >= (1L << 31)) return SAR_EINVAL;
+        tmp.Cout = c.Cout;
+        tmp.x = static_cast<const u16*>(c.x); tmp.dy = static_cast<const u16*>(c.dy); tmp.dw = c.dw; tmp.dbias = c.dbias;
+        tmp.nchunks = cdiv(tmp.g.M, 64);
+        tmp.cap_pos = K == 3 ? patch_rows_bound(tmp.g, 64 < tmp.g.M ? 64 : tmp.g.M) * tmp.g.Wp : 64;
+        tmp.cap_pos = (tmp.cap_pos + 15) & ~15;
+        const int ni = cdiv(4 + tmp.cap_pos / 16, K == 3 ? 9 : 1);
+        if (K == 3 && tmp.cap_pos / tmp.g.Wp > WG_ROWS) return SAR_EINVAL;
+        if (ni > (K == 3 ? WG_MAXNI : 8) || ni * (WG_NBUF - 2) > 16 || ni * (WG_NBUF - 1) > 60) return SAR_EINVAL;   // vmcnt is a 6-bit counter
+        if (tmp.cap_pos > cap_max) cap_max = tmp.cap_pos;
+        memset(co + (size_t)i * 128, 0, 128);
+        memcpy(co + (size_t)i * 128, &tmp, sizeof(tmp));
+        total += (long)tmp.nchunks * (c.Cin / 32) * (c.Cout / 32);
+    }
+    int maxc = (int)((total + target_blocks - 1) / target_blocks);
+    const int minc = K == 3 ? 8 : 2 * WG_NW1;
+    if (maxc < minc) maxc = minc;
+    WgItem* items = static_cast<WgItem*>(items_out);
+    int ni = 0;
+    for (int i = 0; i < n; ++i) {
+        const sarWgradConv& c = convs[i];
+        const int nchunks = cdiv((long)c.B * c.Ho * c.Wo, 64);
+        const int slices = cdiv(nchunks, maxc), cpb = cdiv(nchunks, slices);
+        for (int sl = 0; sl * cpb < nchunks; ++sl)
+            for (int ci = 0; ci < c.Cin; ci += 32)
+                for (int cc = 0; cc < c.Cout; cc += 32) {
+                    if (ni >= max_items) return SAR_EINVAL;
+                    WgItem it;
+                    memset(&it, 0, sizeof(it));
+                    it.conv = i; it.ci0 = ci; it.co0 = cc; it.c_first = sl * cpb;
+                    it.c_count = nchunks - sl * cpb < cpb ? nchunks - sl * cpb : cpb;
+                    it.single = cpb >= nchunks ? 1 : 0;
+                    items[ni++] = it;
+                }
+    }
+    // longest first (the hardware dispatches blocks in index order); stable, so the tiles of one pixel run stay adjacent
+    for (int a = 1; a < ni; ++a) {
+        const WgItem it = items[a];
+        int b = a - 1;
+        while (b >= 0 && items[b].c_count < it.c_count) { items[b + 1] = items[b]; --b; }
+        items[b + 1] = it;
+    }
+    *n_items = ni;
+    *lds_bytes = K == 3 ? WG_TAB_BYTES + WG_NBUF * (64 * 64 + cap_max * 64) : WG_NW1 * WG_NBUF * (64 * 64 + 64 * 64);
+    return *lds_bytes <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
 }
 
-// Kernel-gradient partials: part[slices][K][K][Cin][Cout] = per-slice x^T (*) dy on plain bf16 operands (slices =
-// sar_conv2d_wgrad_slices_bf16; every element is written), dbias (nullable) += column sums of dy (fp32 atomics).
-// Geometry as the forward conv (s = stride, pads as TF).  sar_wgrad_reduce_f32 then adds the slices into the gradient.
-int sar_conv2d_wgrad_bf16(const void* x, const void* dy, float* part, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo,
-                          int Cout, int K, int s, int pt, int pl, hipStream_t stream) {
-    WgP p;
-    memset(&p, 0, sizeof(p));
-    if (!make_geo(p.g, B, H, W, Cin, Ho, Wo, K, s, 1, pt, pl)) return SAR_EINVAL;
-    if (!pow2(Cin) || !pow2(Cout) || Cin < 32 || Cout < 32 || Cin > CMAX || Cout > CMAX || part == nullptr) return SAR_EINVAL;
-    if ((long)B * H * W * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
-    p.Cout = Cout;
-    p.x = static_cast<const u16*>(x); p.dy = static_cast<const u16*>(dy); p.part = part; p.dbias = dbias;
+// Weight gradients of many convolutions, one launch: tables and lds_bytes from sar_wgrad_plan_bf16 (uploaded by the caller),
+// K = kernel size of the planned convolutions.  dw += x^T (*) dy per tap, dbias (where given) += column sums of dy.
+int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, int lds_bytes, hipStream_t stream) {
+    if (convs_dev == nullptr || items_dev == nullptr || n_items < 1 || (K != 1 && K != 3)) return SAR_EINVAL;
+    const int tab = K == 3 ? WG_TAB_BYTES : 0, nbuf = K == 3 ? WG_NBUF : WG_NW1 * WG_NBUF;
+    if (lds_bytes <= tab || lds_bytes > 160 * 1024 || (lds_bytes - tab) % nbuf) return SAR_EINVAL;
     static const uint4* zero_page = nullptr;
     if (zero_page == nullptr) {
         void* zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return SAR_ELAUNCH;
         zero_page = static_cast<const uint4*>(zp);
     }
-    p.zero = zero_page;
-    p.nchunks = cdiv(p.g.M, 64);
-    const int P = wgrad_slices(p.g.M, Cin, Cout, &p.cpb);
-    const int NT = K == 3 ? 576 : 64;
-    p.cap_pos = K == 3 ? patch_rows_bound(p.g, 64 < p.g.M ? 64 : p.g.M) * p.g.Wp : 64;
-    p.cap_pos = (p.cap_pos + 15) & ~15;
-    const size_t lds = (size_t)p.cpb * (256 + WG_ROWS * 4) + (size_t)WG_NBUF * (64 * 64 + (size_t)p.cap_pos * 64);
-    const int ni = cdiv(4 + p.cap_pos / 16, K == 3 ? 9 : 1);
-    if (K == 3 && p.cap_pos / p.g.Wp > WG_ROWS) return SAR_EINVAL;
-    if (lds > 160 * 1024 || ni > (K == 3 ? WG_MAXNI : 8) || ni * (WG_NBUF - 2) > 16 || ni * (WG_NBUF - 1) > 60) return SAR_EINVAL;   // vmcnt is a 6-bit counter
-    const dim3 grid((unsigned)P, (unsigned)(Cin / 32), (unsigned)(Cout / 32));
+    const unsigned buf_bytes = (unsigned)(lds_bytes - tab) / nbuf;
     static bool attr9 = false, attr1 = false;
     if (K == 3) {
         if (!attr9) { if (!allow_lds(wgrad_bf16_kernel<9>, 160 * 1024)) return SAR_ELAUNCH; attr9 = true; }
-        hipLaunchKernelGGL(wgrad_bf16_kernel<9>, grid, dim3(NT), lds, stream, p);
+        hipLaunchKernelGGL(wgrad_bf16_kernel<9>, dim3(n_items), dim3(576), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
+                           static_cast<const WgItem*>(items_dev), zero_page, buf_bytes);
     } else {
         if (!attr1) { if (!allow_lds(wgrad_bf16_kernel<1>, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
-        hipLaunchKernelGGL(wgrad_bf16_kernel<1>, grid, dim3(NT), lds, stream, p);
+        hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
+                           static_cast<const WgItem*>(items_dev), zero_page, buf_bytes);
     }
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
-}
-
-int sar_wgrad_reduce_f32(const void* table, int n, int total_blocks, hipStream_t stream) {
-    if (table == nullptr || n < 1 || total_blocks < 1) return SAR_EINVAL;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const RedRow*>(table), n);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -125,13 +125,10 @@ class _Conv:
               e_bins, e_y, e_saved)
 
     def wgrad16(self, x, dy, B, bias_grad):
-        """Partial kernel gradients of this conv (plain operands); ResNetTrunk._reduce16 adds the slices into kernel.g."""
-        P = _lib.lib().fn["sar_conv2d_wgrad_slices_bf16"](B, self.Ho, self.Wo, self.cin, self.cout)
-        n = self.k * self.k * self.cin * self.cout
-        self.part = self.store.bufs.get(self.name + "/wgrad_part", (P, n))
-        _call("sar_conv2d_wgrad_bf16", x, dy, self.part, self.bias.g if bias_grad else None,
-              B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout, self.k, self.stride, self.pt, self.pl)
-        return [self.part.data_ptr(), self.kernel.g.data_ptr(), P, n]
+        """Descriptor of this conv's weight gradient on plain operands (include/sarnet.h: sarWgradConv); the trunk batches them
+        (ResNetTrunk._wgrad16)."""
+        return dict(x=x, dy=dy, dw=self.kernel.g, dbias=self.bias.g if bias_grad else None, B=B, H=self.H, W=self.W, Cin=self.cin,
+                    Ho=self.Ho, Wo=self.Wo, Cout=self.cout, K=self.k, s=self.stride, pt=self.pt, pl=self.pl)
 
     def out_hw(self, H, W):
         if self.padding == "same":
@@ -334,7 +331,7 @@ class ResNetTrunk(Layer):
             g = self._g_part
         stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
         bf = torch.bfloat16
-        self._red16 = []
+        self._wg16 = []
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
             if blk["stage"] not in stages:
@@ -349,7 +346,9 @@ class ResNetTrunk(Layer):
             da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
             blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
             red.append(blk["conv2"].wgrad16(blk["a1"], g, B, bias_grad=True))
-            gin = self.scratch("res16_gin%d_%dx%dx%d" % (n & 1, H, W, cin), (B, H, W, cin), bf)       # ping-pong: never aliases g
+            # the weight gradients run at the end of the part (_wgrad16), so their gradient operands -- the block's incoming
+            # gradient and dc1 -- live in per-block buffers, not in recycled scratch
+            gin = self._buf16("b%d_gin" % n, (B, H, W, cin))
             if blk["sc"] is not None:
                 dsc = gin if bn1 is None else self.scratch("res16_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
                 blk["sc"].dgrad16(g, None, dsc, B)
@@ -358,7 +357,7 @@ class ResNetTrunk(Layer):
                 dsc = g
             # conv1's output gradient dc1 = BN+ReLU backward of (da2, c1): evaluated in the fill of conv1's input-gradient launch
             # (which owns bn2's parameter gradients) and written back for the weight gradient
-            dc1 = self.scratch("res16_dc1_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
+            dc1 = self._buf16("b%d_dc1" % n, (B, H2, W2, cout))
             if bn1 is not None:
                 da1 = self.scratch("res16_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
                 blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
@@ -367,12 +366,12 @@ class ResNetTrunk(Layer):
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
                 blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True), res=dsc, side=dc1)
             red.append(blk["conv1"].wgrad16(blk["a"] if bn1 is not None else x, dc1, B, bias_grad=False))
-            self._red16.extend(red)
+            self._wg16.extend(red)
             if getattr(self, "debug_tap", None) is not None:          # tests/test_gpu_bf16_trunk.py: per-block tensors before reuse
                 self.debug_tap(n, g, da2, gin)
             g = gin
         self._g_part = g
-        self._reduce16(part)
+        self._wgrad16(part)
         if part in (0, 1):
             return None
         g32 = self.scratch("res16_g32", tuple(g.shape))
@@ -380,17 +379,25 @@ class ResNetTrunk(Layer):
         self._stem_backward(g32, B)
         return None
 
-    def _reduce16(self, part):
-        """One launch adds the per-slice partial weight gradients of every conv of this backward part into the flat gradient."""
-        key = "_redtab_%s" % (part,)
-        rows, blk0 = [], 0
-        for pp, gg, P, n in self._red16:
-            rows.append([pp, gg, P, n, blk0, 0, 0, 0]); blk0 += n // 1024
-        tab = getattr(self, key, None)
-        if tab is None or tab[2] != rows:                           # pointers and shapes are static per (B, T): upload once
-            tab = (torch.tensor(rows, dtype=torch.int64, device="cuda"), blk0, rows)
-            setattr(self, key, tab)
-        _call("sar_wgrad_reduce_f32", tab[0], tab[0].shape[0], tab[1])
+    # launch classes of the batched weight gradient: (kernel size, stride) -> blocks the planner aims for.  Stride-2 convs have
+    # 2.5x larger patches (LDS), so they get their own launch and the stride-1 launch keeps two 9-wave blocks per CU.
+    WGRAD_CLASSES = (((3, 1), 768), ((3, 2), 512), ((1, None), 256))
+
+    def _wgrad16(self, part):
+        """The weight gradients of every conv of this backward part: one launch per class, tables planned once per (B, T)."""
+        plans = getattr(self, "_wgplans", None)
+        if plans is None:
+            plans = self._wgplans = {}
+        key = (part, self.B, self.in_hw, tuple((d["x"].data_ptr(), d["dy"].data_ptr()) for d in self._wg16))
+        if key not in plans:
+            ps = []
+            for (k, s), target in self.WGRAD_CLASSES:
+                ds = [d for d in self._wg16 if d["K"] == k and (s is None or d["s"] == s)]
+                if ds:
+                    ps.append(_lib.WgradPlan(ds, target))
+            plans[key] = ps
+        for p in plans[key]:
+            p.launch()
 
     def _stem_forward(self, x, B):
         T, D = self.in_hw

@@ -61,6 +61,7 @@ def conv_roofline(model, B, iters=10):
 
     bf16 = getattr(tr, "bf16", False)
     eb = 2.0 if bf16 else 4.0
+    wg = []
     for n, blk in enumerate(tr.blocks):
         for cname, bn in (("conv1", blk["bn1"]), ("conv2", blk["bn2"]), ("sc", None)):
             cv = blk[cname]
@@ -78,12 +79,20 @@ def conv_roofline(model, B, iters=10):
                 fb = bn.ref(B * cv.H * cv.W, "saved", False) if bn is not None else None
                 fl = 1 if bn is not None else 0
                 add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd16(x, y, B, fill=fl, fbn=fb)), flops, act_b)
-                add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.wgrad16(x, y, B, False)), flops, act_b)
+                wg.append((cv.wgrad16(x, y, B, False), flops, act_b))       # batched below, as the train step runs them
                 add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad16(y, None, dx, B)), flops, act_b)
                 continue
             add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd(x, y, B, bn=bn)), flops, act_b)
             add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.wgrad(x, y, B, bn=bn)), flops, act_b)
             add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad(y, dx, B)), flops, act_b)
+    if bf16:
+        # weight gradients: one launch per class over all convs of the trunk (ResNetTrunk._wgrad16)
+        for (k, s_), target in tr.WGRAD_CLASSES:
+            sel = [w_ for w_ in wg if w_[0]["K"] == k and (s_ is None or w_[0]["s"] == s_)]
+            if sel:
+                plan = _lib.WgradPlan([w_[0] for w_ in sel], target)
+                c = classes.setdefault("conv_wgrad_%dx%d_%s_batched" % (k, k, "s%d" % s_ if s_ else "all"), dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
+                c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["bytes"] += sum(w_[2] for w_ in sel); c["launches"] += 1
     total = sum(c["time"] for c in classes.values())
     name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
     ach = dom["flops"] / dom["time"] / 1e12

@@ -149,16 +149,24 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarSt
 int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, void* side,
                     int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
-/* Kernel gradient in two steps.  (1) part[slices][K][K][Cin][Cout] = per-pixel-slice x^T (*) dy on PLAIN bf16 operands (x: the
- * `side` tensor of the forward conv, or the raw input of a shortcut / first conv; dy: the gradient tensor, for a conv that
- * feeds a BatchNorm the `side` tensor of its input-gradient launch); slices = sar_conv2d_wgrad_slices_bf16(B, Ho, Wo, Cin, Cout);
- * every element of part is written.  dbias (nullable) += column sums of dy.  (2) sar_wgrad_reduce_f32: dw += sum of the slices,
- * many convolutions per launch: table = device array of n rows of 8 x int64 {part, dw, slices, K*K*Cin*Cout, first_block, 0, 0, 0},
- * blocks per row = K*K*Cin*Cout/1024, first_block = running sum. */
-int sar_conv2d_wgrad_slices_bf16(int B, int Ho, int Wo, int Cin, int Cout);
-int sar_conv2d_wgrad_bf16(const void* x, const void* dy, float* part, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo,
-                          int Cout, int K, int s, int pt, int pl, sarStream_t stream);
-int sar_wgrad_reduce_f32(const void* table, int n, int total_blocks, sarStream_t stream);
+/* Kernel gradients (resnet.py:39-42, 60-63, 82-87, 113-117 under Keras' backward pass) of MANY convolutions in one launch, on
+ * PLAIN bf16 operands: x = the `side` tensor of the forward conv (or the raw input of a shortcut / first conv), dy = the
+ * gradient tensor (for a conv that feeds a BatchNorm: the `side` tensor of its input-gradient launch).
+ *   dw[K][K][Cin][Cout] += x^T (*) dy per tap;  dbias (nullable) += column sums of dy.
+ * They are off the critical path of the backward pass, so the trunk collects them and runs them once per backward part.
+ * (1) sar_wgrad_plan_bf16 -- host only, no device access -- turns n descriptors of equal K (1 or 3) into the two device tables of
+ * one launch: convs_out (n rows of 128 bytes) and items_out (<= max_items rows of 32 bytes: one block each = one convolution, 32
+ * input x 32 output channels, a run of 64-pixel chunks; longest first; runs are cut so that the launch has about target_blocks
+ * items), and returns the item count and the launch's dynamic LDS bytes (largest patch among the convolutions: plan stride-2
+ * and stride-1 convolutions separately to keep the stride-1 launch at two blocks per CU).  (2) The caller uploads both tables
+ * once; sar_conv2d_wgrad_batch_bf16 launches them. */
+typedef struct sarWgradConv {
+    const void* x; const void* dy; float* dw; float* dbias;
+    int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl, pad_;    /* geometry as the forward conv (s = stride, pt/pl = TF pads) */
+} sarWgradConv;
+int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, void* convs_out, void* items_out, int max_items,
+                        int* n_items, int* lds_bytes);
+int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, int lds_bytes, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
 int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
                           int C, int relu, sarStream_t stream);

@@ -93,18 +93,17 @@ class Conv:
                     self.k - 1 - pt, self.k - 1 - pl, fill, fbn, 2 if e_bins is not None else 0, e_bins, e_y, e_saved)
         return dx
 
-    def wgrad(self, x, dy, bias=True):
-        """Partials + slice reduction, added to a non-zero gradient buffer (the reduction accumulates)."""
+    def desc(self, x, dy, dw, db):
         B, H, W, _ = x.shape
         ho, wo, pt, pl = self.geo(H, W)
-        n = self.k * self.k * self.cin * self.cout
-        P = self.L.lib().fn["sar_conv2d_wgrad_slices_bf16"](B, ho, wo, self.cin, self.cout)
-        assert P >= 1
-        part = torch.full((P, n), float("nan"), device="cuda")      # every element must be written
+        return dict(x=x, dy=dy, dw=dw, dbias=db, B=B, H=H, W=W, Cin=self.cin, Ho=ho, Wo=wo, Cout=self.cout, K=self.k, s=self.s, pt=pt, pl=pl)
+
+    def wgrad(self, x, dy, bias=True, target_blocks=768):
+        """One-convolution plan, added to a non-zero gradient buffer (the kernel accumulates)."""
         dw = torch.ones(self.k, self.k, self.cin, self.cout, device="cuda"); db = torch.zeros(self.cout, device="cuda")
-        self.L.call("sar_conv2d_wgrad_bf16", x, dy, part, db if bias else None, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, pt, pl)
-        tab = torch.tensor([[part.data_ptr(), dw.data_ptr(), P, n, 0, 0, 0, 0]], dtype=torch.int64, device="cuda")
-        self.L.call("sar_wgrad_reduce_f32", tab, 1, n // 1024)
+        plan = self.L.WgradPlan([self.desc(x, dy, dw, db if bias else None)], target_blocks)
+        plan.launch()
+        self.last_plan = plan
         return dw - 1.0, db
 
 
@@ -311,9 +310,40 @@ def test_conv_wgrad(L, shape):
     _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
     dw, db = cv.wgrad(dbf(x), dbf(dy))
     check(dw, dw_ref, TOL_F32, "dw"); check(db, db_ref, TOL_F32, "db")
-    dw2, db2 = cv.wgrad(dbf(x), dbf(dy), bias=False)
-    check(dw2, dw_ref, TOL_F32, "dw (no bias gradient)")
+    dw2, db2 = cv.wgrad(dbf(x), dbf(dy), bias=False, target_blocks=1)           # one item per tile: the read-add-write flush
+    check(dw2, dw_ref, TOL_F32, "dw (no bias gradient, single slice)")
     assert float(db2.abs().max()) == 0.0
+    items = np.frombuffer(cv.last_plan.items.cpu().numpy().tobytes(), np.int32).reshape(-1, 8)
+    assert items[:, 5].all() and len(items) == (Cin // 32) * (Cout // 32)
+    dw3, db3 = cv.wgrad(dbf(x), dbf(dy), target_blocks=100000)                   # shortest runs: the atomic flush
+    check(dw3, dw_ref, TOL_F32, "dw (shortest runs)"); check(db3, db_ref, TOL_F32, "db (shortest runs)")
+    items = np.frombuffer(cv.last_plan.items.cpu().numpy().tobytes(), np.int32).reshape(-1, 8)
+    nch = -(-B * ho * wo // 64)
+    assert items[:, 4].max() <= 8 and (nch <= items[:, 4].max() or not items[:, 5].any())
+
+
+def test_conv_wgrad_many_convolutions_in_one_launch(L):
+    """The train step's form: the 3x3 stride-1 convs of several stages in one plan, the 1x1 convs in another."""
+    rng = np.random.default_rng(99)
+    for k, shapes in ((3, [(4, 25, 20, 32, 32, 1), (4, 13, 10, 64, 64, 1), (4, 7, 5, 128, 128, 1), (4, 4, 3, 256, 256, 1), (4, 25, 20, 64, 32, 1)]),
+                      (3, [(3, 25, 20, 32, 64, 2), (3, 13, 10, 64, 128, 2)]),
+                      (1, [(4, 25, 20, 64, 32, 1), (4, 25, 20, 32, 64, 2), (4, 7, 5, 128, 256, 2)])):
+        descs, refs, outs = [], [], []
+        for (B, H, W, Cin, Cout, s) in shapes:
+            pad = "same" if k == 3 else "valid"
+            cv = Conv(L, rng.standard_normal((k, k, Cin, Cout)), s, pad)
+            ho, wo, _, _ = cv.geo(H, W)
+            x = rbf(grid(rng, (B, H, W, Cin)) + 0.4); dy = grid(rng, (B, ho, wo, Cout))
+            _, cache = O.conv2d_fwd(x, cv.wq, np.zeros(Cout), (s, s), pad)
+            _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+            dw = torch.zeros(k, k, Cin, Cout, device="cuda"); db = torch.zeros(Cout, device="cuda")
+            descs.append(cv.desc(dbf(x), dbf(dy), dw, db)); refs.append((dw_ref, db_ref)); outs.append((dw, db))
+        plan = L.WgradPlan(descs, 64)
+        plan.launch()
+        for i, ((dw, db), (dw_ref, db_ref)) in enumerate(zip(outs, refs)):
+            check(dw, dw_ref, TOL_F32, "dw of conv %d (k=%d)" % (i, k)); check(db, db_ref, TOL_F32, "db of conv %d (k=%d)" % (i, k))
+        items = np.frombuffer(plan.items.cpu().numpy().tobytes(), np.int32).reshape(-1, 8)
+        assert (np.diff(items[:, 4]) <= 0).all(), "longest items first"
 
 
 @pytest.mark.parametrize("R,C", [(2496, 256), (77, 32), (128000, 32), (8000, 128), (5, 512)])

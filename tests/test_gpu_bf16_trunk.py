@@ -44,12 +44,16 @@ class RefBN:
     def act(self):
         return rbf(np.maximum(self.x * self.scale + self.shift, 0.0))
 
-    def bwd(self, da):
-        """-> (dx unrounded, dgamma, dbeta): BatchNorm+ReLU backward with the kernel's operation order."""
-        dz = np.where(self.x * self.scale + self.shift > 0, da, 0.0)
+    def bwd(self, da, da_acc=None):
+        """-> (dx unrounded, dgamma, dbeta): BatchNorm+ReLU backward with the kernel's operation order.  da: the STORED (bf16)
+        gradient the consumer fill reads; da_acc: the values the two sums are taken over -- the producing conv's fp32
+        accumulators, before the bf16 store (conv_bf16.hip epilogue, epi == 2)."""
+        mask = self.x * self.scale + self.shift > 0
+        dz = np.where(mask, da, 0.0)
         xh = (self.x - self.mean) * self.rstd
         ax = tuple(range(da.ndim - 1))
-        S1, S2 = dz.sum(ax), (dz * xh).sum(ax)
+        dzs = dz if da_acc is None else np.where(mask, da_acc, 0.0)
+        S1, S2 = dzs.sum(ax), (dzs * xh).sum(ax)
         dx = self.scale * (dz - f32(S1 / self.n) - xh * f32(S2 / self.n))
         return dx, S2, S1
 
@@ -135,7 +139,7 @@ def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T):
         chk("b%d da2" % n, da2_dev, rbf(da2), 1e-2)
         chk("b%d conv2 dw" % n, G[c2v.kernel.name], dw2, 5e-3)
         assert np.abs(G[c2v.bias.name] - db2).max() < 1e-4 * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6, "b%d conv2 db" % n
-        dc1, dg2, dbt2 = bn2.bwd(da2_dev)                            # from the STORED da2, as the fills read it
+        dc1, dg2, dbt2 = bn2.bwd(da2_dev, da2)                       # the STORED da2, as the fills read it; sums over the accumulators
         chk("b%d bn2 dgamma" % n, G[blk["bn2"].gamma.name], dg2, 5e-3); chk("b%d bn2 dbeta" % n, G[blk["bn2"].beta.name], dbt2, 5e-3)
         dc1 = rbf(dc1)
         da1, dw1, _ = O.conv2d_bwd(dc1, cache1)
@@ -149,7 +153,7 @@ def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T):
         else:
             dsc = g
         if bn1 is not None:
-            dxb, dg1, dbt1 = bn1.bwd(rbf(da1))
+            dxb, dg1, dbt1 = bn1.bwd(rbf(da1), da1)
             chk("b%d gin" % n, gin_dev, rbf(dxb + dsc), 1e-2)
             chk("b%d bn1 dgamma" % n, G[blk["bn1"].gamma.name], dg1, 1e-2); chk("b%d bn1 dbeta" % n, G[blk["bn1"].beta.name], dbt1, 1e-2)
         else:

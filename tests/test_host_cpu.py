@@ -24,12 +24,66 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(protos), (exported ^ set(protos))
     # every entry point takes the stream last and returns int (or size_t for workspace queries)
     for name, (ret, at) in protos.items():
-        if name.endswith("_bytes") or name.endswith("_conv_math") or name in ("sar_bn_bins", "sar_conv2d_wgrad_slices_bf16"):
+        if name.endswith("_bytes") or name.endswith("_conv_math") or name in ("sar_bn_bins", "sar_wgrad_plan_bf16"):
             continue
         assert at[-1].__name__ == "c_void_p", name
     assert _lib.ctc_workspace_bytes(64, 39, 72) == 4 * (2 * 64 * 39 * 145 + 64 * 39)    # alpha + emissions + log denominators; host-only query
     assert _lib.bn_workspace_doubles(32) == 1026 * 32        # fp64 totals[2C] + 1024 fp32 partial rows
     assert _lib.get_conv_math() in ("fp32", "bf16x3")
+
+
+def test_wgrad_plan_covers_every_tile_and_chunk_once():
+    """sar_wgrad_plan_bf16 is host-only: the work items of the bench trunk's stride-1 3x3 weight gradients partition every
+    (convolution, 32x32 channel tile)'s chunks, longest first, within the LDS of two blocks per CU."""
+    from aesrc2020_amd import _lib
+    B = 64
+    shapes = [(100, 20, 32, 32)] * 6 + [(100, 20, 64, 32)] + [(50, 10, 64, 64)] * 7 + [(25, 5, 128, 128)] * 11 + [(13, 3, 256, 256)] * 5
+    descs = [dict(x=0x1000, dy=0x2000, dw=0x3000 + i, dbias=None, B=B, H=h, W=w, Cin=ci, Ho=h, Wo=w, Cout=co, K=3, s=1, pt=1, pl=1)
+             for i, (h, w, ci, co) in enumerate(shapes)]
+    convs, items, n, lds = _lib.WgradPlan.plan_host(descs, 768)
+    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 600 <= n <= 1100 and lds <= 80 * 1024
+    it = np.frombuffer(items, np.int32).reshape(n, 8)
+    assert (np.diff(it[:, 4]) <= 0).all()
+    for i, (h, w, ci, co) in enumerate(shapes):
+        mine = it[it[:, 0] == i]
+        nch = -(-B * h * w // 64)
+        for a in range(0, ci, 32):
+            for b in range(0, co, 32):
+                runs = sorted((r[3], r[4]) for r in mine if r[1] == a and r[2] == b)
+                pos = 0
+                for first, cnt in runs:
+                    assert first == pos and cnt >= 1
+                    pos += cnt
+                assert pos == nch
+        assert (mine[:, 5] == (1 if len(mine) == (ci // 32) * (co // 32) else 0)).all()
+    with pytest.raises(RuntimeError):                      # mixed kernel sizes in one plan
+        _lib.WgradPlan.plan_host(descs[:1] + [dict(descs[0], K=1)], 64)
+    with pytest.raises(RuntimeError):                      # channel counts the kernels do not cover
+        _lib.WgradPlan.plan_host([dict(descs[0], Cin=48)], 64)
+
+
+def test_hand_counted_vmcnt_kernels_use_no_scratch():
+    """conv_bf16.hip issues its LDS-DMA through inline asm and counts s_waitcnt vmcnt by hand; a kernel that spilled or kept
+    a private array in scratch would add compiler-issued vector-memory operations to that counter (it happened: a lambda that
+    was not inlined put its captured geometry struct in scratch).  The code object must show no private segment."""
+    import re, shutil, tempfile
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "aesrc2020_amd", "csrc", "conv_bf16.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                              stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    md = asm[asm.index("amdhsa.kernels:"):]
+    seen = 0
+    for blk in md.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "conv_bf16_kernel" in name or "wgrad_bf16_kernel" in name:
+            seen += 1
+            assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
+            assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
+    assert seen >= 22
 
 
 def test_no_cpu_fallback():
