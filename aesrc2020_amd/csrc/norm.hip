@@ -241,7 +241,10 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
         mean[c] = mu; rstd[c] = rs;
         if (mov_mean) {
             mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * mu;
-            mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * var;
+            // Keras 2.2.x BatchNormalization.call feeds the moving average the sample variance
+            // var * n / (n - (1 + epsilon)) ("unbiased estimator of population variance"), not the biased batch variance
+            const float nb = (float)B, corr = nb > 1.f + eps ? nb / (nb - (1.f + eps)) : 1.f;
+            mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * var * corr;
         }
     }
 }

@@ -152,6 +152,9 @@ class SARNetModel:
                         self.disc_bn = cls(n_classes=A, m=c["margin"], name="y_disc_bn", in_dim=nb)
         self.store.finalize()
         self.dp = DataParallel(self.store, trunk_splits=self.trunk.bucket_split_names())
+        # SAR_Net(gpus=N) (model.py:193-194, multi_gpu_model): the caller keeps feeding GLOBAL batches, every rank takes its
+        # contiguous slice (same slicing as multi_gpu_model's Lambda layers)
+        self.shard_global = int(c.get("gpus") or 1) > 1 and self.dp.world > 1
         self.store.set_adam(c["lr"], grad_scale=1.0 / self.dp.world)
         self.bufs = self.store.bufs
         self._loss_weights()
@@ -216,6 +219,10 @@ class SARNetModel:
 
     def _upload(self, inputs, targets):
         c = self.cfg
+        if self.shard_global and self.store.training:
+            from .parallel import shard_batch
+            inputs = shard_batch(inputs, self.dp.rank, self.dp.world)
+            targets = shard_batch(targets, self.dp.rank, self.dp.world) if targets else targets
         x = inputs["x_data"]
         if not torch.is_tensor(x):
             x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, np.float32)))
@@ -261,7 +268,8 @@ class SARNetModel:
                                  % (need, il[b], b))
 
     def set_device_batch(self, dev):
-        """Device-resident batch (dict of torch tensors, same keys as the host batch dict): D2D copies only."""
+        """Device-resident batch of THIS rank (dict of torch tensors, same keys as the host batch dict): D2D copies only; never
+        sharded, whatever `gpus` says (bench.py keeps 64 utterances per GPU)."""
         B, T = dev["x_data"].shape[0], dev["x_data"].shape[1]
         if getattr(self, "B", None) != B or getattr(self, "T", None) != T:
             self._bind_inputs(B, T); self.graph = None; self._eager_done = 0
@@ -467,8 +475,21 @@ class SARNetModel:
             return
         works = []
         ar = lambda i: (lambda: works.extend(self.dp.allreduce_bucket(i, async_op=True)))
-        segs = [("heads", self._seg_heads, ar(0))]
         nparts = self.trunk.N_PARTS
+        if len(self.dp.bounds) != nparts + 1:
+            # the bucket table does not line up with the backward parts (a split parameter did not resolve): overlapping would
+            # reduce ranges that later parts still write.  One all-reduce of everything after the full backward instead.
+            def reduce_all():
+                for i in range(len(self.dp.bounds)):
+                    works.extend(self.dp.allreduce_bucket(i, async_op=True))
+                [w.wait() for w in works]
+            segs = [("heads", self._seg_heads, None)]
+            for part in range(nparts):
+                segs.append(("trunk%d" % part, (lambda part=part: self._seg_trunk(part)), reduce_all if part == nparts - 1 else None))
+            segs.append(("adam", self.store.adam_step, None))
+            self._run_segments(segs)
+            return
+        segs = [("heads", self._seg_heads, ar(0))]
         for part in range(nparts):
             last = part == nparts - 1
             after = (lambda i=part + 1: (works.extend(self.dp.allreduce_bucket(i, async_op=True)), [w.wait() for w in works])) if last else ar(part + 1)
@@ -540,8 +561,14 @@ class SARNetModel:
         np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **d)
 
     def load_weights(self, path, by_name=True, skip_mismatch=True):
-        p = path if str(path).endswith(".npz") else str(path) + ".npz"
-        d = dict(np.load(p))
+        """model.py:181-183 warm start.  .npz checkpoints of this package, or a Keras .h5 (names mapped by keras_compat; needs
+        h5py -- otherwise the error says how to convert the file once)."""
+        if str(path).lower().endswith((".h5", ".hdf5")):
+            from .keras_compat import load_h5
+            d = load_h5(path)
+        else:
+            p = path if str(path).endswith(".npz") else str(path) + ".npz"
+            d = dict(np.load(p))
         loaded, skipped = self.store.load_state_dict(d, by_name, skip_mismatch)
         self.dp.broadcast_params()
         return loaded, skipped
@@ -641,9 +668,19 @@ def SAR_Net(input_shape, ctc_enable=False, ar_enable=True, disc_enable=False, re
             hidden_dim=256, bn_dim=0, bpe_classes=1000, accent_classes=8, max_ctc_len=72, mto=None, vlad_clusters=8,
             ghost_clusters=2, metric_loss="cosface", margin=0.3, raw_model=None, lr=0.01, gpus=1, mode="train", name=None,
             seed=0, use_graph=True):
-    """model.py:204-371.  Returns (model, train_model); with one process per GPU both are the same object -- the
-    data-parallel wrapper of the reference (multi_gpu_model, model.py:193-194) is replaced by torch.distributed/RCCL
-    initialised by the launcher (`gpus` is informational)."""
+    """model.py:204-371.  Returns (model, train_model); with one process per GPU both are the same object.
+    `gpus` > 1 (model.py:193-194, train.py:74): the reference wraps the model in multi_gpu_model inside ONE process; here the
+    same train.py runs as `gpus` processes (python -m torch.distributed.run --nproc-per-node <gpus> train.py), this call joins
+    the RCCL process group from the launcher's environment, parameters are broadcast from rank 0, and the train_model shards
+    every incoming GLOBAL batch itself -- so the script needs no edit beyond the import."""
+    if int(gpus or 1) > 1:
+        from . import parallel
+        _, world, local = parallel.init_from_env()
+        if world != int(gpus):
+            raise RuntimeError("SAR_Net(gpus=%d) needs one process per GPU: launch the script with `python -m torch.distributed.run "
+                               "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 <script>` (WORLD_SIZE is %d)" % (gpus, gpus, world))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
     cfg = dict(locals())
     model = SARNetModel(cfg)
     model.summary()                                                         # model.py:180

@@ -7,6 +7,7 @@ What is different from the reference: the per-utterance MinMax scaling + zero pa
 runs on the MI355X (csrc/feeder.hip, `sar_feat_minmax_pad_f32`) on the ragged batch uploaded through pinned memory, so
 `x_data` comes back as a device tensor that `train_on_batch` / `fit_generator` consume without another copy.  There is no
 host implementation of that arithmetic here: without the HIP library these functions raise."""
+import functools
 import math
 import pickle
 import queue
@@ -112,52 +113,61 @@ def synthetic_batch(input_shape, B, ctc_enable, disc_enable, accent_classes=8, b
     return inputs, targets
 
 
-# ---- Generator (utils.py:71-154)
+# ---- Generator: the batch contract of utils.py:71-154 (keys, dtypes, shapes), built batch-wise
+def _ctc_targets(transcripts, width, encoder_len):
+    """Token-id lists -> the three CTC inputs of a batch: labels (B, width) float32 padded with EOS_ID (K.ctc_batch_cost takes
+    float labels, utils.py:107), label lengths clipped to `width` and encoder lengths, both (B, 1) int32."""
+    n = len(transcripts)
+    lens = np.fromiter((min(len(t), width) for t in transcripts), dtype=np.int32, count=n)
+    labels = np.full((n, width), EOS_ID, dtype=np.float32)
+    keep = np.arange(width)[None, :] < lens[:, None]
+    if lens.sum():
+        labels[keep] = np.concatenate([np.asarray(t[:k], dtype=np.float32) for t, k in zip(transcripts, lens) if k])
+    return labels, lens[:, None], np.full((n, 1), encoder_len, dtype=np.int32)
+
+
 def data_loader(lst, ctc_enable=False, ar_enable=False, disc_enable=False, data_dct=None, accent_dct=None, trans_dct=None,
                 max_input_len=1200, max_ctc_len=72, encoder_len=100, accent_classes=8, bn=0, stream=None):
-    """utils.py:71-116, same arguments and the same (input_data, output_data) dicts; `x_data` is a device tensor produced by
-    feat_norm_pad, the (tiny) label arrays stay numpy.  `data_dct[utt]` is a pickle path (utils.py:84) or an array."""
-    feats = []
-    ctc_input_len, ctc_label_len, ctc_labels, accent_labels = [], [], [], []
-    for utt in lst:
-        f = data_dct[utt]
-        feats.append(load(f) if isinstance(f, str) else f)
-        if ctc_enable and trans_dct:
-            trans = trans_dct[utt]
-            ctc_input_len.append(encoder_len)
-            ctc_label_len.append(min(len(trans), max_ctc_len))
-            ctc_labels.append(text_ids_norm(trans, max_ctc_len))
-        if ar_enable and accent_dct:
-            accent_labels.append(to_categorical(int(accent_dct[utt]), num_classes=accent_classes))
-    input_data = {"x_data": feat_norm_pad(feats, max_input_len, stream=stream)}
-    output_data = {}
+    """One batch for the utterance ids in `lst`, as (inputs, targets) dicts with the reference's keys (utils.py:102-116):
+    x_data (B, max_input_len, D, 1) float32 -- here a device tensor straight out of feat_norm_pad (MinMax + pad on the GPU) --,
+    x_ctc_in_len / x_ctc_out_len (B, 1) int32, x_ctc_label (B, max_ctc_len) float32, y_ctc_loss zeros(B), y_accent / x_accent /
+    y_disc [/ y_disc_bn when `bn`] one-hot (B, accent_classes) float32.  `data_dct[utt]` is a pickle path or an array."""
+    feats = [load(f) if isinstance(f, str) else f for f in (data_dct[utt] for utt in lst)]
+    inputs, targets = {"x_data": feat_norm_pad(feats, max_input_len, stream=stream)}, {}
     if ctc_enable:
-        input_data["x_ctc_in_len"] = np.int32(np.expand_dims(np.asarray(ctc_input_len), axis=1))
-        input_data["x_ctc_out_len"] = np.int32(np.expand_dims(np.asarray(ctc_label_len), axis=1))
-        input_data["x_ctc_label"] = np.float32(np.asarray(ctc_labels))
-        output_data["y_ctc_loss"] = np.zeros([len(lst)])
+        if trans_dct:
+            labels, out_len, in_len = _ctc_targets([trans_dct[utt] for utt in lst], max_ctc_len, encoder_len)
+        else:                                     # the reference appends nothing without transcripts: empty arrays, one trailing axis
+            labels, out_len, in_len = np.zeros((0,), np.float32), np.zeros((0, 1), np.int32), np.zeros((0, 1), np.int32)
+        inputs.update(x_ctc_in_len=in_len, x_ctc_out_len=out_len, x_ctc_label=labels)
+        targets["y_ctc_loss"] = np.zeros(len(lst))
+    # one-hot accent rows exist only when the AR task is on and labels were given (utils.py:99-100); the discriminator keys
+    # reuse them whatever they are
+    if ar_enable and accent_dct:
+        onehot = np.eye(accent_classes, dtype=np.float32)[np.fromiter((int(accent_dct[utt]) for utt in lst), dtype=np.int64, count=len(lst))]
+    else:
+        onehot = np.zeros((0,), np.float32)
     if ar_enable:
-        output_data["y_accent"] = np.asarray(accent_labels)
+        targets["y_accent"] = onehot
     if disc_enable:
-        input_data["x_accent"] = np.asarray(accent_labels)
-        output_data["y_disc"] = np.asarray(accent_labels)
+        inputs["x_accent"] = onehot
+        targets["y_disc"] = onehot
         if bn:
-            output_data["y_disc_bn"] = np.asarray(accent_labels)
-    return input_data, output_data
+            targets["y_disc_bn"] = onehot
+    return inputs, targets
 
 
 def data_generator(lst, ctc_enable=False, ar_enable=False, disc_enable=False, batch_size=32, data_dct=None, accent_dct=None,
                    trans_dct=None, max_input_len=1200, max_ctc_len=72, encoder_len=100, accent_classes=8, bn=0, stream=None):
-    """utils.py:120-154: endless epochs; every epoch shuffles `lst` in place and yields len(lst)//batch_size batches."""
-    n_batchs = len(lst) // batch_size
+    """Endless stream of batches (utils.py:120-154): each epoch reshuffles the caller's list IN PLACE and covers its first
+    len(lst)//batch_size full batches; the remainder of an epoch is dropped."""
+    make = functools.partial(data_loader, ctc_enable=ctc_enable, ar_enable=ar_enable, disc_enable=disc_enable, data_dct=data_dct,
+                             accent_dct=accent_dct, trans_dct=trans_dct, max_input_len=max_input_len, max_ctc_len=max_ctc_len,
+                             encoder_len=encoder_len, accent_classes=accent_classes, bn=bn, stream=stream)
     while True:
         shuffle(lst)
-        for i in range(n_batchs):
-            sub = lst[i * batch_size:(i + 1) * batch_size]
-            yield data_loader(sub, ctc_enable=ctc_enable, ar_enable=ar_enable, disc_enable=disc_enable, data_dct=data_dct,
-                              accent_dct=accent_dct, trans_dct=trans_dct, max_input_len=max_input_len,
-                              max_ctc_len=max_ctc_len, encoder_len=encoder_len, accent_classes=accent_classes, bn=bn,
-                              stream=stream)
+        for start in range(0, len(lst) - batch_size + 1, batch_size):
+            yield make(lst[start:start + batch_size])
 
 
 class Prefetcher:

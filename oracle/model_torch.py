@@ -218,7 +218,7 @@ def bn_train(x, g, b):
 
 def bn(x, P, name, state=None, training=True):
     """BatchNormalization().  training: batch statistics; when `state` is given its moving averages are
-    updated with momentum 0.99 (4-D fused path: Bessel-corrected variance; 2-D path: biased).  not training: the moving
+    updated with momentum 0.99 (4-D fused path: Bessel-corrected variance; 2-D path: Keras' n / (n - (1 + eps)) sample variance).  not training: the moving
     averages normalise (Keras learning phase 0)."""
     g, b = P[name + "/gamma"], P[name + "/beta"]
     if not training:
@@ -231,6 +231,8 @@ def bn(x, P, name, state=None, training=True):
             mu = x.mean(ax); var = x.var(ax, unbiased=False)
             if x.dim() == 4 and n > 1:
                 var = var * n / (n - 1)
+            elif n > 1:                            # Keras 2.2.x BatchNormalization.call: variance *= n / (n - (1 + epsilon))
+                var = var * n / (n - (1.0 + BN_EPS))
             for key, val in ((name + "/moving_mean", mu), (name + "/moving_variance", var)):
                 old = torch.as_tensor(state[key]).to(x.dtype)
                 state[key] = (BN_MOMENTUM * old + (1 - BN_MOMENTUM) * val).detach().cpu().numpy()

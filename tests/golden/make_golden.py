@@ -5,6 +5,12 @@ The reference (pika-online/AESRC2020) ships no golden vectors and TensorFlow/Ker
 container, so these fixtures pin *our restatement* ("parity unpinned" w.r.t. the real Keras path): they freeze
 the oracle's numbers so that (a) the oracle cannot drift silently (CPU test) and (b) the GPU parity tests have
 data-only expectations that travel to the GPU box.      Usage: python tests/golden/make_golden.py
+
+The upstream-HELD known answers (constants published in TensorFlow's ctc_loss_op_test.py, Keras' backend_test.py test_ctc and
+the Keras categorical_crossentropy docstring -- numbers this script does not and must not produce) live next to these files in
+tests/golden/upstream_kat.py, each with its source; tests/test_upstream_kat.py checks the oracle and the HIP kernels against
+them.  They pin tf.nn.ctc_loss / K.ctc_batch_cost (loss to 1e-5, gradient to 2e-6) and the cross-entropy; everything else
+here stays pinned only to the restatement.
 """
 import os
 import sys

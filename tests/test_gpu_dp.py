@@ -19,22 +19,25 @@ GLOBAL_B = 6
 STEPS = 3
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", via_gpus=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), SAR_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), SAR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
     import contextlib, io
     from aesrc2020_amd import parallel
     from aesrc2020_amd.model import SAR_Net
     from oracle import model_torch as MT                     # test infrastructure: synthetic batch generator only
-    parallel.init_from_env()
+    if not via_gpus:
+        parallel.init_from_env()
     with contextlib.redirect_stdout(io.StringIO()):
-        model, tm = SAR_Net(seed=10 + rank, **KW)            # different seeds: rank 0's weights must win (broadcast)
+        # different seeds: rank 0's weights must win (broadcast).  via_gpus: the reference's own switch (model.py:193-194) --
+        # SAR_Net joins the process group itself and the train_model shards the GLOBAL batch
+        model, tm = SAR_Net(seed=10 + rank, gpus=world if via_gpus else 1, **KW)
     cfg = MT.Cfg(**KW)
     out = []
     for i in range(STEPS):
         gb = MT.synthetic_batch(cfg, GLOBAL_B, seed=300 + i)
-        sh = parallel.shard_batch(gb, rank, world)
+        sh = gb if via_gpus else parallel.shard_batch(gb, rank, world)
         p_before = model.store.params.detach().cpu().numpy().copy()
         logs = tm.train_on_batch(sh, sh)
         torch.cuda.synchronize()
@@ -45,14 +48,18 @@ def _worker(rank, world, port, q):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_mean_of_shard_gradients():
+@pytest.mark.parametrize("backend,via_gpus", [("gloo", False), ("gloo", True), ("nccl", True)],
+                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)"])
+def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus):
     import torch.multiprocessing as mp
     from aesrc2020_amd import parallel
     from aesrc2020_amd.model import SAR_Net
     from oracle import model_torch as MT
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 31000 + os.getpid() % 2000
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus)) % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]

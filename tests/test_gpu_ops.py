@@ -294,6 +294,11 @@ def test_batchnorm_2d(L, B, C):
     xd, gd = dev(x), dev(gamma); y, mean, rstd = zeros(B, C), zeros(C), zeros(C)
     L.call("sar_bn1d_fwd_f32", xd, gd, dev(beta), y, mean, rstd, None, None, B, C, 1e-3, 0.99)
     check(y, y_ref, name="bn1d fwd")
+    # moving statistics (model.py:286,289 use): Keras 2.2.x feeds the moving average var * n / (n - (1 + eps))
+    mm, mv = zeros(C), dev(np.ones(C)); y2 = zeros(B, C)
+    L.call("sar_bn1d_fwd_f32", xd, gd, dev(beta), y2, mean, rstd, mm, mv, B, C, 1e-3, 0.99)
+    check(y2, y_ref, name="bn1d fwd (with moving statistics)")
+    check(mm, 0.01 * x.mean(0), name="bn1d moving mean"); check(mv, 0.99 + 0.01 * x.var(0) * B / (B - 1.001), name="bn1d moving variance")
     dy = rng.standard_normal((B, C)); dx_ref, dg_ref, db_ref = O.batchnorm_bwd(dy, cache)
     dx, dg, db = zeros(B, C), zeros(C), zeros(C)
     L.call("sar_bn1d_bwd_f32", dev(dy), xd, gd, mean, rstd, dx, dg, db, B, C)

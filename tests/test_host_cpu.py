@@ -86,6 +86,69 @@ def test_hand_counted_vmcnt_kernels_use_no_scratch():
     assert seen >= 22
 
 
+def test_data_loader_batch_contract(monkeypatch):
+    """utils.py:71-154 contract (keys, dtypes, shapes, EOS padding, label clipping, in-place shuffle, dropped remainder); the
+    feature arithmetic itself is the GPU feeder kernel (tests/test_gpu_feeder.py), stubbed here."""
+    from aesrc2020_amd import utils as U
+    monkeypatch.setattr(U, "feat_norm_pad", lambda feats, T, stream=None: np.zeros((len(feats), T, feats[0].shape[1], 1), np.float32))
+    utts = ["u%d" % i for i in range(7)]
+    data = {u: np.ones((5 + i, 80), np.float32) for i, u in enumerate(utts)}
+    trans = {u: list(range(3, 3 + 2 * i)) for i, u in enumerate(utts)}          # lengths 0, 2, ..., 12
+    acc = {u: str(i % 8) for i, u in enumerate(utts)}
+    x, y = U.data_loader(utts, ctc_enable=True, ar_enable=True, disc_enable=True, data_dct=data, accent_dct=acc, trans_dct=trans,
+                         max_input_len=16, max_ctc_len=8, encoder_len=39, bn=1)
+    assert x["x_data"].shape == (7, 16, 80, 1)
+    assert x["x_ctc_in_len"].dtype == np.int32 and x["x_ctc_in_len"].shape == (7, 1) and (x["x_ctc_in_len"] == 39).all()
+    assert x["x_ctc_out_len"].dtype == np.int32 and x["x_ctc_out_len"].ravel().tolist() == [0, 2, 4, 6, 8, 8, 8]
+    assert x["x_ctc_label"].dtype == np.float32 and x["x_ctc_label"].shape == (7, 8)
+    for i, u in enumerate(utts):
+        assert x["x_ctc_label"][i].tolist() == [float(v) for v in U.text_ids_norm(trans[u], 8)]
+    assert y["y_ctc_loss"].shape == (7,) and not y["y_ctc_loss"].any()
+    onehot = np.stack([U.to_categorical(int(acc[u]), 8) for u in utts])
+    for k, d in (("y_accent", y), ("x_accent", x), ("y_disc", y), ("y_disc_bn", y)):
+        assert d[k].dtype == np.float32 and np.array_equal(d[k], onehot), k
+    x2, y2 = U.data_loader(utts, ctc_enable=True, disc_enable=True, data_dct=data)        # no labels given: empty arrays, as the reference
+    assert x2["x_ctc_label"].shape == (0,) and x2["x_ctc_in_len"].shape == (0, 1) and x2["x_accent"].shape == (0,) and "y_accent" not in y2
+    lst = list(utts)
+    gen = U.data_generator(lst, ar_enable=True, batch_size=3, data_dct=data, accent_dct=acc, max_input_len=16)
+    seen = [next(gen) for _ in range(4)]                                   # two epochs of 7 // 3 = 2 batches
+    assert all(b[0]["x_data"].shape[0] == 3 and b[1]["y_accent"].shape == (3, 8) for b in seen)
+    assert sorted(lst) == sorted(utts)                                     # shuffled in place, nothing lost
+
+
+def test_keras_checkpoint_names_map_onto_package_names():
+    """keras_compat: the weight names a Keras 2.2.x .h5 of the reference model carries (TF ':0' suffix, auto-numbered
+    Bidirectional/CuDNNGRU sub-layers; written from the Keras naming rules -- no Keras artefact can be produced in this image)
+    land on this package's parameter names; tensors keep their layout."""
+    from aesrc2020_amd import keras_compat as KC
+    recorded = {
+        "conv2d_1/kernel:0": "conv2d_1/kernel", "conv2d_1/bias:0": "conv2d_1/bias",
+        "batch_normalization_1/gamma:0": "batch_normalization_1/gamma", "batch_normalization_1/beta:0": "batch_normalization_1/beta",
+        "batch_normalization_1/moving_mean:0": "batch_normalization_1/moving_mean",
+        "batch_normalization_1/moving_variance:0": "batch_normalization_1/moving_variance",
+        "CNN_LIN/kernel:0": "CNN_LIN/kernel", "CNN_LIN/bias:0": "CNN_LIN/bias", "CNN_LIN_LN/gamma:0": "CNN_LIN_LN/gamma", "CNN_LIN_LN/beta:0": "CNN_LIN_LN/beta",
+        "CRNN/forward_cu_dnngru_1/kernel:0": "CRNN/forward/kernel", "CRNN/forward_cu_dnngru_1/recurrent_kernel:0": "CRNN/forward/recurrent_kernel",
+        "CRNN/forward_cu_dnngru_1/bias:0": "CRNN/forward/bias", "CRNN/backward_cu_dnngru_1/kernel:0": "CRNN/backward/kernel",
+        "CRNN/backward_cu_dnngru_1/recurrent_kernel:0": "CRNN/backward/recurrent_kernel", "CRNN/backward_cu_dnngru_1/bias:0": "CRNN/backward/bias",
+        "CTC_BIGRU/forward_cu_dnngru_2/kernel:0": "CTC_BIGRU/forward/kernel", "CTC_BIGRU/backward_cu_dnngru_2/bias:0": "CTC_BIGRU/backward/bias",
+        "ctc_pred/kernel:0": "ctc_pred/kernel", "gvlad_center_assignment/kernel:0": "gvlad_center_assignment/kernel",
+        "gvlad_pool/centers:0": "gvlad_pool/centers", "AR_BN1/moving_variance:0": "AR_BN1/moving_variance",
+        "AR_EMBEDDING/kernel:0": "AR_EMBEDDING/kernel", "y_accent/kernel:0": "y_accent/kernel", "y_disc/W:0": "y_disc/W",
+        b"y_disc_bn/W:0": "y_disc_bn/W",
+    }
+    for k, want in recorded.items():
+        assert KC.keras_to_sar_name(k) == want, k
+    w = KC.convert_keras_weights({"CRNN/forward_cu_dnngru_7/kernel:0": np.ones((4, 6)), "conv2d_3/bias:0": np.zeros(5, np.float64)})
+    assert sorted(w) == ["CRNN/forward/kernel", "conv2d_3/bias"] and w["conv2d_3/bias"].dtype == np.float32 and w["CRNN/forward/kernel"].shape == (4, 6)
+    with pytest.raises(ValueError):
+        KC.convert_keras_weights({"CRNN/forward_cu_dnngru_1/bias:0": np.zeros(3), "CRNN/forward_cu_dnngru_2/bias:0": np.zeros(3)})
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="python -m aesrc2020_amd.keras_compat"):
+            KC.load_h5("exp/does_not_matter.h5")
+
+
 def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -272,7 +272,7 @@ def test_l2norm_gap_adam_unitnorm():
 
 
 def test_whole_graph_inference_mode_and_bottleneck_head():
-    """oracle/model_torch.py: (a) BatchNormalization moving averages follow m <- 0.99 m + 0.01 batch (2-D: biased variance);
+    """oracle/model_torch.py: (a) BatchNormalization moving averages follow m <- 0.99 m + 0.01 batch (2-D: Keras' sample variance var * n / (n - (1 + eps)));
     (b) with the moving averages set to the batch statistics the inference graph equals the training graph;
     (c) the bn_dim head adds y_disc_bn with weight 0.1 and always-CE loss (model.py:363-366)."""
     import torch
@@ -292,7 +292,7 @@ def test_whole_graph_inference_mode_and_bottleneck_head():
         v = torch.relu(out["ar"] @ P["AR_BN_DS/kernel"] + P["AR_BN_DS/bias"])
         mu3 = v.mean(0); var3 = v.var(0, unbiased=False)
     np.testing.assert_allclose(net.state["AR_BN3/moving_mean"], 0.01 * mu3.numpy(), rtol=1e-12, atol=1e-15)
-    np.testing.assert_allclose(net.state["AR_BN3/moving_variance"], 0.99 + 0.01 * var3.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(net.state["AR_BN3/moving_variance"], 0.99 + 0.01 * var3.numpy() * 5 / (5 - 1.001), rtol=1e-12)
     # (b) with momentum 0 the state becomes the batch statistics of this pass; the inference graph then reproduces the
     # training graph up to the n/(n-1) Bessel factor the 4-D layers store in moving_variance (n >= 5*2*3 here)
     st = dict(net.state)
@@ -303,6 +303,7 @@ def test_whole_graph_inference_mode_and_bottleneck_head():
     finally:
         MT.BN_MOMENTUM = old_m
     inf = MT.forward(net.P, b, cfg, state=st, training=False)
-    assert float((inf["y_accent"] - trn["y_accent"]).abs().max()) < 5e-2
+    # ... and the n / (n - (1 + eps)) sample-variance factor of the 2-D layers: 5 / 3.999 = 1.25 at this batch size of 5
+    assert float((inf["y_accent"] - trn["y_accent"]).abs().max()) < 1.5e-1
     assert float((inf["y_accent"] - trn["y_accent"]).abs().max()) > 0          # the Bessel factor is really there
     assert np.isfinite(inf["y_disc_bn"].detach().numpy()).all()
