@@ -44,7 +44,6 @@ __device__ unsigned long long* g_tbuf16 = nullptr;
 
 constexpr int NB = 16;          // statistic bins per BatchNorm (fp32 atomics; contention = blocks / 16 per address)
 constexpr int CMAX = 512;       // max channels of a BatchNorm / conv side
-constexpr int CST_BYTES = 6 * CMAX * 4;
 
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
@@ -108,9 +107,9 @@ struct BnP {
     int pad_;
 };
 
-// cst[0..5][CMAX]: scale, shift, mean, rstd, c2 = S1/N, c3 = S2/N for channels [c0, c0+nc).  mode 1: forward constants
+// cst[0..5][cs]: scale, shift, mean, rstd, c2 = S1/N, c3 = S2/N for channels [c0, c0+nc), row stride cs >= nc.  mode 1: forward constants
 // (from the bins, or from `saved` when there are none: inference, or a backward consumer); mode 2: backward constants.
-__device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int c0, int nc, float* cst, bool owner, int nthreads) {
+__device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int c0, int nc, float* cst, int cs, bool owner, int nthreads) {
     for (int i = threadIdx.x; i < nc; i += nthreads) {
         const int c = c0 + i;
         float mean, rstd, scale, shift;
@@ -133,12 +132,12 @@ __device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int 
         } else {
             mean = bn.saved[c]; rstd = bn.saved[C + c]; scale = bn.saved[2 * C + c]; shift = bn.saved[3 * C + c];
         }
-        cst[i] = scale; cst[CMAX + i] = shift; cst[2 * CMAX + i] = mean; cst[3 * CMAX + i] = rstd;
+        cst[i] = scale; cst[cs + i] = shift; cst[2 * cs + i] = mean; cst[3 * cs + i] = rstd;
         if (mode == 2) {
             double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) { s1 += (double)bn.bbins[(b * 2) * C + c]; s2 += (double)bn.bbins[(b * 2 + 1) * C + c]; }
-            cst[4 * CMAX + i] = (float)(s1 * (double)bn.inv_n); cst[5 * CMAX + i] = (float)(s2 * (double)bn.inv_n);
+            cst[4 * cs + i] = (float)(s1 * (double)bn.inv_n); cst[5 * cs + i] = (float)(s2 * (double)bn.inv_n);
             if (owner && bn.write && bn.dgamma != nullptr) { bn.dgamma[c] += (float)s2; bn.dbeta[c] += (float)s1; }
         }
     }
@@ -146,11 +145,11 @@ __device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int 
 
 // Per-thread constants of 8 consecutive channels (a 16-byte piece), read once from the LDS table.
 struct Cst8 { float sc[8], sh[8], mu[8], rs[8], c2[8], c3[8]; };
-__device__ __forceinline__ void load_cst8(const float* cst, int ch, int mode, Cst8& k) {
+__device__ __forceinline__ void load_cst8(const float* cst, int cs, int ch, int mode, Cst8& k) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        k.sc[j] = cst[ch + j]; k.sh[j] = cst[CMAX + ch + j];
-        if (mode == 2) { k.mu[j] = cst[2 * CMAX + ch + j]; k.rs[j] = cst[3 * CMAX + ch + j]; k.c2[j] = cst[4 * CMAX + ch + j]; k.c3[j] = cst[5 * CMAX + ch + j]; }
+        k.sc[j] = cst[ch + j]; k.sh[j] = cst[cs + ch + j];
+        if (mode == 2) { k.mu[j] = cst[2 * cs + ch + j]; k.rs[j] = cst[3 * cs + ch + j]; k.c2[j] = cst[4 * cs + ch + j]; k.c3[j] = cst[5 * cs + ch + j]; }
     }
 }
 // MODE 0: copy; 1: relu(x*scale+shift); 2: BatchNorm(+ReLU) backward  dx = scale*(dz - c2 - xhat*c3), dz = da*[z>0]
@@ -198,6 +197,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// Workgroup barrier WITHOUT the vmcnt(0) drain of __syncthreads().  It has to be an asm statement with a memory clobber: the
+// s_barrier builtin is IntrNoMem, so the compiler may move LDS reads from behind it to in front of it (observed once the
+// 128-register variants gave the scheduler a reason: ring fragments read before the other waves' DMA had landed).  The caller
+// waits for its own LDS stores / DMA first (gfx950 puts no implicit wait in front of s_barrier).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0, 16]
     switch (n) {
         case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;   case 3: wait_vm<3>(); break;
@@ -212,7 +216,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
 // per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
 // source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
-template <int MODE, int TM>
+template <int MODE, int TM, int U>
 __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid) {
@@ -222,11 +226,11 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
     const int dm = g.d - 1, ssh = g.s - 1;
     const bool do_side = side != nullptr && blockIdx.y == 0;       // block-uniform
     Cst8 k;
-    if constexpr (MODE != 0) load_cst8(cst, c8 * 8, MODE, k);
-    for (unsigned i0 = tid; i0 < total; i0 += 4 * 256) {
-        uint4 q[4], q2[4]; unsigned off[4], lo[4], own[4];
+    if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE, k);
+    for (unsigned i0 = tid; i0 < total; i0 += U * 256) {           // U pieces in flight per thread
+        uint4 q[U], q2[U]; unsigned off[U], lo[U], own[U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < U; ++j) {
             const unsigned i = i0 + 256 * j, pos = i >> lg_pc;
             const unsigned prow = min(udiv(pos, g.mg_wp, (unsigned)g.Wp), nrows - 1), wp = pos - prow * g.Wp;
             const uint2 rt = rowtab[prow];
@@ -240,7 +244,7 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
             if constexpr (MODE == 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < U; ++j) {
             const uint4 r = xform<MODE>(q[j], q2[j], k);                 // branch-free: pieces past the end land in a scratch slot
             *reinterpret_cast<uint4*>(patch + (i0 + 256 * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
             if (do_side && off[j] != NONE && own[j] < (unsigned)TM) *reinterpret_cast<uint4*>(side + off[j]) = r;
@@ -256,21 +260,24 @@ __device__ __forceinline__ void load_afrags(bf16x8 (&a)[NKC], const unsigned cha
 
 // WN: waves along the output channels (tile 32*(4/WN) pixels x 32*WN channels); NKC: 16-channel blocks per virtual tap
 // (2, 4, 8); VT: virtual taps = K*K x channel parts of 128 (Cin = 256: two parts per tap, 512: four): 1, 2, 4, 9, 18, 36.
-// Weights: the packed fragment stream of this block's channels is brought into a 3-deep LDS ring by LDS-DMA in stages of 8
-// fragments per channel tile (one barrier per stage, two stages in flight behind the one being multiplied), so all four
-// waves share one copy and no VGPR or VALU instruction is spent on the B operand.
+// Weights: the packed fragment stream of this block's channels is brought into an RD-deep LDS ring by LDS-DMA in stages of 8
+// fragments per channel tile (one barrier per stage, RD-1 stages in flight behind the one being multiplied), so all four
+// waves share one copy and no VGPR or VALU instruction is spent on the B operand.  RD = 3 for the 128+-channel layers (one
+// block per CU: the stream has to hide its own latency), 2 for the 32 / 64-channel layers, whose blocks then fit 4 / 2 per CU.
 template <int WN, int NKC, int VT>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, NKC == 2 ? 4 : 2) void conv_bf16_kernel(const ConvP p) {
     constexpr int WM = 4 / WN, TM = 32 * WM, TN = 32 * WN;
     constexpr int CP = TN / 2, RG = 256 / CP, RPT = TM / RG;       // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
     constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
     constexpr int SJ = WN * 8, PW = SJ / 4;                        // DMA wave-instructions per stage: block / per wave
+    constexpr int RD = NKC <= 4 ? 2 : 3;                           // ring depth (the launcher sizes the ring with ring_depth())
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cst = reinterpret_cast<float*>(smem);
-    uint2* rowtab = reinterpret_cast<uint2*>(smem + CST_BYTES);
-    unsigned char* patch = smem + CST_BYTES + ROWTAB_BYTES;
-    unsigned char* bring = patch + p.patch_bytes;                  // [3][WN][8][1 KiB]
+    const int cst_bytes = 6 * p.g.Cin * 4;                         // the six constant rows of the fill's BatchNorm
+    uint2* rowtab = reinterpret_cast<uint2*>(smem + cst_bytes);
+    unsigned char* patch = smem + cst_bytes + ROWTAB_BYTES;
+    unsigned char* bring = patch + p.patch_bytes;                  // [RD][WN][8][1 KiB]
     const Geo& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WN, wn = w % WN;
     const unsigned m0 = blockIdx.x * TM;
@@ -289,14 +296,20 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
         mu0 = sv[c]; mu1 = sv[c + 1]; rs0 = sv[C + c]; rs1 = sv[C + c + 1];
         sc0 = sv[2 * C + c]; sc1 = sv[2 * C + c + 1]; sh0 = sv[3 * C + c]; sh1 = sv[3 * C + c + 1];
     }
+    // the 32-channel layers run four blocks per CU (128 registers): their blocks fetch these after the k-phase instead of
+    // holding 2*RPT registers across it -- the other resident blocks cover the latency
+    constexpr bool EARLY = NKC != 2;
     unsigned rv[RPT], yv[RPT];
+    auto load_epi = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const unsigned m = min(m0 + rg + RG * i, M - 1);
-        const size_t o = (size_t)m * p.Cout + c;
-        rv[i] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
-        yv[i] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
-    }
+        for (int i = 0; i < RPT; ++i) {
+            const unsigned m = min(m0 + rg + RG * i, M - 1);
+            const size_t o = (size_t)m * p.Cout + c;
+            rv[i] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
+            yv[i] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
+        }
+    };
+    if constexpr (EARLY) load_epi();
     // ---- weight ring: stages 0 and 1 on their way before anything else
     const bf16x8* wsrc = p.wpk + (size_t)(blockIdx.y * WN) * p.Fs * 64 + lane;
     const unsigned ring0 = lds_addr(bring);
@@ -304,14 +317,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int j = w + 4 * i, nt = j >> 3, f8 = j & 7;
-            dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)(((st % 3) * SJ + j) * 1024));
+            dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)(((st % RD) * SJ + j) * 1024));
         }
     };
     issue_stage(0);
-    if (NST > 1) issue_stage(1);
+    if (RD > 2 && NST > 1) issue_stage(1);
 
 
-    if (p.fill) bn_prologue(p.fb, p.fill, g.Cin, 0, g.Cin, cst, blockIdx.x == 0 && blockIdx.y == 0, 256);
+    if (p.fill) bn_prologue(p.fb, p.fill, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, 256);
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
     pix_rp(g, min(m0 + TM - 1, M - 1), Rp_hi, wtmp);
@@ -329,13 +342,14 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
     }
     // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    wg_barrier();
     TSTAMP(2);
 
     // ---- fill: the padded patch, all input channels, transformed once
-    if (p.fill == 0) fill_patch<0, TM>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else if (p.fill == 1) fill_patch<1, TM>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else fill_patch<2, TM>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    constexpr int FU = NKC == 2 ? 2 : 4;                           // 128-register variants: two pieces per thread in flight
+    if (p.fill == 0) fill_patch<0, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else if (p.fill == 1) fill_patch<1, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else fill_patch<2, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
     // ---- per-lane A address
     unsigned a_lane;
     {
@@ -364,12 +378,15 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
             const int f = v * NKC + kc;
             if (f % 8 == 0) {
                 const int st = f / 8;
-                if (st + 1 < NST) wait_vm<PW>(); else wait_vm<0>();
-                __builtin_amdgcn_s_barrier();
+                if (RD > 2 && st + 1 < NST) wait_vm<PW>(); else wait_vm<0>();
+                // stage 0: this wave's patch stores must have completed before the others read them (gfx950 inserts no
+                // implicit wait in front of a bare s_barrier)
+                if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();
                 if (st == 0) { TSTAMP(4); load_afrags<NKC>(afr[0], patch, a_lane); }
-                if (st + 2 < NST) issue_stage(st + 2);
+                if (st + RD - 1 < NST) issue_stage(st + RD - 1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + ((st % 3) * SJ + i) * 1024);
+                for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + ((st % RD) * SJ + i) * 1024);
             }
             if (kc == 0 && v + 1 < VT) {
                 const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
@@ -382,6 +399,7 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(const ConvP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     TSTAMP(5);
+    if constexpr (!EARLY) load_epi();
     __syncthreads();                                               // the patch is dead: reuse it as the output staging tile
 
     // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), bf16 stores, statistics
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(KK == 1 ? WG_NW1 * 64 : KK * 64) void wgrad_bf16_ke
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (KK != 1) __builtin_amdgcn_s_barrier();
+    if constexpr (KK != 1) wg_barrier();
     TSTAMP(2);
 
     auto issue = [&](int lc) __attribute__((always_inline)) {
@@ -608,7 +626,7 @@ __global__ __launch_bounds__(KK == 1 ? WG_NW1 * 64 : KK * 64) void wgrad_bf16_ke
         // chunk lc has landed once at most min(nmine-1-lc, NBUF-2) younger chunks of this wave are still in flight
         wait_vm_n(NI * min(nmine - 1 - lc, WG_NBUF - 2));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's transpose-reads of chunk lc-1 are done
-        if constexpr (KK != 1) __builtin_amdgcn_s_barrier();       // everyone's pieces landed; everyone has read chunk lc-1
+        if constexpr (KK != 1) wg_barrier();       // everyone's pieces landed; everyone has read chunk lc-1
         if (lc + WG_NBUF - 1 < nmine) issue(lc + WG_NBUF - 1);     // into the slot chunk lc-1 just left
         if (lc + WG_NBUF < nmine) tables(lc + WG_NBUF);            // ring slot of chunk lc-2: last read two barriers ago
         read_ops(lc, An, Bn);
@@ -671,13 +689,13 @@ template <typename DT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const DT* __restrict__ dact, const u16* __restrict__ x, const BnP bn,
                                                                 const u16* __restrict__ add, u16* __restrict__ out, long R, int C, int relu) {
     __shared__ float cst[6 * CMAX];
-    bn_prologue(bn, 2, C, 0, C, cst, blockIdx.x == 0, 256);
+    bn_prologue(bn, 2, C, 0, C, cst, CMAX, blockIdx.x == 0, 256);
     __syncthreads();
     const int pc = C >> 3;                                         // power of two
     const long total = R * pc, stride = (long)gridDim.x * 256;     // stride % pc == 0
     const int c8 = threadIdx.x & (pc - 1);
     Cst8 k;
-    load_cst8(cst, c8 * 8, 2, k);
+    load_cst8(cst, CMAX, c8 * 8, 2, k);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long e = i * 8;
         float a[8], y[8], o[8], ad[8];
@@ -744,13 +762,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const DT* __res
 // Final BatchNorm + ReLU of the trunk (resnet.py:178-181): bf16 in, fp32 out for the sequence layers.
 __global__ __launch_bounds__(256) void bn_apply_bf16_f32_kernel(const u16* __restrict__ x, const BnP bn, float* __restrict__ out, long R, int C, int relu) {
     __shared__ float cst[6 * CMAX];
-    bn_prologue(bn, 1, C, 0, C, cst, blockIdx.x == 0, 256);
+    bn_prologue(bn, 1, C, 0, C, cst, CMAX, blockIdx.x == 0, 256);
     __syncthreads();
     const int pc = C >> 3;
     const long total = R * pc, stride = (long)gridDim.x * 256;
     const int c8 = threadIdx.x & (pc - 1);
     Cst8 k;
-    load_cst8(cst, c8 * 8, 1, k);
+    load_cst8(cst, CMAX, c8 * 8, 1, k);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long e = i * 8;
         float y[8];
@@ -881,13 +899,13 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
     const int WN = Cout >= 64 ? 2 : 1, TM = 32 * (4 / WN), TN = 32 * WN;
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
-    const size_t ring_bytes = (size_t)3 * WN * 8 * 1024;
+    const size_t ring_bytes = (size_t)(Cin <= 64 ? 2 : 3) * WN * 8 * 1024;     // RD of the kernel: NKC = Cin/16 <= 4 -> 2
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
     const size_t stage_bytes = (size_t)TM * TN * 4 + 256 / (TN / 2) * TN * 2 * 4;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
     patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
     p.patch_bytes = (int)patch_bytes;
-    const size_t lds = CST_BYTES + ROWTAB_BYTES + patch_bytes + ring_bytes;
+    const size_t lds = (size_t)6 * Cin * 4 + ROWTAB_BYTES + patch_bytes + ring_bytes;
     if (lds > 160 * 1024) return SAR_EINVAL;
     const dim3 grid((unsigned)cdiv(p.g.M, TM), (unsigned)(Cout / TN));
     // instantiations: [WN][NKC in {2,4,8}][K == 3]; Cin = 256 / 512 run NKC = 8 with 2 / 4 channel parts per tap

@@ -1392,6 +1392,15 @@ extern "C" int sar_conv2d_dgrad_ex_f32(const float* dy, const float* w, float* d
     return conv_dgrad_launch(dy, w, dx, B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, accumulate, wd_hi, wd_lo, stream);
 }
 
+// what the last sar_conv2d_wgrad_f32 call launched: {pixel slices, XCD-grouped 1-D grid (0/1), split-precision kernel (0/1),
+// rows per slice} -- lets the parity tests assert that a bench-shape case really took the multi-slice / XCD path
+static int g_last_wgrad[4] = {0, 0, 0, 0};
+extern "C" int sar_dbg_last_wgrad_launch(int* out4) {
+    if (out4 == nullptr) return SAR_EINVAL;
+    for (int i = 0; i < 4; ++i) out4[i] = g_last_wgrad[i];
+    return SAR_OK;
+}
+
 extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift,
                                     float* dw, float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW,
                                     int stride, int pad_top, int pad_left, hipStream_t stream) {
@@ -1426,6 +1435,7 @@ extern "C" int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float
     // 72 tiles -- stage 3 -- two XCDs would idle: measured 27 -> 38 us)
     static const int xcd_knob = getenv("SAR_WGRAD_XCD") ? atoi(getenv("SAR_WGRAD_XCD")) : 1;
     p.xcd = xcd_knob && ((splits + 7) / 8) * 8 * 100 <= 115 * splits;
+    g_last_wgrad[0] = splits; g_last_wgrad[1] = p.xcd; g_last_wgrad[2] = x3 ? 1 : 0; g_last_wgrad[3] = (int)rows;
     if (x3) {                                                        // bf16x3 split-precision path, XCD-aware 1-D grid
         const dim3 g1(p.xcd ? xcd_slice_blocks(p.gx, p.gy, p.gz) : p.gx * p.gy * p.gz);
         if (narrow) hipLaunchKernelGGL((conv_wgrad_x3_kernel<32>), g1, dim3(256), 0, stream, p);

@@ -78,6 +78,9 @@ int sar_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int B, int 
 int sar_conv2d_wgrad_f32(const float* x, const float* dy, const float* scale, const float* shift, float* dw,
                          float* dbias, int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad_top,
                          int pad_left, sarStream_t stream);
+/* Diagnostics: what the last sar_conv2d_wgrad_f32 call launched -- out4 = {pixel slices, XCD-grouped grid 0/1, split-precision
+ * kernel 0/1, rows per slice}.  Host-only. */
+int sar_dbg_last_wgrad_launch(int* out4);
 /* Matrix-core math of the 3x3/1x1 convolutions with >= 64 output (fwd) / input (dgrad) channels:
  * 0 = fp32 MFMA (bit-exact fp32 fma chains); 1 = bf16x3 split precision (default): x = hi + lo in bf16,
  * A*B ~= Ah*Bh + Ah*Bl + Al*Bh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, ~2^-17 relative error per product.

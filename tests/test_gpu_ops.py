@@ -129,6 +129,73 @@ def test_conv_fwd_dgrad_wgrad(L, case):
     check(db2, db_ref, name="colsum")
 
 
+# Every distinct conv of the bench trunk (res34, F=32, T=400: pooled map 100x20x64) at the bench batch B=64, i.e. the launch
+# configurations bench.py actually runs in the fp32-storage modes: multi-slice weight gradients on the XCD-grouped grid,
+# split-K + pre-split weight planes in stages 2-3 (resnet.py:96-125).  Held per tensor to max-abs <= 2e-4 (fp32 MFMA) /
+# <= 1e-4 (bf16x3) of the tensor's max -- no flat L2.
+BENCH_CONVS = [  # H, W, Cin, Cout, k, stride, pad, prologue+residual
+    (100, 20, 64, 32, 3, 1, "same", False), (100, 20, 64, 32, 1, 1, "valid", False), (100, 20, 32, 32, 3, 1, "same", True),
+    (100, 20, 32, 64, 3, 2, "same", True), (100, 20, 32, 64, 1, 2, "valid", False), (50, 10, 64, 64, 3, 1, "same", True),
+    (50, 10, 64, 128, 3, 2, "same", True), (50, 10, 64, 128, 1, 2, "valid", False), (25, 5, 128, 128, 3, 1, "same", True),
+    (25, 5, 128, 256, 3, 2, "same", True), (25, 5, 128, 256, 1, 2, "valid", False), (13, 3, 256, 256, 3, 1, "same", True),
+]
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("case", BENCH_CONVS, ids=["%dx%dx%d-%d_k%d_s%d" % c[:6] for c in BENCH_CONVS])
+def test_conv_bench_shapes_at_batch_64(L, case, math):
+    import ctypes
+    H, W, Cin, Cout, k, s, pad, full = case
+    B = 64
+    tol = 2e-4 if math == "fp32" else 1e-4
+    rng = np.random.default_rng(sum(case[:6]))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32).astype(np.float64)
+    w = (rng.standard_normal((k, k, Cin, Cout)) * (1.0 / np.sqrt(k * k * Cin))).astype(np.float32).astype(np.float64)
+    b = rng.standard_normal(Cout).astype(np.float32).astype(np.float64)
+    scale = rng.uniform(0.5, 1.5, Cin).astype(np.float32).astype(np.float64); shift = (rng.standard_normal(Cin) * 0.3).astype(np.float32).astype(np.float64)
+    act = np.maximum(x * scale + shift, 0) if full else x
+    y_ref, cache = O.conv2d_fwd(act, w, b, (s, s), pad)
+    _, Ho, Wo, _ = y_ref.shape
+    pt, pl = (O.same_pads(H, k, s)[1], O.same_pads(W, k, s)[1]) if pad == "same" else (0, 0)
+    r = rng.standard_normal(y_ref.shape).astype(np.float32).astype(np.float64) if full else None
+    dy = rng.standard_normal(y_ref.shape).astype(np.float32).astype(np.float64)
+    dact_ref, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+    del cache
+    old = L.get_conv_math()
+    L.set_conv_math(math)
+    try:
+        xd, wd, dyd = dev(x), dev(w), dev(dy)
+        scd, shd = (dev(scale), dev(shift)) if full else (None, None)
+        # the train step's form for the wide layers: kernels pre-split into bf16 planes (forward / input gradient)
+        planes = math == "bf16x3" and Cin % 32 == 0 and Cout % 64 == 0
+        wt = wdp = (None, None)
+        if planes:
+            K = k * k * Cin
+            wt = tuple(torch.empty(Cout, K, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+            wdp = tuple(torch.empty(K, Cout, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+            tab = torch.tensor([[wd.data_ptr(), wt[0].data_ptr(), wt[1].data_ptr(), wdp[0].data_ptr(), wdp[1].data_ptr(), K, Cout, 0]], dtype=torch.int64, device="cuda")
+            L.call("sar_conv_weight_split_bf16", tab, 1, (K // 32) * (Cout // 64))
+        y = zeros(B, Ho, Wo, Cout)
+        L.call("sar_conv2d_fwd_ex_f32", xd, wd, dev(b), scd, shd, dev(r) if full else None, y, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl,
+               wt[0], wt[1], None, None, None, None, None, None, None, None, None, 1e-3, 0.99, 1)
+        check(y, y_ref + (r if full else 0), tol, "conv fwd")
+        dx = zeros(B, H, W, Cin)
+        L.call("sar_conv2d_dgrad_ex_f32", dyd, wd, dx, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl, 0, wdp[0], wdp[1])
+        check(dx, dact_ref, tol, "conv dgrad")
+        dw = zeros(k, k, Cin, Cout); db = zeros(Cout)
+        L.call("sar_conv2d_wgrad_f32", xd, dyd, scd, shd, dw, db, B, H, W, Cin, Ho, Wo, Cout, k, k, s, pt, pl)
+        check(dw, dw_ref, tol, "conv wgrad"); check(db, db_ref, tol, "conv dbias")
+        info = (ctypes.c_int * 4)()
+        assert L.lib().fn["sar_dbg_last_wgrad_launch"](info) == 0
+        slices, xcd, x3, rows = list(info)
+        assert x3 == (1 if math == "bf16x3" else 0)
+        if math == "bf16x3" and k == 3 and Cout >= 64 and B * Ho * Wo >= 8000:
+            # the dominant launch class of the fp32-storage profile: many pixel slices, XCD-grouped 1-D grid, atomic flush
+            assert slices > 8 and xcd == 1, (slices, xcd, rows)
+    finally:
+        L.set_conv_math(old)
+
+
 @pytest.mark.parametrize("case", [  # B,H,W,Cin,Cout,k,stride -- kernels pre-split into bf16 planes (two convs in one table)
     (2, 10, 8, 64, 64, 3, 1), (2, 13, 5, 64, 128, 3, 2), (3, 25, 5, 64, 128, 1, 2), (64, 50, 12, 64, 64, 3, 1), (2, 7, 3, 128, 256, 3, 1)])
 def test_conv_with_weight_planes(L, case):

@@ -18,8 +18,6 @@ sys.path.insert(0, os.path.dirname(HERE))
 lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing16.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.sar_conv2d_bf16.argtypes = [vp] * 7 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
-lib.sar_conv2d_wgrad_bf16.argtypes = [vp] * 4 + [ci] * 11 + [vp]
-lib.sar_conv2d_wgrad_slices_bf16.argtypes = [ci] * 5
 lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
 lib.sar_dbg_set_timing_buffer16.argtypes = [vp]
 BF = torch.bfloat16
@@ -38,10 +36,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
     lib.sar_conv_pack_weights_bf16(tab.data_ptr(), 1, -(-(nf + nd) // 8 // 256), st)
     bins = torch.zeros(16, 2, Cout, device="cuda")
     if mode == "wgrad":
-        P = lib.sar_conv2d_wgrad_slices_bf16(B, H, W, Cin, Cout)
-        part = torch.zeros(P, k * k * Cin * Cout, device="cuda")
-        fn = lambda: lib.sar_conv2d_wgrad_bf16(x.data_ptr(), y.data_ptr(), part.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, st)
-        names = {"prologue": (1, 2), "first issue": (2, 3), "chunk loop": (3, 4), "flush": (4, 5), "total": (1, 5)}
+        raise SystemExit("the weight gradient is a batched launch now: time it with bench.py's roofline classes / rocprofv3")
     else:
         wp = wf if mode == "fwd" else wd
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
