@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsarnet_hip.so")
+LIB_PATH = os.environ.get("SAR_LIB_PATH") or os.path.join(_HERE, "libsarnet_hip.so")   # override: developer A/B builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sarnet.h")
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t}
@@ -121,9 +121,10 @@ class WgradPlan:
     MAX_ITEMS = 16384
 
     @staticmethod
-    def plan_host(descs, target_blocks, max_items=MAX_ITEMS):
-        """descs: dicts with the sarWgradConv fields (pointers: tensors, ints or None), all of equal K.
-        -> (convs table bytes, items table bytes, n_items, lds_bytes); no device access."""
+    def plan_host(descs, target_blocks, tile=(1, 1), max_items=MAX_ITEMS):
+        """descs: dicts with the sarWgradConv fields (pointers: tensors, ints or None), all of equal K; tile = (32-channel planes
+        per block on the input side, on the output side).  -> (convs table bytes, items table bytes, n_items, launch4); no
+        device access."""
         n = len(descs)
         arr = (WgradConv * n)()
         for a, d in zip(arr, descs):
@@ -134,22 +135,28 @@ class WgradPlan:
                 setattr(a, k, int(d[k]))
         cbuf = ctypes.create_string_buffer(n * 128)
         ibuf = ctypes.create_string_buffer(max_items * 32)
-        ni, lds = ctypes.c_int(0), ctypes.c_int(0)
-        rc = lib().fn["sar_wgrad_plan_bf16"](arr, n, int(target_blocks), cbuf, ibuf, max_items, ctypes.byref(ni), ctypes.byref(lds))
+        ni, l4 = ctypes.c_int(0), (ctypes.c_int * 4)()
+        rc = lib().fn["sar_wgrad_plan_bf16"](arr, n, int(target_blocks), int(tile[0]), int(tile[1]), cbuf, ibuf, max_items, ctypes.byref(ni), l4)
         if rc != 0:
             raise RuntimeError("sar_wgrad_plan_bf16 failed with status %d" % rc)
-        return cbuf.raw, ibuf.raw[:ni.value * 32], ni.value, lds.value
+        return cbuf.raw, ibuf.raw[:ni.value * 32], ni.value, list(l4)
 
-    def __init__(self, descs, target_blocks):
+    def __init__(self, descs, target_blocks, tile=(1, 1)):
         import torch
         self.keep = [d[k] for d in descs for k in ("x", "dy", "dw", "dbias")]      # the tensors whose addresses the tables hold
         self.K = int(descs[0]["K"])
-        convs, items, self.n_items, self.lds = self.plan_host(descs, target_blocks)
+        convs, items, self.n_items, l4 = self.plan_host(descs, target_blocks, tile)
+        self.launch4 = (ctypes.c_int * 4)(*l4)
+        self.lds, self.np, self.nbuf = l4[0], l4[1], l4[2]
         self.convs = torch.frombuffer(bytearray(convs), dtype=torch.uint8).cuda()
         self.items = torch.frombuffer(bytearray(items), dtype=torch.uint8).cuda()
 
     def launch(self):
-        call("sar_conv2d_wgrad_batch_bf16", self.convs, self.items, self.n_items, self.K, self.lds)
+        import torch
+        rc = lib().fn["sar_conv2d_wgrad_batch_bf16"](self.convs.data_ptr(), self.items.data_ptr(), self.n_items, self.K, self.launch4,
+                                                      torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("sar_conv2d_wgrad_batch_bf16 failed with status %d" % rc)
 
 
 def bn_bins():

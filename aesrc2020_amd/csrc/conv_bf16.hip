@@ -187,6 +187,7 @@ struct ConvP {
     int Fs;                     // fragment stride of the weight stream per 32 output channels: K*K*Cin/16 + 8 (zero tail)
     int cap_rows;               // patch rows the LDS allocation holds
     int patch_bytes;            // LDS bytes of the patch region (incl. the 1 KiB scratch slot); the weight ring follows
+    int rd;                     // depth of the weight ring: 3, or 4 where the LDS has room (128+-channel stride-1 layers)
 };
 constexpr int ROWTAB_BYTES = 1024;   // per patch row {source row base offset | NONE, owner pixel of the row's first column}
 
@@ -260,18 +261,22 @@ __device__ __forceinline__ void load_afrags(bf16x8 (&a)[NKC], const unsigned cha
 
 // WN: waves along the output channels (tile 32*(4/WN) pixels x 32*WN channels); NKC: 16-channel blocks per virtual tap
 // (2, 4, 8); VT: virtual taps = K*K x channel parts of 128 (Cin = 256: two parts per tap, 512: four): 1, 2, 4, 9, 18, 36.
-// Weights: the packed fragment stream of this block's channels is brought into an RD-deep LDS ring by LDS-DMA in stages of 8
-// fragments per channel tile (one barrier per stage, RD-1 stages in flight behind the one being multiplied), so all four
-// waves share one copy and no VGPR or VALU instruction is spent on the B operand.  RD = 3 for the 128+-channel layers (one
-// block per CU: the stream has to hide its own latency), 2 for the 32 / 64-channel layers, whose blocks then fit 4 / 2 per CU.
+// Weights: the packed fragment stream of this block's channels is brought into an LDS ring (3 deep; 4 for the 128+-channel
+// layers, whose long k-loops run one block per CU) by LDS-DMA in stages of 8 fragments per channel tile (one barrier per stage),
+// so all four waves share one copy and no VGPR or VALU instruction is spent on the B operand.  A stage is WAITED FOR ONE
+// BARRIER BEFORE IT IS READ.  Waiting right in front of the barrier that releases its readers is not enough: with a wait that
+// usually had to stall (2-deep ring) single waves read stale fragments about once in 300 launches -- one wave's 32 x 32 tile
+// wrong, the other waves of the block right (tools/conv16_race.py).  A read-back of the wave's own pieces between vmcnt and the
+// barrier cured it (so a piece that has left the issuing wave's vmcnt is ordered against that wave's LDS reads, not yet against
+// every other wave's), at 5 % of the step; one full stage of margin costs nothing once the ring is a stage deeper.
 template <int WN, int NKC, int VT>
-__global__ __launch_bounds__(256, NKC == 2 ? 4 : 2) void conv_bf16_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     constexpr int WM = 4 / WN, TM = 32 * WM, TN = 32 * WN;
     constexpr int CP = TN / 2, RG = 256 / CP, RPT = TM / RG;       // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
     constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
     constexpr int SJ = WN * 8, PW = SJ / 4;                        // DMA wave-instructions per stage: block / per wave
-    constexpr int RD = NKC <= 4 ? 2 : 3;                           // ring depth (the launcher sizes the ring with ring_depth())
+    const int RD = p.rd;                                           // ring depth, 3 or 4 (launcher: 4 where the LDS has room for it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cst = reinterpret_cast<float*>(smem);
     const int cst_bytes = 6 * p.g.Cin * 4;                         // the six constant rows of the fill's BatchNorm
@@ -296,9 +301,10 @@ __global__ __launch_bounds__(256, NKC == 2 ? 4 : 2) void conv_bf16_kernel(const 
         mu0 = sv[c]; mu1 = sv[c + 1]; rs0 = sv[C + c]; rs1 = sv[C + c + 1];
         sc0 = sv[2 * C + c]; sc1 = sv[2 * C + c + 1]; sh0 = sv[3 * C + c]; sh1 = sv[3 * C + c + 1];
     }
-    // the 32-channel layers run four blocks per CU (128 registers): their blocks fetch these after the k-phase instead of
-    // holding 2*RPT registers across it -- the other resident blocks cover the latency
-    constexpr bool EARLY = NKC != 2;
+    // (a 128-register variant for four blocks per CU -- these loads after the k-phase, two fill pieces in flight -- needs the
+    // 32-channel layers' LDS at 40 KB, i.e. a 2-deep weight ring: see the ring comment; with the 3-deep ring they fit three per CU
+    // and the variant was slower, 23 vs 17 us per stage-0 launch)
+    constexpr bool EARLY = true;
     unsigned rv[RPT], yv[RPT];
     auto load_epi = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -313,15 +319,16 @@ __global__ __launch_bounds__(256, NKC == 2 ? 4 : 2) void conv_bf16_kernel(const 
     // ---- weight ring: stages 0 and 1 on their way before anything else
     const bf16x8* wsrc = p.wpk + (size_t)(blockIdx.y * WN) * p.Fs * 64 + lane;
     const unsigned ring0 = lds_addr(bring);
-    auto issue_stage = [&](int st) {
+    auto issue_stage = [&](int st, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int j = w + 4 * i, nt = j >> 3, f8 = j & 7;
-            dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)(((st % RD) * SJ + j) * 1024));
+            dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)((slot * SJ + j) * 1024));
         }
     };
-    issue_stage(0);
-    if (RD > 2 && NST > 1) issue_stage(1);
+    issue_stage(0, 0);
+    if (NST > 1) issue_stage(1, 1);
+    if (RD > 3 && NST > 2) issue_stage(2, 2);
 
 
     if (p.fill) bn_prologue(p.fb, p.fill, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, 256);
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256, NKC == 2 ? 4 : 2) void conv_bf16_kernel(const 
     TSTAMP(2);
 
     // ---- fill: the padded patch, all input channels, transformed once
-    constexpr int FU = NKC == 2 ? 2 : 4;                           // 128-register variants: two pieces per thread in flight
+    constexpr int FU = 4;                                          // fill pieces per thread in flight
     if (p.fill == 0) fill_patch<0, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
     else if (p.fill == 1) fill_patch<1, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
     else fill_patch<2, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
@@ -378,15 +385,18 @@ __global__ __launch_bounds__(256, NKC == 2 ? 4 : 2) void conv_bf16_kernel(const 
             const int f = v * NKC + kc;
             if (f % 8 == 0) {
                 const int st = f / 8;
-                if (RD > 2 && st + 1 < NST) wait_vm<PW>(); else wait_vm<0>();
+                // stages <= st+1 have landed -- stage st one whole stage and a barrier ago (see above); RD = 4: stage st+2 in flight
+                if (RD == 4 && st + 2 < NST) wait_vm<PW>(); else wait_vm<0>();      // (kernel-uniform branch)
                 // stage 0: this wave's patch stores must have completed before the others read them (gfx950 inserts no
                 // implicit wait in front of a bare s_barrier)
                 if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wg_barrier();
                 if (st == 0) { TSTAMP(4); load_afrags<NKC>(afr[0], patch, a_lane); }
-                if (st + RD - 1 < NST) issue_stage(st + RD - 1);
+                if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
+                else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
+                const int slot = RD == 4 ? (st & 3) : (st % 3);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + ((st % RD) * SJ + i) * 1024);
+                for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + (slot * SJ + i) * 1024);
             }
             if (kc == 0 && v + 1 < VT) {
                 const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
@@ -464,7 +474,8 @@ struct WgConv {                 // device table row, written by sar_wgrad_plan_b
     const u16* x; const u16* dy; float* dw; float* dbias;
     int nchunks;                // 64-pixel chunks
     int cap_pos;                // patch positions of one chunk (multiple of 16)
-    int pad_[2];
+    int la;                     // 3x3: chunks requested ahead of the one being multiplied (1..3: what the position ring holds)
+    int pad_;
 };
 static_assert(sizeof(WgConv) <= 128, "WgConv must fit its 128-byte table row");
 struct WgItem { int conv, ci0, co0, c_first, c_count, single, pad0_, pad1_; };   // 32 bytes
@@ -479,6 +490,7 @@ __device__ __forceinline__ s16x4 lds_tr(const unsigned char* base, unsigned off)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
 }
 
+constexpr int WG_TAB_MAX = 6144; // 3x3: positions in an item's source-offset table (24 KB of LDS at most)
 constexpr int WG_NW1 = 4;       // 1x1: independent waves per block, each on its own share of the item's chunks (merged in LDS at the end)
 
 template <int KK>
@@ -681,6 +693,218 @@ __global__ __launch_bounds__(KK == 1 ? WG_NW1 * 64 : KK * 64) void wgrad_bf16_ke
         }
     }
     TSTAMP(5); TSTAMP(15);
+}
+
+// ---- 3x3 weight gradient, second form: rolling patch ring and up to 64 x 64 channel tiles ---------------------------------------
+// What the first batched form measured (profiles/r2_v8: 7.5 M L2 requests = 960 MB per launch for 300 MB of unique operands, L2 hit
+// rate 24 %, 2.7 TB/s through the fabric, 260 us): every 64-pixel chunk fetched its whole padded patch -- 160 positions for 64 pixels,
+// the halo rows and the partial rows again with the next chunk -- and every 32-channel tile fetched 64-byte halves of 128+-byte rows.
+// Here a block streams its run of pixels through ONE circular buffer of padded positions per 32-channel plane: consecutive chunks
+// only fetch the positions that are new (~70 per 64 pixels), position p lives at slot p mod NP, a tap is a constant position
+// offset (dy*Wp + dx) added before the wrap.  A block owns TCI x TCO planes of 32 channels (64 x 64 where the layer has them): the
+// activation planes are shared by the TCO output planes and vice versa, halving the bytes and the transpose-reads per MFMA.
+// Per chunk the block issues 4*TCO DMA instructions for the gradient rows and TCI per new 16-position group, dealt round-robin to
+// the nine waves; every wave issues the same count (the surplus repeat the last one), so the hand-counted vmcnt stays three
+// scalars: the instruction counts of the chunks in flight.
+struct Wg3Args { const unsigned char* convs; const WgItem* items; const uint4* zero; unsigned np; int nbuf; int tab_pos; };
+
+template <int TCI, int TCO>
+__global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const WgItem it = a.items[blockIdx.x];
+    const WgConv* cvp = reinterpret_cast<const WgConv*>(a.convs + (size_t)it.conv * 128);
+    const Geo g = cvp->g;
+    const int Cout = cvp->Cout, LA = cvp->la;
+    const u16* __restrict__ xp = cvp->x; const u16* __restrict__ dyp = cvp->dy;
+    float* dwp = cvp->dw; float* dbp = cvp->dbias;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = it.ci0, co0 = it.co0;
+    const unsigned M = (unsigned)g.M, NP = a.np, mask = a.np - 1;
+    const int c_first = it.c_first, nmine = it.c_count, nbuf = a.nbuf;
+    unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [2][64]: absolute patch position of every pixel
+    unsigned* soff = qring + 128;                                                  // [tab_pos]: source element offset of every position of this item (NONE: zero)
+    unsigned char* dyr = smem + 512 + (size_t)a.tab_pos * 4;                       // [nbuf][TCO][64 px][64 B]
+    unsigned char* pr = dyr + (size_t)nbuf * TCO * 4096;                           // [TCI][NP][64 B]
+    const unsigned dyr0 = lds_addr(dyr), pr0a = lds_addr(pr);
+    constexpr int MAXNI = 4;
+
+    auto tables = [&](int lc) __attribute__((always_inline)) {
+        if (tid < 64) {
+            const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+            unsigned Rp, wq;
+            pix_rp(g, min(mc0 + tid, M - 1), Rp, wq);                              // past the batch: the last pixel's position; its dY row is zero
+            qring[(lc & 1) * 64 + tid] = Rp * g.Wp + wq;
+        }
+    };
+    unsigned Gn;                                                                   // first 16-position group not requested yet
+    {
+        unsigned Rp, wq;
+        pix_rp(g, (unsigned)c_first * 64, Rp, wq);
+        Gn = (Rp * g.Wp + wq) >> 4;
+    }
+    // Source offsets of all positions this item will ever request, once: position -> (image, row, column) costs two divisions,
+    // and doing that inside every DMA instruction (~45 VALU instructions each, nine waves at the same time right behind the
+    // barrier) made address generation, not the MFMAs, the longest phase of a chunk.
+    const unsigned P0 = Gn * 16;
+    {
+        unsigned Rpl, wql;
+        pix_rp(g, min((unsigned)(c_first + nmine) * 64, M) - 1, Rpl, wql);
+        const unsigned npos = min((((Rpl + g.K) * g.Wp + 15) & ~15u) - P0, (unsigned)a.tab_pos);
+        for (unsigned i = tid; i < npos; i += 576) {
+            const unsigned p = P0 + i;
+            const unsigned Rp = udiv(p, g.mg_wp, (unsigned)g.Wp), wp = p - Rp * g.Wp;
+            const unsigned b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
+            const int u = (int)hp - g.pt, v = (int)wp - g.pl;
+            const bool ok = (u >= 0) & (u < g.Hs) & (v >= 0) & (v < g.Ws) & (b < (unsigned)g.B);
+            soff[i] = ok ? ((b * g.Hs + u) * g.Ws + v) * g.Cin : NONE;
+        }
+    }
+    // per-lane constants of a DMA piece: 4 lanes per position / pixel, 16 bytes = 8 channels each
+    const unsigned l4 = lane >> 2, pc8 = (lane & 3) * 8;
+    auto issue = [&](int lc) __attribute__((always_inline)) -> int {
+        const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+        unsigned Rpl, wql;
+        pix_rp(g, min(mc0 + 63, M - 1), Rpl, wql);
+        const unsigned Gh = ((Rpl + g.K) * g.Wp + 15) >> 4;                        // every position in front of (last row + K) * Wp
+        const int npg = Gh > Gn ? (int)(Gh - Gn) : 0;
+        const int total = 4 * TCO + npg * TCI, NI = (total + 8) / 9;
+        const unsigned dyslot = dyr0 + (unsigned)(lc % nbuf) * (TCO * 4096);
+#pragma unroll
+        for (int i = 0; i < MAXNI; ++i) {
+            if (i < NI) {
+                const int j = min(w + 9 * i, total - 1);
+                const void* src; unsigned dst;
+                if (j < 4 * TCO) {                                                 // gradient rows: plane j/4, 16 pixels j%4
+                    const int pl = j >> 2, blk = j & 3;
+                    const unsigned m = mc0 + blk * 16 + l4;
+                    src = m < M ? (const void*)(dyp + (size_t)m * Cout + co0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
+                    dst = dyslot + (unsigned)(pl * 4096 + blk * 1024);
+                } else {                                                           // 16 new patch positions of one activation plane
+                    const int jj = j - 4 * TCO, pl = TCI == 1 ? 0 : (jj & 1);
+                    const unsigned gi = Gn + (unsigned)(TCI == 1 ? jj : jj >> 1);
+                    const unsigned so = soff[gi * 16 + l4 - P0];
+                    src = so != NONE ? (const void*)(xp + so + ci0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
+                    dst = pr0a + (unsigned)pl * (NP * 64) + ((gi * 16) & mask) * 64;
+                }
+                dma16(src, dst);
+            }
+        }
+        if (Gh > Gn) Gn = Gh;
+        return NI;
+    };
+    TSTAMP(0); TSTAMP(1);
+#ifdef SAR_TIMING
+    unsigned long long t_wait = 0, t_issue = 0, t_mma = 0;
+#define TACC(var, expr) do { const unsigned long long t0__ = __builtin_amdgcn_s_memtime(); expr; var += __builtin_amdgcn_s_memtime() - t0__; } while (0)
+#else
+#define TACC(var, expr) do { expr; } while (0)
+#endif
+    tables(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();                                                                  // the offset table is complete
+    int q1 = 0, q2 = 0, q3 = 0;                                                    // DMA instructions of this wave for chunks lc+1, lc+2, lc+3
+    int q0 = nmine > 0 ? issue(0) : 0;
+    if (LA > 1 && nmine > 1) q1 = issue(1);
+    if (LA > 2 && nmine > 2) q2 = issue(2);
+    (void)q0;
+
+    f32x16 acc[TCI][TCO];
+#pragma unroll
+    for (int i = 0; i < TCI; ++i)
+#pragma unroll
+        for (int j = 0; j < TCO; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[TCO];
+#pragma unroll
+    for (int j = 0; j < TCO; ++j) bsum[j] = 0.f;
+    const bool do_bias = dbp != nullptr && w == 0 && ci0 == 0;
+    const unsigned toff = (unsigned)((w / 3) * g.Wp + (w % 3));                    // this wave's tap, in positions
+    const int gi_ = lane & 15, gg = lane >> 4, cb = gg & 1, kh = gg >> 1;
+    const unsigned colb = (16 * cb + 4 * (gi_ & 3)) * 2;
+    const unsigned prb = 8 * kh + (gi_ >> 2);
+    TSTAMP(2);
+
+    for (int lc = 0; lc < nmine; ++lc) {
+        // chunk lc has landed once only the instructions of the younger chunks in flight are outstanding
+        // (chunk lc+1 too: a full step between "landed" and "read", see conv_bf16_kernel's ring)
+        TACC(t_wait, wait_vm_n(q2 + q3); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wg_barrier());   // everyone's pieces landed; everyone is done with chunk lc-1
+        int qn = 0;
+        TACC(t_issue, if (lc + LA < nmine) qn = issue(lc + LA));   // dY slot of chunk lc+LA-nbuf <= lc-1; ring positions behind chunk lc
+        if (LA == 3) q3 = qn; else if (LA == 2) q2 = qn; else q1 = qn;
+        if (lc + 1 < nmine) tables(lc + 1);
+        const unsigned* qtab = qring + (lc & 1) * 64;
+        const unsigned char* dyt = dyr + (size_t)(lc % nbuf) * (TCO * 4096);
+        bf16x8 A[2][TCI], Bm[2][TCO];
+        auto rd = [&](int ks, bf16x8 (&Ao)[TCI], bf16x8 (&Bo)[TCO]) __attribute__((always_inline)) {
+            const unsigned p0 = 16 * ks + prb, p1 = p0 + 4;
+            const unsigned a0 = ((qtab[p0] + toff) & mask) * 64 + colb, a1 = ((qtab[p1] + toff) & mask) * 64 + colb;
+#pragma unroll
+            for (int i = 0; i < TCI; ++i) {
+                const s16x4 lo = lds_tr(pr + (size_t)i * NP * 64, a0), hi = lds_tr(pr + (size_t)i * NP * 64, a1);
+                Ao[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < TCO; ++j) {
+                const s16x4 lo = lds_tr(dyt + j * 4096, p0 * 64 + colb), hi = lds_tr(dyt + j * 4096, p1 * 64 + colb);
+                Bo[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        };
+        rd(0, A[0], Bm[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) rd(ks + 1, A[(ks + 1) & 1], Bm[(ks + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < TCI; ++i)
+#pragma unroll
+                for (int j = 0; j < TCO; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][i], Bm[ks & 1][j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < TCO; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[j] += (float)Bm[ks & 1][j][e];
+            }
+        }
+        q1 = q2; q2 = q3; q3 = 0;                                  // the chunks in flight move up one place
+    }
+    TSTAMP(3);
+#ifdef SAR_TIMING
+    if (g_tbuf16 && threadIdx.x == 0) {
+        const long bl = blockIdx.x;
+        g_tbuf16[bl * 16 + 8] = t_wait; g_tbuf16[bl * 16 + 9] = t_issue; g_tbuf16[bl * 16 + 10] = (unsigned long long)nmine;
+    }
+#endif
+    // ---- flush
+    {
+        const int col = lane & 31;
+#pragma unroll
+        for (int i = 0; i < TCI; ++i)
+#pragma unroll
+            for (int j = 0; j < TCO; ++j) {
+                float* o = dwp + ((size_t)w * g.Cin + ci0 + i * 32) * Cout + co0 + j * 32 + col;
+                if (it.single) {
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[i][j][r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) atomicAdd(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout, acc[i][j][r]);
+                }
+            }
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < TCO; ++j) {
+                float s = bsum[j];
+                s += __shfl_xor(s, 32, 64);
+                if (lane < 32) atomicAdd(dbp + co0 + j * 32 + lane, s);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(4); TSTAMP(15);
 }
 
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
@@ -899,9 +1123,11 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
     const int WN = Cout >= 64 ? 2 : 1, TM = 32 * (4 / WN), TN = 32 * WN;
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
-    const size_t ring_bytes = (size_t)(Cin <= 64 ? 2 : 3) * WN * 8 * 1024;     // RD of the kernel: NKC = Cin/16 <= 4 -> 2
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
     const size_t stage_bytes = (size_t)TM * TN * 4 + 256 / (TN / 2) * TN * 2 * 4;
+    // the long k-loops of the 128+-channel layers (one block per CU anyway) get a 4-deep weight ring where it fits
+    p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
+    const size_t ring_bytes = (size_t)p.rd * WN * 8 * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
     patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
     p.patch_bytes = (int)patch_bytes;
@@ -926,51 +1152,78 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
 // One convolution of a batched weight-gradient launch as the caller describes it (include/sarnet.h: sarWgradConv).
 struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl, pad_; };
 
-// Host-only planning (no device access): the device tables of ONE launch over `n` convolutions of equal K (1 or 3) --
-// convs_out: n rows of 128 bytes, items_out: up to max_items rows of 32 bytes, longest first -- plus the launch's dynamic
-// LDS size.  Runs of chunks are cut so that the launch has about `target_blocks` items.
-int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, void* convs_out, void* items_out, int max_items,
-                        int* n_items, int* lds_bytes) {
-    if (convs == nullptr || n < 1 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || lds_bytes == nullptr)
+// Host-only planning (no device access): the device tables of ONE launch over `n` convolutions of equal K (1 or 3) and equal
+// channel-tile class -- convs_out: n rows of 128 bytes, items_out: up to max_items rows of 32 bytes, longest first -- plus the
+// launch parameters launch4 = {dynamic LDS bytes, positions of the patch ring (3x3), chunk buffers, tile_ci << 4 | tile_co}.
+// tile_ci / tile_co (1 or 2): 32-channel planes per block on the input / output side (3x3 only; every Cin must be a multiple
+// of 32*tile_ci, every Cout of 32*tile_co).  Runs of chunks are cut so that the launch has about `target_blocks` items.
+int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int tile_ci, int tile_co, void* convs_out, void* items_out,
+                        int max_items, int* n_items, int* launch4) {
+    if (convs == nullptr || n < 1 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || launch4 == nullptr)
         return SAR_EINVAL;
     const int K = convs[0].K;
     if (K != 1 && K != 3) return SAR_EINVAL;
+    if (tile_ci < 1 || tile_ci > 2 || tile_co < 1 || tile_co > 2 || (K == 1 && (tile_ci != 1 || tile_co != 1))) return SAR_EINVAL;
     WgConv tmp;
     unsigned char* co = static_cast<unsigned char*>(convs_out);
     long total = 0;
-    int cap_max = 0;
-    for (int i = 0; i < n; ++i) {
+    auto prep = [&](int i) -> bool {                                 // validates descriptor i and builds its table row in tmp
         const sarWgradConv& c = convs[i];
         memset(&tmp, 0, sizeof(tmp));
-        if (c.K != K || !make_geo(tmp.g, c.B, c.H, c.W, c.Cin, c.Ho, c.Wo, c.K, c.s, 1, c.pt, c.pl)) return SAR_EINVAL;
-        if (!pow2(c.Cin) || !pow2(c.Cout) || c.Cin < 32 || c.Cout < 32 || c.Cin > CMAX || c.Cout > CMAX) return SAR_EINVAL;
-        if (c.x == nullptr || c.dy == nullptr || c.dw == nullptr) return SAR_EINVAL;
-        if ((long)c.B * c.H * c.W * c.Cin >= (1L << 31) || (long)tmp.g.M * c.Cout >= (1L << 31)) return SAR_EINVAL;
+        if (c.K != K || !make_geo(tmp.g, c.B, c.H, c.W, c.Cin, c.Ho, c.Wo, c.K, c.s, 1, c.pt, c.pl)) return false;
+        if (!pow2(c.Cin) || !pow2(c.Cout) || c.Cin < 32 * tile_ci || c.Cout < 32 * tile_co || c.Cin > CMAX || c.Cout > CMAX) return false;
+        if (c.x == nullptr || c.dy == nullptr || c.dw == nullptr) return false;
+        if ((long)c.B * c.H * c.W * c.Cin >= (1L << 31) || (long)tmp.g.M * c.Cout >= (1L << 31)) return false;
         tmp.Cout = c.Cout;
         tmp.x = static_cast<const u16*>(c.x); tmp.dy = static_cast<const u16*>(c.dy); tmp.dw = c.dw; tmp.dbias = c.dbias;
         tmp.nchunks = cdiv(tmp.g.M, 64);
-        tmp.cap_pos = K == 3 ? patch_rows_bound(tmp.g, 64 < tmp.g.M ? 64 : tmp.g.M) * tmp.g.Wp : 64;
-        tmp.cap_pos = (tmp.cap_pos + 15) & ~15;
-        const int ni = cdiv(4 + tmp.cap_pos / 16, K == 3 ? 9 : 1);
-        if (K == 3 && tmp.cap_pos / tmp.g.Wp > WG_ROWS) return SAR_EINVAL;
-        if (ni > (K == 3 ? WG_MAXNI : 8) || ni * (WG_NBUF - 2) > 16 || ni * (WG_NBUF - 1) > 60) return SAR_EINVAL;   // vmcnt is a 6-bit counter
-        if (tmp.cap_pos > cap_max) cap_max = tmp.cap_pos;
+        tmp.cap_pos = K == 1 ? 64 : (patch_rows_bound(tmp.g, 64 < tmp.g.M ? 64 : tmp.g.M) * tmp.g.Wp + 15) & ~15;
+        tmp.la = WG_NBUF - 1;
+        // 3x3: DMA instructions of an item's first chunk (the whole patch) dealt to nine waves: at most 4 each
+        return K == 1 || 4 * tile_co + (tmp.cap_pos / 16 + 1) * tile_ci <= 36;
+    };
+    // 3x3: the ring must hold the padded positions of la + 1 consecutive chunks (the one being multiplied and la in flight) plus
+    // the 16-position alignment at both ends.  512 positions when every convolution then gets la >= 2, otherwise the smallest
+    // power of two with la >= 1; every convolution takes the deepest la <= 3 that fits.
+    auto need = [](const Geo& g, int la) { const int px = (la + 1) * 64; return patch_rows_bound(g, px < g.M ? px : g.M) * g.Wp + 32; };
+    int np = 512, la_max = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!prep(i)) return SAR_EINVAL;
+        if (K == 3)
+            while (need(tmp.g, np <= 512 ? 2 : 1) > np) { np *= 2; if (np > 2048) return SAR_EINVAL; }
+    }
+    for (int i = 0; i < n; ++i) {
+        prep(i);
+        if (K == 3) {
+            tmp.la = 3;
+            while (tmp.la > 1 && need(tmp.g, tmp.la) > np) --tmp.la;
+            if (need(tmp.g, tmp.la) > np) return SAR_EINVAL;
+            if (tmp.la > la_max) la_max = tmp.la;
+        }
         memset(co + (size_t)i * 128, 0, 128);
         memcpy(co + (size_t)i * 128, &tmp, sizeof(tmp));
-        total += (long)tmp.nchunks * (c.Cin / 32) * (c.Cout / 32);
+        total += (long)tmp.nchunks * (convs[i].Cin / (32 * tile_ci)) * (convs[i].Cout / (32 * tile_co));
     }
     int maxc = (int)((total + target_blocks - 1) / target_blocks);
     const int minc = K == 3 ? 8 : 2 * WG_NW1;
     if (maxc < minc) maxc = minc;
     WgItem* items = static_cast<WgItem*>(items_out);
-    int ni = 0;
+    int ni = 0, tab_pos = 0;
     for (int i = 0; i < n; ++i) {
         const sarWgradConv& c = convs[i];
         const int nchunks = cdiv((long)c.B * c.Ho * c.Wo, 64);
-        const int slices = cdiv(nchunks, maxc), cpb = cdiv(nchunks, slices);
+        int slices = cdiv(nchunks, maxc), cpb = cdiv(nchunks, slices);
+        if (K == 3) {
+            // the item's position -> source-offset table (4 bytes per padded position of its run): at most WG_TAB_MAX positions
+            prep(i);
+            auto run_pos = [&](int chunks) { const long px = (long)chunks * 64; return patch_rows_bound(tmp.g, (int)(px < tmp.g.M ? px : tmp.g.M)) * tmp.g.Wp + 48; };
+            while (cpb > 1 && run_pos(cpb) > WG_TAB_MAX) { ++slices; cpb = cdiv(nchunks, slices); }
+            if (run_pos(cpb) > WG_TAB_MAX) return SAR_EINVAL;
+            if (run_pos(cpb) > tab_pos) tab_pos = run_pos(cpb);
+        }
         for (int sl = 0; sl * cpb < nchunks; ++sl)
-            for (int ci = 0; ci < c.Cin; ci += 32)
-                for (int cc = 0; cc < c.Cout; cc += 32) {
+            for (int ci = 0; ci < c.Cin; ci += 32 * tile_ci)
+                for (int cc = 0; cc < c.Cout; cc += 32 * tile_co) {
                     if (ni >= max_items) return SAR_EINVAL;
                     WgItem it;
                     memset(&it, 0, sizeof(it));
@@ -988,29 +1241,42 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, voi
         items[b + 1] = it;
     }
     *n_items = ni;
-    *lds_bytes = K == 3 ? WG_TAB_BYTES + WG_NBUF * (64 * 64 + cap_max * 64) : WG_NW1 * WG_NBUF * (64 * 64 + 64 * 64);
-    return *lds_bytes <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
+    if (K == 3) {
+        tab_pos = (tab_pos + 127) & ~127;
+        launch4[0] = 512 + tab_pos * 4 + (la_max + 1) * tile_co * 4096 + tile_ci * np * 64; launch4[1] = np; launch4[2] = la_max + 1;
+    } else {
+        launch4[0] = WG_NW1 * WG_NBUF * (64 * 64 + 64 * 64); launch4[1] = 0; launch4[2] = WG_NBUF;
+    }
+    launch4[3] = (tile_ci << 4) | tile_co;
+    return launch4[0] <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
 }
 
-// Weight gradients of many convolutions, one launch: tables and lds_bytes from sar_wgrad_plan_bf16 (uploaded by the caller),
+// Weight gradients of many convolutions, one launch: tables and launch4 from sar_wgrad_plan_bf16 (tables uploaded by the caller),
 // K = kernel size of the planned convolutions.  dw += x^T (*) dy per tap, dbias (where given) += column sums of dy.
-int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, int lds_bytes, hipStream_t stream) {
-    if (convs_dev == nullptr || items_dev == nullptr || n_items < 1 || (K != 1 && K != 3)) return SAR_EINVAL;
-    const int tab = K == 3 ? WG_TAB_BYTES : 0, nbuf = K == 3 ? WG_NBUF : WG_NW1 * WG_NBUF;
-    if (lds_bytes <= tab || lds_bytes > 160 * 1024 || (lds_bytes - tab) % nbuf) return SAR_EINVAL;
+int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, hipStream_t stream) {
+    if (convs_dev == nullptr || items_dev == nullptr || launch4 == nullptr || n_items < 1 || (K != 1 && K != 3)) return SAR_EINVAL;
+    const int lds_bytes = launch4[0], np = launch4[1], nbuf = launch4[2], tci = launch4[3] >> 4, tco = launch4[3] & 15;
+    if (lds_bytes <= 0 || lds_bytes > 160 * 1024 || tci < 1 || tci > 2 || tco < 1 || tco > 2) return SAR_EINVAL;
     static const uint4* zero_page = nullptr;
     if (zero_page == nullptr) {
         void* zp = nullptr;
         if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return SAR_ELAUNCH;
         zero_page = static_cast<const uint4*>(zp);
     }
-    const unsigned buf_bytes = (unsigned)(lds_bytes - tab) / nbuf;
-    static bool attr9 = false, attr1 = false;
     if (K == 3) {
-        if (!attr9) { if (!allow_lds(wgrad_bf16_kernel<9>, 160 * 1024)) return SAR_ELAUNCH; attr9 = true; }
-        hipLaunchKernelGGL(wgrad_bf16_kernel<9>, dim3(n_items), dim3(576), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
-                           static_cast<const WgItem*>(items_dev), zero_page, buf_bytes);
+        const int tab_bytes = lds_bytes - (512 + nbuf * tco * 4096 + tci * np * 64);
+        if (!pow2(np) || np < 512 || nbuf < 2 || nbuf > 4 || tab_bytes < 0 || tab_bytes % 512 || tab_bytes > WG_TAB_MAX * 4) return SAR_EINVAL;
+        Wg3Args a{static_cast<const unsigned char*>(convs_dev), static_cast<const WgItem*>(items_dev), zero_page, (unsigned)np, nbuf, tab_bytes / 4};
+        typedef void (*k3_t)(const Wg3Args);
+        static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2>}};
+        static bool attr3[2][2];
+        const k3_t kern = k3[tci - 1][tco - 1];
+        if (!attr3[tci - 1][tco - 1]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr3[tci - 1][tco - 1] = true; }
+        hipLaunchKernelGGL(kern, dim3(n_items), dim3(576), lds_bytes, stream, a);
     } else {
+        if (tci != 1 || tco != 1 || nbuf != WG_NBUF || lds_bytes % (WG_NW1 * WG_NBUF)) return SAR_EINVAL;
+        const unsigned buf_bytes = (unsigned)lds_bytes / (WG_NW1 * WG_NBUF);
+        static bool attr1 = false;
         if (!attr1) { if (!allow_lds(wgrad_bf16_kernel<1>, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
         hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
                            static_cast<const WgItem*>(items_dev), zero_page, buf_bytes);

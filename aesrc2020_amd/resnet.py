@@ -13,6 +13,8 @@ with the max-pool.  Backward mirrors it: dgrad -> (BN+ReLU backward reduce, appl
 Layers are auto-named conv2d_N / batch_normalization_N in construction order like Keras does for the unnamed
 reference layers (checkpoint row).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -332,6 +334,9 @@ class ResNetTrunk(Layer):
         stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
         bf = torch.bfloat16
         self._wg16 = []
+        overlap = part is None and self.WGRAD_OVERLAP
+        if overlap and getattr(self, "_wg_stream", None) is None:
+            self._wg_stream = torch.cuda.Stream()
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
             if blk["stage"] not in stages:
@@ -370,34 +375,62 @@ class ResNetTrunk(Layer):
             if getattr(self, "debug_tap", None) is not None:          # tests/test_gpu_bf16_trunk.py: per-block tensors before reuse
                 self.debug_tap(n, g, da2, gin)
             g = gin
+            # whole backward in one call: a finished stage's weight gradients start on the side stream while the next stage's
+            # input-gradient chain (short, latency-bound launches that leave most of every CU idle) runs on the main stream
+            if overlap and (n == 0 or self.blocks[n - 1]["stage"] != blk["stage"]):
+                self._wgrad16(("stage", blk["stage"]), side=True)
+                self._wg16 = []
         self._g_part = g
-        self._wgrad16(part)
+        if not overlap:
+            self._wgrad16(part)
         if part in (0, 1):
             return None
         g32 = self.scratch("res16_g32", tuple(g.shape))
         _call("sar_cast_bf16_f32", g, g32, g.numel())
         self._stem_backward(g32, B)
+        if overlap:
+            torch.cuda.current_stream().wait_stream(self._wg_stream)       # the branch joins in front of the optimiser
         return None
 
-    # launch classes of the batched weight gradient: (kernel size, stride) -> blocks the planner aims for.  Stride-2 convs have
-    # 2.5x larger patches (LDS), so they get their own launch and the stride-1 launch keeps two 9-wave blocks per CU.
-    WGRAD_CLASSES = (((3, 1), 768), ((3, 2), 512), ((1, None), 256))
+    # launch classes of the batched weight gradient: (kernel size, stride or None, 64-wide channel tiles) -> blocks the planner
+    # aims for.  3x3 stride 1 with Cin, Cout >= 64 (stages 1-3): 64 x 64 tiles, one 9-wave block per CU; the 32-channel layers:
+    # 32 x 32 tiles, three blocks per CU; stride-2 convs need a 4x larger patch ring, so they get their own launch.
+    WGRAD_CLASSES = (((3, 1, True), 640), ((3, 1, False), 768), ((3, 2, False), 512), ((1, None, False), 256))
 
-    def _wgrad16(self, part):
-        """The weight gradients of every conv of this backward part: one launch per class, tables planned once per (B, T)."""
+    @staticmethod
+    def _wgrad_class(d):
+        if d["K"] == 1:
+            return (1, None, False)
+        return (3, d["s"], d["s"] == 1 and d["Cin"] >= 64 and d["Cout"] >= 64)
+
+    # SAR_WGRAD_OVERLAP=1: per-stage weight-gradient launches on a second stream underneath the next stage's input-gradient
+    # chain.  Measured slower (cfg2: 3.14 vs 2.90 ms per step): the batched launch is bound by the memory system and takes it
+    # away from the chain's fills; default = one batch at the end of the backward call, on the main stream.
+    WGRAD_OVERLAP = os.environ.get("SAR_WGRAD_OVERLAP", "0") == "1"
+
+    def _wgrad16(self, part, side=False):
+        """The weight gradients of every conv collected in self._wg16 (a backward part, or one stage): one launch per class,
+        tables planned once per (B, T).  side: on the trunk's second stream, forked from the main stream here (inside a HIP-graph
+        capture this becomes a parallel branch); _backward16 joins it."""
         plans = getattr(self, "_wgplans", None)
         if plans is None:
             plans = self._wgplans = {}
         key = (part, self.B, self.in_hw, tuple((d["x"].data_ptr(), d["dy"].data_ptr()) for d in self._wg16))
         if key not in plans:
             ps = []
-            for (k, s), target in self.WGRAD_CLASSES:
-                ds = [d for d in self._wg16 if d["K"] == k and (s is None or d["s"] == s)]
+            for cls, target in self.WGRAD_CLASSES:
+                ds = [d for d in self._wg16 if self._wgrad_class(d) == cls]
                 if ds:
-                    ps.append(_lib.WgradPlan(ds, target))
+                    ps.append(_lib.WgradPlan(ds, target, (2, 2) if cls[2] else (1, 1)))
             plans[key] = ps
-        for p in plans[key]:
-            p.launch()
+        if side:
+            self._wg_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._wg_stream):
+                for p in plans[key]:
+                    p.launch()
+        else:
+            for p in plans[key]:
+                p.launch()
 
     def _stem_forward(self, x, B):
         T, D = self.in_hw

@@ -87,11 +87,12 @@ def conv_roofline(model, B, iters=10):
             add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad(y, dx, B)), flops, act_b)
     if bf16:
         # weight gradients: one launch per class over all convs of the trunk (ResNetTrunk._wgrad16)
-        for (k, s_), target in tr.WGRAD_CLASSES:
-            sel = [w_ for w_ in wg if w_[0]["K"] == k and (s_ is None or w_[0]["s"] == s_)]
+        for cls, target in tr.WGRAD_CLASSES:
+            sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
-                plan = _lib.WgradPlan([w_[0] for w_ in sel], target)
-                c = classes.setdefault("conv_wgrad_%dx%d_%s_batched" % (k, k, "s%d" % s_ if s_ else "all"), dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
+                plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1))
+                nm = "conv_wgrad_%dx%d_%s%s_batched" % (cls[0], cls[0], "s%d" % cls[1] if cls[1] else "all", "_t64" if cls[2] else "")
+                c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["bytes"] += sum(w_[2] for w_ in sel); c["launches"] += 1
     total = sum(c["time"] for c in classes.values())
     name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])

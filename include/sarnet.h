@@ -158,18 +158,19 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const fl
  *   dw[K][K][Cin][Cout] += x^T (*) dy per tap;  dbias (nullable) += column sums of dy.
  * They are off the critical path of the backward pass, so the trunk collects them and runs them once per backward part.
  * (1) sar_wgrad_plan_bf16 -- host only, no device access -- turns n descriptors of equal K (1 or 3) into the two device tables of
- * one launch: convs_out (n rows of 128 bytes) and items_out (<= max_items rows of 32 bytes: one block each = one convolution, 32
- * input x 32 output channels, a run of 64-pixel chunks; longest first; runs are cut so that the launch has about target_blocks
- * items), and returns the item count and the launch's dynamic LDS bytes (largest patch among the convolutions: plan stride-2
- * and stride-1 convolutions separately to keep the stride-1 launch at two blocks per CU).  (2) The caller uploads both tables
- * once; sar_conv2d_wgrad_batch_bf16 launches them. */
+ * one launch: convs_out (n rows of 128 bytes) and items_out (<= max_items rows of 32 bytes: one block each = one convolution, a
+ * tile of 32*tile_ci input x 32*tile_co output channels, a run of 64-pixel chunks; longest first; runs are cut so that the launch
+ * has about target_blocks items), the item count, and launch4 = {dynamic LDS bytes, positions of the patch ring, chunk buffers,
+ * tile_ci << 4 | tile_co}.  tile_ci, tile_co in {1, 2} (3x3; 1x1: both 1): 64-wide tiles halve the bytes per MFMA where the
+ * layer has 64+ channels.  Plan stride-2 convolutions (4x larger patch ring) and the tile classes separately.
+ * (2) The caller uploads both tables once; sar_conv2d_wgrad_batch_bf16 launches them. */
 typedef struct sarWgradConv {
     const void* x; const void* dy; float* dw; float* dbias;
     int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl, pad_;    /* geometry as the forward conv (s = stride, pt/pl = TF pads) */
 } sarWgradConv;
-int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, void* convs_out, void* items_out, int max_items,
-                        int* n_items, int* lds_bytes);
-int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, int lds_bytes, sarStream_t stream);
+int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int tile_ci, int tile_co, void* convs_out,
+                        void* items_out, int max_items, int* n_items, int* launch4);
+int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
 int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
                           int C, int relu, sarStream_t stream);

@@ -98,10 +98,10 @@ class Conv:
         ho, wo, pt, pl = self.geo(H, W)
         return dict(x=x, dy=dy, dw=dw, dbias=db, B=B, H=H, W=W, Cin=self.cin, Ho=ho, Wo=wo, Cout=self.cout, K=self.k, s=self.s, pt=pt, pl=pl)
 
-    def wgrad(self, x, dy, bias=True, target_blocks=768):
+    def wgrad(self, x, dy, bias=True, target_blocks=768, tile=(1, 1)):
         """One-convolution plan, added to a non-zero gradient buffer (the kernel accumulates)."""
         dw = torch.ones(self.k, self.k, self.cin, self.cout, device="cuda"); db = torch.zeros(self.cout, device="cuda")
-        plan = self.L.WgradPlan([self.desc(x, dy, dw, db if bias else None)], target_blocks)
+        plan = self.L.WgradPlan([self.desc(x, dy, dw, db if bias else None)], target_blocks, tile)
         plan.launch()
         self.last_plan = plan
         return dw - 1.0, db
@@ -314,7 +314,14 @@ def test_conv_wgrad(L, shape):
     check(dw2, dw_ref, TOL_F32, "dw (no bias gradient, single slice)")
     assert float(db2.abs().max()) == 0.0
     items = np.frombuffer(cv.last_plan.items.cpu().numpy().tobytes(), np.int32).reshape(-1, 8)
-    assert items[:, 5].all() and len(items) == (Cin // 32) * (Cout // 32)
+    # (3x3: a run is also bounded by the item's source-offset table, so the largest shapes still get several slices)
+    assert bool(items[:, 5].all()) == (len(items) == (Cin // 32) * (Cout // 32)) and (k == 3 or items[:, 5].all())
+    if k == 3 and s == 1:                                                         # the wider channel tiles (stride-1 convs of the trunk)
+        for tile in ((2, 2), (1, 2), (2, 1)):
+            if Cin >= 32 * tile[0] and Cout >= 32 * tile[1]:
+                dwt, dbt = cv.wgrad(dbf(x), dbf(dy), tile=tile, target_blocks=300)
+                check(dwt, dw_ref, TOL_F32, "dw, tile %dx%d" % tile); check(dbt, db_ref, TOL_F32, "db, tile %dx%d" % tile)
+                assert cv.last_plan.np in (512, 1024) and 2 <= cv.last_plan.nbuf <= 4
     dw3, db3 = cv.wgrad(dbf(x), dbf(dy), target_blocks=100000)                   # shortest runs: the atomic flush
     check(dw3, dw_ref, TOL_F32, "dw (shortest runs)"); check(db3, db_ref, TOL_F32, "db (shortest runs)")
     items = np.frombuffer(cv.last_plan.items.cpu().numpy().tobytes(), np.int32).reshape(-1, 8)
@@ -325,9 +332,10 @@ def test_conv_wgrad(L, shape):
 def test_conv_wgrad_many_convolutions_in_one_launch(L):
     """The train step's form: the 3x3 stride-1 convs of several stages in one plan, the 1x1 convs in another."""
     rng = np.random.default_rng(99)
-    for k, shapes in ((3, [(4, 25, 20, 32, 32, 1), (4, 13, 10, 64, 64, 1), (4, 7, 5, 128, 128, 1), (4, 4, 3, 256, 256, 1), (4, 25, 20, 64, 32, 1)]),
-                      (3, [(3, 25, 20, 32, 64, 2), (3, 13, 10, 64, 128, 2)]),
-                      (1, [(4, 25, 20, 64, 32, 1), (4, 25, 20, 32, 64, 2), (4, 7, 5, 128, 256, 2)])):
+    for k, tile, shapes in ((3, (1, 1), [(4, 25, 20, 32, 32, 1), (4, 13, 10, 64, 64, 1), (4, 7, 5, 128, 128, 1), (4, 4, 3, 256, 256, 1), (4, 25, 20, 64, 32, 1)]),
+                            (3, (2, 2), [(4, 13, 10, 64, 64, 1), (4, 7, 5, 128, 128, 1), (4, 4, 3, 256, 256, 1), (5, 13, 3, 256, 256, 1)]),
+                            (3, (1, 1), [(3, 25, 20, 32, 64, 2), (3, 13, 10, 64, 128, 2)]),
+                            (1, (1, 1), [(4, 25, 20, 64, 32, 1), (4, 25, 20, 32, 64, 2), (4, 7, 5, 128, 256, 2)])):
         descs, refs, outs = [], [], []
         for (B, H, W, Cin, Cout, s) in shapes:
             pad = "same" if k == 3 else "valid"
@@ -338,7 +346,7 @@ def test_conv_wgrad_many_convolutions_in_one_launch(L):
             _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
             dw = torch.zeros(k, k, Cin, Cout, device="cuda"); db = torch.zeros(Cout, device="cuda")
             descs.append(cv.desc(dbf(x), dbf(dy), dw, db)); refs.append((dw_ref, db_ref)); outs.append((dw, db))
-        plan = L.WgradPlan(descs, 64)
+        plan = L.WgradPlan(descs, 64, tile)
         plan.launch()
         for i, ((dw, db), (dw_ref, db_ref)) in enumerate(zip(outs, refs)):
             check(dw, dw_ref, TOL_F32, "dw of conv %d (k=%d)" % (i, k)); check(db, db_ref, TOL_F32, "db of conv %d (k=%d)" % (i, k))

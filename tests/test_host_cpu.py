@@ -40,8 +40,24 @@ def test_wgrad_plan_covers_every_tile_and_chunk_once():
     shapes = [(100, 20, 32, 32)] * 6 + [(100, 20, 64, 32)] + [(50, 10, 64, 64)] * 7 + [(25, 5, 128, 128)] * 11 + [(13, 3, 256, 256)] * 5
     descs = [dict(x=0x1000, dy=0x2000, dw=0x3000 + i, dbias=None, B=B, H=h, W=w, Cin=ci, Ho=h, Wo=w, Cout=co, K=3, s=1, pt=1, pl=1)
              for i, (h, w, ci, co) in enumerate(shapes)]
-    convs, items, n, lds = _lib.WgradPlan.plan_host(descs, 768)
-    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 600 <= n <= 1100 and lds <= 80 * 1024
+    convs, items, n, l4 = _lib.WgradPlan.plan_host(descs, 768)
+    # 32 x 32 tiles: 512-position ring, three chunks in flight -> 512 B + 4 x 4 KB + 32 KB + the items' source-offset table
+    # (4 bytes per padded position of the longest run, <= 24 KB): three blocks per CU
+    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 600 <= n <= 1400 and l4[1:] == [512, 4, 0x11]
+    tab = l4[0] - (512 + 4 * 4096 + 512 * 64)
+    assert 0 < tab <= 24576 and tab % 512 == 0 and l4[0] <= 160 * 1024 // 3
+    wide = [d for d in descs if d["Cin"] >= 64 and d["Cout"] >= 64]
+    _, items64, n64, l64 = _lib.WgradPlan.plan_host(wide, 640, (2, 2))
+    tab64 = l64[0] - (512 + 4 * 2 * 4096 + 2 * 512 * 64)
+    assert l64[1:] == [512, 4, 0x22] and 400 <= n64 <= 900 and 0 < tab64 <= 24576 and tab64 % 512 == 0
+    _, items1, n1, _ = _lib.WgradPlan.plan_host(wide, 1, (2, 2))       # asks for one item per tile: runs still fit the offset table
+    it1 = np.frombuffer(items1, np.int32).reshape(n1, 8)
+    assert it1[:, 4].max() * 64 <= 64 * 500
+    it64 = np.frombuffer(items64, np.int32).reshape(n64, 8)
+    assert (it64[:, 1] % 64 == 0).all() and (it64[:, 2] % 64 == 0).all()
+    # stride-2 convolutions: a 1024-position ring
+    s2 = [dict(x=1, dy=2, dw=3, dbias=None, B=B, H=100, W=20, Cin=32, Ho=50, Wo=10, Cout=64, K=3, s=2, pt=0, pl=0)]
+    assert _lib.WgradPlan.plan_host(s2, 512)[3][1] == 1024
     it = np.frombuffer(items, np.int32).reshape(n, 8)
     assert (np.diff(it[:, 4]) <= 0).all()
     for i, (h, w, ci, co) in enumerate(shapes):
@@ -79,11 +95,11 @@ def test_hand_counted_vmcnt_kernels_use_no_scratch():
     seen = 0
     for blk in md.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        if "conv_bf16_kernel" in name or "wgrad_bf16_kernel" in name:
+        if "conv_bf16_kernel" in name or "wgrad_bf16_kernel" in name or "wgrad3_bf16_kernel" in name:
             seen += 1
             assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
             assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
-    assert seen >= 22
+    assert seen >= 25
 
 
 def test_data_loader_batch_contract(monkeypatch):

@@ -36,7 +36,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
     lib.sar_conv_pack_weights_bf16(tab.data_ptr(), 1, -(-(nf + nd) // 8 // 256), st)
     bins = torch.zeros(16, 2, Cout, device="cuda")
     if mode == "wgrad":
-        raise SystemExit("the weight gradient is a batched launch now: time it with bench.py's roofline classes / rocprofv3")
+        continue
     else:
         wp = wf if mode == "fwd" else wd
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
@@ -64,3 +64,41 @@ for name, H, W, Cin, Cout, k in SHAPES:
     for k_, (a, b) in names.items():
         v = t[:, b] - t[:, a]
         print("   %-12s cycles: p10 %7d  p50 %7d  p90 %7d  max %7d" % (k_, np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
+
+if mode == "wgrad":
+    # the batched 3x3 weight gradient as the train step launches it: all stride-1 convs of stages 1-3 (64 x 64 tiles) in one plan
+    class WC(ctypes.Structure):
+        _fields_ = [(n, vp) for n in ("x", "dy", "dw", "dbias")] + [(n, ci) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl", "pad_")]
+    lib.sar_wgrad_plan_bf16.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp]
+    lib.sar_conv2d_wgrad_batch_bf16.argtypes = [vp, vp, ci, ci, vp, vp]
+    for label, tile, target, layers in (("stages 1-3, 64x64 tiles", (2, 2), 640, [(50, 10, 64, 7), (25, 5, 128, 11), (13, 3, 256, 5)]),
+                                        ("stage 0, 32x32 tiles", (1, 1), 768, [(100, 20, 32, 6)])):
+        keep, descs = [], []
+        for H, W, C, cnt in layers:
+            for _ in range(cnt):
+                x = torch.randn(B, H, W, C, device="cuda").to(BF); dy = torch.randn(B, H, W, C, device="cuda").to(BF)
+                dw = torch.zeros(3, 3, C, C, device="cuda"); keep += [x, dy, dw]
+                descs.append((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, B, H, W, C, H, W, C, 3, 1, 1, 1, 0))
+        arr = (WC * len(descs))(*[WC(*d) for d in descs])
+        cbuf = ctypes.create_string_buffer(len(descs) * 128); ibuf = ctypes.create_string_buffer(16384 * 32)
+        ni, l4 = ctypes.c_int(0), (ctypes.c_int * 4)()
+        assert lib.sar_wgrad_plan_bf16(arr, len(descs), target, tile[0], tile[1], cbuf, ibuf, 16384, ctypes.byref(ni), l4) == 0
+        cd = torch.frombuffer(bytearray(cbuf.raw), dtype=torch.uint8).cuda(); idv = torch.frombuffer(bytearray(ibuf.raw[:ni.value * 32]), dtype=torch.uint8).cuda()
+        fn = lambda: lib.sar_conv2d_wgrad_batch_bf16(cd.data_ptr(), idv.data_ptr(), ni.value, 3, l4, st)
+        tb = torch.zeros(1 << 14, 16, dtype=torch.int64, device="cuda")
+        for it in range(3):
+            lib.sar_dbg_set_timing_buffer16(None); torch.cuda.synchronize(); fn()
+        torch.cuda.synchronize()
+        lib.sar_dbg_set_timing_buffer16(tb.data_ptr()); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rc = fn(); e1.record(); torch.cuda.synchronize()
+        assert rc == 0, rc
+        t = tb.cpu().numpy().astype(np.int64)[:ni.value]
+        rt0 = t[:, 0].min()
+        s_us = (t[:, 0] - rt0) / 100.0; e_us = (t[:, 15] - rt0) / 100.0
+        print("== wgrad batched, %s: items=%d launch4=%s event %.1f us; starts p50 %.1f p90 %.1f max %.1f; ends p50 %.1f max %.1f us"
+              % (label, ni.value, list(l4), e0.elapsed_time(e1) * 1e3, np.percentile(s_us, 50), np.percentile(s_us, 90), s_us.max(), np.percentile(e_us, 50), e_us.max()))
+        nch = np.maximum(t[:, 10], 1)
+        for nm, v in (("setup (first DMA issued)", t[:, 2] - t[:, 1]), ("loop", t[:, 3] - t[:, 2]), ("flush", t[:, 4] - t[:, 3]),
+                      ("loop / chunk", (t[:, 3] - t[:, 2]) / nch), ("wait+barrier / chunk", t[:, 8] / nch), ("issue / chunk", t[:, 9] / nch), ("chunks per item", t[:, 10])):
+            print("   %-26s cycles: p10 %8d  p50 %8d  p90 %8d  max %8d" % (nm, np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90), v.max()))
