@@ -89,6 +89,20 @@ def get_conv_math():
     return {v: k for k, v in CONV_MATH.items()}[lib().fn["sar_get_conv_math"]()]
 
 
+GEMM_MATH = {"fp32": 0, "bf16": 1}
+
+
+def set_gemm_math(mode):
+    """'fp32' (default) or 'bf16' (operands rounded to bf16 in the staging, bf16 MFMA, fp32 accumulate) for the Dense / GRU
+    projection GEMMs whose dimensions are multiples of 64; host-side, process-wide."""
+    if lib().fn["sar_set_gemm_math"](GEMM_MATH[mode]) != 0:
+        raise RuntimeError("sar_set_gemm_math failed")
+
+
+def get_gemm_math():
+    return {v: k for k, v in GEMM_MATH.items()}[lib().fn["sar_get_gemm_math"]()]
+
+
 # ---- activation storage of the conv trunk: "fp32" (round-1 kernels, conv math per set_conv_math) or "bf16" (conv_bf16.hip:
 # 2-byte activations / activation gradients, single-pass bf16 MFMA, fp32 statistics and weights).  Read when a model is built.
 _TRUNK_DTYPE = [os.environ.get("SAR_TRUNK_DTYPE", "fp32")]

@@ -6,6 +6,8 @@
 // Tile 64x64x16, 4 waves (2x2), one 32x32 accumulator per wave. LDS tiles are k-major
 // ([k][m] / [k][n]) so the MFMA operand reads (lane&31 -> m/n, lane>>5 -> k) are conflict-free.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -167,7 +169,137 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
+
+// ---- bf16 MFMA path (sar_set_gemm_math(1); the "bf16" bench mode) ----------------------------------------------------------------
+// Same contract as gemm_f32_kernel for problems whose M, N are multiples of 64 and K of 64, with 16-byte aligned rows: the fp32
+// operands are rounded to bf16 while they are staged into LDS (one v_cvt_pk_bf16_f32 per two elements, RNE) and multiplied on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 1/16 of the fp32-MFMA issue time; bias, activation, accumulate, split-K
+// and the fused column sum stay fp32.  Tile 64 x 64 x 64, four waves (2 x 2), two LDS buffers, one barrier per k-tile.
+// A k-contiguous operand is staged [mn][k] (144-byte rows) and fetched with ds_read_b128; an operand stored (K, MN) is staged
+// as it lies, [k][mn], and fetched through ds_read_b64_tr_b16 (hardware transpose) -- no element-wise scatter for any layout.
+typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 gbf16x2;
+typedef __attribute__((ext_vector_type(4))) short gs16x4;
+constexpr int GB_K = 64, GB_RS = 144;          // k-tile; LDS row stride in bytes (64 bf16 + 16: conflict-free b128 column reads)
+
+__device__ __forceinline__ unsigned gpack2(float a, float b) {
+    gbf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(base + off));
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk,
+                                                        float* __restrict__ colsum) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][64 * GB_RS];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][64 * GB_RS];
+    __shared__ float csum[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nkt = K / GB_K, per = (nkt + splitk - 1) / splitk;
+    const int kt0 = blockIdx.z * per, kt1 = min(nkt, kt0 + per);
+    // staging: thread -> (row = tid / 4 of the tile as stored, 16 consecutive elements (tid % 4) * 16 of that row)
+    const int srow = tid >> 2, sseg = (tid & 3) * 16;
+    float4 ra[2][4], rb[2][4];
+    auto gload = [&](int set, int kt) __attribute__((always_inline)) {
+        const int k0 = min(kt, kt1 - 1) * GB_K;
+        const float* pa = A_KC ? A + (long)(m0 + srow) * lda + k0 + sseg : A + (long)(k0 + srow) * lda + m0 + sseg;
+        const float* pb = B_KC ? B + (long)(n0 + srow) * ldb + k0 + sseg : B + (long)(k0 + srow) * ldb + n0 + sseg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[set][i] = *reinterpret_cast<const float4*>(pa + 4 * i); rb[set][i] = *reinterpret_cast<const float4*>(pb + 4 * i); }
+    };
+    const bool do_colsum = !B_KC && colsum != nullptr && blockIdx.y == 0;
+    float cs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cs[i] = 0.f;
+    auto gstore = [&](int set, int buf, int kt) __attribute__((always_inline)) {
+        const float live = kt < kt1 ? 1.f : 0.f;
+        unsigned wa[8], wb[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 a = ra[set][i], b = rb[set][i];
+            wa[2 * i] = gpack2(a.x * live, a.y * live); wa[2 * i + 1] = gpack2(a.z * live, a.w * live);
+            wb[2 * i] = gpack2(b.x * live, b.y * live); wb[2 * i + 1] = gpack2(b.z * live, b.w * live);
+            if (do_colsum) { cs[4 * i] += b.x * live; cs[4 * i + 1] += b.y * live; cs[4 * i + 2] += b.z * live; cs[4 * i + 3] += b.w * live; }
+        }
+        unsigned char* da = As[buf] + srow * GB_RS + sseg * 2;
+        unsigned char* db = Bs[buf] + srow * GB_RS + sseg * 2;
+        *reinterpret_cast<uint4*>(da) = make_uint4(wa[0], wa[1], wa[2], wa[3]); *reinterpret_cast<uint4*>(da + 16) = make_uint4(wa[4], wa[5], wa[6], wa[7]);
+        *reinterpret_cast<uint4*>(db) = make_uint4(wb[0], wb[1], wb[2], wb[3]); *reinterpret_cast<uint4*>(db + 16) = make_uint4(wb[4], wb[5], wb[6], wb[7]);
+    };
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    // fragment addressing: [mn][k] rows -> lane reads 8 consecutive k of its row; [k][mn] rows -> two transpose-reads (rows
+    // pr, pr + 4 of a 16-row group; the same lane map as the conv weight-gradient kernel)
+    const int gi = lane & 15, gg = lane >> 4, cb = gg & 1, kh = gg >> 1;
+    const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2, prb = 8 * kh + (gi >> 2);
+    auto frag = [&](const unsigned char* T, bool kc, int w32, int ks) __attribute__((always_inline)) -> gbf16x8 {
+        if (kc) return *reinterpret_cast<const gbf16x8*>(T + (w32 * 32 + (lane & 31)) * GB_RS + (ks * 16 + 8 * (lane >> 5)) * 2);
+        const unsigned p0 = 16 * ks + prb;
+        const gs16x4 lo = g_lds_tr(T, p0 * GB_RS + w32 * 64 + colb), hi = g_lds_tr(T, (p0 + 4) * GB_RS + w32 * 64 + colb);
+        return __builtin_bit_cast(gbf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto gmma = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const gbf16x8 a = frag(As[buf], A_KC, wm, ks), b = frag(Bs[buf], B_KC, wn, ks);
+            if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        }
+    };
+    if (kt0 < kt1) {
+        gload(0, kt0); gload(1, kt0 + 1);
+        gstore(0, 0, kt0); gload(0, kt0 + 2);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            gmma(0); gstore(1, 1, kt + 1); gload(1, kt + 3);
+            __syncthreads();
+            gmma(1); gstore(0, 0, kt + 2); gload(0, kt + 4);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    if (do_colsum) {                                  // threads with equal tid % 4 hold the same 16 columns
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = cs[i];
+            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (lane < 4) csum[wave][lane * 16 + i] = v;
+        }
+        __syncthreads();
+        if (tid < 64) atomicAdd(colsum + n0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float v = acc[r] + bv;
+        float* dst = C + (long)row * ldc + col;
+        if (splitk > 1) {
+            atomicAdd(dst, v);
+        } else {
+            if (act == ACT_TANH) v = tanhf(v);
+            else if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            if (accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
 }  // namespace
+
+// GEMM arithmetic: 0 = fp32 MFMA (default), 1 = bf16 MFMA with fp32 accumulate for 64-aligned problems (the "bf16" mode of
+// BASELINE configs[1]; SAR_GEMM_MATH=bf16).  Host-side, process-wide.
+static int g_gemm_math = (getenv("SAR_GEMM_MATH") && !strcmp(getenv("SAR_GEMM_MATH"), "bf16")) ? 1 : 0;
+extern "C" int sar_set_gemm_math(int mode) { if (mode < 0 || mode > 1) return SAR_EINVAL; g_gemm_math = mode; return SAR_OK; }
+extern "C" int sar_get_gemm_math(void) { return g_gemm_math; }
 
 // C-ABI: see include/sarnet.h
 static int gemm_launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
@@ -175,6 +307,20 @@ static int gemm_launch(const float* A, const float* B, float* C, const float* bi
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splitk < 1) return SAR_EINVAL;
     if (splitk > 1 && act != ACT_NONE) return SAR_EINVAL;  // split-K accumulates atomically: C must be pre-zeroed (or hold the addend)
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk), block(256);
+    // bf16 MFMA path: whole 64 x 64 x 64 tiles, 16-byte aligned rows (every Dense / GRU-projection GEMM of the model)
+    if (g_gemm_math == 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && K / 64 >= splitk) {
+#define LAUNCH16(AK, BK_)                                                                                            \
+    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, \
+                       act, accumulate, splitk, colsum)
+        if (a_kc && b_kc) LAUNCH16(true, true);
+        else if (a_kc && !b_kc) LAUNCH16(true, false);
+        else if (!a_kc && b_kc) LAUNCH16(false, true);
+        else LAUNCH16(false, false);
+#undef LAUNCH16
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
 #define LAUNCH(AK, BK_)                                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, block, 0, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, \
                        act, accumulate, splitk, colsum)

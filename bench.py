@@ -220,10 +220,11 @@ def run_workload(name, args, rank, world, with_extras):
 
 
 DTYPES = {
-    # --dtype: (trunk storage, conv math, what the JSON line says)
-    "bf16": ("bf16", "bf16x3", "bf16 activations / activation gradients in HBM, single-pass bf16 MFMA, fp32 accumulate, statistics and master weights"),
-    "bf16x3": ("fp32", "bf16x3", "fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),
-    "f32": ("fp32", "fp32", "fp32 in HBM, fp32 MFMA"),
+    # --dtype: (trunk storage, conv math, Dense / GRU-projection GEMM math, what the JSON line says)
+    "bf16": ("bf16", "bf16x3", "bf16", "bf16 activations / activation gradients of the conv trunk in HBM, single-pass bf16 MFMA (convs and the "
+                                       "Dense / GRU-projection GEMMs), fp32 accumulate, statistics, recurrence, losses and master weights"),
+    "bf16x3": ("fp32", "bf16x3", "fp32", "fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),
+    "f32": ("fp32", "fp32", "fp32", "fp32 in HBM, fp32 MFMA"),
 }
 
 
@@ -250,8 +251,8 @@ def main():
     torch.cuda.set_device(local)
     from aesrc2020_amd import _lib
     import torch.distributed as dist
-    trunk, math, dtype_desc = DTYPES[args.dtype]
-    _lib.set_trunk_dtype(trunk); _lib.set_conv_math(math)
+    trunk, math, gemm_math, dtype_desc = DTYPES[args.dtype]
+    _lib.set_trunk_dtype(trunk); _lib.set_conv_math(math); _lib.set_gemm_math(gemm_math)
 
     r, model = run_workload(args.workload, args, rank, world, True)
     if rank == 0:

@@ -87,6 +87,11 @@ int sar_dbg_last_wgrad_launch(int* out4);
  * Process-wide host-side setting read at launch time (also: env SAR_CONV_MATH=fp32). */
 int sar_set_conv_math(int mode);
 int sar_get_conv_math(void);
+/* GEMM arithmetic of sar_gemm_f32 / sar_gemm_wgrad_f32: 0 = fp32 MFMA (default), 1 = operands rounded to bf16 while they are
+ * staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate (problems whose M, N, K are multiples of 64; others keep fp32).  The
+ * "bf16" mode of BASELINE configs[1]; fp32 tensors at the ABI either way.  Host-side, process-wide (env SAR_GEMM_MATH=bf16). */
+int sar_set_gemm_math(int mode);
+int sar_get_gemm_math(void);
 /* 7x7/2 stem on the 1-channel fbank image: resnet.py:173 / 191.  C0 <= 64, C0 % 4 == 0. */
 int sar_stem_conv7x7_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int Ho,
                              int Wo, int C0, int pad_top, int pad_left, sarStream_t stream);

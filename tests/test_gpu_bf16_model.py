@@ -67,8 +67,13 @@ def test_bf16_trunk_forward_backward_against_oracle(case):
     cfg, ref, model, _, batch = build(CASES[case], "bf16")
     assert model.trunk.bf16
     out, total, parts, G = ref.forward_backward(batch)
-    model.forward_backward_only(batch, batch)
-    torch.cuda.synchronize()
+    from aesrc2020_amd import _lib
+    _lib.set_gemm_math("bf16")                          # the whole "bf16" bench mode: bf16 trunk + bf16-MFMA Dense / GRU projections
+    try:
+        model.forward_backward_only(batch, batch)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_gemm_math("fp32")
     dev = {}
     for k in ("y_accent", "y_disc"):
         if k in out and k in model.out:
@@ -106,7 +111,13 @@ def test_bf16_trunk_train_steps_graph_replay_and_inference():
     batches = [batch, MT.synthetic_batch(cfg, kw["B"], seed=78), MT.synthetic_batch(cfg, kw["B"], seed=79)]
     l16, l32 = [], []
     for i, b in enumerate(batches):
-        l16.append(t16.train_on_batch(b, b)["loss"]); l32.append(t32.train_on_batch(b, b)["loss"])
+        from aesrc2020_amd import _lib
+        _lib.set_gemm_math("bf16")
+        try:
+            l16.append(t16.train_on_batch(b, b)["loss"])
+        finally:
+            _lib.set_gemm_math("fp32")
+        l32.append(t32.train_on_batch(b, b)["loss"])
         if i == 0:
             # same weights went into step 0: BatchNorm moving statistics differ by bf16 noise only (later steps diverge: Adam's
             # first updates are +-lr per element whatever the gradient magnitude)

@@ -70,6 +70,35 @@ def test_gemm_wgrad_with_fused_bias_gradient(L, R, I, N, sk):
     check(dW2, dW0 + X.T @ dY, name="dW without bias")
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K,sk", [(64, 64, 64, 1), (2496, 768, 256, 1), (256, 768, 2496, 3), (128, 192, 8192, 1)])
+def test_gemm_bf16_math(L, a_kc, b_kc, M, N, K, sk):
+    """sar_set_gemm_math(1): operands rounded to bf16 in the staging, bf16 MFMA, fp32 accumulate -- against float64 on the
+    rounded operands (tight) for all four layouts, bias + tanh, accumulate, split-K and the fused column sum."""
+    rng = np.random.default_rng(M + N + K + 2 * a_kc + b_kc)
+    bf = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((K, N)) / np.sqrt(K); bias = rng.standard_normal(N)
+    Ad = dev(A if a_kc else A.T.copy()); Bd = dev(B.T.copy() if b_kc else B)
+    lda = K if a_kc else M; ldb = K if b_kc else N
+    ref = bf(A) @ bf(B)
+    old = L.get_gemm_math()
+    L.set_gemm_math("bf16")
+    try:
+        C = zeros(M, N)
+        L.call("sar_gemm_f32", Ad, Bd, C, dev(bias), M, N, K, lda, ldb, N, a_kc, b_kc, 1, 0, 1)
+        check(C, np.tanh(ref + bias), 2e-5, "bf16 gemm + bias + tanh")
+        C0 = rng.standard_normal((M, N)); C = dev(C0)
+        L.call("sar_gemm_f32", Ad, Bd, C, None, M, N, K, lda, ldb, N, a_kc, b_kc, 0, 1, sk)
+        check(C, C0 + ref, 2e-5, "bf16 gemm accumulate (split-K %d)" % sk)
+        if not a_kc and not b_kc:                              # the Dense weight-gradient form with its fused bias gradient
+            dW = zeros(M, N); db = zeros(N)
+            L.call("sar_gemm_wgrad_f32", Ad, Bd, dW, db, M, N, K, M, N, N, sk)
+            check(dW, ref, 2e-5, "bf16 wgrad gemm"); check(db, B.sum(0), 2e-5, "fused column sum (fp32 values)")
+    finally:
+        L.set_gemm_math(old)
+    assert L.get_gemm_math() == old
+
+
 def test_gemm_transpose_detecting(L):
     # asymmetric B with A = I catches a swapped C write (guide rule 16)
     n = 64
