@@ -1,0 +1,298 @@
+// Bidirectional reset-after GRU recurrence (Keras CuDNNGRU semantics, model.py:44-50) on the gfx950 matrix cores --
+// the form the "bf16" mode runs at hidden_dim = 256 (gru.hip keeps the exact-fp32 kernels for every other case).
+//
+// gru.hip's recurrence is bound by streaming the 786 KB recurrent kernel U from L2 into every CU every step (5 us per step,
+// 64 workgroups of 2 batch rows).  Here U is rounded to bf16 ONCE per optimiser step and packed as MFMA A-fragments
+// (sar_bigru_pack_bf16); a workgroup owns 16 batch rows of one direction and keeps all of U on chip for all L steps -- 32 of a
+// wave's 48 fragments in registers, 16 in LDS -- so a step is: read the 8 B-fragments of h (bf16, LDS), 48
+// v_mfma_f32_16x16x32_bf16 per wave, the gate math in the accumulator layout (the wave that multiplies the z, r and h columns of
+// a unit also owns that unit: no LDS transit of the pre-activations), the new h back to LDS as bf16, ONE barrier.
+//   z = sig(xa_z + hU_z + b_hz); r = sig(xa_r + hU_r + b_hr); q = hU_h + b_hh; hh = tanh(xa_h + r*q); h' = z*h + (1-z)*hh
+// The state h, the gates, every saved tensor and the accumulation stay fp32; only the two MFMA operands (U, and h / the
+// pre-activation gradients in BPTT) are bf16.  BPTT mirrors it: dh_prev += dah(16 x 768) * U^T with U packed by unit rows.
+// Lane map (both kernels): wave w owns units [32w, 32w+32) = two 16-unit tiles u; in a 16x16 accumulator tile lane l holds batch
+// row n = l & 15 and units 32w + 16u + 4*(l >> 4) + reg, reg = 0..3 (MI355X C/D layout: col = lane & 15, row = 4*(lane >> 4) + reg).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+constexpr int GH = 256, GH3 = 768;      // hidden units, gate columns
+constexpr int GNR = 16;                 // batch rows per workgroup (the N of the 16x16x32 MFMA)
+constexpr int GNW = 8;                  // waves per workgroup
+constexpr int GFR = 48;                 // A-fragments per wave (6 tiles x 8 k-steps forward; 2 tiles x 24 k-steps backward)
+constexpr int GREG = 32;                // ... of which in registers; the rest in LDS
+constexpr int HS_STRIDE = GH * 2 + 16;  // bytes per row of the bf16 h image (16-byte pad: the 16 rows start in different banks)
+constexpr int AS_STRIDE = GH3 * 2 + 16; // bytes per row of the bf16 pre-activation-gradient image
+
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
+// sigmoid / tanh on v_exp_f32 + v_rcp_f32 (~1e-7 relative): a lane owns 8 (row, unit) pairs per step here, and libm's expf / tanhf
+// (about 100 instructions per pair) were the longest phase of a step
+__device__ __forceinline__ float fsig(float a) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * a)); }
+__device__ __forceinline__ float ftanh(float a) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008f * a)); }
+__device__ __forceinline__ void wg_sync() {                    // LDS-only workgroup barrier: no vmcnt drain (global stores stay in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// pack[d][kind][wave][fragment][lane][8 bf16].  kind 0 (forward): fragment (u*3 + g)*8 + s holds U[k][g*256 + 32w + 16u + lane%16],
+// k = 32s + 8*(lane/16) + i.  kind 1 (BPTT): fragment u*24 + s holds U[32w + 16u + lane%16][c], c = 32s + 8*(lane/16) + i.
+__global__ __launch_bounds__(256) void gru_pack_kernel(const float* __restrict__ U_f, const float* __restrict__ U_b, uint4* __restrict__ pack) {
+    const int i = blockIdx.x * 256 + threadIdx.x;               // one 16-byte piece each: 2 * 2 * 8 * 48 * 64 pieces
+    if (i >= 2 * 2 * GNW * GFR * 64) return;
+    const int lane = i & 63, f = (i >> 6) % GFR, w = (i >> 6) / GFR % GNW, kind = (i >> 6) / (GFR * GNW) % 2, d = (i >> 6) / (GFR * GNW * 2);
+    const float* U = d ? U_b : U_f;
+    float v[8];
+    if (kind == 0) {
+        const int s = f & 7, g = (f >> 3) % 3, u = (f >> 3) / 3;
+        const int n = g * GH + 32 * w + 16 * u + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = U[(long)(k0 + e) * GH3 + n];
+    } else {
+        const int s = f % 24, u = f / 24;
+        const int j = 32 * w + 16 * u + (lane & 15), c0 = 32 * s + 8 * (lane >> 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = U[(long)j * GH3 + c0 + e];
+    }
+    pack[i] = make_uint4(pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7]));
+}
+
+// dynamic LDS: A-fragments [8 waves][16][64 lanes][16 B] (128 KB) | Hs [2][16 rows][HS_STRIDE] | recurrent biases [3H]
+__global__ __launch_bounds__(512) void gru_mfma_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
+                                                           const uint4* __restrict__ pack, const float* __restrict__ bh_f,
+                                                           const float* __restrict__ bh_b, float* __restrict__ out,
+                                                           float* __restrict__ gates, float* __restrict__ hprev, int B, int L, int rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * rows, n = lane & 15, q4 = lane >> 4, b = b0 + n;
+    const bool row_ok = n < rows && b < B;                         // the MFMA's other batch columns multiply zeros
+    const float* xa = d ? xa_b : xa_f; const float* bh = d ? bh_b : bh_f;
+    uint4* Al = reinterpret_cast<uint4*>(smem) + (size_t)w * (GFR - GREG) * 64;          // this wave's LDS-resident fragments
+    unsigned char* Hs = smem + (size_t)GNW * (GFR - GREG) * 1024;
+    float* bs = reinterpret_cast<float*>(Hs + 2 * GNR * HS_STRIDE);                      // recurrent biases [3H] (LDS: in registers
+    const uint4* pk = pack + ((size_t)(d * 2 + 0) * GNW + w) * GFR * 64 + lane;          // across the MFMA phase they made the kernel spill)
+    bf16x8 A[GREG];
+#pragma unroll
+    for (int f = 0; f < GREG; ++f) A[f] = __builtin_bit_cast(bf16x8, pk[f * 64]);
+#pragma unroll
+    for (int f = GREG; f < GFR; ++f) Al[(f - GREG) * 64 + lane] = pk[f * 64];
+    for (int i = tid; i < 2 * GNR * HS_STRIDE / 4; i += 512) reinterpret_cast<unsigned*>(Hs)[i] = 0u;   // h0 = 0
+    for (int i = tid; i < GH3; i += 512) bs[i] = bh[i];
+    float h[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[u][r] = 0.f;
+    float* g_d = gates + (long)d * B * L * 4 * GH;
+    float* hp_d = hprev + (long)d * B * L * GH;
+    const int jl = 32 * w + 4 * q4;                             // + 16u: first of this lane's four units in tile u
+    wg_sync();
+    for (int s = 0; s < L; ++s) {
+        const int t = d ? (L - 1 - s) : s;
+        const unsigned char* Hc = Hs + (size_t)(s & 1) * GNR * HS_STRIDE;
+        unsigned char* Hn = Hs + (size_t)((s + 1) & 1) * GNR * HS_STRIDE;
+        // input projections + recurrent biases of this lane's (row, units): in flight underneath the MFMA phase
+        const long xo = ((long)b * L + t) * GH3;
+        f32x4 xg[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                xg[u][g] = row_ok ? *reinterpret_cast<const f32x4*>(xa + xo + g * GH + jl + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 Bf = *reinterpret_cast<const bf16x8*>(Hc + n * HS_STRIDE + (32 * ks + 8 * q4) * 2);
+#pragma unroll
+            for (int tl = 0; tl < 6; ++tl) {                    // tile tl = u*3 + g
+                const int f = tl * 8 + ks;
+                const bf16x8 Af = f < GREG ? A[f < GREG ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GREG) * 64 + lane]);
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[tl], 0, 0, 0);
+            }
+        }
+        // gate math in the accumulator layout
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 bg[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) bg[g] = *reinterpret_cast<const f32x4*>(bs + g * GH + jl + 16 * u);
+            f32x4 zv, rv, hv, qv, hn, ho;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = fsig(xg[u][0][r] + (acc[u * 3 + 0][r] + bg[0][r]));
+                const float rr = fsig(xg[u][1][r] + (acc[u * 3 + 1][r] + bg[1][r]));
+                const float q = acc[u * 3 + 2][r] + bg[2][r];
+                const float hh = ftanh(xg[u][2][r] + rr * q);
+                ho[r] = h[u][r];
+                hn[r] = z * h[u][r] + (1.f - z) * hh;
+                zv[r] = z; rv[r] = rr; hv[r] = hh; qv[r] = q;
+                h[u][r] = row_ok ? hn[r] : 0.f;
+            }
+            if (row_ok) {
+                const long go = (((long)b * L + t) * 4) * GH + jl + 16 * u;
+                *reinterpret_cast<f32x4*>(g_d + go) = zv; *reinterpret_cast<f32x4*>(g_d + go + GH) = rv;
+                *reinterpret_cast<f32x4*>(g_d + go + 2 * GH) = hv; *reinterpret_cast<f32x4*>(g_d + go + 3 * GH) = qv;
+                *reinterpret_cast<f32x4*>(hp_d + ((long)b * L + t) * GH + jl + 16 * u) = ho;
+                *reinterpret_cast<f32x4*>(out + ((long)b * L + t) * 2 * GH + d * GH + jl + 16 * u) = hn;
+            }
+            *reinterpret_cast<uint2*>(Hn + n * HS_STRIDE + (jl + 16 * u) * 2) = make_uint2(pk2(h[u][0], h[u][1]), pk2(h[u][2], h[u][3]));
+        }
+        wg_sync();
+    }
+}
+
+// BPTT.  dai / dah: (2, B, L, 3H) input-side / recurrent-side pre-activation gradients (the weight gradients are GEMMs over them).
+// dynamic LDS: A-fragments [8][16][64][16 B] (128 KB) | As [16 rows][AS_STRIDE]
+__global__ __launch_bounds__(512) void gru_mfma_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                           const float* __restrict__ hprev, const uint4* __restrict__ pack,
+                                                           float* __restrict__ dai, float* __restrict__ dah, int B, int L, int rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * rows, n = lane & 15, q4 = lane >> 4, b = b0 + n;
+    const bool row_ok = n < rows && b < B;
+    uint4* Al = reinterpret_cast<uint4*>(smem) + (size_t)w * (GFR - GREG) * 64;
+    unsigned char* As = smem + (size_t)GNW * (GFR - GREG) * 1024;
+    const uint4* pk = pack + ((size_t)(d * 2 + 1) * GNW + w) * GFR * 64 + lane;
+    bf16x8 A[GREG];
+#pragma unroll
+    for (int f = 0; f < GREG; ++f) A[f] = __builtin_bit_cast(bf16x8, pk[f * 64]);
+#pragma unroll
+    for (int f = GREG; f < GFR; ++f) Al[(f - GREG) * 64 + lane] = pk[f * 64];
+    const float* g_d = gates + (long)d * B * L * 4 * GH;
+    const float* hp_d = hprev + (long)d * B * L * GH;
+    float* dai_d = dai + (long)d * B * L * GH3; float* dah_d = dah + (long)d * B * L * GH3;
+    const int jl = 32 * w + 4 * q4;
+    struct Saved { f32x4 z, rr, hh, q, hp, dy; };
+    auto fetch = [&](int s, Saved (&v)[2]) __attribute__((always_inline)) {
+        const int t = d ? (L - 1 - s) : s;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (row_ok && s >= 0) {
+                const long go = (((long)b * L + t) * 4) * GH + jl + 16 * u;
+                v[u].z = *reinterpret_cast<const f32x4*>(g_d + go); v[u].rr = *reinterpret_cast<const f32x4*>(g_d + go + GH);
+                v[u].hh = *reinterpret_cast<const f32x4*>(g_d + go + 2 * GH); v[u].q = *reinterpret_cast<const f32x4*>(g_d + go + 3 * GH);
+                v[u].hp = *reinterpret_cast<const f32x4*>(hp_d + ((long)b * L + t) * GH + jl + 16 * u);
+                v[u].dy = *reinterpret_cast<const f32x4*>(dout + ((long)b * L + t) * 2 * GH + d * GH + jl + 16 * u);
+            } else {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                v[u].z = zero; v[u].rr = zero; v[u].hh = zero; v[u].q = zero; v[u].hp = zero; v[u].dy = zero;
+            }
+        }
+    };
+    Saved cur[2];
+    fetch(L - 1, cur);
+    float dh[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[u][r] = 0.f;
+    wg_sync();
+    for (int s = L - 1; s >= 0; --s) {
+        const int t = d ? (L - 1 - s) : s;
+        // gate backward for this lane's (row, 8 units); the recurrent-side gradients go to LDS as the MFMA's B operand
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 daz, dar, dahh, a2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = cur[u].z[r], rr = cur[u].rr[r], hh = cur[u].hh[r], q = cur[u].q[r], hp = cur[u].hp[r];
+                const float g = dh[u][r] + cur[u].dy[r];
+                dh[u][r] = g * z;                                  // the direct path; the recurrent-kernel path is added below
+                dahh[r] = g * (1.f - z) * (1.f - hh * hh);
+                daz[r] = g * (hp - hh) * z * (1.f - z);
+                dar[r] = dahh[r] * q * rr * (1.f - rr);
+                a2[r] = dahh[r] * rr;
+            }
+            if (row_ok) {
+                const long oo = ((long)b * L + t) * GH3 + jl + 16 * u;
+                *reinterpret_cast<f32x4*>(dai_d + oo) = daz; *reinterpret_cast<f32x4*>(dai_d + oo + GH) = dar; *reinterpret_cast<f32x4*>(dai_d + oo + 2 * GH) = dahh;
+                *reinterpret_cast<f32x4*>(dah_d + oo) = daz; *reinterpret_cast<f32x4*>(dah_d + oo + GH) = dar; *reinterpret_cast<f32x4*>(dah_d + oo + 2 * GH) = a2;
+            }
+            unsigned char* ar = As + n * AS_STRIDE + (jl + 16 * u) * 2;
+            *reinterpret_cast<uint2*>(ar) = make_uint2(pk2(daz[0], daz[1]), pk2(daz[2], daz[3]));
+            *reinterpret_cast<uint2*>(ar + GH * 2) = make_uint2(pk2(dar[0], dar[1]), pk2(dar[2], dar[3]));
+            *reinterpret_cast<uint2*>(ar + 2 * GH * 2) = make_uint2(pk2(a2[0], a2[1]), pk2(a2[2], a2[3]));
+        }
+        wg_sync();
+        fetch(s - 1, cur);                                        // the saved activations of the next step: in flight under the MFMAs
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) {
+            const bf16x8 Bf = *reinterpret_cast<const bf16x8*>(As + n * AS_STRIDE + (32 * ks + 8 * q4) * 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = u * 24 + ks;
+                const bf16x8 Af = f < GREG ? A[f < GREG ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GREG) * 64 + lane]);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh[u][r] += acc[u][r];
+        wg_sync();                                                // everyone is done with As before the next step rewrites it
+    }
+}
+
+}  // namespace
+
+// Batch rows per workgroup (of the MFMA's 16 batch columns): a step moves 9 KB per row through one CU (input projections in, gates /
+// saved state out, and the same again in BPTT), which at 16 rows -- 8 workgroups for B = 64 -- was the longest phase of a step
+// (5.4 us per step, no faster than streaming U).  Fewer rows per workgroup spread that over more CUs; the MFMA has time to spare.
+static int gru_rows(int B) {
+    static const int knob = getenv("SAR_GRU_ROWS") ? atoi(getenv("SAR_GRU_ROWS")) : 0;
+    if (knob >= 1 && knob <= GNR) return knob;
+    int rows = 4;
+    while (rows < GNR && cdiv(B, rows) * 2 > 256) rows *= 2;
+    return rows;
+}
+
+// U (H, 3H) fp32 of both directions -> the bf16 A-fragment streams of the two kernels below; once per optimiser step.
+// pack: 2 * 2 * 3H * H bf16 (1.5 MB at H = 256).
+extern "C" int sar_bigru_pack_bf16(const float* U_fwd, const float* U_bwd, void* pack, int H, hipStream_t stream) {
+    if (!U_fwd || !U_bwd || !pack || H != GH) return SAR_EINVAL;
+    hipLaunchKernelGGL(gru_pack_kernel, dim3(2 * 2 * GNW * GFR * 64 / 256), dim3(256), 0, stream, U_fwd, U_bwd, static_cast<uint4*>(pack));
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// Same contract as sar_bigru_fwd_f32 (H = 256 only) with the recurrent matmul on bf16 MFMA from the packed kernel.
+extern "C" int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, const void* pack, const float* bh_fwd, const float* bh_bwd,
+                                  float* out, float* gates, float* hprev, int B, int L, int H, hipStream_t stream) {
+    if (!xa_fwd || !xa_bwd || !pack || !bh_fwd || !bh_bwd || !out || !gates || !hprev || H != GH || B < 1 || L < 1) return SAR_EINVAL;
+    const size_t lds = (size_t)GNW * (GFR - GREG) * 1024 + 2 * GNR * HS_STRIDE + GH3 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
+        attr = true;
+    }
+    const int rows = gru_rows(B);
+    hipLaunchKernelGGL(gru_mfma_fwd_kernel, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, xa_fwd, xa_bwd, static_cast<const uint4*>(pack),
+                       bh_fwd, bh_bwd, out, gates, hprev, B, L, rows);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// Same contract as sar_bigru_bwd_f32 (H = 256 only; no transposed kernels needed: the pack holds both orientations).
+extern "C" int sar_bigru_bwd_bf16(const float* dout, const float* gates, const float* hprev, const void* pack, float* dai, float* dah,
+                                  int B, int L, int H, hipStream_t stream) {
+    if (!dout || !gates || !hprev || !pack || !dai || !dah || H != GH || B < 1 || L < 1) return SAR_EINVAL;
+    const size_t lds = (size_t)GNW * (GFR - GREG) * 1024 + GNR * AS_STRIDE;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
+        attr = true;
+    }
+    const int rows = gru_rows(B);
+    hipLaunchKernelGGL(gru_mfma_bwd_kernel, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, dout, gates, hprev, static_cast<const uint4*>(pack),
+                       dai, dah, B, L, rows);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}

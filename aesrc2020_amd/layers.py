@@ -146,7 +146,14 @@ class BiGRU(Layer):
             gemm(x, k.w, xa[i], b.w, R, 3 * H, I, I, 3 * H, 3 * H, 1, 0)
         self.out = self.buf("out", (B, L, 2 * H)); self.gates = self.buf("gates", (2, B, L, 4, H)); self.hprev = self.buf("hprev", (2, B, L, H))
         (kf, uf, bf), (kb, ub, bb) = self.p["forward"], self.p["backward"]
-        _call("sar_bigru_fwd_f32", xa[0], xa[1], uf.w, ub.w, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
+        # "bf16" mode at the reference's hidden_dim: recurrent kernels packed as bf16 MFMA fragments, resident on chip (gru_mfma.hip)
+        self.mfma = H == 256 and _lib.get_gemm_math() == "bf16"
+        if self.mfma:
+            self.pack = self.buf("u_pack", (2 * 2 * 3 * H * H,), torch.bfloat16)
+            _call("sar_bigru_pack_bf16", uf.w, ub.w, self.pack, H)
+            _call("sar_bigru_fwd_bf16", xa[0], xa[1], self.pack, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
+        else:
+            _call("sar_bigru_fwd_f32", xa[0], xa[1], uf.w, ub.w, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
         if self.seq:
             return self.out
         y = self.buf("last", (B, 2 * H))
@@ -161,11 +168,14 @@ class BiGRU(Layer):
             _call("sar_bigru_last_bwd_f32", dy, dout, B, L, H)
         else:
             dout = dy
-        UT = [self.scratch("gru_UT0_%d" % H, (3 * H, H)), self.scratch("gru_UT1_%d" % H, (3 * H, H))]
-        for i, d in enumerate(("forward", "backward")):
-            _call("sar_transpose_f32", self.p[d][1].w, UT[i], H, 3 * H)
         dai = self.scratch("gru_dai%d_%d_%d" % (B, L, H), (2, B, L, 3 * H)); dah = self.scratch("gru_dah%d_%d_%d" % (B, L, H), (2, B, L, 3 * H))
-        _call("sar_bigru_bwd_f32", dout, self.gates, self.hprev, UT[0], UT[1], dai, dah, B, L, H)
+        if self.mfma:
+            _call("sar_bigru_bwd_bf16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H)
+        else:
+            UT = [self.scratch("gru_UT0_%d" % H, (3 * H, H)), self.scratch("gru_UT1_%d" % H, (3 * H, H))]
+            for i, d in enumerate(("forward", "backward")):
+                _call("sar_transpose_f32", self.p[d][1].w, UT[i], H, 3 * H)
+            _call("sar_bigru_bwd_f32", dout, self.gates, self.hprev, UT[0], UT[1], dai, dah, B, L, H)
         dx = None
         if need_dx:
             dx = dx_out if dx_out is not None else self.buf("dx", (R, I))

@@ -231,6 +231,16 @@ int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const float* U_f
                       int H, sarStream_t stream);
 int sar_bigru_bwd_f32(const float* dout, const float* gates, const float* hprev, const float* UT_fwd,
                       const float* UT_bwd, float* dai, float* dah, int B, int L, int H, sarStream_t stream);
+/* The recurrence of the "bf16" mode at hidden_dim 256 (model.py:44-50, train.py default): the recurrent kernels are rounded to
+ * bf16 and packed once per optimiser step (pack: 2 directions x 2 orientations x 3H x H bf16 = 1.5 MB), then stay on chip for all
+ * L steps -- registers + LDS of 16-row workgroups, v_mfma_f32_16x16x32_bf16 -- instead of streaming from L2 every step.  State,
+ * gates, saved tensors and accumulation are fp32; same tensors and layouts as sar_bigru_fwd_f32 / sar_bigru_bwd_f32 (no
+ * transposed kernels needed).  H must be 256. */
+int sar_bigru_pack_bf16(const float* U_fwd, const float* U_bwd, void* pack, int H, sarStream_t stream);
+int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, const void* pack, const float* bh_fwd, const float* bh_bwd,
+                       float* out, float* gates, float* hprev, int B, int L, int H, sarStream_t stream);
+int sar_bigru_bwd_bf16(const float* dout, const float* gates, const float* hprev, const void* pack, float* dai, float* dah,
+                       int B, int L, int H, sarStream_t stream);
 int sar_bigru_last_fwd_f32(const float* out, float* y, int B, int L, int H, sarStream_t stream); /* seq=False, model.py:128 */
 int sar_bigru_last_bwd_f32(const float* dy, float* dout, int B, int L, int H, sarStream_t stream);
 

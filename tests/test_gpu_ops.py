@@ -459,6 +459,64 @@ def test_bigru(L, B, Lq, I, H):
     check(dout, ref, 1e-7, "bigru last bwd")
 
 
+def _gru_bf16_emulation(xa, U, bh, dy_dir, reverse):
+    """One direction of the bf16-MFMA recurrence in float64, rounding to bf16 exactly where gru_mfma.hip does: U once, h before
+    every recurrent matmul, the recurrent-side pre-activation gradients before the BPTT matmul.  xa (B, L, 3H) holds x*W + b_i.
+    Returns (out (B, L, H), dai, dah)."""
+    bf = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()
+    B, Lq, H3 = xa.shape; H = H3 // 3
+    Ub = bf(U); sig = lambda a: 1.0 / (1.0 + np.exp(-a))
+    order = range(Lq - 1, -1, -1) if reverse else range(Lq)
+    h = np.zeros((B, H)); out = np.zeros((B, Lq, H)); saved = {}
+    for t in order:
+        G = bf(h) @ Ub
+        z = sig(xa[:, t, :H] + G[:, :H] + bh[:H]); r = sig(xa[:, t, H:2 * H] + G[:, H:2 * H] + bh[H:2 * H]); q = G[:, 2 * H:] + bh[2 * H:]
+        hh = np.tanh(xa[:, t, 2 * H:] + r * q)
+        saved[t] = (z, r, hh, q, h)
+        h = z * h + (1 - z) * hh
+        out[:, t] = h
+    dai = np.zeros((B, Lq, H3)); dah = np.zeros((B, Lq, H3)); dh = np.zeros((B, H))
+    for t in reversed(list(order)):
+        z, r, hh, q, hp = saved[t]
+        g = dh + dy_dir[:, t]
+        da_h = g * (1 - z) * (1 - hh * hh); da_z = g * (hp - hh) * z * (1 - z); da_r = da_h * q * r * (1 - r)
+        dai[:, t] = np.concatenate([da_z, da_r, da_h], 1); a = np.concatenate([da_z, da_r, da_h * r], 1); dah[:, t] = a
+        dh = g * z + bf(a) @ Ub.T
+    return out, dai, dah
+
+
+@pytest.mark.parametrize("B,Lq", [(64, 39), (5, 7), (19, 3)])
+def test_bigru_bf16_mfma(L, B, Lq):
+    """gru_mfma.hip (the "bf16" mode at hidden_dim 256): against a float64 emulation that rounds the MFMA operands where the
+    kernels do (wiring errors are O(1); agreement is limited by last-bit rounding flips of h), and loosely against the exact
+    float64 GRU of the oracle (what bf16 operands cost)."""
+    H, I = 256, 24
+    rng = np.random.default_rng(B * Lq + 1)
+    x = rng.standard_normal((B, Lq, I))
+    mk = lambda: (rng.standard_normal((I, 3 * H)) / np.sqrt(I), rng.standard_normal((H, 3 * H)) / np.sqrt(H), rng.standard_normal(6 * H) * 0.1)
+    P = [mk(), mk()]
+    dy = rng.standard_normal((B, Lq, 2 * H))
+    xa_np = [x @ p[0] + p[2][:3 * H] for p in P]
+    xa = [dev(a.reshape(B * Lq, 3 * H)) for a in xa_np]
+    U = [dev(p[1]) for p in P]; bh = [dev(p[2][3 * H:]) for p in P]
+    pack = torch.zeros(2 * 2 * 3 * H * H, dtype=torch.bfloat16, device="cuda")
+    L.call("sar_bigru_pack_bf16", U[0], U[1], pack, H)
+    out = zeros(B, Lq, 2 * H); gates = zeros(2, B, Lq, 4, H); hprev = zeros(2, B, Lq, H)
+    L.call("sar_bigru_fwd_bf16", xa[0], xa[1], pack, bh[0], bh[1], out, gates, hprev, B, Lq, H)
+    dai = zeros(2, B, Lq, 3 * H); dah = zeros(2, B, Lq, 3 * H)
+    L.call("sar_bigru_bwd_bf16", dev(dy), gates, hprev, pack, dai, dah, B, Lq, H)
+    y_exact, cache = O.bigru_fwd(x, P[0], P[1], True)
+    for d in range(2):
+        o, ai, ah = _gru_bf16_emulation(xa_np[d], P[d][1], P[d][2][3 * H:], dy[:, :, d * H:(d + 1) * H], reverse=bool(d))
+        check(out[:, :, d * H:(d + 1) * H], o, 3e-3, "bf16 gru out, direction %d" % d)
+        check(dai[d], ai, 3e-3, "bf16 gru dai, direction %d" % d); check(dah[d], ah, 3e-3, "bf16 gru dah, direction %d" % d)
+        hp = np.zeros_like(o)
+        if d == 0: hp[:, 1:] = o[:, :-1]
+        else: hp[:, :-1] = o[:, 1:]
+        check(hprev[d], hp, 3e-3, "bf16 gru hprev, direction %d" % d)
+    check(out, y_exact, 3e-2, "bf16 gru against the exact recurrence")
+
+
 # ------------------------------------------------------------------ CTC
 def _ctc_inputs(B, Lq, V, maxU, rng, Umax):
     p = O.softmax(rng.standard_normal((B, Lq, V)) * 2)
