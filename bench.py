@@ -40,8 +40,8 @@ WORKLOADS = {
 
 
 def conv_roofline(model, B, iters=10):
-    """Time every conv launch class of the ResNet trunk in isolation (HIP events on the launch stream) and return the
-    dominant class: achieved = algorithmic FLOPs per launch / average launch duration."""
+    """Time every conv launch of the ResNet trunk in isolation (HIP events on the launch stream), class them by kernel and
+    return the dominant class: achieved = algorithmic FLOPs per launch / average launch duration."""
     from aesrc2020_amd import _lib
     tr = model.trunk
     classes = {}
@@ -62,26 +62,68 @@ def conv_roofline(model, B, iters=10):
     bf16 = getattr(tr, "bf16", False)
     eb = 2.0 if bf16 else 4.0
     wg = []
+    def bf16_block(blk):
+        """The six conv launches of one residual block exactly as ResNetTrunk._forward16 / _backward16 issue them (same fills,
+        side tensors, epilogue statistics; BatchNorm constants from the last step's saved values, statistics into scratch bins),
+        classed by the kernel instantiation rocprofv3 reports: conv_bf16_kernel<WN, NKC, VT>, WN = 2 for 64+ output channels of
+        the launch, NKC = source channels / 16 up to 8, VT = taps x 128-channel parts."""
+        BF = torch.bfloat16
+        H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
+        cin, cout = blk["cin"], blk["cout"]
+        R1, R2 = B * H * W, B * H2 * W2
+        bn1, bn2, c1v, c2v, scv = blk["bn1"], blk["bn2"], blk["conv1"], blk["conv2"], blk["sc"]
+        x, c1 = blk["x"], blk["c1"]
+        rnd = lambda *s: torch.randn(*s, device="cuda").to(BF)
+        emp = lambda *s: torch.empty(*s, device="cuda", dtype=BF)
+        bins = lambda c: torch.zeros(_lib.bn_bins() * 2 * c, device="cuda")
+        g, da2, res = rnd(B, H2, W2, cout), rnd(B, H2, W2, cout), rnd(B, H2, W2, cout)
+        y, a1, dx2, dc1 = emp(B, H2, W2, cout), emp(B, H2, W2, cout), emp(B, H2, W2, cout), emp(B, H2, W2, cout)
+        a, dx1 = emp(B, H, W, cin), emp(B, H, W, cin)
+        b1, b2 = bins(cout), bins(cin)
+
+        def inst(cv, ci, co):
+            return "conv_bf16_kernel<%d, %d, %d>" % (2 if co >= 64 else 1, min(ci // 16, 8), cv.k * cv.k * max(1, ci // 128))
+
+        def fl(cv):
+            return 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k
+
+        def by(cv, extra=0):
+            return eb * (B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + cv.k * cv.k * cv.cin * cv.cout + extra)
+
+        fb1 = bn1.ref(R1, "saved", False) if bn1 is not None else None
+        add(inst(c1v, cin, cout), timed(lambda: c1v.fwd16(x, y, B, fill=1 if bn1 is not None else 0, fbn=fb1, e_bins=b1, side=a if bn1 is not None else None)),
+            fl(c1v), by(c1v, x.numel() if bn1 is not None else 0))
+        add(inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
+            fl(c2v), by(c2v, 2 * c1.numel()))
+        add(inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
+        if bn1 is not None:
+            add(inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
+                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
+        else:
+            r1 = rnd(B, H, W, cin)
+            add(inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
+                fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
+        if scv is not None:
+            add(inst(scv, cin, cout), timed(lambda: scv.fwd16(x, y, B)), fl(scv), by(scv))
+            add(inst(scv, cout, cin), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv))
+        for cv, xx in ((c1v, x), (c2v, c1)) + (((scv, x),) if scv is not None else ()):
+            wg.append((cv.wgrad16(xx, g, B, False), fl(cv), by(cv)))             # batched below, as the train step runs them
+
     for n, blk in enumerate(tr.blocks):
+        if bf16:
+            bf16_block(blk)
+            continue
         for cname, bn in (("conv1", blk["bn1"]), ("conv2", blk["bn2"]), ("sc", None)):
             cv = blk[cname]
             if cv is None:
                 continue
             x = blk["x"] if cname != "conv2" else blk["c1"]
-            dt = torch.bfloat16 if bf16 else torch.float32
+            dt = torch.float32
             y = torch.randn(B, cv.Ho, cv.Wo, cv.cout, device="cuda").to(dt); dx = torch.empty(B, cv.H, cv.W, cv.cin, device="cuda", dtype=dt)
             flops = 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k
             act_b = eb * B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + eb * cv.k * cv.k * cv.cin * cv.cout
             tile = "n32" if cv.cout <= 32 else "n64"
             tile_d = "n32" if cv.cin <= 32 else "n64"
-            if bf16:
-                # the launches of the train step: BN+ReLU in the forward / weight-gradient fills (saved constants), plain gradient
-                fb = bn.ref(B * cv.H * cv.W, "saved", False) if bn is not None else None
-                fl = 1 if bn is not None else 0
-                add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd16(x, y, B, fill=fl, fbn=fb)), flops, act_b)
-                wg.append((cv.wgrad16(x, y, B, False), flops, act_b))       # batched below, as the train step runs them
-                add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad16(y, None, dx, B)), flops, act_b)
-                continue
             add("conv_fwd_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.fwd(x, y, B, bn=bn)), flops, act_b)
             add("conv_wgrad_%dx%d_%s" % (cv.k, cv.k, tile), timed(lambda: cv.wgrad(x, y, B, bn=bn)), flops, act_b)
             add("conv_dgrad_%dx%d_%s" % (cv.k, cv.k, tile_d), timed(lambda: cv.dgrad(y, dx, B)), flops, act_b)
@@ -91,7 +133,7 @@ def conv_roofline(model, B, iters=10):
             sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
                 plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1))
-                nm = "conv_wgrad_%dx%d_%s%s_batched" % (cls[0], cls[0], "s%d" % cls[1] if cls[1] else "all", "_t64" if cls[2] else "")
+                nm = ("wgrad3_bf16_kernel<2, 2>" if cls[2] else "wgrad3_bf16_kernel<1, 1>") if cls[0] == 3 else "wgrad_bf16_kernel<1>"
                 c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["bytes"] += sum(w_[2] for w_ in sel); c["launches"] += 1
     total = sum(c["time"] for c in classes.values())

@@ -9,7 +9,7 @@ by = {}
 for k, c, v, n in rows:
     by.setdefault(k, {})[c] = (v, n)
 for k, d in by.items():
-    if "conv" not in k and (len(sys.argv) < 3 or sys.argv[2] not in k):
+    if "conv" not in k and "wgrad" not in k and (len(sys.argv) < 3 or sys.argv[2] not in k):
         continue
     print(k[:90])
     for c, (v, n) in sorted(d.items()):

@@ -20,6 +20,12 @@ CLASS = [("conv_wgrad_x3_kernel<64>", "conv_wgrad_3x3_n64"), ("conv_fwd_x3_kerne
          ("conv_fwd_kernel<4, 1, 1, 32, false>", "conv_fwd_3x3_n32"), ("conv_dgrad_x3_kernel<4, 1, 1, 32, false>", "conv_dgrad_3x3_n32")]
 out = {"source": src, "note": "per-launch average over all dispatches of the kernel in a step (3x3 and 1x1 launches of one template together); "
        "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
+# bf16 trunk: bench.py's classes ARE the kernel instantiations
+for k, d in vals.items():
+    m = re.search(r"((?:conv_bf16_kernel|wgrad3_bf16_kernel|wgrad_bf16_kernel)<[^>]*>)", k)
+    if m and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
+        out["bf16:" + m.group(1)] = {"kernel": m.group(1), "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}
 for kname, cls in CLASS:
     for k, d in vals.items():
         if kname in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
