@@ -67,6 +67,52 @@ def test_ctc_sum_rule_full_size():
         assert (dp[b, 30:] == 0).all()                              # frames beyond in_len get exactly zero gradient
 
 
+CFG2 = dict(input_shape=[400, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=32, ghost_clusters=2,
+            disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)
+CFG5 = dict(input_shape=[2000, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=64, ghost_clusters=2,
+            disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)
+
+
+def _dup_half(kw, B, tol_out, tol_grad, seed=11):
+    """B-utterance batch = two copies of a B/2 batch: per-utterance outputs of the full run equal the half run's, halves agree,
+    batch-mean gradients agree."""
+    from aesrc2020_amd.model import SAR_Net
+    half = _batch(kw, B // 2, seed)
+    full = {k: np.concatenate([v, v]) for k, v in half.items()}
+    mf, _ = SAR_Net(seed=0, use_graph=False, **kw)
+    mh, _ = SAR_Net(seed=0, use_graph=False, **kw)
+    mh.set_weights_dict(mf.get_weights_dict())
+    mf.forward_backward_only(full, full); mh.forward_backward_only(half, half)
+    for k in ("y_accent", "y_disc"):
+        a = mf.out[k].cpu().numpy(); b = mh.out[k].cpu().numpy()
+        assert np.all(np.isfinite(a)) and np.abs(a.sum(1) - 1).max() < 1e-4
+        assert np.abs(a[:B // 2] - a[B // 2:]).max() <= tol_out, k
+        assert np.abs(a[:B // 2] - b).max() <= tol_out, k
+    gf = mf.store.grads.cpu().numpy(); gh = mh.store.grads.cpu().numpy()
+    assert np.all(np.isfinite(gf))
+    assert np.linalg.norm(gf - gh) <= tol_grad * np.linalg.norm(gh)
+    return mf
+
+
+@pytest.mark.parametrize("B", [32, 64])
+def test_cfg5_duplicated_half_batch_invariance(B):
+    """BASELINE configs[4] shape (2000x80, GhostVLAD 64+2) at its batch sizes, fp32-class default mode."""
+    m = _dup_half(CFG5, B, 2e-4, 2e-2)
+    assert m.L == 189 and m.merge.pool.out.shape == (B, 64 * 256)
+
+
+def test_cfg2_bf16_mode_duplicated_half_batch_invariance():
+    """The bench's default workload and mode (cfg2, B=64, bf16 trunk + bf16-MFMA GEMMs / GRU).  The halves see different atomic
+    orders in the statistic bins, so stored bf16 values flip last bits: probabilities agree to bf16 noise, not to 1e-4."""
+    from aesrc2020_amd import _lib
+    _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    try:
+        m = _dup_half(CFG2, 64, 6e-2, 2.5e-1)
+        assert m.trunk.bf16
+    finally:
+        _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32")
+
+
 def test_cfg5_long_utterance_stress():
     from aesrc2020_amd.model import SAR_Net
     kw = dict(input_shape=[2000, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=64, ghost_clusters=2,
