@@ -152,9 +152,10 @@ __device__ __forceinline__ void load_cst8(const float* cst, int cs, int ch, int 
         if (mode == 2) { k.mu[j] = cst[2 * cs + ch + j]; k.rs[j] = cst[3 * cs + ch + j]; k.c2[j] = cst[4 * cs + ch + j]; k.c3[j] = cst[5 * cs + ch + j]; }
     }
 }
-// MODE 0: copy; 1: relu(x*scale+shift); 2: BatchNorm(+ReLU) backward  dx = scale*(dz - c2 - xhat*c3), dz = da*[z>0]
+// MODE 0: copy; 1: relu(x*scale+shift); 2: BatchNorm(+ReLU) backward  dx = scale*(dz - c2 - xhat*c3), dz = da*[z>0];
+// 3: mode 2 + a third tensor (the shortcut gradient of the residual block behind this BatchNorm)
 template <int MODE>
-__device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const Cst8& k) {
+__device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint4 q3, const Cst8& k) {
     if constexpr (MODE == 0) return q;
     float a[8], o[8];
     unpack8(q, a);
@@ -171,6 +172,12 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const Cst8
             const float xh = (y[j] - k.mu[j]) * k.rs[j];
             o[j] = k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]);
         }
+        if constexpr (MODE == 3) {
+            float ad[8];
+            unpack8(q3, ad);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += ad[j];
+        }
     }
     return pack8(o);
 }
@@ -178,7 +185,7 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const Cst8
 // ---------------------------------------------------------------------------------------------------- conv (fwd / dgrad)
 struct ConvP {
     Geo g; int Cout;
-    const u16* x; const u16* x2; const bf16x8* wpk; const float* bias; const u16* res; u16* y;
+    const u16* x; const u16* x2; const u16* x3; const bf16x8* wpk; const float* bias; const u16* res; u16* y;
     u16* side;                  // nullable: the fill transform T(x) written back to HBM (same shape as x) for the weight gradient
     int fill; BnP fb;
     int epi; float* e_bins; const u16* e_y; const float* e_saved;
@@ -218,7 +225,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
 // source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
 template <int MODE, int TM, int U>
-__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, u16* __restrict__ side,
+__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid) {
     const unsigned pc = 1u << lg_pc, total = (nrows * g.Wp) << lg_pc;
@@ -227,9 +234,9 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
     const int dm = g.d - 1, ssh = g.s - 1;
     const bool do_side = side != nullptr && blockIdx.y == 0;       // block-uniform
     Cst8 k;
-    if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE, k);
+    if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
     for (unsigned i0 = tid; i0 < total; i0 += U * 256) {           // U pieces in flight per thread
-        uint4 q[U], q2[U]; unsigned off[U], lo[U], own[U];
+        uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const unsigned i = i0 + 256 * j, pos = i >> lg_pc;
@@ -242,11 +249,12 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
             lo[j] = pos * rs + c8 * 16;
             const unsigned o = ok ? off[j] : 0u;
             q[j] = *reinterpret_cast<const uint4*>(x + o);
-            if constexpr (MODE == 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
+            if constexpr (MODE >= 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
+            if constexpr (MODE == 3) q3[j] = *reinterpret_cast<const uint4*>(x3 + o); else q3[j] = q[j];
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint4 r = xform<MODE>(q[j], q2[j], k);                 // branch-free: pieces past the end land in a scratch slot
+            const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);                 // branch-free: pieces past the end land in a scratch slot
             *reinterpret_cast<uint4*>(patch + (i0 + 256 * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
             if (do_side && off[j] != NONE && own[j] < (unsigned)TM) *reinterpret_cast<uint4*>(side + off[j]) = r;
         }
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     if (RD > 3 && NST > 2) issue_stage(2, 2);
 
 
-    if (p.fill) bn_prologue(p.fb, p.fill, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, 256);
+    if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, 256);
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
     pix_rp(g, min(m0 + TM - 1, M - 1), Rp_hi, wtmp);
@@ -354,9 +362,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
 
     // ---- fill: the padded patch, all input channels, transformed once
     constexpr int FU = 4;                                          // fill pieces per thread in flight
-    if (p.fill == 0) fill_patch<0, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else if (p.fill == 1) fill_patch<1, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else fill_patch<2, TM, FU>(g, p.x, p.x2, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    if (p.fill == 0) fill_patch<0, TM, FU>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else if (p.fill == 1) fill_patch<1, TM, FU>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else if (p.fill == 2) fill_patch<2, TM, FU>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else fill_patch<3, TM, 2>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);   // three tensors: two pieces in flight
     // ---- per-lane A address
     unsigned a_lane;
     {
@@ -1098,23 +1107,23 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, hipSt
 
 // Generic bf16 convolution: y[M][Cout] = sum over taps, channels of T(src)[padded position] * wpk (+ bias) (+ res), with
 //   fill 0: T = identity; 1: T = relu(bn(.)) of `fbn` (forward statistics from fbn->bins, or fbn->saved when bins is null);
-//        2: T = BatchNorm(+ReLU) backward of (da = src, y = src2) through `fbn`.
+//        2: T = BatchNorm(+ReLU) backward of (da = src, y = src2) through `fbn`;  3: the same + src3 (the shortcut gradient).
 //   side (nullable): T(src) written back to HBM (shape of src) -- the plain operand of the matching weight gradient.
 //   epi  0: none; 1: sum / sum of squares of y into e_bins; 2: BatchNorm-backward sums of y (= da) against (e_y, e_saved).
 // Forward: d = 1, s = stride, pads as TF.  Input gradient: src = dy, d = stride, s = 1, pt = K-1-pad_top, wpk = dgrad stream.
-int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, void* side,
+int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                     int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, hipStream_t stream) {
     ConvP p;
     memset(&p, 0, sizeof(p));
     if (!make_geo(p.g, B, Hs, Ws, Cin, Ho, Wo, K, s, d, pt, pl)) return SAR_EINVAL;
     if (!pow2(Cin) || !pow2(Cout) || Cin < 32 || Cout < 32 || Cin > CMAX || Cout > CMAX) return SAR_EINVAL;
-    if (fill < 0 || fill > 2 || epi < 0 || epi > 2 || (fill && fbn == nullptr) || (fill == 2 && src2 == nullptr)) return SAR_EINVAL;
+    if (fill < 0 || fill > 3 || epi < 0 || epi > 2 || (fill && fbn == nullptr) || (fill >= 2 && src2 == nullptr) || (fill == 3 && src3 == nullptr)) return SAR_EINVAL;
     if (epi && e_bins == nullptr) return SAR_EINVAL;
     if (epi == 2 && (e_y == nullptr || e_saved == nullptr)) return SAR_EINVAL;
     if ((long)B * Hs * Ws * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
     p.Cout = Cout;
-    p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.wpk = static_cast<const bf16x8*>(wpk);
+    p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.x3 = static_cast<const u16*>(src3); p.wpk = static_cast<const bf16x8*>(wpk);
     p.bias = bias; p.res = static_cast<const u16*>(res); p.y = static_cast<u16*>(y); p.side = static_cast<u16*>(side);
     p.fill = fill; if (fbn) p.fb = *fbn;
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;

@@ -115,14 +115,14 @@ class _Conv:
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
     def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
-        _call("sar_conv2d_bf16", x, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+        _call("sar_conv2d_bf16", x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
               self.k, self.stride, 1, self.pt, self.pl, fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
 
-    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None):
-        """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2 (written back to
-        `side` for the weight gradient); the epilogue leaves the backward sums of the BatchNorm in FRONT of this conv (input
-        e_y) in e_bins."""
-        _call("sar_conv2d_bf16", dy, dy2, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
+    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
+        """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2, + dy3 when fill == 3
+        (written back to `side` for the weight gradient and the other consumers of that gradient); the epilogue leaves the backward
+        sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
+        _call("sar_conv2d_bf16", dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
               self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
               e_bins, e_y, e_saved)
 
@@ -337,6 +337,11 @@ class ResNetTrunk(Layer):
         overlap = part is None and self.WGRAD_OVERLAP
         if overlap and getattr(self, "_wg_stream", None) is None:
             self._wg_stream = torch.cuda.Stream()
+        # `pend`: the gradient the block behind handed over, not materialised yet -- (da1, x, shortcut gradient, bn1 of that block):
+        # g = bn1_bwd(da1, x) + dsc is formed in the fill of THIS block's conv2 input-gradient launch (fill 3) and written back to
+        # `g` for the gradient's other consumers (weight gradients, the shortcut path), instead of by a BatchNorm-apply launch
+        pend = self._pend16 if part not in (None, 0) else None
+        tap = getattr(self, "debug_tap", None)
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
             if blk["stage"] not in stages:
@@ -349,13 +354,21 @@ class ResNetTrunk(Layer):
             # bn2's backward in bn2.bbins
             red = []
             da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
-            blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
+            if pend is None:
+                blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
+            else:
+                p_da1, p_x, p_dsc, p_bn, p_R, p_tap = pend
+                blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True), dy3=p_dsc, side=g,
+                                     e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
+                if p_tap is not None:                                 # tests: (block, its g, its da2 copy) + the now materialised gin
+                    tap(p_tap[0], p_tap[1], p_tap[2], g)
+                pend = None
             red.append(blk["conv2"].wgrad16(blk["a1"], g, B, bias_grad=True))
             # the weight gradients run at the end of the part (_wgrad16), so their gradient operands -- the block's incoming
             # gradient and dc1 -- live in per-block buffers, not in recycled scratch
             gin = self._buf16("b%d_gin" % n, (B, H, W, cin))
             if blk["sc"] is not None:
-                dsc = gin if bn1 is None else self.scratch("res16_dsc_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
+                dsc = gin if bn1 is None else self._buf16("b%d_dsc" % n, (B, H, W, cin))
                 blk["sc"].dgrad16(g, None, dsc, B)
                 red.append(blk["sc"].wgrad16(x, g, B, bias_grad=True))
             else:
@@ -364,22 +377,24 @@ class ResNetTrunk(Layer):
             # (which owns bn2's parameter gradients) and written back for the weight gradient
             dc1 = self._buf16("b%d_dc1" % n, (B, H2, W2, cout))
             if bn1 is not None:
-                da1 = self.scratch("res16_da1_%dx%dx%d" % (H, W, cin), (B, H, W, cin), bf)
+                da1 = self._buf16("b%d_da1" % n, (B, H, W, cin))
                 blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
-                _call("sar_bn_bwd_apply_bf16", da1, 0, x, bn1.ref(R1, "bwd", True), dsc, gin, R1, cin, 1)
+                pend = (da1, x, dsc, bn1, R1, (n, g, da2.clone()) if tap is not None else None)
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
                 blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True), res=dsc, side=dc1)
+                if tap is not None:
+                    tap(n, g, da2, gin)
             red.append(blk["conv1"].wgrad16(blk["a"] if bn1 is not None else x, dc1, B, bias_grad=False))
             self._wg16.extend(red)
-            if getattr(self, "debug_tap", None) is not None:          # tests/test_gpu_bf16_trunk.py: per-block tensors before reuse
-                self.debug_tap(n, g, da2, gin)
             g = gin
             # whole backward in one call: a finished stage's weight gradients start on the side stream while the next stage's
             # input-gradient chain (short, latency-bound launches that leave most of every CU idle) runs on the main stream
             if overlap and (n == 0 or self.blocks[n - 1]["stage"] != blk["stage"]):
                 self._wgrad16(("stage", blk["stage"]), side=True)
                 self._wg16 = []
+        self._pend16 = pend
+        assert pend is None or part in (0, 1), "the first block's conv1 takes the pooled tensor directly (resnet.py:111-117)"
         self._g_part = g
         if not overlap:
             self._wgrad16(part)
@@ -395,7 +410,8 @@ class ResNetTrunk(Layer):
     # launch classes of the batched weight gradient: (kernel size, stride or None, 64-wide channel tiles) -> blocks the planner
     # aims for.  3x3 stride 1 with Cin, Cout >= 64 (stages 1-3): 64 x 64 tiles, one 9-wave block per CU; the 32-channel layers:
     # 32 x 32 tiles, three blocks per CU; stride-2 convs need a 4x larger patch ring, so they get their own launch.
-    WGRAD_CLASSES = (((3, 1, True), 640), ((3, 1, False), 768), ((3, 2, False), 512), ((1, None, False), 256))
+    WGRAD_CLASSES = (((3, 1, True), int(os.environ.get("SAR_WG_T64", 640))), ((3, 1, False), int(os.environ.get("SAR_WG_T32", 768))),
+                     ((3, 2, False), 512), ((1, None, False), 256))
 
     @staticmethod
     def _wgrad_class(d):

@@ -62,7 +62,7 @@ def conv_roofline(model, B, iters=10):
     bf16 = getattr(tr, "bf16", False)
     eb = 2.0 if bf16 else 4.0
     wg = []
-    def bf16_block(blk):
+    def bf16_block(blk, nxt_bn1):
         """The six conv launches of one residual block exactly as ResNetTrunk._forward16 / _backward16 issue them (same fills,
         side tensors, epilogue statistics; BatchNorm constants from the last step's saved values, statistics into scratch bins),
         classed by the kernel instantiation rocprofv3 reports: conv_bf16_kernel<WN, NKC, VT>, WN = 2 for 64+ output channels of
@@ -95,7 +95,12 @@ def conv_roofline(model, B, iters=10):
             fl(c1v), by(c1v, x.numel() if bn1 is not None else 0))
         add(inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
             fl(c2v), by(c2v, 2 * c1.numel()))
-        add(inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
+        if nxt_bn1 is None:                                         # last block: its gradient comes materialised from the final BatchNorm
+            add(inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
+        else:                                                       # fill 3: the block behind hands over (da1, x, shortcut gradient)
+            xn = rnd(B, H2, W2, cout)
+            add(inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res, side=y,
+                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, 4 * c1.numel()))
         if bn1 is not None:
             add(inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
                                                                 e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
@@ -111,7 +116,7 @@ def conv_roofline(model, B, iters=10):
 
     for n, blk in enumerate(tr.blocks):
         if bf16:
-            bf16_block(blk)
+            bf16_block(blk, tr.blocks[n + 1]["bn1"] if n + 1 < len(tr.blocks) else None)
             continue
         for cname, bn in (("conv1", blk["bn1"]), ("conv2", blk["bn2"]), ("sc", None)):
             cv = blk[cname]

@@ -147,14 +147,16 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarSt
 /* Generic bf16 convolution, forward (resnet.py:39-42, 60-63, 82-87, 113-117) and input gradient in one kernel:
  *   y[B*Ho*Wo][Cout] = sum_taps T(src)[padded position] * wpk (+ bias) (+ res)
  * fill 0: T = identity; 1: T = relu(bn(.)) of fbn (statistics from fbn->bins, or fbn->saved when bins is NULL: inference /
- * recompute); 2: T = BatchNorm+ReLU backward of (da = src, y = src2) through fbn (sums from fbn->bbins).
+ * recompute); 2: T = BatchNorm+ReLU backward of (da = src, y = src2) through fbn (sums from fbn->bbins); 3: the same + src3 --
+ * the gradient a residual block hands to the block in front of it, bn1_bwd(da1, x) + shortcut gradient (resnet.py:96-125), formed
+ * in the fill of that block's conv2 input-gradient launch instead of by a BatchNorm-apply launch of its own.
  * side (nullable, shape of src): T(src) written back to HBM -- the plain operand of the matching weight gradient.
  * epi 0: none; 1: sum and sum of squares of y into e_bins (the statistics of the BatchNorm that consumes y); 2: the two
  * BatchNorm-backward sums of y (= da) against (e_y = that BN's input, e_saved) into e_bins.
  * Forward: d = 1, s = stride, pt/pl = TF pads, wpk = wf.  Input gradient: src = dy, Hs/Ws = its size, d = stride, s = 1,
  * Ho/Wo = the forward INPUT size, pt = K-1-pad_top, pl = K-1-pad_left, wpk = wd.  K in {1,3}; Cin, Cout powers of two in
  * [32, 512]. */
-int sar_conv2d_bf16(const void* src, const void* src2, const void* wpk, const float* bias, const void* res, void* y, void* side,
+int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                     int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
 /* Kernel gradients (resnet.py:39-42, 60-63, 82-87, 113-117 under Keras' backward pass) of MANY convolutions in one launch, on

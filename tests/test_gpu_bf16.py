@@ -81,15 +81,15 @@ class Conv:
         B, H, W, _ = x.shape
         ho, wo, pt, pl = self.geo(H, W)
         y = torch.empty(B, ho, wo, self.cout, dtype=BF, device="cuda")
-        self.L.call("sar_conv2d_bf16", x, None, self.wf, bias, res, y, side, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, 1, pt, pl,
+        self.L.call("sar_conv2d_bf16", x, None, None, self.wf, bias, res, y, side, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, 1, pt, pl,
                     fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
         return y
 
-    def dgrad(self, dy, H, W, dy2=None, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None):
+    def dgrad(self, dy, H, W, dy2=None, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
         B, ho, wo, _ = dy.shape
         _, _, pt, pl = self.geo(H, W)
         dx = torch.empty(B, H, W, self.cin, dtype=BF, device="cuda")
-        self.L.call("sar_conv2d_bf16", dy, dy2, self.wd, None, res, dx, side, B, ho, wo, self.cout, H, W, self.cin, self.k, 1, self.s,
+        self.L.call("sar_conv2d_bf16", dy, dy2, dy3, self.wd, None, res, dx, side, B, ho, wo, self.cout, H, W, self.cin, self.k, 1, self.s,
                     self.k - 1 - pt, self.k - 1 - pl, fill, fbn, 2 if e_bins is not None else 0, e_bins, e_y, e_saved)
         return dx
 
@@ -296,6 +296,14 @@ def test_conv_dgrad_with_batchnorm_backward_in_the_fill(L, shape):
     check(dx, ref, TOL_BF, "dx")
     check(side, dyq, TOL_BF, "side = BatchNorm backward of (da, y)")
     check(bn.d["dg"], bn.S2, 1e-5, "dgamma"); check(bn.d["db"], bn.S1, 1e-5, "dbeta")
+    # fill 3: + the shortcut gradient -- the gradient a residual block hands to the block in front of it (resnet.py:96-125)
+    add = grid(rng, da.shape)
+    dyq3 = rbf(bn.dx(da, yb) + add)
+    ref3 = O.conv2d_bwd(dyq3, cache)[0]
+    side3 = torch.full(da.shape, float("nan"), dtype=BF, device="cuda")
+    dx3 = cv.dgrad(dbf(da), H, W, dy2=dbf(yb), fill=3, fbn=bn.ref(bn.n, "bwd", False), side=side3, dy3=dbf(add))
+    check(dx3, ref3, TOL_BF, "dx (fill 3)"); check(side3, dyq3, TOL_BF, "side = BatchNorm backward + shortcut gradient")
+    check(bn.d["dg"], bn.S2, 1e-5, "dgamma untouched by a launch that does not own the side effects")
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)

@@ -18,7 +18,7 @@ L.call("sar_conv_pack_weights_bf16", tab, 1, -(-(nf + nd) // 8 // 256))
 ys = []
 def run():
     y = torch.empty(B, H, W, Cout, dtype=BF, device="cuda")
-    L.call("sar_conv2d_bf16", x, None, wf, None, res, y, None, B, H, W, Cin, H, W, Cout, 3, 1, 1, 1, 1, 0, None, 0, None, None, None)
+    L.call("sar_conv2d_bf16", x, None, None, wf, None, res, y, None, B, H, W, Cin, H, W, Cout, 3, 1, 1, 1, 1, 0, None, 0, None, None, None)
     return y
 ref = run(); torch.cuda.synchronize()
 bad = 0

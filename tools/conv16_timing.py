@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing16.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
-lib.sar_conv2d_bf16.argtypes = [vp] * 7 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
+lib.sar_conv2d_bf16.argtypes = [vp] * 8 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
 lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
 lib.sar_dbg_set_timing_buffer16.argtypes = [vp]
 BF = torch.bfloat16
@@ -39,7 +39,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
         continue
     else:
         wp = wf if mode == "fwd" else wd
-        fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
+        fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
                                          0, None, 1, bins.data_ptr(), None, None, st)
         names = {"prologue": (1, 2), "fill": (2, 3), "fill sync": (3, 4), "k-phase": (4, 5), "epilogue": (5, 6), "stats": (6, 7), "total": (1, 7)}
     tb = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
