@@ -15,11 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KW = dict(input_shape=[100, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="gvlad", vlad_clusters=4,
           ghost_clusters=1, disc_enable=True, ctc_enable=True, bpe_classes=30, max_ctc_len=6, metric_loss="arcface")
+# the bf16 mode needs res_filters = 32; hidden_dim 256 takes the MFMA recurrence
+KW16 = dict(KW, res_filters=32, hidden_dim=256)
 GLOBAL_B = 6
 STEPS = 3
 
 
-def _worker(rank, world, port, q, backend="gloo", via_gpus=False):
+def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SAR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
@@ -29,11 +31,15 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False):
     from oracle import model_torch as MT                     # test infrastructure: synthetic batch generator only
     if not via_gpus:
         parallel.init_from_env()
+    kw = KW16 if mode == "bf16" else KW
+    if mode == "bf16":
+        from aesrc2020_amd import _lib
+        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
     with contextlib.redirect_stdout(io.StringIO()):
         # different seeds: rank 0's weights must win (broadcast).  via_gpus: the reference's own switch (model.py:193-194) --
         # SAR_Net joins the process group itself and the train_model shards the GLOBAL batch
-        model, tm = SAR_Net(seed=10 + rank, gpus=world if via_gpus else 1, **KW)
-    cfg = MT.Cfg(**KW)
+        model, tm = SAR_Net(seed=10 + rank, gpus=world if via_gpus else 1, **kw)
+    cfg = MT.Cfg(**kw)
     out = []
     for i in range(STEPS):
         gb = MT.synthetic_batch(cfg, GLOBAL_B, seed=300 + i)
@@ -48,9 +54,10 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,via_gpus", [("gloo", False), ("gloo", True), ("nccl", True)],
-                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)"])
-def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus):
+@pytest.mark.parametrize("backend,via_gpus,mode", [("gloo", False, "fp32"), ("gloo", True, "fp32"), ("nccl", True, "fp32"), ("gloo", True, "bf16"),
+                                                   ("nccl", True, "bf16")],
+                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16-mode", "rccl-bf16-mode"])
+def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode):
     import torch.multiprocessing as mp
     from aesrc2020_amd import parallel
     from aesrc2020_amd.model import SAR_Net
@@ -58,15 +65,24 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus):
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus)) % 2000
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus)) for r in range(2)]
+    q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus) + 3 * len(mode)) % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus, mode)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
     (_, r0, g0), (_, r1, g1) = res
     assert g0 == ["adam", "heads", "trunk0", "trunk1", "trunk2"] and g1 == g0      # steps 2.. ran from the five captured graphs
-    single, _ = SAR_Net(seed=99, **KW)
-    cfg = MT.Cfg(**KW)
+    from aesrc2020_amd import _lib
+    kw = KW16 if mode == "bf16" else KW
+    # bf16 mode: the shard runs of the reference see other atomic orders in the statistic bins -- agreement to bf16 noise
+    tol = 2.5e-1 if mode == "bf16" else 2e-2
+    if mode == "bf16":
+        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    try:
+        single, _ = SAR_Net(seed=99, **kw)
+    finally:
+        _lib.set_trunk_dtype("fp32")
+    cfg = MT.Cfg(**kw)
     st = single.store
     for i in range(STEPS):
         a, b = r0[i], r1[i]
@@ -85,5 +101,6 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus):
         # (observed: 1e-6 typically, up to 5e-3 when a flip happens on these 3-utterance shards; a missed or doubled bucket
         # would show as O(1))
         err = float(np.linalg.norm(a["grads"] - gsum) / np.linalg.norm(gsum))
-        assert err < 2e-2, (i, err)
+        assert err < tol, (i, err)
         assert not np.array_equal(a["p_before"], a["p_after"])
+    _lib.set_gemm_math("fp32")
