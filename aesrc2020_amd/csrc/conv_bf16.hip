@@ -471,13 +471,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
 // ---------------------------------------------------------------------------------------------------- weight gradient
 // dw[tap][ci][co] += sum over pixels of A[pixel + tap][ci] * dY[pixel][co] on PLAIN bf16 operands: A = the activated tensor the
 // forward conv's fill wrote back (ConvP::side; the raw tensor for shortcuts / the first conv), dY = the gradient tensor (for
-// conv1 of a block: the BatchNorm-backward the input-gradient conv's fill wrote back).  Both arrive by LDS-DMA, 64-pixel chunks,
-// three chunks in flight, and feed the MFMA through ds_read_b64_tr_b16; no VALU work on the data at all.
+// conv1 of a block: the BatchNorm-backward the input-gradient conv's fill wrote back).  Both arrive by LDS-DMA in 64-pixel
+// chunks and feed the MFMA through ds_read_b64_tr_b16 (hardware transpose); no VALU work on the data at all.
 // ONE launch computes the weight gradients of MANY convolutions (they are off the critical path of the backward pass, so the
-// trunk runs them at the end of each backward part): a block takes one work item = (convolution, 32 input x 32 output
-// channels, a run of pixel chunks) from a table the host planned (sar_wgrad_plan_bf16: longest items first, runs sized so the
-// whole launch is ~3 blocks per CU), KK waves = one per tap, and adds its 32x32 tiles into the gradient (fp32 atomics when the
-// convolution's pixels are split over several items, plain read-add-write otherwise).
+// trunk runs them at the end of each backward part): a block takes one work item = (convolution, channel tile, a run of pixel
+// chunks) from a table the host planned (sar_wgrad_plan_bf16: longest items first) and adds its tiles into the gradient --
+// fp32 atomics when the convolution's pixels are split over several items, plain read-add-write otherwise.
 struct WgConv {                 // device table row, written by sar_wgrad_plan_bf16 (128 bytes)
     Geo g; int Cout;
     const u16* x; const u16* dy; float* dw; float* dbias;
@@ -489,114 +488,52 @@ struct WgConv {                 // device table row, written by sar_wgrad_plan_b
 static_assert(sizeof(WgConv) <= 128, "WgConv must fit its 128-byte table row");
 struct WgItem { int conv, ci0, co0, c_first, c_count, single, pad0_, pad1_; };   // 32 bytes
 __device__ uint4 g_zero_page[64];
-constexpr int WG_NBUF = 4;      // chunk buffers (three chunks in flight behind the one being multiplied)
-constexpr int WG_TR = 6;        // geometry-table ring: a chunk's tables are written four steps before its operands are read
-constexpr int WG_MAXNI = 4;     // DMA wave-instructions per wave and chunk, 9-wave blocks (8 for the single-wave 1x1 blocks; planner checks)
-constexpr int WG_ROWS = 64;     // patch rows per chunk the row table holds (planner checks)
-constexpr int WG_TAB_BYTES = WG_TR * (64 + WG_ROWS) * 4;
+constexpr int WG_NBUF = 4;      // 1x1: chunk buffers per wave (three chunks in flight behind the one being multiplied)
+constexpr int WG_TAB_MAX = 6144; // 3x3: positions in an item's source-offset table (24 KB of LDS at most)
+constexpr int WG_NW1 = 4;       // 1x1: independent waves per block, each on its own share of the item's chunks (merged in LDS at the end)
 
 __device__ __forceinline__ s16x4 lds_tr(const unsigned char* base, unsigned off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
 }
 
-constexpr int WG_TAB_MAX = 6144; // 3x3: positions in an item's source-offset table (24 KB of LDS at most)
-constexpr int WG_NW1 = 4;       // 1x1: independent waves per block, each on its own share of the item's chunks (merged in LDS at the end)
-
-template <int KK>
-__global__ __launch_bounds__(KK == 1 ? WG_NW1 * 64 : KK * 64) void wgrad_bf16_kernel(const unsigned char* __restrict__ convs, const WgItem* __restrict__ items,
-                                                             const uint4* __restrict__ zero, const unsigned buf_bytes) {
+// 1x1 convolutions (the shortcuts, resnet.py:82-87): the "patch" of a chunk is its 64 pixels (strided gather for stride 2).  A
+// block's four waves split the item's chunks and never synchronise inside the loop: each wave runs its own DMA ring (8 KB per
+// chunk: dY [64][32] | x [64][32]) and waits on its own vmcnt; the four 32 x 32 tiles are merged in LDS at the end.
+__global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned char* __restrict__ convs, const WgItem* __restrict__ items,
+                                                                 const uint4* __restrict__ zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr unsigned BUF = 8192;
     const WgItem it = items[blockIdx.x];
     const WgConv* cvp = reinterpret_cast<const WgConv*>(convs + (size_t)it.conv * 128);
     const Geo g = cvp->g;                                                          // by value: scalar registers for the whole kernel
-    const int Cout = cvp->Cout, cap_pos = cvp->cap_pos;
+    const int Cout = cvp->Cout;
     const u16* __restrict__ xp = cvp->x; const u16* __restrict__ dyp = cvp->dy;
     float* dwp = cvp->dw; float* dbp = cvp->dbias;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = KK == 1 ? 0 : wv;                                                // tap of this wave
     const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M;
-    // 3x3: the KK waves share every chunk (one tap each).  1x1: the block's WG_NW1 waves split the item's chunks and never
-    // synchronise inside the loop
-    const int cw = KK == 1 ? (it.c_count + WG_NW1 - 1) / WG_NW1 : it.c_count;
-    const int c_first = it.c_first + (KK == 1 ? wv * cw : 0);
-    const int nmine = KK == 1 ? max(0, min(cw, it.c_count - wv * cw)) : it.c_count;
-    unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [WG_TR][64]: patch byte offset of every pixel
-    unsigned* rring = qring + WG_TR * 64;                                         // [WG_TR][WG_ROWS]: source offset of every patch row
-    unsigned char* bufs = smem + (KK == 1 ? (size_t)wv * WG_NBUF * buf_bytes : (size_t)WG_TAB_BYTES);   // [WG_NBUF]: dY [64][32] | patch [pos][32]
+    const int cw = (it.c_count + WG_NW1 - 1) / WG_NW1;
+    const int c_first = it.c_first + wv * cw, nmine = max(0, min(cw, it.c_count - wv * cw));
+    unsigned char* bufs = smem + (size_t)wv * WG_NBUF * BUF;
     const unsigned bufs0 = lds_addr(bufs);
-    // DMA wave-instructions per chunk: 4 (dY) + cap_pos/16 (patch), dealt to the KK waves; every wave issues the same count
-    // NI (the surplus ones repeat the block's last instruction: same source, same destination)
-    const int nblk_i = 4 + cap_pos / 16, NI = (nblk_i + KK - 1) / KK;
-    TSTAMP(0); TSTAMP(1);
-
-    // ---- geometry tables of one chunk (3x3 only): 64 threads the pixel offsets, 64 threads the patch rows
-    auto tables = [&](int lc) __attribute__((always_inline)) {
-        if constexpr (KK != 1) {
-            if (tid < 128) {
-                const unsigned mc0 = (unsigned)(c_first + lc) * 64;
-                const int slot = lc % WG_TR;
-                unsigned Rp_lo, wtmp;
-                pix_rp(g, mc0, Rp_lo, wtmp);
-                if (tid < 64) {
-                    unsigned Rp, wq;
-                    pix_rp(g, min(mc0 + tid, M - 1), Rp, wq);
-                    unsigned q = ((Rp - Rp_lo) * g.Wp + wq) * 64;
-                    if (mc0 + tid >= M || q + ((g.K - 1) * g.Wp + g.K) * 64 > (unsigned)cap_pos * 64) q = 0;   // past the batch: its dY row is zero
-                    qring[slot * 64 + tid] = q;
-                } else {
-                    const unsigned Rp = Rp_lo + (tid - 64), b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
-                    const int u = (int)hp - g.pt;
-                    rring[slot * WG_ROWS + tid - 64] = (u >= 0 && u < g.Hs && b < (unsigned)g.B) ? ((b * g.Hs + u) * g.Ws) * g.Cin : NONE;
-                }
-            }
-        }
-    };
-    for (int k = 0; k < WG_NBUF && k < nmine; ++k) tables(k);
-    // ---- per-lane, chunk-independent part of every DMA piece this wave issues
-    constexpr int MAXNI = KK == 1 ? 8 : WG_MAXNI;
-    int jj[MAXNI]; unsigned prow_i[MAXNI], col_i[MAXNI], row_i[MAXNI];
-#pragma unroll
-    for (int i = 0; i < MAXNI; ++i) {
-        const int j = min(w + KK * i, nblk_i - 1);
-        jj[i] = j;
-        const unsigned piece = (j < 4 ? j : j - 4) * 64 + lane, c8 = piece & 3, row = piece >> 2;
-        row_i[i] = row;
-        if (j < 4) { prow_i[i] = 0; col_i[i] = co0 + c8 * 8; }
-        else if constexpr (KK == 1) { prow_i[i] = 0; col_i[i] = ci0 + c8 * 8; }
-        else {
-            const unsigned prow = udiv(row, g.mg_wp, (unsigned)g.Wp), wp = row - prow * g.Wp;
-            const int v = (int)wp - g.pl;
-            prow_i[i] = min(prow, (unsigned)WG_ROWS - 1);
-            col_i[i] = (v >= 0 && v < g.Ws && prow < (unsigned)WG_ROWS) ? (unsigned)v * g.Cin + ci0 + c8 * 8 : NONE;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (KK != 1) wg_barrier();
-    TSTAMP(2);
-
-    auto issue = [&](int lc) __attribute__((always_inline)) {
+    const unsigned row = lane >> 2, pc8 = (lane & 3) * 8;                          // a DMA instruction = 16 pixels x 32 channels
+    TSTAMP(0); TSTAMP(1); TSTAMP(2);
+    auto issue = [&](int lc) __attribute__((always_inline)) {                      // 8 instructions: 4 for dY, 4 for x
         const unsigned mc0 = (unsigned)(c_first + lc) * 64;
-        const unsigned dst0 = bufs0 + (unsigned)(lc % WG_NBUF) * buf_bytes;
+        const unsigned dst0 = bufs0 + (unsigned)(lc % WG_NBUF) * BUF;
 #pragma unroll
-        for (int i = 0; i < MAXNI; ++i) {
-            if (i < NI) {
-                const int j = jj[i];
-                const void* src;
-                if (j < 4) {                                       // dY rows
-                    const unsigned m = mc0 + row_i[i];
-                    src = m < M ? (const void*)(dyp + (size_t)m * Cout + col_i[i]) : (const void*)(zero + lane);
-                } else if constexpr (KK == 1) {                    // 1x1: the "patch" is the 64 pixels themselves
-                    unsigned Rp, wq;
-                    pix_rp(g, min(mc0 + row_i[i], M - 1), Rp, wq);
-                    const unsigned off = src_off(g, Rp, wq, mc0 + row_i[i] < M);
-                    src = off != NONE ? (const void*)(xp + off + col_i[i]) : (const void*)(zero + lane);
-                } else {
-                    const unsigned rb = rring[(lc % WG_TR) * WG_ROWS + prow_i[i]];
-                    src = (rb != NONE && col_i[i] != NONE) ? (const void*)(xp + rb + col_i[i]) : (const void*)(zero + lane);
-                }
-                dma16(src, dst0 + (unsigned)j * 1024);
+        for (int j = 0; j < 8; ++j) {
+            const unsigned m = mc0 + (j & 3) * 16 + row;
+            const void* src;
+            if (j < 4) {
+                src = m < M ? (const void*)(dyp + (size_t)m * Cout + co0 + pc8) : (const void*)(zero + lane);
+            } else {
+                unsigned Rp, wq;
+                pix_rp(g, min(m, M - 1), Rp, wq);
+                const unsigned off = src_off(g, Rp, wq, m < M);
+                src = off != NONE ? (const void*)(xp + off + ci0 + pc8) : (const void*)(zero + lane);
             }
+            dma16(src, dst0 + (unsigned)j * 1024);
         }
     };
     for (int k = 0; k < WG_NBUF - 1 && k < nmine; ++k) issue(k);
@@ -606,106 +543,63 @@ __global__ __launch_bounds__(KK == 1 ? WG_NW1 * 64 : KK * 64) void wgrad_bf16_ke
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     float bsum = 0.f;
-    const bool do_bias = dbp != nullptr && w == 0 && ci0 == 0;
-    const unsigned toff = KK == 1 ? 0u : (unsigned)(((w / g.K) * g.Wp + (w % g.K)) * 64);
+    const bool do_bias = dbp != nullptr && ci0 == 0;
     const int gi = lane & 15, gg = lane >> 4, cb = gg & 1, kh = gg >> 1;
     const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2;
     const unsigned prb = 8 * kh + (gi >> 2);
-
-    // Chunk loop, software-pipelined by one chunk: iteration lc waits for chunk lc's DMA, passes the barrier, starts the DMA
-    // of chunk lc+3, writes the tables of chunk lc+4, ISSUES the transpose-reads of chunk lc -- and multiplies chunk lc-1, whose
-    // operands were read one iteration earlier (LDS latency is hidden behind MFMAs and DMA issue).
-    bf16x8 Af[2][4], Bf[2][4];
-    auto read_ops = [&](int lc, bf16x8 (&A)[4], bf16x8 (&Bm)[4]) __attribute__((always_inline)) {
-        const unsigned char* buf = bufs + (size_t)(lc % WG_NBUF) * buf_bytes;
-        const unsigned* qtab = qring + (lc % WG_TR) * 64;
-        const unsigned char* dyt = buf;
-        const unsigned char* ap = buf + 64 * 64;
+    for (int lc = 0; lc < nmine; ++lc) {
+        // chunk lc has landed once at most min(nmine-1-lc, NBUF-2) younger chunks of this wave are still in flight (same wave
+        // issues and reads: its vmcnt orders the two)
+        wait_vm_n(8 * min(nmine - 1 - lc, WG_NBUF - 2));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the transpose-reads of chunk lc-1 are done: its slot is free
+        if (lc + WG_NBUF - 1 < nmine) issue(lc + WG_NBUF - 1);
+        const unsigned char* dyt = bufs + (size_t)(lc % WG_NBUF) * BUF;
+        const unsigned char* ap = dyt + 4096;
+        bf16x8 A[4], Bm[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const unsigned pr0 = 16 * ks + prb, pr1 = pr0 + 4;
-            const unsigned q0 = KK == 1 ? pr0 * 64 : qtab[pr0], q1 = KK == 1 ? pr1 * 64 : qtab[pr1];
-            const s16x4 b_lo = lds_tr(dyt, pr0 * 64 + colb), b_hi = lds_tr(dyt, pr1 * 64 + colb);
-            const s16x4 a_lo = lds_tr(ap, q0 + toff + colb), a_hi = lds_tr(ap, q1 + toff + colb);
+            const unsigned o0 = (16 * ks + prb) * 64 + colb, o1 = o0 + 4 * 64;
+            const s16x4 b_lo = lds_tr(dyt, o0), b_hi = lds_tr(dyt, o1), a_lo = lds_tr(ap, o0), a_hi = lds_tr(ap, o1);
             A[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
             Bm[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-    };
-    auto mma = [&](const bf16x8 (&A)[4], const bf16x8 (&Bm)[4]) __attribute__((always_inline)) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bm[0], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bm[1], acc2, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bm[2], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], Bm[3], acc2, 0, 0, 0);
-        if (do_bias) {                                             // wave-uniform (scalar branch)
+        if (do_bias) {                                             // block-uniform
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bsum += (float)Bm[ks][j];
         }
-    };
-    auto step = [&](int lc, bf16x8 (&An)[4], bf16x8 (&Bn)[4], const bf16x8 (&Ao)[4], const bf16x8 (&Bo)[4]) __attribute__((always_inline)) {
-        // chunk lc has landed once at most min(nmine-1-lc, NBUF-2) younger chunks of this wave are still in flight
-        wait_vm_n(NI * min(nmine - 1 - lc, WG_NBUF - 2));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's transpose-reads of chunk lc-1 are done
-        if constexpr (KK != 1) wg_barrier();       // everyone's pieces landed; everyone has read chunk lc-1
-        if (lc + WG_NBUF - 1 < nmine) issue(lc + WG_NBUF - 1);     // into the slot chunk lc-1 just left
-        if (lc + WG_NBUF < nmine) tables(lc + WG_NBUF);            // ring slot of chunk lc-2: last read two barriers ago
-        read_ops(lc, An, Bn);
-        if (lc > 0) mma(Ao, Bo);
-    };
-    int lc = 0;
-    for (; lc + 1 < nmine; lc += 2) {
-        step(lc, Af[0], Bf[0], Af[1], Bf[1]);
-        step(lc + 1, Af[1], Bf[1], Af[0], Bf[0]);
     }
-    if (lc < nmine) { step(lc, Af[0], Bf[0], Af[1], Bf[1]); mma(Af[0], Bf[0]); }
-    else if (nmine > 0) mma(Af[1], Bf[1]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     TSTAMP(4);
-    // ---- flush: dw[tap][ci0+row][co0+col] += acc
-    if constexpr (KK == 1) {
-        // merge the waves' tiles in LDS (each wave's own first buffer: its transpose-reads are done), then one add per element
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        float* mine = reinterpret_cast<float*>(bufs);
+    // ---- merge the waves' tiles in LDS (each wave's own first buffer: its reads are done), then one add per element
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    float* mine = reinterpret_cast<float*>(bufs);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[r];
-        __syncthreads();
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[r];
+    __syncthreads();
 #pragma unroll
-        for (int e = tid; e < 1024; e += WG_NW1 * 64) {
-            float s = 0.f;
+    for (int e = tid; e < 1024; e += WG_NW1 * 64) {
+        float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < WG_NW1; ++k) s += reinterpret_cast<const float*>(smem + (size_t)k * WG_NBUF * buf_bytes)[e];
-            float* o = dwp + (size_t)(ci0 + (e >> 5)) * Cout + co0 + (e & 31);
-            if (it.single) *o += s; else atomicAdd(o, s);
-        }
-        if (do_bias) {
-            bsum += __shfl_xor(bsum, 32, 64);
-            if (lane < 32) atomicAdd(dbp + co0 + lane, bsum);
-        }
-    } else {
-        const int col = lane & 31;
-        float* o = dwp + ((size_t)w * g.Cin + ci0) * Cout + co0 + col;
-        if (it.single) {                                           // block-uniform: this item owns the tile
-            float old[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout, acc[r]);
-        }
-        if (do_bias) {
-            bsum += __shfl_xor(bsum, 32, 64);
-            if (lane < 32) atomicAdd(dbp + co0 + lane, bsum);
-        }
+        for (int k = 0; k < WG_NW1; ++k) s += reinterpret_cast<const float*>(smem + (size_t)k * WG_NBUF * BUF)[e];
+        float* o = dwp + (size_t)(ci0 + (e >> 5)) * Cout + co0 + (e & 31);
+        if (it.single) *o += s; else atomicAdd(o, s);
+    }
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lane < 32) atomicAdd(dbp + co0 + lane, bsum);
     }
     TSTAMP(5); TSTAMP(15);
 }
 
-// ---- 3x3 weight gradient, second form: rolling patch ring and up to 64 x 64 channel tiles ---------------------------------------
-// What the first batched form measured (profiles/r2_v8: 7.5 M L2 requests = 960 MB per launch for 300 MB of unique operands, L2 hit
+// ---- 3x3: rolling patch ring and up to 64 x 64 channel tiles --------------------------------------------------------------------
+// What the first batched form (one private 160-position patch per chunk, 32 x 32 tiles) measured (profiles/r2_v8_wgrad_pmc.txt: 7.5 M L2 requests = 960 MB per launch for 300 MB of unique operands, L2 hit
 // rate 24 %, 2.7 TB/s through the fabric, 260 us): every 64-pixel chunk fetched its whole padded patch -- 160 positions for 64 pixels,
 // the halo rows and the partial rows again with the next chunk -- and every 32-channel tile fetched 64-byte halves of 128+-byte rows.
 // Here a block streams its run of pixels through ONE circular buffer of padded positions per 32-channel plane: consecutive chunks
@@ -1187,7 +1081,7 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
         tmp.x = static_cast<const u16*>(c.x); tmp.dy = static_cast<const u16*>(c.dy); tmp.dw = c.dw; tmp.dbias = c.dbias;
         tmp.nchunks = cdiv(tmp.g.M, 64);
         tmp.cap_pos = K == 1 ? 64 : (patch_rows_bound(tmp.g, 64 < tmp.g.M ? 64 : tmp.g.M) * tmp.g.Wp + 15) & ~15;
-        tmp.la = WG_NBUF - 1;
+        tmp.la = 3;
         // 3x3: DMA instructions of an item's first chunk (the whole patch) dealt to nine waves: at most 4 each
         return K == 1 || 4 * tile_co + (tmp.cap_pos / 16 + 1) * tile_ci <= 36;
     };
@@ -1254,7 +1148,7 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
         tab_pos = (tab_pos + 127) & ~127;
         launch4[0] = 512 + tab_pos * 4 + (la_max + 1) * tile_co * 4096 + tile_ci * np * 64; launch4[1] = np; launch4[2] = la_max + 1;
     } else {
-        launch4[0] = WG_NW1 * WG_NBUF * (64 * 64 + 64 * 64); launch4[1] = 0; launch4[2] = WG_NBUF;
+        launch4[0] = WG_NW1 * WG_NBUF * 8192; launch4[1] = 0; launch4[2] = WG_NBUF;
     }
     launch4[3] = (tile_ci << 4) | tile_co;
     return launch4[0] <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
@@ -1283,12 +1177,11 @@ int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, in
         if (!attr3[tci - 1][tco - 1]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr3[tci - 1][tco - 1] = true; }
         hipLaunchKernelGGL(kern, dim3(n_items), dim3(576), lds_bytes, stream, a);
     } else {
-        if (tci != 1 || tco != 1 || nbuf != WG_NBUF || lds_bytes % (WG_NW1 * WG_NBUF)) return SAR_EINVAL;
-        const unsigned buf_bytes = (unsigned)lds_bytes / (WG_NW1 * WG_NBUF);
+        if (tci != 1 || tco != 1 || nbuf != WG_NBUF || lds_bytes != WG_NW1 * WG_NBUF * 8192) return SAR_EINVAL;
         static bool attr1 = false;
-        if (!attr1) { if (!allow_lds(wgrad_bf16_kernel<1>, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
-        hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
-                           static_cast<const WgItem*>(items_dev), zero_page, buf_bytes);
+        if (!attr1) { if (!allow_lds(wgrad1_bf16_kernel, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
+        hipLaunchKernelGGL(wgrad1_bf16_kernel, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
+                           static_cast<const WgItem*>(items_dev), zero_page);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;

@@ -138,7 +138,7 @@ def conv_roofline(model, B, iters=10):
             sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
                 plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1))
-                nm = ("wgrad3_bf16_kernel<2, 2>" if cls[2] else "wgrad3_bf16_kernel<1, 1>") if cls[0] == 3 else "wgrad_bf16_kernel<1>"
+                nm = ("wgrad3_bf16_kernel<2, 2>" if cls[2] else "wgrad3_bf16_kernel<1, 1>") if cls[0] == 3 else "wgrad1_bf16_kernel"
                 c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["bytes"] += sum(w_[2] for w_ in sel); c["launches"] += 1
     total = sum(c["time"] for c in classes.values())

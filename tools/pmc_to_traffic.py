@@ -22,7 +22,7 @@ out = {"source": src, "note": "per-launch average over all dispatches of the ker
        "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 # bf16 trunk: bench.py's classes ARE the kernel instantiations
 for k, d in vals.items():
-    m = re.search(r"((?:conv_bf16_kernel|wgrad3_bf16_kernel|wgrad_bf16_kernel)<[^>]*>)", k)
+    m = re.search(r"((?:conv_bf16_kernel|wgrad3_bf16_kernel|wgrad1_bf16_kernel)(?:<[^>]*>)?)", k)
     if m and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
         out["bf16:" + m.group(1)] = {"kernel": m.group(1), "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}
