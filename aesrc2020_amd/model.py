@@ -87,6 +87,9 @@ class SARNetModel:
         self.name = c["name"] or "model"
         T, D, _ = c["input_shape"]
         H, A = c["hidden_dim"], c["accent_classes"]
+        if H < 1 or H > 256 or H % 4:
+            raise ValueError("hidden_dim must be a multiple of 4 in [4, 256] for the gfx950 GRU kernels (got %r; the reference's "
+                             "default is 256, model.py:204)" % (H,))
         with store_scope(self.store):
             inputs = Input(shape=c["input_shape"], name="x_data")
             fn = {"res18": resnet18_, "res34": resnet34_, "res50": resnet50_, "res101": resnet101_, "res152": resnet152_}
@@ -577,20 +580,26 @@ class SARNetModel:
         self.store.load_state_dict(d, True, False)
 
     def fit_generator(self, generator, steps_per_epoch, epochs=1, callbacks=None, initial_epoch=0, validation_data=None,
-                      max_queue_size=10, verbose=1, log_every=50):
-        """Keras fit_generator subset used by train.py:38-44 (single feeding thread; callbacks get Keras-style logs)."""
+                      max_queue_size=10, verbose=1, log_every=50, **keras_kwargs):
+        """Keras fit_generator as train.py:38-44 uses it (single feeding thread; callbacks get Keras-style logs).  Returns a
+        History: `.history` = {log name: [value per epoch]}, `.epoch` = epoch indices; it also iterates / indexes as the list of
+        per-epoch log dicts.  Keras keywords that have no meaning here (workers, use_multiprocessing, validation_steps,
+        class_weight, shuffle) are accepted and ignored."""
         from .callbacks import CallbackList
         from .utils import Prefetcher
+        unknown = set(keras_kwargs) - {"workers", "use_multiprocessing", "validation_steps", "class_weight", "shuffle", "validation_freq"}
+        if unknown:
+            raise TypeError("fit_generator() got unexpected keyword arguments %s" % sorted(unknown))
         cbs = CallbackList(callbacks or [], self)
         cbs.on_train_begin()
-        history = []
+        logs = []
         feed = Prefetcher(generator, max_queue_size)                         # Keras: one feeding thread, bounded queue
         try:
-            history = self._fit_loop(feed, steps_per_epoch, epochs, cbs, initial_epoch, validation_data, verbose, log_every)
+            logs = self._fit_loop(feed, steps_per_epoch, epochs, cbs, initial_epoch, validation_data, verbose, log_every)
         finally:
             feed.close()
         cbs.on_train_end()
-        return history
+        return History(logs, initial_epoch)
 
     def _fit_loop(self, generator, steps_per_epoch, epochs, cbs, initial_epoch, validation_data, verbose, log_every):
         history = []
@@ -662,6 +671,18 @@ class SARNetModel:
                     outs[k].append(self.out[k].detach().cpu().numpy().copy())
         res = [np.concatenate(outs[k]) for k in self.output_names]
         return res if len(res) > 1 else res[0]
+
+
+class History(list):
+    """keras.callbacks.History as fit_generator returns it (`.history`, `.epoch`), on top of the list of per-epoch log dicts."""
+
+    def __init__(self, logs, initial_epoch=0):
+        super().__init__(logs)
+        self.epoch = list(range(initial_epoch, initial_epoch + len(logs)))
+        self.history = {}
+        for l in logs:
+            for k, v in l.items():
+                self.history.setdefault(k, []).append(v)
 
 
 def SAR_Net(input_shape, ctc_enable=False, ar_enable=True, disc_enable=False, res_type="res18", res_filters=64,
@@ -736,5 +757,10 @@ def ctc_pred(model, x, batch_size, input_len):
             dec = torch.empty(B, L, dtype=torch.int32, device="cuda"); dl = torch.empty(B, dtype=torch.int32, device="cuda")
             _call("sar_ctc_greedy_decode_f32", model.out["ctc_pred"], il, dec, dl, B, L, V)
             dec, dl = dec.cpu().numpy(), dl.cpu().numpy()
-            res += [dec[b, :dl[b]].tolist() for b in range(B)]
-    return res
+            res += [dec[b, :dl[b]] for b in range(B)]
+    # K.get_value(K.ctc_decode(...)[0][0]) (model.py:385-389): one dense int array, rows padded with -1 to the longest decoding
+    width = max([len(r) for r in res] + [0])
+    out = np.full((len(res), width), -1, dtype=np.int64)
+    for i, r in enumerate(res):
+        out[i, :len(r)] = r
+    return out

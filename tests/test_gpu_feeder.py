@@ -104,8 +104,12 @@ def test_fit_generator_with_device_feeder(tmp_path):
     p0 = model.store.params.clone()
     with contextlib.redirect_stdout(io.StringIO()):
         hist = tm.fit_generator(generator=gen, steps_per_epoch=3, epochs=3, initial_epoch=0, validation_data=(dev_x, dev_y),
-                                max_queue_size=4, callbacks=[ReduceLROnPlateau(monitor="val_y_accent_acc", factor=0.5, patience=1),
-                                                             EarlyStopping(monitor="val_y_accent_acc", patience=5)])
+                                max_queue_size=4, workers=1, use_multiprocessing=False,       # Keras keywords without meaning here
+                                callbacks=[ReduceLROnPlateau(monitor="val_y_accent_acc", factor=0.5, patience=1),
+                                           EarlyStopping(monitor="val_y_accent_acc", patience=5)])
+    assert hist.epoch == [0, 1, 2] and len(hist.history["loss"]) == 3 and "val_loss" in hist.history   # keras History
+    with pytest.raises(TypeError):
+        tm.fit_generator(generator=gen, steps_per_epoch=1, no_such_keyword=1)
     assert len(hist) == 3 and all(np.isfinite(h["loss"]) and np.isfinite(h["val_loss"]) for h in hist)
     assert {"val_y_accent_acc", "val_y_disc_acc", "y_ctc_loss_loss", "lr"} <= set(hist[-1])
     assert not torch.equal(p0, model.store.params)
