@@ -177,6 +177,10 @@ def bn_bins():
     return lib().fn["sar_bn_bins"]()
 
 
+def stem16_wgrad_workspace_bytes(C0):
+    return lib().fn["sar_stem16_wgrad_workspace_bytes"](C0)
+
+
 def bn_workspace_doubles(C):
     """Length (in float64 elements) of the BatchNorm reduction workspace for C channels."""
     return (lib().fn["sar_bn_workspace_bytes"](C) + 7) // 8

@@ -1,0 +1,676 @@
+// The stem of the bf16 trunk on gfx950: 7x7/2 conv (Cin = 1) -> BatchNorm -> ReLU -> MaxPool 3x3/2 'same'
+// (resnet.py:173-174 / 191-192, _conv_bn_relu resnet.py:34-45), forward and backward, WITHOUT the full-resolution map.
+//
+// At B=64 the conv output is 64 x 200 x 40 x 64 = 131 MB in fp32 (round 1 wrote it once and read it twice: 257 us per step for
+// 4 GFLOP).  The conv is 49 multiply-adds per output on an 8 MB input, so it is recomputed wherever it is needed instead:
+//   forward  pass 1 (stem16_stats):  conv tile on MFMA -> per-channel sum / sum of squares -> the BatchNorm's statistic bins
+//            pass 2 (stem16_pool):   conv tile again -> BatchNorm + ReLU from the bins -> 3x3/2 max-pool from an LDS tile ->
+//                                    pooled map (bf16, 16 MB) + argmax slots (u8) -- the only tensors that reach HBM
+//   backward pass 1 (stem16_bwd_reduce): the two BatchNorm-backward sums from (gradient, pooled, slots): where ReLU is active the
+//                                    pooled value IS gamma*xhat + beta, so xhat follows from it
+//            pass 2 (stem16_wgrad):  conv tile a third time -> xhat -> dy = BatchNorm/ReLU/pool backward per pixel (<= 4 candidate
+//                                    windows from an LDS image of the pooled window) -> dW += patches^T dy on MFMA, both operands
+//                                    through transpose-reads of wave-private pixel-major LDS images; per-block partial tiles,
+//                                    summed by stem16_wsum
+// MFMA view of the conv (v_mfma_f32_32x32x16_bf16): rows = output channels (A = kernel fragments, held in registers), columns =
+// 32 output pixels, k = ky*8 + kx (kx = 7 and ky = 7 are zero kernel entries): the B fragment of a pixel is 8 consecutive bf16 of
+// input row 2*oy + ky starting at column 2*ox -- four aligned dwords of the LDS patch, no gather.  Input and kernel are rounded
+// to bf16 (the "bf16" mode of BASELINE configs[1]); accumulation, statistics and the kernel gradient are fp32.
+#include "trunk16.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+struct StemG {
+    int B, T, D;                // input (B, T, D) fp32 (the reference's (B, T, 80, 1))
+    int Ho, Wo, C0;             // conv output; C0 = 32 * NT
+    int pt, pl;                 // TF-SAME padding in front
+    int Hp, Wp, ppt, ppl;       // pooled output, pool padding in front
+    int TR;                     // rows per tile: conv rows (stats, wgrad) / pooled rows (pool)
+    int tiles;                  // tiles per image
+    int pld;                    // patch row pitch in bf16 elements (even): 2*(Wo-1) + 8
+    int patch_bytes;            // LDS bytes reserved for the patch
+    int fast;                   // D and pl even, pld <= 128: the patch fill may use 8-byte loads, one column pair per thread
+    unsigned mg_wo;
+};
+
+constexpr int IP = 80;          // bytes per pixel row of a 32-channel bf16 LDS image: 64 + 16, so the 16-byte stores of 16 consecutive pixels hit 64 different banks
+constexpr int PLANE = 32 * IP;  // one 32-pixel x 32-channel image
+constexpr int ZP = 32 * 4 + 16; // bytes per pixel row of the fp32 activation tile (32 channels per pass): conflict-free 16-byte stores
+
+// ---- kernel fragments.  wa[ct][s] = w[ky = 2s + h][kx = 0..7][channel ct*32 + lane%32] (zero for ky = 7 / kx = 7), h = lane/32.
+// The block gathers them once (7*NT loads per thread, all in flight), rounds to bf16 and parks them in LDS as ready fragments
+// [ct*4 + s][lane][16 B]; every wave then reads its NT*4 fragments with ds_read_b128.
+template <int NT> struct WStage { float v[NT][7]; };
+template <int NT>
+__device__ __forceinline__ void stem_w_load(WStage<NT>& ws, const float* __restrict__ w, int tid) {
+    constexpr int C0 = NT * 32;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int fl = tid + 256 * i, f = fl >> 6, ln = fl & 63, ct = f >> 2, s = f & 3, ky = min(2 * s + (ln >> 5), 6);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) ws.v[i][j] = w[(ky * 7 + j) * C0 + ct * 32 + (ln & 31)];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stem_w_store(const WStage<NT>& ws, unsigned char* wfr, int tid) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int fl = tid + 256 * i, f = fl >> 6, ln = fl & 63, s = f & 3;
+        const bool ok = 2 * s + (ln >> 5) < 7;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o[j] = (__bf16)(ok ? ws.v[i][j] : 0.f);
+        o[7] = (__bf16)0.f;
+        *reinterpret_cast<bf16x8*>(wfr + fl * 16) = o;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stem_w_frags(bf16x8 (&wa)[NT][4], const unsigned char* wfr, int lane) {
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wa[ct][s] = *reinterpret_cast<const bf16x8*>(wfr + ((ct * 4 + s) * 64 + lane) * 16);
+}
+
+// ---- input patch.  patch[r][c] = bf16(x[n][row0 + r][c - pl]) (zero outside the image), r < nprow, c < pld.
+// Fast form (g.fast: D and pl even, pld <= 128, nprow <= 4*ITER): a thread owns one column pair and ITER rows, all its 8-byte
+// loads in flight before the first LDS store.
+template <int ITER> struct XStage { float2 v[ITER]; };
+template <int ITER>
+__device__ __forceinline__ void stem_x_load(XStage<ITER>& xs, const float* __restrict__ x, const StemG& g, int n, int row0, int nprow, int tid) {
+    const float* xb = x + (size_t)n * g.T * g.D;
+    const int c = 2 * (tid & 63), w0 = c - g.pl;
+    const bool cok = c < g.pld && w0 >= 0 && w0 < g.D;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int r = (tid >> 6) + 4 * i, hi = row0 + r;
+        const bool ok = cok && r < nprow && hi >= 0 && hi < g.T;
+        const float2 v = *reinterpret_cast<const float2*>(xb + (size_t)(ok ? hi : 0) * g.D + (ok ? w0 : 0));
+        xs.v[i] = ok ? v : make_float2(0.f, 0.f);
+    }
+}
+template <int ITER>
+__device__ __forceinline__ void stem_x_store(const XStage<ITER>& xs, u16* patch, const StemG& g, int nprow, int tid) {
+    const int c = 2 * (tid & 63);
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int r = (tid >> 6) + 4 * i;
+        if (r < nprow && c < g.pld) *reinterpret_cast<unsigned*>(patch + r * g.pld + c) = pack2(xs.v[i].x, xs.v[i].y);
+    }
+}
+// general form: any D / padding, two columns per thread, one row group at a time
+__device__ __noinline__ void stem_fill_slow(u16* patch, const float* __restrict__ x, int T, int D, int pl, int pld, int n, int row0, int nprow, int tid) {
+    const float* xb = x + (size_t)n * T * D;
+    const int cp = tid & 63;
+    for (int r = tid >> 6; r < nprow; r += 4) {
+        const int hi = row0 + r;
+        const bool rok = hi >= 0 && hi < T;
+        const float* xr = xb + (size_t)(rok ? hi : 0) * D;
+        for (int c = 2 * cp; c < pld; c += 128) {
+            const int w0 = c - pl, w1 = w0 + 1;
+            const bool ok0 = rok && w0 >= 0 && w0 < D, ok1 = rok && w1 >= 0 && w1 < D;
+            const float v0 = xr[ok0 ? w0 : 0], v1 = xr[ok1 ? w1 : 0];
+            *reinterpret_cast<unsigned*>(patch + r * pld + c) = pack2(ok0 ? v0 : 0.f, ok1 ? v1 : 0.f);
+        }
+    }
+}
+// both: kernel fragments and patch of one tile into LDS; `mid` runs between the loads and the stores (the BatchNorm prologue)
+template <int NT, int ITER, typename MID>
+__device__ __forceinline__ void stem_stage(unsigned char* wfr, u16* patch, const float* __restrict__ x, const float* __restrict__ w, const StemG& g,
+                                           int n, int row0, int nprow, int tid, bool with_w, MID mid) {
+    WStage<NT> ws; XStage<ITER> xs;
+    const bool fast = g.fast && nprow <= 4 * ITER;                                  // block-uniform
+    if (with_w) stem_w_load<NT>(ws, w, tid);
+    if (fast) stem_x_load<ITER>(xs, x, g, n, row0, nprow, tid);
+    mid();
+    if (with_w) stem_w_store<NT>(ws, wfr, tid);
+    if (fast) stem_x_store<ITER>(xs, patch, g, nprow, tid);
+    else stem_fill_slow(patch, x, g.T, g.D, g.pl, g.pld, n, row0, nprow, tid);
+}
+
+// One 32-pixel column block: acc[ct] += W(ct) * patches for ct in [CT0, CT0 + NC); boff = (2*ty + h) * pld + 2*tx (bf16 index of
+// the lane's first element); lanes of pixels past the tile multiply zeros
+template <int NT, int CT0, int NC>
+__device__ __forceinline__ void stem_mtile(const bf16x8 (&wa)[NT][4], const u16* patch, int pld, unsigned boff, bool valid, f32x16 (&acc)[NC], bf16x8 (&bfr)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(patch + boff + 2 * s * pld);
+        const uint4 v = make_uint4(q[0], q[1], q[2], q[3]);
+        bfr[s] = __builtin_bit_cast(bf16x8, valid ? v : make_uint4(0u, 0u, 0u, 0u));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[CT0 + c][s], bfr[s], acc[c], 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------- forward pass 1: statistics
+template <int NT>
+__global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ bins, const StemG g) {
+    constexpr int C0 = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wfr = smem;                                                       // [NT*4][64][16 B]
+    u16* patch = reinterpret_cast<u16*>(smem + NT * 4096);
+    float* red = reinterpret_cast<float*>(smem + NT * 4096 + g.patch_bytes);         // [4 waves][2][C0]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int n = blockIdx.x / g.tiles, tr = blockIdx.x % g.tiles;
+    const int r0 = tr * g.TR, nr = min(g.TR, g.Ho - r0), npix = nr * g.Wo;
+    stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r0 - g.pt, 2 * (nr - 1) + 8, tid, true, [] {});
+    __syncthreads();
+    bf16x8 wa[NT][4];
+    stem_w_frags<NT>(wa, wfr, lane);
+    float s1[NT][16], s2[NT][16];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[ct][r] = 0.f; s2[ct][r] = 0.f; }
+    for (int mt = wave; mt * 32 < npix; mt += 4) {
+        const int p = mt * 32 + (lane & 31);
+        const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
+        f32x16 acc[NT]; bf16x8 bfr[4];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+        stem_mtile<NT, 0, NT>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, p < npix, acc, bfr);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1[ct][r] += acc[ct][r]; s2[ct][r] = fmaf(acc[ct][r], acc[ct][r], s2[ct][r]); }
+    }
+    // sum over the 32 pixels (lanes) that share h; lane%32 == 0 then holds the totals of its 16*NT channels
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = s1[ct][r], b = s2[ct][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if ((lane & 31) == 0) {
+                const int ch = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                red[(wave * 2 + 0) * C0 + ch] = a; red[(wave * 2 + 1) * C0 + ch] = b;
+            }
+        }
+    __syncthreads();
+    if (tid < 2 * C0) {
+        const int which = tid / C0, c = tid % C0;
+        float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { S1 += red[(wv * 2 + 0) * C0 + c]; S2 += red[(wv * 2 + 1) * C0 + c]; }
+        // the sums are of the raw products; the BatchNorm input is y = conv + bias
+        const float b = bias[c], np = (float)npix;
+        const float out = which == 0 ? S1 + np * b : S2 + 2.f * b * S1 + np * b * b;
+        atomicAdd(bins + ((blockIdx.x % NB) * 2 + which) * C0 + c, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward pass 2: BN + ReLU + max-pool
+// A tile = TR pooled rows x the full pooled width; the conv rows its windows touch (2*TR + 1) are recomputed, activated and kept
+// as an fp32 LDS tile [pixel][32 channels] (one pass per 32 channels); pooling reads the nine window positions from there.
+// Non-negative floats order like unsigned integers, so (bits & ~15 | 15 - slot) under max() yields the maximum AND its first window
+// slot in one operation (values closer than 2^-19 relative count as equal).  The comparison is in fp32 on purpose: a bf16 tile made
+// ~1 % of the windows pick a neighbour of the true maximum, a 7 % error of the kernel gradient against the float64 oracle.
+template <int NT>
+__global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const BnP bn, u16* __restrict__ pooled, uint8_t* __restrict__ idx, const StemG g) {
+    constexpr int C0 = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* cst = reinterpret_cast<float*>(smem);                                     // [4][C0]: scale, shift (+ scale*bias), mean, rstd
+    unsigned char* wfr = smem + 4 * C0 * 4;
+    u16* patch = reinterpret_cast<u16*>(wfr + NT * 4096);
+    unsigned char* zt = wfr + NT * 4096 + g.patch_bytes;                             // [pixel][ZP bytes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+    const int n = blockIdx.x / g.tiles, tile = blockIdx.x % g.tiles;
+    const int i0 = tile * g.TR, npr = min(g.TR, g.Hp - i0);
+    const int r_lo = max(2 * i0 - g.ppt, 0), r_hi = min(2 * (i0 + npr - 1) - g.ppt + 3, g.Ho);
+    const int nr = r_hi - r_lo, npix = nr * g.Wo;
+    stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r_lo - g.pt, 2 * (nr - 1) + 8, tid, true, [&] {
+        bn_prologue(bn, 1, C0, 0, C0, cst, C0, blockIdx.x == 0, 256);
+        for (int i = tid; i < C0; i += 256) cst[C0 + i] += cst[i] * bias[i];         // same thread wrote both entries
+    });
+    __syncthreads();
+    bf16x8 wa[NT][4];
+    stem_w_frags<NT>(wa, wfr, lane);
+    const int nitems = npr * g.Wp * 8;
+    auto pass = [&](auto ctc) __attribute__((always_inline)) {
+        constexpr int CT = decltype(ctc)::value;
+        for (int mt = wave; mt * 32 < npix; mt += 4) {
+            const int p = mt * 32 + (lane & 31);
+            const bool valid = p < npix;
+            const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
+            f32x16 acc[1]; bf16x8 bfr[4];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+            stem_mtile<NT, CT, 1>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int cl = 8 * gq + 4 * h, ch0 = CT * 32 + cl;
+                const float4 sc = *reinterpret_cast<const float4*>(cst + ch0), sh = *reinterpret_cast<const float4*>(cst + C0 + ch0);
+                float4 z;
+                z.x = fmaxf(fmaf(acc[0][gq * 4 + 0], sc.x, sh.x), 0.f); z.y = fmaxf(fmaf(acc[0][gq * 4 + 1], sc.y, sh.y), 0.f);
+                z.z = fmaxf(fmaf(acc[0][gq * 4 + 2], sc.z, sh.z), 0.f); z.w = fmaxf(fmaf(acc[0][gq * 4 + 3], sc.w, sh.w), 0.f);
+                if (valid) *reinterpret_cast<float4*>(zt + (size_t)p * ZP + cl * 4) = z;
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < nitems; it += 256) {
+            const int g4 = it & 7, pp = it >> 3, pj = pp % g.Wp, pi = pp / g.Wp;
+            unsigned k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int r = 2 * (i0 + pi) - g.ppt + kh, c = 2 * pj - g.ppl + kw;
+                    const bool ok = r >= r_lo && r < r_hi && c >= 0 && c < g.Wo;
+                    const uint4 q = *reinterpret_cast<const uint4*>(zt + (size_t)(ok ? (r - r_lo) * g.Wo + c : 0) * ZP + g4 * 16);
+                    const unsigned code = 15u - (unsigned)(kh * 3 + kw), m = ok ? 0xfffffff0u : 0u, cd = ok ? code : 0u;
+                    k0 = max(k0, (q.x & m) | cd); k1 = max(k1, (q.y & m) | cd); k2 = max(k2, (q.z & m) | cd); k3 = max(k3, (q.w & m) | cd);
+                }
+            const size_t o = (((size_t)n * g.Hp + i0 + pi) * g.Wp + pj) * C0 + CT * 32 + g4 * 4;
+            *reinterpret_cast<uint2*>(pooled + o) = make_uint2(pack2(__uint_as_float(k0 & ~15u), __uint_as_float(k1 & ~15u)),
+                                                               pack2(__uint_as_float(k2 & ~15u), __uint_as_float(k3 & ~15u)));
+            *reinterpret_cast<unsigned*>(idx + o) = (15u - (k0 & 15u)) | ((15u - (k1 & 15u)) << 8) | ((15u - (k2 & 15u)) << 16) | ((15u - (k3 & 15u)) << 24);
+        }
+    };
+    pass(std::integral_constant<int, 0>{});
+    if constexpr (NT == 2) {
+        __syncthreads();                                                             // the pooling reads of pass 0 are done
+        pass(std::integral_constant<int, 1>{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward pass 1: the two sums
+// conv output at one position, for the degenerate-gamma fallback below (never taken by a trained or freshly initialised model)
+__device__ __noinline__ float stem_point(const float* __restrict__ x, const float* __restrict__ w, float b, int T, int D, int pt, int pl, int C0, int n, int r, int c, int ch) {
+    float y = 0.f;
+    for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx) {
+            const int hi = 2 * r - pt + ky, wi = 2 * c - pl + kx;
+            if (hi < 0 || hi >= T || wi < 0 || wi >= D) continue;
+            const float xv = bf_lo(pack2(x[((size_t)n * T + hi) * D + wi], 0.f)), wv = bf_lo(pack2(w[(ky * 7 + kx) * C0 + ch], 0.f));
+            y = fmaf(xv, wv, y);
+        }
+    return y + b;
+}
+
+// bbins[bin][0][c] += sum dz, bbins[bin][1][c] += sum dz * xhat over the conv output, where dz is the pooled gradient routed to
+// the argmax position of every window whose maximum is positive (ReLU active).  There z = gamma*xhat + beta equals the pooled
+// value, so xhat = (pooled - beta) / gamma: one pass over the pooled tensors, no full-resolution operand.
+__global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
+                                                                const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ saved,
+                                                                float* __restrict__ bbins, int* __restrict__ counter, const StemG g, unsigned npix) {
+    __shared__ float r1[256 * 8], r2[256 * 8];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;                           // the tile counter of stem16_wgrad_kernel
+    const int C0 = g.C0, tpr = C0 / 8;
+    const int tid = threadIdx.x, cv = tid % tpr, pg = tid / tpr, npg = 256 / tpr;
+    float be[8], ig[8]; bool okc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float gm = gamma[cv * 8 + k];
+        be[k] = beta[cv * 8 + k]; okc[k] = fabsf(gm) > 1e-6f; ig[k] = okc[k] ? 1.f / gm : 0.f;
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
+        const size_t o = (size_t)pix * C0 + cv * 8;
+        const uint4 av = *reinterpret_cast<const uint4*>(pooled + o), gv = *reinterpret_cast<const uint4*>(gp + o);
+        float a[8], gg[8];
+        unpack8(av, a); unpack8(gv, gg);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (a[k] > 0.f) {
+                float xh;
+                if (okc[k]) xh = (a[k] - be[k]) * ig[k];
+                else {
+                    const int pj = pix % g.Wp, pi = (pix / g.Wp) % g.Hp, n = pix / (g.Wp * g.Hp), slot = idx[o + k], ch = cv * 8 + k;
+                    const float y = stem_point(x, w, bias[ch], g.T, g.D, g.pt, g.pl, C0, n, 2 * pi - g.ppt + slot / 3, 2 * pj - g.ppl + slot % 3, ch);
+                    xh = (y - saved[ch]) * saved[C0 + ch];
+                }
+                s1[k] += gg[k]; s2[k] = fmaf(gg[k], xh, s2[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { r1[tid * 8 + k] = s1[k]; r2[tid * 8 + k] = s2[k]; }
+    __syncthreads();
+    if (tid < 2 * C0) {
+        const int which = tid / C0, c = tid % C0;
+        const float* rr = which ? r2 : r1;
+        float s = 0.f;
+        for (int q = 0; q < npg; ++q) s += rr[(q * tpr + c / 8) * 8 + (c & 7)];
+        atomicAdd(bbins + ((blockIdx.x % NB) * 2 + which) * C0 + c, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward pass 2: kernel gradient
+// part[block][ky*8 + kx][c] = this block's share of dW.  Per 32-pixel column block a wave recomputes the conv, turns it into
+// dy = A*dz + E*acc + F per channel (A = scale, E = -scale*c3*rstd, F = -scale*(c2 + c3*(bias - mean)*rstd): BatchNorm backward
+// with xhat = (acc + bias - mean)*rstd folded in), writes dy and its own B fragments (= the im2col rows of its pixels) as
+// pixel-major bf16 images into wave-private LDS and multiplies them through transpose-reads: no barrier inside a tile.
+// win[window][c] = (bf16 gradient of the window if its pooled value is positive) << 16 | argmax slot; a window's row is C0 + 4
+// words so that the 16 windows the 32 pixels of a column block look at spread over all banks.
+// Tiles are handed out through an atomic counter (work[0], zeroed by the reduce pass in front of this kernel): blocks stay
+// resident, keep their accumulators, and the chip stays balanced whatever the tile count.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
+                                                           const BnP bn, int* __restrict__ counter, float* __restrict__ part, const StemG g, int ntiles,
+                                                           int win_bytes) {
+    constexpr int C0 = NT * 32, SCR = (2 + NT) * PLANE, WS = C0 + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_tile;
+    float* cst = reinterpret_cast<float*>(smem);                                     // [6][C0] from the prologue, then [3][C0]: A, E, F
+    float* aef = cst + 6 * C0;
+    unsigned char* wfr = smem + 9 * C0 * 4;
+    u16* patch = reinterpret_cast<u16*>(wfr + NT * 4096);
+    unsigned* win = reinterpret_cast<unsigned*>(wfr + NT * 4096 + g.patch_bytes);
+    unsigned char* scr0 = wfr + NT * 4096 + g.patch_bytes + win_bytes;               // [4 waves][SCR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    unsigned char* scr = scr0 + wave * SCR;
+    bf16x8 wa[NT][4];
+    f32x16 accw[2][NT];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw[tp][ct][r] = 0.f;
+    const int gi = lane & 15, gg = lane >> 4, cb = gg & 1, kh2 = gg >> 1;
+    const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2, prb = 8 * kh2 + (gi >> 2);
+    constexpr int G8 = C0 / 8;
+
+    // once per block: kernel fragments, BatchNorm constants
+    {
+        WStage<NT> ws;
+        stem_w_load<NT>(ws, w, tid);
+        bn_prologue(bn, 2, C0, 0, C0, cst, C0, blockIdx.x == 0, 256);
+        for (int i = tid; i < C0; i += 256) {
+            const float scale = cst[i], mean = cst[2 * C0 + i], rstd = cst[3 * C0 + i], c2 = cst[4 * C0 + i], c3 = cst[5 * C0 + i];
+            const float xb = (bias[i] - mean) * rstd, Cc = -scale * c3;
+            aef[i] = scale; aef[C0 + i] = Cc * rstd; aef[2 * C0 + i] = -scale * c2 + Cc * xb;
+        }
+        stem_w_store<NT>(ws, wfr, tid);
+        __syncthreads();
+        stem_w_frags<NT>(wa, wfr, lane);
+    }
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(counter, 1);
+        __syncthreads();                                                             // also: the previous tile's readers are done
+        const int tile = s_tile;
+        if (tile >= ntiles) break;
+        const int n = tile / g.tiles, tr = tile % g.tiles;
+        const int r0 = tr * g.TR, nr = min(g.TR, g.Ho - r0), npix = nr * g.Wo;
+        const int i_lo = max((r0 + g.ppt - 1) >> 1, 0), i_hi = min((r0 + nr - 1 + g.ppt) >> 1, g.Hp - 1), nwr = i_hi - i_lo + 1;
+        stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r0 - g.pt, 2 * (nr - 1) + 8, tid, false, [&] {
+            for (int it = tid; it < nwr * g.Wp * G8; it += 256) {
+                const int gch = it % G8, pp = it / G8;                               // pp = local window index (row-major over nwr x Wp)
+                const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + gch * 8;
+                const uint4 pv = *reinterpret_cast<const uint4*>(pooled + o), gv = *reinterpret_cast<const uint4*>(gp + o);
+                const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
+                const unsigned ps[4] = {pv.x, pv.y, pv.z, pv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+                unsigned o8[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // pooled >= 0 always (ReLU): positive <=> non-zero magnitude bits
+                    const unsigned s0 = ((k < 2 ? iv.x : iv.y) >> (16 * (k & 1))) & 255u, s1 = ((k < 2 ? iv.x : iv.y) >> (16 * (k & 1) + 8)) & 255u;
+                    o8[2 * k] = ((ps[k] & 0x7fffu) ? (gs[k] << 16) : 0u) | s0;
+                    o8[2 * k + 1] = ((ps[k] & 0x7fff0000u) ? (gs[k] & 0xffff0000u) : 0u) | s1;
+                }
+                unsigned* dst = win + (size_t)pp * WS + gch * 8;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+                *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+            }
+        });
+        __syncthreads();
+        for (int mt = wave; mt * 32 < npix; mt += 4) {
+            const int p = mt * 32 + q;
+            const bool valid = p < npix;
+            const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
+            f32x16 acc[NT]; bf16x8 bfr[4];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+            stem_mtile<NT, 0, NT>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
+            // the lane's B fragments ARE its pixel's im2col row (taps (2s+h)*8 .. +8): plane (2s+h)/4, 16 bytes at ((2s+h)%4)*16
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<bf16x8*>(scr + ((2 * s + h) >> 2) * PLANE + q * IP + ((2 * s + h) & 3) * 16) = bfr[s];
+            // candidate windows of the pixel: row a = r + ppt lies in window a>>1 at slot row a&1 and, a even, in window (a>>1)-1 at row 2
+            const int a = r0 + (int)ty + g.ppt, b = (int)tx + g.ppl, ho1 = a >> 1, wo1 = b >> 1;
+            const int hos[2] = {ho1, ho1 - 1}, khs[2] = {a & 1, 2}, wos[2] = {wo1, wo1 - 1}, kws[2] = {b & 1, 2};
+            const bool vh[2] = {ho1 < g.Hp, (a & 1) == 0 && ho1 >= 1}, vw[2] = {wo1 < g.Wp, (b & 1) == 0 && wo1 >= 1};
+            unsigned woff[4], slot[4];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int lr = min(max(hos[ii] - i_lo, 0), nwr - 1), lc = min(max(wos[jj], 0), g.Wp - 1);
+                    woff[ii * 2 + jj] = (unsigned)(lr * g.Wp + lc) * WS;
+                    slot[ii * 2 + jj] = (valid && vh[ii] && vw[jj]) ? (unsigned)(khs[ii] * 3 + kws[jj]) : 256u;   // 256: never a slot
+                }
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch0 = ct * 32 + 8 * gq + 4 * h;
+                    float dz[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(win + woff[c4] + ch0);
+                        dz[0] += (v.x & 255u) == slot[c4] ? __uint_as_float(v.x & 0xffff0000u) : 0.f;
+                        dz[1] += (v.y & 255u) == slot[c4] ? __uint_as_float(v.y & 0xffff0000u) : 0.f;
+                        dz[2] += (v.z & 255u) == slot[c4] ? __uint_as_float(v.z & 0xffff0000u) : 0.f;
+                        dz[3] += (v.w & 255u) == slot[c4] ? __uint_as_float(v.w & 0xffff0000u) : 0.f;
+                    }
+                    const float4 A4 = *reinterpret_cast<const float4*>(aef + ch0), E4 = *reinterpret_cast<const float4*>(aef + C0 + ch0),
+                                 F4 = *reinterpret_cast<const float4*>(aef + 2 * C0 + ch0);
+                    // lanes past the tile: acc = 0 and dz = 0, so F alone has to be masked
+                    const float d0 = fmaf(A4.x, dz[0], fmaf(E4.x, acc[ct][gq * 4 + 0], valid ? F4.x : 0.f));
+                    const float d1 = fmaf(A4.y, dz[1], fmaf(E4.y, acc[ct][gq * 4 + 1], valid ? F4.y : 0.f));
+                    const float d2 = fmaf(A4.z, dz[2], fmaf(E4.z, acc[ct][gq * 4 + 2], valid ? F4.z : 0.f));
+                    const float d3 = fmaf(A4.w, dz[3], fmaf(E4.w, acc[ct][gq * 4 + 3], valid ? F4.w : 0.f));
+                    *reinterpret_cast<uint2*>(scr + (2 + ct) * PLANE + q * IP + (8 * gq + 4 * h) * 2) = make_uint2(pack2(d0, d1), pack2(d2, d3));
+                }
+            // the wave's own LDS stores are ordered in front of its own reads (same queue); keep the compiler from reordering them
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned o0 = (16 * ks + prb) * IP + colb, o1 = o0 + 4 * IP;
+                bf16x8 Af[2], Bf[NT];
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    const s16x4 lo = lds_tr(scr + tp * PLANE, o0), hi = lds_tr(scr + tp * PLANE, o1);
+                    Af[tp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) {
+                    const s16x4 lo = lds_tr(scr + (2 + ct) * PLANE, o0), hi = lds_tr(scr + (2 + ct) * PLANE, o1);
+                    Bf[ct] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) accw[tp][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[tp], Bf[ct], accw[tp][ct], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the transpose-reads are done before the images are rewritten
+        }
+    }
+    // ---- merge the four waves' tiles in LDS (over patch / win / scratch: everything is dead), then one coalesced store
+    float* ot = reinterpret_cast<float*>(wfr);                                       // [64][C0]
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = tp * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col = ct * 32 + q;
+                        if (wv == 0) ot[row * C0 + col] = accw[tp][ct][r]; else ot[row * C0 + col] += accw[tp][ct][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float4* dst = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 64 * C0);
+    for (int i = tid; i < 64 * C0 / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(ot)[i];
+}
+
+// dw[(ky*7 + kx)][c] += sum over blocks of part[block][ky*8 + kx][c]; one block per tap
+__global__ __launch_bounds__(256) void stem16_wsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, int C0, int* __restrict__ counter) {
+    __shared__ float red[256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
+    const int t = blockIdx.x, row = (t / 7) * 8 + (t % 7);
+    const int c = threadIdx.x % C0, sl = threadIdx.x / C0, nsl = 256 / C0;
+    float s = 0.f;
+    for (int b = sl; b < nblk; b += nsl) s += part[((size_t)b * 64 + row) * C0 + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C0) {
+        float a = 0.f;
+        for (int k = 0; k < nsl; ++k) a += red[k * C0 + c];
+        dw[t * C0 + c] += a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- host side
+static inline unsigned magic(int d) { return d <= 1 ? 0xffffffffu : (unsigned)(0x100000000ULL / (unsigned long long)d); }
+
+static bool stem_geo(StemG& g, int B, int T, int D, int Ho, int Wo, int C0, int pt, int pl, int Hp, int Wp, int ppt, int ppl) {
+    if (B < 1 || T < 1 || D < 1 || Ho < 1 || Wo < 1 || (C0 != 32 && C0 != 64) || pt < 0 || pl < 0 || pt > 6 || pl > 6) return false;
+    if (Hp < 1 || Wp < 1 || ppt < 0 || ppt > 2 || ppl < 0 || ppl > 2) return false;
+    if ((long)B * Ho * Wo * 2 >= (1L << 31) || (long)B * T * D >= (1L << 31)) return false;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.T = T; g.D = D; g.Ho = Ho; g.Wo = Wo; g.C0 = C0; g.pt = pt; g.pl = pl; g.Hp = Hp; g.Wp = Wp; g.ppt = ppt; g.ppl = ppl;
+    g.pld = 2 * (Wo - 1) + 8;
+    g.mg_wo = magic(Wo);
+    g.fast = (D % 2 == 0 && pl % 2 == 0 && g.pld <= 128) ? 1 : 0;
+    return true;
+}
+static void stem_tiles(StemG& g, int TR, int rows, int conv_rows_per_tile) {
+    g.TR = TR; g.tiles = (rows + TR - 1) / TR;
+    g.patch_bytes = (((2 * (conv_rows_per_tile - 1) + 8) * g.pld * 2) + 15) & ~15;
+}
+template <typename KT>
+static bool allow_lds(KT kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+constexpr int WG_MAX_BLOCKS = 512;
+
+}  // namespace
+
+extern "C" {
+
+typedef BnP sarBnRef;
+
+// Forward pass 1: sum / sum of squares of y = conv7x7/2(x) + bias per channel, added into bins [sar_bn_bins()][2][C0] (zeroed by the
+// caller once per step, like every BatchNorm of the bf16 trunk).  x (B,T,D) fp32, w (7,7,1,C0) fp32 HWIO, C0 in {32, 64}.
+int sar_stem16_stats(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
+                     int pad_top, int pad_left, hipStream_t stream) {
+    StemG g;
+    if (!x || !w || !bias || !bins || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, 1, 1, 0, 0)) return SAR_EINVAL;
+    int TR = env_int("SAR_STEM_STATS_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
+    stem_tiles(g, TR, Ho, TR);
+    const size_t lds = (size_t)(C0 / 32) * 4096 + g.patch_bytes + 4 * 2 * C0 * 4;
+    if (lds > 160 * 1024) return SAR_EINVAL;
+    const int nblk = B * g.tiles;
+    if (C0 == 64) {
+        if (!allow_lds(stem16_stats_kernel<2>, lds)) return SAR_ELAUNCH;
+        hipLaunchKernelGGL(stem16_stats_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, bins, g);
+    } else {
+        if (!allow_lds(stem16_stats_kernel<1>, lds)) return SAR_ELAUNCH;
+        hipLaunchKernelGGL(stem16_stats_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, bins, g);
+    }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// Forward pass 2: pooled (B,Hp,Wp,C0) bf16 = maxpool3x3/2(relu(bn(conv(x) + bias))), idx (same shape, u8) = window slot kh*3+kw of the
+// first maximum.  bn: statistics from bn->bins (training; the launch with bn->write also stores saved / moving statistics) or
+// bn->saved (bins null: inference with folded moving averages).
+int sar_stem16_pool_fwd(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
+                        int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+    StemG g;
+    if (!x || !w || !bias || !bn || !pooled || !idx || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
+    int TR = env_int("SAR_STEM_POOL_ROWS", 3); TR = TR < 1 ? 1 : (TR > Hp ? Hp : TR);
+    const int crows = 2 * TR + 1;
+    stem_tiles(g, TR, Hp, crows);
+    const size_t lds = (size_t)4 * C0 * 4 + (size_t)(C0 / 32) * 4096 + g.patch_bytes + (size_t)crows * Wo * ZP;
+    if (lds > 160 * 1024) return SAR_EINVAL;
+    const int nblk = B * g.tiles;
+    if (C0 == 64) {
+        if (!allow_lds(stem16_pool_kernel<2>, lds)) return SAR_ELAUNCH;
+        hipLaunchKernelGGL(stem16_pool_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, *bn, static_cast<u16*>(pooled), idx, g);
+    } else {
+        if (!allow_lds(stem16_pool_kernel<1>, lds)) return SAR_ELAUNCH;
+        hipLaunchKernelGGL(stem16_pool_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, *bn, static_cast<u16*>(pooled), idx, g);
+    }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// Backward pass 1: the BatchNorm-backward sums (sum dz | sum dz*xhat) of the stem's BatchNorm, added into bn->bbins, from the
+// gradient of the pooled map g (bf16), the pooled map and its argmax slots.  Needs bn->saved (written by the forward).  work: the
+// workspace sar_stem16_wgrad will get (its tile counter is reset here).
+int sar_stem16_bwd_reduce(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                          const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                          int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+    StemG g;
+    if (!g_pooled || !pooled || !idx || !x || !w || !bias || !bn || !bn->bbins || !bn->saved || !work ||
+        !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
+    const long npix = (long)B * Hp * Wp;
+    if (npix * C0 >= (1L << 31)) return SAR_EINVAL;
+    const int npg = 256 / (C0 / 8);
+    int nblk = (int)((npix + npg - 1) / npg); nblk = nblk > 1024 ? 1024 : nblk;
+    hipLaunchKernelGGL(stem16_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, static_cast<const u16*>(g_pooled), static_cast<const u16*>(pooled), idx,
+                       x, w, bias, bn->gamma, bn->beta, bn->saved, const_cast<float*>(bn->bbins), reinterpret_cast<int*>(work), g, (unsigned)npix);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+size_t sar_stem16_wgrad_workspace_bytes(int C0) { return 64 + (size_t)WG_MAX_BLOCKS * 64 * C0 * sizeof(float); }
+
+// Backward pass 2: dw (7,7,1,C0) fp32 += kernel gradient.  bn: saved + bbins (after sar_stem16_bwd_reduce); the launch owns the
+// BatchNorm's parameter gradients when bn->write.  work: sar_stem16_wgrad_workspace_bytes(C0) bytes of scratch, the same buffer
+// sar_stem16_bwd_reduce got.  The stem's bias
+// gradient is exactly zero (it feeds a BatchNorm) and is not computed.
+int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
+                     const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
+                     int Hp, int Wp, int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+    StemG g;
+    if (!x || !w || !bias || !g_pooled || !pooled || !idx || !bn || !bn->bbins || !bn->saved || !dw || !work ||
+        !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
+    int TR = env_int("SAR_STEM_WG_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
+    stem_tiles(g, TR, Ho, TR);
+    const int NT = C0 / 32;
+    const int win_bytes = (TR / 2 + 2) * Wp * (C0 + 4) * 4;
+    size_t lds = (size_t)9 * C0 * 4 + (size_t)NT * 4096 + g.patch_bytes + win_bytes + 4 * (2 + NT) * PLANE;
+    const size_t merge = (size_t)9 * C0 * 4 + 64 * C0 * 4;
+    if (lds < merge) lds = merge;
+    if (lds > 160 * 1024) return SAR_EINVAL;
+    const int ntiles = B * g.tiles;
+    const int nblk = ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS;
+    int* counter = reinterpret_cast<int*>(work);
+    float* part = work + 16;
+    if (C0 == 64) {
+        if (!allow_lds(stem16_wgrad_kernel<2>, lds)) return SAR_ELAUNCH;
+        hipLaunchKernelGGL(stem16_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
+                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, win_bytes);
+    } else {
+        if (!allow_lds(stem16_wgrad_kernel<1>, lds)) return SAR_ELAUNCH;
+        hipLaunchKernelGGL(stem16_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
+                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, win_bytes);
+    }
+    hipLaunchKernelGGL(stem16_wsum_kernel, dim3(49), dim3(256), 0, stream, part, nblk, dw, C0, counter);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+}  // extern "C"

@@ -253,7 +253,7 @@ class ResNetTrunk(Layer):
         return [cv for blk in self.blocks for cv in (blk["conv1"], blk["conv2"], blk["sc"]) if cv is not None]
 
     def _all_bns(self):
-        return [bn for blk in self.blocks for bn in (blk["bn1"], blk["bn2"]) if bn is not None] + [self.final_bn]
+        return [self.stem_bn] + [bn for blk in self.blocks for bn in (blk["bn1"], blk["bn2"]) if bn is not None] + [self.final_bn]
 
     def _setup16(self):
         if getattr(self, "_pack_table", None) is not None:
@@ -285,12 +285,8 @@ class ResNetTrunk(Layer):
         else:
             for bn in self._all_bns():
                 bn.fold16()
-        pooled = self._stem_forward(x, B)
-        Hp, Wp = self.pool_hw
-        c0 = self.stem.cout
-        cur = self._buf16("pooled16", (B, Hp, Wp, c0))
-        _call("sar_cast_f32_bf16", pooled, cur, pooled.numel())
         st = "fwd" if training else "saved"
+        cur = self._stem_forward16(x, B, st)
         nblk = len(self.blocks)
         for n, blk in enumerate(self.blocks):
             H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
@@ -400,9 +396,7 @@ class ResNetTrunk(Layer):
             self._wgrad16(part)
         if part in (0, 1):
             return None
-        g32 = self.scratch("res16_g32", tuple(g.shape))
-        _call("sar_cast_bf16_f32", g, g32, g.numel())
-        self._stem_backward(g32, B)
+        self._stem_backward16(g, B)
         if overlap:
             torch.cuda.current_stream().wait_stream(self._wg_stream)       # the branch joins in front of the optimiser
         return None
@@ -447,6 +441,34 @@ class ResNetTrunk(Layer):
         else:
             for p in plans[key]:
                 p.launch()
+
+    # stem of the bf16 trunk (csrc/stem_bf16.hip): the 7x7 conv is recomputed wherever its output is needed, so only the pooled map
+    # (bf16) and its argmax slots exist in HBM -- no (B, T/2, D/2, C0) tensor, forward or backward
+    def _stem_geo(self, B):
+        T, D = self.in_hw
+        (H, W), (Hp, Wp) = self.stem_hw, self.pool_hw
+        return (B, T, D, H, W, self.stem.cout, self.stem.pt, self.stem.pl), (Hp, Wp, self.pool_pt, self.pool_pl)
+
+    def _stem_forward16(self, x, B, st):
+        conv, pool = self._stem_geo(B)
+        H, W = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
+        sb, cv = self.stem_bn, self.stem
+        training = self.store.training
+        if training:
+            _call("sar_stem16_stats", x, cv.kernel.w, cv.bias.w, sb.bins, *conv)
+        self.pooled16 = self._buf16("pooled16", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
+        _call("sar_stem16_pool_fwd", x, cv.kernel.w, cv.bias.w, sb.ref(B * H * W, st, training), self.pooled16, self.pool_idx, *conv, *pool)
+        return self.pooled16
+
+    def _stem_backward16(self, g, B):
+        """g: gradient of the pooled map (bf16).  BatchNorm sums from (g, pooled, slots), then the 7x7 kernel gradient."""
+        conv, pool = self._stem_geo(B)
+        H, W = self.stem_hw
+        sb, cv = self.stem_bn, self.stem
+        ref = sb.ref(B * H * W, "bwd", True)
+        work = self.scratch("stem16_work", (_lib.stem16_wgrad_workspace_bytes(cv.cout) // 4,))
+        _call("sar_stem16_bwd_reduce", g, self.pooled16, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)
+        _call("sar_stem16_wgrad", self.x, cv.kernel.w, cv.bias.w, g, self.pooled16, self.pool_idx, ref, cv.kernel.g, work, *conv, *pool)
 
     def _stem_forward(self, x, B):
         T, D = self.in_hw

@@ -188,6 +188,28 @@ int sar_bn_bwd_reduce_bf16(const void* dact, int dact_f32, const void* x, const 
 int sar_bn_apply_bf16_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, sarStream_t stream);
 int sar_cast_f32_bf16(const float* x, void* y, long n, sarStream_t stream);   /* n % 8 == 0 */
 int sar_cast_bf16_f32(const void* x, float* y, long n, sarStream_t stream);
+/* The stem of the bf16 trunk -- Conv2D 7x7/2 'same' (Cin = 1) -> BatchNormalization -> ReLU -> MaxPooling2D 3x3/2 'same',
+ * resnet.py:173-174 / 191-192 (_conv_bn_relu, resnet.py:34-45) -- without the full-resolution map (131 MB in fp32 at B=64): the
+ * conv is recomputed on bf16 MFMA wherever its output is needed.  x (B,T,D) fp32 (the (B,T,80,1) input), w (7,7,1,C0) fp32 HWIO,
+ * C0 in {32, 64}; Ho/Wo, pad_top/pad_left = the conv's TF-SAME geometry, Hp/Wp, pool_pad_* = the pool's.  pooled / g_pooled
+ * (B,Hp,Wp,C0) bf16; idx (same shape, u8) = window slot kh*3+kw of the first maximum.
+ *   forward : sar_stem16_stats (training: sum / sum of squares of conv+bias into the BatchNorm's bins) -> sar_stem16_pool_fwd (bn
+ *             like a consumer of the bf16 trunk: statistics from bn->bins, or bn->saved when bins is NULL = inference).
+ *   backward: sar_stem16_bwd_reduce (the two BatchNorm-backward sums into bn->bbins, from g_pooled / pooled / idx alone; it also
+ *             resets the tile counter at the head of `work`, the buffer sar_stem16_wgrad gets) ->
+ *             sar_stem16_wgrad (dw += kernel gradient; owns dgamma / dbeta when bn->write; the bias gradient is exactly zero and
+ *             not computed; work = sar_stem16_wgrad_workspace_bytes(C0) bytes of scratch).  No input gradient: first layer. */
+int sar_stem16_stats(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
+                     int pad_top, int pad_left, sarStream_t stream);
+int sar_stem16_pool_fwd(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
+                        int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
+int sar_stem16_bwd_reduce(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                          const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                          int pool_pad_top, int pool_pad_left, sarStream_t stream);
+size_t sar_stem16_wgrad_workspace_bytes(int C0);
+int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
+                     const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
+                     int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a
