@@ -23,6 +23,19 @@
 
 namespace {
 
+// In-kernel phase timing (tools/stem_timing.py; only with -DSAR_TIMING into tools/libsarnet_timing_stem.so, never part of
+// libsarnet_hip.so): thread 0 of every block stamps s_memtime (shader clock) / s_memrealtime (100 MHz, device-wide: slots 0, 15).
+#ifdef SAR_TIMING
+__device__ unsigned long long* g_tbuf_stem = nullptr;
+#define TSTAMP(slot)                                                                                                   \
+    do {                                                                                                               \
+        if (g_tbuf_stem && threadIdx.x == 0)                                                                           \
+            g_tbuf_stem[(long)blockIdx.x * 16 + (slot)] = ((slot) == 0 || (slot) == 15) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#endif
+
 struct StemG {
     int B, T, D;                // input (B, T, D) fp32 (the reference's (B, T, 80, 1))
     int Ho, Wo, C0;             // conv output; C0 = 32 * NT
@@ -33,12 +46,21 @@ struct StemG {
     int pld;                    // patch row pitch in bf16 elements (even): 2*(Wo-1) + 8
     int patch_bytes;            // LDS bytes reserved for the patch
     int fast;                   // D and pl even, pld <= 128: the patch fill may use 8-byte loads, one column pair per thread
-    unsigned mg_wo;
+    unsigned mg_wo, mg_wp;
 };
 
 constexpr int IP = 80;          // bytes per pixel row of a 32-channel bf16 LDS image: 64 + 16, so the 16-byte stores of 16 consecutive pixels hit 64 different banks
 constexpr int PLANE = 32 * IP;  // one 32-pixel x 32-channel image
 constexpr int ZP = 32 * 4 + 16; // bytes per pixel row of the fp32 activation tile (32 channels per pass): conflict-free 16-byte stores
+
+// sum over the 16 lanes of a DPP row, in every lane: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
 
 // ---- kernel fragments.  wa[ct][s] = w[ky = 2s + h][kx = 0..7][channel ct*32 + lane%32] (zero for ky = 7 / kx = 7), h = lane/32.
 // The block gathers them once (7*NT loads per thread, all in flight), rounds to bf16 and parks them in LDS as ready fragments
@@ -155,12 +177,14 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wfr = smem;                                                       // [NT*4][64][16 B]
     u16* patch = reinterpret_cast<u16*>(smem + NT * 4096);
-    float* red = reinterpret_cast<float*>(smem + NT * 4096 + g.patch_bytes);         // [4 waves][2][C0]
+    float* red = reinterpret_cast<float*>(smem + NT * 4096 + g.patch_bytes);         // [4 waves x 2 lane rows][2][C0]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int n = blockIdx.x / g.tiles, tr = blockIdx.x % g.tiles;
     const int r0 = tr * g.TR, nr = min(g.TR, g.Ho - r0), npix = nr * g.Wo;
+    TSTAMP(0); TSTAMP(1);
     stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r0 - g.pt, 2 * (nr - 1) + 8, tid, true, [] {});
     __syncthreads();
+    TSTAMP(2);
     bf16x8 wa[NT][4];
     stem_w_frags<NT>(wa, wfr, lane);
     float s1[NT][16], s2[NT][16];
@@ -182,30 +206,32 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s1[ct][r] += acc[ct][r]; s2[ct][r] = fmaf(acc[ct][r], acc[ct][r], s2[ct][r]); }
     }
-    // sum over the 32 pixels (lanes) that share h; lane%32 == 0 then holds the totals of its 16*NT channels
+    TSTAMP(3);
+    // sum over the 32 pixels (lanes) that share h: four DPP adds give every lane the total of its row of 16 lanes (__shfl_xor is
+    // ds_bpermute on this target: 640 of them per wave were two thirds of the block's life); the two rows of an h meet in LDS
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float a = s1[ct][r], b = s2[ct][r];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if ((lane & 31) == 0) {
-                const int ch = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                red[(wave * 2 + 0) * C0 + ch] = a; red[(wave * 2 + 1) * C0 + ch] = b;
+            const float a = row16_sum(s1[ct][r]), b = row16_sum(s2[ct][r]);
+            if ((lane & 15) == 0) {
+                const int ch = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, slot = wave * 2 + ((lane >> 4) & 1);
+                red[(slot * 2 + 0) * C0 + ch] = a; red[(slot * 2 + 1) * C0 + ch] = b;
             }
         }
     __syncthreads();
+    TSTAMP(4);
     if (tid < 2 * C0) {
         const int which = tid / C0, c = tid % C0;
         float S1 = 0.f, S2 = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) { S1 += red[(wv * 2 + 0) * C0 + c]; S2 += red[(wv * 2 + 1) * C0 + c]; }
+        for (int wv = 0; wv < 8; ++wv) { S1 += red[(wv * 2 + 0) * C0 + c]; S2 += red[(wv * 2 + 1) * C0 + c]; }
         // the sums are of the raw products; the BatchNorm input is y = conv + bias
         const float b = bias[c], np = (float)npix;
         const float out = which == 0 ? S1 + np * b : S2 + 2.f * b * S1 + np * b * b;
         atomicAdd(bins + ((blockIdx.x % NB) * 2 + which) * C0 + c, out);
     }
+    TSTAMP(5); TSTAMP(15);
 }
 
 // ---------------------------------------------------------------------------------------------------- forward pass 2: BN + ReLU + max-pool
@@ -228,11 +254,13 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
     const int i0 = tile * g.TR, npr = min(g.TR, g.Hp - i0);
     const int r_lo = max(2 * i0 - g.ppt, 0), r_hi = min(2 * (i0 + npr - 1) - g.ppt + 3, g.Ho);
     const int nr = r_hi - r_lo, npix = nr * g.Wo;
+    TSTAMP(0); TSTAMP(1);
     stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r_lo - g.pt, 2 * (nr - 1) + 8, tid, true, [&] {
         bn_prologue(bn, 1, C0, 0, C0, cst, C0, blockIdx.x == 0, 256);
         for (int i = tid; i < C0; i += 256) cst[C0 + i] += cst[i] * bias[i];         // same thread wrote both entries
     });
     __syncthreads();
+    TSTAMP(2);
     bf16x8 wa[NT][4];
     stem_w_frags<NT>(wa, wfr, lane);
     const int nitems = npr * g.Wp * 8;
@@ -257,6 +285,7 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
             }
         }
         __syncthreads();
+        TSTAMP(3 + 2 * CT);
         for (int it = tid; it < nitems; it += 256) {
             const int g4 = it & 7, pp = it >> 3, pj = pp % g.Wp, pi = pp / g.Wp;
             unsigned k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
@@ -277,10 +306,12 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
         }
     };
     pass(std::integral_constant<int, 0>{});
+    TSTAMP(4);
     if constexpr (NT == 2) {
         __syncthreads();                                                             // the pooling reads of pass 0 are done
         pass(std::integral_constant<int, 1>{});
     }
+    TSTAMP(6); TSTAMP(15);
 }
 
 // ---------------------------------------------------------------------------------------------------- backward pass 1: the two sums
@@ -349,28 +380,33 @@ __global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __res
 }
 
 // ---------------------------------------------------------------------------------------------------- backward pass 2: kernel gradient
-// part[block][ky*8 + kx][c] = this block's share of dW.  Per 32-pixel column block a wave recomputes the conv, turns it into
-// dy = A*dz + E*acc + F per channel (A = scale, E = -scale*c3*rstd, F = -scale*(c2 + c3*(bias - mean)*rstd): BatchNorm backward
-// with xhat = (acc + bias - mean)*rstd folded in), writes dy and its own B fragments (= the im2col rows of its pixels) as
-// pixel-major bf16 images into wave-private LDS and multiplies them through transpose-reads: no barrier inside a tile.
-// win[window][c] = (bf16 gradient of the window if its pooled value is positive) << 16 | argmax slot; a window's row is C0 + 4
-// words so that the 16 windows the 32 pixels of a column block look at spread over all banks.
+// part[block][ky*8 + kx][c] = this block's share of dW.  A tile = TR conv rows x the full width, 32 channels per pass:
+//  scatter : every pooled window whose maximum is positive adds its gradient to the conv pixel its argmax slot names -- one
+//            packed-bf16 LDS atomic (ds_pk_add_bf16) into the tile's dz image [pixel][32 ch].  (The first form gathered instead: every
+//            pixel tested its <= 4 candidate windows per channel -- 5 VALU instructions per candidate and channel, ~900 per
+//            32-pixel block, 4 000 cycles of a 5 000-cycle block with one wave per SIMD; tools/stem_timing.py.)
+//  m-tiles : per 32-pixel column block a wave recomputes the conv, turns it into dy = A*dz + E*acc + F per channel (A = scale,
+//            E = -scale*c3*rstd, F = -scale*(c2 + c3*(bias - mean)*rstd): BatchNorm backward with xhat = (acc + bias - mean)*rstd
+//            folded in), clears the dz entries it read, writes dy and its own B fragments (= the im2col rows of its pixels) as
+//            pixel-major bf16 images into wave-private LDS and multiplies them through transpose-reads: no barrier inside.
 // Tiles are handed out through an atomic counter (work[0], zeroed by the reduce pass in front of this kernel): blocks stay
 // resident, keep their accumulators, and the chip stays balanced whatever the tile count.
+constexpr int DZP = 64 + 8;     // bytes per pixel row of the dz image (32 bf16 + 8: the 8-byte reads of 16 pixels hit 32 different banks)
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                           const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
-                                                           const BnP bn, int* __restrict__ counter, float* __restrict__ part, const StemG g, int ntiles,
-                                                           int win_bytes) {
-    constexpr int C0 = NT * 32, SCR = (2 + NT) * PLANE, WS = C0 + 4;
+                                                              const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
+                                                              const BnP bn, int* __restrict__ counter, float* __restrict__ part, const StemG g, int ntiles,
+                                                              int dz_bytes) {
+    constexpr int C0 = NT * 32, SCR = 3 * PLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_tile;
     float* cst = reinterpret_cast<float*>(smem);                                     // [6][C0] from the prologue, then [3][C0]: A, E, F
     float* aef = cst + 6 * C0;
     unsigned char* wfr = smem + 9 * C0 * 4;
     u16* patch = reinterpret_cast<u16*>(wfr + NT * 4096);
-    unsigned* win = reinterpret_cast<unsigned*>(wfr + NT * 4096 + g.patch_bytes);
-    unsigned char* scr0 = wfr + NT * 4096 + g.patch_bytes + win_bytes;               // [4 waves][SCR]
+    unsigned char* dz = wfr + NT * 4096 + g.patch_bytes;                             // [pixel][DZP]
+    unsigned char* scr0 = dz + dz_bytes + 256;                                       // [4 waves][SCR]: P planes 0, 1, dy plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     unsigned char* scr = scr0 + wave * SCR;
     bf16x8 wa[NT][4];
@@ -383,9 +419,9 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
             for (int r = 0; r < 16; ++r) accw[tp][ct][r] = 0.f;
     const int gi = lane & 15, gg = lane >> 4, cb = gg & 1, kh2 = gg >> 1;
     const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2, prb = 8 * kh2 + (gi >> 2);
-    constexpr int G8 = C0 / 8;
+    TSTAMP(0); TSTAMP(1);
 
-    // once per block: kernel fragments, BatchNorm constants
+    // once per block: kernel fragments, BatchNorm constants, a clean dz image
     {
         WStage<NT> ws;
         stem_w_load<NT>(ws, w, tid);
@@ -396,113 +432,148 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
             aef[i] = scale; aef[C0 + i] = Cc * rstd; aef[2 * C0 + i] = -scale * c2 + Cc * xb;
         }
         stem_w_store<NT>(ws, wfr, tid);
+        for (int i = tid * 16; i < dz_bytes; i += 256 * 16) *reinterpret_cast<uint4*>(dz + i) = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         stem_w_frags<NT>(wa, wfr, lane);
     }
+    TSTAMP(2);
+#ifdef SAR_TIMING
+    unsigned long long t_stage = 0, t_mt = 0, t_n = 0, t_a, t_b;
+#endif
     for (;;) {
         if (tid == 0) s_tile = atomicAdd(counter, 1);
-        __syncthreads();                                                             // also: the previous tile's readers are done
+        __syncthreads();                                                             // also: the previous tile's readers are done, its dz entries cleared
         const int tile = s_tile;
         if (tile >= ntiles) break;
         const int n = tile / g.tiles, tr = tile % g.tiles;
         const int r0 = tr * g.TR, nr = min(g.TR, g.Ho - r0), npix = nr * g.Wo;
         const int i_lo = max((r0 + g.ppt - 1) >> 1, 0), i_hi = min((r0 + nr - 1 + g.ppt) >> 1, g.Hp - 1), nwr = i_hi - i_lo + 1;
-        stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r0 - g.pt, 2 * (nr - 1) + 8, tid, false, [&] {
-            for (int it = tid; it < nwr * g.Wp * G8; it += 256) {
-                const int gch = it % G8, pp = it / G8;                               // pp = local window index (row-major over nwr x Wp)
-                const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + gch * 8;
-                const uint4 pv = *reinterpret_cast<const uint4*>(pooled + o), gv = *reinterpret_cast<const uint4*>(gp + o);
-                const uint2 iv = *reinterpret_cast<const uint2*>(idx + o);
-                const unsigned ps[4] = {pv.x, pv.y, pv.z, pv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
-                unsigned o8[8];
+        const int nitems = nwr * g.Wp * 4;                                           // (window, 8 of the pass's 32 channels)
+        auto pass = [&](auto ctc) __attribute__((always_inline)) {
+            constexpr int CT = decltype(ctc)::value;
+#ifdef SAR_TIMING
+            t_a = __builtin_amdgcn_s_memtime();
+#endif
+            auto scatter = [&]() __attribute__((always_inline)) {
+                uint4 pv[2], gv[2]; uint2 iv[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // pooled >= 0 always (ReLU): positive <=> non-zero magnitude bits
-                    const unsigned s0 = ((k < 2 ? iv.x : iv.y) >> (16 * (k & 1))) & 255u, s1 = ((k < 2 ? iv.x : iv.y) >> (16 * (k & 1) + 8)) & 255u;
-                    o8[2 * k] = ((ps[k] & 0x7fffu) ? (gs[k] << 16) : 0u) | s0;
-                    o8[2 * k + 1] = ((ps[k] & 0x7fff0000u) ? (gs[k] & 0xffff0000u) : 0u) | s1;
+                for (int u = 0; u < 2; ++u) {
+                    const int it = min(tid + 256 * u, nitems - 1), cg = it & 3, pp = it >> 2;
+                    const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
+                    pv[u] = *reinterpret_cast<const uint4*>(pooled + o); gv[u] = *reinterpret_cast<const uint4*>(gp + o);
+                    iv[u] = *reinterpret_cast<const uint2*>(idx + o);
                 }
-                unsigned* dst = win + (size_t)pp * WS + gch * 8;
-                *reinterpret_cast<uint4*>(dst) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
-                *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o8[4], o8[5], o8[6], o8[7]);
-            }
-        });
-        __syncthreads();
-        for (int mt = wave; mt * 32 < npix; mt += 4) {
-            const int p = mt * 32 + q;
-            const bool valid = p < npix;
-            const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
-            f32x16 acc[NT]; bf16x8 bfr[4];
+                for (int it0 = tid + 512; it0 < nitems; it0 += 256) {               // tiles with more than 512 items (wide inputs): one at a time
+                    const int cg = it0 & 3, pp = it0 >> 2;
+                    const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
+                    const uint4 p1 = *reinterpret_cast<const uint4*>(pooled + o), g1 = *reinterpret_cast<const uint4*>(gp + o);
+                    const uint2 i1 = *reinterpret_cast<const uint2*>(idx + o);
+                    const int wi = pp / g.Wp, wj = pp - wi * g.Wp;
+                    const unsigned ps[4] = {p1.x, p1.y, p1.z, p1.w}, gs[4] = {g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-            stem_mtile<NT, 0, NT>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
-            // the lane's B fragments ARE its pixel's im2col row (taps (2s+h)*8 .. +8): plane (2s+h)/4, 16 bytes at ((2s+h)%4)*16
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                *reinterpret_cast<bf16x8*>(scr + ((2 * s + h) >> 2) * PLANE + q * IP + ((2 * s + h) & 3) * 16) = bfr[s];
-            // candidate windows of the pixel: row a = r + ppt lies in window a>>1 at slot row a&1 and, a even, in window (a>>1)-1 at row 2
-            const int a = r0 + (int)ty + g.ppt, b = (int)tx + g.ppl, ho1 = a >> 1, wo1 = b >> 1;
-            const int hos[2] = {ho1, ho1 - 1}, khs[2] = {a & 1, 2}, wos[2] = {wo1, wo1 - 1}, kws[2] = {b & 1, 2};
-            const bool vh[2] = {ho1 < g.Hp, (a & 1) == 0 && ho1 >= 1}, vw[2] = {wo1 < g.Wp, (b & 1) == 0 && wo1 >= 1};
-            unsigned woff[4], slot[4];
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int lr = min(max(hos[ii] - i_lo, 0), nwr - 1), lc = min(max(wos[jj], 0), g.Wp - 1);
-                    woff[ii * 2 + jj] = (unsigned)(lr * g.Wp + lc) * WS;
-                    slot[ii * 2 + jj] = (valid && vh[ii] && vw[jj]) ? (unsigned)(khs[ii] * 3 + kws[jj]) : 256u;   // 256: never a slot
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = (gs[k >> 1] >> sh) & 0xffffu;
+                        const int slot = ((k < 4 ? i1.x : i1.y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
+                        const int r = 2 * (i_lo + wi) - g.ppt + kh - r0, c = 2 * wj - g.ppl + kw;
+                        if (pz != 0u && r >= 0 && r < nr) {
+                            const s16x2 val = __builtin_bit_cast(s16x2, gz << sh);
+                            __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2), val);
+                        }
+                    }
                 }
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct)
+                for (int u = 0; u < 2; ++u) {
+                    const int it = tid + 256 * u, cg = it & 3, pp = it >> 2;
+                    const int wi = (int)udiv((unsigned)pp, g.mg_wp, (unsigned)g.Wp), wj = pp - wi * g.Wp;
+                    const unsigned ps[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+                    const int rb = 2 * (i_lo + wi) - g.ppt - r0, cbase = 2 * wj - g.ppl;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        // pooled >= 0 always (ReLU): positive <=> non-zero magnitude bits.  (A branch-free form -- misses add 0 to a dummy
+                        // word -- doubled the phase: it is the LDS atomics that cost, not the branches.)
+                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = (gs[k >> 1] >> sh) & 0xffffu;
+                        const int slot = ((k < 4 ? iv[u].x : iv[u].y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
+                        const int r = rb + kh, c = cbase + kw;
+                        if (it < nitems && pz != 0u && r >= 0 && r < nr) {
+                            const s16x2 val = __builtin_bit_cast(s16x2, gz << sh);
+                            __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2), val);
+                        }
+                    }
+                }
+            };
+            if (CT == 0) stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r0 - g.pt, 2 * (nr - 1) + 8, tid, false, scatter);
+            else scatter();
+            __syncthreads();
+#ifdef SAR_TIMING
+            t_b = __builtin_amdgcn_s_memtime(); t_stage += t_b - t_a;
+#endif
+            // 10 column blocks over 4 waves: the waves that take the odd ones out rotate with the pass
+            for (int mt = (wave + 2 * CT) & 3; mt * 32 < npix; mt += 4) {
+                const int p = mt * 32 + q;
+                const bool valid = p < npix;
+                const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
+                f32x16 acc[1]; bf16x8 bfr[4];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+                stem_mtile<NT, CT, 1>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
+                // the lane's B fragments ARE its pixel's im2col row (taps (2s+h)*8 .. +8): plane (2s+h)/4, 16 bytes at ((2s+h)%4)*16
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    *reinterpret_cast<bf16x8*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = bfr[s2];
+                unsigned char* dzp = dz + (size_t)pc * DZP + 8 * h;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const int ch0 = ct * 32 + 8 * gq + 4 * h;
-                    float dz[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(win + woff[c4] + ch0);
-                        dz[0] += (v.x & 255u) == slot[c4] ? __uint_as_float(v.x & 0xffff0000u) : 0.f;
-                        dz[1] += (v.y & 255u) == slot[c4] ? __uint_as_float(v.y & 0xffff0000u) : 0.f;
-                        dz[2] += (v.z & 255u) == slot[c4] ? __uint_as_float(v.z & 0xffff0000u) : 0.f;
-                        dz[3] += (v.w & 255u) == slot[c4] ? __uint_as_float(v.w & 0xffff0000u) : 0.f;
-                    }
+                    const int cl = 8 * gq + 4 * h, ch0 = CT * 32 + cl;
+                    uint2 dv = *reinterpret_cast<const uint2*>(dzp + 16 * gq);
+                    if (valid) *reinterpret_cast<uint2*>(dzp + 16 * gq) = make_uint2(0u, 0u);       // leave the image clean for the next scatter
+                    else dv = make_uint2(0u, 0u);
                     const float4 A4 = *reinterpret_cast<const float4*>(aef + ch0), E4 = *reinterpret_cast<const float4*>(aef + C0 + ch0),
                                  F4 = *reinterpret_cast<const float4*>(aef + 2 * C0 + ch0);
                     // lanes past the tile: acc = 0 and dz = 0, so F alone has to be masked
-                    const float d0 = fmaf(A4.x, dz[0], fmaf(E4.x, acc[ct][gq * 4 + 0], valid ? F4.x : 0.f));
-                    const float d1 = fmaf(A4.y, dz[1], fmaf(E4.y, acc[ct][gq * 4 + 1], valid ? F4.y : 0.f));
-                    const float d2 = fmaf(A4.z, dz[2], fmaf(E4.z, acc[ct][gq * 4 + 2], valid ? F4.z : 0.f));
-                    const float d3 = fmaf(A4.w, dz[3], fmaf(E4.w, acc[ct][gq * 4 + 3], valid ? F4.w : 0.f));
-                    *reinterpret_cast<uint2*>(scr + (2 + ct) * PLANE + q * IP + (8 * gq + 4 * h) * 2) = make_uint2(pack2(d0, d1), pack2(d2, d3));
+                    const float d0 = fmaf(A4.x, bf_lo(dv.x), fmaf(E4.x, acc[0][gq * 4 + 0], valid ? F4.x : 0.f));
+                    const float d1 = fmaf(A4.y, bf_hi(dv.x), fmaf(E4.y, acc[0][gq * 4 + 1], valid ? F4.y : 0.f));
+                    const float d2 = fmaf(A4.z, bf_lo(dv.y), fmaf(E4.z, acc[0][gq * 4 + 2], valid ? F4.z : 0.f));
+                    const float d3 = fmaf(A4.w, bf_hi(dv.y), fmaf(E4.w, acc[0][gq * 4 + 3], valid ? F4.w : 0.f));
+                    *reinterpret_cast<uint2*>(scr + 2 * PLANE + q * IP + cl * 2) = make_uint2(pack2(d0, d1), pack2(d2, d3));
                 }
-            // the wave's own LDS stores are ordered in front of its own reads (same queue); keep the compiler from reordering them
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the wave's own LDS stores are ordered in front of its own reads (same queue); keep the compiler from reordering them
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const unsigned o0 = (16 * ks + prb) * IP + colb, o1 = o0 + 4 * IP;
-                bf16x8 Af[2], Bf[NT];
+                for (int ks = 0; ks < 2; ++ks) {
+                    const unsigned o0 = (16 * ks + prb) * IP + colb, o1 = o0 + 4 * IP;
+                    bf16x8 Af[2], Bf;
 #pragma unroll
-                for (int tp = 0; tp < 2; ++tp) {
-                    const s16x4 lo = lds_tr(scr + tp * PLANE, o0), hi = lds_tr(scr + tp * PLANE, o1);
-                    Af[tp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    for (int tp = 0; tp < 2; ++tp) {
+                        const s16x4 lo = lds_tr(scr + tp * PLANE, o0), hi = lds_tr(scr + tp * PLANE, o1);
+                        Af[tp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+                    {
+                        const s16x4 lo = lds_tr(scr + 2 * PLANE, o0), hi = lds_tr(scr + 2 * PLANE, o1);
+                        Bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+#pragma unroll
+                    for (int tp = 0; tp < 2; ++tp) accw[tp][CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[tp], Bf, accw[tp][CT], 0, 0, 0);
                 }
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct) {
-                    const s16x4 lo = lds_tr(scr + (2 + ct) * PLANE, o0), hi = lds_tr(scr + (2 + ct) * PLANE, o1);
-                    Bf[ct] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-                    for (int ct = 0; ct < NT; ++ct) accw[tp][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[tp], Bf[ct], accw[tp][ct], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the transpose-reads are done before the images are rewritten
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the transpose-reads are done before the images are rewritten
+#ifdef SAR_TIMING
+            t_mt += __builtin_amdgcn_s_memtime() - t_b;
+#endif
+        };
+        pass(std::integral_constant<int, 0>{});
+        if constexpr (NT == 2) {
+            __syncthreads();                                                         // pass 0's readers are done: the dz image is clean again
+            pass(std::integral_constant<int, 1>{});
         }
+#ifdef SAR_TIMING
+        ++t_n;
+#endif
     }
-    // ---- merge the four waves' tiles in LDS (over patch / win / scratch: everything is dead), then one coalesced store
+    TSTAMP(3);
+#ifdef SAR_TIMING
+    if (g_tbuf_stem && threadIdx.x == 0) { g_tbuf_stem[(long)blockIdx.x * 16 + 8] = t_stage; g_tbuf_stem[(long)blockIdx.x * 16 + 9] = t_mt; g_tbuf_stem[(long)blockIdx.x * 16 + 10] = t_n; }
+#endif
+    // ---- merge the four waves' tiles in LDS (over patch / dz / scratch: everything is dead), then one coalesced store
     float* ot = reinterpret_cast<float*>(wfr);                                       // [64][C0]
     for (int wv = 0; wv < 4; ++wv) {
         if (wave == wv) {
@@ -520,22 +591,30 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
     }
     float4* dst = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 64 * C0);
     for (int i = tid; i < 64 * C0 / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(ot)[i];
+    TSTAMP(4); TSTAMP(15);
 }
 
-// dw[(ky*7 + kx)][c] += sum over blocks of part[block][ky*8 + kx][c]; one block per tap
+// dw[(ky*7 + kx)][c] += sum over blocks of part[block][ky*8 + kx][c]; grid (49 taps, WS_SLICES slices of the blocks)
+constexpr int WS_SLICES = 8;
 __global__ __launch_bounds__(256) void stem16_wsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, int C0, int* __restrict__ counter) {
     __shared__ float red[256];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *counter = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *counter = 0;
     const int t = blockIdx.x, row = (t / 7) * 8 + (t % 7);
     const int c = threadIdx.x % C0, sl = threadIdx.x / C0, nsl = 256 / C0;
-    float s = 0.f;
-    for (int b = sl; b < nblk; b += nsl) s += part[((size_t)b * 64 + row) * C0 + c];
-    red[threadIdx.x] = s;
+    const int per = (nblk + WS_SLICES - 1) / WS_SLICES, b0 = blockIdx.y * per, b1 = min(b0 + per, nblk);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0 + sl;
+    for (; b + 3 * nsl < b1; b += 4 * nsl) {                                         // four loads in flight
+        s0 += part[((size_t)b * 64 + row) * C0 + c]; s1 += part[((size_t)(b + nsl) * 64 + row) * C0 + c];
+        s2 += part[((size_t)(b + 2 * nsl) * 64 + row) * C0 + c]; s3 += part[((size_t)(b + 3 * nsl) * 64 + row) * C0 + c];
+    }
+    for (; b < b1; b += nsl) s0 += part[((size_t)b * 64 + row) * C0 + c];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < C0) {
         float a = 0.f;
         for (int k = 0; k < nsl; ++k) a += red[k * C0 + c];
-        dw[t * C0 + c] += a;
+        atomicAdd(dw + t * C0 + c, a);
     }
 }
 
@@ -549,7 +628,7 @@ static bool stem_geo(StemG& g, int B, int T, int D, int Ho, int Wo, int C0, int 
     memset(&g, 0, sizeof(g));
     g.B = B; g.T = T; g.D = D; g.Ho = Ho; g.Wo = Wo; g.C0 = C0; g.pt = pt; g.pl = pl; g.Hp = Hp; g.Wp = Wp; g.ppt = ppt; g.ppl = ppl;
     g.pld = 2 * (Wo - 1) + 8;
-    g.mg_wo = magic(Wo);
+    g.mg_wo = magic(Wo); g.mg_wp = magic(Wp);
     g.fast = (D % 2 == 0 && pl % 2 == 0 && g.pld <= 128) ? 1 : 0;
     return true;
 }
@@ -578,7 +657,7 @@ int sar_stem16_stats(const float* x, const float* w, const float* bias, float* b
     if (!x || !w || !bias || !bins || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, 1, 1, 0, 0)) return SAR_EINVAL;
     int TR = env_int("SAR_STEM_STATS_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
     stem_tiles(g, TR, Ho, TR);
-    const size_t lds = (size_t)(C0 / 32) * 4096 + g.patch_bytes + 4 * 2 * C0 * 4;
+    const size_t lds = (size_t)(C0 / 32) * 4096 + g.patch_bytes + 8 * 2 * C0 * 4;
     if (lds > 160 * 1024) return SAR_EINVAL;
     const int nblk = B * g.tiles;
     if (C0 == 64) {
@@ -650,8 +729,8 @@ int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const vo
     int TR = env_int("SAR_STEM_WG_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
     stem_tiles(g, TR, Ho, TR);
     const int NT = C0 / 32;
-    const int win_bytes = (TR / 2 + 2) * Wp * (C0 + 4) * 4;
-    size_t lds = (size_t)9 * C0 * 4 + (size_t)NT * 4096 + g.patch_bytes + win_bytes + 4 * (2 + NT) * PLANE;
+    const int dz_bytes = (TR * Wo * DZP + 15) & ~15;                  // + 256 bytes behind it: the scatter's per-lane dummy words
+    size_t lds = (size_t)9 * C0 * 4 + (size_t)NT * 4096 + g.patch_bytes + dz_bytes + 256 + 4 * 3 * PLANE;
     const size_t merge = (size_t)9 * C0 * 4 + 64 * C0 * 4;
     if (lds < merge) lds = merge;
     if (lds > 160 * 1024) return SAR_EINVAL;
@@ -662,15 +741,21 @@ int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const vo
     if (C0 == 64) {
         if (!allow_lds(stem16_wgrad_kernel<2>, lds)) return SAR_ELAUNCH;
         hipLaunchKernelGGL(stem16_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
-                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, win_bytes);
+                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, dz_bytes);
     } else {
         if (!allow_lds(stem16_wgrad_kernel<1>, lds)) return SAR_ELAUNCH;
         hipLaunchKernelGGL(stem16_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
-                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, win_bytes);
+                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, dz_bytes);
     }
-    hipLaunchKernelGGL(stem16_wsum_kernel, dim3(49), dim3(256), 0, stream, part, nblk, dw, C0, counter);
+    hipLaunchKernelGGL(stem16_wsum_kernel, dim3(49, WS_SLICES), dim3(256), 0, stream, part, nblk, dw, C0, counter);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
+
+#ifdef SAR_TIMING
+int sar_dbg_set_timing_buffer_stem(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf_stem), &buf, sizeof(buf)) == hipSuccess ? SAR_OK : SAR_ELAUNCH;
+}
+#endif
 
 }  // extern "C"

@@ -158,5 +158,17 @@ def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T):
             chk("b%d bn1 dgamma" % n, G[blk["bn1"].gamma.name], dg1, 1e-2); chk("b%d bn1 dbeta" % n, G[blk["bn1"].beta.name], dbt1, 1e-2)
         else:
             chk("b%d gin" % n, gin_dev, rbf(da1 + dsc), 1e-2)
-    chk("gradient handed to the stem", val(store.bufs.d["scratch/res16_g32"]), val(taps[0][2]), 1e-9)
+    # ---- the stem (csrc/stem_bf16.hip: conv recomputed in every pass, no full-resolution map): wiring of its four launches
+    xq, wq = rbf(val(x)), rbf(P[tr.stem.kernel.name])
+    ys, ccache = O.conv2d_fwd(xq, wq, P[tr.stem.bias.name], (2, 2), "same")
+    zs, bcache = O.batchnorm_fwd(ys, P[tr.stem_bn.gamma.name], P[tr.stem_bn.beta.name], 1e-3)
+    as_ = O.relu_fwd(zs)
+    pooled_ref, pcache = O.maxpool_fwd(as_)
+    chk("stem pooled map", tr.pooled16, pooled_ref, 4e-3)
+    g0 = val(taps[0][2])                                            # the gradient block 0 handed to the stem
+    dys, dgs, dbs_ = O.batchnorm_bwd(O.relu_bwd(O.maxpool_bwd(g0, pcache), as_), bcache)
+    _, dws, _ = O.conv2d_bwd(dys, ccache)
+    chk("stem dw", G[tr.stem.kernel.name], dws, 2e-2)
+    chk("stem bn dgamma", G[tr.stem_bn.gamma.name], dgs, 2e-2); chk("stem bn dbeta", G[tr.stem_bn.beta.name], dbs_, 1e-2)
+    assert np.abs(G[tr.stem.bias.name]).max() == 0.0               # feeds a BatchNorm: exactly zero, not computed
     print("bf16 trunk %s B=%d T=%d: worst block-local error %.3e (%s)" % (res_type, B, T, max(errs.values()), max(errs, key=errs.get)))
