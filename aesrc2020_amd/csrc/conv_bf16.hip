@@ -150,22 +150,22 @@ __device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0,
 // Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
 // per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
 // source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
-template <int MODE, int TM, int U>
+template <int MODE, int TM, int U, int NTHR>
 __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid) {
     const unsigned pc = 1u << lg_pc, total = (nrows * g.Wp) << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
-    const unsigned c8 = tid & (pc - 1);                            // 256 % pc == 0: a thread keeps its channel group
+    const unsigned c8 = tid & (pc - 1);                            // NTHR % pc == 0: a thread keeps its channel group
     const int dm = g.d - 1, ssh = g.s - 1;
     const bool do_side = side != nullptr && blockIdx.y == 0;       // block-uniform
     Cst8 k;
     if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
-    for (unsigned i0 = tid; i0 < total; i0 += U * 256) {           // U pieces in flight per thread
+    for (unsigned i0 = tid; i0 < total; i0 += U * NTHR) {          // U pieces in flight per thread
         uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const unsigned i = i0 + 256 * j, pos = i >> lg_pc;
+            const unsigned i = i0 + NTHR * j, pos = i >> lg_pc;
             const unsigned prow = min(udiv(pos, g.mg_wp, (unsigned)g.Wp), nrows - 1), wp = pos - prow * g.Wp;
             const uint2 rt = rowtab[prow];
             const int v = (int)wp - g.pl, vs = v >> dm;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);                 // branch-free: pieces past the end land in a scratch slot
-            *reinterpret_cast<uint4*>(patch + (i0 + 256 * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
+            *reinterpret_cast<uint4*>(patch + (i0 + NTHR * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
             if (do_side && off[j] != NONE && own[j] < (unsigned)TM) *reinterpret_cast<uint4*>(side + off[j]) = r;
         }
     }
@@ -203,13 +203,18 @@ __device__ __forceinline__ void load_afrags(bf16x8 (&a)[NKC], const unsigned cha
 // wrong, the other waves of the block right (tools/conv16_race.py).  A read-back of the wave's own pieces between vmcnt and the
 // barrier cured it (so a piece that has left the issuing wave's vmcnt is ordered against that wave's LDS reads, not yet against
 // every other wave's), at 5 % of the step; one full stage of margin costs nothing once the ring is a stage deeper.
-template <int WN, int NKC, int VT>
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
+// KG = 2 (NKC = 8 only: the 128+-channel layers, whose tiles are one block per CU or fewer): eight waves -- two groups of four that
+// split every virtual tap's eight fragments between them (channels 0-63 / 64-127 of the part) and meet in the output staging tile.
+// Twice the waves per SIMD for the LDS latency of the k-phase, twice the threads for prologue, fill and epilogue.
+template <int WN, int NKC, int VT, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(const ConvP p) {
+    static_assert(KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
+    constexpr int NTHR = 256 * KG, NW = 4 * KG, KPF = NKC / KG;    // threads, waves, fragments per virtual tap and group
     constexpr int WM = 4 / WN, TM = 32 * WM, TN = 32 * WN;
-    constexpr int CP = TN / 2, RG = 256 / CP, RPT = TM / RG;       // epilogue: column pairs, row groups, rows per thread
+    constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
     constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
-    constexpr int SJ = WN * 8, PW = SJ / 4;                        // DMA wave-instructions per stage: block / per wave
+    constexpr int SJ = WN * 8, PW = SJ / NW;                       // DMA wave-instructions per stage: block / per wave
     const int RD = p.rd;                                           // ring depth, 3 or 4 (launcher: 4 where the LDS has room for it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cst = reinterpret_cast<float*>(smem);
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     unsigned char* patch = smem + cst_bytes + ROWTAB_BYTES;
     unsigned char* bring = patch + p.patch_bytes;                  // [RD][WN][8][1 KiB]
     const Geo& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WN, wn = w % WN;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), kg = w >> 2, wm = (w & 3) / WN, wn = (w & 3) % WN;
     const unsigned m0 = blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
     const unsigned M = (unsigned)g.M;
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     auto issue_stage = [&](int st, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int j = w + 4 * i, nt = j >> 3, f8 = j & 7;
+            const int j = w + NW * i, nt = j >> 3, f8 = j & 7;
             dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)((slot * SJ + j) * 1024));
         }
     };
@@ -265,7 +270,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     if (RD > 3 && NST > 2) issue_stage(2, 2);
 
 
-    if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, 256);
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
     pix_rp(g, min(m0 + TM - 1, M - 1), Rp_hi, wtmp);
@@ -281,17 +285,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
         rt.y = b * (unsigned)(g.Ho * g.Wo) + (dm ? 2u * us : (unsigned)us >> (g.s - 1)) * g.Wo;
         rowtab[tid] = rt;
     }
+    if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, NTHR);
     // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
     TSTAMP(2);
 
-    // ---- fill: the padded patch, all input channels, transformed once
+    // (Issuing the patch loads in front of the BatchNorm prologue -- row table, barrier, loads, prologue, barrier, transform + store --
+    // was built and measured: no gain.  What the fill costs is its address arithmetic, ~1 400 cycles before the first load leaves,
+    // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
     constexpr int FU = 4;                                          // fill pieces per thread in flight
-    if (p.fill == 0) fill_patch<0, TM, FU>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else if (p.fill == 1) fill_patch<1, TM, FU>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else if (p.fill == 2) fill_patch<2, TM, FU>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else fill_patch<3, TM, 2>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);   // three tensors: two pieces in flight
+    // ---- fill: the padded patch, all input channels, transformed once
+    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
+    else fill_patch<3, TM, 2, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);   // three tensors: two pieces in flight
     // ---- per-lane A address
     unsigned a_lane;
     {
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
         pix_rp(g, min(m0 + wm * 32 + (lane & 31), M - 1), Rp, wq);
         unsigned prow = Rp - Rp_lo;
         if (prow + g.K > nrows) prow = 0;                          // only with the clamp above
-        a_lane = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16;
+        a_lane = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16 + kg * (KPF * 32);   // + the group's channel half of every tap
     }
     TSTAMP(3);
 
@@ -311,13 +319,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     f32x16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-    bf16x8 afr[2][NKC], bfr[8];
-    const unsigned char* bmine = bring + wn * 8 * 1024 + lane * 16;
+    bf16x8 afr[2][KPF], bfr[8 / KG];
+    const unsigned char* bmine = bring + (wn * 8 + kg * KPF) * 1024 + lane * 16;
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
 #pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) {
-            const int f = v * NKC + kc;
+        for (int kc = 0; kc < KPF; ++kc) {
+            const int f = v * NKC + kc;                            // group 0's fragment; the wave's own is f + kg * KPF
             if (f % 8 == 0) {
                 const int st = f / 8;
                 // stages <= st+1 have landed -- stage st one whole stage and a barrier ago (see above); RD = 4: stage st+2 in flight
@@ -326,16 +334,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
                 // implicit wait in front of a bare s_barrier)
                 if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wg_barrier();
-                if (st == 0) { TSTAMP(4); load_afrags<NKC>(afr[0], patch, a_lane); }
+                if (st == 0) { TSTAMP(4); load_afrags<KPF>(afr[0], patch, a_lane); }
                 if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
                 else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
                 const int slot = RD == 4 ? (st & 3) : (st % 3);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + (slot * SJ + i) * 1024);
+                for (int i = 0; i < 8 / KG; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + (slot * SJ + i) * 1024);
             }
             if (kc == 0 && v + 1 < VT) {
                 const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
-                load_afrags<NKC>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
+                load_afrags<KPF>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
             }
             if (f & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[v & 1][kc], bfr[f % 8], acc2, 0, 0, 0);
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[v & 1][kc], bfr[f % 8], acc, 0, 0, 0);
@@ -348,8 +356,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     __syncthreads();                                               // the patch is dead: reuse it as the output staging tile
 
     // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), bf16 stores, statistics
-    float* ot = reinterpret_cast<float*>(patch);                   // [TM][TN]
-    float* part = ot + TM * TN;                                    // [RG][TN][2]
+    float* ot = reinterpret_cast<float*>(patch) + kg * (TM * TN);  // [KG][TM][TN]: each k-group stages its partial tile
+    float* part = reinterpret_cast<float*>(patch) + KG * TM * TN;  // [RG][TN][2]
     {
         const int col = wn * 32 + (lane & 31);
 #pragma unroll
@@ -364,7 +372,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvP p) {
     for (int i = 0; i < RPT; ++i) {
         const int row = rg + RG * i;
         const unsigned m = m0 + row;
-        const float2 a = *reinterpret_cast<const float2*>(ot + row * TN + 2 * cp);
+        float2 a = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + row * TN + 2 * cp);
+        if constexpr (KG == 2) {
+            const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + TM * TN + row * TN + 2 * cp);
+            a.x += a2.x; a.y += a2.y;
+        }
         float v0 = a.x + b0 + bf_lo(rv[i]), v1 = a.y + b1 + bf_hi(rv[i]);
         const unsigned pk = pack2(v0, v1);
         if (m < M) {
@@ -907,6 +919,11 @@ template <typename KT>
 static bool allow_lds(KT kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
+// k-groups of the 128+-channel conv launches: 2 (default) or 1 (SAR_CONV16_KG=1: the four-wave kernel for every layer)
+static int conv16_kgroups() {
+    static const int v = [] { const char* e = getenv("SAR_CONV16_KG"); return e && atoi(e) == 1 ? 1 : 2; }();
+    return v;
+}
 
 }  // namespace
 
@@ -950,7 +967,8 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const v
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
-    const size_t stage_bytes = (size_t)TM * TN * 4 + 256 / (TN / 2) * TN * 2 * 4;
+    const int KG = (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;                  // two k-groups (512 threads) for the one-block-per-CU layers
+    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (256 * KG) / (TN / 2) * TN * 2 * 4;
     // the long k-loops of the 128+-channel layers (one block per CU anyway) get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
     const size_t ring_bytes = (size_t)p.rd * WN * 8 * 1024;
@@ -968,6 +986,17 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const v
 #undef CV
     static bool attr[2][5][2];
     const int ki = ilog2(Cin / 16) - 1, k3 = K == 3 ? 1 : 0;
+#define CV2(WN_, NH_) {conv_bf16_kernel<WN_, 8, NH_, 2>, conv_bf16_kernel<WN_, 8, 9 * NH_, 2>}
+    static const kern_t kerns2[2][3][2] = {{CV2(1, 1), CV2(1, 2), CV2(1, 4)}, {CV2(2, 1), CV2(2, 2), CV2(2, 4)}};
+#undef CV2
+    static bool attr2[2][3][2];
+    if (KG == 2) {
+        const kern_t kern = kerns2[WN - 1][ki - 2][k3];
+        if (!attr2[WN - 1][ki - 2][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr2[WN - 1][ki - 2][k3] = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     const kern_t kern = kerns[WN - 1][ki][k3];
     if (!attr[WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[WN - 1][ki][k3] = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
