@@ -124,6 +124,20 @@ class BnRef(ctypes.Structure):
                [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("pad_", ctypes.c_int)]
 
 
+class GemmBatch(ctypes.Structure):
+    """include/sarnet.h: sarGemmBatch -- up to four (A, B, C, bias) pointer sets of equal-shape GEMMs for one launch."""
+    _fields_ = [(n, ctypes.c_void_p * 4) for n in ("A", "B", "C", "bias")]
+
+    def __init__(self, sets):
+        super().__init__()
+        assert 1 <= len(sets) <= 4
+        self.n = len(sets)
+        self.keep = sets                                                     # the tensors whose addresses the struct holds
+        for i, st in enumerate(sets):
+            for name, t in zip(("A", "B", "C", "bias"), st):
+                getattr(self, name)[i] = None if t is None else t.data_ptr()
+
+
 class WgradConv(ctypes.Structure):
     """include/sarnet.h: sarWgradConv."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dy", "dw", "dbias")] + \

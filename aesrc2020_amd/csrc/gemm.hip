@@ -50,11 +50,17 @@ __device__ __forceinline__ void store_tile(const float (&r)[4], float (*S)[LDP],
     }
 }
 
+// Up to four problems of equal shape in one launch (grid.z = batch x split-K slices): the two directions of a BiGRU's input
+// projections, the four weight gradients of its kernels -- launches of ~1 us of matrix time each that otherwise queue behind one another.
+struct GemmBatch { const float* A[4]; const float* B[4]; float* C[4]; const float* bias[4]; float* colsum[4]; };
+
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                       float* __restrict__ C, const float* __restrict__ bias, int M,
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmBatch gb, int M,
                                                        int N, int K, int lda, int ldb, int ldc, int act,
-                                                       int accumulate, int splitk, float* __restrict__ colsum) {
+                                                       int accumulate, int splitk) {
+    const int bz = blockIdx.z / splitk, kz = blockIdx.z - bz * splitk;
+    const float* __restrict__ A = gb.A[bz]; const float* __restrict__ B = gb.B[bz];
+    float* __restrict__ C = gb.C[bz]; const float* __restrict__ bias = gb.bias[bz]; float* __restrict__ colsum = gb.colsum[bz];
     __shared__ __attribute__((aligned(16))) float As2[2][BK][LDP];
     __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LDP];
     float (*As)[LDP] = As2[0];
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // split-K: slice z handles k-tiles [kt0, kt1)
     const int nkt = (K + BK - 1) / BK;
     const int per = (nkt + splitk - 1) / splitk;
-    const int kt0 = blockIdx.z * per, kt1 = min(nkt, kt0 + per);
+    const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
     const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
 
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= N) return;
-    const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
+    const float bv = (bias != nullptr && kz == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -191,17 +197,18 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                        float* __restrict__ C, const float* __restrict__ bias, int M, int N,
-                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk,
-                                                        float* __restrict__ colsum) {
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
+                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
+    const int bz = blockIdx.z / splitk, kz = blockIdx.z - bz * splitk;
+    const float* __restrict__ A = gb.A[bz]; const float* __restrict__ B = gb.B[bz];
+    float* __restrict__ C = gb.C[bz]; const float* __restrict__ bias = gb.bias[bz]; float* __restrict__ colsum = gb.colsum[bz];
     __shared__ __attribute__((aligned(16))) unsigned char As[2][64 * GB_RS];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][64 * GB_RS];
     __shared__ float csum[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int nkt = K / GB_K, per = (nkt + splitk - 1) / splitk;
-    const int kt0 = blockIdx.z * per, kt1 = min(nkt, kt0 + per);
+    const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
     // staging: thread -> (row = tid / 4 of the tile as stored, 16 consecutive elements (tid % 4) * 16 of that row)
     const int srow = tid >> 2, sseg = (tid & 3) * 16;
     float4 ra[2][4], rb[2][4];
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const float* __restrict_
         if (tid < 64) atomicAdd(colsum + n0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
     }
     const int col = n0 + wn * 32 + (lane & 31);
-    const float bv = (bias != nullptr && blockIdx.z == 0) ? bias[col] : 0.f;
+    const float bv = (bias != nullptr && kz == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -302,17 +309,21 @@ extern "C" int sar_set_gemm_math(int mode) { if (mode < 0 || mode > 1) return SA
 extern "C" int sar_get_gemm_math(void) { return g_gemm_math; }
 
 // C-ABI: see include/sarnet.h
-static int gemm_launch(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
-                       int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk, float* colsum, hipStream_t stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splitk < 1) return SAR_EINVAL;
+static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda, int ldb,
+                       int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk, hipStream_t stream) {
+    if (nb < 1 || nb > 4 || M <= 0 || N <= 0 || K <= 0 || splitk < 1) return SAR_EINVAL;
     if (splitk > 1 && act != ACT_NONE) return SAR_EINVAL;  // split-K accumulates atomically: C must be pre-zeroed (or hold the addend)
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk), block(256);
+    bool aligned = true;
+    for (int i = 0; i < nb; ++i) {
+        if (!gb.A[i] || !gb.B[i] || !gb.C[i]) return SAR_EINVAL;
+        aligned = aligned && (reinterpret_cast<uintptr_t>(gb.A[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(gb.B[i]) & 15) == 0;
+    }
+    if (nb > 1 && !aligned) return SAR_EINVAL;             // a batch runs one code path: all operands 16-byte aligned
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk * nb), block(256);
     // bf16 MFMA path: whole 64 x 64 x 64 tiles, 16-byte aligned rows (every Dense / GRU-projection GEMM of the model)
-    if (g_gemm_math == 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 &&
-        (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0 && K / 64 >= splitk) {
+    if (g_gemm_math == 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && aligned && K / 64 >= splitk) {
 #define LAUNCH16(AK, BK_)                                                                                            \
-    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, \
-                       act, accumulate, splitk, colsum)
+    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)
         if (a_kc && b_kc) LAUNCH16(true, true);
         else if (a_kc && !b_kc) LAUNCH16(true, false);
         else if (!a_kc && b_kc) LAUNCH16(false, true);
@@ -322,8 +333,7 @@ static int gemm_launch(const float* A, const float* B, float* C, const float* bi
         return SAR_OK;
     }
 #define LAUNCH(AK, BK_)                                                                                              \
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, block, 0, stream, A, B, C, bias, M, N, K, lda, ldb, ldc, \
-                       act, accumulate, splitk, colsum)
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)
     if (a_kc && b_kc) LAUNCH(true, true);
     else if (a_kc && !b_kc) LAUNCH(true, false);
     else if (!a_kc && b_kc) LAUNCH(false, true);
@@ -336,12 +346,38 @@ static int gemm_launch(const float* A, const float* B, float* C, const float* bi
 extern "C" int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                             int ldb, int ldc, int a_kc, int b_kc, int act, int accumulate, int splitk,
                             hipStream_t stream) {
-    return gemm_launch(A, B, C, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, accumulate, splitk, nullptr, stream);
+    GemmBatch gb{};
+    gb.A[0] = A; gb.B[0] = B; gb.C[0] = C; gb.bias[0] = bias;
+    return gemm_launch(gb, 1, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, accumulate, splitk, stream);
 }
 
 // Weight gradient of a Dense layer with its bias gradient: dW[in,out] += X^T[in,R] dY[R,out], db[out] += sum_R dY.
 // X is (R, in) row-major (lda), dY is (R, out) row-major (ldb); both results ACCUMULATE (split-K uses atomics).
 extern "C" int sar_gemm_wgrad_f32(const float* X, const float* dY, float* dW, float* db, int in_dim, int out_dim, int R,
                                   int lda, int ldb, int ldc, int splitk, hipStream_t stream) {
-    return gemm_launch(X, dY, dW, nullptr, in_dim, out_dim, R, lda, ldb, ldc, 0, 0, ACT_NONE, 1, splitk, db, stream);
+    GemmBatch gb{};
+    gb.A[0] = X; gb.B[0] = dY; gb.C[0] = dW; gb.colsum[0] = db;
+    return gemm_launch(gb, 1, in_dim, out_dim, R, lda, ldb, ldc, 0, 0, ACT_NONE, 1, splitk, stream);
+}
+
+// include/sarnet.h: sarGemmBatch (host struct of device pointers; entries >= nbatch ignored)
+struct sarGemmBatch { const float* A[4]; const float* B[4]; float* C[4]; const float* bias[4]; };
+
+// nbatch (1..4) problems of equal shape, layouts and flags in ONE launch: C[i] = act(op(A[i]) op(B[i]) + bias[i]) as sar_gemm_f32.
+extern "C" int sar_gemm_batched_f32(const sarGemmBatch* b, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int a_kc,
+                                    int b_kc, int act, int accumulate, int splitk, hipStream_t stream) {
+    if (!b || nbatch < 1 || nbatch > 4) return SAR_EINVAL;
+    GemmBatch gb{};
+    for (int i = 0; i < nbatch; ++i) { gb.A[i] = b->A[i]; gb.B[i] = b->B[i]; gb.C[i] = b->C[i]; gb.bias[i] = b->bias[i]; }
+    return gemm_launch(gb, nbatch, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, accumulate, splitk, stream);
+}
+
+// nbatch weight gradients of equal shape in one launch: A[i] = X_i (R, in), B[i] = dY_i (R, out), C[i] = dW_i (+=), bias[i] = db_i
+// (+=, nullable), as sar_gemm_wgrad_f32.
+extern "C" int sar_gemm_wgrad_batched_f32(const sarGemmBatch* b, int nbatch, int in_dim, int out_dim, int R, int lda, int ldb,
+                                          int ldc, int splitk, hipStream_t stream) {
+    if (!b || nbatch < 1 || nbatch > 4) return SAR_EINVAL;
+    GemmBatch gb{};
+    for (int i = 0; i < nbatch; ++i) { gb.A[i] = b->A[i]; gb.B[i] = b->B[i]; gb.C[i] = b->C[i]; gb.colsum[i] = const_cast<float*>(b->bias[i]); }
+    return gemm_launch(gb, nbatch, in_dim, out_dim, R, lda, ldb, ldc, 0, 0, ACT_NONE, 1, splitk, stream);
 }

@@ -141,9 +141,9 @@ class BiGRU(Layer):
         self.x, self.B, self.L = x, B, L
         R = B * L
         xa = [self.buf("xa_f", (R, 3 * H)), self.buf("xa_b", (R, 3 * H))]
-        for i, d in enumerate(("forward", "backward")):
-            k, u, b = self.p[d]
-            gemm(x, k.w, xa[i], b.w, R, 3 * H, I, I, 3 * H, 3 * H, 1, 0)
+        # both directions' input projections in one launch (two ~1 us GEMMs would queue behind each other)
+        gb = _lib.GemmBatch([(x, self.p[d][0].w, xa[i], self.p[d][2].w) for i, d in enumerate(("forward", "backward"))])
+        _call("sar_gemm_batched_f32", gb, 2, R, 3 * H, I, I, 3 * H, 3 * H, 1, 0, 0, 0, 1)
         self.out = self.buf("out", (B, L, 2 * H)); self.gates = self.buf("gates", (2, B, L, 4, H)); self.hprev = self.buf("hprev", (2, B, L, H))
         (kf, uf, bf), (kb, ub, bb) = self.p["forward"], self.p["backward"]
         # "bf16" mode at the reference's hidden_dim: recurrent kernels packed as bf16 MFMA fragments, resident on chip (gru_mfma.hip)
@@ -181,10 +181,17 @@ class BiGRU(Layer):
             dx = dx_out if dx_out is not None else self.buf("dx", (R, I))
         sk = pick_splitk(I, 3 * H, R)
         sku = pick_splitk(H, 3 * H, R)
+        # the weight gradients of the four kernels (input / recurrent x two directions): one launch when they have one shape
+        # (in_dim == hidden: the reference's CNN_LIN -> CRNN), else one per kind
+        ks = [(self.x, dai[i], self.p[d][0].g, self.p[d][2].g[:3 * H]) for i, d in enumerate(("forward", "backward"))]
+        us = [(self.hprev[i], dah[i], self.p[d][1].g, self.p[d][2].g[3 * H:]) for i, d in enumerate(("forward", "backward"))]
+        if I == H and sk == sku:
+            _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(ks + us), 4, I, 3 * H, R, I, 3 * H, 3 * H, sk)
+        else:
+            _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(ks), 2, I, 3 * H, R, I, 3 * H, 3 * H, sk)
+            _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(us), 2, H, 3 * H, R, H, 3 * H, 3 * H, sku)
         for i, d in enumerate(("forward", "backward")):
             k, u, b = self.p[d]
-            _call("sar_gemm_wgrad_f32", self.x, dai[i], k.g, b.g[:3 * H], I, 3 * H, R, I, 3 * H, 3 * H, sk)
-            _call("sar_gemm_wgrad_f32", self.hprev[i], dah[i], u.g, b.g[3 * H:], H, 3 * H, R, H, 3 * H, 3 * H, sku)
             if need_dx:
                 gemm(dai[i], k.w, dx, None, R, I, 3 * H, 3 * H, 3 * H, I, 1, 1, 0, 1 if (accumulate_dx or i == 1) else 0)
         return dx

@@ -65,8 +65,8 @@ def conv_roofline(model, B, iters=10):
     def bf16_block(blk, nxt_bn1):
         """The six conv launches of one residual block exactly as ResNetTrunk._forward16 / _backward16 issue them (same fills,
         side tensors, epilogue statistics; BatchNorm constants from the last step's saved values, statistics into scratch bins),
-        classed by the kernel instantiation rocprofv3 reports: conv_bf16_kernel<WN, NKC, VT>, WN = 2 for 64+ output channels of
-        the launch, NKC = source channels / 16 up to 8, VT = taps x 128-channel parts."""
+        classed by the kernel instantiation rocprofv3 reports: conv_bf16_kernel<WN, NKC, VT, KG>, WN = 2 for 64+ output channels of
+        the launch, NKC = source channels / 16 up to 8, VT = taps x 128-channel parts, KG = 2 (eight waves) for 128+ source channels."""
         BF = torch.bfloat16
         H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
         cin, cout = blk["cin"], blk["cout"]
@@ -82,7 +82,8 @@ def conv_roofline(model, B, iters=10):
         b1, b2 = bins(cout), bins(cin)
 
         def inst(cv, ci, co):
-            return "conv_bf16_kernel<%d, %d, %d>" % (2 if co >= 64 else 1, min(ci // 16, 8), cv.k * cv.k * max(1, ci // 128))
+            kg = 2 if ci >= 128 and os.environ.get("SAR_CONV16_KG") != "1" else 1          # k-groups: eight waves for the 128+-channel sources
+            return "conv_bf16_kernel<%d, %d, %d, %d>" % (2 if co >= 64 else 1, min(ci // 16, 8), cv.k * cv.k * max(1, ci // 128), kg)
 
         def fl(cv):
             return 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k

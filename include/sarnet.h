@@ -38,6 +38,16 @@ int sar_gemm_f32(const float* A, const float* B, float* C, const float* bias, in
 int sar_gemm_wgrad_f32(const float* X, const float* dY, float* dW, float* db, int in_dim, int out_dim, int R, int lda,
                        int ldb, int ldc, int splitk, sarStream_t stream);
 
+/* Up to four problems of equal shape, layouts and flags in ONE launch (grid.z = batch x split-K slices): the input projections of
+ * the two directions of Bidirectional(CuDNNGRU) (model.py:44-50) and the weight gradients of its four kernels -- ~1 us of matrix
+ * time each, so separate launches only queue behind one another.  Host struct of device pointers; entries >= nbatch are ignored. */
+typedef struct sarGemmBatch { const float* A[4]; const float* B[4]; float* C[4]; const float* bias[4]; } sarGemmBatch;
+int sar_gemm_batched_f32(const sarGemmBatch* b, int nbatch, int M, int N, int K, int lda, int ldb, int ldc, int a_kc, int b_kc,
+                         int act, int accumulate, int splitk, sarStream_t stream);
+/* A[i] = X_i (R,in), B[i] = dY_i (R,out), C[i] = dW_i (+=), bias[i] = db_i (+=, nullable): sar_gemm_wgrad_f32, batched */
+int sar_gemm_wgrad_batched_f32(const sarGemmBatch* b, int nbatch, int in_dim, int out_dim, int R, int lda, int ldb, int ldc,
+                               int splitk, sarStream_t stream);
+
 /* ---- ResNet convolutions: Conv2D at resnet.py:39-42, 60-63, 82-87, 113-117 (TF SAME / VALID padding given as
  * explicit pad_top/pad_left).  scale/shift (nullable) fold the preceding BatchNormalization+ReLU
  * (resnet.py:22-26) into the operand load: P(x)=relu(x*scale+shift).  residual (nullable) is the Add() of

@@ -99,6 +99,37 @@ def test_gemm_bf16_math(L, a_kc, b_kc, M, N, K, sk):
     assert L.get_gemm_math() == old
 
 
+@pytest.mark.parametrize("math", ["fp32", "bf16"])
+def test_gemm_batched(L, math):
+    """sar_gemm_batched_f32 / sar_gemm_wgrad_batched_f32: up to four equal-shape problems in one launch (the BiGRU's projections
+    and kernel gradients) against float64 per problem, both arithmetic modes, split-K included."""
+    rng = np.random.default_rng(5)
+    bf = (lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()) if math == "bf16" else (lambda a: a)
+    tol = 2e-5 if math == "bf16" else 2e-4
+    R, I, N = 2496, 256, 768
+    old = L.get_gemm_math()
+    L.set_gemm_math(math)
+    try:
+        X = rng.standard_normal((R, I)); Ws = [rng.standard_normal((I, N)) / 16 for _ in range(2)]; bs = [rng.standard_normal(N) for _ in range(2)]
+        Xd = dev(X); Wd = [dev(w) for w in Ws]; bd = [dev(b) for b in bs]; Cs = [zeros(R, N) for _ in range(2)]
+        gb = L.GemmBatch([(Xd, Wd[i], Cs[i], bd[i]) for i in range(2)])
+        L.call("sar_gemm_batched_f32", gb, 2, R, N, I, I, N, N, 1, 0, 0, 0, 1)
+        for i in range(2):
+            check(Cs[i], bf(X) @ bf(Ws[i]) + bs[i], tol, "batched projection %d" % i)
+        Xs = [rng.standard_normal((R, I)) for _ in range(4)]; dYs = [rng.standard_normal((R, N)) / 50 for _ in range(4)]
+        dW0 = [rng.standard_normal((I, N)) for _ in range(4)]; db0 = [rng.standard_normal(N) for _ in range(4)]
+        dW = [dev(a) for a in dW0]; db = [dev(a) for a in db0[:3]] + [None]
+        Xsd = [dev(a) for a in Xs]; dYd = [dev(a) for a in dYs]
+        gb = L.GemmBatch([(Xsd[i], dYd[i], dW[i], db[i]) for i in range(4)])
+        L.call("sar_gemm_wgrad_batched_f32", gb, 4, I, N, R, I, N, N, 3)
+        for i in range(4):
+            check(dW[i], dW0[i] + bf(Xs[i]).T @ bf(dYs[i]), tol, "batched dW %d" % i)
+            if db[i] is not None:
+                check(db[i], db0[i] + dYs[i].sum(0), tol, "batched db %d" % i)
+    finally:
+        L.set_gemm_math(old)
+
+
 def test_gemm_transpose_detecting(L):
     # asymmetric B with A = I catches a swapped C write (guide rule 16)
     n = 64
