@@ -48,10 +48,16 @@ def conv_roofline(model, B, iters=10):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn):
+        """Average duration of one launch: `iters` launches captured into a HIP graph (as the train step runs them -- eager launches
+        of ~10 us kernels would measure the host's launch rate), replayed between two events on the launch stream."""
         fn(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay(); torch.cuda.synchronize()
         ev0.record()
-        for _ in range(iters):
-            fn()
+        g.replay()
         ev1.record(); torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) * 1e-3 / iters
 
