@@ -147,6 +147,12 @@ __device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0,
     }
 }
 
+// 16-byte store that is not kept in the writer's L2 (nobody on this XCD reads it again before the launch ends)
+__device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(dst));
+}
+
 // Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
 // per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
 // source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
@@ -182,7 +188,7 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
         for (int j = 0; j < U; ++j) {
             const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);                 // branch-free: pieces past the end land in a scratch slot
             *reinterpret_cast<uint4*>(patch + (i0 + NTHR * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
-            if (do_side && off[j] != NONE && own[j] < (unsigned)TM) *reinterpret_cast<uint4*>(side + off[j]) = r;
+            if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
         }
     }
 }
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
         float v0 = a.x + b0 + bf_lo(rv[i]), v1 = a.y + b1 + bf_hi(rv[i]);
         const unsigned pk = pack2(v0, v1);
         if (m < M) {
-            *reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c) = pk;
+            __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
             // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
             if (p.epi == 1) { v0 = bf_lo(pk); v1 = bf_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }

@@ -473,7 +473,7 @@ class SARNetModel:
         backward: stage 3], [stage 2], [stages 1-0 + stem], [L2+Adam] -- and after each backward graph the RCCL all-reduce
         of the gradient bucket it completed is launched asynchronously, so it runs on RCCL's stream underneath the next
         graph; only the last, small bucket (stages 1-0 + stem, 1.5 MB at F=32) is exposed before Adam waits for all."""
-        if self.dp.world == 1:
+        if not self.dp.enabled:
             self._run_segments([("step", self._device_step, None)])
             return
         works = []

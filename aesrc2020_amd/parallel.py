@@ -11,11 +11,18 @@ import torch
 import torch.distributed as dist
 
 
+def forced():
+    """SAR_DP_FORCE=1: run the data-parallel step (five graphs, bucketed asynchronous all-reduce) even in a world of ONE rank --
+    how a 1-GPU box exercises the real RCCL path (communicator, RCCL's stream under graph replays, work.wait()); the reduction of a
+    one-rank group is the identity, so the step must agree with the single-graph step."""
+    return os.environ.get("SAR_DP_FORCE", "0") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("SAR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
@@ -61,7 +68,7 @@ class DataParallel:
         pooling, GRUs), then the conv trunk from its end towards its start, cut at the parameters named in `trunk_splits`
         (ResNetTrunk.bucket_split_names(): stage 3, stage 2), the rest last."""
         self.store = store
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         split = store.n

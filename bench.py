@@ -338,7 +338,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(r["kw"], r["input_shape"], r["B"])
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():                       # world > 1, or the forced one-rank data-parallel step (SAR_DP_FORCE=1)
         dist.barrier()
         dist.destroy_process_group()
 
