@@ -6,6 +6,8 @@ model methods train.py uses (fit_generator / train_on_batch / save / load_weight
 The step itself is a static plan of hand-written HIP kernel launches (forward, explicit backward, fused L2+Adam)
 captured into one HIP graph; data parallelism is one process per GPU with an RCCL all-reduce of the flat gradient
 buffer (parallel.py) instead of keras.utils.multi_gpu_model (model.py:193-194)."""
+import os
+
 import numpy as np
 import torch
 
@@ -107,6 +109,7 @@ class SARNetModel:
                 self.CTC_BIGRU = BIGRU(2 * H, H, name="CTC_BIGRU"); self.CTC_BIGRU_LN = LN(2 * H, name="CTC_BIGRU_LN")
                 self.CTC_DS = DS(2 * H, H, "tanh", name="CTC_DS"); self.CTC_DS_LN = LN(H, name="CTC_DS_LN")
                 self.ctc_pred = DS(H, c["bpe_classes"], "softmax", name="ctc_pred")
+            self._fused_accent = False
             if c["ar_enable"]:
                 self.AR_DS = DS(2 * H, H, "tanh", name="AR_DS"); self.AR_DS_LN = LN(H, name="AR_DS_LN")
                 mto = c["mto"]
@@ -124,6 +127,8 @@ class SARNetModel:
                 self.AR_BN2 = BN(H, name="AR_BN2")
                 self.AR_CF_DS1 = DS(H, 64, "relu", name="AR_CF_DS1"); self.AR_CF_DS2 = DS(64, 64, "relu", name="AR_CF_DS2")
                 self.y_accent = DS(64, A, "softmax", name="y_accent")
+                # one launch for the three layers + cross-entropy + their backward where the sizes fit its LDS plan
+                self._fused_accent = A <= 32 and H <= 256 and os.environ.get("SAR_FUSED_ACCENT", "1") == "1"
                 self.disc = None
                 if c["disc_enable"]:
                     ml = c["metric_loss"]
@@ -289,7 +294,26 @@ class SARNetModel:
             self.in_ctc_out_len.copy_(dev["x_ctc_out_len"].view(-1))
 
     # ------------------------------------------------------------------ forward / backward plans
-    def _forward(self):
+    def _accent_classifier(self, ar, mode):
+        """AR_CF_DS1 -> AR_CF_DS2 -> y_accent (+ categorical cross-entropy, + the whole backward down to d(ar) in mode 'train') in one
+        launch (csrc/heads_fused.hip): 15 launches of ~1 us of arithmetic otherwise.  The layers keep their parameters, names,
+        `.output` tensors and gradient buffers; only who computes them changes."""
+        l1, l2, l3 = self.AR_CF_DS1, self.AR_CF_DS2, self.y_accent
+        B = self.B
+        h1, h2, probs = l1.buf("y", (B, l1.units)), l2.buf("y", (B, l2.units)), l3.buf("y", (B, l3.units))
+        self._accent_loss = self.store.bufs.get("loss/y_accent/loss", (B,))
+        self._accent_dx = l1.buf("dx", (B, l1.in_dim))
+        want_loss = mode != "predict" and "y_accent" in self.loss_weights
+        train = mode == "train" and want_loss
+        _call("sar_accent_classifier_f32", ar, l1.kernel.w, l1.bias.w, l2.kernel.w, l2.bias.w, l3.kernel.w, l3.bias.w,
+              self.in_y_accent if want_loss else None, self.seed["y_accent"] if train else None, h1, h2, probs, self._accent_loss,
+              l1.kernel.g, l1.bias.g, l2.kernel.g, l2.bias.g, l3.kernel.g, l3.bias.g, self._accent_dx, B, l1.in_dim, l1.units, l2.units, l3.units)
+        l1.output, l2.output, l3.output = h1, h2, probs
+        return probs
+
+    def _forward(self, mode="predict"):
+        """mode: 'predict' (outputs only), 'eval' (+ losses follow), 'train' (+ backward follows) -- what the fused accent classifier
+        (forward + loss + backward in one launch) is asked to produce; everything else runs the same in all three."""
         c = self.cfg
         B, L = self.B, self.L
         cnn = self.trunk.forward(self.in_x, B)
@@ -317,8 +341,11 @@ class SARNetModel:
             ar = self.AR_EMBEDDING.forward(ar)
             ar = self.AR_BN2.forward(ar, B)
             self.out["ar"] = ar
-            a1 = self.AR_CF_DS2.forward(self.AR_CF_DS1.forward(ar))
-            self.out["y_accent"] = self.y_accent.forward(a1)
+            if self._fused_accent:
+                self.out["y_accent"] = self._accent_classifier(ar, mode)
+            else:
+                a1 = self.AR_CF_DS2.forward(self.AR_CF_DS1.forward(ar))
+                self.out["y_accent"] = self.y_accent.forward(a1)
             if c["disc_enable"]:
                 ml = c["metric_loss"]
                 if ml == "softmax":
@@ -343,7 +370,8 @@ class SARNetModel:
         c = self.cfg
         self.loss_vec = {}
         if "y_accent" in self.loss_weights:
-            self.loss_vec["y_accent"] = self.cce_accent.forward(self.in_y_accent, self.out["y_accent"])
+            self.loss_vec["y_accent"] = (self._accent_loss if self._fused_accent else
+                                         self.cce_accent.forward(self.in_y_accent, self.out["y_accent"]))
         if "y_disc" in self.loss_weights:
             if c["metric_loss"] == "circleloss":
                 self.loss_vec["y_disc"] = self.circle.forward(self.in_y_disc, self.out["y_disc"], gamma=256, margin=c["margin"])
@@ -374,10 +402,13 @@ class SARNetModel:
             g = self.CTC_BIGRU_LN.backward(g)
             d_crnn = self.CTC_BIGRU.backward(g.view(B, L, -1))
         if c["ar_enable"]:
-            dp = self.cce_accent.backward(self.seed["y_accent"])
-            g = self.y_accent.backward(dp)
-            g = self.AR_CF_DS1.backward(self.AR_CF_DS2.backward(g))           # -> d(ar) buffer of AR_CF_DS1
-            d_ar = g
+            if self._fused_accent:
+                d_ar = self._accent_dx                                        # written by the forward's launch (mode 'train')
+            else:
+                dp = self.cce_accent.backward(self.seed["y_accent"])
+                g = self.y_accent.backward(dp)
+                g = self.AR_CF_DS1.backward(self.AR_CF_DS2.backward(g))       # -> d(ar) buffer of AR_CF_DS1
+                d_ar = g
             if c["disc_enable"]:
                 ml = c["metric_loss"]
                 if ml == "circleloss":
@@ -425,13 +456,13 @@ class SARNetModel:
 
     def _device_step(self, update=True):
         self.store.zero_grads()
-        self._forward(); self._losses_forward(); self._backward()
+        self._forward("train"); self._losses_forward(); self._backward()
         if update:
             self.store.adam_step()
 
     def _seg_heads(self):
         self.store.zero_grads()
-        self._forward(); self._losses_forward(); self._backward_heads()
+        self._forward("train"); self._losses_forward(); self._backward_heads()
 
     def _seg_trunk(self, part):
         self.trunk.backward(self._g_trunk, part=part)
@@ -527,7 +558,7 @@ class SARNetModel:
         """For tests: forward + losses + backward without the optimizer update; grads stay in store.grads."""
         self._upload(x, y)
         self.store.zero_grads()
-        self._forward(); self._losses_forward(); self._backward()
+        self._forward("train"); self._losses_forward(); self._backward()
         return self._logs_no_l2()
 
     def _logs_no_l2(self):
@@ -650,7 +681,7 @@ class SARNetModel:
                 sl = slice(s, min(n, s + batch_size))
                 xb = {k: v[sl] for k, v in x.items()}; yb = {k: v[sl] for k, v in (y or {}).items()}
                 self._upload(xb, yb)
-                self._forward(); self._losses_forward()
+                self._forward("eval"); self._losses_forward()
                 self.store.l2_penalty()
                 logs = self._logs()
                 nb = sl.stop - sl.start; tot += nb

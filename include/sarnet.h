@@ -302,6 +302,15 @@ int sar_margin_head_fwd_f32(const float* x, const float* y, const float* W, floa
 int sar_margin_head_bwd_f32(const float* dprobs, const float* probs, const float* cosv, const float* x, const float* y,
                             const float* W, const float* inv_x, const float* inv_w, float* dx, float* dW, float* dwn_ws,
                             int B, int D, int A, int mode, float s, float m, int accumulate_dx, sarStream_t stream);
+/* ---- The accent classifier in one launch: AR_CF_DS1 = Dense(relu) -> AR_CF_DS2 = Dense(relu) -> y_accent = Dense(softmax)
+ * (model.py:150-152 via DS, model.py:35-42) + categorical_crossentropy(y_true, y_accent) (model.py:350) + their backward.  x (B,H);
+ * W1 (H,D1), W2 (D1,D2), W3 (D2,A) with biases; h1 (B,D1), h2 (B,D2), probs (B,A) are the three layers' outputs.  y_true NULL:
+ * forward only; dloss (B, = loss weight / B) NULL: + loss (B); both: + backward -- dW / db of the three layers accumulate, dx (B,H) is
+ * written.  D1, D2 <= 64, A <= 32 (the reference: 64 / 64 / 8); larger shapes take the per-layer entry points. */
+int sar_accent_classifier_f32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                              const float* b3, const float* y_true, const float* dloss, float* h1, float* h2, float* probs,
+                              float* loss, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dx,
+                              int B, int H, int D1, int D2, int A, sarStream_t stream);
 /* ---- circle_loss: losses.py:157-172 ; Keras categorical_crossentropy: model.py:350,354 */
 int sar_circle_loss_fwd_f32(const float* y, const float* s, float* loss, int B, int A, float gamma, float margin, sarStream_t stream);
 int sar_circle_loss_bwd_f32(const float* y, const float* s, const float* dloss, float* ds, int B, int A, float gamma, float margin, sarStream_t stream);

@@ -130,6 +130,37 @@ def test_gemm_batched(L, math):
         L.set_gemm_math(old)
 
 
+@pytest.mark.parametrize("B,H,D1,D2,A", [(64, 256, 64, 64, 8), (5, 32, 64, 64, 8), (130, 64, 48, 33, 11)])
+def test_accent_classifier_fused(L, B, H, D1, D2, A):
+    """sar_accent_classifier_f32: Dense(relu) -> Dense(relu) -> Dense(softmax) -> categorical_crossentropy, forward + loss + backward in
+    one launch, against the float64 oracle ops (dense / softmax / Keras cross-entropy); all three call modes; several row blocks."""
+    rng = np.random.default_rng(B + H)
+    x = rng.standard_normal((B, H)); Ws = [rng.standard_normal(s_) / np.sqrt(s_[0]) for s_ in ((H, D1), (D1, D2), (D2, A))]
+    bs = [0.1 * rng.standard_normal(n) for n in (D1, D2, A)]
+    y = np.eye(A)[rng.integers(0, A, B)]; dl = rng.uniform(0.5, 1.5, B) / B
+    h1, c1 = O.dense_fwd(x, Ws[0], bs[0], "relu"); h2, c2 = O.dense_fwd(h1, Ws[1], bs[1], "relu"); p, c3 = O.dense_fwd(h2, Ws[2], bs[2], "softmax")
+    loss, dp = O.categorical_crossentropy_fwd_bwd(y, p)
+    g, dW3, db3 = O.dense_bwd(dp * dl[:, None], c3); g, dW2, db2 = O.dense_bwd(g, c2); dx, dW1, db1 = O.dense_bwd(g, c1)
+    d = [dev(a) for a in (x, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])]
+    outs = lambda: (zeros(B, D1), zeros(B, D2), zeros(B, A), zeros(B))
+    g0 = [rng.standard_normal(s_) for s_ in ((H, D1), (D1,), (D1, D2), (D2,), (D2, A), (A,))]
+    # predict
+    o = outs()
+    L.call("sar_accent_classifier_f32", *d, None, None, *o, None, None, None, None, None, None, None, B, H, D1, D2, A)
+    check(o[0], h1, name="h1"); check(o[1], h2, name="h2"); check(o[2], p, name="probs")
+    # evaluate: + loss
+    o = outs()
+    L.call("sar_accent_classifier_f32", *d, dev(y), None, *o, None, None, None, None, None, None, None, B, H, D1, D2, A)
+    check(o[2], p, name="probs (eval)"); check(o[3], loss, name="loss")
+    # train: + gradients (accumulated onto what the buffers held) and dx (written)
+    o = outs(); gd = [dev(a) for a in g0]; dxd = dev(rng.standard_normal((B, H)))
+    L.call("sar_accent_classifier_f32", *d, dev(y), dev(dl), *o, *gd, dxd, B, H, D1, D2, A)
+    check(o[3], loss, name="loss (train)")
+    for got, base, ref, nm in zip(gd, g0, (dW1, db1, dW2, db2, dW3, db3), ("dW1", "db1", "dW2", "db2", "dW3", "db3")):
+        check(got, base + ref, name=nm)
+    check(dxd, dx, name="dx")
+
+
 def test_gemm_transpose_detecting(L):
     # asymmetric B with A = I catches a swapped C write (guide rule 16)
     n = 64
