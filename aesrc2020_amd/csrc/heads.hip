@@ -111,8 +111,102 @@ __global__ __launch_bounds__(64) void margin_bwd_kernel(const float* __restrict_
     }
 }
 
+// Forward + Keras categorical_crossentropy + backward of one sample in ONE wave (margin_fwd_kernel, cce_fwd / cce_bwd, margin_bwd_kernel
+// back to back on the same lanes: lane a < A owns class a): the training step's six launches around the head become two (this + the
+// column-normalisation backward).  grid = B, block = 64.  dwn (D,A): zero on entry (margin_wbwd_kernel<true> leaves it zero again).
+__global__ __launch_bounds__(64) void margin_train_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ y_true, const float* __restrict__ dloss,
+                                                          const float* __restrict__ W, float* __restrict__ probs, float* __restrict__ loss,
+                                                          float* __restrict__ inv_w, float* __restrict__ dx, float* __restrict__ dwn,
+                                                          int D, int A, int mode, float s, float m, int accumulate_dx) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float* xr = x + (long)b * D;
+    float sx = 0.f;
+    for (int d = lane; d < D; d += 64) sx = fmaf(xr[d], xr[d], sx);
+    sx = wave_sum(sx);
+    const float ix = 1.f / sqrtf(fmaxf(sx, 1e-12f));
+    float my_logit = -INFINITY, c = 0.f, my_iw = 0.f;
+    const float yy = lane < A ? y[(long)b * A + lane] : 0.f;
+    for (int a = 0; a < A; ++a) {
+        float sw = 0.f, dot = 0.f;
+        for (int d = lane; d < D; d += 64) { const float w = W[(long)d * A + a]; sw = fmaf(w, w, sw); dot = fmaf(xr[d], w, dot); }
+        sw = wave_sum(sw); dot = wave_sum(dot);
+        const float iw = 1.f / sqrtf(fmaxf(sw, 1e-12f));
+        if (lane == a) {
+            c = dot * ix * iw; my_iw = iw;
+            float t;
+            if (mode == HEAD_COS) t = c - m;
+            else {
+                const float th = acosf(fminf(fmaxf(c, -1.f + KEPS), 1.f - KEPS));
+                t = mode == HEAD_ARC ? cosf(th + m) : cosf(m * th);
+            }
+            my_logit = (c * (1.f - yy) + t * yy) * s;
+            if (b == 0) inv_w[a] = sw >= 1e-12f ? iw : -iw;
+        }
+    }
+    const float mx = wave_max(my_logit);
+    const float e = lane < A ? expf(my_logit - mx) : 0.f;
+    const float p = e / wave_sum(e);
+    if (lane < A) probs[(long)b * A + lane] = p;
+    // categorical_crossentropy(y_true, p): renormalise, clip (cce_fwd_kernel / cce_bwd_kernel)
+    const float yt = lane < A ? y_true[(long)b * A + lane] : 0.f;
+    const float S = wave_sum(p), q = p / S;
+    const float l = wave_sum(lane < A ? -yt * logf(fminf(fmaxf(q, KEPS), 1.f - KEPS)) : 0.f);
+    if (lane == 0) loss[b] = l;
+    const float dq = (lane < A && q >= KEPS && q <= 1.f - KEPS) ? -yt / q : 0.f;
+    const float acc = wave_sum(dq * q);
+    const float dp = lane < A ? dloss[b] * (dq - acc) / S : 0.f;
+    // margin_bwd_kernel
+    const float sd = wave_sum(p * dp);
+    float dc = 0.f;
+    if (lane < A) {
+        const float dlog = p * (dp - sd);
+        float dt = 1.f;
+        if (mode != HEAD_COS) {
+            const float lo = -1.f + KEPS, hi = 1.f - KEPS;
+            if (c < lo || c > hi) dt = 0.f;
+            else {
+                const float th = acosf(c);
+                dt = mode == HEAD_ARC ? sinf(th + m) / sinf(th) : m * sinf(m * th) / sinf(th);
+            }
+        }
+        dc = s * dlog * ((1.f - yy) + yy * dt);
+    }
+    float proj = 0.f;
+    float dxn_l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dxn_l[i] = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float dca = __shfl(dc, a, 64), iw = __shfl(my_iw, a, 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = lane + i * 64;
+            if (d < D) {
+                const float wn = W[(long)d * A + a] * iw;
+                dxn_l[i] = fmaf(dca, wn, dxn_l[i]);
+                atomicAdd(dwn + (long)d * A + a, xr[d] * ix * dca);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const int d = lane + i * 64; if (d < D) proj = fmaf(xr[d] * ix, dxn_l[i], proj); }
+    proj = wave_sum(proj);
+    if (sx < 1e-12f) proj = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int d = lane + i * 64;
+        if (d < D) {
+            const float g = (dxn_l[i] - xr[d] * ix * proj) * ix;
+            float* dst = dx + (long)b * D + d;
+            *dst = accumulate_dx ? *dst + g : g;
+        }
+    }
+}
+
 // column-normalisation backward: dW[:,a] += (dwn[:,a] - wn[:,a] (wn[:,a].dwn[:,a])) * inv_w[a];  grid = A, block = 64
-__global__ __launch_bounds__(64) void margin_wbwd_kernel(const float* __restrict__ dwn, const float* __restrict__ W,
+// CLEAR: the workspace is left zero for the next step (saves the zeroing launch in front of the next margin_train_kernel)
+template <bool CLEAR>
+__global__ __launch_bounds__(64) void margin_wbwd_kernel(float* __restrict__ dwn, const float* __restrict__ W,
                                                          const float* __restrict__ inv_w, float* __restrict__ dW, int D,
                                                          int A) {
     const int a = blockIdx.x, lane = threadIdx.x;
@@ -121,7 +215,10 @@ __global__ __launch_bounds__(64) void margin_wbwd_kernel(const float* __restrict
     for (int d = lane; d < D; d += 64) proj = fmaf(W[(long)d * A + a] * iw, dwn[(long)d * A + a], proj);
     proj = wave_sum(proj);
     if (iws < 0.f) proj = 0.f;
-    for (int d = lane; d < D; d += 64) dW[(long)d * A + a] += (dwn[(long)d * A + a] - W[(long)d * A + a] * iw * proj) * iw;
+    for (int d = lane; d < D; d += 64) {
+        dW[(long)d * A + a] += (dwn[(long)d * A + a] - W[(long)d * A + a] * iw * proj) * iw;
+        if (CLEAR) dwn[(long)d * A + a] = 0.f;
+    }
 }
 
 // thread per sample
@@ -225,7 +322,22 @@ extern "C" int sar_margin_head_bwd_f32(const float* dprobs, const float* probs, 
     if (!dprobs || !probs || !cosv || !x || !y || !W || !inv_x || !inv_w || !dx || !dW || !dwn_ws || A > 64 || D > 512) return SAR_EINVAL;
     if (sar_zero_async(dwn_ws, sizeof(float) * D * A, stream) != hipSuccess) return SAR_ELAUNCH;
     hipLaunchKernelGGL(margin_bwd_kernel, dim3(B), dim3(64), 0, stream, dprobs, probs, cosv, x, y, W, inv_x, inv_w, dx, dwn_ws, D, A, mode, s, m, accumulate_dx);
-    hipLaunchKernelGGL(margin_wbwd_kernel, dim3(A), dim3(64), 0, stream, dwn_ws, W, inv_w, dW, D, A);
+    hipLaunchKernelGGL(margin_wbwd_kernel<false>, dim3(A), dim3(64), 0, stream, dwn_ws, W, inv_w, dW, D, A);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// The training step of a margin head in two launches: forward (probs), categorical_crossentropy(y_true, probs) (loss), and the backward
+// of both -- dx (written or accumulated), dW += -- per sample in one wave, then the column-normalisation backward.  y = the one-hot
+// labels the margin is applied to (losses.py: the layer's second input), y_true = the loss target, dloss (B) = d total / d loss_b.
+// inv_w: float[A] scratch.  dwn_ws: float[D*A], ZERO on entry and zero again on return (clear it once after allocating it).
+extern "C" int sar_margin_head_train_f32(const float* x, const float* y, const float* y_true, const float* dloss, const float* W,
+                                         float* probs, float* loss, float* inv_w, float* dx, float* dW, float* dwn_ws, int B, int D,
+                                         int A, int mode, float s, float m, int accumulate_dx, hipStream_t stream) {
+    if (!x || !y || !y_true || !dloss || !W || !probs || !loss || !inv_w || !dx || !dW || !dwn_ws || A > 64 || A < 1 || D > 512 || mode < 0 || mode > 2)
+        return SAR_EINVAL;
+    hipLaunchKernelGGL(margin_train_kernel, dim3(B), dim3(64), 0, stream, x, y, y_true, dloss, W, probs, loss, inv_w, dx, dwn_ws, D, A, mode, s, m, accumulate_dx);
+    hipLaunchKernelGGL(margin_wbwd_kernel<true>, dim3(A), dim3(64), 0, stream, dwn_ws, W, inv_w, dW, D, A);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

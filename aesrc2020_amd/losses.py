@@ -44,10 +44,25 @@ class _MarginHead(Layer):
         _call("sar_margin_head_fwd_f32", x, y, self.W.w, self.probs, self.cosv, self.inv_x, self.inv_w, B, D, A, self.MODE, self.s, self.m)
         return self.probs
 
+    def train(self, x, y, y_true, dloss, dx_out, accumulate_dx=False):
+        """forward + categorical_crossentropy(y_true, probs) + backward of both in two launches (csrc/heads.hip: margin_train_kernel):
+        -> (probs, per-sample loss); dx_out written / accumulated, W.g accumulated."""
+        B, D, A = x.shape[0], self.D, self.n_classes
+        self.x, self.y, self.B = x, y, B
+        self.probs = self.buf("probs", (B, A)); self.inv_w = self.buf("inv_w", (A,)); loss = self.buf("loss", (B,))
+        key = self.name + "/dwn_ws"
+        fresh = key not in self.store.bufs.d
+        ws = self.buf("dwn_ws", (D, A))
+        if fresh:
+            ws.zero_()                                             # the kernels keep it zero from here on (first step is eager)
+        _call("sar_margin_head_train_f32", x, y, y_true, dloss, self.W.w, self.probs, loss, self.inv_w, dx_out, self.W.g, ws, B, D, A,
+              self.MODE, self.s, self.m, 1 if accumulate_dx else 0)
+        return self.probs, loss
+
     def backward(self, dprobs, dx_out=None, accumulate_dx=False):
         B, D, A = self.B, self.D, self.n_classes
         dx = dx_out if dx_out is not None else self.buf("dx", (B, D))
-        ws = self.buf("dwn_ws", (D, A))
+        ws = self.buf("dwn_ws_bwd", (D, A))
         _call("sar_margin_head_bwd_f32", dprobs, self.probs, self.cosv, self.x, self.y, self.W.w, self.inv_x, self.inv_w, dx,
               self.W.g, ws, B, D, A, self.MODE, self.s, self.m, 1 if accumulate_dx else 0)
         return dx

@@ -316,6 +316,7 @@ class SARNetModel:
         (forward + loss + backward in one launch) is asked to produce; everything else runs the same in all three."""
         c = self.cfg
         B, L = self.B, self.L
+        self._fused_disc = False
         cnn = self.trunk.forward(self.in_x, B)
         x = self.CNN_LIN.forward(cnn.view(B * L, -1))                         # CNN2SEQ (model.py:252) is a view
         x = self.CNN_LIN_LN.forward(x)
@@ -352,6 +353,12 @@ class SARNetModel:
                     self.out["y_disc"] = self.disc.forward(ar)
                 elif ml == "circleloss":
                     self.out["y_disc"] = self.disc.forward(self.disc_norm.forward(ar, B))
+                elif mode == "train" and self._fused_accent and "y_disc" in self.loss_weights and "y_accent" in self.loss_weights:
+                    # margin head: forward + cross-entropy + backward in two launches; its input gradient joins d(ar), which the
+                    # classifier's launch above has just written
+                    self.out["y_disc"], self._disc_loss = self.disc.train(ar, self.in_x_accent, self.in_y_disc, self.seed["y_disc"],
+                                                                         dx_out=self._accent_dx, accumulate_dx=True)
+                    self._fused_disc = True
                 else:
                     self.out["y_disc"] = self.disc.forward(ar, self.in_x_accent)
                 if c["bn_dim"]:
@@ -375,6 +382,8 @@ class SARNetModel:
         if "y_disc" in self.loss_weights:
             if c["metric_loss"] == "circleloss":
                 self.loss_vec["y_disc"] = self.circle.forward(self.in_y_disc, self.out["y_disc"], gamma=256, margin=c["margin"])
+            elif self._fused_disc:
+                self.loss_vec["y_disc"] = self._disc_loss
             else:
                 self.loss_vec["y_disc"] = self.cce_disc.forward(self.in_y_disc, self.out["y_disc"])
         if "y_ctc_loss" in self.loss_weights:
@@ -418,7 +427,7 @@ class SARNetModel:
                 elif ml == "softmax":
                     dpd = self.cce_disc.backward(self.seed["y_disc"])
                     self.disc.backward(dpd, accumulate_dx=True, dx_out=d_ar)
-                else:
+                elif not self._fused_disc:
                     dpd = self.cce_disc.backward(self.seed["y_disc"])
                     self.disc.backward(dpd, dx_out=d_ar, accumulate_dx=True)
                 if c["bn_dim"]:

@@ -302,6 +302,13 @@ int sar_margin_head_fwd_f32(const float* x, const float* y, const float* W, floa
 int sar_margin_head_bwd_f32(const float* dprobs, const float* probs, const float* cosv, const float* x, const float* y,
                             const float* W, const float* inv_x, const float* inv_w, float* dx, float* dW, float* dwn_ws,
                             int B, int D, int A, int mode, float s, float m, int accumulate_dx, sarStream_t stream);
+/* The training step of a margin head in two launches instead of six: forward, categorical_crossentropy(y_true, probs) and the backward
+ * of both per sample in one wave, then the column-normalisation backward of W.  y = the one-hot labels the margin is applied to (the
+ * layer's second input, losses.py:38-47), y_true = the loss target (model.py:354), dloss (B) = d total / d loss_b; dx written or
+ * accumulated, dW +=.  inv_w: float[A] scratch; dwn_ws: float[D*A], ZERO on entry and zero again on return. */
+int sar_margin_head_train_f32(const float* x, const float* y, const float* y_true, const float* dloss, const float* W,
+                              float* probs, float* loss, float* inv_w, float* dx, float* dW, float* dwn_ws, int B, int D,
+                              int A, int mode, float s, float m, int accumulate_dx, sarStream_t stream);
 /* ---- The accent classifier in one launch: AR_CF_DS1 = Dense(relu) -> AR_CF_DS2 = Dense(relu) -> y_accent = Dense(softmax)
  * (model.py:150-152 via DS, model.py:35-42) + categorical_crossentropy(y_true, y_accent) (model.py:350) + their backward.  x (B,H);
  * W1 (H,D1), W2 (D1,D2), W3 (D2,A) with biases; h1 (B,D1), h2 (B,D2), probs (B,A) are the three layers' outputs.  y_true NULL:

@@ -161,6 +161,32 @@ def test_accent_classifier_fused(L, B, H, D1, D2, A):
     check(dxd, dx, name="dx")
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_margin_head_train_fused(L, mode):
+    """sar_margin_head_train_f32 (forward + cross-entropy + backward in two launches) against the per-op entry points it replaces
+    (those are held to the float64 oracle by test_margin_heads): probabilities, loss, dx (accumulated), dW; workspace left zero."""
+    rng = np.random.default_rng(40 + mode)
+    B, D, A = 64, 256, 8
+    x = rng.standard_normal((B, D)); W = rng.standard_normal((D, A)) / 16; lab = np.eye(A)[rng.integers(0, A, B)]
+    dl = rng.uniform(0.5, 1.5, B) / B; dx0 = rng.standard_normal((B, D)); dW0 = rng.standard_normal((D, A))
+    s_, m_ = 30.0, (1.35, 0.35, 0.3)[mode]
+    xd, Wd, ld, dld = dev(x), dev(W), dev(lab), dev(dl)
+    # reference: the separate launches
+    probs, cosv, invx, invw, loss, dp = zeros(B, A), zeros(B, A), zeros(B), zeros(A), zeros(B), zeros(B, A)
+    L.call("sar_margin_head_fwd_f32", xd, ld, Wd, probs, cosv, invx, invw, B, D, A, mode, s_, m_)
+    L.call("sar_cce_fwd_f32", ld, probs, loss, B, A); L.call("sar_cce_bwd_f32", ld, probs, dld, dp, B, A)
+    dx_ref, dW_ref, ws = dev(dx0), dev(dW0), zeros(D, A)
+    L.call("sar_margin_head_bwd_f32", dp, probs, cosv, xd, ld, Wd, invx, invw, dx_ref, dW_ref, ws, B, D, A, mode, s_, m_, 1)
+    # fused
+    probs2, loss2, invw2, dx2, dW2, ws2 = zeros(B, A), zeros(B), zeros(A), dev(dx0), dev(dW0), zeros(D, A)
+    for _ in range(2):                                        # twice: the second call relies on the workspace being left zero
+        dx2.copy_(dev(dx0)); dW2.copy_(dev(dW0))
+        L.call("sar_margin_head_train_f32", xd, ld, ld, dld, Wd, probs2, loss2, invw2, dx2, dW2, ws2, B, D, A, mode, s_, m_, 1)
+    check(probs2, probs.cpu().double().numpy(), 1e-5, "probs"); check(loss2, loss.cpu().double().numpy(), 1e-5, "loss")
+    check(dx2, dx_ref.cpu().double().numpy(), 1e-4, "dx"); check(dW2, dW_ref.cpu().double().numpy(), 1e-4, "dW")
+    assert float(ws2.abs().max()) == 0.0
+
+
 def test_gemm_transpose_detecting(L):
     # asymmetric B with A = I catches a swapped C write (guide rule 16)
     n = 64
