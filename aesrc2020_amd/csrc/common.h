@@ -19,10 +19,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Wave-wide reductions without LDS: four DPP steps give every lane the result of its row of 16 lanes (quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror), v_readlane of one lane per row combines the four rows.  (__shfl_xor is ds_bpermute_b32 on this
+// target -- six dependent LDS round trips per reduction, and most kernels here are one wave per row waiting on exactly that.)
+#define SAR_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += SAR_DPP_F(v, 0xB1); v += SAR_DPP_F(v, 0x4E); v += SAR_DPP_F(v, 0x141); v += SAR_DPP_F(v, 0x140);
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -30,9 +36,13 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    // inactive / out-of-row sources read as 0 with bound_ctrl, which is wrong for a maximum of negative numbers: these four patterns
+    // are permutations within the row, every lane has a source
+    v = fmaxf(v, SAR_DPP_F(v, 0xB1)); v = fmaxf(v, SAR_DPP_F(v, 0x4E)); v = fmaxf(v, SAR_DPP_F(v, 0x141)); v = fmaxf(v, SAR_DPP_F(v, 0x140));
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Block-wide sum; `red` is a __shared__ float[16] scratch. All threads get the result.
