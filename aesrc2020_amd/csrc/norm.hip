@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
-                                                     int C, int accumulate) {
+                                                     int C, int accumulate, int act) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // 4 waves x 2 x C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
@@ -356,6 +356,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 float4 o;
                 o.x = rs * (g[j].x - m1 - xh[j].x * m2); o.y = rs * (g[j].y - m1 - xh[j].y * m2);
                 o.z = rs * (g[j].z - m1 - xh[j].z * m2); o.w = rs * (g[j].w - m1 - xh[j].w * m2);
+                if (act == ACT_TANH) {                              // x = tanh(z) of the Dense in front: hand back d/dz (kernel-uniform)
+                    const float ir = 1.f / rs;
+                    const float v0 = fmaf(xh[j].x, ir, mu), v1 = fmaf(xh[j].y, ir, mu), v2 = fmaf(xh[j].z, ir, mu), v3 = fmaf(xh[j].w, ir, mu);
+                    o.x *= 1.f - v0 * v0; o.y *= 1.f - v1 * v1; o.z *= 1.f - v2 * v2; o.w *= 1.f - v3 * v3;
+                }
                 float4* d = reinterpret_cast<float4*>(dx + r * C) + c4;
                 if (accumulate) { const float4 e = *d; o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
                 *d = o;
@@ -517,7 +522,21 @@ extern "C" int sar_layernorm_bwd_f32(const float* dy, const float* x, const floa
                                      int accumulate, hipStream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     const int nb = (int)((R + 3) / 4 < 256 ? (R + 3) / 4 : 256);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, ACT_NONE);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// LayerNormalization backward fused with the backward of the activation in FRONT of it: the reference's DS(..., 'tanh') -> LN pairs
+// (model.py:253-254, 265-266, 279-280).  x = act(z) is the LayerNorm's input, so dx = d/dz = LN'(dy) * act'(x) -- what
+// sar_layernorm_bwd_f32 followed by sar_act_bwd_f32 computes, without the second launch.  act: SAR_ACT_NONE / SAR_ACT_TANH.
+extern "C" int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                         const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
+                                         int accumulate, int act, hipStream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
+    if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
+    const int nb = (int)((R + 3) / 4 < 256 ? (R + 3) / 4 : 256);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -75,9 +75,11 @@ class Dense(Layer):
         self.y = y
         return y
 
-    def backward(self, dy, need_dx=True, accumulate_dx=False, dx_out=None):
+    def backward(self, dy, need_dx=True, accumulate_dx=False, dx_out=None, dz_ready=False):
         R = self.R
-        if self.activation == "softmax":
+        if dz_ready:                                               # the caller (LayerNorm.backward(act=...)) already applied act'
+            dz = dy
+        elif self.activation == "softmax":
             dz = self.scratch("dz%dx%d" % (R, self.units), (R, self.units))
             _call("sar_softmax_bwd_f32", dy, self.y, dz, R, self.units)
         elif ACT[self.activation] != 0:
@@ -112,10 +114,12 @@ class LayerNorm(Layer):
         _call("sar_layernorm_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, R, self.dim, LN_EPS)
         return y
 
-    def backward(self, dy, accumulate_dx=False, dx_out=None):
+    def backward(self, dy, accumulate_dx=False, dx_out=None, act=None):
+        """act: activation of the Dense whose OUTPUT this layer normalises ('tanh'): its backward is applied here as well, the
+        result is d/dz of that Dense (pass it on with Dense.backward(..., dz_ready=True))."""
         dx = dx_out if dx_out is not None else self.buf("dx", (self.R, self.dim))
-        _call("sar_layernorm_bwd_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g,
-              self.R, self.dim, 1 if accumulate_dx else 0)
+        _call("sar_layernorm_bwd_act_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g,
+              self.R, self.dim, 1 if accumulate_dx else 0, ACT[act])
         return dx
 
 

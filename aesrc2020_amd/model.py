@@ -407,7 +407,7 @@ class SARNetModel:
                   self.ctc_loss, self.seed["y_ctc_loss"], self.ctc_ws, self.ctc_ws_bytes, self.ctc_dprobs, B, L, c["bpe_classes"],
                   c["max_ctc_len"])
             g = self.ctc_pred.backward(self.ctc_dprobs)
-            g = self.CTC_DS.backward(self.CTC_DS_LN.backward(g))
+            g = self.CTC_DS.backward(self.CTC_DS_LN.backward(g, act=self.CTC_DS.activation), dz_ready=True)      # tanh' inside the LayerNorm launch
             g = self.CTC_BIGRU_LN.backward(g)
             d_crnn = self.CTC_BIGRU.backward(g.view(B, L, -1))
         if c["ar_enable"]:
@@ -447,15 +447,15 @@ class SARNetModel:
                 g = self.merge.backward(g)
             else:
                 g = self.merge.backward(g)
-            g = self.AR_DS_LN.backward(g)
+            g = self.AR_DS_LN.backward(g, act=self.AR_DS.activation)
             if d_crnn is not None:
-                self.AR_DS.backward(g, dx_out=d_crnn, accumulate_dx=True)
+                self.AR_DS.backward(g, dx_out=d_crnn, accumulate_dx=True, dz_ready=True)
             else:
-                d_crnn = self.AR_DS.backward(g)
+                d_crnn = self.AR_DS.backward(g, dz_ready=True)
         g = self.CRNN_LN.backward(d_crnn)
         g = self.CRNN.backward(g.view(B, L, -1))
-        g = self.CNN_LIN_LN.backward(g)
-        g = self.CNN_LIN.backward(g)
+        g = self.CNN_LIN_LN.backward(g, act=self.CNN_LIN.activation)
+        g = self.CNN_LIN.backward(g, dz_ready=True)
         self._g_trunk = g.view(B, self.trunk.out_hw[0], self.trunk.out_hw[1], -1)
         return self._g_trunk
 

@@ -256,6 +256,10 @@ int sar_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta,
                           long R, int C, float eps, sarStream_t stream);
 int sar_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                           float* dx, float* dgamma, float* dbeta, long R, int C, int accumulate, sarStream_t stream);
+/* LayerNormalization backward + the backward of the activation in front of it (DS(..., 'tanh') -> LN, model.py:253-254, 265-266,
+ * 279-280): x = act(z) is the LayerNorm's input, dx = d/dz.  act: SAR_ACT_NONE / SAR_ACT_TANH. */
+int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              float* dx, float* dgamma, float* dbeta, long R, int C, int accumulate, int act, sarStream_t stream);
 
 /* ---- Bidirectional(CuDNNGRU), merge_mode='concat': model.py:44-50.  xa_* = x*kernel + bias[:3H] (B,L,3H);
  * out (B,L,2H) = [fwd | bwd]; gates (2,B,L,4,H), hprev (2,B,L,H) are saved for BPTT; UT_* = U^T (3H,H);

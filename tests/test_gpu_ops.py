@@ -503,6 +503,14 @@ def test_layernorm(L, R, C):
     check(dx, dx_ref, name="ln dx"); check(dg, dg_ref, name="ln dgamma"); check(db, db_ref, name="ln dbeta")
     L.call("sar_layernorm_bwd_f32", dev(dy), xd, gd, mean, rstd, dx, dg, db, R, C, 1)
     check(dx, 2 * dx_ref, name="ln dx accumulate")
+    # fused with the tanh in front of the LayerNorm (DS(..., 'tanh') -> LN): x = tanh(z), result = d/dz
+    xt = np.tanh(x); yt_ref, cache_t = O.layernorm_fwd(xt, gamma, beta)
+    xtd = dev(xt)
+    L.call("sar_layernorm_fwd_f32", xtd, gd, dev(beta), y, mean, rstd, R, C, 1e-14)
+    dxt_ref, dgt_ref, dbt_ref = O.layernorm_bwd(dy, cache_t)
+    dx, dg, db = zeros(R, C), zeros(C), zeros(C)
+    L.call("sar_layernorm_bwd_act_f32", dev(dy), xtd, gd, mean, rstd, dx, dg, db, R, C, 0, 1)
+    check(dx, dxt_ref * (1 - xt * xt), name="ln+tanh dz"); check(dg, dgt_ref, name="ln+tanh dgamma"); check(db, dbt_ref, name="ln+tanh dbeta")
 
 
 # ------------------------------------------------------------------ BiGRU
