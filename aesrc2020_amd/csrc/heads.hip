@@ -114,6 +114,10 @@ __global__ __launch_bounds__(64) void margin_bwd_kernel(const float* __restrict_
 // Forward + Keras categorical_crossentropy + backward of one sample in ONE wave (margin_fwd_kernel, cce_fwd / cce_bwd, margin_bwd_kernel
 // back to back on the same lanes: lane a < A owns class a): the training step's six launches around the head become two (this + the
 // column-normalisation backward).  grid = B, block = 64.  dwn (D,A): zero on entry (margin_wbwd_kernel<true> leaves it zero again).
+// CACHE: the wave keeps its slice of W in registers (A <= 8, D <= 256: the reference's 8 accents on a 256-wide embedding) -- every
+// operand of the sample is requested in ONE memory phase; looping over the classes with the loads inside was ~15 dependent round trips
+// (29 us for 4 KB of arithmetic).
+template <bool CACHE>
 __global__ __launch_bounds__(64) void margin_train_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ y_true, const float* __restrict__ dloss,
                                                           const float* __restrict__ W, float* __restrict__ probs, float* __restrict__ loss,
@@ -121,41 +125,71 @@ __global__ __launch_bounds__(64) void margin_train_kernel(const float* __restric
                                                           int D, int A, int mode, float s, float m, int accumulate_dx) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* xr = x + (long)b * D;
+    float xv[4], wv[4][8], dxo[4];
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = min(lane + 64 * i, D - 1);
+            xv[i] = lane + 64 * i < D ? xr[d] : 0.f;
+            dxo[i] = accumulate_dx ? dx[(long)b * D + d] : 0.f;
+            const float4 w0 = *reinterpret_cast<const float4*>(W + (long)d * A), w1 = A > 4 ? *reinterpret_cast<const float4*>(W + (long)d * A + 4) : make_float4(0, 0, 0, 0);
+            const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int a = 0; a < 8; ++a) wv[i][a] = (lane + 64 * i < D && a < A) ? ws[a] : 0.f;
+        }
+    }
+    const float yy = lane < A ? y[(long)b * A + lane] : 0.f;
+    const float yt = lane < A ? y_true[(long)b * A + lane] : 0.f;
+    const float gl = dloss[b];
     float sx = 0.f;
-    for (int d = lane; d < D; d += 64) sx = fmaf(xr[d], xr[d], sx);
+    if constexpr (CACHE) { for (int i = 0; i < 4; ++i) sx = fmaf(xv[i], xv[i], sx); }
+    else for (int d = lane; d < D; d += 64) sx = fmaf(xr[d], xr[d], sx);
     sx = wave_sum(sx);
     const float ix = 1.f / sqrtf(fmaxf(sx, 1e-12f));
     float my_logit = -INFINITY, c = 0.f, my_iw = 0.f;
-    const float yy = lane < A ? y[(long)b * A + lane] : 0.f;
-    for (int a = 0; a < A; ++a) {
-        float sw = 0.f, dot = 0.f;
-        for (int d = lane; d < D; d += 64) { const float w = W[(long)d * A + a]; sw = fmaf(w, w, sw); dot = fmaf(xr[d], w, dot); }
+    auto fwd_class = [&](int a, float sw, float dot) __attribute__((always_inline)) {
         sw = wave_sum(sw); dot = wave_sum(dot);
         const float iw = 1.f / sqrtf(fmaxf(sw, 1e-12f));
         if (lane == a) {
             c = dot * ix * iw; my_iw = iw;
-            float t;
-            if (mode == HEAD_COS) t = c - m;
-            else {
-                const float th = acosf(fminf(fmaxf(c, -1.f + KEPS), 1.f - KEPS));
-                t = mode == HEAD_ARC ? cosf(th + m) : cosf(m * th);
-            }
-            my_logit = (c * (1.f - yy) + t * yy) * s;
             if (b == 0) inv_w[a] = sw >= 1e-12f ? iw : -iw;
         }
+    };
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            float sw = 0.f, dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sw = fmaf(wv[i][a], wv[i][a], sw); dot = fmaf(xv[i], wv[i][a], dot); }
+            if (a < A) fwd_class(a, sw, dot);                       // wave-uniform
+        }
+    } else {
+        for (int a = 0; a < A; ++a) {
+            float sw = 0.f, dot = 0.f;
+            for (int d = lane; d < D; d += 64) { const float w = W[(long)d * A + a]; sw = fmaf(w, w, sw); dot = fmaf(xr[d], w, dot); }
+            fwd_class(a, sw, dot);
+        }
+    }
+    if (lane < A) {
+        float t;
+        if (mode == HEAD_COS) t = c - m;
+        else {
+            const float th = acosf(fminf(fmaxf(c, -1.f + KEPS), 1.f - KEPS));
+            t = mode == HEAD_ARC ? cosf(th + m) : cosf(m * th);
+        }
+        my_logit = (c * (1.f - yy) + t * yy) * s;
     }
     const float mx = wave_max(my_logit);
     const float e = lane < A ? expf(my_logit - mx) : 0.f;
     const float p = e / wave_sum(e);
     if (lane < A) probs[(long)b * A + lane] = p;
     // categorical_crossentropy(y_true, p): renormalise, clip (cce_fwd_kernel / cce_bwd_kernel)
-    const float yt = lane < A ? y_true[(long)b * A + lane] : 0.f;
     const float S = wave_sum(p), q = p / S;
     const float l = wave_sum(lane < A ? -yt * logf(fminf(fmaxf(q, KEPS), 1.f - KEPS)) : 0.f);
     if (lane == 0) loss[b] = l;
     const float dq = (lane < A && q >= KEPS && q <= 1.f - KEPS) ? -yt / q : 0.f;
     const float acc = wave_sum(dq * q);
-    const float dp = lane < A ? dloss[b] * (dq - acc) / S : 0.f;
+    const float dp = lane < A ? gl * (dq - acc) / S : 0.f;
     // margin_bwd_kernel
     const float sd = wave_sum(p * dp);
     float dc = 0.f;
@@ -176,29 +210,48 @@ __global__ __launch_bounds__(64) void margin_train_kernel(const float* __restric
     float dxn_l[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) dxn_l[i] = 0.f;
-    for (int a = 0; a < A; ++a) {
-        const float dca = __shfl(dc, a, 64), iw = __shfl(my_iw, a, 64);
+    if constexpr (CACHE) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int d = lane + i * 64;
-            if (d < D) {
-                const float wn = W[(long)d * A + a] * iw;
-                dxn_l[i] = fmaf(dca, wn, dxn_l[i]);
-                atomicAdd(dwn + (long)d * A + a, xr[d] * ix * dca);
+        for (int a = 0; a < 8; ++a) {
+            if (a < A) {                                            // wave-uniform
+                const float dca = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dc), a));
+                const float iw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_iw), a));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int d = lane + i * 64;
+                    if (d < D) {
+                        dxn_l[i] = fmaf(dca, wv[i][a] * iw, dxn_l[i]);
+                        atomicAdd(dwn + (long)d * A + a, xv[i] * ix * dca);
+                    }
+                }
+            }
+        }
+    } else {
+        for (int a = 0; a < A; ++a) {
+            const float dca = __shfl(dc, a, 64), iw = __shfl(my_iw, a, 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = lane + i * 64;
+                if (d < D) {
+                    dxn_l[i] = fmaf(dca, W[(long)d * A + a] * iw, dxn_l[i]);
+                    atomicAdd(dwn + (long)d * A + a, xr[d] * ix * dca);
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const int d = lane + i * 64; if (d < D) proj = fmaf(xr[d] * ix, dxn_l[i], proj); }
+    for (int i = 0; i < (CACHE ? 4 : 8); ++i) { const int d = lane + i * 64; if (d < D) proj = fmaf((CACHE ? xv[i < 4 ? i : 0] : xr[d]) * ix, dxn_l[i], proj); }
     proj = wave_sum(proj);
     if (sx < 1e-12f) proj = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < (CACHE ? 4 : 8); ++i) {
         const int d = lane + i * 64;
         if (d < D) {
-            const float g = (dxn_l[i] - xr[d] * ix * proj) * ix;
+            const float xd = CACHE ? xv[i < 4 ? i : 0] : xr[d];
+            const float g = (dxn_l[i] - xd * ix * proj) * ix;
             float* dst = dx + (long)b * D + d;
-            *dst = accumulate_dx ? *dst + g : g;
+            if (CACHE) *dst = dxo[i < 4 ? i : 0] + g;
+            else *dst = accumulate_dx ? *dst + g : g;
         }
     }
 }
@@ -336,7 +389,11 @@ extern "C" int sar_margin_head_train_f32(const float* x, const float* y, const f
                                          int A, int mode, float s, float m, int accumulate_dx, hipStream_t stream) {
     if (!x || !y || !y_true || !dloss || !W || !probs || !loss || !inv_w || !dx || !dW || !dwn_ws || A > 64 || A < 1 || D > 512 || mode < 0 || mode > 2)
         return SAR_EINVAL;
-    hipLaunchKernelGGL(margin_train_kernel, dim3(B), dim3(64), 0, stream, x, y, y_true, dloss, W, probs, loss, inv_w, dx, dwn_ws, D, A, mode, s, m, accumulate_dx);
+    // register-cached form: A <= 8 (two 16-byte loads per kernel row: rows 16-byte aligned when A % 4 == 0), D <= 256
+    if (A <= 8 && A % 4 == 0 && D <= 256 && (reinterpret_cast<uintptr_t>(W) & 15) == 0)
+        hipLaunchKernelGGL(margin_train_kernel<true>, dim3(B), dim3(64), 0, stream, x, y, y_true, dloss, W, probs, loss, inv_w, dx, dwn_ws, D, A, mode, s, m, accumulate_dx);
+    else
+        hipLaunchKernelGGL(margin_train_kernel<false>, dim3(B), dim3(64), 0, stream, x, y, y_true, dloss, W, probs, loss, inv_w, dx, dwn_ws, D, A, mode, s, m, accumulate_dx);
     hipLaunchKernelGGL(margin_wbwd_kernel<true>, dim3(A), dim3(64), 0, stream, dwn_ws, W, inv_w, dW, D, A);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
