@@ -196,7 +196,10 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(base + off));
 }
 
-template <bool A_KC, bool B_KC>
+// TAIL: N and / or K need not be multiples of 64 (multiples of 4: rows stay 16-byte pieces) -- the bpe-1k CTC output layer
+// (N = 1000 forward and in its weight gradient, K = 1000 in its input gradient): pieces past the edge are loaded from a clamped
+// address and zeroed, stores past N are dropped.  M stays a multiple of 64.
+template <bool A_KC, bool B_KC, bool TAIL = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
                                                         int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
     const int bz = blockIdx.z / splitk, kz = blockIdx.z - bz * splitk;
@@ -207,17 +210,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int 
     __shared__ float csum[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int nkt = K / GB_K, per = (nkt + splitk - 1) / splitk;
+    const int nkt = (K + GB_K - 1) / GB_K, per = (nkt + splitk - 1) / splitk;
     const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
     // staging: thread -> (row = tid / 4 of the tile as stored, 16 consecutive elements (tid % 4) * 16 of that row)
     const int srow = tid >> 2, sseg = (tid & 3) * 16;
     float4 ra[2][4], rb[2][4];
     auto gload = [&](int set, int kt) __attribute__((always_inline)) {
         const int k0 = min(kt, kt1 - 1) * GB_K;
-        const float* pa = A_KC ? A + (long)(m0 + srow) * lda + k0 + sseg : A + (long)(k0 + srow) * lda + m0 + sseg;
-        const float* pb = B_KC ? B + (long)(n0 + srow) * ldb + k0 + sseg : B + (long)(k0 + srow) * ldb + n0 + sseg;
+        if constexpr (!TAIL) {
+            const float* pa = A_KC ? A + (long)(m0 + srow) * lda + k0 + sseg : A + (long)(k0 + srow) * lda + m0 + sseg;
+            const float* pb = B_KC ? B + (long)(n0 + srow) * ldb + k0 + sseg : B + (long)(k0 + srow) * ldb + n0 + sseg;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[set][i] = *reinterpret_cast<const float4*>(pa + 4 * i); rb[set][i] = *reinterpret_cast<const float4*>(pb + 4 * i); }
+            for (int i = 0; i < 4; ++i) { ra[set][i] = *reinterpret_cast<const float4*>(pa + 4 * i); rb[set][i] = *reinterpret_cast<const float4*>(pb + 4 * i); }
+        } else {
+            // operand stored [mn][k]: row = mn (always inside for A: M % 64 == 0; B rows < N), pieces along k; stored [k][mn]: row = k, pieces along mn
+            const int rowa = A_KC ? m0 + srow : k0 + srow, cola = A_KC ? k0 + sseg : m0 + sseg, lima_r = A_KC ? M : K, lima_c = A_KC ? K : M;
+            const int rowb = B_KC ? n0 + srow : k0 + srow, colb = B_KC ? k0 + sseg : n0 + sseg, limb_r = B_KC ? N : K, limb_c = B_KC ? K : N;
+            const float* pa = A + (long)min(rowa, lima_r - 1) * lda; const float* pb = B + (long)min(rowb, limb_r - 1) * ldb;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ca = cola + 4 * i, cb = colb + 4 * i;
+                const float4 va = *reinterpret_cast<const float4*>(pa + min(ca, lima_c - 4)), vb = *reinterpret_cast<const float4*>(pb + min(cb, limb_c - 4));
+                ra[set][i] = (rowa < lima_r && ca + 3 < lima_c) ? va : z4; rb[set][i] = (rowb < limb_r && cb + 3 < limb_c) ? vb : z4;
+            }
+        }
     };
     const bool do_colsum = !B_KC && colsum != nullptr && blockIdx.y == 0;
     float cs[16];
@@ -280,9 +297,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int 
             if (lane < 4) csum[wave][lane * 16 + i] = v;
         }
         __syncthreads();
-        if (tid < 64) atomicAdd(colsum + n0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
+        if (tid < 64 && (!TAIL || n0 + tid < N)) atomicAdd(colsum + n0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
     }
     const int col = n0 + wn * 32 + (lane & 31);
+    if (TAIL && col >= N) return;
     const float bv = (bias != nullptr && kz == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -321,6 +339,20 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     if (nb > 1 && !aligned) return SAR_EINVAL;             // a batch runs one code path: all operands 16-byte aligned
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk * nb), block(256);
     // bf16 MFMA path: whole 64 x 64 x 64 tiles, 16-byte aligned rows (every Dense / GRU-projection GEMM of the model)
+    const bool tail16 = g_gemm_math == 1 && M % 64 == 0 && (N % 64 || K % 64) && N % 4 == 0 && K % 4 == 0 && N >= 64 && K >= 64 && (lda & 3) == 0 &&
+                        (ldb & 3) == 0 && aligned && (K + 63) / 64 >= splitk;
+    if (tail16) {
+        grid.x = cdiv(N, 64);
+#define LAUNCH16T(AK, BK_)                                                                                           \
+    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)
+        if (a_kc && b_kc) LAUNCH16T(true, true);
+        else if (a_kc && !b_kc) LAUNCH16T(true, false);
+        else if (!a_kc && b_kc) LAUNCH16T(false, true);
+        else LAUNCH16T(false, false);
+#undef LAUNCH16T
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     if (g_gemm_math == 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && aligned && K / 64 >= splitk) {
 #define LAUNCH16(AK, BK_)                                                                                            \
     hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)

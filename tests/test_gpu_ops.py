@@ -71,7 +71,8 @@ def test_gemm_wgrad_with_fused_bias_gradient(L, R, I, N, sk):
 
 
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
-@pytest.mark.parametrize("M,N,K,sk", [(64, 64, 64, 1), (2496, 768, 256, 1), (256, 768, 2496, 3), (128, 192, 8192, 1)])
+@pytest.mark.parametrize("M,N,K,sk", [(64, 64, 64, 1), (2496, 768, 256, 1), (256, 768, 2496, 3), (128, 192, 8192, 1),
+                                      (2496, 1000, 256, 1), (256, 1000, 2496, 3), (2496, 256, 1000, 1), (128, 100, 68, 1)])   # last four: N / K tails (bpe-1k layer)
 def test_gemm_bf16_math(L, a_kc, b_kc, M, N, K, sk):
     """sar_set_gemm_math(1): operands rounded to bf16 in the staging, bf16 MFMA, fp32 accumulate -- against float64 on the
     rounded operands (tight) for all four layouts, bias + tanh, accumulate, split-K and the fused column sum."""
