@@ -62,6 +62,48 @@ def broadcast_flat(flat, src=0, group=None):
     dist.broadcast(flat, src=src, group=group)
 
 
+class RcclComm:
+    """The C-ABI collective (include/sarnet.h: sar_comm_* / sar_allreduce_bucket_f32) as DataParallel uses it when
+    SAR_DP_COLLECTIVE=cabi: a communicator of its own (unique id made by rank 0, broadcast through the already-initialised
+    torch.distributed group), all-reduces enqueued on a dedicated stream behind the work submitted so far, `wait()` = the
+    current stream waits for that stream -- the same overlap contract as torch.distributed's asynchronous work handles."""
+
+    class _Work:
+        def __init__(self, stream):
+            self.stream = stream
+
+        def wait(self):
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+    def __init__(self):
+        import ctypes
+        from . import _lib
+        self.fn = _lib.lib().fn
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            if self.fn["sar_comm_unique_id"](buf) != 0:
+                raise RuntimeError("sar_comm_unique_id failed (is librccl loadable?)")
+            ident = [buf.raw]
+        dist.broadcast_object_list(ident, src=0)
+        self.handle = ctypes.c_void_p()
+        if self.fn["sar_comm_init"](ctypes.byref(self.handle), ident[0], world, rank) != 0:
+            raise RuntimeError("sar_comm_init failed (rank %d of %d)" % (rank, world))
+        self.stream = torch.cuda.Stream()
+
+    def allreduce(self, t):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        if self.fn["sar_allreduce_bucket_f32"](self.handle, t.data_ptr(), t.numel(), self.stream.cuda_stream) != 0:
+            raise RuntimeError("sar_allreduce_bucket_f32 failed")
+        return self._Work(self.stream)
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            self.fn["sar_comm_destroy"](self.handle); self.handle = None
+
+
 class DataParallel:
     def __init__(self, store, split_name_prefix="CNN_LIN", trunk_splits=()):
         """Buckets of the flat gradient buffer in the order backward completes them: [first post-trunk parameter, n) (heads,
@@ -84,6 +126,8 @@ class DataParallel:
                 lo_hi.append((c, hi)); hi = c
             lo_hi.append((0, hi))
             self.bounds = [self.bounds[0]] + lo_hi
+        # SAR_DP_COLLECTIVE=cabi: the gradient buckets go through the library's own RCCL entry point instead of torch.distributed's
+        self.cabi = RcclComm() if (self.enabled and os.environ.get("SAR_DP_COLLECTIVE") == "cabi" and store.grads.is_cuda) else None
         if self.enabled:
             self.broadcast_params()
 
@@ -105,4 +149,10 @@ class DataParallel:
         A model without post-trunk parameters has a single bucket: index 1 is then empty."""
         if not self.enabled or i >= len(self.bounds):
             return []
+        if self.cabi is not None:
+            lo, hi = self.bounds[i]
+            w = self.cabi.allreduce(self.store.grads[lo:hi])
+            if not async_op:
+                w.wait()
+            return [w] if async_op else []
         return [w for w in allreduce_flat(self.store.grads, [self.bounds[i]], async_op=async_op) if w is not None]

@@ -341,6 +341,16 @@ int sar_l2norm_rows_fwd_f32(const float* x, float* v, float* inv, int R, int C, 
 int sar_l2norm_rows_bwd_f32(const float* dv, const float* v, const float* inv, float* dx, int R, int C, int accumulate, sarStream_t stream);
 int sar_transpose_f32(const float* x, float* y, int R, int C, sarStream_t stream);
 
+/* ---- Gradient exchange of the data-parallel step (the reference: keras.utils.multi_gpu_model inside one process, model.py:193-194;
+ * here one process per GPU): sum-all-reduce of a bucket of the flat gradient buffer over RCCL / xGMI.  RCCL is bound at run time
+ * (the copy the process already has, else /opt/rocm's): without it these return SAR_ELAUNCH, everything else in the library works.
+ * id128: 128 bytes made by rank 0 (sar_comm_unique_id) and handed to every rank by the launcher's own channel; sar_comm_init is
+ * collective and binds the communicator to the CURRENT HIP device; sar_allreduce_bucket_f32 is enqueued on `stream` (in place). */
+int sar_comm_unique_id(void* out128);
+int sar_comm_init(void** comm, const void* id128, int nranks, int rank);
+int sar_allreduce_bucket_f32(void* comm, float* buf, long count, sarStream_t stream);
+int sar_comm_destroy(void* comm);
+
 /* ---- Adam(lr, decay=2e-4) + l2 regularisers + unit_norm: model.py:197, 35-48, 163.
  * state: device block {float lr, decay, beta1, beta2, eps, lr_t; int iterations; float grad_scale}. */
 int sar_adam_prepare(void* state, sarStream_t stream);

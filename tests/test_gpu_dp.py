@@ -106,11 +106,11 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode):
     _lib.set_gemm_math("fp32")
 
 
-def _worker_one_rank(port, q, mode):
+def _worker_one_rank(port, q, mode, collective="torch"):
     """One rank, backend nccl (= RCCL), SAR_DP_FORCE=1: the five-graph step with its bucketed asynchronous all-reduces on a real RCCL
     communicator -- what a 1-GPU box can run of the multi-GPU path."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", SAR_DIST_BACKEND="nccl",
-                      SAR_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      SAR_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAR_DP_COLLECTIVE=collective)
     sys.path.insert(0, ROOT)
     import contextlib, io
     from aesrc2020_amd import parallel, _lib
@@ -125,6 +125,11 @@ def _worker_one_rank(port, q, mode):
     with contextlib.redirect_stdout(io.StringIO()):
         model, tm = SAR_Net(seed=21, **kw)
     assert model.dp.enabled and model.dp.world == 1 and len(model.dp.bounds) == model.trunk.N_PARTS + 1
+    assert (model.dp.cabi is not None) == (collective == "cabi")
+    if collective == "cabi":                                   # the entry point itself: one rank, sum = identity
+        probe = torch.arange(1000, dtype=torch.float32, device="cuda")
+        model.dp.cabi.allreduce(probe).wait(); torch.cuda.synchronize()
+        assert torch.equal(probe.cpu(), torch.arange(1000, dtype=torch.float32))
     cfg = MT.Cfg(**kw)
     out = []
     for i in range(STEPS + 1):
@@ -138,8 +143,9 @@ def _worker_one_rank(port, q, mode):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_rccl_one_rank_five_graph_step(mode):
+@pytest.mark.parametrize("mode,collective", [("fp32", "torch"), ("bf16", "torch"), ("bf16", "cabi")],
+                         ids=["fp32-torch.distributed", "bf16-torch.distributed", "bf16-sar_allreduce_bucket"])
+def test_rccl_one_rank_five_graph_step(mode, collective):
     """RCCL itself on this box: a process group of one rank over backend nccl, the data-parallel step forced on (SAR_DP_FORCE=1).
     Communicator set-up, the all-reduces on RCCL's stream between replays of the five captured graphs and the stream-ordered
     work.wait() all execute; a one-rank reduction is the identity, so parameters and losses must follow the single-graph step."""
@@ -148,8 +154,8 @@ def test_rccl_one_rank_five_graph_step(mode):
     from aesrc2020_amd.model import SAR_Net
     from oracle import model_torch as MT
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 33000 + (os.getpid() + 11 * len(mode)) % 2000
-    p = ctx.Process(target=_worker_one_rank, args=(port, q, mode))
+    q = ctx.Queue(); port = 33000 + (os.getpid() + 11 * len(mode) + 5 * len(collective)) % 2000
+    p = ctx.Process(target=_worker_one_rank, args=(port, q, mode, collective))
     p.start()
     out, graphs = q.get(timeout=600)
     p.join(120)
