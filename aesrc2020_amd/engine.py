@@ -106,12 +106,42 @@ class ParamStore:
     def iterations(self):
         return int(self.adam_state.view(torch.int32)[6].item())
 
+    # ---- buffers that must be zero when a train step starts (gradients, the penalty scalar, and whatever layers register: BatchNorm
+    # statistic bins, split-K outputs): ONE launch at the top of the step instead of one fill launch each
+    def zero_at_step_start(self, t):
+        """Called by a layer where it would zero `t` itself.  True: the step-start launch of THIS step already covered `t` (skip the
+        fill); False: zero it here (first sighting of the buffer, or no step-start launch ran: evaluate / predict)."""
+        key = (t.data_ptr(), t.numel())
+        zl = self.__dict__.setdefault("_zero_list", {})
+        if key not in zl:
+            zl[key] = t
+            return False
+        # covered only if the table the step-start launch used already had this buffer's row
+        return self.__dict__.get("_zeroed_this_step", False) and key in self.__dict__.get("_zero_rows", ())
+
+    def _zero_table_sync(self):
+        """(Re)build the device table of the zero list; never inside a HIP-graph capture (it is a host-to-device copy): the eager first
+        step registers every buffer and rebuilds the table in its adam_step, so the captured step finds it ready."""
+        zl = self.__dict__.setdefault("_zero_list", {})
+        for t in (self.grads, self.l2_loss):
+            zl.setdefault((t.data_ptr(), t.numel()), t)
+        tab = self.__dict__.get("_zero_table")
+        if (tab is None or tab.shape[0] != len(zl)) and not torch.cuda.is_current_stream_capturing():
+            self._zero_table = torch.tensor([[t.data_ptr(), t.numel() * t.element_size() // 4] for t in zl.values()], dtype=torch.int64, device=self.grads.device)
+            self._zero_rows = set(zl)
+        return self.__dict__.get("_zero_table")
+
     def zero_grads(self):
-        _lib.call("sar_fill_f32", self.grads, 0.0, self.n)
+        tab = self._zero_table_sync()
+        _lib.call("sar_zero_ranges", tab, tab.shape[0])
+        self._zeroed_this_step = True
 
     def adam_step(self):
         """L2 gradient + Keras Adam over the whole flat buffer, then the unit_norm constraints."""
-        _lib.call("sar_fill_f32", self.l2_loss, 0.0, 1)
+        if not self.__dict__.get("_zeroed_this_step", False):
+            _lib.call("sar_fill_f32", self.l2_loss, 0.0, 1)
+        self._zeroed_this_step = False                                       # the step is over: later forwards (evaluate) zero for themselves
+        self._zero_table_sync()                                              # buffers registered during this (eager) step join the table now
         _lib.call("sar_adam_prepare", self.adam_state)
         _lib.call("sar_adam_l2_step_f32", self.params, self.grads, self.m, self.v, self.chunk_l2, self.adam_state,
                   self.l2_loss, self.n)

@@ -68,7 +68,7 @@ class Dense(Layer):
             _call("sar_softmax_fwd_f32", z, y, R, self.units)
         else:
             sk = pick_splitk(R, self.units, self.in_dim) if ACT[self.activation] == 0 else 1
-            if sk > 1:
+            if sk > 1 and not (self.store.training and self.store.zero_at_step_start(y)):
                 _call("sar_fill_f32", y, 0.0, y.numel())
             gemm(x, self.kernel.w, y, b, R, self.units, self.in_dim, self.in_dim, self.units, self.units, 1, 0,
                  ACT[self.activation], 0, sk)

@@ -196,6 +196,8 @@ class SARNetModel:
     # ------------------------------------------------------------------ inputs
     def _bind_inputs(self, B, T=None):
         c = self.cfg
+        self.store._zero_list = {}; self.store._zero_table = None; self.store._zero_rows = set()   # buffers of the old batch shape are about to be replaced
+        self.store._zeroed_this_step = False; self._copy_tables = {}; self._copy_tables_for = None
         D = c["input_shape"][1]
         T = int(T if T is not None else c["input_shape"][0])
         if T != self.trunk.in_hw[0]:
@@ -281,17 +283,35 @@ class SARNetModel:
         B, T = dev["x_data"].shape[0], dev["x_data"].shape[1]
         if getattr(self, "B", None) != B or getattr(self, "T", None) != T:
             self._bind_inputs(B, T); self.graph = None; self._eager_done = 0
-        self.in_x.copy_(dev["x_data"].view(self.in_x.shape))
         c = self.cfg
+        pairs = [(self.in_x, dev["x_data"])]
         if c["ar_enable"]:
-            self.in_y_accent.copy_(dev["y_accent"])
+            pairs.append((self.in_y_accent, dev["y_accent"]))
         if c["disc_enable"]:
-            self.in_x_accent.copy_(dev["x_accent"]); self.in_y_disc.copy_(dev["y_disc"])
+            pairs += [(self.in_x_accent, dev["x_accent"]), (self.in_y_disc, dev["y_disc"])]
             if c["bn_dim"]:
-                self.in_y_disc_bn.copy_(dev.get("y_disc_bn", dev["y_disc"]))
+                pairs.append((self.in_y_disc_bn, dev.get("y_disc_bn", dev["y_disc"])))
         if c["ctc_enable"]:
-            self.in_ctc_label.copy_(dev["x_ctc_label"]); self.in_ctc_in_len.copy_(dev["x_ctc_in_len"].view(-1))
-            self.in_ctc_out_len.copy_(dev["x_ctc_out_len"].view(-1))
+            pairs += [(self.in_ctc_label, dev["x_ctc_label"]), (self.in_ctc_in_len, dev["x_ctc_in_len"]),
+                      (self.in_ctc_out_len, dev["x_ctc_out_len"])]
+        # ONE launch for all of them (a table of {destination, source, words}, cached per set of source buffers) when every pair is a
+        # plain byte copy; anything else (dtype conversion, strided or unaligned source) goes through torch's copy
+        key = tuple(s.data_ptr() for _, s in pairs)
+        tab = self._copy_tables.get(key) if getattr(self, "_copy_tables_for", None) == (B, T) else None
+        if tab is None:
+            plain = all(s.is_cuda and s.dtype == d.dtype and s.is_contiguous() and s.numel() == d.numel() and s.data_ptr() % 16 == 0
+                        and d.data_ptr() % 16 == 0 for d, s in pairs)
+            if getattr(self, "_copy_tables_for", None) != (B, T):
+                self._copy_tables = {}; self._copy_tables_for = (B, T)
+            if plain and len(self._copy_tables) < 64 and not torch.cuda.is_current_stream_capturing():
+                tab = torch.tensor([[d.data_ptr(), s.data_ptr(), d.numel() * d.element_size() // 4] for d, s in pairs],
+                                   dtype=torch.int64, device=self.in_x.device)
+                self._copy_tables[key] = tab
+        if tab is not None:
+            _call("sar_copy_ranges", tab, tab.shape[0])
+        else:
+            for d, s in pairs:
+                d.copy_(s.view(d.shape))
 
     # ------------------------------------------------------------------ forward / backward plans
     def _accent_classifier(self, ar, mode):

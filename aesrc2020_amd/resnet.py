@@ -281,7 +281,8 @@ class ResNetTrunk(Layer):
         training = self.store.training
         _call("sar_conv_pack_weights_bf16", self._pack_table, self._pack_table.shape[0], self._pack_blocks)
         if training:
-            _call("sar_fill_f32", self._arena, 0.0, self._arena.numel())
+            if not self.store.zero_at_step_start(self._arena):              # the step-start launch covers it from the second step on
+                _call("sar_fill_f32", self._arena, 0.0, self._arena.numel())
         else:
             for bn in self._all_bns():
                 bn.fold16()

@@ -335,6 +335,10 @@ int sar_softmax_bwd_f32(const float* dp, const float* p, float* dz, int rows, in
 int sar_colsum_f32(const float* x, float* out, long R, int C, sarStream_t stream);                /* out += */
 int sar_axpy_f32(const float* x, float* y, float a, long n, sarStream_t stream);
 int sar_fill_f32(float* y, float v, long n, sarStream_t stream);
+/* zero n buffers in one launch: table = device array of n rows {pointer (16-byte aligned), number of 32-bit words} as 2 x int64 */
+int sar_zero_ranges(const void* table, int n, sarStream_t stream);
+/* copy n buffers in one launch: rows {destination, source, number of 32-bit words} as 3 x int64, 16-byte aligned pointers */
+int sar_copy_ranges(const void* table, int n, sarStream_t stream);
 int sar_avgpool1d_fwd_f32(const float* x, float* y, int B, int L, int C, sarStream_t stream);     /* model.py:125 */
 int sar_avgpool1d_bwd_f32(const float* dy, float* dx, int B, int L, int C, int accumulate, sarStream_t stream);
 int sar_l2norm_rows_fwd_f32(const float* x, float* v, float* inv, int R, int C, sarStream_t stream); /* model.py:162 */
