@@ -241,6 +241,205 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd_kernel(const float* __restri
     }
 }
 
+
+// ---- four-row workgroups (the default up to B = 512): the compact lane map --------------------------------------------------------
+// With rows <= 4 only lanes n < 4 of a 16-lane row hold live accumulator values -- 16 lanes x 4 registers = 64 values per tile, one per
+// lane once register r of lane n moves to lane n + 4r of the same row (three DPP moves, row_shr:4r with bank mask 1 << r).  Lane l then
+// owns batch row l & 3 and unit 16u + 4*(l >> 4) + ((l >> 2) & 3) of the wave's 32: every per-step tensor is ONE float per lane and
+// tile, which buys the registers for what the step time was made of (tools/gru_bench.py, phases removed one at a time: transcendentals
+// 0.07 of 2.8 us, MFMAs 0.5, the saved-tensor STORES 0.9): vmcnt retires in order, so a step that waits for loads issued behind its
+// predecessor's stores waits for their write acknowledgements too.  Here the loads of step s+1 are issued in front of the stores of
+// step s and waited for a whole step later; the stores are never waited for inside the loop.
+__device__ __forceinline__ float compact4(const f32x4 a) {
+    int v = __float_as_int(a[0]);
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[1]), 0x114, 0xf, 0x2, false);
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[2]), 0x118, 0xf, 0x4, false);
+    v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[3]), 0x11C, 0xf, 0x8, false);
+    return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ unsigned short bf1(float a) { return __builtin_bit_cast(unsigned short, (__bf16)a); }
+
+// ALL: every lane's batch row exists (rows == 4, B % 4 == 0): the stores are unconditional, so the compiler can count them -- behind a
+// divergent `if (row_ok)` it cannot, and waits for vmcnt(0) wherever it needs the prefetched loads.
+// A-fragments in registers: the one-float-per-lane tensors leave room for more than the 16-row kernels' 32, and every fragment that is
+// not re-read from LDS each step is 8 KB of LDS traffic less per step and workgroup (a step reads 16 fragments per wave + the h / gradient
+// image = 192 KB forward, 320 KB backward at 32: 1 500 / 2 500 cycles of the CU's 128 B per clock).
+constexpr int GR4B = 44;
+template <bool ALL>
+__global__ __launch_bounds__(512) void gru_mfma_fwd4_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b,
+                                                            const uint4* __restrict__ pack, const float* __restrict__ bh_f,
+                                                            const float* __restrict__ bh_b, float* __restrict__ out,
+                                                            float* __restrict__ gates, float* __restrict__ hprev, int B, int L, int rows) {
+    constexpr int GR4F = ALL ? 40 : 36;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * rows, n = lane & 15, q4 = lane >> 4;
+    const int nb = lane & 3, b = b0 + nb, ju = 4 * q4 + ((lane >> 2) & 3);   // compact map: batch row, unit within a 16-unit tile
+    const bool row_ok = ALL || (nb < rows && b < B);
+    const float* xa = d ? xa_b : xa_f; const float* bh = d ? bh_b : bh_f;
+    uint4* Al = reinterpret_cast<uint4*>(smem) + (size_t)w * (GFR - GR4F) * 64;
+    unsigned char* Hs = smem + (size_t)GNW * (GFR - GR4F) * 1024;
+    const uint4* pk = pack + ((size_t)(d * 2 + 0) * GNW + w) * GFR * 64 + lane;
+    bf16x8 A[GR4F];
+#pragma unroll
+    for (int f = 0; f < GR4F; ++f) A[f] = __builtin_bit_cast(bf16x8, pk[f * 64]);
+#pragma unroll
+    for (int f = GR4F; f < GFR; ++f) Al[(f - GR4F) * 64 + lane] = pk[f * 64];
+    for (int i = tid; i < 2 * GNR * HS_STRIDE / 4; i += 512) reinterpret_cast<unsigned*>(Hs)[i] = 0u;   // h0 = 0; rows 4..15 stay zero
+    const int j0 = 32 * w + ju;                                    // + 16u
+    float bg[2][3], h[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) bg[u][g] = bh[g * GH + j0 + 16 * u];
+    float* g_d = gates + (long)d * B * L * 4 * GH;
+    float* hp_d = hprev + (long)d * B * L * GH;
+    const int bc = min(b, B - 1);                                  // loads are unconditional (clamped row / step): no exec branches around them
+    auto loadx = [&](int s, float (&x)[2][3]) __attribute__((always_inline)) {
+        const int sc = min(s, L - 1), t = d ? (L - 1 - sc) : sc;
+        const long xo = ((long)bc * L + t) * GH3 + j0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) x[u][g] = xa[xo + g * GH + 16 * u];
+    };
+    float xc[2][3], xn[2][3];
+    loadx(0, xc);
+    // the values are consumed here (an empty asm that reads them): nothing is pending at loop entry, so the waits the compiler puts
+    // inside the loop count only the loop's own operations (a pending load at entry makes it wait for vmcnt(0) -- the stores -- every step)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(xc[u][g]), "+v"(bg[u][g]));
+    wg_sync();
+    for (int s = 0; s < L; ++s) {
+        const int t = d ? (L - 1 - s) : s;
+        const unsigned char* Hc = Hs + (size_t)(s & 1) * GNR * HS_STRIDE;
+        unsigned char* Hn = Hs + (size_t)((s + 1) & 1) * GNR * HS_STRIDE;
+        loadx(s + 1, xn);                                          // in front of this step's stores
+        f32x4 acc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 Bf = *reinterpret_cast<const bf16x8*>(Hc + n * HS_STRIDE + (32 * ks + 8 * q4) * 2);
+#pragma unroll
+            for (int tl = 0; tl < 6; ++tl) {
+                const int f = tl * 8 + ks;
+                const bf16x8 Af = f < GR4F ? A[f < GR4F ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GR4F) * 64 + lane]);
+                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[tl], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float z = fsig(xc[u][0] + (compact4(acc[u * 3 + 0]) + bg[u][0]));
+            const float rr = fsig(xc[u][1] + (compact4(acc[u * 3 + 1]) + bg[u][1]));
+            const float q = compact4(acc[u * 3 + 2]) + bg[u][2];
+            const float hh = ftanh(xc[u][2] + rr * q);
+            const float ho = h[u], hn = z * ho + (1.f - z) * hh;
+            h[u] = row_ok ? hn : 0.f;
+            if (row_ok) {
+                const long bt = (long)b * L + t;
+                float* go = g_d + bt * 4 * GH + j0 + 16 * u;
+                go[0] = z; go[GH] = rr; go[2 * GH] = hh; go[3 * GH] = q;
+                hp_d[bt * GH + j0 + 16 * u] = ho;
+                out[bt * 2 * GH + d * GH + j0 + 16 * u] = hn;
+            }
+            *reinterpret_cast<unsigned short*>(Hn + nb * HS_STRIDE + (j0 + 16 * u) * 2) = bf1(h[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) xc[u][g] = xn[u][g];
+        wg_sync();
+    }
+}
+
+template <bool ALL>
+__global__ __launch_bounds__(512) void gru_mfma_bwd4_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
+                                                            const float* __restrict__ hprev, const uint4* __restrict__ pack,
+                                                            float* __restrict__ dai, float* __restrict__ dah, int B, int L, int rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * rows, n = lane & 15, q4 = lane >> 4;
+    const int nb = lane & 3, b = b0 + nb, ju = 4 * q4 + ((lane >> 2) & 3);
+    const bool row_ok = ALL || (nb < rows && b < B);
+    uint4* Al = reinterpret_cast<uint4*>(smem) + (size_t)w * (GFR - GR4B) * 64;
+    unsigned char* As = smem + (size_t)GNW * (GFR - GR4B) * 1024;
+    const uint4* pk = pack + ((size_t)(d * 2 + 1) * GNW + w) * GFR * 64 + lane;
+    bf16x8 A[GR4B];
+#pragma unroll
+    for (int f = 0; f < GR4B; ++f) A[f] = __builtin_bit_cast(bf16x8, pk[f * 64]);
+#pragma unroll
+    for (int f = GR4B; f < GFR; ++f) Al[(f - GR4B) * 64 + lane] = pk[f * 64];
+    // As: two images (step parity) of FIVE rows -- the four live batch rows and one row of zeros that the MFMA's other twelve batch
+    // columns all read: 15 KB instead of 25, so the image can be double-buffered and a step needs ONE barrier (the writers of step s-1
+    // use the other image; the image of step s is rewritten in step s-2, behind the barrier of step s-1)
+    for (int i = tid; i < 2 * 5 * AS_STRIDE / 4; i += 512) reinterpret_cast<unsigned*>(As)[i] = 0u;
+    const float* g_d = gates + (long)d * B * L * 4 * GH;
+    const float* hp_d = hprev + (long)d * B * L * GH;
+    float* dai_d = dai + (long)d * B * L * GH3; float* dah_d = dah + (long)d * B * L * GH3;
+    const int j0 = 32 * w + ju;
+    struct Saved { float z, rr, hh, q, hp, dy; };
+    const int bc = min(b, B - 1);
+    auto fetch = [&](int s, Saved (&v)[2]) __attribute__((always_inline)) {
+        const int sc = max(s, 0), t = d ? (L - 1 - sc) : sc;     // s = -1 (behind the last step): a valid address, the values are not used
+        const long bt = (long)bc * L + t;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float* go = g_d + bt * 4 * GH + j0 + 16 * u;
+            v[u].z = go[0]; v[u].rr = go[GH]; v[u].hh = go[2 * GH]; v[u].q = go[3 * GH];
+            v[u].hp = hp_d[bt * GH + j0 + 16 * u];
+            v[u].dy = row_ok ? dout[bt * 2 * GH + d * GH + j0 + 16 * u] : 0.f;   // the only one that must be zero for a dead row: g = dh + dy
+        }
+    };
+    Saved cur[2], nxt[2];
+    fetch(L - 1, cur);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)                                   // consumed here: nothing pending at loop entry (see the forward kernel)
+        asm volatile("" : "+v"(cur[u].z), "+v"(cur[u].rr), "+v"(cur[u].hh), "+v"(cur[u].q), "+v"(cur[u].hp), "+v"(cur[u].dy));
+    float dh[2] = {0.f, 0.f};
+    wg_sync();
+    for (int s = L - 1; s >= 0; --s) {
+        const int t = d ? (L - 1 - s) : s;
+        fetch(s - 1, nxt);                                        // in front of this step's stores
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float z = cur[u].z, rr = cur[u].rr, hh = cur[u].hh, q = cur[u].q, hp = cur[u].hp;
+            const float g = dh[u] + cur[u].dy;
+            dh[u] = g * z;
+            const float dahh = g * (1.f - z) * (1.f - hh * hh);
+            const float daz = g * (hp - hh) * z * (1.f - z);
+            const float dar = dahh * q * rr * (1.f - rr);
+            const float a2 = dahh * rr;
+            if (row_ok) {
+                const long oo = ((long)b * L + t) * GH3 + j0 + 16 * u;
+                dai_d[oo] = daz; dai_d[oo + GH] = dar; dai_d[oo + 2 * GH] = dahh;
+                dah_d[oo] = daz; dah_d[oo + GH] = dar; dah_d[oo + 2 * GH] = a2;
+            }
+            unsigned char* ar = As + (size_t)(s & 1) * 5 * AS_STRIDE + nb * AS_STRIDE + (j0 + 16 * u) * 2;
+            *reinterpret_cast<unsigned short*>(ar) = bf1(daz);
+            *reinterpret_cast<unsigned short*>(ar + GH * 2) = bf1(dar);
+            *reinterpret_cast<unsigned short*>(ar + 2 * GH * 2) = bf1(a2);
+        }
+        wg_sync();
+        f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};   // [u][k-step parity]: four chains of 12
+        const unsigned char* Ar = As + (size_t)(s & 1) * 5 * AS_STRIDE + min(n, 4) * AS_STRIDE + 8 * q4 * 2;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks) {
+            const bf16x8 Bf = *reinterpret_cast<const bf16x8*>(Ar + 32 * ks * 2);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = u * 24 + ks;
+                const bf16x8 Af = f < GR4B ? A[f < GR4B ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GR4B) * 64 + lane]);
+                acc[u][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[u][ks & 1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { dh[u] += compact4(acc[u][0] + acc[u][1]); cur[u] = nxt[u]; }
+    }
+}
+
 }  // namespace
 
 // Batch rows per workgroup (of the MFMA's 16 batch columns): a step moves 9 KB per row through one CU (input projections in, gates /
@@ -274,7 +473,14 @@ extern "C" int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, cons
         attr = true;
     }
     const int rows = gru_rows(B);
-    hipLaunchKernelGGL(gru_mfma_fwd_kernel, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, xa_fwd, xa_bwd, static_cast<const uint4*>(pack),
+    static bool attr4 = false;
+    if (rows <= 4 && !attr4) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_fwd4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_fwd4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
+        attr4 = true;
+    }
+    const bool all = rows == 4 && B % 4 == 0;
+    hipLaunchKernelGGL(rows > 4 ? gru_mfma_fwd_kernel : all ? gru_mfma_fwd4_kernel<true> : gru_mfma_fwd4_kernel<false>, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, xa_fwd, xa_bwd, static_cast<const uint4*>(pack),
                        bh_fwd, bh_bwd, out, gates, hprev, B, L, rows);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -291,7 +497,14 @@ extern "C" int sar_bigru_bwd_bf16(const float* dout, const float* gates, const f
         attr = true;
     }
     const int rows = gru_rows(B);
-    hipLaunchKernelGGL(gru_mfma_bwd_kernel, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, dout, gates, hprev, static_cast<const uint4*>(pack),
+    static bool attr4 = false;
+    if (rows <= 4 && !attr4) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_bwd4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_bwd4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
+        attr4 = true;
+    }
+    const bool all = rows == 4 && B % 4 == 0;
+    hipLaunchKernelGGL(rows > 4 ? gru_mfma_bwd_kernel : all ? gru_mfma_bwd4_kernel<true> : gru_mfma_bwd4_kernel<false>, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, dout, gates, hprev, static_cast<const uint4*>(pack),
                        dai, dah, B, L, rows);
     SAR_CHECK_LAUNCH();
     return SAR_OK;

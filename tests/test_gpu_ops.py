@@ -582,7 +582,7 @@ def _gru_bf16_emulation(xa, U, bh, dy_dir, reverse):
     return out, dai, dah
 
 
-@pytest.mark.parametrize("B,Lq", [(64, 39), (5, 7), (19, 3)])
+@pytest.mark.parametrize("B,Lq", [(64, 39), (5, 7), (19, 3), (8, 5), (520, 2)])   # four-row kernels: all rows live / ragged; 520: eight-row workgroups
 def test_bigru_bf16_mfma(L, B, Lq):
     """gru_mfma.hip (the "bf16" mode at hidden_dim 256): against a float64 emulation that rounds the MFMA operands where the
     kernels do (wiring errors are O(1); agreement is limited by last-bit rounding flips of h), and loosely against the exact
