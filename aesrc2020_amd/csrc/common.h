@@ -19,6 +19,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): inside a recurrence whose steps store to (or
+// atomically update) global memory, every step then waits for the write acknowledgements of the step before (~1 us each) although the
+// threads only exchange data through LDS.  (An asm statement with a memory clobber: the s_barrier builtin alone does not keep LDS
+// accesses on their side of it.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Wave-wide reductions without LDS: four DPP steps give every lane the result of its row of 16 lanes (quad_perm [1,0,3,2], quad_perm
 // [2,3,0,1], row_half_mirror, row_mirror), v_readlane of one lane per row combines the four rows.  (__shfl_xor is ds_bpermute_b32 on this
 // target -- six dependent LDS round trips per reduction, and most kernels here are one wave per row waiting on exactly that.)

@@ -871,8 +871,15 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const u16* __restric
 struct PackRow { const float* w; u16* wf; u16* wd; long taps, Cin, Cout, first_block, pad_; };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __restrict__ tab, int n) {
-    int r = 0;
-    while (r + 1 < n && (long)blockIdx.x >= tab[r + 1].first_block) ++r;
+    // the row of this block: rows are sorted by first_block; every lane tests one row (one load round trip for up to 64 rows -- a scan
+    // was up to n dependent L2 round trips in front of the last convolutions' blocks, most of this kernel's 25 us)
+    int r = -1;
+    for (int base = 0; base < n; base += 64) {
+        const int q = base + (threadIdx.x & 63);
+        const bool le = q < n && tab[q].first_block <= (long)blockIdx.x;
+        r += __popcll(__ballot(le));
+    }
+    r = __builtin_amdgcn_readfirstlane(r);
     const PackRow row = tab[r];
     const int taps = (int)row.taps, Cin = (int)row.Cin, Cout = (int)row.Cout;
     const int Ff = taps * Cin / 16, Ffp = Ff + 8, Fd = taps * Cout / 16, Fdp = Fd + 8;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
             a += LDS_E ? e_s[t * Smax + s_] : ew[(long)t * Smax + s_];
             al[cur][s_] = a; aw[(long)t * Smax + s_] = a;
         }
-        __syncthreads();
+        lds_barrier();                                                // the frames talk through al[][] only; the alpha stores stay in flight
     }
     if (tid == 0) {
         float ll = -INFINITY;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
             const float w = expf(c + bb);
             if (w > 0.f) atomicAdd(&dp[(long)t * V + xl[s_]], -g * w);
         }
-        __syncthreads();
+        lds_barrier();                                                // be[][] only; the atomics stay in flight
     }
 }
 

@@ -73,7 +73,7 @@ CFG5 = dict(input_shape=[2000, 80, 1], res_type="res34", res_filters=32, hidden_
             disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)
 
 
-def _dup_half(kw, B, tol_out, tol_grad, seed=11):
+def _dup_half(kw, B, tol_out, tol_grad, seed=11, tol_halves=None):
     """B-utterance batch = two copies of a B/2 batch: per-utterance outputs of the full run equal the half run's, halves agree,
     batch-mean gradients agree."""
     from aesrc2020_amd.model import SAR_Net
@@ -86,7 +86,7 @@ def _dup_half(kw, B, tol_out, tol_grad, seed=11):
     for k in ("y_accent", "y_disc"):
         a = mf.out[k].cpu().numpy(); b = mh.out[k].cpu().numpy()
         assert np.all(np.isfinite(a)) and np.abs(a.sum(1) - 1).max() < 1e-4
-        assert np.abs(a[:B // 2] - a[B // 2:]).max() <= tol_out, k
+        assert np.abs(a[:B // 2] - a[B // 2:]).max() <= (tol_out if tol_halves is None else tol_halves), k
         assert np.abs(a[:B // 2] - b).max() <= tol_out, k
     gf = mf.store.grads.cpu().numpy(); gh = mh.store.grads.cpu().numpy()
     assert np.all(np.isfinite(gf))
@@ -102,12 +102,14 @@ def test_cfg5_duplicated_half_batch_invariance(B):
 
 
 def test_cfg2_bf16_mode_duplicated_half_batch_invariance():
-    """The bench's default workload and mode (cfg2, B=64, bf16 trunk + bf16-MFMA GEMMs / GRU).  The halves see different atomic
-    orders in the statistic bins, so stored bf16 values flip last bits: probabilities agree to bf16 noise, not to 1e-4."""
+    """The bench's default workload and mode (cfg2, B=64, bf16 trunk + bf16-MFMA GEMMs / GRU).  The two runs see different atomic
+    orders in the statistic bins, so stored bf16 values flip last bits: the B=64 and B=32 runs agree to bf16 noise, not to 1e-4
+    (tools/dup_half_stats.py, 36 fresh runs: accent 1.4e-2 .. 3.2e-2, disc 2.4e-2 .. 4.6e-2 -- a 6e-2 bound failed once in three
+    suite runs -- gradient 0.106 .. 0.121), while the two halves of ONE run (same bins) agree to 7e-5 at most."""
     from aesrc2020_amd import _lib
     _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
     try:
-        m = _dup_half(CFG2, 64, 6e-2, 2.5e-1)
+        m = _dup_half(CFG2, 64, 1e-1, 2.5e-1, tol_halves=1e-3)
         assert m.trunk.bf16
     finally:
         _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32")
