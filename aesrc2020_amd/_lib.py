@@ -138,6 +138,37 @@ class GemmBatch(ctypes.Structure):
                 getattr(self, name)[i] = None if t is None else t.data_ptr()
 
 
+class GemmWgrad(ctypes.Structure):
+    """include/sarnet.h: sarGemmWgrad."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("X", "dY", "dW", "db")] + \
+               [(n, ctypes.c_int) for n in ("in_dim", "out_dim", "R", "lda", "ldb", "ldc", "splitk", "pad_")]
+
+
+class GemmWgradGroup:
+    """Device table of one grouped weight-gradient launch (sar_gemm_wgrad_group_plan runs on the host; uploaded once).
+    probs: tuples (X, dY, dW, db | None, in_dim, out_dim, R, lda, ldb, ldc, splitk).  Raises ValueError when a problem is not
+    eligible for the bf16 GEMM path (the caller launches them one by one then)."""
+
+    def __init__(self, probs):
+        import torch
+        n = len(probs)
+        arr = (GemmWgrad * n)()
+        for a, q in zip(arr, probs):
+            a.X, a.dY, a.dW, a.db = q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), (None if q[3] is None else q[3].data_ptr())
+            a.in_dim, a.out_dim, a.R, a.lda, a.ldb, a.ldc, a.splitk = (int(v) for v in q[4:11])
+        buf = ctypes.create_string_buffer(n * 64)
+        tb = ctypes.c_int(0)
+        rc = lib().fn["sar_gemm_wgrad_group_plan"](arr, n, buf, ctypes.byref(tb))
+        if rc != 0:
+            raise ValueError("sar_gemm_wgrad_group_plan: status %d (a problem is not on the bf16 GEMM path)" % rc)
+        self.keep = [t for q in probs for t in q[:4]]                          # the tensors whose addresses the table holds
+        self.n, self.blocks = n, tb.value
+        self.table = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
+
+    def launch(self):
+        call("sar_gemm_wgrad_group_f32", self.table, self.n, self.blocks)
+
+
 class WgradConv(ctypes.Structure):
     """include/sarnet.h: sarWgradConv."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dy", "dw", "dbias")] + \

@@ -199,17 +199,16 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
 // TAIL: N and / or K need not be multiples of 64 (multiples of 4: rows stay 16-byte pieces) -- the bpe-1k CTC output layer
 // (N = 1000 forward and in its weight gradient, K = 1000 in its input gradient): pieces past the edge are loaded from a clamped
 // address and zeroed, stores past N are dropped.  M stays a multiple of 64.
-template <bool A_KC, bool B_KC, bool TAIL = false>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
-                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
-    const int bz = blockIdx.z / splitk, kz = blockIdx.z - bz * splitk;
-    const float* __restrict__ A = gb.A[bz]; const float* __restrict__ B = gb.B[bz];
-    float* __restrict__ C = gb.C[bz]; const float* __restrict__ bias = gb.bias[bz]; float* __restrict__ colsum = gb.colsum[bz];
-    __shared__ __attribute__((aligned(16))) unsigned char As[2][64 * GB_RS];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][64 * GB_RS];
-    __shared__ float csum[4][64];
+// One 64 x 64 output tile (tile column bx, tile row by, split-K slice kz); the LDS comes from the calling kernel, so that a kernel
+// which holds several instantiations (the grouped weight-gradient launch below) still has ONE set of buffers.
+struct GemmLds { unsigned char As[2][64 * GB_RS]; unsigned char Bs[2][64 * GB_RS]; float csum[4][64]; };
+template <bool A_KC, bool B_KC, bool TAIL>
+__device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                               const float* __restrict__ bias, float* __restrict__ colsum, int M, int N, int K, int lda, int ldb,
+                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLds& L) {
+    unsigned char (&As)[2][64 * GB_RS] = L.As; unsigned char (&Bs)[2][64 * GB_RS] = L.Bs; float (&csum)[4][64] = L.csum;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int nkt = (K + GB_K - 1) / GB_K, per = (nkt + splitk - 1) / splitk;
     const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
     // staging: thread -> (row = tid / 4 of the tile as stored, 16 consecutive elements (tid % 4) * 16 of that row)
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int 
             }
         }
     };
-    const bool do_colsum = !B_KC && colsum != nullptr && blockIdx.y == 0;
+    const bool do_colsum = !B_KC && colsum != nullptr && by == 0;
     float cs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) cs[i] = 0.f;
@@ -316,6 +315,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int 
             *dst = v;
         }
     }
+}
+
+template <bool A_KC, bool B_KC, bool TAIL = false>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
+                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
+    const int bz = blockIdx.z / splitk, kz = blockIdx.z - bz * splitk;
+    __shared__ __attribute__((aligned(16))) GemmLds L;
+    gemm_bf16_tile<A_KC, B_KC, TAIL>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
+                                     blockIdx.x, blockIdx.y, kz, L);
+}
+
+// Weight gradients of MANY Dense / GRU kernels in one launch (they are off the critical path of the backward pass: the host collects
+// them and launches the group once, behind the last input gradient): dW_i[in_i, out_i] += X_i^T dY_i, db_i += column sums of dY_i, the
+// problems of any (bf16-path) shape.  A block finds its problem in a table sorted by first block (one load round trip, as in
+// pack_weights_kernel), then runs the same tile code as sar_gemm_wgrad_f32.  Launches of 7-35 us that each filled a fraction of
+// the chip become one.
+struct WgRow { const float* X; const float* dY; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk, first_block; };   // 64 bytes
+__global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow* __restrict__ tab, int n) {
+    __shared__ __attribute__((aligned(16))) GemmLds L;
+    int r = -1;
+    for (int base = 0; base < n; base += 64) {
+        const int q = base + (threadIdx.x & 63);
+        r += __popcll(__ballot(q < n && tab[q].first_block <= (int)blockIdx.x));
+    }
+    r = __builtin_amdgcn_readfirstlane(r);
+    const WgRow p = tab[r];
+    const int local = (int)blockIdx.x - p.first_block, nbx = (p.N + 63) / 64, nby = p.M / 64;
+    const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
+    if ((p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
+    else gemm_bf16_tile<false, false, false>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
 }
 
 }  // namespace
@@ -412,4 +441,34 @@ extern "C" int sar_gemm_wgrad_batched_f32(const sarGemmBatch* b, int nbatch, int
     GemmBatch gb{};
     for (int i = 0; i < nbatch; ++i) { gb.A[i] = b->A[i]; gb.B[i] = b->B[i]; gb.C[i] = b->C[i]; gb.colsum[i] = const_cast<float*>(b->bias[i]); }
     return gemm_launch(gb, nbatch, in_dim, out_dim, R, lda, ldb, ldc, 0, 0, ACT_NONE, 1, splitk, stream);
+}
+
+// include/sarnet.h: sarGemmWgrad.  Host-only planning: validates that every problem runs on the bf16-MFMA path (SAR_EINVAL otherwise:
+// the caller then launches them one by one) and writes the device table rows (64 bytes each) + the grid size.
+struct sarGemmWgrad { const float* X; const float* dY; float* dW; float* db; int in_dim, out_dim, R, lda, ldb, ldc, splitk, pad_; };
+extern "C" int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void* table_out, int* total_blocks) {
+    if (!probs || n < 1 || n > 4096 || !table_out || !total_blocks || g_gemm_math != 1) return SAR_EINVAL;
+    WgRow* rows = static_cast<WgRow*>(table_out);
+    long blk = 0;
+    for (int i = 0; i < n; ++i) {
+        const sarGemmWgrad& q = probs[i];
+        const int M = q.in_dim, N = q.out_dim, K = q.R;
+        if (!q.X || !q.dY || !q.dW || M < 64 || N < 64 || K < 64 || M % 64 || q.splitk < 1 || (K + 63) / 64 < q.splitk) return SAR_EINVAL;
+        if ((N % 64 || K % 64) && (N % 4 || K % 4)) return SAR_EINVAL;
+        if ((q.lda & 3) || (q.ldb & 3) || (reinterpret_cast<uintptr_t>(q.X) & 15) || (reinterpret_cast<uintptr_t>(q.dY) & 15)) return SAR_EINVAL;
+        WgRow r;
+        r.X = q.X; r.dY = q.dY; r.dW = q.dW; r.db = q.db; r.M = M; r.N = N; r.K = K; r.lda = q.lda; r.ldb = q.ldb; r.ldc = q.ldc;
+        r.splitk = q.splitk; r.first_block = (int)blk;
+        rows[i] = r;
+        blk += (long)((N + 63) / 64) * (M / 64) * q.splitk;
+        if (blk > (1L << 30)) return SAR_EINVAL;
+    }
+    *total_blocks = (int)blk;
+    return SAR_OK;
+}
+extern "C" int sar_gemm_wgrad_group_f32(const void* table_dev, int n, int total_blocks, hipStream_t stream) {
+    if (!table_dev || n < 1 || total_blocks < 1 || g_gemm_math != 1) return SAR_EINVAL;
+    hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const WgRow*>(table_dev), n);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
 }

@@ -6,6 +6,7 @@ train step runs in libsarnet_hip.so.  There is no CPU path: constructing a Param
 raises.
 """
 import math
+import os
 import numpy as np
 import torch
 
@@ -130,6 +131,40 @@ class ParamStore:
             self._zero_table = torch.tensor([[t.data_ptr(), t.numel() * t.element_size() // 4] for t in zl.values()], dtype=torch.int64, device=self.grads.device)
             self._zero_rows = set(zl)
         return self.__dict__.get("_zero_table")
+
+    # ---- deferred weight gradients: the Dense / GRU kernel gradients of a backward pass are off its critical path; in the bf16 GEMM
+    # mode the layers hand them over here and ONE grouped launch (csrc/gemm.hip: gemm_bf16_wgrad_group_kernel) runs them behind the
+    # last input gradient -- 5 (cfg2) to 10 (cfg3) launches of 7-35 us that each filled a fraction of the chip
+    def begin_deferred_wgrads(self):
+        self._defer = [] if (self.training and _lib.get_gemm_math() == "bf16" and os.environ.get("SAR_WGRAD_GROUP", "1") == "1") else None
+
+    def deferring_wgrads(self):
+        return self.__dict__.get("_defer") is not None
+
+    def defer_wgrad(self, X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, splitk):
+        """The operands must stay as they are until flush_wgrads(): per-layer buffers, not shared scratch."""
+        self._defer.append((X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, splitk))
+
+    def flush_wgrads(self):
+        probs, self._defer = self.__dict__.get("_defer"), None
+        if not probs:
+            return
+        key = tuple((q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr()) + tuple(q[4:]) for q in probs)
+        groups = self.__dict__.setdefault("_wg_groups", {})
+        grp = groups.get(key)
+        if grp is None and not torch.cuda.is_current_stream_capturing():      # (the table upload cannot be captured: built in the eager step)
+            try:
+                grp = _lib.GemmWgradGroup(probs)
+            except ValueError:
+                grp = False                                                     # an ineligible shape: one launch each, as without deferral
+            if len(groups) > 16:
+                groups.clear()
+            groups[key] = grp
+        if grp:
+            grp.launch()
+        else:
+            for q in probs:
+                _lib.call("sar_gemm_wgrad_f32", *q)
 
     def zero_grads(self):
         tab = self._zero_table_sync()

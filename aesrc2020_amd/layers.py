@@ -77,19 +77,26 @@ class Dense(Layer):
 
     def backward(self, dy, need_dx=True, accumulate_dx=False, dx_out=None, dz_ready=False):
         R = self.R
+        defer = self.store.deferring_wgrads() and self.in_dim % 64 == 0 and self.units >= 64 and R >= 64
+        # a deferred weight gradient reads dz when the group is launched: the layer's own buffer then, not the shared scratch
+        dzbuf = (lambda: self.buf("dz", (R, self.units))) if defer else (lambda: self.scratch("dz%dx%d" % (R, self.units), (R, self.units)))
         if dz_ready:                                               # the caller (LayerNorm.backward(act=...)) already applied act'
             dz = dy
         elif self.activation == "softmax":
-            dz = self.scratch("dz%dx%d" % (R, self.units), (R, self.units))
+            dz = dzbuf()
             _call("sar_softmax_bwd_f32", dy, self.y, dz, R, self.units)
         elif ACT[self.activation] != 0:
-            dz = self.scratch("dz%dx%d" % (R, self.units), (R, self.units))
+            dz = dzbuf()
             _call("sar_act_bwd_f32", dy, self.y, dz, R * self.units, ACT[self.activation])
         else:
             dz = dy
         sk = pick_splitk(self.in_dim, self.units, R)
-        _call("sar_gemm_wgrad_f32", self.x, dz, self.kernel.g, self.bias.g if self.bias is not None else None, self.in_dim,
-              self.units, R, self.in_dim, self.units, self.units, sk)
+        wg = (self.x, dz, self.kernel.g, self.bias.g if self.bias is not None else None, self.in_dim, self.units, R, self.in_dim,
+              self.units, self.units, sk)
+        if defer:
+            self.store.defer_wgrad(*wg)
+        else:
+            _call("sar_gemm_wgrad_f32", *wg)
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else self.buf("dx", (R, self.in_dim))
@@ -172,7 +179,11 @@ class BiGRU(Layer):
             _call("sar_bigru_last_bwd_f32", dy, dout, B, L, H)
         else:
             dout = dy
-        dai = self.scratch("gru_dai%d_%d_%d" % (B, L, H), (2, B, L, 3 * H)); dah = self.scratch("gru_dah%d_%d_%d" % (B, L, H), (2, B, L, 3 * H))
+        defer = self.store.deferring_wgrads() and I % 64 == 0 and H % 64 == 0 and R >= 64
+        if defer:                                                  # read when the group is launched: this layer's own buffers
+            dai = self.buf("dai", (2, B, L, 3 * H)); dah = self.buf("dah", (2, B, L, 3 * H))
+        else:
+            dai = self.scratch("gru_dai%d_%d_%d" % (B, L, H), (2, B, L, 3 * H)); dah = self.scratch("gru_dah%d_%d_%d" % (B, L, H), (2, B, L, 3 * H))
         if self.mfma:
             _call("sar_bigru_bwd_bf16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H)
         else:
@@ -189,7 +200,10 @@ class BiGRU(Layer):
         # (in_dim == hidden: the reference's CNN_LIN -> CRNN), else one per kind
         ks = [(self.x, dai[i], self.p[d][0].g, self.p[d][2].g[:3 * H]) for i, d in enumerate(("forward", "backward"))]
         us = [(self.hprev[i], dah[i], self.p[d][1].g, self.p[d][2].g[3 * H:]) for i, d in enumerate(("forward", "backward"))]
-        if I == H and sk == sku:
+        if defer:
+            for (x_, dy_, dw_, db_), in_, sk_ in [(q, I, sk) for q in ks] + [(q, H, sku) for q in us]:
+                self.store.defer_wgrad(x_, dy_, dw_, db_, in_, 3 * H, R, in_, 3 * H, 3 * H, sk_)
+        elif I == H and sk == sku:
             _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(ks + us), 4, I, 3 * H, R, I, 3 * H, 3 * H, sk)
         else:
             _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(ks), 2, I, 3 * H, R, I, 3 * H, 3 * H, sk)

@@ -422,6 +422,7 @@ class SARNetModel:
         c = self.cfg
         B, L = self.B, self.L
         d_crnn = None
+        self.store.begin_deferred_wgrads()                                   # bf16 GEMM mode: Dense / GRU kernel gradients in one launch, below
         if c["ctc_enable"]:
             _call("sar_ctc_batch_cost_bwd_f32", self.out["ctc_pred"], self.in_ctc_label, self.in_ctc_in_len, self.in_ctc_out_len,
                   self.ctc_loss, self.seed["y_ctc_loss"], self.ctc_ws, self.ctc_ws_bytes, self.ctc_dprobs, B, L, c["bpe_classes"],
@@ -476,6 +477,7 @@ class SARNetModel:
         g = self.CRNN.backward(g.view(B, L, -1))
         g = self.CNN_LIN_LN.backward(g, act=self.CNN_LIN.activation)
         g = self.CNN_LIN.backward(g, dz_ready=True)
+        self.store.flush_wgrads()
         self._g_trunk = g.view(B, self.trunk.out_hw[0], self.trunk.out_hw[1], -1)
         return self._g_trunk
 

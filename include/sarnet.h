@@ -97,6 +97,18 @@ int sar_dbg_last_wgrad_launch(int* out4);
  * Process-wide host-side setting read at launch time (also: env SAR_CONV_MATH=fp32). */
 int sar_set_conv_math(int mode);
 int sar_get_conv_math(void);
+/* Weight gradients of many Dense / GRU kernels in ONE launch (bf16-MFMA GEMM mode only): problem i is sar_gemm_wgrad_f32(X, dY, dW,
+ * db, in_dim, out_dim, R, lda, ldb, ldc, splitk).  sar_gemm_wgrad_group_plan runs on the host: it checks that every problem is
+ * eligible for the bf16 path (in_dim % 64 == 0; out_dim, R multiples of 64, or of 4 with out_dim, R >= 64; 16-byte aligned rows) and
+ * writes n table rows of 64 bytes + the grid size; SAR_EINVAL = launch them one by one instead.  The caller uploads the table once;
+ * sar_gemm_wgrad_group_f32 launches it (the operands only have to be valid when it runs: the host defers the weight gradients of a
+ * backward pass and launches the group behind its last input gradient, model.py:340-366 compile/fit has no such ordering). */
+typedef struct sarGemmWgrad {
+    const float* X; const float* dY; float* dW; float* db;
+    int in_dim, out_dim, R, lda, ldb, ldc, splitk, pad_;
+} sarGemmWgrad;
+int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void* table_out, int* total_blocks);
+int sar_gemm_wgrad_group_f32(const void* table_dev, int n, int total_blocks, sarStream_t stream);
 /* GEMM arithmetic of sar_gemm_f32 / sar_gemm_wgrad_f32: 0 = fp32 MFMA (default), 1 = operands rounded to bf16 while they are
  * staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate (problems whose M, N, K are multiples of 64; others keep fp32).  The
  * "bf16" mode of BASELINE configs[1]; fp32 tensors at the ABI either way.  Host-side, process-wide (env SAR_GEMM_MATH=bf16). */

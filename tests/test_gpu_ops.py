@@ -100,6 +100,40 @@ def test_gemm_bf16_math(L, a_kc, b_kc, M, N, K, sk):
     assert L.get_gemm_math() == old
 
 
+def test_gemm_wgrad_group(L):
+    """sar_gemm_wgrad_group_plan / _f32: weight gradients of different shapes in ONE launch (the deferred Dense / GRU kernel gradients
+    of a backward pass: cfg2 / cfg3 shapes incl. the bpe-1k tail, a K = 64 problem, split-K) against float64 on the bf16-rounded
+    operands; both results accumulate; a problem without a bias gradient; the plan refuses the fp32 mode and ineligible shapes."""
+    rng = np.random.default_rng(17)
+    bf = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()
+    shapes = [(2496, 768, 256, 1, True), (2496, 256, 768, 3, True), (2496, 256, 768, 3, True), (64, 8192, 256, 1, True), (2496, 512, 256, 2, False),
+              (2496, 256, 1000, 2, True), (312, 128, 100, 1, True)]          # (R, in, out, splitk, bias gradient)
+    old = L.get_gemm_math()
+    L.set_gemm_math("bf16")
+    try:
+        probs, refs = [], []
+        for R, I, N, sk, hb in shapes:
+            X = rng.standard_normal((R, I)); dY = rng.standard_normal((R, N)) / np.sqrt(R)
+            dW0 = rng.standard_normal((I, N)); db0 = rng.standard_normal(N)
+            dW, db = dev(dW0), (dev(db0) if hb else None)
+            probs.append((dev(X), dev(dY), dW, db, I, N, R, I, N, N, sk))
+            refs.append((dW0 + bf(X).T @ bf(dY), db0 + dY.sum(0)))
+        grp = L.GemmWgradGroup(probs)
+        assert grp.n == len(shapes) and grp.blocks == sum(-(-N // 64) * (I // 64) * sk for R, I, N, sk, hb in shapes)
+        grp.launch()
+        for q, (rw, rb), sh in zip(probs, refs, shapes):
+            check(q[2], rw, 2e-5, "grouped dW %r" % (sh,))
+            if q[3] is not None:
+                check(q[3], rb, 2e-5, "grouped db %r" % (sh,))
+        with pytest.raises(ValueError):                                      # in_dim not a multiple of 64
+            L.GemmWgradGroup([(zeros(128, 33), zeros(128, 64), zeros(33, 64), None, 33, 64, 128, 33, 64, 64, 1)])
+        L.set_gemm_math("fp32")
+        with pytest.raises(ValueError):                                      # fp32 GEMM mode: no grouped launch
+            L.GemmWgradGroup(probs[:1])
+    finally:
+        L.set_gemm_math(old)
+
+
 @pytest.mark.parametrize("math", ["fp32", "bf16"])
 def test_gemm_batched(L, math):
     """sar_gemm_batched_f32 / sar_gemm_wgrad_batched_f32: up to four equal-shape problems in one launch (the BiGRU's projections
