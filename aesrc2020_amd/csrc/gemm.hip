@@ -235,19 +235,28 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             }
         }
     };
+    // (Sharing the fused column sum out over the row blocks -- block `by` sums the k-tiles kt % nby == by -- was measured: the grouped
+    // weight-gradient launch went from 63 to 71 us, every block then pays the final cross-lane reduction; without any column sum it is 51.)
     const bool do_colsum = !B_KC && colsum != nullptr && by == 0;
     float cs[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) cs[i] = 0.f;
     auto gstore = [&](int set, int buf, int kt) __attribute__((always_inline)) {
-        const float live = kt < kt1 ? 1.f : 0.f;
+        // a k-tile past the slice (the pipeline's second half-step when the slice has an odd number of tiles) is staged as zeros: a
+        // block-uniform branch -- as a multiplier on every element it was 32 of the ~90 VALU instructions a thread spends per k-tile,
+        // and this kernel is bound by exactly those (tools/gemm_group_bench.py: ~500 cycles per k-tile and SIMD for 128 of MFMA)
         unsigned wa[8], wb[8];
+        if (kt < kt1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 a = ra[set][i], b = rb[set][i];
-            wa[2 * i] = gpack2(a.x * live, a.y * live); wa[2 * i + 1] = gpack2(a.z * live, a.w * live);
-            wb[2 * i] = gpack2(b.x * live, b.y * live); wb[2 * i + 1] = gpack2(b.z * live, b.w * live);
-            if (do_colsum) { cs[4 * i] += b.x * live; cs[4 * i + 1] += b.y * live; cs[4 * i + 2] += b.z * live; cs[4 * i + 3] += b.w * live; }
+            for (int i = 0; i < 4; ++i) {
+                const float4 a = ra[set][i], b = rb[set][i];
+                wa[2 * i] = gpack2(a.x, a.y); wa[2 * i + 1] = gpack2(a.z, a.w);
+                wb[2 * i] = gpack2(b.x, b.y); wb[2 * i + 1] = gpack2(b.z, b.w);
+                if (do_colsum) { cs[4 * i] += b.x; cs[4 * i + 1] += b.y; cs[4 * i + 2] += b.z; cs[4 * i + 3] += b.w; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { wa[i] = 0u; wb[i] = 0u; }
         }
         unsigned char* da = As[buf] + srow * GB_RS + sseg * 2;
         unsigned char* db = Bs[buf] + srow * GB_RS + sseg * 2;
@@ -317,13 +326,26 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
     }
 }
 
+// XCD-aware tile order.  Workgroups go to the eight XCDs round-robin by their linear id, and every XCD has its own 4 MB L2: in
+// dispatch order the tiles that share operand rows (the N / 64 column tiles of one row block; the tiles of one split-K slice) sit
+// on eight different L2s, each of which fetches those rows from the fabric again -- the grouped weight gradient moved 300 MB for
+// 50 MB of operands and ran at the 4.7 TB/s that comes to (91 TFLOP/s).  Here XCD c takes the c-th CONTIGUOUS eighth of the tile
+// sequence (column tile fastest, then row block, then split-K slice / batch), so neighbours in that sequence share an L2.
+__device__ __forceinline__ unsigned xcd_order(unsigned l, unsigned total) {
+    const unsigned chunk = total >> 3, body = chunk << 3;           // the last total % 8 blocks keep their place
+    return l < body ? (l & 7u) * chunk + (l >> 3) : l;
+}
+
 template <bool A_KC, bool B_KC, bool TAIL = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
                                                         int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
-    const int bz = blockIdx.z / splitk, kz = blockIdx.z - bz * splitk;
+    const unsigned nbx = gridDim.x, nby = gridDim.y;
+    const unsigned t = xcd_order(blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z), nbx * nby * gridDim.z);
+    const int bx = (int)(t % nbx), by = (int)(t / nbx % nby), z = (int)(t / (nbx * nby));
+    const int bz = z / splitk, kz = z - bz * splitk;
     __shared__ __attribute__((aligned(16))) GemmLds L;
     gemm_bf16_tile<A_KC, B_KC, TAIL>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
-                                     blockIdx.x, blockIdx.y, kz, L);
+                                     bx, by, kz, L);
 }
 
 // Weight gradients of MANY Dense / GRU kernels in one launch (they are off the critical path of the backward pass: the host collects
@@ -341,8 +363,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
     }
     r = __builtin_amdgcn_readfirstlane(r);
     const WgRow p = tab[r];
-    const int local = (int)blockIdx.x - p.first_block, nbx = (p.N + 63) / 64, nby = p.M / 64;
+    const int nbx = (p.N + 63) / 64, nby = p.M / 64;
+    const int local = (int)xcd_order(blockIdx.x - p.first_block, (unsigned)(nbx * nby * p.splitk));   // first_block % 8 == 0 (the plan pads)
     const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
+    if (kz >= p.splitk) return;                                      // padding blocks of the plan
     if ((p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
     else gemm_bf16_tile<false, false, false>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
 }
@@ -460,7 +484,7 @@ extern "C" int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void*
         r.X = q.X; r.dY = q.dY; r.dW = q.dW; r.db = q.db; r.M = M; r.N = N; r.K = K; r.lda = q.lda; r.ldb = q.ldb; r.ldc = q.ldc;
         r.splitk = q.splitk; r.first_block = (int)blk;
         rows[i] = r;
-        blk += (long)((N + 63) / 64) * (M / 64) * q.splitk;
+        blk += ((long)((N + 63) / 64) * (M / 64) * q.splitk + 7) & ~7L;   // every problem starts on XCD 0 (xcd_order); <= 7 idle blocks each
         if (blk > (1L << 30)) return SAR_EINVAL;
     }
     *total_blocks = (int)blk;

@@ -143,7 +143,9 @@ class ParamStore:
 
     def defer_wgrad(self, X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, splitk):
         """The operands must stay as they are until flush_wgrads(): per-layer buffers, not shared scratch."""
-        self._defer.append((X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, splitk))
+        # split-K: pick_splitk aims a SINGLE launch at 256 blocks; the group fills the chip anyway and every extra slice is another
+        # round of atomics (tools/gemm_group_bench.py, cfg2 problem set: 1 / 2 / 4 / 8 slices = 85 / 60 / 54 / 67 us)
+        self._defer.append((X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, min(splitk, 4)))
 
     def flush_wgrads(self):
         probs, self._defer = self.__dict__.get("_defer"), None
