@@ -155,18 +155,25 @@ class ParamStore:
         groups = self.__dict__.setdefault("_wg_groups", {})
         grp = groups.get(key)
         if grp is None and not torch.cuda.is_current_stream_capturing():      # (the table upload cannot be captured: built in the eager step)
-            try:
-                grp = _lib.GemmWgradGroup(probs)
-            except ValueError:
-                grp = False                                                     # an ineligible shape: one launch each, as without deferral
+            def eligible(q):
+                try:
+                    _lib.GemmWgradGroup([q]); return True
+                except ValueError:
+                    return False
+            flags = [eligible(q) for q in probs]                                # the rest (a shape off the bf16 path): one launch each
+            if sum(flags) < 2:
+                flags = [False] * len(probs)
+            ok = [q for q, f in zip(probs, flags) if f]
+            grp = (_lib.GemmWgradGroup(ok) if ok else None, [q for q, f in zip(probs, flags) if not f])
             if len(groups) > 16:
                 groups.clear()
             groups[key] = grp
-        if grp:
-            grp.launch()
-        else:
-            for q in probs:
-                _lib.call("sar_gemm_wgrad_f32", *q)
+        if grp is None:                                                         # first sighting inside a capture: as without deferral
+            grp = (None, probs)
+        if grp[0] is not None:
+            grp[0].launch()
+        for q in grp[1]:
+            _lib.call("sar_gemm_wgrad_f32", *q)
 
     def zero_grads(self):
         tab = self._zero_table_sync()
