@@ -196,9 +196,11 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gs16x4*)(base + off));
 }
 
-// TAIL: N and / or K need not be multiples of 64 (multiples of 4: rows stay 16-byte pieces) -- the bpe-1k CTC output layer
-// (N = 1000 forward and in its weight gradient, K = 1000 in its input gradient): pieces past the edge are loaded from a clamped
-// address and zeroed, stores past N are dropped.  M stays a multiple of 64.
+// TAIL: M, N and / or K need not be multiples of 64 (multiples of 4: rows stay 16-byte pieces) -- the bpe-1k CTC output layer (N = 1000
+// forward and in its weight gradient, K = 1000 in its input gradient), cfg5's 6 048 rows: pieces past the edge are loaded from a
+// clamped address and zeroed, stores past M / N are dropped.  (Element-by-element staging for extents that are not multiples of 4 --
+// the 34 / 66 / 10 columns of the VLAD assignment layer -- was built and measured: 24.6 us against the fp32 kernel's 19.6 forward,
+// and its weight gradient cost the grouped launch 17 us where it had cost 11.7 alone; those problems stay on the fp32 kernel.)
 // One 64 x 64 output tile (tile column bx, tile row by, split-K slice kz); the LDS comes from the calling kernel, so that a kernel
 // which holds several instantiations (the grouped weight-gradient launch below) still has ONE set of buffers.
 struct GemmLds { unsigned char As[2][64 * GB_RS]; unsigned char Bs[2][64 * GB_RS]; float csum[4][64]; };
@@ -313,6 +315,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (TAIL && row >= M) continue;
         float v = acc[r] + bv;
         float* dst = C + (long)row * ldc + col;
         if (splitk > 1) {
@@ -363,11 +366,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
     }
     r = __builtin_amdgcn_readfirstlane(r);
     const WgRow p = tab[r];
-    const int nbx = (p.N + 63) / 64, nby = p.M / 64;
+    const int nbx = (p.N + 63) / 64, nby = (p.M + 63) / 64;
     const int local = (int)xcd_order(blockIdx.x - p.first_block, (unsigned)(nbx * nby * p.splitk));   // first_block % 8 == 0 (the plan pads)
     const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
     if (kz >= p.splitk) return;                                      // padding blocks of the plan
-    if ((p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
+    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
     else gemm_bf16_tile<false, false, false>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
 }
 
@@ -392,10 +395,12 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     if (nb > 1 && !aligned) return SAR_EINVAL;             // a batch runs one code path: all operands 16-byte aligned
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk * nb), block(256);
     // bf16 MFMA path: whole 64 x 64 x 64 tiles, 16-byte aligned rows (every Dense / GRU-projection GEMM of the model)
-    const bool tail16 = g_gemm_math == 1 && M % 64 == 0 && (N % 64 || K % 64) && N % 4 == 0 && K % 4 == 0 && N >= 64 && K >= 64 && (lda & 3) == 0 &&
-                        (ldb & 3) == 0 && aligned && (K + 63) / 64 >= splitk;
+    // bf16 MFMA path with tails: extents and row strides that are multiples of 4, from 64 up (smaller problems keep the fp32 kernel)
+    const bool pieces = ((M | N | K | lda | ldb) & 3) == 0 && aligned;
+    const bool whole = pieces && M % 64 == 0 && N % 64 == 0 && K % 64 == 0;
+    const bool tail16 = g_gemm_math == 1 && pieces && !whole && M >= 64 && N >= 64 && K >= 64 && (K + 63) / 64 >= splitk;
     if (tail16) {
-        grid.x = cdiv(N, 64);
+        grid.x = cdiv(N, 64); grid.y = cdiv(M, 64);
 #define LAUNCH16T(AK, BK_)                                                                                           \
     hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)
         if (a_kc && b_kc) LAUNCH16T(true, true);
@@ -477,14 +482,13 @@ extern "C" int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void*
     for (int i = 0; i < n; ++i) {
         const sarGemmWgrad& q = probs[i];
         const int M = q.in_dim, N = q.out_dim, K = q.R;
-        if (!q.X || !q.dY || !q.dW || M < 64 || N < 64 || K < 64 || M % 64 || q.splitk < 1 || (K + 63) / 64 < q.splitk) return SAR_EINVAL;
-        if ((N % 64 || K % 64) && (N % 4 || K % 4)) return SAR_EINVAL;
-        if ((q.lda & 3) || (q.ldb & 3) || (reinterpret_cast<uintptr_t>(q.X) & 15) || (reinterpret_cast<uintptr_t>(q.dY) & 15)) return SAR_EINVAL;
+        if (!q.X || !q.dY || !q.dW || M < 64 || N < 64 || K < 64 || q.splitk < 1 || (K + 63) / 64 < q.splitk) return SAR_EINVAL;
+        if (((M | N | K | q.lda | q.ldb) & 3) || ((reinterpret_cast<uintptr_t>(q.X) | reinterpret_cast<uintptr_t>(q.dY)) & 15)) return SAR_EINVAL;
         WgRow r;
         r.X = q.X; r.dY = q.dY; r.dW = q.dW; r.db = q.db; r.M = M; r.N = N; r.K = K; r.lda = q.lda; r.ldb = q.ldb; r.ldc = q.ldc;
         r.splitk = q.splitk; r.first_block = (int)blk;
         rows[i] = r;
-        blk += ((long)((N + 63) / 64) * (M / 64) * q.splitk + 7) & ~7L;   // every problem starts on XCD 0 (xcd_order); <= 7 idle blocks each
+        blk += ((long)((N + 63) / 64) * ((M + 63) / 64) * q.splitk + 7) & ~7L;   // every problem starts on XCD 0 (xcd_order); <= 7 idle blocks each
         if (blk > (1L << 30)) return SAR_EINVAL;
     }
     *total_blocks = (int)blk;

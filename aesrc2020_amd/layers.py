@@ -77,7 +77,7 @@ class Dense(Layer):
 
     def backward(self, dy, need_dx=True, accumulate_dx=False, dx_out=None, dz_ready=False):
         R = self.R
-        defer = self.store.deferring_wgrads() and self.in_dim % 64 == 0 and self.units >= 64 and R >= 64 and self.units % 4 == 0 and R % 4 == 0
+        defer = self.store.deferring_wgrads() and self.in_dim >= 64 and self.units >= 64 and R >= 64 and (self.in_dim | self.units | R) % 4 == 0
         # a deferred weight gradient reads dz when the group is launched: the layer's own buffer then, not the shared scratch
         dzbuf = (lambda: self.buf("dz", (R, self.units))) if defer else (lambda: self.scratch("dz%dx%d" % (R, self.units), (R, self.units)))
         if dz_ready:                                               # the caller (LayerNorm.backward(act=...)) already applied act'

@@ -72,7 +72,8 @@ def test_gemm_wgrad_with_fused_bias_gradient(L, R, I, N, sk):
 
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0), (0, 1)])
 @pytest.mark.parametrize("M,N,K,sk", [(64, 64, 64, 1), (2496, 768, 256, 1), (256, 768, 2496, 3), (128, 192, 8192, 1),
-                                      (2496, 1000, 256, 1), (256, 1000, 2496, 3), (2496, 256, 1000, 1), (128, 100, 68, 1)])   # last four: N / K tails (bpe-1k layer)
+                                      (2496, 1000, 256, 1), (256, 1000, 2496, 3), (2496, 256, 1000, 1), (128, 100, 68, 1),    # N / K tails (bpe-1k layer)
+                                      (6048, 256, 512, 1), (104, 256, 256, 1), (6048, 1000, 512, 1)])   # M tails (cfg5's 6 048 rows)
 def test_gemm_bf16_math(L, a_kc, b_kc, M, N, K, sk):
     """sar_set_gemm_math(1): operands rounded to bf16 in the staging, bf16 MFMA, fp32 accumulate -- against float64 on the
     rounded operands (tight) for all four layouts, bias + tanh, accumulate, split-K and the fused column sum."""
@@ -107,7 +108,7 @@ def test_gemm_wgrad_group(L):
     rng = np.random.default_rng(17)
     bf = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()
     shapes = [(2496, 768, 256, 1, True), (2496, 256, 768, 3, True), (2496, 256, 768, 3, True), (64, 8192, 256, 1, True), (2496, 512, 256, 2, False),
-              (2496, 256, 1000, 2, True), (312, 128, 100, 1, True)]          # (R, in, out, splitk, bias gradient)
+              (2496, 256, 1000, 2, True), (312, 128, 100, 1, True), (6048, 256, 768, 3, True)]   # (R, in, out, splitk, bias gradient)
     old = L.get_gemm_math()
     L.set_gemm_math("bf16")
     try:
@@ -125,8 +126,8 @@ def test_gemm_wgrad_group(L):
             check(q[2], rw, 2e-5, "grouped dW %r" % (sh,))
             if q[3] is not None:
                 check(q[3], rb, 2e-5, "grouped db %r" % (sh,))
-        with pytest.raises(ValueError):                                      # in_dim not a multiple of 64
-            L.GemmWgradGroup([(zeros(128, 33), zeros(128, 64), zeros(33, 64), None, 33, 64, 128, 33, 64, 64, 1)])
+        with pytest.raises(ValueError):                                      # a 34-column layer (rows are not 16-byte pieces)
+            L.GemmWgradGroup([(zeros(128, 64), zeros(128, 34), zeros(64, 34), None, 64, 34, 128, 64, 34, 34, 1)])
         L.set_gemm_math("fp32")
         with pytest.raises(ValueError):                                      # fp32 GEMM mode: no grouped launch
             L.GemmWgradGroup(probs[:1])
