@@ -376,10 +376,14 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     for (int i = tid; i < KP * DP1; i += 256) dres[i] = 0.f;
     // The prologue loops are chains of memory round trips (a workgroup per utterance: nothing else hides them), so they are
     // unrolled to keep independent loads in flight (as plain loops: 82 us for the kernel, unrolled 71 us)
-    for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments
+    // One workgroup per (utterance, chunk of VB_LC frames): everything behind dres -- dA, the softmax backward, dfeat -- is private to a
+    // frame, and the centre gradient is linear in the column sums of A, so each chunk adds the share of ITS frames.  (One workgroup per
+    // utterance looped over the chunks: 32 workgroups x 6 chunks in cfg5, 258 us; the dres prologue is repeated per chunk instead.)
+    const int l_first = blockIdx.y * VB_LC, l_end = min(L, l_first + VB_LC);
+    for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments, this chunk's frames
         float t = 0.f;
-#pragma unroll 13
-        for (int l = 0; l < L; ++l) t += Ab[(long)l * KG + k];
+#pragma unroll 8
+        for (int l = l_first; l < l_end; ++l) t += Ab[(long)l * KG + k];
         asum[k] = t;
     }
     for (int k = wave; k < K; k += 4) {                              // n . dO per cluster (wave per cluster)
@@ -405,8 +409,8 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
         if (lane == 0) cd[k] = t;
     }
     const int i31 = lane & 31, kk = lane >> 5;
-    for (int l0 = 0; l0 < L; l0 += VB_LC) {
-        const int rows = min(VB_LC, L - l0);
+    {
+        const int l0 = l_first, rows = l_end - l_first;
         __syncthreads();                                             // dres complete / previous chunk consumed
         stage_rows(X_c, DP1, x + (long)l0 * D, D, rows, VB_LC, tid);
         for (int i = tid; i < VB_LC * KGP1; i += 256) {
@@ -517,7 +521,7 @@ extern "C" int sar_vlad_bwd_f32(const float* dout, const float* feat, const floa
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(vlad_bwd_mfma_kernel, dim3(B), dim3(256), ldsm, stream, dout, feat, A, centers, out, inv, dfeat, dscore, dcenters, L, D, K, KG, accumulate_dfeat);
+        hipLaunchKernelGGL(vlad_bwd_mfma_kernel, dim3(B, (L + VB_LC - 1) / VB_LC), dim3(256), ldsm, stream, dout, feat, A, centers, out, inv, dfeat, dscore, dcenters, L, D, K, KG, accumulate_dfeat);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
