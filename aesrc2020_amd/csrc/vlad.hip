@@ -386,27 +386,48 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
         for (int l = l_first; l < l_end; ++l) t += Ab[(long)l * KG + k];
         asum[k] = t;
     }
-    for (int k = wave; k < K; k += 4) {                              // n . dO per cluster (wave per cluster)
-        float t = 0.f;
-#pragma unroll 4
-        for (int d = lane; d < D; d += 64) t = fmaf(n[(long)k * D + d], dO[(long)k * D + d], t);
-        t = wave_sum(t);
-        if (lane == 0) dot[k] = t;
-    }
-    __syncthreads();
-    for (int k = wave; k < K; k += 4) {                              // l2-normalise backward; dcenters; dres . c
-        const float iv = inv[(long)b * K + k];
-        const float aiv = fabsf(iv), dt = iv > 0.f ? dot[k] : 0.f;
-        float t = 0.f;
-#pragma unroll 4
-        for (int d = lane; d < D; d += 64) {
-            const float g = (dO[(long)k * D + d] - n[(long)k * D + d] * dt) * aiv;
-            dres[k * DP1 + d] = g;
-            t = fmaf(g, centers[(long)k * D + d], t);
-            atomicAdd(dcenters + (long)k * D + d, -asum[k] * g);
+    __syncthreads();                                                 // asum complete, dres zeroed
+    // l2-normalise backward; dcenters; dres . c -- a wave takes its clusters four at a time with every load of the four (n, dO, centres,
+    // inv: 13 per lane and cluster) in flight at once, and keeps n . dO in registers (one pass, no barrier in between).  Cluster by
+    // cluster this was 2 x K/4 dependent round trips in front of the MFMA work: ~40 of the kernel's 48 us.
+    for (int k0 = wave; k0 < K; k0 += 16) {
+        float nv[4][4], dv[4][4], cv[4][4], ivv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k0 + 4 * j;
+            const bool kv = kk < K;
+            ivv[j] = kv ? inv[(long)b * K + kk] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = lane + 64 * i;
+                const bool ok = kv && d < D;
+                const long o = ok ? (long)kk * D + d : 0;
+                nv[j][i] = ok ? n[o] : 0.f; dv[j][i] = ok ? dO[o] : 0.f; cv[j][i] = ok ? centers[o] : 0.f;
+            }
         }
-        t = wave_sum(t);
-        if (lane == 0) cd[k] = t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k0 + 4 * j;
+            if (kk >= K) break;                                      // wave-uniform
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t = fmaf(nv[j][i], dv[j][i], t);
+            t = wave_sum(t);
+            const float aiv = fabsf(ivv[j]), dt = ivv[j] > 0.f ? t : 0.f, as = asum[kk];
+            float u = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = lane + 64 * i;
+                if (d < D) {
+                    const float g = (dv[j][i] - nv[j][i] * dt) * aiv;
+                    dres[kk * DP1 + d] = g;
+                    u = fmaf(g, cv[j][i], u);
+                    atomicAdd(dcenters + (long)kk * D + d, -as * g);
+                }
+            }
+            u = wave_sum(u);
+            if (lane == 0) cd[kk] = u;
+        }
     }
     const int i31 = lane & 31, kk = lane >> 5;
     {
