@@ -13,6 +13,15 @@ constexpr float CTC_EPS = 1e-7f;
 constexpr int CTC_SMAX = 512;      // 2*max_label_len+1 (reference: 2*72+1 = 145)
 constexpr size_t CTC_LDS_CAP = 56 * 1024;   // dynamic LDS for the e / alpha staging (with the static arrays: < 64 KB, no attribute needed)
 
+// log(exp(a) + exp(b)) for the recursions: m + log(1 + exp(-|a - b|)) on v_exp_f32 / v_log_f32 (one of each; ~1e-7 relative in the
+// probability domain).  common.h's lse2 is two libm expf and a logf, ~120 instructions -- with up to two of them per state and frame
+// that arithmetic, not memory, was the recursion's 1.1 us per frame.
+__device__ __forceinline__ float lse2f(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(1.f + __expf(-fabsf(a - b)));
+}
+
 __device__ __forceinline__ int ext_label(const float* lab, int s, int blank) {
     return (s & 1) ? (int)lab[s >> 1] : blank;
 }
@@ -91,8 +100,8 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
         for (int s_ = tid; s_ < S; s_ += 256) {
             const int k = xl[s_];
             float a = al[prv][s_];
-            if (s_ >= 1) a = lse2(a, al[prv][s_ - 1]);
-            if (s_ >= 2 && k != blank && k != xl[s_ - 2]) a = lse2(a, al[prv][s_ - 2]);
+            if (s_ >= 1) a = lse2f(a, al[prv][s_ - 1]);
+            if (s_ >= 2 && k != blank && k != xl[s_ - 2]) a = lse2f(a, al[prv][s_ - 2]);
             a += LDS_E ? e_s[t * Smax + s_] : ew[(long)t * Smax + s_];
             al[cur][s_] = a; aw[(long)t * Smax + s_] = a;
         }
@@ -181,15 +190,15 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
                 const int k0 = xl[s_];
                 const float e0 = LDS_E ? e_s[(t + 1) * Smax + s_] : ew[(long)(t + 1) * Smax + s_];
                 bb = be[nxt][s_] + e0;
-                if (s_ + 1 < S) bb = lse2(bb, be[nxt][s_ + 1] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 1] : ew[(long)(t + 1) * Smax + s_ + 1]));
+                if (s_ + 1 < S) bb = lse2f(bb, be[nxt][s_ + 1] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 1] : ew[(long)(t + 1) * Smax + s_ + 1]));
                 if (s_ + 2 < S) {
                     const int k2 = xl[s_ + 2];
-                    if (k2 != blank && k2 != k0) bb = lse2(bb, be[nxt][s_ + 2] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 2] : ew[(long)(t + 1) * Smax + s_ + 2]));
+                    if (k2 != blank && k2 != k0) bb = lse2f(bb, be[nxt][s_ + 2] + (LDS_E ? e_s[(t + 1) * Smax + s_ + 2] : ew[(long)(t + 1) * Smax + s_ + 2]));
                 }
             }
             be[cur][s_] = bb;
             const float c = LDS_E ? c_s[t * Smax + s_] : (aw[(long)t * Smax + s_] - ew[(long)t * Smax + s_] - ld[t] - ll);
-            const float w = expf(c + bb);
+            const float w = __expf(c + bb);
             if (w > 0.f) atomicAdd(&dp[(long)t * V + xl[s_]], -g * w);
         }
         lds_barrier();                                                // be[][] only; the atomics stay in flight

@@ -585,6 +585,22 @@ class SARNetModel:
             logs[k + "_acc"] = float((self.out[k].argmax(1) == tgt.argmax(1)).float().mean().item())
         return logs
 
+    def _logs_device_names(self):
+        return ["loss"] + [k + "_loss" for k in self.output_names] + [k + "_acc" for k in self.output_names if k != "y_ctc_loss"]
+
+    def _logs_device(self):
+        """The scalars of _logs() as ONE device vector (order: _logs_device_names()), no host sync: what fit_generator accumulates."""
+        per = [self.loss_vec[k].mean() for k in self.output_names]
+        total = self.store.l2_loss.reshape(()) + sum(self.loss_weights[k] * v for k, v in zip(self.output_names, per))
+        accs = []
+        for k in self.output_names:
+            if k == "y_ctc_loss":
+                continue
+            tgt = {"y_accent": self.in_y_accent, "y_disc": getattr(self, "in_y_disc", None),
+                   "y_disc_bn": getattr(self, "in_y_disc_bn", None)}[k]
+            accs.append((self.out[k].argmax(1) == tgt.argmax(1)).float().mean())
+        return torch.stack([total] + per + accs)
+
     def forward_backward_only(self, x, y=None):
         """For tests: forward + losses + backward without the optimizer update; grads stay in store.grads."""
         self._upload(x, y)
@@ -667,15 +683,19 @@ class SARNetModel:
         history = []
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
-            agg = {}
+            # Keras reports the running mean over EVERY batch of the epoch (CSVLogger / ReduceLROnPlateau / EarlyStopping read it):
+            # the per-step scalars are added up on the device (a few tiny launches behind the step's graph, no host sync) and read
+            # back once per epoch; `log_every` only paces the optional progress print
+            acc = None
             for step in range(steps_per_epoch):
                 x, y = next(generator)
-                want = (step % log_every == 0) or step == steps_per_epoch - 1
-                logs = self.train_on_batch(x, y, sync=want)
-                if logs:
-                    for k, v in logs.items():
-                        agg.setdefault(k, []).append(v)
-            logs = {k: float(np.mean(v)) for k, v in agg.items()}
+                self.train_on_batch(x, y, sync=False)
+                vec = self._logs_device()
+                acc = vec.clone() if acc is None else acc.add_(vec)
+                if verbose > 1 and (step % log_every == 0):
+                    print("  step %d/%d loss %.4f" % (step + 1, steps_per_epoch, float(vec[0].item())))
+            mean = (acc / steps_per_epoch).cpu().numpy()
+            logs = {k: float(v) for k, v in zip(self._logs_device_names(), mean)}
             if validation_data is not None:
                 vl = self.evaluate(validation_data[0], validation_data[1])
                 logs.update({"val_" + k: v for k, v in vl.items()})
