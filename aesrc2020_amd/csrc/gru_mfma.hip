@@ -340,8 +340,10 @@ __global__ __launch_bounds__(512) void gru_mfma_fwd4_kernel(const float* __restr
             h[u] = row_ok ? hn : 0.f;
             if (row_ok) {
                 const long bt = (long)b * L + t;
-                float* go = g_d + bt * 4 * GH + j0 + 16 * u;
-                go[0] = z; go[GH] = rr; go[2 * GH] = hh; go[3 * GH] = q;
+                // the saved gates of the four-row kernels are unit-major, (.., H, 4): one 16-byte store (BPTT: one load) per lane and
+                // tile instead of four -- the vector memory pipe takes ~70 cycles per instruction here, eight waves share it, and a step
+                // has little else to hide behind (BPTT without its 12 loads, or without its 12 stores: 1.6 us per step instead of 2.3)
+                *reinterpret_cast<f32x4*>(g_d + (bt * GH + j0 + 16 * u) * 4) = f32x4{z, rr, hh, q};
                 hp_d[bt * GH + j0 + 16 * u] = ho;
                 out[bt * 2 * GH + d * GH + j0 + 16 * u] = hn;
             }
@@ -387,8 +389,8 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd4_kernel(const float* __restr
         const long bt = (long)bc * L + t;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const float* go = g_d + bt * 4 * GH + j0 + 16 * u;
-            v[u].z = go[0]; v[u].rr = go[GH]; v[u].hh = go[2 * GH]; v[u].q = go[3 * GH];
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(g_d + (bt * GH + j0 + 16 * u) * 4);   // unit-major gates: see the forward kernel
+            v[u].z = gq[0]; v[u].rr = gq[1]; v[u].hh = gq[2]; v[u].q = gq[3];
             v[u].hp = hp_d[bt * GH + j0 + 16 * u];
             v[u].dy = row_ok ? dout[bt * 2 * GH + d * GH + j0 + 16 * u] : 0.f;   // the only one that must be zero for a dead row: g = dh + dy
         }

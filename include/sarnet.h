@@ -285,7 +285,8 @@ int sar_bigru_bwd_f32(const float* dout, const float* gates, const float* hprev,
  * bf16 and packed once per optimiser step (pack: 2 directions x 2 orientations x 3H x H bf16 = 1.5 MB), then stay on chip for all
  * L steps -- registers + LDS of 16-row workgroups, v_mfma_f32_16x16x32_bf16 -- instead of streaming from L2 every step.  State,
  * gates, saved tensors and accumulation are fp32; same tensors and layouts as sar_bigru_fwd_f32 / sar_bigru_bwd_f32 (no
- * transposed kernels needed).  H must be 256. */
+ * transposed kernels needed), except that `gates` (2*B*L*4*H floats) is opaque: what sar_bigru_fwd_bf16 wrote is for
+ * sar_bigru_bwd_bf16 of the same B (the four-row kernels of B <= 512 keep it unit-major).  H must be 256. */
 int sar_bigru_pack_bf16(const float* U_fwd, const float* U_bwd, void* pack, int H, sarStream_t stream);
 int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, const void* pack, const float* bh_fwd, const float* bh_bwd,
                        float* out, float* gates, float* hprev, int B, int L, int H, sarStream_t stream);
