@@ -554,6 +554,35 @@ class SARNetModel:
             segs.append(("adam", self.store.adam_step, None))
             self._run_segments(segs)
             return
+        if os.environ.get("SAR_DP_SEGMENTS", "3") == "2":
+            # TWO graphs, no overlap: [the whole forward + backward] -> one all-reduce of the flat buffer, waited for -> [L2 + Adam]
+            def after_all():
+                works.extend(self.dp.allreduce_range(0, self.store.n, async_op=True))
+                [w.wait() for w in works]
+            self._run_segments([("fwd_bwd", (lambda: self._device_step(update=False)), after_all), ("adam", self.store.adam_step, None)])
+            return
+        if os.environ.get("SAR_DP_SEGMENTS", "3") == "3" and nparts == 3:
+            # THREE graphs: [forward + heads / GRU backward + trunk backward down to stage 2] -> [stages 1-0 + stem] -> [L2 + Adam].  The
+            # first all-reduce covers the tail, stage-3 and stage-2 buckets -- one contiguous 33.6 MB range of the 35 MB at F=32 -- and
+            # runs underneath the second graph (~0.6 ms of backward); only the last 1.5 MB is exposed.  The five-graph form above it
+            # (SAR_DP_SEGMENTS=5: one all-reduce per backward part) starts the collectives earlier but pays for it at every N: four host
+            # gaps and the weight gradients batched per part -- 0.30 ms on a 2.14 ms step (forced one-rank run), this form 0.1x.
+            def seg_a():
+                self._seg_heads()
+                self._seg_trunk("01")
+            def after_a():
+                lo, hi = self.dp.bounds[2][0], self.dp.bounds[0][1]
+                if hi > lo and all(self.dp.bounds[i][0] == self.dp.bounds[i + 1][1] for i in (0, 1)):
+                    works.extend(self.dp.allreduce_range(lo, hi, async_op=True))
+                else:
+                    for i in (0, 1, 2):
+                        works.extend(self.dp.allreduce_bucket(i, async_op=True))
+            def after_b():
+                works.extend(self.dp.allreduce_bucket(3, async_op=True))
+                [w.wait() for w in works]
+            self._run_segments([("heads_s32", seg_a, after_a), ("trunk_s10", (lambda: self._seg_trunk(2)), after_b),
+                                ("adam", self.store.adam_step, None)])
+            return
         segs = [("heads", self._seg_heads, ar(0))]
         for part in range(nparts):
             last = part == nparts - 1

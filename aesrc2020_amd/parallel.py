@@ -156,3 +156,14 @@ class DataParallel:
                 w.wait()
             return [w] if async_op else []
         return [w for w in allreduce_flat(self.store.grads, [self.bounds[i]], async_op=async_op) if w is not None]
+
+    def allreduce_range(self, lo, hi, async_op=True):
+        """Sum-all-reduce of grads[lo:hi] (several adjacent buckets as one collective); same stream semantics as allreduce_bucket."""
+        if not self.enabled or hi <= lo:
+            return []
+        if self.cabi is not None:
+            w = self.cabi.allreduce(self.store.grads[lo:hi])
+            if not async_op:
+                w.wait()
+            return [w] if async_op else []
+        return [w for w in allreduce_flat(self.store.grads, [(lo, hi)], async_op=async_op) if w is not None]

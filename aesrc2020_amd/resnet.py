@@ -319,7 +319,7 @@ class ResNetTrunk(Layer):
 
     def _backward16(self, dy, part):
         B = self.B
-        if part in (None, 0):
+        if part in (None, 0, "01"):
             H, W = self.out_hw
             fb = self.final_bn
             R = B * H * W
@@ -328,7 +328,7 @@ class ResNetTrunk(Layer):
             _call("sar_bn_bwd_apply_bf16", dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1)
         else:
             g = self._g_part
-        stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
+        stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0), "01": (3, 2)}[part]
         bf = torch.bfloat16
         self._wg16 = []
         overlap = part is None and self.WGRAD_OVERLAP
@@ -337,7 +337,7 @@ class ResNetTrunk(Layer):
         # `pend`: the gradient the block behind handed over, not materialised yet -- (da1, x, shortcut gradient, bn1 of that block):
         # g = bn1_bwd(da1, x) + dsc is formed in the fill of THIS block's conv2 input-gradient launch (fill 3) and written back to
         # `g` for the gradient's other consumers (weight gradients, the shortcut path), instead of by a BatchNorm-apply launch
-        pend = self._pend16 if part not in (None, 0) else None
+        pend = self._pend16 if part not in (None, 0, "01") else None
         tap = getattr(self, "debug_tap", None)
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
@@ -391,11 +391,11 @@ class ResNetTrunk(Layer):
                 self._wgrad16(("stage", blk["stage"]), side=True)
                 self._wg16 = []
         self._pend16 = pend
-        assert pend is None or part in (0, 1), "the first block's conv1 takes the pooled tensor directly (resnet.py:111-117)"
+        assert pend is None or part in (0, 1, "01"), "the first block's conv1 takes the pooled tensor directly (resnet.py:111-117)"
         self._g_part = g
         if not overlap:
             self._wgrad16(part)
-        if part in (0, 1):
+        if part in (0, 1, "01"):
             return None
         self._stem_backward16(g, B)
         if overlap:
@@ -561,17 +561,17 @@ class ResNetTrunk(Layer):
         return names
 
     def backward(self, dy, part=None):
-        """part None: the whole backward; 0/1/2: one part (see above), dy only read by part 0."""
+        """part None: the whole backward; 0/1/2: one part (see above), "01": parts 0 and 1 in one call; dy only read by part 0 / "01"."""
         if self.bf16:
             return self._backward16(dy, part)
         B = self.B
-        if part in (None, 0):
+        if part in (None, 0, "01"):
             H, W = self.out_hw
             g = self.scratch("res_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c))
             self.final_bn.bwd(dy, self.pre_final, None, g, B * H * W, relu=1)
         else:
             g = self._g_part
-        stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0)}[part]
+        stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0), "01": (3, 2)}[part]
         for n in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[n]
             if blk["stage"] not in stages:
@@ -607,7 +607,7 @@ class ResNetTrunk(Layer):
                     _call("sar_axpy_f32", g, gin, 1.0, gin.numel())
             g = gin
         self._g_part = g
-        if part in (0, 1):
+        if part in (0, 1, "01"):
             return None
         self._stem_backward(g, B)
         return None

@@ -21,9 +21,12 @@ GLOBAL_B = 6
 STEPS = 3
 
 
-def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32"):
+GRAPHS = {"3": ["adam", "heads_s32", "trunk_s10"], "5": ["adam", "heads", "trunk0", "trunk1", "trunk2"]}   # SAR_DP_SEGMENTS -> captured graphs
+
+
+def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", segments="3"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), SAR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(rank), SAR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", SAR_DP_SEGMENTS=segments)
     sys.path.insert(0, ROOT)
     import contextlib, io
     from aesrc2020_amd import parallel
@@ -54,10 +57,12 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32"):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend,via_gpus,mode", [("gloo", False, "fp32"), ("gloo", True, "fp32"), ("nccl", True, "fp32"), ("gloo", True, "bf16"),
-                                                   ("nccl", True, "bf16")],
-                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16-mode", "rccl-bf16-mode"])
-def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode):
+@pytest.mark.parametrize("backend,via_gpus,mode,segments", [("gloo", False, "fp32", "3"), ("gloo", True, "fp32", "3"), ("nccl", True, "fp32", "3"),
+                                                            ("gloo", True, "bf16", "3"), ("nccl", True, "bf16", "3"), ("gloo", True, "fp32", "5"),
+                                                            ("gloo", True, "bf16", "5")],
+                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16-mode", "rccl-bf16-mode",
+                              "gloo-five-graphs", "gloo-bf16-five-graphs"])
+def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, segments):
     import torch.multiprocessing as mp
     from aesrc2020_amd import parallel
     from aesrc2020_amd.model import SAR_Net
@@ -65,13 +70,13 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode):
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus) + 3 * len(mode)) % 2000
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus, mode)) for r in range(2)]
+    q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus) + 3 * len(mode) + 13 * int(segments)) % 2000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus, mode, segments)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
     (_, r0, g0), (_, r1, g1) = res
-    assert g0 == ["adam", "heads", "trunk0", "trunk1", "trunk2"] and g1 == g0      # steps 2.. ran from the five captured graphs
+    assert g0 == GRAPHS[segments] and g1 == g0                 # steps 2.. ran from the captured graphs of the chosen form
     from aesrc2020_amd import _lib
     kw = KW16 if mode == "bf16" else KW
     # bf16 mode: the shard runs of the reference see other atomic orders in the statistic bins -- agreement to bf16 noise
@@ -106,11 +111,11 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode):
     _lib.set_gemm_math("fp32")
 
 
-def _worker_one_rank(port, q, mode, collective="torch"):
+def _worker_one_rank(port, q, mode, collective="torch", segments="3"):
     """One rank, backend nccl (= RCCL), SAR_DP_FORCE=1: the five-graph step with its bucketed asynchronous all-reduces on a real RCCL
     communicator -- what a 1-GPU box can run of the multi-GPU path."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", SAR_DIST_BACKEND="nccl",
-                      SAR_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAR_DP_COLLECTIVE=collective)
+                      SAR_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAR_DP_COLLECTIVE=collective, SAR_DP_SEGMENTS=segments)
     sys.path.insert(0, ROOT)
     import contextlib, io
     from aesrc2020_amd import parallel, _lib
@@ -143,9 +148,11 @@ def _worker_one_rank(port, q, mode, collective="torch"):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,collective", [("fp32", "torch"), ("bf16", "torch"), ("bf16", "cabi")],
-                         ids=["fp32-torch.distributed", "bf16-torch.distributed", "bf16-sar_allreduce_bucket"])
-def test_rccl_one_rank_five_graph_step(mode, collective):
+@pytest.mark.parametrize("mode,collective,segments", [("fp32", "torch", "3"), ("bf16", "torch", "3"), ("bf16", "cabi", "3"), ("bf16", "torch", "5"),
+                                                      ("bf16", "cabi", "5")],
+                         ids=["fp32-torch.distributed", "bf16-torch.distributed", "bf16-sar_allreduce_bucket", "bf16-five-graphs",
+                              "bf16-five-graphs-sar_allreduce_bucket"])
+def test_rccl_one_rank_segmented_step(mode, collective, segments):
     """RCCL itself on this box: a process group of one rank over backend nccl, the data-parallel step forced on (SAR_DP_FORCE=1).
     Communicator set-up, the all-reduces on RCCL's stream between replays of the five captured graphs and the stream-ordered
     work.wait() all execute; a one-rank reduction is the identity, so parameters and losses must follow the single-graph step."""
@@ -154,12 +161,12 @@ def test_rccl_one_rank_five_graph_step(mode, collective):
     from aesrc2020_amd.model import SAR_Net
     from oracle import model_torch as MT
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 33000 + (os.getpid() + 11 * len(mode) + 5 * len(collective)) % 2000
-    p = ctx.Process(target=_worker_one_rank, args=(port, q, mode, collective))
+    q = ctx.Queue(); port = 33000 + (os.getpid() + 11 * len(mode) + 5 * len(collective) + 17 * int(segments)) % 2000
+    p = ctx.Process(target=_worker_one_rank, args=(port, q, mode, collective, segments))
     p.start()
     out, graphs = q.get(timeout=600)
     p.join(120)
-    assert graphs == ["adam", "heads", "trunk0", "trunk1", "trunk2"]
+    assert graphs == GRAPHS[segments]
     kw = KW16 if mode == "bf16" else KW
     if mode == "bf16":
         _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
