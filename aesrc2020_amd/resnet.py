@@ -405,7 +405,10 @@ class ResNetTrunk(Layer):
     # launch classes of the batched weight gradient: (kernel size, stride or None, 64-wide channel tiles) -> blocks the planner
     # aims for.  3x3 stride 1 with Cin, Cout >= 64 (stages 1-3): 64 x 64 tiles, one 9-wave block per CU; the 32-channel layers:
     # 32 x 32 tiles, three blocks per CU; stride-2 convs need a 4x larger patch ring, so they get their own launch.
-    WGRAD_CLASSES = (((3, 1, True), int(os.environ.get("SAR_WG_T64", 640))), ((3, 1, False), int(os.environ.get("SAR_WG_T32", 768))),
+    # (targets re-measured at v36 with the flush known to be 40 % of the 64-wide launch -- every item ends in 147 KB of fp32 atomics,
+    # tools/conv_variants.py phase removal: 156 us with, 94 without --: 256 / 320 / 384 / 512 / 640 / 896 items = 163 / 135 / 139 / 166 /
+    # 156 / 178 us; 32-wide class 256 / 384 / 512 / 768 / 1024 = 133 / 132 / 116 / 123 / 129 us)
+    WGRAD_CLASSES = (((3, 1, True), int(os.environ.get("SAR_WG_T64", 320))), ((3, 1, False), int(os.environ.get("SAR_WG_T32", 512))),
                      ((3, 2, False), 512), ((1, None, False), 256))
 
     @staticmethod
