@@ -1073,7 +1073,8 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
         total += (long)tmp.nchunks * (convs[i].Cin / (32 * tile_ci)) * (convs[i].Cout / (32 * tile_co));
     }
     int maxc = (int)((total + target_blocks - 1) / target_blocks);
-    const int minc = K == 3 ? 8 : 2 * WG_NW1;
+    static const int minc3 = getenv("SAR_WG_MINC") ? atoi(getenv("SAR_WG_MINC")) : 16;   // chunks per item at least: an item ends in its tiles' atomics (8 / 16 / 24 / 32 / 48: 2.327 / 2.307 / 2.317 / 2.331 / 2.365 ms, forced one-rank three-graph step)
+    const int minc = K == 3 ? minc3 : 2 * WG_NW1;
     if (maxc < minc) maxc = minc;
     WgItem* items = static_cast<WgItem*>(items_out);
     int ni = 0, tab_pos = 0;
