@@ -296,7 +296,7 @@ class SARNetModel:
                       (self.in_ctc_out_len, dev["x_ctc_out_len"])]
         # ONE launch for all of them (a table of {destination, source, words}, cached per set of source buffers) when every pair is a
         # plain byte copy; anything else (dtype conversion, strided or unaligned source) goes through torch's copy
-        key = tuple(s.data_ptr() for _, s in pairs)
+        key = tuple((s.data_ptr(), s.dtype, s.numel(), s.is_contiguous()) for _, s in pairs)
         tab = self._copy_tables.get(key) if getattr(self, "_copy_tables_for", None) == (B, T) else None
         if tab is None:
             plain = all(s.is_cuda and s.dtype == d.dtype and s.is_contiguous() and s.numel() == d.numel() and s.data_ptr() % 16 == 0
