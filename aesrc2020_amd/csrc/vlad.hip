@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
                 float m = -INFINITY;
                 for (int k = 0; k < KG; ++k) m = fmaxf(m, srow[k]);
                 float sum = 0.f;
-                for (int k = 0; k < KG; ++k) { const float e = expf(srow[k] - m); srow[k] = e; sum += e; }
+                for (int k = 0; k < KG; ++k) { const float e = __expf(srow[k] - m); srow[k] = e; sum += e; }   // v_exp_f32 form: one thread walks a row
                 const float inv = 1.f / sum;
                 for (int k = 0; k < KG; ++k) srow[k] *= inv;
                 for (int k = KG; k < KGP; ++k) srow[k] = 0.f;
@@ -292,7 +292,12 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
         }
         __syncthreads();
         for (int i = tid; i < rows * KG; i += 256) { const int r = i / KG, k = i - r * KG; Ao[(long)(l0 + r) * KG + k] = A_c[r * KGP + k]; }
-        if (tid < KG) { float t = 0.f; for (int r = 0; r < rows; ++r) t += A_c[r * KGP + tid]; asum[tid] += t; }
+        for (int i = tid; i < 4 * KG; i += 256) {                    // column sums: four row groups per column, LDS atomics (was one thread
+            const int kc = i >> 2, rg = i & 3;                       // per column walking all rows)
+            float t = 0.f;
+            for (int r = rg; r < rows; r += 4) t += A_c[r * KGP + kc];
+            atomicAdd(&asum[kc], t);
+        }
         const int i31 = lane & 31, kk = lane >> 5;
         for (int r0 = 0; r0 < VF_LC; r0 += 2) {
             if (r0 >= rows) break;                                    // block-uniform; further rows are zero
@@ -324,8 +329,10 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
                 if ((wave + 4 * a) < Dt && d < D && k < K) v = acc[a][c][r] - asum[k] * centers[(long)k * D + d];
                 acc[a][c][r] = v; sq = fmaf(v, v, sq);
             }
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            // sum over the 32 lanes of a half-wave: four DPP steps give every lane its 16-lane row's sum, one cross-row exchange the rest
+            // (five ds_bpermute round trips per value before, 160 per thread)
+            sq += SAR_DPP_F(sq, 0xB1); sq += SAR_DPP_F(sq, 0x4E); sq += SAR_DPP_F(sq, 0x141); sq += SAR_DPP_F(sq, 0x140);
+            sq += __shfl_xor(sq, 16, 64);
             if ((lane & 31) == 0 && k < K) atomicAdd(&ss[k], sq);
         }
     }
