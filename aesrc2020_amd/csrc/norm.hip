@@ -6,6 +6,7 @@
 //  * BatchNormalization on 2-D (B, C) inputs (model.py:286,289): thread-per-channel
 //  * LayerNormalization (keras_layer_normalization, eps = 1e-14, model.py:32-33): wave-per-row
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -521,7 +522,8 @@ extern "C" int sar_layernorm_bwd_f32(const float* dy, const float* x, const floa
                                      const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                                      int accumulate, hipStream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
-    const int nb = (int)((R + 3) / 4 < 256 ? (R + 3) / 4 : 256);
+    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
+    const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, ACT_NONE);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -535,7 +537,8 @@ extern "C" int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const 
                                          int accumulate, int act, hipStream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
-    const int nb = (int)((R + 3) / 4 < 256 ? (R + 3) / 4 : 256);
+    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
+    const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
