@@ -387,10 +387,16 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     // frame, and the centre gradient is linear in the column sums of A, so each chunk adds the share of ITS frames.  (One workgroup per
     // utterance looped over the chunks: 32 workgroups x 6 chunks in cfg5, 258 us; the dres prologue is repeated per chunk instead.)
     const int l_first = blockIdx.y * VB_LC, l_end = min(L, l_first + VB_LC);
-    for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments, this chunk's frames
+    // the centre gradient -asum[k] * dres[k][d] is the same dres for every chunk of the utterance: chunk 0 adds it once with the column
+    // sums over ALL frames (128 workgroups adding into the same 8 192 addresses were half of this kernel: device-scope atomics on one
+    // address serialise)
+    const bool centres = blockIdx.y == 0;
+    for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments (chunk 0 only)
         float t = 0.f;
-#pragma unroll 8
-        for (int l = l_first; l < l_end; ++l) t += Ab[(long)l * KG + k];
+        if (centres) {
+#pragma unroll 13
+            for (int l = 0; l < L; ++l) t += Ab[(long)l * KG + k];
+        }
         asum[k] = t;
     }
     __syncthreads();                                                 // asum complete, dres zeroed
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
                     const float g = (dv[j][i] - nv[j][i] * dt) * aiv;
                     dres[kk * DP1 + d] = g;
                     u = fmaf(g, cv[j][i], u);
-                    atomicAdd(dcenters + (long)kk * D + d, -as * g);
+                    if (centres) atomicAdd(dcenters + (long)kk * D + d, -as * g);
                 }
             }
             u = wave_sum(u);
