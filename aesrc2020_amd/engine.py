@@ -299,6 +299,8 @@ def gemm(A, B, C, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=0, accumulate=0,
 
 def pick_splitk(M, N, K):
     tiles = -(-M // 64) * -(-N // 64)
-    if tiles >= 128 or K < 512:
+    if tiles >= 128 or K < 256:
         return 1
-    return int(max(1, min(32, 256 // tiles, K // 256)))
+    if K < 512:                                                    # a skinny output (the 34-column assignment layer: 39 tiles on 256 CUs)
+        return int(max(1, min(4, 256 // tiles, K // 64))) if tiles < 64 else 1
+    return int(max(1, min(32, 256 // tiles, K // (128 if tiles <= 8 else 256))))   # a handful of tiles (the assignment layer's weight gradient): finer slices
