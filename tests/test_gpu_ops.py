@@ -649,6 +649,26 @@ def test_bigru_bf16_mfma(L, B, Lq):
     check(out, y_exact, 3e-2, "bf16 gru against the exact recurrence")
 
 
+def test_zero_and_copy_ranges(L):
+    """sar_zero_ranges / sar_copy_ranges: many buffers in one launch from a device table (the step-start zeroing and the device batch's
+    input copies), sizes that are and are not multiples of four words, untouched neighbours."""
+    sizes = [1, 3, 4, 5, 1024, 4099, 1 << 20]
+    bufs = [torch.full((n + 8,), 7.0, device="cuda") for n in sizes]
+    tab = torch.tensor([[b.data_ptr(), n] for b, n in zip(bufs, sizes)], dtype=torch.int64, device="cuda")
+    L.call("sar_zero_ranges", tab, len(sizes))
+    for b, n in zip(bufs, sizes):
+        assert float(b[:n].abs().max()) == 0.0 and bool((b[n:] == 7.0).all())
+    src = [torch.randn(n, device="cuda") for n in sizes]
+    dst = [torch.full((n + 8,), 7.0, device="cuda") for n in sizes]
+    tab = torch.tensor([[d.data_ptr(), s_.data_ptr(), n] for d, s_, n in zip(dst, src, sizes)], dtype=torch.int64, device="cuda")
+    L.call("sar_copy_ranges", tab, len(sizes))
+    for d, s_, n in zip(dst, src, sizes):
+        assert torch.equal(d[:n], s_) and bool((d[n:] == 7.0).all())
+    xi = torch.arange(10, dtype=torch.int32, device="cuda"); yi = torch.zeros(12, dtype=torch.int32, device="cuda")   # words, whatever the dtype
+    L.call("sar_copy_ranges", torch.tensor([[yi.data_ptr(), xi.data_ptr(), 10]], dtype=torch.int64, device="cuda"), 1)
+    assert torch.equal(yi[:10], xi) and int(yi[10:].abs().max()) == 0
+
+
 # ------------------------------------------------------------------ CTC
 def _ctc_inputs(B, Lq, V, maxU, rng, Umax):
     p = O.softmax(rng.standard_normal((B, Lq, V)) * 2)
