@@ -115,6 +115,18 @@ def test_cfg2_bf16_mode_duplicated_half_batch_invariance():
         _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32")
 
 
+def test_cfg5_bf16_mode_duplicated_half_batch_invariance():
+    """BASELINE configs[4] as bench.py runs it: 2000 x 80, GhostVLAD 64+2, B=32, the bf16 mode (2-byte conv activations; the config
+    names fp16 -- DESIGN section 8).  Same property and bounds as the cfg2 case above."""
+    from aesrc2020_amd import _lib
+    _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    try:
+        m = _dup_half(CFG5, 32, 1e-1, 2.5e-1, tol_halves=1e-3)
+        assert m.trunk.bf16 and m.L == 189 and m.merge.pool.out.shape == (32, 64 * 256)
+    finally:
+        _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32")
+
+
 def test_cfg5_long_utterance_stress():
     from aesrc2020_amd.model import SAR_Net
     kw = dict(input_shape=[2000, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=64, ghost_clusters=2,

@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from aesrc2020_amd import _lib
 from aesrc2020_amd.model import SAR_Net
-from tests.test_gpu_fullsize import CFG2, _batch
+from tests.test_gpu_fullsize import CFG2, CFG5, _batch
 _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
-B = 64
+CFG, B = (CFG5, 32) if (len(sys.argv) > 2 and sys.argv[2] == "cfg5") else (CFG2, 64)
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
-    half = _batch(CFG2, B // 2, 11)
+    half = _batch(CFG, B // 2, 11)
     full = {k: np.concatenate([v, v]) for k, v in half.items()}
-    mf, _ = SAR_Net(seed=0, use_graph=False, **CFG2); mh, _ = SAR_Net(seed=0, use_graph=False, **CFG2)
+    mf, _ = SAR_Net(seed=0, use_graph=False, **CFG); mh, _ = SAR_Net(seed=0, use_graph=False, **CFG)
     mh.set_weights_dict(mf.get_weights_dict())
     mf.forward_backward_only(full, full); mh.forward_backward_only(half, half)
     o = []
