@@ -31,10 +31,11 @@ __device__ __forceinline__ int ext_label(const float* lab, int s, int blank) {
 // dependent global load of the 10 MB probability tensor and two block barriers per frame (~2 us x L of pure latency); now it
 // reads e (and alpha, backward) from LDS when T*S fits (always for the reference shapes: 39 x 33), else from the
 // L2-resident workspace.
+constexpr int CTC_NT = 1024;       // threads per workgroup: one workgroup walks an utterance's L x V probabilities, so the parallel phases want the loads of many waves in flight
 constexpr int CTC_NF = 4;           // frames a wave reduces at once (independent loads in flight)
 
 template <bool LDS_E>
-__global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
+__global__ __launch_bounds__(CTC_NT) void ctc_fwd_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
                                                       const int* __restrict__ in_len, const int* __restrict__ lab_len,
                                                       float* __restrict__ loss, float* __restrict__ alpha_ws,
                                                       float* __restrict__ logden_ws, float* __restrict__ e_ws, int L, int V,
@@ -49,12 +50,12 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     // the extended label sequence l' (blank, l1, blank, l2, ...) once into LDS: the recursion below reads it every frame, and a
     // global (even L1-resident) load per frame sits in its critical path
     __shared__ int xl[CTC_SMAX];
-    for (int s_ = threadIdx.x; s_ < 2 * min(lab_len[b], maxU) + 1; s_ += 256) xl[s_] = ext_label(lab, s_, V - 1);
+    for (int s_ = threadIdx.x; s_ < 2 * min(lab_len[b], maxU) + 1; s_ += CTC_NT) xl[s_] = ext_label(lab, s_, V - 1);
     float* aw = alpha_ws + (long)b * L * Smax;
     float* ew = e_ws + (long)b * L * Smax;
     float* ld = logden_ws + (long)b * L;
     // (1) log denominators: each wave reduces CTC_NF frames at a time
-    for (int t0 = wave * CTC_NF; t0 < T; t0 += 4 * CTC_NF) {
+    for (int t0 = wave * CTC_NF; t0 < T; t0 += (CTC_NT / 64) * CTC_NF) {
         float acc[CTC_NF];
 #pragma unroll
         for (int j = 0; j < CTC_NF; ++j) acc[j] = 0.f;
@@ -70,16 +71,16 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     // (2) emissions of the extended label: e[t][s] = log y_t(l'_s), all (t, s) in parallel
-    for (int i0 = tid; i0 < T * S; i0 += 4 * 256) {                   // four gathers in flight per thread
+    for (int i0 = tid; i0 < T * S; i0 += 4 * CTC_NT) {                   // four gathers in flight per thread
         float pv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = min(i0 + 256 * j, T * S - 1), t = i / S, s_ = i - t * S;
+            const int i = min(i0 + CTC_NT * j, T * S - 1), t = i / S, s_ = i - t * S;
             pv[j] = p[(long)t * V + xl[s_]];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = i0 + 256 * j;
+            const int i = i0 + CTC_NT * j;
             if (i < T * S) {
                 const int t = i / S, s_ = i - t * S;
                 const float e = logf(pv[j] + CTC_EPS) - ld[t];
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     // (3) alpha recursion
-    for (int s_ = tid; s_ < S; s_ += 256) {
+    for (int s_ = tid; s_ < S; s_ += CTC_NT) {
         const float a = (s_ < 2 && T > 0) ? (LDS_E ? e_s[s_] : ew[s_]) : -INFINITY;
         al[0][s_] = a; aw[s_] = a;
     }
     __syncthreads();
     for (int t = 1; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
-        for (int s_ = tid; s_ < S; s_ += 256) {
+        for (int s_ = tid; s_ < S; s_ += CTC_NT) {
             const int k = xl[s_];
             float a = al[prv][s_];
             if (s_ >= 1) a = lse2f(a, al[prv][s_ - 1]);
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void ctc_fwd_kernel(const float* __restrict__ 
 // Dense part g/den_t first (parallel), then per frame the few label symbols are corrected with atomics:
 // occ_t(l'_s)/(p+eps) = exp(alpha_t(s) + beta_t(s) - ll - e_t(s) - log den_t)   [beta excludes the emission at t].
 template <bool LDS_E>
-__global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
+__global__ __launch_bounds__(CTC_NT) void ctc_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ labels,
                                                       const int* __restrict__ in_len, const int* __restrict__ lab_len,
                                                       const float* __restrict__ loss, const float* __restrict__ dloss,
                                                       const float* __restrict__ alpha_ws,
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
     // the extended label sequence l' (blank, l1, blank, l2, ...) once into LDS: the recursion below reads it every frame, and a
     // global (even L1-resident) load per frame sits in its critical path
     __shared__ int xl[CTC_SMAX];
-    for (int s_ = threadIdx.x; s_ < 2 * min(lab_len[b], maxU) + 1; s_ += 256) xl[s_] = ext_label(lab, s_, V - 1);
+    for (int s_ = threadIdx.x; s_ < 2 * min(lab_len[b], maxU) + 1; s_ += CTC_NT) xl[s_] = ext_label(lab, s_, V - 1);
     const float* aw = alpha_ws + (long)b * L * Smax;
     const float* ew = e_ws + (long)b * L * Smax;
     const float* ld = logden_ws + (long)b * L;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
     const int Tl = feasible ? T : 0;
     const int lane = tid & 63, wave = tid >> 6;
     const bool vec = (V & 3) == 0 && (reinterpret_cast<uintptr_t>(dp) & 15) == 0;
-    for (int t = wave; t < L; t += 4) {                               // one wave per frame row, 16-byte stores
+    for (int t = wave; t < L; t += CTC_NT / 64) {                     // one wave per frame row, 16-byte stores
         const float val = t < Tl ? g * expf(-ld[t]) : 0.f;
         float* row = dp + (long)t * V;
         if (vec) {
@@ -162,16 +163,16 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
     }
     if (!feasible) return;
     if (LDS_E) {
-        for (int i0 = tid; i0 < T * S; i0 += 4 * 256) {               // eight loads in flight per thread
+        for (int i0 = tid; i0 < T * S; i0 += 4 * CTC_NT) {               // eight loads in flight per thread
             float ev[4], av[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int i = min(i0 + 256 * j, T * S - 1), t = i / S, s_ = i - t * S;
+                const int i = min(i0 + CTC_NT * j, T * S - 1), t = i / S, s_ = i - t * S;
                 ev[j] = ew[(long)t * Smax + s_]; av[j] = aw[(long)t * Smax + s_];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int i = i0 + 256 * j;
+                const int i = i0 + CTC_NT * j;
                 if (i < T * S) {
                     const int t = i / S, s_ = i - t * S;
                     e_s[t * Smax + s_] = ev[j]; c_s[t * Smax + s_] = av[j] - ev[j] - ld[t] - ll;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void ctc_bwd_kernel(const float* __restrict__ 
     __syncthreads();                                                  // dense rows written before the atomics below
     for (int t = T - 1; t >= 0; --t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        for (int s_ = tid; s_ < S; s_ += 256) {
+        for (int s_ = tid; s_ < S; s_ += CTC_NT) {
             float bb;
             if (t == T - 1) {
                 bb = (s_ >= S - 2) ? 0.f : -INFINITY;
@@ -244,9 +245,9 @@ extern "C" int sar_ctc_batch_cost_fwd_f32(const float* probs, const float* label
     float* logden = ews + (size_t)B * L * Smax;
     const size_t lds = sizeof(float) * (size_t)L * Smax;
     if (lds <= CTC_LDS_CAP)
-        hipLaunchKernelGGL(ctc_fwd_kernel<true>, dim3(B), dim3(256), lds, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
+        hipLaunchKernelGGL(ctc_fwd_kernel<true>, dim3(B), dim3(CTC_NT), lds, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
     else
-        hipLaunchKernelGGL(ctc_fwd_kernel<false>, dim3(B), dim3(256), 0, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
+        hipLaunchKernelGGL(ctc_fwd_kernel<false>, dim3(B), dim3(CTC_NT), 0, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -264,9 +265,9 @@ extern "C" int sar_ctc_batch_cost_bwd_f32(const float* probs, const float* label
     const float* logden = ews + (size_t)B * L * Smax;
     const size_t lds = 2 * sizeof(float) * (size_t)L * Smax;
     if (lds <= CTC_LDS_CAP)
-        hipLaunchKernelGGL(ctc_bwd_kernel<true>, dim3(B), dim3(256), lds, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
+        hipLaunchKernelGGL(ctc_bwd_kernel<true>, dim3(B), dim3(CTC_NT), lds, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
     else
-        hipLaunchKernelGGL(ctc_bwd_kernel<false>, dim3(B), dim3(256), 0, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
+        hipLaunchKernelGGL(ctc_bwd_kernel<false>, dim3(B), dim3(CTC_NT), 0, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
