@@ -90,15 +90,17 @@ __global__ __launch_bounds__(CTC_NT) void ctc_fwd_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    // (3) alpha recursion
-    for (int s_ = tid; s_ < S; s_ += CTC_NT) {
+    // (3) alpha recursion: four waves are plenty for <= 145 states, and a barrier among four is cheaper than among sixteen -- the waves
+    // that only served the parallel phases leave (a finished wave does not take part in later barriers)
+    if (tid >= 256) return;
+    for (int s_ = tid; s_ < S; s_ += 256) {
         const float a = (s_ < 2 && T > 0) ? (LDS_E ? e_s[s_] : ew[s_]) : -INFINITY;
         al[0][s_] = a; aw[s_] = a;
     }
     __syncthreads();
     for (int t = 1; t < T; ++t) {
         const int cur = t & 1, prv = cur ^ 1;
-        for (int s_ = tid; s_ < S; s_ += CTC_NT) {
+        for (int s_ = tid; s_ < S; s_ += 256) {
             const int k = xl[s_];
             float a = al[prv][s_];
             if (s_ >= 1) a = lse2f(a, al[prv][s_ - 1]);
@@ -181,9 +183,10 @@ __global__ __launch_bounds__(CTC_NT) void ctc_bwd_kernel(const float* __restrict
         }
     }
     __syncthreads();                                                  // dense rows written before the atomics below
+    if (tid >= 256) return;                                           // the recursion runs on four waves (see the forward kernel)
     for (int t = T - 1; t >= 0; --t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        for (int s_ = tid; s_ < S; s_ += CTC_NT) {
+        for (int s_ = tid; s_ < S; s_ += 256) {
             float bb;
             if (t == T - 1) {
                 bb = (s_ >= S - 2) ? 0.f : -INFINITY;
