@@ -109,9 +109,22 @@ _TRUNK_DTYPE = [os.environ.get("SAR_TRUNK_DTYPE", "fp32")]
 
 
 def set_trunk_dtype(dtype):
-    if dtype not in ("fp32", "bf16"):
-        raise ValueError("trunk dtype must be 'fp32' or 'bf16', got %r" % (dtype,))
+    if dtype not in ("fp32", "bf16", "fp16"):
+        raise ValueError("trunk dtype must be 'fp32', 'bf16' or 'fp16', got %r" % (dtype,))
     _TRUNK_DTYPE[0] = dtype
+
+
+# fp16 trunk: static scale of the activation gradients inside the trunk (include/sarnet.h, "fp16 trunk").  Power of two, so scaling and
+# unscaling are exact.  Read when a model is built.
+_TRUNK_GSCALE = [float(os.environ.get("SAR_F16_GSCALE", 4096.0))]
+
+
+def set_trunk_gscale(s):
+    _TRUNK_GSCALE[0] = float(s)
+
+
+def get_trunk_gscale():
+    return _TRUNK_GSCALE[0]
 
 
 def get_trunk_dtype():
@@ -121,7 +134,12 @@ def get_trunk_dtype():
 class BnRef(ctypes.Structure):
     """include/sarnet.h: sarBnRef."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("gamma", "beta", "bins", "bbins", "saved", "moving_mean", "moving_var", "dgamma", "dbeta")] + \
-               [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("pad_", ctypes.c_int)]
+               [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("ginv", ctypes.c_float)]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if "ginv" not in k and len(a) < 15:
+            self.ginv = 1.0                                                  # no gradient scale unless the caller sets one
 
 
 class GemmBatch(ctypes.Structure):
@@ -172,7 +190,7 @@ class GemmWgradGroup:
 class WgradConv(ctypes.Structure):
     """include/sarnet.h: sarWgradConv."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "dy", "dw", "dbias")] + \
-               [(n, ctypes.c_int) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl", "pad_")]
+               [(n, ctypes.c_int) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl")] + [("ginv", ctypes.c_float)]
 
 
 class WgradPlan:
@@ -192,6 +210,7 @@ class WgradPlan:
                 setattr(a, k, t.data_ptr() if hasattr(t, "data_ptr") else t)
             for k in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl"):
                 setattr(a, k, int(d[k]))
+            a.ginv = float(d.get("ginv", 1.0))
         cbuf = ctypes.create_string_buffer(n * 128)
         ibuf = ctypes.create_string_buffer(max_items * 32)
         ni, l4 = ctypes.c_int(0), (ctypes.c_int * 4)()
@@ -200,8 +219,9 @@ class WgradPlan:
             raise RuntimeError("sar_wgrad_plan_bf16 failed with status %d" % rc)
         return cbuf.raw, ibuf.raw[:ni.value * 32], ni.value, list(l4)
 
-    def __init__(self, descs, target_blocks, tile=(1, 1)):
+    def __init__(self, descs, target_blocks, tile=(1, 1), sfx="bf16"):
         import torch
+        self.entry = "sar_conv2d_wgrad_batch_" + sfx                                # "bf16" | "f16": the 2-byte type of the operands
         self.keep = [d[k] for d in descs for k in ("x", "dy", "dw", "dbias")]      # the tensors whose addresses the tables hold
         self.K = int(descs[0]["K"])
         convs, items, self.n_items, l4 = self.plan_host(descs, target_blocks, tile)
@@ -212,10 +232,10 @@ class WgradPlan:
 
     def launch(self):
         import torch
-        rc = lib().fn["sar_conv2d_wgrad_batch_bf16"](self.convs.data_ptr(), self.items.data_ptr(), self.n_items, self.K, self.launch4,
+        rc = lib().fn[self.entry](self.convs.data_ptr(), self.items.data_ptr(), self.n_items, self.K, self.launch4,
                                                       torch.cuda.current_stream().cuda_stream)
         if rc != 0:
-            raise RuntimeError("sar_conv2d_wgrad_batch_bf16 failed with status %d" % rc)
+            raise RuntimeError("%s failed with status %d" % (self.entry, rc))
 
 
 def bn_bins():

@@ -112,7 +112,7 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint
 // ---------------------------------------------------------------------------------------------------- conv (fwd / dgrad)
 struct ConvP {
     Geo g; int Cout;
-    const u16* x; const u16* x2; const u16* x3; const bf16x8* wpk; const float* bias; const u16* res; u16* y;
+    const u16* x; const u16* x2; const u16* x3; const h16x8* wpk; const float* bias; const u16* res; u16* y;
     u16* side;                  // nullable: the fill transform T(x) written back to HBM (same shape as x) for the weight gradient
     int fill; BnP fb;
     int epi; float* e_bins; const u16* e_y; const float* e_saved;
@@ -194,9 +194,9 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
 }
 
 template <int NKC>
-__device__ __forceinline__ void load_afrags(bf16x8 (&a)[NKC], const unsigned char* patch, unsigned addr) {
+__device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char* patch, unsigned addr) {
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) a[kc] = *reinterpret_cast<const bf16x8*>(patch + addr + kc * 32);
+    for (int kc = 0; kc < NKC; ++kc) a[kc] = *reinterpret_cast<const h16x8*>(patch + addr + kc * 32);
 }
 
 // WN: waves along the output channels (tile 32*(4/WN) pixels x 32*WN channels); NKC: 16-channel blocks per virtual tap
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     };
     if constexpr (EARLY) load_epi();
     // ---- weight ring: stages 0 and 1 on their way before anything else
-    const bf16x8* wsrc = p.wpk + (size_t)(blockIdx.y * WN) * p.Fs * 64 + lane;
+    const h16x8* wsrc = p.wpk + (size_t)(blockIdx.y * WN) * p.Fs * 64 + lane;
     const unsigned ring0 = lds_addr(bring);
     auto issue_stage = [&](int st, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     f32x16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-    bf16x8 afr[2][KPF], bfr[8 / KG];
+    h16x8 afr[2][KPF], bfr[8 / KG];
     const unsigned char* bmine = bring + (wn * 8 + kg * KPF) * 1024 + lane * 16;
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
@@ -345,14 +345,14 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
                 else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
                 const int slot = RD == 4 ? (st & 3) : (st % 3);
 #pragma unroll
-                for (int i = 0; i < 8 / KG; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(bmine + (slot * SJ + i) * 1024);
+                for (int i = 0; i < 8 / KG; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
             }
             if (kc == 0 && v + 1 < VT) {
                 const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
                 load_afrags<KPF>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
             }
-            if (f & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[v & 1][kc], bfr[f % 8], acc2, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[v & 1][kc], bfr[f % 8], acc, 0, 0, 0);
+            if (f & 1) acc2 = MFMA16(afr[v & 1][kc], bfr[f % 8], acc2, 0, 0, 0);
+            else acc = MFMA16(afr[v & 1][kc], bfr[f % 8], acc, 0, 0, 0);
         }
     }
 #pragma unroll
@@ -383,15 +383,15 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
             const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + TM * TN + row * TN + 2 * cp);
             a.x += a2.x; a.y += a2.y;
         }
-        float v0 = a.x + b0 + bf_lo(rv[i]), v1 = a.y + b1 + bf_hi(rv[i]);
+        float v0 = a.x + b0 + h_lo(rv[i]), v1 = a.y + b1 + h_hi(rv[i]);
         const unsigned pk = pack2(v0, v1);
         if (m < M) {
             __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
             // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
-            if (p.epi == 1) { v0 = bf_lo(pk); v1 = bf_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
+            if (p.epi == 1) { v0 = h_lo(pk); v1 = h_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
             if (p.epi == 2) {
-                const float y0 = bf_lo(yv[i]), y1 = bf_hi(yv[i]);
+                const float y0 = h_lo(yv[i]), y1 = h_hi(yv[i]);
                 const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
                 s10 += d0; s11 += d1; s20 += d0 * (y0 - mu0) * rs0; s21 += d1 * (y1 - mu1) * rs1;
             }
@@ -427,7 +427,7 @@ struct WgConv {                 // device table row, written by sar_wgrad_plan_b
     int nchunks;                // 64-pixel chunks
     int cap_pos;                // patch positions of one chunk (multiple of 16)
     int la;                     // 3x3: chunks requested ahead of the one being multiplied (1..3: what the position ring holds)
-    int pad_;
+    float ginv;                 // the flush multiplies by it: 1 / (gradient scale dy carries; 1 in the bf16 build)
 };
 static_assert(sizeof(WgConv) <= 128, "WgConv must fit its 128-byte table row");
 struct WgItem { int conv, ci0, co0, c_first, c_count, single, pad0_, pad1_; };   // 32 bytes
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned
     const int Cout = cvp->Cout;
     const u16* __restrict__ xp = cvp->x; const u16* __restrict__ dyp = cvp->dy;
     float* dwp = cvp->dw; float* dbp = cvp->dbias;
+    const float ginv = cvp->ginv;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M;
@@ -496,18 +497,18 @@ __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned
         if (lc + WG_NBUF - 1 < nmine) issue(lc + WG_NBUF - 1);
         const unsigned char* dyt = bufs + (size_t)(lc % WG_NBUF) * BUF;
         const unsigned char* ap = dyt + 4096;
-        bf16x8 A[4], Bm[4];
+        h16x8 A[4], Bm[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const unsigned o0 = (16 * ks + prb) * 64 + colb, o1 = o0 + 4 * 64;
             const s16x4 b_lo = lds_tr(dyt, o0), b_hi = lds_tr(dyt, o1), a_lo = lds_tr(ap, o0), a_hi = lds_tr(ap, o1);
-            A[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            Bm[ks] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            A[ks] = __builtin_bit_cast(h16x8, __builtin_shufflevector(a_lo, a_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            Bm[ks] = __builtin_bit_cast(h16x8, __builtin_shufflevector(b_lo, b_hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bm[0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bm[1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bm[2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], Bm[3], acc2, 0, 0, 0);
+        acc = MFMA16(A[0], Bm[0], acc, 0, 0, 0);
+        acc2 = MFMA16(A[1], Bm[1], acc2, 0, 0, 0);
+        acc = MFMA16(A[2], Bm[2], acc, 0, 0, 0);
+        acc2 = MFMA16(A[3], Bm[3], acc2, 0, 0, 0);
         if (do_bias) {                                             // block-uniform
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -530,11 +531,12 @@ __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned
 #pragma unroll
         for (int k = 0; k < WG_NW1; ++k) s += reinterpret_cast<const float*>(smem + (size_t)k * WG_NBUF * BUF)[e];
         float* o = dwp + (size_t)(ci0 + (e >> 5)) * Cout + co0 + (e & 31);
+        s *= ginv;
         if (it.single) *o += s; else atomicAdd(o, s);
     }
     if (do_bias) {
         bsum += __shfl_xor(bsum, 32, 64);
-        if (lane < 32) atomicAdd(dbp + co0 + lane, bsum);
+        if (lane < 32) atomicAdd(dbp + co0 + lane, bsum * ginv);
     }
     TSTAMP(5); TSTAMP(15);
 }
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
     const int Cout = cvp->Cout, LA = cvp->la;
     const u16* __restrict__ xp = cvp->x; const u16* __restrict__ dyp = cvp->dy;
     float* dwp = cvp->dw; float* dbp = cvp->dbias;
+    const float ginv = cvp->ginv;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M, NP = a.np, mask = a.np - 1;
@@ -679,19 +682,19 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
         if (lc + 1 < nmine) tables(lc + 1);
         const unsigned* qtab = qring + (lc & 1) * 64;
         const unsigned char* dyt = dyr + (size_t)(lc % nbuf) * (TCO * 4096);
-        bf16x8 A[2][TCI], Bm[2][TCO];
-        auto rd = [&](int ks, bf16x8 (&Ao)[TCI], bf16x8 (&Bo)[TCO]) __attribute__((always_inline)) {
+        h16x8 A[2][TCI], Bm[2][TCO];
+        auto rd = [&](int ks, h16x8 (&Ao)[TCI], h16x8 (&Bo)[TCO]) __attribute__((always_inline)) {
             const unsigned p0 = 16 * ks + prb, p1 = p0 + 4;
             const unsigned a0 = ((qtab[p0] + toff) & mask) * 64 + colb, a1 = ((qtab[p1] + toff) & mask) * 64 + colb;
 #pragma unroll
             for (int i = 0; i < TCI; ++i) {
                 const s16x4 lo = lds_tr(pr + (size_t)i * NP * 64, a0), hi = lds_tr(pr + (size_t)i * NP * 64, a1);
-                Ao[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                Ao[i] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int j = 0; j < TCO; ++j) {
                 const s16x4 lo = lds_tr(dyt + j * 4096, p0 * 64 + colb), hi = lds_tr(dyt + j * 4096, p1 * 64 + colb);
-                Bo[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                Bo[j] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         };
         rd(0, A[0], Bm[0]);
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
             for (int i = 0; i < TCI; ++i)
 #pragma unroll
                 for (int j = 0; j < TCO; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks & 1][i], Bm[ks & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = MFMA16(A[ks & 1][i], Bm[ks & 1][j], acc[i][j], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
                 for (int j = 0; j < TCO; ++j)
@@ -732,10 +735,10 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[i][j][r] * ginv;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) atomicAdd(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout, acc[i][j][r]);
+                    for (int r = 0; r < 16; ++r) atomicAdd(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout, acc[i][j][r] * ginv);
                 }
             }
         if (do_bias) {
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
             for (int j = 0; j < TCO; ++j) {
                 float s = bsum[j];
                 s += __shfl_xor(s, 32, 64);
-                if (lane < 32) atomicAdd(dbp + co0 + j * 32 + lane, s);
+                if (lane < 32) atomicAdd(dbp + co0 + j * 32 + lane, s * ginv);
             }
         }
     }
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
 // Residual-stream gradient: out = BN(+ReLU) backward of `dact` through the BatchNorm whose input was x (+ add).
 template <typename DT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const DT* __restrict__ dact, const u16* __restrict__ x, const BnP bn,
-                                                                const u16* __restrict__ add, u16* __restrict__ out, long R, int C, int relu) {
+                                                                const u16* __restrict__ add, u16* __restrict__ out, long R, int C, int relu, float out_scale) {
     __shared__ float cst[6 * CMAX];
     bn_prologue(bn, 2, C, 0, C, cst, CMAX, blockIdx.x == 0, 256);
     __syncthreads();
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const DT* __rest
             const float z = fmaf(y[j], k.sc[j], k.sh[j]);
             const float dz = (!relu || z > 0.f) ? a[j] : 0.f;
             const float xh = (y[j] - k.mu[j]) * k.rs[j];
-            o[j] = k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]) + (add ? ad[j] : 0.f);
+            o[j] = (k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]) + (add ? ad[j] : 0.f)) * out_scale;
         }
         *reinterpret_cast<uint4*>(out + e) = pack8(o);
     }
@@ -945,7 +948,7 @@ extern "C" {
 // mirrors BnP (include/sarnet.h: sarBnRef)
 typedef BnP sarBnRef;
 
-int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, hipStream_t stream) {
+int SAR_T16(sar_conv_pack_weights_)(const void* table, int n, int total_blocks, hipStream_t stream) {
     if (table == nullptr || n < 1 || total_blocks < 1) return SAR_EINVAL;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const PackRow*>(table), n);
     SAR_CHECK_LAUNCH();
@@ -958,7 +961,7 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, hipSt
 //   side (nullable): T(src) written back to HBM (shape of src) -- the plain operand of the matching weight gradient.
 //   epi  0: none; 1: sum / sum of squares of y into e_bins; 2: BatchNorm-backward sums of y (= da) against (e_y, e_saved).
 // Forward: d = 1, s = stride, pads as TF.  Input gradient: src = dy, d = stride, s = 1, pt = K-1-pad_top, wpk = dgrad stream.
-int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                     int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, hipStream_t stream) {
     ConvP p;
@@ -970,7 +973,7 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const v
     if (epi == 2 && (e_y == nullptr || e_saved == nullptr)) return SAR_EINVAL;
     if ((long)B * Hs * Ws * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
     p.Cout = Cout;
-    p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.x3 = static_cast<const u16*>(src3); p.wpk = static_cast<const bf16x8*>(wpk);
+    p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.x3 = static_cast<const u16*>(src3); p.wpk = static_cast<const h16x8*>(wpk);
     p.bias = bias; p.res = static_cast<const u16*>(res); p.y = static_cast<u16*>(y); p.side = static_cast<u16*>(side);
     p.fill = fill; if (fbn) p.fb = *fbn;
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;
@@ -1018,9 +1021,10 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const v
 }
 
 // One convolution of a batched weight-gradient launch as the caller describes it (include/sarnet.h: sarWgradConv).
-struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl, pad_; };
+struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl; float ginv; };
 
-// Host-only planning (no device access): the device tables of ONE launch over `n` convolutions of equal K (1 or 3) and equal
+#if !SAR_HALF
+// Host-only planning (no device access; shared by both builds of this file): the device tables of ONE launch over `n` convolutions of equal K (1 or 3) and equal
 // channel-tile class -- convs_out: n rows of 128 bytes, items_out: up to max_items rows of 32 bytes, longest first -- plus the
 // launch parameters launch4 = {dynamic LDS bytes, positions of the patch ring (3x3), chunk buffers, tile_ci << 4 | tile_co}.
 // tile_ci / tile_co (1 or 2): 32-channel planes per block on the input / output side (3x3 only; every Cin must be a multiple
@@ -1047,6 +1051,7 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
         tmp.nchunks = cdiv(tmp.g.M, 64);
         tmp.cap_pos = K == 1 ? 64 : (patch_rows_bound(tmp.g, 64 < tmp.g.M ? 64 : tmp.g.M) * tmp.g.Wp + 15) & ~15;
         tmp.la = 3;
+        tmp.ginv = c.ginv != 0.f ? c.ginv : 1.f;                        // (0: descriptors written before the field existed)
         // 3x3: DMA instructions of an item's first chunk (the whole patch) dealt to nine waves: at most 4 each
         return K == 1 || 4 * tile_co + (tmp.cap_pos / 16 + 1) * tile_ci <= 36;
     };
@@ -1120,9 +1125,11 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
     return launch4[0] <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
 }
 
+#endif  // !SAR_HALF
+
 // Weight gradients of many convolutions, one launch: tables and launch4 from sar_wgrad_plan_bf16 (tables uploaded by the caller),
 // K = kernel size of the planned convolutions.  dw += x^T (*) dy per tap, dbias (where given) += column sums of dy.
-int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, hipStream_t stream) {
+int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, hipStream_t stream) {
     if (convs_dev == nullptr || items_dev == nullptr || launch4 == nullptr || n_items < 1 || (K != 1 && K != 3)) return SAR_EINVAL;
     const int lds_bytes = launch4[0], np = launch4[1], nbuf = launch4[2], tci = launch4[3] >> 4, tco = launch4[3] & 15;
     if (lds_bytes <= 0 || lds_bytes > 160 * 1024 || tci < 1 || tci > 2 || tco < 1 || tco > 2) return SAR_EINVAL;
@@ -1161,21 +1168,22 @@ static int bn_grid(long R, int C) {
     return (int)nb;
 }
 
-int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
-                          int C, int relu, hipStream_t stream) {
+// out_scale: multiplies the result (the fp16 trunk's static gradient scale enters here, at the final BatchNorm; 1 otherwise)
+int SAR_T16(sar_bn_bwd_apply_)(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
+                          int C, int relu, float out_scale, hipStream_t stream) {
     if (bn == nullptr || !pow2(C) || C < 8 || C > CMAX || R < 1) return SAR_EINVAL;
     const dim3 grid(bn_grid(R, C));
     if (dact_f32)
         hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float*>(dact), static_cast<const u16*>(x), *bn,
-                           static_cast<const u16*>(add), static_cast<u16*>(out), R, C, relu);
+                           static_cast<const u16*>(add), static_cast<u16*>(out), R, C, relu, out_scale);
     else
         hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel<u16>, grid, dim3(256), 0, stream, static_cast<const u16*>(dact), static_cast<const u16*>(x), *bn,
-                           static_cast<const u16*>(add), static_cast<u16*>(out), R, C, relu);
+                           static_cast<const u16*>(add), static_cast<u16*>(out), R, C, relu, out_scale);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
 
-int sar_bn_bwd_reduce_bf16(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
+int SAR_T16(sar_bn_bwd_reduce_)(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
                            hipStream_t stream) {
     if (!pow2(C) || C < 8 || C > CMAX || R < 1) return SAR_EINVAL;
     const dim3 grid(bn_grid(R, C));
@@ -1187,21 +1195,28 @@ int sar_bn_bwd_reduce_bf16(const void* dact, int dact_f32, const void* x, const 
     return SAR_OK;
 }
 
-int sar_bn_apply_bf16_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, hipStream_t stream) {
+#if SAR_HALF
+#define sar_bn_apply_T16_f32 sar_bn_apply_f16_f32
+#define sar_cast_T16_f32 sar_cast_f16_f32
+#else
+#define sar_bn_apply_T16_f32 sar_bn_apply_bf16_f32
+#define sar_cast_T16_f32 sar_cast_bf16_f32
+#endif
+int sar_bn_apply_T16_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, hipStream_t stream) {
     if (bn == nullptr || !pow2(C) || C < 8 || C > CMAX || R < 1) return SAR_EINVAL;
     hipLaunchKernelGGL(bn_apply_bf16_f32_kernel, dim3(bn_grid(R, C)), dim3(256), 0, stream, static_cast<const u16*>(x), *bn, out, R, C, relu);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
 
-int sar_cast_f32_bf16(const float* x, void* y, long n, hipStream_t stream) {
+int SAR_T16(sar_cast_f32_)(const float* x, void* y, long n, hipStream_t stream) {
     if (n < 8 || n % 8) return SAR_EINVAL;
     long nb = (n / 8 + 1023) / 1024; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, static_cast<u16*>(y), n / 8);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
-int sar_cast_bf16_f32(const void* x, float* y, long n, hipStream_t stream) {
+int sar_cast_T16_f32(const void* x, float* y, long n, hipStream_t stream) {
     if (n < 8 || n % 8) return SAR_EINVAL;
     long nb = (n / 8 + 1023) / 1024; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)nb), dim3(256), 0, stream, static_cast<const u16*>(x), y, n / 8);
@@ -1209,7 +1224,9 @@ int sar_cast_bf16_f32(const void* x, float* y, long n, hipStream_t stream) {
     return SAR_OK;
 }
 
+#if !SAR_HALF
 int sar_bn_bins(void) { return NB; }
+#endif
 
 #ifdef SAR_TIMING
 int sar_dbg_set_timing_buffer16(unsigned long long* buf) {

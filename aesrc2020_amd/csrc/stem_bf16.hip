@@ -82,19 +82,19 @@ __device__ __forceinline__ void stem_w_store(const WStage<NT>& ws, unsigned char
     for (int i = 0; i < NT; ++i) {
         const int fl = tid + 256 * i, f = fl >> 6, ln = fl & 63, s = f & 3;
         const bool ok = 2 * s + (ln >> 5) < 7;
-        bf16x8 o;
+        h16x8 o;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) o[j] = (__bf16)(ok ? ws.v[i][j] : 0.f);
-        o[7] = (__bf16)0.f;
-        *reinterpret_cast<bf16x8*>(wfr + fl * 16) = o;
+        for (int j = 0; j < 7; ++j) o[j] = (h16)(ok ? ws.v[i][j] : 0.f);
+        o[7] = (h16)0.f;
+        *reinterpret_cast<h16x8*>(wfr + fl * 16) = o;
     }
 }
 template <int NT>
-__device__ __forceinline__ void stem_w_frags(bf16x8 (&wa)[NT][4], const unsigned char* wfr, int lane) {
+__device__ __forceinline__ void stem_w_frags(h16x8 (&wa)[NT][4], const unsigned char* wfr, int lane) {
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wa[ct][s] = *reinterpret_cast<const bf16x8*>(wfr + ((ct * 4 + s) * 64 + lane) * 16);
+        for (int s = 0; s < 4; ++s) wa[ct][s] = *reinterpret_cast<const h16x8*>(wfr + ((ct * 4 + s) * 64 + lane) * 16);
 }
 
 // ---- input patch.  patch[r][c] = bf16(x[n][row0 + r][c - pl]) (zero outside the image), r < nprow, c < pld.
@@ -156,17 +156,17 @@ __device__ __forceinline__ void stem_stage(unsigned char* wfr, u16* patch, const
 // One 32-pixel column block: acc[ct] += W(ct) * patches for ct in [CT0, CT0 + NC); boff = (2*ty + h) * pld + 2*tx (bf16 index of
 // the lane's first element); lanes of pixels past the tile multiply zeros
 template <int NT, int CT0, int NC>
-__device__ __forceinline__ void stem_mtile(const bf16x8 (&wa)[NT][4], const u16* patch, int pld, unsigned boff, bool valid, f32x16 (&acc)[NC], bf16x8 (&bfr)[4]) {
+__device__ __forceinline__ void stem_mtile(const h16x8 (&wa)[NT][4], const u16* patch, int pld, unsigned boff, bool valid, f32x16 (&acc)[NC], h16x8 (&bfr)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const unsigned* q = reinterpret_cast<const unsigned*>(patch + boff + 2 * s * pld);
         const uint4 v = make_uint4(q[0], q[1], q[2], q[3]);
-        bfr[s] = __builtin_bit_cast(bf16x8, valid ? v : make_uint4(0u, 0u, 0u, 0u));
+        bfr[s] = __builtin_bit_cast(h16x8, valid ? v : make_uint4(0u, 0u, 0u, 0u));
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[CT0 + c][s], bfr[s], acc[c], 0, 0, 0);
+        for (int c = 0; c < NC; ++c) acc[c] = MFMA16(wa[CT0 + c][s], bfr[s], acc[c], 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------- forward pass 1: statistics
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
     stem_stage<NT, 6>(wfr, patch, x, w, g, n, 2 * r0 - g.pt, 2 * (nr - 1) + 8, tid, true, [] {});
     __syncthreads();
     TSTAMP(2);
-    bf16x8 wa[NT][4];
+    h16x8 wa[NT][4];
     stem_w_frags<NT>(wa, wfr, lane);
     float s1[NT][16], s2[NT][16];
 #pragma unroll
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
     for (int mt = wave; mt * 32 < npix; mt += 4) {
         const int p = mt * 32 + (lane & 31);
         const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
-        f32x16 acc[NT]; bf16x8 bfr[4];
+        f32x16 acc[NT]; h16x8 bfr[4];
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
     });
     __syncthreads();
     TSTAMP(2);
-    bf16x8 wa[NT][4];
+    h16x8 wa[NT][4];
     stem_w_frags<NT>(wa, wfr, lane);
     const int nitems = npr * g.Wp * 8;
     auto pass = [&](auto ctc) __attribute__((always_inline)) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
             const int p = mt * 32 + (lane & 31);
             const bool valid = p < npix;
             const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
-            f32x16 acc[1]; bf16x8 bfr[4];
+            f32x16 acc[1]; h16x8 bfr[4];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
             stem_mtile<NT, CT, 1>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
@@ -322,7 +322,7 @@ __device__ __noinline__ float stem_point(const float* __restrict__ x, const floa
         for (int kx = 0; kx < 7; ++kx) {
             const int hi = 2 * r - pt + ky, wi = 2 * c - pl + kx;
             if (hi < 0 || hi >= T || wi < 0 || wi >= D) continue;
-            const float xv = bf_lo(pack2(x[((size_t)n * T + hi) * D + wi], 0.f)), wv = bf_lo(pack2(w[(ky * 7 + kx) * C0 + ch], 0.f));
+            const float xv = h_lo(pack2(x[((size_t)n * T + hi) * D + wi], 0.f)), wv = h_lo(pack2(w[(ky * 7 + kx) * C0 + ch], 0.f));
             y = fmaf(xv, wv, y);
         }
     return y + b;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
     unsigned char* scr0 = dz + dz_bytes + 256;                                       // [4 waves][SCR]: P planes 0, 1, dy plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     unsigned char* scr = scr0 + wave * SCR;
-    bf16x8 wa[NT][4];
+    h16x8 wa[NT][4];
     f32x16 accw[2][NT];
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
@@ -479,8 +479,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                         const int slot = ((k < 4 ? i1.x : i1.y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
                         const int r = 2 * (i_lo + wi) - g.ppt + kh - r0, c = 2 * wj - g.ppl + kw;
                         if (pz != 0u && r >= 0 && r < nr) {
-                            const s16x2 val = __builtin_bit_cast(s16x2, gz << sh);
-                            __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2), val);
+                            lds_pk_add(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2, gz << sh);
                         }
                     }
                 }
@@ -498,8 +497,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                         const int slot = ((k < 4 ? iv[u].x : iv[u].y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
                         const int r = rb + kh, c = cbase + kw;
                         if (it < nitems && pz != 0u && r >= 0 && r < nr) {
-                            const s16x2 val = __builtin_bit_cast(s16x2, gz << sh);
-                            __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2), val);
+                            lds_pk_add(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2, gz << sh);
                         }
                     }
                 }
@@ -515,14 +513,14 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                 const int p = mt * 32 + q;
                 const bool valid = p < npix;
                 const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
-                f32x16 acc[1]; bf16x8 bfr[4];
+                f32x16 acc[1]; h16x8 bfr[4];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
                 stem_mtile<NT, CT, 1>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
                 // the lane's B fragments ARE its pixel's im2col row (taps (2s+h)*8 .. +8): plane (2s+h)/4, 16 bytes at ((2s+h)%4)*16
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2)
-                    *reinterpret_cast<bf16x8*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = bfr[s2];
+                    *reinterpret_cast<h16x8*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = bfr[s2];
                 unsigned char* dzp = dz + (size_t)pc * DZP + 8 * h;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
@@ -533,10 +531,10 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                     const float4 A4 = *reinterpret_cast<const float4*>(aef + ch0), E4 = *reinterpret_cast<const float4*>(aef + C0 + ch0),
                                  F4 = *reinterpret_cast<const float4*>(aef + 2 * C0 + ch0);
                     // lanes past the tile: acc = 0 and dz = 0, so F alone has to be masked
-                    const float d0 = fmaf(A4.x, bf_lo(dv.x), fmaf(E4.x, acc[0][gq * 4 + 0], valid ? F4.x : 0.f));
-                    const float d1 = fmaf(A4.y, bf_hi(dv.x), fmaf(E4.y, acc[0][gq * 4 + 1], valid ? F4.y : 0.f));
-                    const float d2 = fmaf(A4.z, bf_lo(dv.y), fmaf(E4.z, acc[0][gq * 4 + 2], valid ? F4.z : 0.f));
-                    const float d3 = fmaf(A4.w, bf_hi(dv.y), fmaf(E4.w, acc[0][gq * 4 + 3], valid ? F4.w : 0.f));
+                    const float d0 = fmaf(A4.x, h_lo(dv.x), fmaf(E4.x, acc[0][gq * 4 + 0], valid ? F4.x : 0.f));
+                    const float d1 = fmaf(A4.y, h_hi(dv.x), fmaf(E4.y, acc[0][gq * 4 + 1], valid ? F4.y : 0.f));
+                    const float d2 = fmaf(A4.z, h_lo(dv.y), fmaf(E4.z, acc[0][gq * 4 + 2], valid ? F4.z : 0.f));
+                    const float d3 = fmaf(A4.w, h_hi(dv.y), fmaf(E4.w, acc[0][gq * 4 + 3], valid ? F4.w : 0.f));
                     *reinterpret_cast<uint2*>(scr + 2 * PLANE + q * IP + cl * 2) = make_uint2(pack2(d0, d1), pack2(d2, d3));
                 }
                 // the wave's own LDS stores are ordered in front of its own reads (same queue); keep the compiler from reordering them
@@ -544,18 +542,18 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const unsigned o0 = (16 * ks + prb) * IP + colb, o1 = o0 + 4 * IP;
-                    bf16x8 Af[2], Bf;
+                    h16x8 Af[2], Bf;
 #pragma unroll
                     for (int tp = 0; tp < 2; ++tp) {
                         const s16x4 lo = lds_tr(scr + tp * PLANE, o0), hi = lds_tr(scr + tp * PLANE, o1);
-                        Af[tp] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        Af[tp] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
                     {
                         const s16x4 lo = lds_tr(scr + 2 * PLANE, o0), hi = lds_tr(scr + 2 * PLANE, o1);
-                        Bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        Bf = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
 #pragma unroll
-                    for (int tp = 0; tp < 2; ++tp) accw[tp][CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Af[tp], Bf, accw[tp][CT], 0, 0, 0);
+                    for (int tp = 0; tp < 2; ++tp) accw[tp][CT] = MFMA16(Af[tp], Bf, accw[tp][CT], 0, 0, 0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the transpose-reads are done before the images are rewritten
             }
@@ -599,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
 
 // dw[(ky*7 + kx)][c] += sum over blocks of part[block][ky*8 + kx][c]; grid (49 taps, WS_SLICES slices of the blocks)
 constexpr int WS_SLICES = 8;
-__global__ __launch_bounds__(256) void stem16_wsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, int C0, int* __restrict__ counter) {
+__global__ __launch_bounds__(256) void stem16_wsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, int C0, int* __restrict__ counter, float ginv) {
     __shared__ float red[256];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *counter = 0;
     const int t = blockIdx.x, row = (t / 7) * 8 + (t % 7);
@@ -617,7 +615,7 @@ __global__ __launch_bounds__(256) void stem16_wsum_kernel(const float* __restric
     if (threadIdx.x < C0) {
         float a = 0.f;
         for (int k = 0; k < nsl; ++k) a += red[k * C0 + c];
-        atomicAdd(dw + t * C0 + c, a);
+        atomicAdd(dw + t * C0 + c, a * ginv);                                            // ginv: the gradient scale of the fp16 build leaves here
     }
 }
 
@@ -654,7 +652,7 @@ typedef BnP sarBnRef;
 
 // Forward pass 1: sum / sum of squares of y = conv7x7/2(x) + bias per channel, added into bins [sar_bn_bins()][2][C0] (zeroed by the
 // caller once per step, like every BatchNorm of the bf16 trunk).  x (B,T,D) fp32, w (7,7,1,C0) fp32 HWIO, C0 in {32, 64}.
-int sar_stem16_stats(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
+int SAR_STEM(sar_stem16_stats)(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
                      int pad_top, int pad_left, hipStream_t stream) {
     StemG g;
     if (!x || !w || !bias || !bins || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, 1, 1, 0, 0)) return SAR_EINVAL;
@@ -677,7 +675,7 @@ int sar_stem16_stats(const float* x, const float* w, const float* bias, float* b
 // Forward pass 2: pooled (B,Hp,Wp,C0) bf16 = maxpool3x3/2(relu(bn(conv(x) + bias))), idx (same shape, u8) = window slot kh*3+kw of the
 // first maximum.  bn: statistics from bn->bins (training; the launch with bn->write also stores saved / moving statistics) or
 // bn->saved (bins null: inference with folded moving averages).
-int sar_stem16_pool_fwd(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
+int SAR_STEM(sar_stem16_pool_fwd)(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
                         int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, hipStream_t stream) {
     StemG g;
     if (!x || !w || !bias || !bn || !pooled || !idx || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
@@ -701,7 +699,7 @@ int sar_stem16_pool_fwd(const float* x, const float* w, const float* bias, const
 // Backward pass 1: the BatchNorm-backward sums (sum dz | sum dz*xhat) of the stem's BatchNorm, added into bn->bbins, from the
 // gradient of the pooled map g (bf16), the pooled map and its argmax slots.  Needs bn->saved (written by the forward).  work: the
 // workspace sar_stem16_wgrad will get (its tile counter is reset here).
-int sar_stem16_bwd_reduce(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+int SAR_STEM(sar_stem16_bwd_reduce)(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
                           const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
                           int pool_pad_top, int pool_pad_left, hipStream_t stream) {
     StemG g;
@@ -717,13 +715,15 @@ int sar_stem16_bwd_reduce(const void* g_pooled, const void* pooled, const uint8_
     return SAR_OK;
 }
 
+#if !SAR_HALF
 size_t sar_stem16_wgrad_workspace_bytes(int C0) { return 64 + (size_t)WG_MAX_BLOCKS * 64 * C0 * sizeof(float); }
+#endif
 
 // Backward pass 2: dw (7,7,1,C0) fp32 += kernel gradient.  bn: saved + bbins (after sar_stem16_bwd_reduce); the launch owns the
 // BatchNorm's parameter gradients when bn->write.  work: sar_stem16_wgrad_workspace_bytes(C0) bytes of scratch, the same buffer
 // sar_stem16_bwd_reduce got.  The stem's bias
 // gradient is exactly zero (it feeds a BatchNorm) and is not computed.
-int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
+int SAR_STEM(sar_stem16_wgrad)(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
                      const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
                      int Hp, int Wp, int pool_pad_top, int pool_pad_left, hipStream_t stream) {
     StemG g;
@@ -750,13 +750,13 @@ int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const vo
         hipLaunchKernelGGL(stem16_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
                            static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, dz_bytes);
     }
-    hipLaunchKernelGGL(stem16_wsum_kernel, dim3(49, WS_SLICES), dim3(256), 0, stream, part, nblk, dw, C0, counter);
+    hipLaunchKernelGGL(stem16_wsum_kernel, dim3(49, WS_SLICES), dim3(256), 0, stream, part, nblk, dw, C0, counter, bn->ginv);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
 
 #ifdef SAR_TIMING
-int sar_dbg_set_timing_buffer_stem(unsigned long long* buf) {
+int SAR_STEM(sar_dbg_set_timing_buffer_stem)(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf_stem), &buf, sizeof(buf)) == hipSuccess ? SAR_OK : SAR_ELAUNCH;
 }
 #endif

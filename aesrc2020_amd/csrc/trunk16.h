@@ -6,23 +6,54 @@
 namespace {
 
 typedef unsigned short u16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+// The 2-byte storage / MFMA operand type of the trunk.  conv_bf16.hip and stem_bf16.hip are compiled twice: as they are (bf16: BASELINE
+// configs[1]; entry points sar_*_bf16 / sar_stem16_*) and with -DSAR_HALF=1 (IEEE fp16: BASELINE configs[4]; entry points sar_*_f16 /
+// sar_stem16_*_f16).  Same bytes, same MFMA rate (v_mfma_f32_32x32x16_f16), three more mantissa bits; fp16's narrow exponent is why
+// that build carries a static gradient scale (BnP::ginv, WgConv::ginv undo it where parameter gradients leave the trunk).
+#ifndef SAR_HALF
+#define SAR_HALF 0
+#endif
+#if SAR_HALF
+typedef _Float16 h16;
+#define MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define SAR_T16(pre) pre##f16
+#define SAR_STEM(name) name##_f16
+#else
+typedef __bf16 h16;
+#define MFMA16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define SAR_T16(pre) pre##bf16
+#define SAR_STEM(name) name
+#endif
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 
 constexpr int NB = 16;          // statistic bins per BatchNorm (fp32 atomics; contention = blocks / 16 per address)
 constexpr int CMAX = 512;       // max channels of a BatchNorm / conv side
 
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+#if SAR_HALF
+__device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(h16x2, u)[0]; }   // v_cvt_f32_f16 (sdwa for the high half)
+__device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(h16x2, u)[1]; }
+// LDS add of a 2-byte pair (stem weight gradient's scatter): ds_pk_add_f16
+__device__ __forceinline__ void lds_pk_add(unsigned char* dst, unsigned val) {
+    __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h16x2*)dst, __builtin_bit_cast(h16x2, val));
+}
+#else
+__device__ __forceinline__ float h_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float h_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void lds_pk_add(unsigned char* dst, unsigned val) {                        // ds_pk_add_bf16
+    __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)dst, __builtin_bit_cast(s16x2, val));
+}
+#endif
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;           // v_cvt_pk_bf16_f32 (RNE)
+    h16x2 p; p[0] = (h16)a; p[1] = (h16)b;                  // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (RNE)
     return __builtin_bit_cast(unsigned, p);
 }
 __device__ __forceinline__ void unpack8(const uint4 q, float (&f)[8]) {
-    f[0] = bf_lo(q.x); f[1] = bf_hi(q.x); f[2] = bf_lo(q.y); f[3] = bf_hi(q.y);
-    f[4] = bf_lo(q.z); f[5] = bf_hi(q.z); f[6] = bf_lo(q.w); f[7] = bf_hi(q.w);
+    f[0] = h_lo(q.x); f[1] = h_hi(q.x); f[2] = h_lo(q.y); f[3] = h_hi(q.y);
+    f[4] = h_lo(q.z); f[5] = h_hi(q.z); f[6] = h_lo(q.w); f[7] = h_hi(q.w);
 }
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
     return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
@@ -45,7 +76,7 @@ struct BnP {
     float* dgamma; float* dbeta;
     float inv_n, unbias, eps, momentum;
     int write;                  // this launch owns the side effects: saved / moving statistics / parameter gradients
-    int pad_;
+    float ginv;                 // 1 / (gradient scale the backward sums in `bbins` carry): applied where dgamma / dbeta are written
 };
 
 // cst[0..5][cs]: scale, shift, mean, rstd, c2 = S1/N, c3 = S2/N for channels [c0, c0+nc), row stride cs >= nc.  mode 1: forward constants
@@ -79,7 +110,7 @@ __device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int 
 #pragma unroll
             for (int b = 0; b < NB; ++b) { s1 += (double)bn.bbins[(b * 2) * C + c]; s2 += (double)bn.bbins[(b * 2 + 1) * C + c]; }
             cst[4 * cs + i] = (float)(s1 * (double)bn.inv_n); cst[5 * cs + i] = (float)(s2 * (double)bn.inv_n);
-            if (owner && bn.write && bn.dgamma != nullptr) { bn.dgamma[c] += (float)s2; bn.dbeta[c] += (float)s1; }
+            if (owner && bn.write && bn.dgamma != nullptr) { bn.dgamma[c] += (float)s2 * bn.ginv; bn.dbeta[c] += (float)s1 * bn.ginv; }
         }
     }
 }

@@ -490,6 +490,8 @@ class SARNetModel:
         self._forward("train"); self._losses_forward(); self._backward()
         if update:
             self.store.adam_step()
+        elif not self.dp.enabled:
+            self.store._zeroed_this_step = False  # (the data-parallel two-graph form runs adam_step as its next segment)
 
     def _seg_heads(self):
         self.store.zero_grads()
@@ -635,6 +637,7 @@ class SARNetModel:
         self._upload(x, y)
         self.store.zero_grads()
         self._forward("train"); self._losses_forward(); self._backward()
+        self.store._zeroed_this_step = False     # no adam_step follows: the next forward must not rely on this step's zeroing
         return self._logs_no_l2()
 
     def _logs_no_l2(self):

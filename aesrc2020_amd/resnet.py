@@ -60,9 +60,10 @@ class _BN:
         self.saved = self._b("saved", (4, self.C))
         return off + 2 * n
 
-    def ref(self, R, stats, write):
+    def ref(self, R, stats, write, ginv=1.0):
         """sarBnRef for a consumer kernel.  stats: 'fwd' = batch statistics from the bins (training forward), 'saved' = the
-        saved mean/rstd/scale/shift (backward consumers; inference after fold16), 'bwd' = saved + backward sums."""
+        saved mean/rstd/scale/shift (backward consumers; inference after fold16), 'bwd' = saved + backward sums.  ginv: 1 / (the
+        gradient scale the backward sums carry) -- the fp16 trunk's static scale leaves the parameter gradients here."""
         r = _lib.BnRef()
         r.gamma, r.beta, r.saved = self.gamma.w.data_ptr(), self.beta.w.data_ptr(), self.saved.data_ptr()
         r.bins = self.bins.data_ptr() if stats == "fwd" else None
@@ -70,7 +71,7 @@ class _BN:
         r.moving_mean, r.moving_var = self.moving_mean.w.data_ptr(), self.moving_var.w.data_ptr()
         r.dgamma, r.dbeta = self.gamma.g.data_ptr(), self.beta.g.data_ptr()
         r.inv_n, r.unbias, r.eps, r.momentum = 1.0 / R, R / max(R - 1.0, 1.0), BN_EPS, BN_MOMENTUM
-        r.write = int(write)
+        r.write = int(write); r.ginv = float(ginv)
         return r
 
     def fold16(self):
@@ -95,6 +96,8 @@ class _Conv:
         self.wp_ok = cin % 32 == 0 and cout % 64 == 0
         self.wt = self.wd = (None, None)
         self.use_planes = False
+        # 2-byte trunk (ResNetTrunk sets them): entry-point suffix "bf16" | "f16", torch dtype, 1 / gradient scale
+        self.sfx, self.t16, self.ginv = "bf16", torch.bfloat16, 1.0
 
     def planes(self):
         K = self.k * self.k * self.cin
@@ -110,19 +113,19 @@ class _Conv:
         nf = (self.cout // 32) * (taps * self.cin // 16 + 8) * 512          # bf16 elements
         nd = (self.cin // 32) * (taps * self.cout // 16 + 8) * 512
         b = self.store.bufs
-        self.wf = b.get(self.name + "/wf16", (nf,), torch.bfloat16)
-        self.wd = b.get(self.name + "/wd16", (nd,), torch.bfloat16)
+        self.wf = b.get(self.name + "/wf16", (nf,), self.t16)
+        self.wd = b.get(self.name + "/wd16", (nd,), self.t16)
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
     def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
-        _call("sar_conv2d_bf16", x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+        _call("sar_conv2d_" + self.sfx, x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
               self.k, self.stride, 1, self.pt, self.pl, fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
 
     def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
         """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2, + dy3 when fill == 3
         (written back to `side` for the weight gradient and the other consumers of that gradient); the epilogue leaves the backward
         sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
-        _call("sar_conv2d_bf16", dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
+        _call("sar_conv2d_" + self.sfx, dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
               self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
               e_bins, e_y, e_saved)
 
@@ -130,7 +133,7 @@ class _Conv:
         """Descriptor of this conv's weight gradient on plain operands (include/sarnet.h: sarWgradConv); the trunk batches them
         (ResNetTrunk._wgrad16)."""
         return dict(x=x, dy=dy, dw=self.kernel.g, dbias=self.bias.g if bias_grad else None, B=B, H=self.H, W=self.W, Cin=self.cin,
-                    Ho=self.Ho, Wo=self.Wo, Cout=self.cout, K=self.k, s=self.stride, pt=self.pt, pl=self.pl)
+                    Ho=self.Ho, Wo=self.Wo, Cout=self.cout, K=self.k, s=self.stride, pt=self.pt, pl=self.pl, ginv=self.ginv)
 
     def out_hw(self, H, W):
         if self.padding == "same":
@@ -181,9 +184,15 @@ class ResNetTrunk(Layer):
         stem_c = filters if res_type == "res18" else 64                      # resnet.py:173 vs 191
         if stem_c > 64 or stem_c % 4:
             raise ValueError("stem width %d unsupported (<= 64, multiple of 4)" % stem_c)
-        self.bf16 = _lib.get_trunk_dtype() == "bf16"
+        # 2-byte trunk (csrc/conv_bf16.hip, stem_bf16.hip; compiled for bf16 and for fp16): `bf16` keeps its round-2 name and means
+        # "2-byte storage"; `half` tells the two apart.  fp16 carries a static gradient scale through the trunk (include/sarnet.h)
+        dt = _lib.get_trunk_dtype()
+        self.bf16, self.half = dt in ("bf16", "fp16"), dt == "fp16"
+        self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("bf16", torch.bfloat16)
+        self.gscale = _lib.get_trunk_gscale() if self.half else 1.0
+        self.ginv = 1.0 / self.gscale
         if self.bf16 and (filters != 32 or stem_c not in (32, 64)):
-            raise ValueError("bf16 trunk: res_filters must be 32 (the reference's train.py:54 default; channel counts are powers of two "
+            raise ValueError("2-byte trunk: res_filters must be 32 (the reference's train.py:54 default; channel counts are powers of two "
                              "in [32, 256], the 512-channel stage of F=64 does not fit the LDS patch); got %d" % filters)
         self.stem = _Conv(st, st.auto_name("conv2d"), 7, 1, stem_c, 2, "same")
         self.stem_bn = _BN(st, st.auto_name("batch_normalization"), stem_c)
@@ -206,6 +215,8 @@ class ResNetTrunk(Layer):
             f *= 2
         self.final_bn = _BN(st, st.auto_name("batch_normalization"), cin)
         self.out_c = cin
+        for cv in self._all_convs():
+            cv.sfx, cv.t16, cv.ginv = self.sfx, self.t16, self.ginv
         self.plan(*input_hw)
 
     def plan(self, T, D):
@@ -272,14 +283,17 @@ class ResNetTrunk(Layer):
             off = bn.prepare16(self._arena, off)
 
     def _buf16(self, key, shape):
-        return self.buf(key, shape, torch.bfloat16)
+        return self.buf(key, shape, self.t16)
+
+    def _stem_fn(self, name):
+        return name + "_f16" if self.half else name
 
     def _forward16(self, x, B):
         """Same graph as forward() on bf16 activations: one launch per conv (BN+ReLU of the producer evaluated in the conv's
         patch fill from the statistic bins; statistics of the consumer BN out of the epilogue), stem on the fp32 kernels."""
         self._setup16()
         training = self.store.training
-        _call("sar_conv_pack_weights_bf16", self._pack_table, self._pack_table.shape[0], self._pack_blocks)
+        _call("sar_conv_pack_weights_" + self.sfx, self._pack_table, self._pack_table.shape[0], self._pack_blocks)
         if training:
             if not self.store.zero_at_step_start(self._arena):              # the step-start launch covers it from the second step on
                 _call("sar_fill_f32", self._arena, 0.0, self._arena.numel())
@@ -314,7 +328,7 @@ class ResNetTrunk(Layer):
         H, W = self.out_hw
         self.pre_final = cur
         out = self.buf("out", (B, H, W, self.out_c))
-        _call("sar_bn_apply_bf16_f32", cur, self.final_bn.ref(B * H * W, st, training), out, B * H * W, self.out_c, 1)
+        _call("sar_bn_apply_%s_f32" % self.sfx, cur, self.final_bn.ref(B * H * W, st, training), out, B * H * W, self.out_c, 1)
         return out
 
     def _backward16(self, dy, part):
@@ -323,13 +337,14 @@ class ResNetTrunk(Layer):
             H, W = self.out_hw
             fb = self.final_bn
             R = B * H * W
-            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), torch.bfloat16)
-            _call("sar_bn_bwd_reduce_bf16", dy, 1, self.pre_final, fb.saved, fb.bbins, R, self.out_c, 1)
-            _call("sar_bn_bwd_apply_bf16", dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1)
+            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t16)
+            # the gradient enters the trunk here: fp32 sums and constants, the result times the fp16 build's gradient scale (1 for bf16)
+            _call("sar_bn_bwd_reduce_" + self.sfx, dy, 1, self.pre_final, fb.saved, fb.bbins, R, self.out_c, 1)
+            _call("sar_bn_bwd_apply_" + self.sfx, dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1, self.gscale)
         else:
             g = self._g_part
         stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0), "01": (3, 2)}[part]
-        bf = torch.bfloat16
+        bf, gi = self.t16, self.ginv
         self._wg16 = []
         overlap = part is None and self.WGRAD_OVERLAP
         if overlap and getattr(self, "_wg_stream", None) is None:
@@ -355,7 +370,7 @@ class ResNetTrunk(Layer):
                 blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
             else:
                 p_da1, p_x, p_dsc, p_bn, p_R, p_tap = pend
-                blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True), dy3=p_dsc, side=g,
+                blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True, gi), dy3=p_dsc, side=g,
                                      e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
                 if p_tap is not None:                                 # tests: (block, its g, its da2 copy) + the now materialised gin
                     tap(p_tap[0], p_tap[1], p_tap[2], g)
@@ -375,11 +390,11 @@ class ResNetTrunk(Layer):
             dc1 = self._buf16("b%d_dc1" % n, (B, H2, W2, cout))
             if bn1 is not None:
                 da1 = self._buf16("b%d_da1" % n, (B, H, W, cin))
-                blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
+                blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
                 pend = (da1, x, dsc, bn1, R1, (n, g, da2.clone()) if tap is not None else None)
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
-                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True), res=dsc, side=dc1)
+                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), res=dsc, side=dc1)
                 if tap is not None:
                     tap(n, g, da2, gin)
             red.append(blk["conv1"].wgrad16(blk["a"] if bn1 is not None else x, dc1, B, bias_grad=False))
@@ -435,7 +450,7 @@ class ResNetTrunk(Layer):
             for cls, target in self.WGRAD_CLASSES:
                 ds = [d for d in self._wg16 if self._wgrad_class(d) == cls]
                 if ds:
-                    ps.append(_lib.WgradPlan(ds, target, (2, 2) if cls[2] else (1, 1)))
+                    ps.append(_lib.WgradPlan(ds, target, (2, 2) if cls[2] else (1, 1), self.sfx))
             plans[key] = ps
         if side:
             self._wg_stream.wait_stream(torch.cuda.current_stream())
@@ -459,9 +474,9 @@ class ResNetTrunk(Layer):
         sb, cv = self.stem_bn, self.stem
         training = self.store.training
         if training:
-            _call("sar_stem16_stats", x, cv.kernel.w, cv.bias.w, sb.bins, *conv)
+            _call(self._stem_fn("sar_stem16_stats"), x, cv.kernel.w, cv.bias.w, sb.bins, *conv)
         self.pooled16 = self._buf16("pooled16", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
-        _call("sar_stem16_pool_fwd", x, cv.kernel.w, cv.bias.w, sb.ref(B * H * W, st, training), self.pooled16, self.pool_idx, *conv, *pool)
+        _call(self._stem_fn("sar_stem16_pool_fwd"), x, cv.kernel.w, cv.bias.w, sb.ref(B * H * W, st, training), self.pooled16, self.pool_idx, *conv, *pool)
         return self.pooled16
 
     def _stem_backward16(self, g, B):
@@ -469,10 +484,10 @@ class ResNetTrunk(Layer):
         conv, pool = self._stem_geo(B)
         H, W = self.stem_hw
         sb, cv = self.stem_bn, self.stem
-        ref = sb.ref(B * H * W, "bwd", True)
+        ref = sb.ref(B * H * W, "bwd", True, self.ginv)
         work = self.scratch("stem16_work", (_lib.stem16_wgrad_workspace_bytes(cv.cout) // 4,))
-        _call("sar_stem16_bwd_reduce", g, self.pooled16, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)
-        _call("sar_stem16_wgrad", self.x, cv.kernel.w, cv.bias.w, g, self.pooled16, self.pool_idx, ref, cv.kernel.g, work, *conv, *pool)
+        _call(self._stem_fn("sar_stem16_bwd_reduce"), g, self.pooled16, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)
+        _call(self._stem_fn("sar_stem16_wgrad"), self.x, cv.kernel.w, cv.bias.w, g, self.pooled16, self.pool_idx, ref, cv.kernel.g, work, *conv, *pool)
 
     def _stem_forward(self, x, B):
         T, D = self.in_hw
@@ -556,12 +571,22 @@ class ResNetTrunk(Layer):
     N_PARTS = 3
 
     def bucket_split_names(self):
-        """First parameter of stage 3 and of stage 2 (creation order = flat-buffer order)."""
-        names = []
+        """Where the gradient buckets of a data-parallel step are cut (creation order = flat-buffer order): at conv1's KERNEL of the
+        first block of stage 3 and of stage 2 -- not at that block's bn1.  In the bf16 trunk the BatchNorm backward of a stage's first
+        block is evaluated in the fill of the PREVIOUS block's conv2 input-gradient launch (`pend` in _backward16), i.e. its gamma / beta
+        gradients are written by the NEXT backward part; with the cut at conv1.kernel they belong to that part's bucket, so no bucket is
+        written after its all-reduce has been launched (the cut at bn1.gamma raced with the in-flight collective and dropped
+        the other ranks' contribution)."""
+        return [next(b for b in self.blocks if b["stage"] == stage)["conv1"].kernel.name for stage in (3, 2)]
+
+    def late_bn_params(self):
+        """Names of the parameters whose gradients the bf16 trunk writes one backward part later than their block's (see above)."""
+        out = []
         for stage in (3, 2):
-            blk = next(b for b in self.blocks if b["stage"] == stage)
-            names.append((blk["bn1"].gamma if blk["bn1"] is not None else blk["conv1"].kernel).name)
-        return names
+            bn1 = next(b for b in self.blocks if b["stage"] == stage)["bn1"]
+            if bn1 is not None:
+                out += [bn1.gamma.name, bn1.beta.name]
+        return out
 
     def backward(self, dy, part=None):
         """part None: the whole backward; 0/1/2: one part (see above), "01": parts 0 and 1 in one call; dy only read by part 0 / "01"."""

@@ -73,7 +73,7 @@ def conv_roofline(model, B, iters=10):
         side tensors, epilogue statistics; BatchNorm constants from the last step's saved values, statistics into scratch bins),
         classed by the kernel instantiation rocprofv3 reports: conv_bf16_kernel<WN, NKC, VT, KG>, WN = 2 for 64+ output channels of
         the launch, NKC = source channels / 16 up to 8, VT = taps x 128-channel parts, KG = 2 (eight waves) for 128+ source channels."""
-        BF = torch.bfloat16
+        BF = tr.t16
         H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
         cin, cout = blk["cin"], blk["cout"]
         R1, R2 = B * H * W, B * H2 * W2
@@ -144,7 +144,7 @@ def conv_roofline(model, B, iters=10):
         for cls, target in tr.WGRAD_CLASSES:
             sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
-                plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1))
+                plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1), tr.sfx)
                 nm = ("wgrad3_bf16_kernel<2, 2>" if cls[2] else "wgrad3_bf16_kernel<1, 1>") if cls[0] == 3 else "wgrad1_bf16_kernel"
                 c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["bytes"] += sum(w_[2] for w_ in sel); c["launches"] += 1
@@ -169,7 +169,8 @@ def conv_roofline(model, B, iters=10):
             traffic, tsrc = pj[key]["traffic_bytes"], pj["source"]
     except (OSError, ValueError, KeyError):
         pass
-    math = ("single-pass bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM, fp32 accumulate" if bf16 else
+    math = ("single-pass fp16 MFMA (v_mfma_f32_32x32x16_f16), fp16 activations in HBM, fp32 accumulate" if getattr(tr, "half", False) else
+            "single-pass bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM, fp32 accumulate" if bf16 else
             "bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate" if dom_x3 else
             "fp32 MFMA (v_mfma_f32_32x32x2_f32)")
     if bound == "hbm":
@@ -277,6 +278,8 @@ DTYPES = {
     # --dtype: (trunk storage, conv math, Dense / GRU-projection GEMM math, what the JSON line says)
     "bf16": ("bf16", "bf16x3", "bf16", "bf16 activations / activation gradients of the conv trunk in HBM, single-pass bf16 MFMA (convs and the "
                                        "Dense / GRU-projection GEMMs), fp32 accumulate, statistics, recurrence, losses and master weights"),
+    "fp16": ("fp16", "bf16x3", "bf16", "fp16 activations / activation gradients of the conv trunk in HBM (static gradient scale), single-pass fp16 MFMA in the "
+                                       "convs; bf16 MFMA in the Dense / GRU-projection GEMMs; fp32 accumulate, statistics, recurrence, losses and master weights"),
     "bf16x3": ("fp32", "bf16x3", "fp32", "fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),
     "f32": ("fp32", "fp32", "fp32", "fp32 in HBM, fp32 MFMA"),
 }
@@ -289,7 +292,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--dtype", default=os.environ.get("SAR_BENCH_DTYPE", "bf16"), choices=list(DTYPES),
-                    help="arithmetic of the conv trunk: bf16 (BASELINE configs[1]), bf16x3 (fp32-class), f32")
+                    help="arithmetic of the conv trunk: bf16 (BASELINE configs[1]), fp16 (configs[4]), bf16x3 (fp32-class), f32")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64; cfg5: 32)")
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")

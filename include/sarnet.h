@@ -158,7 +158,7 @@ typedef struct sarBnRef {      /* one BatchNormalization (resnet.py:25) as a con
     float* dgamma; float* dbeta;             /* += when `write` in a backward consumer (nullable) */
     float inv_n, unbias, eps, momentum;      /* 1/rows, rows/(rows-1) */
     int write;                 /* this launch owns the side effects (block 0 performs them) */
-    int pad_;
+    float ginv;                /* dgamma / dbeta += sums * ginv: 1 / (the gradient scale the sums in bbins carry); 1 in the bf16 trunk */
 } sarBnRef;
 int sar_bn_bins(void);
 /* Kernels of many convolutions (fp32 HWIO) -> the bf16 fragment streams sar_conv2d_bf16 reads, one launch.  table = device
@@ -195,14 +195,15 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const v
  * (2) The caller uploads both tables once; sar_conv2d_wgrad_batch_bf16 launches them. */
 typedef struct sarWgradConv {
     const void* x; const void* dy; float* dw; float* dbias;
-    int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl, pad_;    /* geometry as the forward conv (s = stride, pt/pl = TF pads) */
+    int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl;          /* geometry as the forward conv (s = stride, pt/pl = TF pads) */
+    float ginv;                /* dw, dbias += result * ginv: 1 / (the gradient scale dy carries); 0 is read as 1 */
 } sarWgradConv;
 int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int tile_ci, int tile_co, void* convs_out,
                         void* items_out, int max_items, int* n_items, int* launch4);
 int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
 int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
-                          int C, int relu, sarStream_t stream);
+                          int C, int relu, float out_scale, sarStream_t stream);   /* out_scale multiplies the result (1 in the bf16 trunk) */
 /* bbins += the two BatchNorm(+ReLU) backward sums for a gradient that does not come out of a conv epilogue (the final BN) */
 int sar_bn_bwd_reduce_bf16(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
                            sarStream_t stream);
@@ -232,6 +233,37 @@ size_t sar_stem16_wgrad_workspace_bytes(int C0);
 int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
                      const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
                      int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
+
+/* ---- fp16 trunk (BASELINE configs[4] "fp16"; also the better-conditioned 2-byte mode for configs[1]): the SAME kernels compiled
+ * with IEEE fp16 as the 2-byte type (csrc/trunk16.h: SAR_HALF) -- v_mfma_f32_32x32x16_f16, same bytes and matrix rate as bf16,
+ * 2^-11 instead of 2^-8 relative rounding per stored value.  Every `void*` tensor of the functions below is fp16; arguments and
+ * semantics are those of the _bf16 function of the same name (sar_wgrad_plan_bf16, sar_bn_bins and
+ * sar_stem16_wgrad_workspace_bytes are host-side and shared).  fp16 has 5 exponent bits, so activation GRADIENTS travel through
+ * the trunk multiplied by a static scale S: the caller passes out_scale = S where the gradient enters (sar_bn_bwd_apply_f16 at the
+ * final BatchNorm, resnet.py:178) and ginv = 1/S wherever parameter gradients leave (sarBnRef.ginv, sarWgradConv.ginv); everything
+ * in between is linear in the gradient. */
+int sar_conv_pack_weights_f16(const void* table, int n, int total_blocks, sarStream_t stream);
+int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                   int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                   const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
+int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, sarStream_t stream);
+int sar_bn_bwd_apply_f16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
+                         int C, int relu, float out_scale, sarStream_t stream);
+int sar_bn_bwd_reduce_f16(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
+                          sarStream_t stream);
+int sar_bn_apply_f16_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, sarStream_t stream);
+int sar_cast_f32_f16(const float* x, void* y, long n, sarStream_t stream);
+int sar_cast_f16_f32(const void* x, float* y, long n, sarStream_t stream);
+int sar_stem16_stats_f16(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
+                         int pad_top, int pad_left, sarStream_t stream);
+int sar_stem16_pool_fwd_f16(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
+                            int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
+int sar_stem16_bwd_reduce_f16(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                              const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                              int pool_pad_top, int pool_pad_left, sarStream_t stream);
+int sar_stem16_wgrad_f16(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
+                         const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
+                         int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a

@@ -14,8 +14,28 @@ import torch
 from oracle import ops_np as O
 
 pytestmark = pytest.mark.gpu
-BF = torch.bfloat16
+BF, SFX = torch.bfloat16, "bf16"
 TOL_BF, TOL_F32 = 4e-3, 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True, params=["bf16", "fp16"])
+def two_byte_type(request):
+    """The module runs twice: against the bf16 build of the trunk kernels (entry points sar_*_bf16) and against the fp16 build
+    (sar_*_f16: the same sources with IEEE half as the 2-byte type, csrc/trunk16.h).  Inputs are drawn on the grid of the type under
+    test; a stored tensor is within half an ulp of the float64 oracle: 2^-9 (bf16) / 2^-12 (fp16) relative, bounded at twice that of
+    the reference's max-abs."""
+    global BF, SFX, TOL_BF
+    old = (BF, SFX, TOL_BF)
+    BF, SFX, TOL_BF = (torch.float16, "f16", 5e-4) if request.param == "fp16" else (torch.bfloat16, "bf16", 4e-3)
+    yield request.param
+    BF, SFX, TOL_BF = old
+
+
+def bench_shape_only_bf16(shape):
+    """The full-size (B = 64) shapes run once, in the bf16 build; the fp16 build -- the same code with another element type -- takes
+    the small cases and every fourth bench shape."""
+    if SFX == "f16" and shape not in SOME:
+        pytest.skip("full-size shape list: bf16 build only")
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +87,7 @@ class Conv:
         nb = -(-(nf + nd) // 8 // 256)
         tab = torch.tensor([[self.wdev.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout, 0, 0]],
                            dtype=torch.int64, device="cuda")
-        L.call("sar_conv_pack_weights_bf16", tab, 1, nb)
+        L.call("sar_conv_pack_weights_" + SFX, tab, 1, nb)
         self.wq = rbf(self.w)                                   # what the kernels multiply with
 
     def geo(self, H, W):
@@ -81,7 +101,7 @@ class Conv:
         B, H, W, _ = x.shape
         ho, wo, pt, pl = self.geo(H, W)
         y = torch.empty(B, ho, wo, self.cout, dtype=BF, device="cuda")
-        self.L.call("sar_conv2d_bf16", x, None, None, self.wf, bias, res, y, side, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, 1, pt, pl,
+        self.L.call("sar_conv2d_" + SFX, x, None, None, self.wf, bias, res, y, side, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, 1, pt, pl,
                     fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
         return y
 
@@ -89,7 +109,7 @@ class Conv:
         B, ho, wo, _ = dy.shape
         _, _, pt, pl = self.geo(H, W)
         dx = torch.empty(B, H, W, self.cin, dtype=BF, device="cuda")
-        self.L.call("sar_conv2d_bf16", dy, dy2, dy3, self.wd, None, res, dx, side, B, ho, wo, self.cout, H, W, self.cin, self.k, 1, self.s,
+        self.L.call("sar_conv2d_" + SFX, dy, dy2, dy3, self.wd, None, res, dx, side, B, ho, wo, self.cout, H, W, self.cin, self.k, 1, self.s,
                     self.k - 1 - pt, self.k - 1 - pl, fill, fbn, 2 if e_bins is not None else 0, e_bins, e_y, e_saved)
         return dx
 
@@ -101,7 +121,7 @@ class Conv:
     def wgrad(self, x, dy, bias=True, target_blocks=768, tile=(1, 1)):
         """One-convolution plan, added to a non-zero gradient buffer (the kernel accumulates)."""
         dw = torch.ones(self.k, self.k, self.cin, self.cout, device="cuda"); db = torch.zeros(self.cout, device="cuda")
-        plan = self.L.WgradPlan([self.desc(x, dy, dw, db if bias else None)], target_blocks, tile)
+        plan = self.L.WgradPlan([self.desc(x, dy, dw, db if bias else None)], target_blocks, tile, SFX)
         plan.launch()
         self.last_plan = plan
         return dw - 1.0, db
@@ -120,7 +140,7 @@ class BN:
                       mm=torch.zeros(C, device="cuda"), mv=torch.ones(C, device="cuda"), dg=torch.zeros(C, device="cuda"),
                       db=torch.zeros(C, device="cuda"))
 
-    def ref(self, R, stats, write):
+    def ref(self, R, stats, write, ginv=1.0):
         r = self.L.BnRef()
         d = self.d
         r.gamma, r.beta, r.saved = d["gamma"].data_ptr(), d["beta"].data_ptr(), d["saved"].data_ptr()
@@ -128,6 +148,7 @@ class BN:
         r.bbins = d["bbins"].data_ptr() if stats == "bwd" else None
         r.moving_mean, r.moving_var, r.dgamma, r.dbeta = d["mm"].data_ptr(), d["mv"].data_ptr(), d["dg"].data_ptr(), d["db"].data_ptr()
         r.inv_n, r.unbias, r.eps, r.momentum, r.write = 1.0 / R, R / max(R - 1.0, 1.0), self.EPS, self.MOM, int(write)
+        r.ginv = float(ginv)
         return r
 
     def set_fwd_stats(self, x):
@@ -212,6 +233,7 @@ def grid(rng, shape, scale=1.0):
 
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)
 def test_conv_fwd_plain_residual_and_statistics(L, shape):
+    bench_shape_only_bf16(shape)
     B, H, W, Cin, Cout, k, s, pad = shape
     rng = np.random.default_rng(sum(shape[:7]))
     x = grid(rng, (B, H, W, Cin)); w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
@@ -255,6 +277,7 @@ def test_conv_fwd_with_batchnorm_relu_in_the_fill(L, shape):
 
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)
 def test_conv_dgrad_plain_and_batchnorm_sums(L, shape):
+    bench_shape_only_bf16(shape)
     B, H, W, Cin, Cout, k, s, pad = shape
     rng = np.random.default_rng(2 + sum(shape[:7]))
     w = rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cout)
@@ -308,6 +331,7 @@ def test_conv_dgrad_with_batchnorm_backward_in_the_fill(L, shape):
 
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)
 def test_conv_wgrad(L, shape):
+    bench_shape_only_bf16(shape)
     B, H, W, Cin, Cout, k, s, pad = shape
     rng = np.random.default_rng(4 + sum(shape[:7]))
     w = rng.standard_normal((k, k, Cin, Cout))
@@ -354,7 +378,7 @@ def test_conv_wgrad_many_convolutions_in_one_launch(L):
             _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
             dw = torch.zeros(k, k, Cin, Cout, device="cuda"); db = torch.zeros(Cout, device="cuda")
             descs.append(cv.desc(dbf(x), dbf(dy), dw, db)); refs.append((dw_ref, db_ref)); outs.append((dw, db))
-        plan = L.WgradPlan(descs, 64, tile)
+        plan = L.WgradPlan(descs, 64, tile, SFX)
         plan.launch()
         for i, ((dw, db), (dw_ref, db_ref)) in enumerate(zip(outs, refs)):
             check(dw, dw_ref, TOL_F32, "dw of conv %d (k=%d)" % (i, k)); check(db, db_ref, TOL_F32, "db of conv %d (k=%d)" % (i, k))
@@ -369,29 +393,69 @@ def test_batchnorm_passes(L, R, C):
     bn = BN(L, C, rng)
     bn.set_fwd_stats(x)
     out = torch.empty(R, C, device="cuda")
-    L.call("sar_bn_apply_bf16_f32", dbf(x), bn.ref(R, "fwd", True), out, R, C, 1)
+    L.call("sar_bn_apply_%s_f32" % SFX, dbf(x), bn.ref(R, "fwd", True), out, R, C, 1)
     s, h = bn.scale.astype(np.float32).astype(np.float64), bn.shift.astype(np.float32).astype(np.float64)
     check(out, np.maximum(x * s + h, 0), 1e-5, "final bn+relu")
     check(bn.d["saved"], np.stack([bn.mean, bn.rstd, bn.scale, bn.shift]), 1e-5, "saved")
     for f32 in (1, 0):
         bn.d["bbins"].zero_(); bn.d["dg"].zero_(); bn.d["db"].zero_()
         dd = dev(da) if f32 else dbf(da)
-        L.call("sar_bn_bwd_reduce_bf16", dd, f32, dbf(x), bn.d["saved"], bn.d["bbins"], R, C, 1)
+        L.call("sar_bn_bwd_reduce_" + SFX, dd, f32, dbf(x), bn.d["saved"], bn.d["bbins"], R, C, 1)
         S1, S2, _, _ = bn.bwd_sums(da, x)
         tot = val(bn.d["bbins"]).sum(0)
         check(tot[0], S1, 2e-4, "S1"); check(tot[1], S2, 2e-4, "S2")
         g = torch.empty(R, C, dtype=BF, device="cuda")
-        L.call("sar_bn_bwd_apply_bf16", dd, f32, dbf(x), bn.ref(R, "bwd", True), dbf(add), g, R, C, 1)
+        L.call("sar_bn_bwd_apply_" + SFX, dd, f32, dbf(x), bn.ref(R, "bwd", True), dbf(add), g, R, C, 1, 1.0)
         check(g, bn.dx(da, x) + add, TOL_BF, "bn bwd apply")
         check(bn.d["dg"], S2, 2e-4, "dgamma"); check(bn.d["db"], S1, 2e-4, "dbeta")
+
+
+def test_gradient_scale_enters_at_the_final_batchnorm_and_leaves_with_the_parameter_gradients(L):
+    """The fp16 trunk's static gradient scale S (include/sarnet.h, "fp16 trunk"; the entry points of both builds take it): out_scale
+    multiplies the gradient where it enters, sarBnRef.ginv / sarWgradConv.ginv = 1/S divide the parameter gradients where they leave."""
+    rng = np.random.default_rng(5)
+    S = 256.0
+    R, C = 640, 64
+    x = rbf(grid(rng, (R, C)) + 0.3); da = grid(rng, (R, C))
+    bn = BN(L, C, rng)
+    bn.set_fwd_stats(x); bn.set_saved()
+    L.call("sar_bn_bwd_reduce_" + SFX, dev(da), 1, dbf(x), bn.d["saved"], bn.d["bbins"], R, C, 1)
+    g = torch.empty(R, C, dtype=BF, device="cuda")
+    L.call("sar_bn_bwd_apply_" + SFX, dev(da), 1, dbf(x), bn.ref(R, "bwd", True), None, g, R, C, 1, S)
+    check(g, S * bn.dx(da, x), TOL_BF, "scaled gradient")
+    S1, S2, _, _ = bn.bwd_sums(da, x)
+    check(bn.d["dg"], S2, 2e-4, "dgamma of the final BatchNorm: unscaled sums, ginv = 1")
+    # a conv whose gradient operands carry S: the BatchNorm backward in its fill (sums scaled) and its weight gradient
+    B, H, W, Cin, Cout = 3, 13, 5, 64, 64
+    cv = Conv(L, rng.standard_normal((3, 3, Cin, Cout)) / 24.0, 1, "same")
+    _, cache = O.conv2d_fwd(np.zeros((B, H, W, Cin)), cv.wq, None, (1, 1), "same")
+    da2 = grid(rng, (B, H, W, Cout)); yb = rbf(grid(rng, (B, H, W, Cout)) + 0.2)
+    bn2 = BN(L, Cout, rng)
+    bn2.set_fwd_stats(yb); bn2.set_saved(); bn2.set_bwd_stats(S * da2, yb)
+    ref_dx = O.conv2d_bwd(rbf(S * bn2.dx(da2, yb)), cache)[0]
+    dx = cv.dgrad(dbf(S * da2), H, W, dy2=dbf(yb), fill=2, fbn=bn2.ref(bn2.n, "bwd", True, 1.0 / S))
+    check(dx, ref_dx, TOL_BF, "dx (scaled)")
+    check(bn2.d["dg"], bn2.S2 / S, 1e-5, "dgamma = scaled sums * ginv"); check(bn2.d["db"], bn2.S1 / S, 1e-5, "dbeta")
+    xw = rbf(grid(rng, (B, H, W, Cin)) + 0.4); dy = grid(rng, (B, H, W, Cout))
+    _, cache = O.conv2d_fwd(xw, cv.wq, np.zeros(Cout), (1, 1), "same")
+    _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+    dw = torch.zeros(3, 3, Cin, Cout, device="cuda"); db = torch.zeros(Cout, device="cuda")
+    L.WgradPlan([dict(cv.desc(dbf(xw), dbf(S * dy), dw, db), ginv=1.0 / S)], 8, (2, 2), SFX).launch()
+    check(dw, dw_ref, TOL_F32, "dw"); check(db, db_ref, TOL_F32, "db")
+    cv1 = Conv(L, rng.standard_normal((1, 1, Cin, Cout)), 1, "valid")
+    _, cache = O.conv2d_fwd(xw, cv1.wq, np.zeros(Cout), (1, 1), "valid")
+    _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+    dw1 = torch.zeros(1, 1, Cin, Cout, device="cuda"); db1 = torch.zeros(Cout, device="cuda")
+    L.WgradPlan([dict(cv1.desc(dbf(xw), dbf(S * dy), dw1, db1), ginv=1.0 / S)], 8, (1, 1), SFX).launch()
+    check(dw1, dw_ref, TOL_F32, "dw (1x1)"); check(db1, db_ref, TOL_F32, "db (1x1)")
 
 
 def test_casts(L):
     rng = np.random.default_rng(0)
     a = rng.standard_normal(8 * 1000 + 8).astype(np.float32)
     y = torch.empty(a.size, dtype=BF, device="cuda")
-    L.call("sar_cast_f32_bf16", dev(a), y, a.size)
+    L.call("sar_cast_f32_" + SFX, dev(a), y, a.size)
     assert torch.equal(y.cpu(), torch.tensor(a).to(BF))
     z = torch.empty(a.size, device="cuda")
-    L.call("sar_cast_bf16_f32", y, z, a.size)
+    L.call("sar_cast_%s_f32" % SFX, y, z, a.size)
     assert torch.equal(z.cpu(), torch.tensor(a).to(BF).float())

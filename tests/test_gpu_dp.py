@@ -52,7 +52,9 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", s
         torch.cuda.synchronize()
         out.append(dict(p_before=p_before, grads=model.store.grads.detach().cpu().numpy().copy(),
                         p_after=model.store.params.detach().cpu().numpy().copy(), loss=logs["loss"]))
-    q.put((rank, out, isinstance(model.graph, dict) and sorted(model.graph)))
+    offs = {r.name: (r.offset, r.size) for r in model.store.refs}
+    late = [offs[n] for n in model.trunk.late_bn_params()]
+    q.put((rank, out, isinstance(model.graph, dict) and sorted(model.graph), late))
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()
 
@@ -75,7 +77,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
     [p.start() for p in ps]
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
-    (_, r0, g0), (_, r1, g1) = res
+    (_, r0, g0, late), (_, r1, g1, _) = res
     assert g0 == GRAPHS[segments] and g1 == g0                 # steps 2.. ran from the captured graphs of the chosen form
     from aesrc2020_amd import _lib
     kw = KW16 if mode == "bf16" else KW
@@ -107,6 +109,14 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         # would show as O(1))
         err = float(np.linalg.norm(a["grads"] - gsum) / np.linalg.norm(gsum))
         assert err < tol, (i, err)
+        # per parameter: the gamma / beta gradients of the first BatchNorm of stages 3 and 2, which the bf16 trunk writes one backward
+        # part later than the rest of their block (ResNetTrunk.bucket_split_names) -- reduced after an early all-reduce they would come
+        # back without any rank's contribution (the whole-vector L2 above cannot see two missing BatchNorm vectors)
+        assert len(late) == 4
+        for off, size in late:
+            ga, gs = a["grads"][off:off + size], gsum[off:off + size]
+            e1 = float(np.linalg.norm(ga - gs) / np.linalg.norm(gs))
+            assert e1 < (6e-1 if mode == "bf16" else 5e-2) and np.linalg.norm(ga) > 0.5 * np.linalg.norm(gs), (i, off, e1)
         assert not np.array_equal(a["p_before"], a["p_after"])
     _lib.set_gemm_math("fp32")
 

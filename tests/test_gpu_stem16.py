@@ -14,8 +14,18 @@ import torch
 from oracle import ops_np as O
 
 pytestmark = pytest.mark.gpu
-BF = torch.bfloat16
+BF, SFX, TOL_ST = torch.bfloat16, "", 4e-3
 EPS, MOM = 1e-3, 0.99
+
+
+@pytest.fixture(scope="module", autouse=True, params=["bf16", "fp16"])
+def two_byte_type(request):
+    """Both builds of csrc/stem_bf16.hip: bf16 (sar_stem16_*) and fp16 (sar_stem16_*_f16, the same source with IEEE half)."""
+    global BF, SFX, TOL_ST
+    old = (BF, SFX, TOL_ST)
+    BF, SFX, TOL_ST = (torch.float16, "_f16", 5e-4) if request.param == "fp16" else (torch.bfloat16, "", 4e-3)
+    yield request.param
+    BF, SFX, TOL_ST = old
 
 
 @pytest.fixture(scope="module")
@@ -62,6 +72,7 @@ def run_case(L, B, T, D, C0, seed, train=True):
         r.bbins = d["bbins"].data_ptr() if stats == "bwd" else None
         r.moving_mean, r.moving_var, r.dgamma, r.dbeta = d["mm"].data_ptr(), d["mv"].data_ptr(), d["dg"].data_ptr(), d["db"].data_ptr()
         r.inv_n, r.unbias, r.eps, r.momentum, r.write = 1.0 / R, R / max(R - 1.0, 1.0), EPS, MOM, int(write)
+        r.ginv = 1.0
         return r
 
     conv = (B, T, D, Ho, Wo, C0, pt, pl); pool = (Hp, Wp, ppt, ppl)
@@ -82,19 +93,19 @@ def run_case(L, B, T, D, C0, seed, train=True):
     # ---- kernels forward
     pooled = torch.zeros(B, Hp, Wp, C0, dtype=BF, device="cuda"); idx = torch.full((B, Hp, Wp, C0), 99, dtype=torch.uint8, device="cuda")
     if train:
-        L.call("sar_stem16_stats", d["x"], d["w"], d["b"], d["bins"], *conv)
+        L.call("sar_stem16_stats" + SFX, d["x"], d["w"], d["b"], d["bins"], *conv)
         sums = d["bins"].double().sum(0).cpu().numpy()
         assert rel(sums[0], y.sum((0, 1, 2))) < 1e-4 and rel(sums[1], (y * y).sum((0, 1, 2))) < 1e-4
-        L.call("sar_stem16_pool_fwd", d["x"], d["w"], d["b"], ref("fwd"), pooled, idx, *conv, *pool)
+        L.call("sar_stem16_pool_fwd" + SFX, d["x"], d["w"], d["b"], ref("fwd"), pooled, idx, *conv, *pool)
         sv = d["saved"].double().cpu().numpy()
         assert rel(sv[0], mu) < 1e-4 and rel(sv[1], 1 / np.sqrt(var + EPS)) < 1e-4
         assert rel(d["mm"], (1 - MOM) * mu) < 1e-4 and rel(d["mv"], MOM + (1 - MOM) * var * R / (R - 1)) < 1e-4
     else:
         rstd = 1.0 / np.sqrt(var + EPS)
         d["saved"].copy_(dev(np.stack([mu, rstd, gamma * rstd, beta - mu * gamma * rstd])))
-        L.call("sar_stem16_pool_fwd", d["x"], d["w"], d["b"], ref("saved", False), pooled, idx, *conv, *pool)
+        L.call("sar_stem16_pool_fwd" + SFX, d["x"], d["w"], d["b"], ref("saved", False), pooled, idx, *conv, *pool)
     torch.cuda.synchronize()
-    assert rel(pooled, pooled_ref) <= 4e-3
+    assert rel(pooled, pooled_ref) <= TOL_ST
     # argmax slots: equal wherever the oracle's best and second-best window values are clearly apart
     xp = np.pad(a, ((0, 0), (ppt, 2), (ppl, 2), (0, 0)), constant_values=-np.inf)
     cols = O._im2col(xp, 3, 3, 2, 2, Hp, Wp).reshape(B, Hp, Wp, 9, C0)
@@ -114,12 +125,12 @@ def run_case(L, B, T, D, C0, seed, train=True):
     _, dw_ref, _ = O.conv2d_bwd(dy, ccache)
     gd = torch.tensor(g, dtype=torch.float32).to(BF).cuda()
     work = torch.empty(L.stem16_wgrad_workspace_bytes(C0) // 4, device="cuda")
-    L.call("sar_stem16_bwd_reduce", gd, pooled, idx, d["x"], d["w"], d["b"], ref("bwd"), work, *conv, *pool)
+    L.call("sar_stem16_bwd_reduce" + SFX, gd, pooled, idx, d["x"], d["w"], d["b"], ref("bwd"), work, *conv, *pool)
     bs = d["bbins"].double().sum(0).cpu().numpy()
     assert rel(bs[0], dbeta) < 2e-3, rel(bs[0], dbeta)
     assert rel(bs[1], dgamma) < 1e-2, rel(bs[1], dgamma)
     dw = torch.ones(7, 7, 1, C0, device="cuda")
-    L.call("sar_stem16_wgrad", d["x"], d["w"], d["b"], gd, pooled, idx, ref("bwd"), dw, work, *conv, *pool)
+    L.call("sar_stem16_wgrad" + SFX, d["x"], d["w"], d["b"], gd, pooled, idx, ref("bwd"), dw, work, *conv, *pool)
     torch.cuda.synchronize()
     e = rel(dw - 1.0, dw_ref)
     assert e < 1e-2, e

@@ -290,3 +290,25 @@ def test_gradient_buckets_follow_backward_order():
     assert sorted(dp.bounds) == [(0, 768), (768, 2048), (2048, 3072), (3072, 4096)]
     assert parallel.DataParallel(st).bounds == [(3072, 4096), (0, 3072)]
     assert parallel.DataParallel(st, trunk_splits=["no_such_param"]).bounds == [(3072, 4096), (0, 3072)]
+
+
+def test_trunk_bucket_cuts_keep_late_batchnorm_gradients_in_the_later_bucket():
+    """the bf16 trunk writes the gamma / beta gradients of a stage's first BatchNorm one backward part later than the
+    rest of that block (they are evaluated in the previous block's conv2 input-gradient fill).  The data-parallel bucket cuts must put
+    them into the bucket that is reduced AFTER that later part: the cuts are conv1 kernels, and every late parameter lies in front."""
+    from aesrc2020_amd.engine import ParamStore, store_scope
+    from aesrc2020_amd.resnet import ResNetTrunk
+    for res in ("res18", "res34"):
+        st = ParamStore(seed=0)
+        with store_scope(st):
+            tr = ResNetTrunk(res, 32, (100, 80))
+        order = {r.name: i for i, r in enumerate(st.refs)}
+        cuts = tr.bucket_split_names()
+        assert len(cuts) == 2 and all(c.endswith("/kernel") for c in cuts) and order[cuts[0]] > order[cuts[1]]
+        late = tr.late_bn_params()
+        assert len(late) == 4
+        for k, stage_cut in zip((late[0:2], late[2:4]), cuts):
+            for name in k:
+                assert order[name] < order[stage_cut]                      # in the bucket below the cut: reduced one part later
+                # and directly below it: nothing but this BatchNorm's own parameters lies between
+                assert order[stage_cut] - order[name] <= 2
