@@ -430,7 +430,13 @@ struct WgConv {                 // device table row, written by sar_wgrad_plan_b
     float ginv;                 // the flush multiplies by it: 1 / (gradient scale dy carries; 1 in the bf16 build)
 };
 static_assert(sizeof(WgConv) <= 128, "WgConv must fit its 128-byte table row");
-struct WgItem { int conv, ci0, co0, c_first, c_count, single, pad0_, pad1_; };   // 32 bytes
+struct WgItem { int conv, ci0, co0, c_first, c_count, single, slab, pad1_; };    // 32 bytes; slab: partial-tile slot of a non-single item
+// Flush of an item whose tile is shared with other items (its convolution's pixels are split over several runs): the raw partial
+// tile goes to the item's own slab of a workspace -- plain 16-byte stores in accumulator-register order (1 KiB per wave-instruction) --
+// and wgrad_reduce_kernel, launched behind, sums a tile's slabs in a fixed order and adds the result into the gradient.  Round 2 added
+// every partial tile with fp32 atomics: 40 % of the 64-wide launch (147 KB of device-scope atomics per item, executed behind the
+// fabric) and an order-dependent sum.
+struct WgTile { int conv, ci0, co0, first, count, pad0_, pad1_, pad2_; };          // 32 bytes: the slices of one gradient tile: slices[first .. first+count)
 __device__ uint4 g_zero_page[64];
 constexpr int WG_NBUF = 4;      // 1x1: chunk buffers per wave (three chunks in flight behind the one being multiplied)
 constexpr int WG_TAB_MAX = 6144; // 3x3: positions in an item's source-offset table (24 KB of LDS at most)
@@ -441,7 +447,7 @@ constexpr int WG_NW1 = 4;       // 1x1: independent waves per block, each on its
 // block's four waves split the item's chunks and never synchronise inside the loop: each wave runs its own DMA ring (8 KB per
 // chunk: dY [64][32] | x [64][32]) and waits on its own vmcnt; the four 32 x 32 tiles are merged in LDS at the end.
 __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned char* __restrict__ convs, const WgItem* __restrict__ items,
-                                                                 const uint4* __restrict__ zero) {
+                                                                 const uint4* __restrict__ zero, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr unsigned BUF = 8192;
     const WgItem it = items[blockIdx.x];
@@ -531,8 +537,7 @@ __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned
 #pragma unroll
         for (int k = 0; k < WG_NW1; ++k) s += reinterpret_cast<const float*>(smem + (size_t)k * WG_NBUF * BUF)[e];
         float* o = dwp + (size_t)(ci0 + (e >> 5)) * Cout + co0 + (e & 31);
-        s *= ginv;
-        if (it.single) *o += s; else atomicAdd(o, s);
+        if (it.single) *o += s * ginv; else slab[(size_t)it.slab * 1024 + e] = s;   // slab: natural [32][32] order, raw
     }
     if (do_bias) {
         bsum += __shfl_xor(bsum, 32, 64);
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned
 // Per chunk the block issues 4*TCO DMA instructions for the gradient rows and TCI per new 16-position group, dealt round-robin to
 // the nine waves; every wave issues the same count (the surplus repeat the last one), so the hand-counted vmcnt stays three
 // scalars: the instruction counts of the chunks in flight.
-struct Wg3Args { const unsigned char* convs; const WgItem* items; const uint4* zero; unsigned np; int nbuf; int tab_pos; };
+struct Wg3Args { const unsigned char* convs; const WgItem* items; const uint4* zero; unsigned np; int nbuf; int tab_pos; float* slab; };
 
 template <int TCI, int TCO>
 __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
@@ -737,8 +742,12 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[i][j][r] * ginv;
                 } else {
+                    // slab[item][tap][i][j][q][lane] x float4: the accumulator registers as they are (rows 8q + 4(lane/32) + 0..3, column lane%32)
+                    float4* sl = reinterpret_cast<float4*>(a.slab) + ((((size_t)it.slab * 9 + w) * TCI + i) * TCO + j) * 256 + lane;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) atomicAdd(o + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout, acc[i][j][r] * ginv);
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_nontemporal_store(f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]},
+                                                    reinterpret_cast<f32x4*>(sl + q * 64));
                 }
             }
         if (do_bias) {
@@ -752,6 +761,44 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP(4); TSTAMP(15);
+}
+
+// Sum of the partial tiles of every multi-slice gradient tile, in slice order (deterministic), added into the gradient: grid
+// (tiles, 32 x 32 sub-tiles of a tile = taps x TCI x TCO), 256 threads x float4.  K3: slabs in accumulator-register order (above).
+template <bool K3>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const unsigned char* __restrict__ convs, const WgTile* __restrict__ tiles,
+                                                           const int* __restrict__ slices, const float* __restrict__ slab, int tci, int tco) {
+    const WgTile t = tiles[blockIdx.x];
+    const WgConv* cvp = reinterpret_cast<const WgConv*>(convs + (size_t)t.conv * 128);
+    const int Cin = cvp->g.Cin, Cout = cvp->Cout;
+    const float ginv = cvp->ginv;
+    float* dwp = cvp->dw;
+    const int sub = blockIdx.y, nsub = gridDim.y, tid = threadIdx.x;
+    const float4* base = reinterpret_cast<const float4*>(slab) + (size_t)sub * 256 + tid;
+    const size_t per = (size_t)nsub * 256;                                           // float4 per slab
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+    const int* sl = slices + t.first;
+    int s = 0;
+    for (; s + 3 < t.count; s += 4) {                                                 // four slabs in flight
+        const float4 v0 = base[sl[s] * per], v1 = base[sl[s + 1] * per], v2 = base[sl[s + 2] * per], v3 = base[sl[s + 3] * per];
+        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;   a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;   a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+    }
+    for (; s < t.count; ++s) { const float4 v0 = base[sl[s] * per]; a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w; }
+    const float r[4] = {((a0.x + a1.x) + (a2.x + a3.x)) * ginv, ((a0.y + a1.y) + (a2.y + a3.y)) * ginv,
+                        ((a0.z + a1.z) + (a2.z + a3.z)) * ginv, ((a0.w + a1.w) + (a2.w + a3.w)) * ginv};
+    if constexpr (K3) {
+        const int j = sub % tco, i = (sub / tco) % tci, w = sub / (tco * tci);
+        const int q = tid >> 6, lane = tid & 63, col = lane & 31, row0 = 8 * q + 4 * (lane >> 5);
+        float* o = dwp + ((size_t)w * Cin + t.ci0 + i * 32 + row0) * Cout + t.co0 + j * 32 + col;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[(size_t)k * Cout] += r[k];
+    } else {
+        float4* o = reinterpret_cast<float4*>(dwp + (size_t)(t.ci0 + (tid >> 3)) * Cout + t.co0 + (tid & 7) * 4);
+        float4 v = *o;
+        v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
+        *o = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
@@ -1030,8 +1077,9 @@ struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; in
 // tile_ci / tile_co (1 or 2): 32-channel planes per block on the input / output side (3x3 only; every Cin must be a multiple
 // of 32*tile_ci, every Cout of 32*tile_co).  Runs of chunks are cut so that the launch has about `target_blocks` items.
 int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int tile_ci, int tile_co, void* convs_out, void* items_out,
-                        int max_items, int* n_items, int* launch4) {
-    if (convs == nullptr || n < 1 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || launch4 == nullptr)
+                        int max_items, int* n_items, int* launch4, void* tiles_out, int* slices_out) {
+    if (convs == nullptr || n < 1 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || launch4 == nullptr ||
+        tiles_out == nullptr || slices_out == nullptr)
         return SAR_EINVAL;
     const int K = convs[0].K;
     if (K != 1 && K != 3) return SAR_EINVAL;
@@ -1115,6 +1163,33 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
         items[b + 1] = it;
     }
     *n_items = ni;
+    // partial-tile slabs and the reduction table: an item that shares its tile gets the next slab; tiles are listed in (convolution,
+    // channel tile) order with their slices in pixel order, so the reduction's sum order is fixed by the plan
+    {
+        WgTile* tiles = static_cast<WgTile*>(tiles_out);
+        int nslab = 0, ntile = 0, nsl = 0;
+        for (int a = 0; a < ni; ++a) items[a].slab = items[a].single ? -1 : nslab++;
+        for (int i = 0; i < n; ++i)
+            for (int ci = 0; ci < convs[i].Cin; ci += 32 * tile_ci)
+                for (int cc = 0; cc < convs[i].Cout; cc += 32 * tile_co) {
+                    WgTile t;
+                    memset(&t, 0, sizeof(t));
+                    t.conv = i; t.ci0 = ci; t.co0 = cc; t.first = nsl;
+                    // (quadratic in the worst case, a few thousand items: microseconds, once per plan)
+                    int last_first = -1;
+                    for (;;) {                                                   // slices in increasing c_first
+                        int best = -1;
+                        for (int a = 0; a < ni; ++a)
+                            if (!items[a].single && items[a].conv == i && items[a].ci0 == ci && items[a].co0 == cc && items[a].c_first > last_first &&
+                                (best < 0 || items[a].c_first < items[best].c_first)) best = a;
+                        if (best < 0) break;
+                        slices_out[nsl++] = items[best].slab; last_first = items[best].c_first;
+                    }
+                    t.count = nsl - t.first;
+                    if (t.count > 0) tiles[ntile++] = t;
+                }
+        launch4[4] = ntile; launch4[5] = nslab; launch4[6] = (K == 3 ? 9 : 1) * tile_ci * tile_co * 1024; launch4[7] = 0;
+    }
     if (K == 3) {
         tab_pos = (tab_pos + 127) & ~127;
         launch4[0] = 512 + tab_pos * 4 + (la_max + 1) * tile_co * 4096 + tile_ci * np * 64; launch4[1] = np; launch4[2] = la_max + 1;
@@ -1129,9 +1204,12 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
 
 // Weight gradients of many convolutions, one launch: tables and launch4 from sar_wgrad_plan_bf16 (tables uploaded by the caller),
 // K = kernel size of the planned convolutions.  dw += x^T (*) dy per tap, dbias (where given) += column sums of dy.
-int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, hipStream_t stream) {
+int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
+                                     const int* slices_dev, float* slab, hipStream_t stream) {
     if (convs_dev == nullptr || items_dev == nullptr || launch4 == nullptr || n_items < 1 || (K != 1 && K != 3)) return SAR_EINVAL;
     const int lds_bytes = launch4[0], np = launch4[1], nbuf = launch4[2], tci = launch4[3] >> 4, tco = launch4[3] & 15;
+    const int n_tiles = launch4[4], n_slabs = launch4[5];
+    if (n_tiles < 0 || n_slabs < 0 || (n_slabs > 0 && (n_tiles < 1 || tiles_dev == nullptr || slices_dev == nullptr || slab == nullptr))) return SAR_EINVAL;
     if (lds_bytes <= 0 || lds_bytes > 160 * 1024 || tci < 1 || tci > 2 || tco < 1 || tco > 2) return SAR_EINVAL;
     static const uint4* zero_page = nullptr;
     if (zero_page == nullptr) {
@@ -1142,19 +1220,26 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
     if (K == 3) {
         const int tab_bytes = lds_bytes - (512 + nbuf * tco * 4096 + tci * np * 64);
         if (!pow2(np) || np < 512 || nbuf < 2 || nbuf > 4 || tab_bytes < 0 || tab_bytes % 512 || tab_bytes > WG_TAB_MAX * 4) return SAR_EINVAL;
-        Wg3Args a{static_cast<const unsigned char*>(convs_dev), static_cast<const WgItem*>(items_dev), zero_page, (unsigned)np, nbuf, tab_bytes / 4};
+        if (launch4[6] != 9 * tci * tco * 1024) return SAR_EINVAL;
+        Wg3Args a{static_cast<const unsigned char*>(convs_dev), static_cast<const WgItem*>(items_dev), zero_page, (unsigned)np, nbuf, tab_bytes / 4, slab};
         typedef void (*k3_t)(const Wg3Args);
         static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2>}};
         static bool attr3[2][2];
         const k3_t kern = k3[tci - 1][tco - 1];
         if (!attr3[tci - 1][tco - 1]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr3[tci - 1][tco - 1] = true; }
         hipLaunchKernelGGL(kern, dim3(n_items), dim3(576), lds_bytes, stream, a);
+        if (n_tiles > 0)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(n_tiles, 9 * tci * tco), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
+                               static_cast<const WgTile*>(tiles_dev), slices_dev, slab, tci, tco);
     } else {
         if (tci != 1 || tco != 1 || nbuf != WG_NBUF || lds_bytes != WG_NW1 * WG_NBUF * 8192) return SAR_EINVAL;
         static bool attr1 = false;
         if (!attr1) { if (!allow_lds(wgrad1_bf16_kernel, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
         hipLaunchKernelGGL(wgrad1_bf16_kernel, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
-                           static_cast<const WgItem*>(items_dev), zero_page);
+                           static_cast<const WgItem*>(items_dev), zero_page, slab);
+        if (n_tiles > 0)
+            hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(n_tiles, 1), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
+                               static_cast<const WgTile*>(tiles_dev), slices_dev, slab, 1, 1);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;

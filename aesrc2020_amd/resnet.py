@@ -189,8 +189,8 @@ class ResNetTrunk(Layer):
         dt = _lib.get_trunk_dtype()
         self.bf16, self.half = dt in ("bf16", "fp16"), dt == "fp16"
         self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("bf16", torch.bfloat16)
-        self.gscale = _lib.get_trunk_gscale() if self.half else 1.0
-        self.ginv = 1.0 / self.gscale
+        self._gscale_cfg = _lib.get_trunk_gscale() if self.half else 1.0      # 0: automatic, 64 x batch (_set_gscale)
+        self.gscale = self.ginv = 1.0
         if self.bf16 and (filters != 32 or stem_c not in (32, 64)):
             raise ValueError("2-byte trunk: res_filters must be 32 (the reference's train.py:54 default; channel counts are powers of two "
                              "in [32, 256], the 512-channel stage of F=64 does not fit the LDS patch); got %d" % filters)
@@ -216,8 +216,17 @@ class ResNetTrunk(Layer):
         self.final_bn = _BN(st, st.auto_name("batch_normalization"), cin)
         self.out_c = cin
         for cv in self._all_convs():
-            cv.sfx, cv.t16, cv.ginv = self.sfx, self.t16, self.ginv
+            cv.sfx, cv.t16 = self.sfx, self.t16
         self.plan(*input_hw)
+
+    def _set_gscale(self, B):
+        """fp16 trunk: the static gradient scale for batches of B utterances (a power of two; see _lib._TRUNK_GSCALE)."""
+        s = self._gscale_cfg if self._gscale_cfg > 0 else float(2 ** int(round(np.log2(64.0 * max(B, 1)))))
+        if s != self.gscale:
+            self.gscale, self.ginv = s, 1.0 / s
+            for cv in self._all_convs():
+                cv.ginv = self.ginv
+            self._wgplans = None                                             # the planned weight-gradient tables carry ginv
 
     def plan(self, T, D):
         """Spatial sizes of every layer for a (T, D) input.  Parameters do not depend on them, so an inference model
@@ -292,6 +301,8 @@ class ResNetTrunk(Layer):
         """Same graph as forward() on bf16 activations: one launch per conv (BN+ReLU of the producer evaluated in the conv's
         patch fill from the statistic bins; statistics of the consumer BN out of the epilogue), stem on the fp32 kernels."""
         self._setup16()
+        if self.half:
+            self._set_gscale(B)
         training = self.store.training
         _call("sar_conv_pack_weights_" + self.sfx, self._pack_table, self._pack_table.shape[0], self._pack_blocks)
         if training:

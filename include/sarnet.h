@@ -198,9 +198,15 @@ typedef struct sarWgradConv {
     int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl;          /* geometry as the forward conv (s = stride, pt/pl = TF pads) */
     float ginv;                /* dw, dbias += result * ginv: 1 / (the gradient scale dy carries); 0 is read as 1 */
 } sarWgradConv;
+/* Flush (round 3): an item that shares its gradient tile with other items stores its raw partial tile into its own slab of a caller-owned
+ * workspace (plain 16-byte stores) and a reduction launched by the same call sums a tile's slabs in the plan's fixed order and adds the
+ * result into dw -- no atomics on dw, a deterministic sum.  The plan therefore also returns tiles_out (rows of 32 bytes, at most one per
+ * (convolution, channel tile)), slices_out (ints, at most one per item) and launch4[4..6] = {reduction tiles, slabs, floats per slab};
+ * launch4 has EIGHT ints.  The caller uploads both tables and allocates slab = launch4[5] * launch4[6] floats. */
 int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int tile_ci, int tile_co, void* convs_out,
-                        void* items_out, int max_items, int* n_items, int* launch4);
-int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, sarStream_t stream);
+                        void* items_out, int max_items, int* n_items, int* launch4, void* tiles_out, int* slices_out);
+int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
+                                const int* slices_dev, float* slab, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
 int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
                           int C, int relu, float out_scale, sarStream_t stream);   /* out_scale multiplies the result (1 in the bf16 trunk) */
@@ -246,7 +252,8 @@ int sar_conv_pack_weights_f16(const void* table, int n, int total_blocks, sarStr
 int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
-int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, sarStream_t stream);
+int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
+                               const int* slices_dev, float* slab, sarStream_t stream);
 int sar_bn_bwd_apply_f16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
                          int C, int relu, float out_scale, sarStream_t stream);
 int sar_bn_bwd_reduce_f16(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,

@@ -1,16 +1,20 @@
-"""Whole-graph tests of the bf16 trunk mode (SAR_TRUNK_DTYPE=bf16 / _lib.set_trunk_dtype("bf16"), BASELINE configs[1] "bf16").
+"""Whole-graph tests of the 2-byte trunk modes: "fp16" (the bench default since round 3) and "bf16" (_lib.set_trunk_dtype).
 
-The kernels themselves are held to the oracle bit-tightly in tests/test_gpu_bf16.py (inputs on the bf16 grid).  Here the
-question is what 2-byte activations cost end to end, so the float64 oracle (oracle/model_torch.py) is the reference and the
-tolerances are the measured bf16 deviation with head-room (DESIGN.md section 5 records the numbers):
-  accent / disc probabilities  <= 1e-1 absolute  (measured 3-5e-2: s=30 margin heads amplify the 2 % feature noise that 34
-                                                  bf16 layers accumulate; the fp32-storage modes hold 1e-3)
-  per-utterance CTC loss       <= 5e-2 relative
-  parameter gradients          cosine >= 0.90 per tensor that carries >= 1e-3 of the largest gradient norm (measured: conv kernels
-                               and everything behind the trunk 0.97-0.999; the lowest are BatchNorm beta / gamma of the trunk,
-                               0.94-0.96: near-cancelling sums over all pixels, and the s=30 heads turn a 2-3e-2 output
-                               deviation into a ~10 % different dL/dlogits to begin with)
-The wiring of the bf16 trunk is checked separately and tightly against a rounding-aware oracle (tests/test_gpu_bf16_trunk.py).
+The kernels themselves are held to the oracle bit-tightly in tests/test_gpu_bf16.py (inputs on the 2-byte grid, both builds).  Here the
+question is what 2-byte activations cost end to end, so the float64 oracle (oracle/model_torch.py) is the reference and the bounds are
+TWICE the measured deviation of each recipe (tools/numerics_table.py, DESIGN.md section 5c records the table):
+
+                                   fp16 trunk (measured)      bound     bf16 trunk (measured)     bound
+  accent probabilities, max |d|    6.2e-3 .. 1.0e-2           2e-2      2.3e-2 .. 2.9e-2          6e-2
+  disc probabilities, max |d|      3.3e-3 .. 2.1e-2           4e-2      1.0e-2 .. 6.0e-2          1.2e-1
+  per-utterance CTC loss, rel.     1.3e-3 .. 2.0e-3           4e-3      2.2e-3 .. 3.9e-3          8e-3
+  parameter-gradient cosine, min   0.990 (BatchNorm), 0.995   0.98      0.93 (BatchNorm), 0.957   0.90
+  flat gradient, relative L2       7.0e-2 .. 8.1e-2           1.6e-1    1.9e-1 .. 2.4e-1          4.5e-1
+
+Why single-pass 2-byte operands cannot reach the north-star's 1e-3: every conv rounds both operands to 2^-12 (fp16) / 2^-9 (bf16)
+relative; 34 layers accumulate sqrt(34) x sqrt(2) x 2^-12/sqrt(3) ~ 1.2e-3 (fp16) on the trunk output, and the sequence layers plus
+the s = 30 / gamma = 256 heads amplify that 3-5x.  The 1e-3 tolerance belongs to the fp32-class modes (bf16x3: 1e-5 .. 4e-5).
+The wiring of the 2-byte trunk is checked separately and tightly against a rounding-aware oracle (tests/test_gpu_bf16_trunk.py).
 """
 import numpy as np
 import pytest
@@ -20,7 +24,9 @@ from oracle import model_torch as MT
 
 pytestmark = pytest.mark.gpu
 
-COS_MIN = 0.90
+# per recipe: max |d prob| accent, disc; CTC relative; min gradient cosine; flat-gradient relative L2
+BOUNDS = {"fp16": dict(accent=2e-2, disc=4e-2, ctc=4e-3, cos=0.98, l2=1.6e-1),
+          "bf16": dict(accent=6e-2, disc=1.2e-1, ctc=8e-3, cos=0.90, l2=4.5e-1)}
 
 CASES = {
     "cfg2_gvlad_arcface": dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad",
@@ -62,10 +68,12 @@ def cosine(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
 
 
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
 @pytest.mark.parametrize("case", list(CASES))
-def test_bf16_trunk_forward_backward_against_oracle(case):
-    cfg, ref, model, _, batch = build(CASES[case], "bf16")
-    assert model.trunk.bf16
+def test_bf16_trunk_forward_backward_against_oracle(case, mode):
+    cfg, ref, model, _, batch = build(CASES[case], mode)
+    bnd = BOUNDS[mode]
+    assert model.trunk.bf16 and model.trunk.half == (mode == "fp16")
     out, total, parts, G = ref.forward_backward(batch)
     from aesrc2020_amd import _lib
     _lib.set_gemm_math("bf16")                          # the whole "bf16" bench mode: bf16 trunk + bf16-MFMA Dense / GRU projections
@@ -79,11 +87,11 @@ def test_bf16_trunk_forward_backward_against_oracle(case):
         if k in out and k in model.out:
             got = model.out[k].cpu().numpy(); want = out[k].detach().numpy()
             dev[k] = float(np.abs(got - want).max())
-            assert np.all(np.isfinite(got)) and dev[k] < 1e-1, (case, k, dev[k])
+            assert np.all(np.isfinite(got)) and dev[k] < bnd["accent" if k == "y_accent" else "disc"], (case, k, dev[k])
     if cfg.ctc_enable:
         got = model.out["y_ctc_loss"].cpu().numpy(); want = out["y_ctc_loss"].detach().numpy()[:, 0]
         dev["ctc"] = float(np.abs(got - want).max() / np.abs(want).max())
-        assert dev["ctc"] < 5e-2, (case, dev["ctc"])
+        assert dev["ctc"] < bnd["ctc"], (case, dev["ctc"])
     ref_g = {r.name: G[r.name].numpy() - (2 * MT.L2 * ref.P[r.name].numpy() if r.name in ref.reg else 0.0) for r in model.store.refs}
     norms = {k: np.linalg.norm(v) for k, v in ref_g.items()}
     big = max(norms.values())
@@ -96,17 +104,22 @@ def test_bf16_trunk_forward_backward_against_oracle(case):
         c = cosine(g, ref_g[r.name]); worst = min(worst, c)
         rel = np.linalg.norm(g - ref_g[r.name]) / norms[r.name]
         allc.append((round(c, 4), round(float(rel), 4), r.name))
-        if c < COS_MIN:
+        if c < bnd["cos"]:
             bad.append((r.name, round(c, 4), round(float(rel), 4)))
-    print("bf16 trunk %s: output deviation %s, worst gradient cosine %.5f; lowest: %s" % (case, dev, worst, sorted(allc)[:6]))
+    flat_ref = np.concatenate([ref_g[r.name].ravel() for r in model.store.refs])
+    flat = np.concatenate([r.g.cpu().numpy().ravel() for r in model.store.refs])
+    l2 = float(np.linalg.norm(flat - flat_ref) / np.linalg.norm(flat_ref))
+    print("%s trunk %s: output deviation %s, worst gradient cosine %.5f, flat gradient rel. L2 %.3e; lowest: %s" % (mode, case, dev, worst, l2, sorted(allc)[:6]))
     assert not bad, (case, bad[:10])
+    assert l2 < bnd["l2"], (case, l2)
 
 
-def test_bf16_trunk_train_steps_graph_replay_and_inference():
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_bf16_trunk_train_steps_graph_replay_and_inference(mode):
     """Three optimiser steps (2-3 from the captured HIP graph) stay finite and track the fp32-storage model started from the
     same weights; predict() (moving averages folded into the conv fills) agrees between the two storage modes."""
     kw = CASES["cfg3_ctc_circle"]
-    cfg, ref, m16, t16, batch = build(kw, "bf16")
+    cfg, ref, m16, t16, batch = build(kw, mode)
     _, _, m32, t32, _ = build(kw, "fp32")
     batches = [batch, MT.synthetic_batch(cfg, kw["B"], seed=78), MT.synthetic_batch(cfg, kw["B"], seed=79)]
     l16, l32 = [], []

@@ -1,0 +1,124 @@
+"""Does a model trained in the 2-byte trunk modes track one trained in the fp32-class mode?  
+
+A learnable synthetic task at the cfg3 parity size (ResNet-34/F=32 + BiGRU, CTC branch + GhostVLAD + Circle-Loss head, 200 frames, B = 8):
+the accent label is a function of the input -- every class adds its own spectral ripple (frequency and phase over the 80 feature
+bins) and temporal envelope to U[0,1) noise -- and the CTC target is a 4-token sequence determined by the class, so both heads can
+be learned.  300 Adam steps from the SAME initial weights over the same cycled pool of 48 batches in three modes: "bf16x3" (fp32
+storage, split-precision convs: the fp32-class reference, 1e-5 on outputs), "fp16" and "bf16" (2-byte trunks, bf16-MFMA GEMMs).
+
+Asserted: every run learns (smoothed total loss falls below 60 % of its start, final accuracy of the accent classifier above chance
+by a margin), and each 2-byte run stays in a band around the fp32-class run: the smoothed loss curves (windows of 25 steps) agree
+within BAND_LOSS relative at every window and the accuracy over the last 50 steps within BAND_ACC absolute.  Trajectories are not
+compared parameter by parameter: Adam's first steps move every weight by +-lr whatever the gradient's magnitude, so two runs that
+differ in the last bit decorrelate -- what has to agree is the learning curve.
+
+    python tests/test_gpu_convergence.py          prints the three curves (the numbers DESIGN.md quotes)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=8, ghost_clusters=2,
+          disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", lr=float(os.environ.get("CONV_LR", 1e-3)))
+B, STEPS, POOL, WIN = 8, int(os.environ.get("CONV_STEPS", 300)), 48, int(os.environ.get("CONV_WIN", 50))
+AMP = float(os.environ.get("CONV_AMP", 0.10))
+BAND_LOSS, BAND_ACC = 0.25, 0.15
+MODES = {"bf16x3": ("fp32", "bf16x3", "fp32"), "f32": ("fp32", "fp32", "fp32"), "fp16": ("fp16", "bf16x3", "bf16"), "bf16": ("bf16", "bf16x3", "bf16")}
+
+
+def make_pool(seed=2026):
+    """POOL batches of the learnable task (batch dicts exactly as utils.data_generator / the oracle's synthetic_batch build them)."""
+    rng = np.random.default_rng(seed)
+    T, D, A, V = 200, 80, 8, 50
+    L = 7 * 3                                                         # ceil^5(200 / 2) x ceil^5(80 / 2)
+    d = np.arange(D)[None, :] / D; t = np.arange(T)[:, None] / T
+    protos = np.stack([AMP * np.sin(2 * np.pi * (1 + a % 4) * d + 0.7 * a) * (0.6 + 0.4 * np.cos(2 * np.pi * (1 + a // 4) * t + 0.3 * a)) for a in range(A)])
+    pool = []
+    for _ in range(POOL):
+        acc = rng.integers(0, A, B)
+        x = 0.25 + 0.5 * rng.random((B, T, D)) + protos[acc]
+        x = np.clip(x, 0.0, 1.0).astype(np.float32)
+        for b in range(B):
+            x[b, rng.integers(int(0.7 * T), T + 1):] = 0                 # zero-padded tails like utils.py:44-46
+        onehot = np.eye(A, dtype=np.float32)[acc]
+        lab = np.full((B, KW["max_ctc_len"]), 2, np.float32)
+        for b in range(B):
+            lab[b, :4] = [(5 * acc[b] + 7 * j + 3) % (V - 1) for j in range(4)]
+        pool.append({"x_data": x[..., None], "y_accent": onehot, "x_accent": onehot, "y_disc": onehot, "x_ctc_label": lab,
+                     "x_ctc_out_len": np.full((B, 1), 4, np.int32), "x_ctc_in_len": np.full((B, 1), L, np.int32),
+                     "y_ctc_loss": np.zeros(B, np.float32)})
+    return pool
+
+
+def train(mode, pool, weights=None, steps=STEPS):
+    from aesrc2020_amd import _lib
+    from aesrc2020_amd.model import SAR_Net
+    trunk, conv, gemm = MODES[mode]
+    _lib.set_trunk_dtype(trunk); _lib.set_conv_math(conv); _lib.set_gemm_math(gemm)
+    try:
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model, tm = SAR_Net(seed=11, **KW)
+        if weights is not None:
+            model.set_weights_dict(weights)
+        w0 = model.get_weights_dict()
+        loss, acc = [], []
+        for i in range(steps):
+            logs = tm.train_on_batch(pool[i % len(pool)], pool[i % len(pool)])
+            loss.append(logs["loss"]); acc.append(logs["y_accent_acc"])
+    finally:
+        _lib.set_trunk_dtype("fp32"); _lib.set_conv_math("bf16x3"); _lib.set_gemm_math("fp32")
+    return np.asarray(loss), np.asarray(acc), w0
+
+
+def smooth(v):
+    return np.asarray([v[i:i + WIN].mean() for i in range(0, len(v) - WIN + 1, WIN)])
+
+
+def run_all():
+    pool = make_pool()
+    ref_loss, ref_acc, w0 = train("bf16x3", pool)
+    out = {"bf16x3": (ref_loss, ref_acc)}
+    for mode in ("f32", "fp16", "bf16"):
+        l, a, _ = train(mode, pool, weights=w0)
+        out[mode] = (l, a)
+    return out
+
+
+@pytest.fixture(scope="module")
+def curves():
+    return run_all()
+
+
+def test_every_mode_learns_the_task(curves):
+    for mode, (loss, acc) in curves.items():
+        s = smooth(loss)
+        assert np.all(np.isfinite(loss)), mode
+        assert s[-1] < 0.6 * s[0], (mode, s[0], s[-1])
+        assert acc[-50:].mean() > 0.4, (mode, acc[-50:].mean())          # chance = 0.125
+
+
+@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+def test_two_byte_training_tracks_the_fp32_class_run(curves, mode):
+    ref, got = smooth(curves["bf16x3"][0]), smooth(curves[mode][0])
+    rel = np.abs(got - ref) / ref
+    assert rel.max() < BAND_LOSS, (mode, np.round(rel, 3))
+    da = abs(curves[mode][1][-50:].mean() - curves["bf16x3"][1][-50:].mean())
+    assert da < BAND_ACC, (mode, da)
+
+
+if __name__ == "__main__":
+    c = run_all()
+    ref = smooth(c["bf16x3"][0])
+    for mode, (loss, acc) in c.items():
+        s = smooth(loss)
+        print("%-7s smoothed loss (windows of %d): %s" % (mode, WIN, " ".join("%.3f" % v for v in s)))
+        print("        max rel. distance to bf16x3 %.3f; accent accuracy over the last 50 steps %.3f (first 50: %.3f)"
+              % (float((np.abs(s - ref) / ref).max()), acc[-50:].mean(), acc[:50].mean()))

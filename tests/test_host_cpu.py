@@ -41,17 +41,17 @@ def test_wgrad_plan_covers_every_tile_and_chunk_once():
     shapes = [(100, 20, 32, 32)] * 6 + [(100, 20, 64, 32)] + [(50, 10, 64, 64)] * 7 + [(25, 5, 128, 128)] * 11 + [(13, 3, 256, 256)] * 5
     descs = [dict(x=0x1000, dy=0x2000, dw=0x3000 + i, dbias=None, B=B, H=h, W=w, Cin=ci, Ho=h, Wo=w, Cout=co, K=3, s=1, pt=1, pl=1)
              for i, (h, w, ci, co) in enumerate(shapes)]
-    convs, items, n, l4 = _lib.WgradPlan.plan_host(descs, 768)
+    convs, items, n, l4, tiles, slices = _lib.WgradPlan.plan_host(descs, 768)
     # 32 x 32 tiles: 512-position ring, three chunks in flight -> 512 B + 4 x 4 KB + 32 KB + the items' source-offset table
     # (4 bytes per padded position of the longest run, <= 24 KB): three blocks per CU
-    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 600 <= n <= 1400 and l4[1:] == [512, 4, 0x11]
+    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 600 <= n <= 1400 and l4[1:4] == [512, 4, 0x11]
     tab = l4[0] - (512 + 4 * 4096 + 512 * 64)
     assert 0 < tab <= 24576 and tab % 512 == 0 and l4[0] <= 80 * 1024
     wide = [d for d in descs if d["Cin"] >= 64 and d["Cout"] >= 64]
-    _, items64, n64, l64 = _lib.WgradPlan.plan_host(wide, 640, (2, 2))
+    _, items64, n64, l64 = _lib.WgradPlan.plan_host(wide, 640, (2, 2))[:4]
     tab64 = l64[0] - (512 + 4 * 2 * 4096 + 2 * 512 * 64)
-    assert l64[1:] == [512, 4, 0x22] and 400 <= n64 <= 900 and 0 < tab64 <= 24576 and tab64 % 512 == 0
-    _, items1, n1, _ = _lib.WgradPlan.plan_host(wide, 1, (2, 2))       # asks for one item per tile: runs still fit the offset table
+    assert l64[1:4] == [512, 4, 0x22] and l64[6] == 9 * 4 * 1024 and 400 <= n64 <= 900 and 0 < tab64 <= 24576 and tab64 % 512 == 0
+    _, items1, n1, l1, tiles1, _ = _lib.WgradPlan.plan_host(wide, 1, (2, 2))       # asks for one item per tile: runs still fit the offset table
     it1 = np.frombuffer(items1, np.int32).reshape(n1, 8)
     assert it1[:, 4].max() * 64 <= 64 * 500
     it64 = np.frombuffer(items64, np.int32).reshape(n64, 8)
@@ -73,6 +73,17 @@ def test_wgrad_plan_covers_every_tile_and_chunk_once():
                     pos += cnt
                 assert pos == nch
         assert (mine[:, 5] == (1 if len(mine) == (ci // 32) * (co // 32) else 0)).all()
+    # the flush plan (round 3): every item that shares its tile owns one slab; every multi-slice tile lists its slabs once, in pixel order
+    tl = np.frombuffer(tiles, np.int32).reshape(-1, 8); sl = np.frombuffer(slices, np.int32)
+    shared = it[it[:, 5] == 0]
+    assert l4[4] == len(tl) and l4[5] == len(shared) == len(sl) and l4[6] == 9 * 1024
+    assert sorted(shared[:, 6]) == list(range(len(shared))) and sorted(sl) == list(range(len(shared))) and (it[it[:, 5] == 1][:, 6] == -1).all()
+    by_slab = {r[6]: r for r in shared}
+    for conv, ci0, co0, first, count in tl[:, :5]:
+        rows = [by_slab[k] for k in sl[first:first + count]]
+        assert count >= 2 and all(r[0] == conv and r[1] == ci0 and r[2] == co0 for r in rows)
+        assert [r[3] for r in rows] == sorted(r[3] for r in rows)
+    assert tl[:, 4].sum() == len(shared)
     with pytest.raises(RuntimeError):                      # mixed kernel sizes in one plan
         _lib.WgradPlan.plan_host(descs[:1] + [dict(descs[0], K=1)], 64)
     with pytest.raises(RuntimeError):                      # channel counts the kernels do not cover

@@ -69,8 +69,8 @@ if mode == "wgrad":
     # the batched 3x3 weight gradient as the train step launches it: all stride-1 convs of stages 1-3 (64 x 64 tiles) in one plan
     class WC(ctypes.Structure):
         _fields_ = [(n, vp) for n in ("x", "dy", "dw", "dbias")] + [(n, ci) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl", "pad_")]
-    lib.sar_wgrad_plan_bf16.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp]
-    lib.sar_conv2d_wgrad_batch_bf16.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.sar_wgrad_plan_bf16.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
+    lib.sar_conv2d_wgrad_batch_bf16.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
     for label, tile, target, layers in (("stages 1-3, 64x64 tiles", (2, 2), 640, [(50, 10, 64, 7), (25, 5, 128, 11), (13, 3, 256, 5)]),
                                         ("stage 0, 32x32 tiles", (1, 1), 768, [(100, 20, 32, 6)])):
         keep, descs = [], []
@@ -81,10 +81,13 @@ if mode == "wgrad":
                 descs.append((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, B, H, W, C, H, W, C, 3, 1, 1, 1, 0))
         arr = (WC * len(descs))(*[WC(*d) for d in descs])
         cbuf = ctypes.create_string_buffer(len(descs) * 128); ibuf = ctypes.create_string_buffer(16384 * 32)
-        ni, l4 = ctypes.c_int(0), (ctypes.c_int * 4)()
-        assert lib.sar_wgrad_plan_bf16(arr, len(descs), target, tile[0], tile[1], cbuf, ibuf, 16384, ctypes.byref(ni), l4) == 0
+        ni, l4 = ctypes.c_int(0), (ctypes.c_int * 8)()
+        tbuf = ctypes.create_string_buffer(16384 * 32); sbuf = (ctypes.c_int * 16384)()
+        assert lib.sar_wgrad_plan_bf16(arr, len(descs), target, tile[0], tile[1], cbuf, ibuf, 16384, ctypes.byref(ni), l4, tbuf, sbuf) == 0
+        td = torch.frombuffer(bytearray(tbuf.raw[:max(l4[4], 1) * 32]), dtype=torch.uint8).cuda(); sd = torch.tensor(list(sbuf)[:max(l4[5], 1)], dtype=torch.int32).cuda()
+        slab = torch.empty(max(l4[5] * l4[6], 1), device="cuda")
         cd = torch.frombuffer(bytearray(cbuf.raw), dtype=torch.uint8).cuda(); idv = torch.frombuffer(bytearray(ibuf.raw[:ni.value * 32]), dtype=torch.uint8).cuda()
-        fn = lambda: lib.sar_conv2d_wgrad_batch_bf16(cd.data_ptr(), idv.data_ptr(), ni.value, 3, l4, st)
+        fn = lambda: lib.sar_conv2d_wgrad_batch_bf16(cd.data_ptr(), idv.data_ptr(), ni.value, 3, l4, td.data_ptr(), sd.data_ptr(), slab.data_ptr(), st)
         tb = torch.zeros(1 << 14, 16, dtype=torch.int64, device="cuda")
         for it in range(3):
             lib.sar_dbg_set_timing_buffer16(None); torch.cuda.synchronize(); fn()

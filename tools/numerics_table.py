@@ -33,6 +33,12 @@ CASES = {
     "cfg3_h256": dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad",
                       vlad_clusters=8, ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=50,
                       max_ctc_len=8, metric_loss="circleloss", B=8),
+    "smoke_b4_t100": dict(input_shape=[100, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8,
+                          ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", B=4),
+    "b8_t100": dict(input_shape=[100, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8,
+                    ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", B=8),
+    "b4_t200": dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8,
+                    ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", B=4),
 }
 MODES = {"f32": ("fp32", "fp32", "fp32"), "bf16x3": ("fp32", "bf16x3", "fp32"), "bf16": ("bf16", "bf16x3", "bf16"), "fp16": ("fp16", "bf16x3", "bf16"),
          "bf16+g32": ("bf16", "bf16x3", "fp32"), "fp16+g32": ("fp16", "bf16x3", "fp32")}
@@ -56,6 +62,9 @@ def run(case, mode, seed=0):
         out, total, parts, G = ref.forward_backward(batch)
         model.forward_backward_only(batch, batch)
         torch.cuda.synchronize()
+        if os.environ.get("NT_ACT") and getattr(model.trunk, "bf16", False):   # largest stored activation of the 2-byte trunk
+            mx = max(float(t.float().abs().max()) for key, t in model.trunk.store.bufs.d.items() if t.dtype == model.trunk.t16 and "wf16" not in key and "wd16" not in key)
+            print("          largest stored 2-byte value of the trunk: %.4g" % mx)
     finally:
         _lib.set_trunk_dtype("fp32"); _lib.set_conv_math("bf16x3"); _lib.set_gemm_math("fp32")
     row = {}
@@ -93,7 +102,7 @@ def run(case, mode, seed=0):
 
 
 def main():
-    cases = sys.argv[1:] or list(CASES)
+    cases = sys.argv[1:] or list(CASES)[:3]
     for case in cases:
         print("== %s" % case)
         keys = None
