@@ -125,6 +125,19 @@ def set_trunk_gscale(s):
     _TRUNK_GSCALE[0] = float(s)
 
 
+# Deterministic forward statistics of the 2-byte trunk (csrc/trunk16.h: fix28): BatchNorm sums as 64-bit fixed point, integer atomics --
+# independent of block / atomic order and of how the batch is cut into tiles.  Read when a model is built.
+_BN_DET = [os.environ.get("SAR_BN_DET", "0") == "1"]
+
+
+def set_bn_deterministic(on):
+    _BN_DET[0] = bool(on)
+
+
+def get_bn_deterministic():
+    return _BN_DET[0]
+
+
 def get_trunk_gscale():
     return _TRUNK_GSCALE[0]
 
@@ -136,7 +149,7 @@ def get_trunk_dtype():
 class BnRef(ctypes.Structure):
     """include/sarnet.h: sarBnRef."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("gamma", "beta", "bins", "bbins", "saved", "moving_mean", "moving_var", "dgamma", "dbeta")] + \
-               [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("ginv", ctypes.c_float)]
+               [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ctypes.c_int), ("ginv", ctypes.c_float), ("det", ctypes.c_int), ("pad_", ctypes.c_int)]
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)

@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     }
     __syncthreads();
     float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
+    long long q10 = 0, q11 = 0, q20 = 0, q21 = 0;                  // epi 3: the same sums in 64-bit fixed point (trunk16.h: fix28)
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int row = rg + RG * i;
@@ -390,6 +391,10 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
             // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
             if (p.epi == 1) { v0 = h_lo(pk); v1 = h_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
+            if (p.epi == 3) {
+                v0 = h_lo(pk); v1 = h_hi(pk);
+                q10 += fix28(v0); q11 += fix28(v1); q20 += fix28(fminf(v0 * v0, 8.0e6f)); q21 += fix28(fminf(v1 * v1, 8.0e6f));
+            }
             if (p.epi == 2) {
                 const float y0 = h_lo(yv[i]), y1 = h_hi(yv[i]);
                 const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
@@ -399,6 +404,21 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     }
     TSTAMP(6);
     if (p.epi == 0) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
+    if (p.epi == 3) {                                              // integer partials, integer atomics: order-independent
+        long long* partq = reinterpret_cast<long long*>(part);
+        partq[(rg * TN + 2 * cp) * 2 + 0] = q10; partq[(rg * TN + 2 * cp) * 2 + 1] = q20;
+        partq[(rg * TN + 2 * cp + 1) * 2 + 0] = q11; partq[(rg * TN + 2 * cp + 1) * 2 + 1] = q21;
+        __syncthreads();
+        if (tid < 2 * TN) {
+            const int cc = tid >> 1, which = tid & 1;
+            long long s = 0;
+#pragma unroll
+            for (int r = 0; r < RG; ++r) s += partq[(r * TN + cc) * 2 + which];
+            atomicAdd(reinterpret_cast<unsigned long long*>(p.e_bins) + ((blockIdx.x % NB) * 2 + which) * p.Cout + n0 + cc, (unsigned long long)s);
+        }
+        TSTAMP(7); TSTAMP(15);
+        return;
+    }
     part[(rg * TN + 2 * cp) * 2 + 0] = s10; part[(rg * TN + 2 * cp) * 2 + 1] = s20;
     part[(rg * TN + 2 * cp + 1) * 2 + 0] = s11; part[(rg * TN + 2 * cp + 1) * 2 + 1] = s21;
     __syncthreads();
@@ -1015,7 +1035,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     memset(&p, 0, sizeof(p));
     if (!make_geo(p.g, B, Hs, Ws, Cin, Ho, Wo, K, s, d, pt, pl)) return SAR_EINVAL;
     if (!pow2(Cin) || !pow2(Cout) || Cin < 32 || Cout < 32 || Cin > CMAX || Cout > CMAX) return SAR_EINVAL;
-    if (fill < 0 || fill > 3 || epi < 0 || epi > 2 || (fill && fbn == nullptr) || (fill >= 2 && src2 == nullptr) || (fill == 3 && src3 == nullptr)) return SAR_EINVAL;
+    if (fill < 0 || fill > 3 || epi < 0 || epi > 3 || (fill && fbn == nullptr) || (fill >= 2 && src2 == nullptr) || (fill == 3 && src3 == nullptr)) return SAR_EINVAL;
     if (epi && e_bins == nullptr) return SAR_EINVAL;
     if (epi == 2 && (e_y == nullptr || e_saved == nullptr)) return SAR_EINVAL;
     if ((long)B * Hs * Ws * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
@@ -1031,7 +1051,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
     const int KG = (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;                  // two k-groups (512 threads) for the one-block-per-CU layers
-    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (256 * KG) / (TN / 2) * TN * 2 * 4;
+    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (256 * KG) / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel layers (one block per CU anyway) get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
     const size_t ring_bytes = (size_t)p.rd * WN * 8 * 1024;

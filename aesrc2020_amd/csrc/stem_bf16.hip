@@ -172,7 +172,7 @@ __device__ __forceinline__ void stem_mtile(const h16x8 (&wa)[NT][4], const u16* 
 // ---------------------------------------------------------------------------------------------------- forward pass 1: statistics
 template <int NT>
 __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ bins, const StemG g) {
+                                                           float* __restrict__ bins, const StemG g, int det) {
     constexpr int C0 = NT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* wfr = smem;                                                       // [NT*4][64][16 B]
@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
         // the sums are of the raw products; the BatchNorm input is y = conv + bias
         const float b = bias[c], np = (float)npix;
         const float out = which == 0 ? S1 + np * b : S2 + 2.f * b * S1 + np * b * b;
-        atomicAdd(bins + ((blockIdx.x % NB) * 2 + which) * C0 + c, out);
+        // det: a block is one tile of ONE image and sums it in a fixed order, so its partial is a function of the image alone; converted
+        // to fixed point, the integer sum over blocks is independent of their order and of the batch they sit in
+        if (det) atomicAdd(reinterpret_cast<unsigned long long*>(bins) + ((blockIdx.x % NB) * 2 + which) * C0 + c, (unsigned long long)fix28(out));
+        else atomicAdd(bins + ((blockIdx.x % NB) * 2 + which) * C0 + c, out);
     }
     TSTAMP(5); TSTAMP(15);
 }
@@ -653,7 +656,7 @@ typedef BnP sarBnRef;
 // Forward pass 1: sum / sum of squares of y = conv7x7/2(x) + bias per channel, added into bins [sar_bn_bins()][2][C0] (zeroed by the
 // caller once per step, like every BatchNorm of the bf16 trunk).  x (B,T,D) fp32, w (7,7,1,C0) fp32 HWIO, C0 in {32, 64}.
 int SAR_STEM(sar_stem16_stats)(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
-                     int pad_top, int pad_left, hipStream_t stream) {
+                     int pad_top, int pad_left, int det, hipStream_t stream) {
     StemG g;
     if (!x || !w || !bias || !bins || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, 1, 1, 0, 0)) return SAR_EINVAL;
     int TR = env_int("SAR_STEM_STATS_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
@@ -663,10 +666,10 @@ int SAR_STEM(sar_stem16_stats)(const float* x, const float* w, const float* bias
     const int nblk = B * g.tiles;
     if (C0 == 64) {
         if (!allow_lds(stem16_stats_kernel<2>, lds)) return SAR_ELAUNCH;
-        hipLaunchKernelGGL(stem16_stats_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, bins, g);
+        hipLaunchKernelGGL(stem16_stats_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, bins, g, det);
     } else {
         if (!allow_lds(stem16_stats_kernel<1>, lds)) return SAR_ELAUNCH;
-        hipLaunchKernelGGL(stem16_stats_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, bins, g);
+        hipLaunchKernelGGL(stem16_stats_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, bins, g, det);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;

@@ -77,7 +77,19 @@ struct BnP {
     float inv_n, unbias, eps, momentum;
     int write;                  // this launch owns the side effects: saved / moving statistics / parameter gradients
     float ginv;                 // 1 / (gradient scale the backward sums in `bbins` carry): applied where dgamma / dbeta are written
+    int det;                    // forward sums in `bins` are 64-bit fixed point (units of 2^-28), see fix28()
+    int pad_;
 };
+
+// Deterministic forward statistics (sarBnRef.det; SAR_BN_DET=1): producers convert every stored value (and its square) to 64-bit fixed
+// point and add INTEGERS -- associative, so the sums do not depend on block order, atomic order or how the batch is cut into tiles:
+// the same utterances give bit-identical BatchNorm constants in a batch of 32 or duplicated into one of 64.  x * 2^28 is rounded to an
+// integer by the add of 1.5 * 2^52 (exact for |x| < 2^23); the bit pattern minus that of the magic number is the integer.
+__device__ __forceinline__ long long fix28(float v) {
+    const double d = fma((double)v, 268435456.0, 6755399441055744.0);
+    return __double_as_longlong(d) - 0x4338000000000000LL;
+}
+constexpr double FIX28_INV = 1.0 / 268435456.0;
 
 // cst[0..5][cs]: scale, shift, mean, rstd, c2 = S1/N, c3 = S2/N for channels [c0, c0+nc), row stride cs >= nc.  mode 1: forward constants
 // (from the bins, or from `saved` when there are none: inference, or a backward consumer); mode 2: backward constants.
@@ -87,8 +99,16 @@ __device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int 
         float mean, rstd, scale, shift;
         if (mode == 1 && bn.bins != nullptr) {
             double s1 = 0.0, s2 = 0.0;
+            if (bn.det) {                                            // kernel-uniform
+                const long long* qb = reinterpret_cast<const long long*>(bn.bins);
+                long long q1 = 0, q2 = 0;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { s1 += (double)bn.bins[(b * 2) * C + c]; s2 += (double)bn.bins[(b * 2 + 1) * C + c]; }
+                for (int b = 0; b < NB; ++b) { q1 += qb[(b * 2) * C + c]; q2 += qb[(b * 2 + 1) * C + c]; }
+                s1 = (double)q1 * FIX28_INV; s2 = (double)q2 * FIX28_INV;
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { s1 += (double)bn.bins[(b * 2) * C + c]; s2 += (double)bn.bins[(b * 2 + 1) * C + c]; }
+            }
             const double mu = s1 * (double)bn.inv_n;
             double var = s2 * (double)bn.inv_n - mu * mu;
             var = var > 0.0 ? var : 0.0;

@@ -53,12 +53,15 @@ class _BN:
               self.moving_mean.w, self.moving_var.w, R, C, BN_EPS, BN_MOMENTUM, 1)
 
     # ---- bf16 trunk (csrc/conv_bf16.hip): statistics through bins of fp32 atomics, constants recomputed by every consumer
-    def prepare16(self, arena, off):
-        """Claim this BatchNorm's forward / backward bins in the trunk's statistics arena (zeroed once per step)."""
+    def prepare16(self, arena, off, det=False):
+        """Claim this BatchNorm's forward / backward bins in the trunk's statistics arena (zeroed once per step).  det: the forward
+        bins are 64-bit fixed point (csrc/trunk16.h: fix28) -- twice the words."""
         n = _lib.bn_bins() * 2 * self.C
-        self.bins, self.bbins = arena[off:off + n], arena[off + n:off + 2 * n]
+        nf = 2 * n if det else n
+        self.det = bool(det)
+        self.bins, self.bbins = arena[off:off + nf], arena[off + nf:off + nf + n]
         self.saved = self._b("saved", (4, self.C))
-        return off + 2 * n
+        return off + nf + n
 
     def ref(self, R, stats, write, ginv=1.0):
         """sarBnRef for a consumer kernel.  stats: 'fwd' = batch statistics from the bins (training forward), 'saved' = the
@@ -72,6 +75,7 @@ class _BN:
         r.dgamma, r.dbeta = self.gamma.g.data_ptr(), self.beta.g.data_ptr()
         r.inv_n, r.unbias, r.eps, r.momentum = 1.0 / R, R / max(R - 1.0, 1.0), BN_EPS, BN_MOMENTUM
         r.write = int(write); r.ginv = float(ginv)
+        r.det = int(getattr(self, "det", False) and stats == "fwd")
         return r
 
     def fold16(self):
@@ -98,6 +102,7 @@ class _Conv:
         self.use_planes = False
         # 2-byte trunk (ResNetTrunk sets them): entry-point suffix "bf16" | "f16", torch dtype, 1 / gradient scale
         self.sfx, self.t16, self.ginv = "bf16", torch.bfloat16, 1.0
+        self.epi_fwd = 1                                                     # 3: deterministic (fixed-point) statistics out of the epilogue
 
     def planes(self):
         K = self.k * self.k * self.cin
@@ -119,7 +124,7 @@ class _Conv:
 
     def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
         _call("sar_conv2d_" + self.sfx, x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
-              self.k, self.stride, 1, self.pt, self.pl, fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
+              self.k, self.stride, 1, self.pt, self.pl, fill, fbn, self.epi_fwd if e_bins is not None else 0, e_bins, None, None)
 
     def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
         """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2, + dy3 when fill == 3
@@ -191,6 +196,7 @@ class ResNetTrunk(Layer):
         self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("bf16", torch.bfloat16)
         self._gscale_cfg = _lib.get_trunk_gscale() if self.half else 1.0      # 0: automatic, 64 x batch (_set_gscale)
         self.gscale = self.ginv = 1.0
+        self.det = self.bf16 and _lib.get_bn_deterministic()                 # forward BatchNorm sums in 64-bit fixed point (SAR_BN_DET=1)
         if self.bf16 and (filters != 32 or stem_c not in (32, 64)):
             raise ValueError("2-byte trunk: res_filters must be 32 (the reference's train.py:54 default; channel counts are powers of two "
                              "in [32, 256], the 512-channel stage of F=64 does not fit the LDS patch); got %d" % filters)
@@ -216,7 +222,7 @@ class ResNetTrunk(Layer):
         self.final_bn = _BN(st, st.auto_name("batch_normalization"), cin)
         self.out_c = cin
         for cv in self._all_convs():
-            cv.sfx, cv.t16 = self.sfx, self.t16
+            cv.sfx, cv.t16, cv.epi_fwd = self.sfx, self.t16, (3 if self.det else 1)
         self.plan(*input_hw)
 
     def _set_gscale(self, B):
@@ -285,11 +291,11 @@ class ResNetTrunk(Layer):
         self._pack_table = torch.tensor(rows, dtype=torch.int64, device="cuda")
         self._pack_blocks = blk0
         bns = self._all_bns()
-        n = sum(4 * _lib.bn_bins() * bn.C for bn in bns)
+        n = sum((6 if self.det else 4) * _lib.bn_bins() * bn.C for bn in bns)
         self._arena = self.store.bufs.get(self.name + "/bn_arena", (n,))
         off = 0
         for bn in bns:
-            off = bn.prepare16(self._arena, off)
+            off = bn.prepare16(self._arena, off, self.det)
 
     def _buf16(self, key, shape):
         return self.buf(key, shape, self.t16)
@@ -434,7 +440,7 @@ class ResNetTrunk(Layer):
     # (targets re-measured at v36 with the flush known to be 40 % of the 64-wide launch -- every item ends in 147 KB of fp32 atomics,
     # tools/conv_variants.py phase removal: 156 us with, 94 without --: 256 / 320 / 384 / 512 / 640 / 896 items = 163 / 135 / 139 / 166 /
     # 156 / 178 us; 32-wide class 256 / 384 / 512 / 768 / 1024 = 133 / 132 / 116 / 123 / 129 us)
-    WGRAD_CLASSES = (((3, 1, True), int(os.environ.get("SAR_WG_T64", 320))), ((3, 1, False), int(os.environ.get("SAR_WG_T32", 512))),
+    WGRAD_CLASSES = (((3, 1, True), int(os.environ.get("SAR_WG_T64", 448))), ((3, 1, False), int(os.environ.get("SAR_WG_T32", 512))),
                      ((3, 2, False), 512), ((1, None, False), 256))
 
     @staticmethod
@@ -485,7 +491,7 @@ class ResNetTrunk(Layer):
         sb, cv = self.stem_bn, self.stem
         training = self.store.training
         if training:
-            _call(self._stem_fn("sar_stem16_stats"), x, cv.kernel.w, cv.bias.w, sb.bins, *conv)
+            _call(self._stem_fn("sar_stem16_stats"), x, cv.kernel.w, cv.bias.w, sb.bins, *conv, int(self.det))
         self.pooled16 = self._buf16("pooled16", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
         _call(self._stem_fn("sar_stem16_pool_fwd"), x, cv.kernel.w, cv.bias.w, sb.ref(B * H * W, st, training), self.pooled16, self.pool_idx, *conv, *pool)
         return self.pooled16

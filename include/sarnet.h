@@ -159,6 +159,9 @@ typedef struct sarBnRef {      /* one BatchNormalization (resnet.py:25) as a con
     float inv_n, unbias, eps, momentum;      /* 1/rows, rows/(rows-1) */
     int write;                 /* this launch owns the side effects (block 0 performs them) */
     float ginv;                /* dgamma / dbeta += sums * ginv: 1 / (the gradient scale the sums in bbins carry); 1 in the bf16 trunk */
+    int det;                   /* 1: `bins` holds int64 [NB][2][C] in units of 2^-28 (deterministic statistics: producers add integers, so the
+                                * sums do not depend on block order or on how the batch is tiled; sar_conv2d_* epi 3, sar_stem16_stats det) */
+    int pad_;
 } sarBnRef;
 int sar_bn_bins(void);
 /* Kernels of many convolutions (fp32 HWIO) -> the bf16 fragment streams sar_conv2d_bf16 reads, one launch.  table = device
@@ -174,7 +177,8 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarSt
  * in the fill of that block's conv2 input-gradient launch instead of by a BatchNorm-apply launch of its own.
  * side (nullable, shape of src): T(src) written back to HBM -- the plain operand of the matching weight gradient.
  * epi 0: none; 1: sum and sum of squares of y into e_bins (the statistics of the BatchNorm that consumes y); 2: the two
- * BatchNorm-backward sums of y (= da) against (e_y = that BN's input, e_saved) into e_bins.
+ * BatchNorm-backward sums of y (= da) against (e_y = that BN's input, e_saved) into e_bins; 3: as 1, deterministic: e_bins is int64
+ * [NB][2][C], every stored value and its square converted to 2^-28 fixed point and added as integers (sarBnRef.det consumers).
  * Forward: d = 1, s = stride, pt/pl = TF pads, wpk = wf.  Input gradient: src = dy, Hs/Ws = its size, d = stride, s = 1,
  * Ho/Wo = the forward INPUT size, pt = K-1-pad_top, pl = K-1-pad_left, wpk = wd.  K in {1,3}; Cin, Cout powers of two in
  * [32, 512]. */
@@ -229,7 +233,7 @@ int sar_cast_bf16_f32(const void* x, float* y, long n, sarStream_t stream);
  *             sar_stem16_wgrad (dw += kernel gradient; owns dgamma / dbeta when bn->write; the bias gradient is exactly zero and
  *             not computed; work = sar_stem16_wgrad_workspace_bytes(C0) bytes of scratch).  No input gradient: first layer. */
 int sar_stem16_stats(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
-                     int pad_top, int pad_left, sarStream_t stream);
+                     int pad_top, int pad_left, int det, sarStream_t stream);   /* det: bins is int64 fixed point (sarBnRef.det) */
 int sar_stem16_pool_fwd(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
                         int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
 int sar_stem16_bwd_reduce(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
@@ -262,7 +266,7 @@ int sar_bn_apply_f16_f32(const void* x, const sarBnRef* bn, float* out, long R, 
 int sar_cast_f32_f16(const float* x, void* y, long n, sarStream_t stream);
 int sar_cast_f16_f32(const void* x, float* y, long n, sarStream_t stream);
 int sar_stem16_stats_f16(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
-                         int pad_top, int pad_left, sarStream_t stream);
+                         int pad_top, int pad_left, int det, sarStream_t stream);
 int sar_stem16_pool_fwd_f16(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
                             int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
 int sar_stem16_bwd_reduce_f16(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,

@@ -3,16 +3,22 @@
 A learnable synthetic task at the cfg3 parity size (ResNet-34/F=32 + BiGRU, CTC branch + GhostVLAD + Circle-Loss head, 200 frames, B = 8):
 the accent label is a function of the input -- every class adds its own spectral ripple (frequency and phase over the 80 feature
 bins) and temporal envelope to U[0,1) noise -- and the CTC target is a 4-token sequence determined by the class, so both heads can
-be learned.  300 Adam steps from the SAME initial weights over the same cycled pool of 48 batches in three modes: "bf16x3" (fp32
-storage, split-precision convs: the fp32-class reference, 1e-5 on outputs), "fp16" and "bf16" (2-byte trunks, bf16-MFMA GEMMs).
+be learned.  400 Adam steps (lr 1e-3) from the SAME initial weights over the same cycled pool of 48 batches in four modes: "bf16x3"
+(fp32 storage, split-precision convs: the fp32-class reference, 1e-5 on outputs), "f32" (exact fp32 MFMA: the CONTROL -- it differs
+from bf16x3 by 1e-5 per output, so its distance to the reference is what last-bit differences alone grow into over 400 steps),
+"fp16" and "bf16" (2-byte trunks, bf16-MFMA GEMMs).
 
-Asserted: every run learns (smoothed total loss falls below 60 % of its start, final accuracy of the accent classifier above chance
-by a margin), and each 2-byte run stays in a band around the fp32-class run: the smoothed loss curves (windows of 25 steps) agree
-within BAND_LOSS relative at every window and the accuracy over the last 50 steps within BAND_ACC absolute.  Trajectories are not
-compared parameter by parameter: Adam's first steps move every weight by +-lr whatever the gradient's magnitude, so two runs that
-differ in the last bit decorrelate -- what has to agree is the learning curve.
+Asserted: every run learns (smoothed total loss falls below 10 % of its start, accent accuracy over the last 50 steps > 0.9 with
+chance at 0.125), and every run -- control included -- stays in one band around the reference: smoothed loss (windows of 50 steps)
+within BAND_LOSS relative at every window, the last window within BAND_FINAL, accuracy over the last 50 steps within BAND_ACC.
+Measured (round 3, four runs of this script over two batch pools): control 0.08 .. 0.40, fp16 0.16 .. 0.33, bf16 0.07 .. 0.10 at the
+worst window (all in the steep second to fourth windows, where a few steps of lead or lag are a large relative difference -- and two
+bf16x3 runs of the same pool differ by 1.4 % in their FIRST window already: fp32 atomics); last window within 3 % of the reference
+in every run (1.00 .. 1.03); accuracy 1.0 everywhere.  The 2-byte runs are no further from the reference than the fp32 control's chaos level allows one to
+resolve.  Trajectories are not compared parameter by parameter: Adam's first steps move every weight by +-lr whatever the gradient's
+magnitude, so two runs that differ in the last bit decorrelate -- what has to agree is the learning curve.
 
-    python tests/test_gpu_convergence.py          prints the three curves (the numbers DESIGN.md quotes)
+    python tests/test_gpu_convergence.py          prints the curves (the numbers DESIGN.md quotes)
 """
 import os
 import sys
@@ -27,13 +33,13 @@ pytestmark = pytest.mark.gpu
 
 KW = dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=8, ghost_clusters=2,
           disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", lr=float(os.environ.get("CONV_LR", 1e-3)))
-B, STEPS, POOL, WIN = 8, int(os.environ.get("CONV_STEPS", 300)), 48, int(os.environ.get("CONV_WIN", 50))
+B, STEPS, POOL, WIN = 8, int(os.environ.get("CONV_STEPS", 400)), 48, int(os.environ.get("CONV_WIN", 50))
 AMP = float(os.environ.get("CONV_AMP", 0.10))
-BAND_LOSS, BAND_ACC = 0.25, 0.15
+BAND_LOSS, BAND_FINAL, BAND_ACC = 0.5, 0.05, 0.1
 MODES = {"bf16x3": ("fp32", "bf16x3", "fp32"), "f32": ("fp32", "fp32", "fp32"), "fp16": ("fp16", "bf16x3", "bf16"), "bf16": ("bf16", "bf16x3", "bf16")}
 
 
-def make_pool(seed=2026):
+def make_pool(seed=int(os.environ.get("CONV_SEED", 2026))):
     """POOL batches of the learnable task (batch dicts exactly as utils.data_generator / the oracle's synthetic_batch build them)."""
     rng = np.random.default_rng(seed)
     T, D, A, V = 200, 80, 8, 50
@@ -101,21 +107,24 @@ def test_every_mode_learns_the_task(curves):
     for mode, (loss, acc) in curves.items():
         s = smooth(loss)
         assert np.all(np.isfinite(loss)), mode
-        assert s[-1] < 0.6 * s[0], (mode, s[0], s[-1])
-        assert acc[-50:].mean() > 0.4, (mode, acc[-50:].mean())          # chance = 0.125
+        assert s[-1] < 0.1 * s[0], (mode, s[0], s[-1])
+        assert acc[-50:].mean() > 0.9, (mode, acc[-50:].mean())          # chance = 0.125
 
 
-@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "fp16", "bf16"])
 def test_two_byte_training_tracks_the_fp32_class_run(curves, mode):
     ref, got = smooth(curves["bf16x3"][0]), smooth(curves[mode][0])
     rel = np.abs(got - ref) / ref
-    assert rel.max() < BAND_LOSS, (mode, np.round(rel, 3))
+    print("%s: relative distance of the smoothed loss to the bf16x3 run per window: %s" % (mode, np.round(rel, 3)))
+    assert rel.max() < BAND_LOSS and rel[-1] < BAND_FINAL, (mode, np.round(rel, 3))
     da = abs(curves[mode][1][-50:].mean() - curves["bf16x3"][1][-50:].mean())
     assert da < BAND_ACC, (mode, da)
 
 
 if __name__ == "__main__":
     c = run_all()
+    if os.environ.get("CONV_DUMP"):
+        np.savez(os.environ["CONV_DUMP"], **{m + "_loss": v[0] for m, v in c.items()}, **{m + "_acc": v[1] for m, v in c.items()})
     ref = smooth(c["bf16x3"][0])
     for mode, (loss, acc) in c.items():
         s = smooth(loss)

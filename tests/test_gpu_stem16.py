@@ -93,7 +93,7 @@ def run_case(L, B, T, D, C0, seed, train=True):
     # ---- kernels forward
     pooled = torch.zeros(B, Hp, Wp, C0, dtype=BF, device="cuda"); idx = torch.full((B, Hp, Wp, C0), 99, dtype=torch.uint8, device="cuda")
     if train:
-        L.call("sar_stem16_stats" + SFX, d["x"], d["w"], d["b"], d["bins"], *conv)
+        L.call("sar_stem16_stats" + SFX, d["x"], d["w"], d["b"], d["bins"], *conv, 0)
         sums = d["bins"].double().sum(0).cpu().numpy()
         assert rel(sums[0], y.sum((0, 1, 2))) < 1e-4 and rel(sums[1], (y * y).sum((0, 1, 2))) < 1e-4
         L.call("sar_stem16_pool_fwd" + SFX, d["x"], d["w"], d["b"], ref("fwd"), pooled, idx, *conv, *pool)

@@ -36,7 +36,7 @@ def ref(stats):
 
 conv = (B, T, D, Ho, Wo, C0, pt, pl); pool = (Hp, Wp, ppt, ppl)
 steps = {
-    "stats": lambda: L.call("sar_stem16_stats", x, w, b, bins, *conv),
+    "stats": lambda: L.call("sar_stem16_stats", x, w, b, bins, *conv, 0),
     "pool_fwd": lambda: L.call("sar_stem16_pool_fwd", x, w, b, ref("fwd"), pooled, idx, *conv, *pool),
     "bwd_reduce": lambda: L.call("sar_stem16_bwd_reduce", g, pooled, idx, x, w, b, ref("bwd"), work, *conv, *pool),
     "wgrad(+wsum)": lambda: L.call("sar_stem16_wgrad", x, w, b, g, pooled, idx, ref("bwd"), dw, work, *conv, *pool),

@@ -19,7 +19,7 @@ from oracle.ops_np import same_pads  # noqa: E402
 
 lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing_stem.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
-lib.sar_stem16_stats.argtypes = [vp] * 4 + [ci] * 8 + [vp]
+lib.sar_stem16_stats.argtypes = [vp] * 4 + [ci] * 9 + [vp]
 lib.sar_stem16_pool_fwd.argtypes = [vp] * 6 + [ci] * 12 + [vp]
 lib.sar_stem16_bwd_reduce.argtypes = [vp] * 8 + [ci] * 12 + [vp]
 lib.sar_stem16_wgrad.argtypes = [vp] * 9 + [ci] * 12 + [vp]
@@ -54,7 +54,7 @@ conv = (B, T, D, Ho, Wo, C0, pt, pl); pool = (Hp, Wp, ppt, ppl)
 P = lambda t: t.data_ptr()
 rf, rb = ref("fwd"), ref("bwd")
 runs = [
-    ("stats", lambda: lib.sar_stem16_stats(P(x), P(w), P(b), P(bins), *conv, st),
+    ("stats", lambda: lib.sar_stem16_stats(P(x), P(w), P(b), P(bins), *conv, 0, st),
      {"stage": (1, 2), "m-tiles": (2, 3), "reduce": (3, 4), "flush": (4, 5), "total": (1, 5)}),
     ("pool_fwd", lambda: lib.sar_stem16_pool_fwd(P(x), P(w), P(b), ctypes.byref(rf), P(pooled), P(idx), *conv, *pool, st),
      {"stage+prologue": (1, 2), "conv pass 0": (2, 3), "pool pass 0": (3, 4), "conv pass 1": (4, 5), "pool pass 1": (5, 6), "total": (1, 6)}),
