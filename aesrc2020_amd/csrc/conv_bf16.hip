@@ -137,14 +137,14 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // 128-register variants gave the scheduler a reason: ring fragments read before the other waves' DMA had landed).  The caller
 // waits for its own LDS stores / DMA first (gfx950 puts no implicit wait in front of s_barrier).
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
-__device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0, 16]
+__device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0, 63]: vmcnt is a 6-bit counter; larger n wait for 63
+#define WVM4(b) case b: wait_vm<b>(); break; case b + 1: wait_vm<b + 1>(); break; case b + 2: wait_vm<b + 2>(); break; case b + 3: wait_vm<b + 3>(); break;
     switch (n) {
-        case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;   case 3: wait_vm<3>(); break;
-        case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;   case 6: wait_vm<6>(); break;   case 7: wait_vm<7>(); break;
-        case 8: wait_vm<8>(); break;   case 9: wait_vm<9>(); break;   case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
-        case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break; case 15: wait_vm<15>(); break;
-        default: wait_vm<16>(); break;
+        WVM4(0) WVM4(4) WVM4(8) WVM4(12) WVM4(16) WVM4(20) WVM4(24) WVM4(28) WVM4(32) WVM4(36) WVM4(40) WVM4(44) WVM4(48) WVM4(52) WVM4(56)
+        case 60: wait_vm<60>(); break; case 61: wait_vm<61>(); break; case 62: wait_vm<62>(); break;
+        default: wait_vm<63>(); break;
     }
+#undef WVM4
 }
 
 // 16-byte store that is not kept in the writer's L2 (nobody on this XCD reads it again before the launch ends)
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
         }
     };
     if constexpr (EARLY) load_epi();
+    TSTAMP(11);
     // ---- weight ring: stages 0 and 1 on their way before anything else
     const h16x8* wsrc = p.wpk + (size_t)(blockIdx.y * WN) * p.Fs * 64 + lane;
     const unsigned ring0 = lds_addr(bring);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     issue_stage(0, 0);
     if (NST > 1) issue_stage(1, 1);
     if (RD > 3 && NST > 2) issue_stage(2, 2);
-
+    TSTAMP(12);
 
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
@@ -291,7 +292,9 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
         rt.y = b * (unsigned)(g.Ho * g.Wo) + (dm ? 2u * us : (unsigned)us >> (g.s - 1)) * g.Wo;
         rowtab[tid] = rt;
     }
+    TSTAMP(13);
     if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, NTHR);
+    TSTAMP(14);
     // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
                 if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wg_barrier();
                 if (st == 0) { TSTAMP(4); load_afrags<KPF>(afr[0], patch, a_lane); }
+                if (st == NST / 2) TSTAMP(8);
                 if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
                 else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
                 const int slot = RD == 4 ? (st & 3) : (st % 3);
@@ -579,8 +583,20 @@ __global__ __launch_bounds__(WG_NW1 * 64) void wgrad1_bf16_kernel(const unsigned
 // scalars: the instruction counts of the chunks in flight.
 struct Wg3Args { const unsigned char* convs; const WgItem* items; const uint4* zero; unsigned np; int nbuf; int tab_pos; float* slab; };
 
-template <int TCI, int TCO>
-__global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
+// W12 (64 x 64 tiles only): TWELVE waves -- wave = (tap row, 32 x 32 sub-tile), three taps each -- instead of nine (wave = tap, the
+// whole tile).  Nine waves sit 3-2-2-2 on the four SIMDs, so a chunk's 144 MFMAs cost 1 536 cycles on the fullest SIMD and the other
+// six waves wait for it at the chunk's barrier; twelve sit 3-3-3-3 (1 152 cycles), and the DMA issue of a chunk is dealt to twelve.
+// Per wave and 16-pixel step: three A fragments (one activation plane at three consecutive positions) and ONE gradient fragment.
+// NL > 0 (experiment, SAR_WG_LOADERS=1; NOT the default): NL extra LOADER waves issue all of the block's LDS-DMA and keep the pixel ->
+// position table, the NWV compute waves only read LDS and multiply.  Measured SLOWER (64-wide launch 125 -> 141 us, 32-wide 52 -> 63):
+// with the issue off their hands the compute waves wait 3 300-3 900 cycles per chunk for the loaders' data instead of 1 400 -- what a
+// chunk waits for is the ARRIVAL of ~17 KB of 64 / 128-byte pieces per CU (the launch moves ~400 MB at ~1.5 TB/s with three chunks
+// in flight per block: latency x bytes in flight, not instruction issue and not the MFMAs, 1 152 of ~3 700 cycles per chunk).
+template <int TCI, int TCO, bool W12 = false, int NL = 0>
+__global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kernel(const Wg3Args a) {
+    static_assert(!W12 || (TCI == 2 && TCO == 2), "twelve waves: three tap rows x the four sub-tiles of a 64 x 64 tile");
+    constexpr int NWV = W12 ? 12 : 9, NTHR = (NWV + NL) * 64;
+    constexpr int NA = W12 ? 3 : TCI, NBF = W12 ? 1 : TCO, NJ = W12 ? 3 : TCI * TCO;   // A / B fragments per step, MFMAs per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const WgItem it = a.items[blockIdx.x];
     const WgConv* cvp = reinterpret_cast<const WgConv*>(a.convs + (size_t)it.conv * 128);
@@ -593,6 +609,7 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
     const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M, NP = a.np, mask = a.np - 1;
     const int c_first = it.c_first, nmine = it.c_count, nbuf = a.nbuf;
+    const bool loader = NL > 0 && w >= NWV;                                        // wave-uniform
     unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [2][64]: absolute patch position of every pixel
     unsigned* soff = qring + 128;                                                  // [tab_pos]: source element offset of every position of this item (NONE: zero)
     unsigned char* dyr = smem + 512 + (size_t)a.tab_pos * 4;                       // [nbuf][TCO][64 px][64 B]
@@ -601,11 +618,11 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
     constexpr int MAXNI = 4;
 
     auto tables = [&](int lc) __attribute__((always_inline)) {
-        if (tid < 64) {
+        if (NL > 0 ? w == NWV : tid < 64) {                                        // the first loader wave, or wave 0
             const unsigned mc0 = (unsigned)(c_first + lc) * 64;
             unsigned Rp, wq;
-            pix_rp(g, min(mc0 + tid, M - 1), Rp, wq);                              // past the batch: the last pixel's position; its dY row is zero
-            qring[(lc & 1) * 64 + tid] = Rp * g.Wp + wq;
+            pix_rp(g, min(mc0 + lane, M - 1), Rp, wq);                             // past the batch: the last pixel's position; its dY row is zero
+            qring[(lc & 1) * 64 + lane] = Rp * g.Wp + wq;
         }
     };
     unsigned Gn;                                                                   // first 16-position group not requested yet
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
         unsigned Rpl, wql;
         pix_rp(g, min((unsigned)(c_first + nmine) * 64, M) - 1, Rpl, wql);
         const unsigned npos = min((((Rpl + g.K) * g.Wp + 15) & ~15u) - P0, (unsigned)a.tab_pos);
-        for (unsigned i = tid; i < npos; i += 576) {
+        for (unsigned i = tid; i < npos; i += NTHR) {
             const unsigned p = P0 + i;
             const unsigned Rp = udiv(p, g.mg_wp, (unsigned)g.Wp), wp = p - Rp * g.Wp;
             const unsigned b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
@@ -639,27 +656,42 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
         pix_rp(g, min(mc0 + 63, M - 1), Rpl, wql);
         const unsigned Gh = ((Rpl + g.K) * g.Wp + 15) >> 4;                        // every position in front of (last row + K) * Wp
         const int npg = Gh > Gn ? (int)(Gh - Gn) : 0;
-        const int total = 4 * TCO + npg * TCI, NI = (total + 8) / 9;
+        const int total = 4 * TCO + npg * TCI;
+        const int NI = NL > 0 ? (loader ? (total - (w - NWV) + NL - 1) / NL : 0) : (total + NWV - 1) / NWV;
         const unsigned dyslot = dyr0 + (unsigned)(lc % nbuf) * (TCO * 4096);
-#pragma unroll
-        for (int i = 0; i < MAXNI; ++i) {
-            if (i < NI) {
-                const int j = min(w + 9 * i, total - 1);
-                const void* src; unsigned dst;
-                if (j < 4 * TCO) {                                                 // gradient rows: plane j/4, 16 pixels j%4
-                    const int pl = j >> 2, blk = j & 3;
-                    const unsigned m = mc0 + blk * 16 + l4;
-                    src = m < M ? (const void*)(dyp + (size_t)m * Cout + co0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
-                    dst = dyslot + (unsigned)(pl * 4096 + blk * 1024);
-                } else {                                                           // 16 new patch positions of one activation plane
-                    const int jj = j - 4 * TCO, pl = TCI == 1 ? 0 : (jj & 1);
-                    const unsigned gi = Gn + (unsigned)(TCI == 1 ? jj : jj >> 1);
-                    const unsigned so = soff[gi * 16 + l4 - P0];
-                    src = so != NONE ? (const void*)(xp + so + ci0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
-                    dst = pr0a + (unsigned)pl * (NP * 64) + ((gi * 16) & mask) * 64;
-                }
-                dma16(src, dst);
+        // (Computing the addresses of a batch first and issuing its DMA instructions back to back -- dma16's memory clobber keeps the
+        // next instruction's table read behind it -- was measured: 125 -> 134 us for the 64-wide launch.  Issue order is not the limit.)
+        auto addr = [&](int j, const void*& src, unsigned& dst) __attribute__((always_inline)) {
+            if (j < 4 * TCO) {                                                     // gradient rows: plane j/4, 16 pixels j%4
+                const int pl = j >> 2, blk = j & 3;
+                const unsigned m = mc0 + blk * 16 + l4;
+                src = m < M ? (const void*)(dyp + (size_t)m * Cout + co0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
+                dst = dyslot + (unsigned)(pl * 4096 + blk * 1024);
+            } else {                                                               // 16 new patch positions of one activation plane
+                const int jj = j - 4 * TCO, pl = TCI == 1 ? 0 : (jj & 1);
+                const unsigned gi = Gn + (unsigned)(TCI == 1 ? jj : jj >> 1);
+                const unsigned so = soff[gi * 16 + l4 - P0];
+                src = so != NONE ? (const void*)(xp + so + ci0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
+                dst = pr0a + (unsigned)pl * (NP * 64) + ((gi * 16) & mask) * 64;
             }
+        };
+        if constexpr (NL > 0) {                                                    // loader waves: their share of the chunk, four at a time
+            for (int i0 = 0; i0 < NI; i0 += 4) {
+                const void* src[4]; unsigned dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) addr(min((w - NWV) + NL * (i0 + u), total - 1), src[u], dst[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < NI) dma16(src[u], dst[u]);
+            }
+        } else {                                                                   // every wave issues, at most MAXNI each
+#pragma unroll
+            for (int i = 0; i < MAXNI; ++i)
+                if (i < NI) {
+                    const void* src; unsigned dst;
+                    addr(min(w + NWV * i, total - 1), src, dst);
+                    dma16(src, dst);
+                }
         }
         if (Gh > Gn) Gn = Gh;
         return NI;
@@ -680,18 +712,19 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
     if (LA > 2 && nmine > 2) q2 = issue(2);
     (void)q0;
 
-    f32x16 acc[TCI][TCO];
+    // job k of a wave = one 32 x 32 accumulator: nine waves: (i, j) = (k / TCO, k % TCO) of tap w; twelve: tap 3 * (w / 4) + k of sub-tile
+    // (wi, wj) = ((w / 2) % 2, w % 2)
+    f32x16 acc[NJ];
 #pragma unroll
-    for (int i = 0; i < TCI; ++i)
+    for (int k = 0; k < NJ; ++k)
 #pragma unroll
-        for (int j = 0; j < TCO; ++j)
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    float bsum[NBF];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bsum[TCO];
-#pragma unroll
-    for (int j = 0; j < TCO; ++j) bsum[j] = 0.f;
-    const bool do_bias = dbp != nullptr && w == 0 && ci0 == 0;
-    const unsigned toff = (unsigned)((w / 3) * g.Wp + (w % 3));                    // this wave's tap, in positions
+    for (int j = 0; j < NBF; ++j) bsum[j] = 0.f;
+    const int wi = W12 ? (w >> 1) & 1 : 0, wj = W12 ? w & 1 : 0, wrow = W12 ? w >> 2 : 0;
+    const bool do_bias = dbp != nullptr && ci0 == 0 && (W12 ? (wrow == 0 && wi == 0) : w == 0);
+    const unsigned toff = W12 ? (unsigned)(wrow * g.Wp) : (unsigned)((w / 3) * g.Wp + (w % 3));   // first tap of this wave, in positions
     const int gi_ = lane & 15, gg = lane >> 4, cb = gg & 1, kh = gg >> 1;
     const unsigned colb = (16 * cb + 4 * (gi_ & 3)) * 2;
     const unsigned prb = 8 * kh + (gi_ >> 2);
@@ -705,20 +738,25 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
         TACC(t_issue, if (lc + LA < nmine) qn = issue(lc + LA));   // dY slot of chunk lc+LA-nbuf <= lc-1; ring positions behind chunk lc
         if (LA == 3) q3 = qn; else if (LA == 2) q2 = qn; else q1 = qn;
         if (lc + 1 < nmine) tables(lc + 1);
+        if (loader) { q1 = q2; q2 = q3; q3 = 0; continue; }                        // (wave-uniform) loader waves: back to the next chunk's wait
         const unsigned* qtab = qring + (lc & 1) * 64;
         const unsigned char* dyt = dyr + (size_t)(lc % nbuf) * (TCO * 4096);
-        h16x8 A[2][TCI], Bm[2][TCO];
-        auto rd = [&](int ks, h16x8 (&Ao)[TCI], h16x8 (&Bo)[TCO]) __attribute__((always_inline)) {
+        h16x8 A[2][NA], Bm[2][NBF];
+        auto rd = [&](int ks, h16x8 (&Ao)[NA], h16x8 (&Bo)[NBF]) __attribute__((always_inline)) {
             const unsigned p0 = 16 * ks + prb, p1 = p0 + 4;
-            const unsigned a0 = ((qtab[p0] + toff) & mask) * 64 + colb, a1 = ((qtab[p1] + toff) & mask) * 64 + colb;
+            const unsigned q0p = qtab[p0] + toff, q1p = qtab[p1] + toff;
 #pragma unroll
-            for (int i = 0; i < TCI; ++i) {
-                const s16x4 lo = lds_tr(pr + (size_t)i * NP * 64, a0), hi = lds_tr(pr + (size_t)i * NP * 64, a1);
+            for (int i = 0; i < NA; ++i) {
+                // nine waves: plane i at the wave's tap; twelve: plane wi at the three taps of the wave's row
+                const unsigned char* pl = pr + (size_t)(W12 ? wi : i) * NP * 64;
+                const unsigned a0 = ((q0p + (W12 ? i : 0)) & mask) * 64 + colb, a1 = ((q1p + (W12 ? i : 0)) & mask) * 64 + colb;
+                const s16x4 lo = lds_tr(pl, a0), hi = lds_tr(pl, a1);
                 Ao[i] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
-            for (int j = 0; j < TCO; ++j) {
-                const s16x4 lo = lds_tr(dyt + j * 4096, p0 * 64 + colb), hi = lds_tr(dyt + j * 4096, p1 * 64 + colb);
+            for (int j = 0; j < NBF; ++j) {
+                const unsigned char* pl = dyt + (W12 ? wj : j) * 4096;
+                const s16x4 lo = lds_tr(pl, p0 * 64 + colb), hi = lds_tr(pl, p1 * 64 + colb);
                 Bo[j] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         };
@@ -727,13 +765,11 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) rd(ks + 1, A[(ks + 1) & 1], Bm[(ks + 1) & 1]);
 #pragma unroll
-            for (int i = 0; i < TCI; ++i)
-#pragma unroll
-                for (int j = 0; j < TCO; ++j)
-                    acc[i][j] = MFMA16(A[ks & 1][i], Bm[ks & 1][j], acc[i][j], 0, 0, 0);
+            for (int k = 0; k < NJ; ++k)
+                acc[k] = MFMA16(A[ks & 1][W12 ? k : k / TCO], Bm[ks & 1][W12 ? 0 : k % TCO], acc[k], 0, 0, 0);
             if (do_bias) {
 #pragma unroll
-                for (int j = 0; j < TCO; ++j)
+                for (int j = 0; j < NBF; ++j)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bsum[j] += (float)Bm[ks & 1][j][e];
             }
@@ -748,34 +784,33 @@ __global__ __launch_bounds__(576) void wgrad3_bf16_kernel(const Wg3Args a) {
     }
 #endif
     // ---- flush
-    {
+    if (!loader) {
         const int col = lane & 31;
 #pragma unroll
-        for (int i = 0; i < TCI; ++i)
+        for (int k = 0; k < NJ; ++k) {
+            const int tap = W12 ? 3 * wrow + k : w, i = W12 ? wi : k / TCO, j = W12 ? wj : k % TCO;
+            float* o = dwp + ((size_t)tap * g.Cin + ci0 + i * 32) * Cout + co0 + j * 32 + col;
+            if (it.single) {
+                float old[16];
 #pragma unroll
-            for (int j = 0; j < TCO; ++j) {
-                float* o = dwp + ((size_t)w * g.Cin + ci0 + i * 32) * Cout + co0 + j * 32 + col;
-                if (it.single) {
-                    float old[16];
+                for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) old[r] = o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout];
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[k][r] * ginv;
+            } else {
+                // slab[item][tap][i][j][q][lane] x float4: the accumulator registers as they are (rows 8q + 4(lane/32) + 0..3, column lane%32)
+                float4* sl = reinterpret_cast<float4*>(a.slab) + ((((size_t)it.slab * 9 + tap) * TCI + i) * TCO + j) * 256 + lane;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * Cout] = old[r] + acc[i][j][r] * ginv;
-                } else {
-                    // slab[item][tap][i][j][q][lane] x float4: the accumulator registers as they are (rows 8q + 4(lane/32) + 0..3, column lane%32)
-                    float4* sl = reinterpret_cast<float4*>(a.slab) + ((((size_t)it.slab * 9 + w) * TCI + i) * TCO + j) * 256 + lane;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        __builtin_nontemporal_store(f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]},
-                                                    reinterpret_cast<f32x4*>(sl + q * 64));
-                }
+                for (int q = 0; q < 4; ++q)
+                    __builtin_nontemporal_store(f32x4{acc[k][4 * q], acc[k][4 * q + 1], acc[k][4 * q + 2], acc[k][4 * q + 3]},
+                                                reinterpret_cast<f32x4*>(sl + q * 64));
             }
+        }
         if (do_bias) {
 #pragma unroll
-            for (int j = 0; j < TCO; ++j) {
+            for (int j = 0; j < NBF; ++j) {
                 float s = bsum[j];
                 s += __shfl_xor(s, 32, 64);
-                if (lane < 32) atomicAdd(dbp + co0 + j * 32 + lane, s * ginv);
+                if (lane < 32) atomicAdd(dbp + co0 + (W12 ? wj : j) * 32 + lane, s * ginv);
             }
         }
     }
@@ -1243,11 +1278,18 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
         if (launch4[6] != 9 * tci * tco * 1024) return SAR_EINVAL;
         Wg3Args a{static_cast<const unsigned char*>(convs_dev), static_cast<const WgItem*>(items_dev), zero_page, (unsigned)np, nbuf, tab_bytes / 4, slab};
         typedef void (*k3_t)(const Wg3Args);
-        static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2>}};
-        static bool attr3[2][2];
-        const k3_t kern = k3[tci - 1][tco - 1];
-        if (!attr3[tci - 1][tco - 1]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr3[tci - 1][tco - 1] = true; }
-        hipLaunchKernelGGL(kern, dim3(n_items), dim3(576), lds_bytes, stream, a);
+        // 64 x 64 tiles run the twelve-wave form (SAR_WG_W12=0: the nine-wave kernel, for A/B timing)
+        // 64 x 64 tiles: the twelve-wave form.  SAR_WG_LOADERS=1: the loader-wave experiment (12 + 2 / 9 + 1 waves; slower, see the kernel)
+        static const bool ldr = getenv("SAR_WG_LOADERS") && atoi(getenv("SAR_WG_LOADERS")) == 1;
+        static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2, true>}};
+        static const k3_t k3l[2] = {wgrad3_bf16_kernel<1, 1, false, 1>, wgrad3_bf16_kernel<2, 2, true, 2>};
+        static bool attr3[2][2], attrl[2];
+        const bool sq = tci == tco, usel = ldr && sq;
+        const k3_t kern = usel ? k3l[tci - 1] : k3[tci - 1][tco - 1];
+        bool& at = usel ? attrl[tci - 1] : attr3[tci - 1][tco - 1];
+        if (!at) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at = true; }
+        const int threads = (tci == 2 && tco == 2 ? 768 : 576) + (usel ? 64 * tci : 0);
+        hipLaunchKernelGGL(kern, dim3(n_items), dim3(threads), lds_bytes, stream, a);
         if (n_tiles > 0)
             hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(n_tiles, 9 * tci * tco), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
                                static_cast<const WgTile*>(tiles_dev), slices_dev, slab, tci, tco);
