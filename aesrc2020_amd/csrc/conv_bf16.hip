@@ -212,11 +212,15 @@ __device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char
 // KG = 2 (NKC = 8 only: the 128+-channel layers, whose tiles are one block per CU or fewer): eight waves -- two groups of four that
 // split every virtual tap's eight fragments between them (channels 0-63 / 64-127 of the part) and meet in the output staging tile.
 // Twice the waves per SIMD for the LDS latency of the k-phase, twice the threads for prologue, fill and epilogue.
-template <int WN, int NKC, int VT, int KG = 1>
-__global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(const ConvP p) {
+// WMX: waves along the pixels (default 4 / WN: four waves per k-group).  WMX = 2 with WN = 1 -- 64-pixel tiles on TWO waves -- is the
+// form of the 32-channel layers since round 3: at B = 64 their 128-pixel tiles were 1 000 blocks for 768 resident slots (1.3 rounds,
+// the second a third full); 2 000 half-size blocks pack the rounds.
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN>
+__global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
     static_assert(KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
-    constexpr int NTHR = 256 * KG, NW = 4 * KG, KPF = NKC / KG;    // threads, waves, fragments per virtual tap and group
-    constexpr int WM = 4 / WN, TM = 32 * WM, TN = 32 * WN;
+    constexpr int NG = WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
+    constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
+    static_assert((WN * 8) % NW == 0 && NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "stage DMA and epilogue maps must divide evenly");
     constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
     constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     unsigned char* patch = smem + cst_bytes + ROWTAB_BYTES;
     unsigned char* bring = patch + p.patch_bytes;                  // [RD][WN][8][1 KiB]
     const Geo& g = p.g;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), kg = w >> 2, wm = (w & 3) / WN, wn = (w & 3) % WN;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), kg = w / NG, wm = (w % NG) / WN, wn = (w % NG) % WN;
     const unsigned m0 = blockIdx.x * TM;
     const int n0 = blockIdx.y * TN;
     const unsigned M = (unsigned)g.M;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     // (a 128-register variant for four blocks per CU -- these loads after the k-phase, two fill pieces in flight -- needs the
     // 32-channel layers' LDS at 40 KB, i.e. a 2-deep weight ring: see the ring comment; with the 3-deep ring they fit three per CU
     // and the variant was slower, 23 vs 17 us per stage-0 launch)
-    constexpr bool EARLY = true;
+    constexpr bool EARLY = NG != 8;                                 // (the eight-wave form lives on 128 registers: operands loaded behind the k-phase)
     unsigned rv[RPT], yv[RPT];
     auto load_epi = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -303,12 +307,12 @@ __global__ __launch_bounds__(256 * KG, KG == 1 ? 2 : 1) void conv_bf16_kernel(co
     // (Issuing the patch loads in front of the BatchNorm prologue -- row table, barrier, loads, prologue, barrier, transform + store --
     // was built and measured: no gain.  What the fill costs is its address arithmetic, ~1 400 cycles before the first load leaves,
     // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
-    constexpr int FU = 4;                                          // fill pieces per thread in flight
+    constexpr int FU = NG == 8 ? 2 : 4;                            // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers)
     // ---- fill: the padded patch, all input channels, transformed once
     if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
     else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
     else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else fill_patch<3, TM, 2, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);   // three tensors: two pieces in flight
+    else fill_patch<3, TM, (FU < 2 ? FU : 2), NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);   // three tensors: two pieces in flight
     // ---- per-lane A address
     unsigned a_lane;
     {
@@ -1081,12 +1085,29 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;
     p.lg_pc = ilog2(Cin / 8); p.rs = Cin * 2 + 16;
     p.Fs = K * K * Cin / 16 + 8;
-    const int WN = Cout >= 64 ? 2 : 1, TM = 32 * (4 / WN), TN = 32 * WN;
+    const int WN = Cout >= 64 ? 2 : 1, TN = 32 * WN;
+    // 32 output channels from up to 64 source channels (stage 0 and its gradients): 64-pixel tiles on two waves (SAR_CONV16_TM64=0: 128 / four)
+    // Pixel tile of the 32-output-channel launches (stage 0, its shortcut and gradients).  Round 2 ran them as 128-pixel tiles on four
+    // waves: 1 000 blocks at B = 64 for 768 resident slots -- 1.3 rounds, the second a third full.  256 pixels on EIGHT waves (128
+    // registers, two blocks per CU) are 500 blocks = ONE round: the ten stage-0 launches 171 -> 128 us.  Taken where two such blocks fit
+    // a CU's LDS.  64 pixels on two waves went the other way (169 -> 270 us: twice the blocks pay the fixed prologue / statistics phases,
+    // 1.5x the halo rows).  SAR_CONV16_TM = 64 | 128 | 256 forces one form.
+    static const int tm_env = getenv("SAR_CONV16_TM") ? atoi(getenv("SAR_CONV16_TM")) : 0;
+    const bool narrow = WN == 1 && Cin <= 64;
+    bool tm256 = false;
+    if (narrow && (tm_env == 0 || tm_env == 256)) {
+        const size_t pb = (size_t)patch_rows_bound(p.g, 256 < p.g.M ? 256 : p.g.M) * p.g.Wp * p.rs + 1024;
+        tm256 = tm_env == 256 || (size_t)6 * Cin * 4 + ROWTAB_BYTES * 2 + ((pb + 1023) & ~(size_t)1023) + 3 * 8 * 1024 <= 80 * 1024;
+    }
+    const bool tm64 = tm_env == 64 && narrow;
+    const int TM = tm64 ? 64 : tm256 ? 256 : 32 * (4 / WN);
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
     const int KG = (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;                  // two k-groups (512 threads) for the one-block-per-CU layers
-    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (256 * KG) / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
+    const int nthr = tm64 ? 128 : tm256 ? 512 : 256 * KG;
+    if (p.cap_rows > nthr) return SAR_EINVAL;                                      // one thread per row of the row table
+    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel layers (one block per CU anyway) get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
     const size_t ring_bytes = (size_t)p.rd * WN * 8 * 1024;
@@ -1112,6 +1133,18 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
         const kern_t kern = kerns2[WN - 1][ki - 2][k3];
         if (!attr2[WN - 1][ki - 2][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr2[WN - 1][ki - 2][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
+    if (tm64 || tm256) {
+#define CVX(NKC_, WMX_) {conv_bf16_kernel<1, NKC_, 1, 1, WMX_>, conv_bf16_kernel<1, NKC_, 9, 1, WMX_>}
+        static const kern_t kernsx[2][2][2] = {{CVX(2, 2), CVX(4, 2)}, {CVX(2, 8), CVX(4, 8)}};
+#undef CVX
+        static bool attrx[2][2][2];
+        const int wx = tm256 ? 1 : 0;
+        const kern_t kern = kernsx[wx][ki][k3];
+        if (!attrx[wx][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[wx][ki][k3] = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }

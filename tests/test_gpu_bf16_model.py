@@ -8,7 +8,7 @@ TWICE the measured deviation of each recipe (tools/numerics_table.py, DESIGN.md 
   accent probabilities, max |d|    6.2e-3 .. 1.0e-2           2e-2      2.3e-2 .. 2.9e-2          6e-2
   disc probabilities, max |d|      3.3e-3 .. 2.1e-2           4e-2      1.0e-2 .. 6.0e-2          1.2e-1
   per-utterance CTC loss, rel.     1.3e-3 .. 2.0e-3           4e-3      2.2e-3 .. 3.9e-3          8e-3
-  parameter-gradient cosine, min   0.990 (BatchNorm), 0.995   0.98      0.93 (BatchNorm), 0.957   0.90
+  parameter-gradient cosine, min   0.990 (BatchNorm), 0.995   0.98      0.90 .. 0.93 (BN, GRU bias)  0.85
   flat gradient, relative L2       7.0e-2 .. 8.1e-2           1.6e-1    1.9e-1 .. 2.4e-1          4.5e-1
 
 Why single-pass 2-byte operands cannot reach the north-star's 1e-3: every conv rounds both operands to 2^-12 (fp16) / 2^-9 (bf16)
@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 # per recipe: max |d prob| accent, disc; CTC relative; min gradient cosine; flat-gradient relative L2
 BOUNDS = {"fp16": dict(accent=2e-2, disc=4e-2, ctc=4e-3, cos=0.98, l2=1.6e-1),
-          "bf16": dict(accent=6e-2, disc=1.2e-1, ctc=8e-3, cos=0.90, l2=4.5e-1)}
+          "bf16": dict(accent=6e-2, disc=1.2e-1, ctc=8e-3, cos=0.85, l2=4.5e-1)}   # (1 - cos measured up to 0.10 from run to run)
 
 CASES = {
     "cfg2_gvlad_arcface": dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad",
