@@ -215,6 +215,13 @@ __device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char
 // WMX: waves along the pixels (default 4 / WN: four waves per k-group).  WMX = 2 with WN = 1 -- 64-pixel tiles on TWO waves -- is the
 // form of the 32-channel layers since round 3: at B = 64 their 128-pixel tiles were 1 000 blocks for 768 resident slots (1.3 rounds,
 // the second a third full); 2 000 half-size blocks pack the rounds.
+#ifndef SAR_KP_PFB
+#define SAR_KP_PFB 0
+#endif
+#ifndef SAR_KPV
+#define SAR_KPV 0          // phase-removal variants of the k-phase for tools/conv16_timing.py (results wrong by construction): 1 no MFMAs, 2 no
+#endif                     // ring refill, 3 no stage barriers, 4 no B-fragment reads, 5 no A-fragment reads
+constexpr bool PFB = SAR_KP_PFB != 0;
 template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN>
 __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
     static_assert(KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
     issue_stage(0, 0);
     if (NST > 1) issue_stage(1, 1);
     if (RD > 3 && NST > 2) issue_stage(2, 2);
+    if (KG == 2 && PFB && NST > 3) issue_stage(3, 3);              // B fragments read one stage ahead (k-phase below)
     TSTAMP(12);
 
     unsigned Rp_lo, Rp_hi, wtmp;
@@ -334,6 +342,44 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     h16x8 afr[2][KPF], bfr[8 / KG];
     const unsigned char* bmine = bring + (wn * 8 + kg * KPF) * 1024 + lane * 16;
+    if constexpr (KG == 2 && PFB) {
+        // (EXPERIMENT, off: -DSAR_KP_PFB=1.  Measured SLOWER: k-phase of the stage-2 block 6 370 -> 6 780 cycles.)  Two k-groups (the 128+-channel layers; a stage = one virtual tap = four fragments per wave; RD = 4, the launcher sees to it).
+        // Round 2 read a stage's B fragments right behind the stage's barrier and multiplied at once: ~200 cycles of LDS latency in
+        // front of the MFMAs of EVERY stage, 9 (stage 2) or 18 (stage 3) times per block.  Here the fragments of stage st+1 are read
+        // at boundary st, behind the issue of the MFMAs' predecessors, into the other register set.  The ring runs one stage further
+        // ahead to keep the landed-one-barrier-before-read margin: at boundary st stage st+2 has landed, st+3 is in flight, st+4 is
+        // issued into the slot of stage st (whose fragments every wave read at boundary st-1, completed by the lgkmcnt(0) below).
+        h16x8 bpf[2][KPF];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int st = v;
+            if (st + 2 < NST) { if (st + 3 < NST) wait_vm<PW>(); else wait_vm<0>(); }
+            else if (st == 0) wait_vm<0>();                        // one or two stages in all: everything has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own patch stores (st 0); own reads of the slot refilled below
+            wg_barrier();
+            if (st == 0) {
+                TSTAMP(4);
+                load_afrags<KPF>(afr[0], patch, a_lane);
+#pragma unroll
+                for (int i = 0; i < KPF; ++i) bpf[0][i] = *reinterpret_cast<const h16x8*>(bmine + i * 1024);
+            }
+            if (st == NST / 2) TSTAMP(8);
+            if (st + 4 < NST) issue_stage(st + 4, st & 3);
+            if (st + 1 < NST) {
+#pragma unroll
+                for (int i = 0; i < KPF; ++i) bpf[(st + 1) & 1][i] = *reinterpret_cast<const h16x8*>(bmine + (((st + 1) & 3) * SJ + i) * 1024);
+            }
+            if (v + 1 < VT) {
+                const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
+                load_afrags<KPF>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
+            }
+#pragma unroll
+            for (int kc = 0; kc < KPF; ++kc) {
+                if (kc & 1) acc2 = MFMA16(afr[v & 1][kc], bpf[st & 1][kc], acc2, 0, 0, 0);
+                else acc = MFMA16(afr[v & 1][kc], bpf[st & 1][kc], acc, 0, 0, 0);
+            }
+        }
+    } else {
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
 #pragma unroll
@@ -346,22 +392,28 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
                 // stage 0: this wave's patch stores must have completed before the others read them (gfx950 inserts no
                 // implicit wait in front of a bare s_barrier)
                 if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wg_barrier();
+                if (SAR_KPV != 3 || st == 0) wg_barrier();
                 if (st == 0) { TSTAMP(4); load_afrags<KPF>(afr[0], patch, a_lane); }
                 if (st == NST / 2) TSTAMP(8);
-                if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
-                else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
+                if (SAR_KPV != 2) {
+                    if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
+                    else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
+                }
                 const int slot = RD == 4 ? (st & 3) : (st % 3);
+                if (SAR_KPV != 4 || st == 0) {
 #pragma unroll
-                for (int i = 0; i < 8 / KG; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
+                    for (int i = 0; i < 8 / KG; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
+                }
             }
-            if (kc == 0 && v + 1 < VT) {
+            if (kc == 0 && v + 1 < VT && SAR_KPV != 5) {
                 const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
                 load_afrags<KPF>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
             }
+            if (SAR_KPV == 1) { if (f == 0) acc = MFMA16(afr[0][0], bfr[0], acc, 0, 0, 0); continue; }
             if (f & 1) acc2 = MFMA16(afr[v & 1][kc], bfr[f % 8], acc2, 0, 0, 0);
             else acc = MFMA16(afr[v & 1][kc], bfr[f % 8], acc, 0, 0, 0);
         }
+    }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
@@ -1130,6 +1182,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
 #undef CV2
     static bool attr2[2][3][2];
     if (KG == 2) {
+        if (PFB && p.rd != 4) return SAR_EINVAL;                                    // the prefetching k-phase (experiment) runs a four-slot ring
         const kern_t kern = kerns2[WN - 1][ki - 2][k3];
         if (!attr2[WN - 1][ki - 2][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr2[WN - 1][ki - 2][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);

@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aesrc2020_amd import _lib as L
 BF = torch.bfloat16
-B, H, W, Cin, Cout = 64, 100, 20, int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 32
+B, H, W, Cin, Cout = 64, int(os.environ.get("RH", 100)), int(os.environ.get("RW", 20)), int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 torch.manual_seed(0)
 x = torch.randn(B, H, W, Cin, device="cuda").to(BF); w = (torch.randn(3, 3, Cin, Cout, device="cuda") * 0.1)

@@ -15,7 +15,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing16.so"))
+lib = ctypes.CDLL(os.environ.get("TIMING16_LIB") or os.path.join(HERE, "libsarnet_timing16.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.sar_conv2d_bf16.argtypes = [vp] * 8 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
 lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
