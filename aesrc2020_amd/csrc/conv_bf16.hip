@@ -222,12 +222,36 @@ __device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char
 #define SAR_KPV 0          // phase-removal variants of the k-phase for tools/conv16_timing.py (results wrong by construction): 1 no MFMAs, 2 no
 #endif                     // ring refill, 3 no stage barriers, 4 no B-fragment reads, 5 no A-fragment reads
 constexpr bool PFB = SAR_KP_PFB != 0;
-template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN>
-__global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
-    static_assert(KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
-    constexpr int NG = WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
+// Barriers of the epilogue: LDS traffic only.  __syncthreads() also drains vmcnt(0): behind the k-phase that is the round trip of the
+// epilogue operands requested a moment earlier (eight-wave form), behind the output stores their write acknowledgements.
+#ifndef SAR_BR_PD
+#define SAR_BR_PD 8        // BR form: weight fragments in flight ahead of the MFMA that consumes them
+#endif
+#ifndef SAR_BR_WHEN
+#define SAR_BR_WHEN 0      // BR form: where the first 18 weight fragments are requested: 0 kernel entry, 1 behind the BatchNorm prologue, 2 behind the fill
+#endif
+#ifndef SAR_EPI_SYNC
+#define SAR_EPI_SYNC 0
+#endif
+#if SAR_EPI_SYNC
+#define EPI_BARRIER() __syncthreads()
+#else
+#define EPI_BARRIER() lds_barrier()
+#endif
+// BR ("B in registers", round 3; the 64+-channel sources with 64+ output channels: stages 1-3): the block is still 64 pixels x 64 channels,
+// but its waves are 2 channel halves x KG k-groups, a wave owns BOTH 32-pixel halves of its 32 channels (two accumulators) on a 1/KG share
+// of every tap's channels (two fragments per virtual tap), and its weight fragments -- which no other wave of the block needs -- come
+// straight from the packed stream into registers: requested at kernel entry (18 per wave; the other 18 of the 256+-channel layers behind
+// the fill), consumed ~3 us later.  No weight ring, no DMA, no barrier inside the k-phase, and HALF the LDS reads per MFMA (an A fragment
+// feeds one MFMA, a B fragment two; round 2's k-phase was bound by LDS reads 2 : 1 -- 2 KB per MFMA -- and by a barrier per 8 fragments).
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
+__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
+    static_assert(BR || KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
+    static_assert(!BR || (WN == 2 && WMX == 2 && NKC / KG == 2), "BR: 64 x 64 tiles, two fragments per virtual tap and wave");
+    constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
     constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
-    static_assert((WN * 8) % NW == 0 && NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "stage DMA and epilogue maps must divide evenly");
+    static_assert(BR || (WN * 8) % NW == 0, "stage DMA must divide evenly");
+    static_assert(NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "epilogue maps must divide evenly");
     constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
     constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
@@ -283,10 +307,21 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
             dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)((slot * SJ + j) * 1024));
         }
     };
-    issue_stage(0, 0);
-    if (NST > 1) issue_stage(1, 1);
-    if (RD > 3 && NST > 2) issue_stage(2, 2);
-    if (KG == 2 && PFB && NST > 3) issue_stage(3, 3);              // B fragments read one stage ahead (k-phase below)
+    constexpr int NF = BR ? VT * KPF : 1, NF0 = NF < SAR_BR_PD ? NF : SAR_BR_PD; // BR: this wave's k-steps (= weight fragments); those requested ahead of the k-phase
+    h16x8 breg[NF];
+    const h16x8* wmine = p.wpk + ((size_t)(blockIdx.y * WN + wn) * p.Fs + kg * KPF) * 64 + lane;
+    auto load_b0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NF0; ++i) breg[i] = wmine[((i / KPF) * NKC + (i % KPF)) * 64];
+    };
+    if constexpr (BR) {
+        if (SAR_BR_WHEN == 0) load_b0();
+    } else {
+        issue_stage(0, 0);
+        if (NST > 1) issue_stage(1, 1);
+        if (RD > 3 && NST > 2) issue_stage(2, 2);
+        if (KG == 2 && PFB && NST > 3) issue_stage(3, 3);          // B fragments read one stage ahead (k-phase below)
+    }
     TSTAMP(12);
 
     unsigned Rp_lo, Rp_hi, wtmp;
@@ -306,6 +341,7 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
     }
     TSTAMP(13);
     if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, NTHR);
+    if constexpr (BR) { if (SAR_BR_WHEN == 1) load_b0(); }
     TSTAMP(14);
     // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -340,9 +376,41 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
     f32x16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-    h16x8 afr[2][KPF], bfr[8 / KG];
+    h16x8 afr[2][KPF], bfr[BR ? 1 : 8 / KG];
     const unsigned char* bmine = bring + (wn * 8 + kg * KPF) * 1024 + lane * 16;
-    if constexpr (KG == 2 && PFB) {
+    if constexpr (BR) {
+        // acc: pixels 0-31 of the tile, acc2: pixels 32-63; both on this wave's 32 channels and its share of every tap's channels
+        unsigned a_hi;
+        {
+            unsigned Rp, wq;
+            pix_rp(g, min(m0 + 32 + (lane & 31), M - 1), Rp, wq);
+            unsigned prow = Rp - Rp_lo;
+            if (prow + g.K > nrows) prow = 0;
+            a_hi = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16 + kg * (KPF * 32);
+        }
+        if (SAR_BR_WHEN == 2) load_b0();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's patch stores
+        wg_barrier();
+        TSTAMP(4);
+        auto a_off = [&](int i) __attribute__((always_inline)) {
+            const int v = i / KPF, j = i % KPF, tap = v / NH, hh = v % NH, dy = tap / KS, dx = tap % KS;
+            return (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32) + j * 32);
+        };
+        h16x8 a0[2], a1[2];
+        a0[0] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(0)); a1[0] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(0));
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            if (i == NF / 2) TSTAMP(8);
+            if (i + NF0 < NF) breg[i + NF0] = wmine[(((i + NF0) / KPF) * NKC + ((i + NF0) % KPF)) * 64];   // the stream stays NF0 fragments ahead
+            if (i + 1 < NF) {
+                a0[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(i + 1));
+                a1[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(i + 1));
+            }
+            acc = MFMA16(a0[i & 1], breg[i], acc, 0, 0, 0);
+            acc2 = MFMA16(a1[i & 1], breg[i], acc2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                     // (the scheduler otherwise sinks the stream's loads to their uses: distance 1-2 instead of NF0)
+        }
+    } else if constexpr (KG == 2 && PFB) {
         // (EXPERIMENT, off: -DSAR_KP_PFB=1.  Measured SLOWER: k-phase of the stage-2 block 6 370 -> 6 780 cycles.)  Two k-groups (the 128+-channel layers; a stage = one virtual tap = four fragments per wave; RD = 4, the launcher sees to it).
         // Round 2 read a stage's B fragments right behind the stage's barrier and multiplied at once: ~200 cycles of LDS latency in
         // front of the MFMAs of EVERY stage, 9 (stage 2) or 18 (stage 3) times per block.  Here the fragments of stage st+1 are read
@@ -415,11 +483,13 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
         }
     }
     }
+    if constexpr (!BR) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+    }
     TSTAMP(5);
     if constexpr (!EARLY) load_epi();
-    __syncthreads();                                               // the patch is dead: reuse it as the output staging tile
+    EPI_BARRIER();                                               // the patch is dead: reuse it as the output staging tile
 
     // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), bf16 stores, statistics
     float* ot = reinterpret_cast<float*>(patch) + kg * (TM * TN);  // [KG][TM][TN]: each k-group stages its partial tile
@@ -430,9 +500,10 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             ot[row * TN + col] = acc[r];
+            if constexpr (BR) ot[(row + 32) * TN + col] = acc2[r];
         }
     }
-    __syncthreads();
+    EPI_BARRIER();
     float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
     long long q10 = 0, q11 = 0, q20 = 0, q21 = 0;                  // epi 3: the same sums in 64-bit fixed point (trunk16.h: fix28)
 #pragma unroll
@@ -440,8 +511,9 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
         const int row = rg + RG * i;
         const unsigned m = m0 + row;
         float2 a = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + row * TN + 2 * cp);
-        if constexpr (KG == 2) {
-            const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + TM * TN + row * TN + 2 * cp);
+#pragma unroll
+        for (int kk = 1; kk < KG; ++kk) {                           // the other k-groups' partial tiles
+            const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + kk * (TM * TN) + row * TN + 2 * cp);
             a.x += a2.x; a.y += a2.y;
         }
         float v0 = a.x + b0 + h_lo(rv[i]), v1 = a.y + b1 + h_hi(rv[i]);
@@ -468,7 +540,7 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
         long long* partq = reinterpret_cast<long long*>(part);
         partq[(rg * TN + 2 * cp) * 2 + 0] = q10; partq[(rg * TN + 2 * cp) * 2 + 1] = q20;
         partq[(rg * TN + 2 * cp + 1) * 2 + 0] = q11; partq[(rg * TN + 2 * cp + 1) * 2 + 1] = q21;
-        __syncthreads();
+        EPI_BARRIER();
         if (tid < 2 * TN) {
             const int cc = tid >> 1, which = tid & 1;
             long long s = 0;
@@ -481,7 +553,7 @@ __global__ __launch_bounds__(64 * WMX * WN * KG, KG == 1 ? (WMX * WN == 2 ? 3 : 
     }
     part[(rg * TN + 2 * cp) * 2 + 0] = s10; part[(rg * TN + 2 * cp) * 2 + 1] = s20;
     part[(rg * TN + 2 * cp + 1) * 2 + 0] = s11; part[(rg * TN + 2 * cp + 1) * 2 + 1] = s21;
-    __syncthreads();
+    EPI_BARRIER();
     if (tid < 2 * TN) {
         const int cc = tid >> 1, which = tid & 1;
         float s = 0.f;
@@ -1156,13 +1228,16 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
-    const int KG = (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;                  // two k-groups (512 threads) for the one-block-per-CU layers
-    const int nthr = tm64 ? 128 : tm256 ? 512 : 256 * KG;
+    // BR form (weight fragments in registers, no ring): 64+ source channels into 64+ output channels -- stages 1-3.  SAR_CONV16_BR=0: round 2's forms
+    static const bool br_env = !(getenv("SAR_CONV16_BR") && atoi(getenv("SAR_CONV16_BR")) == 0);
+    const bool br = br_env && WN == 2 && Cin >= 64 && Cin <= 256;      // (512 source channels: 36 fragments per wave would spill)
+    const int KG = br ? (Cin >= 128 ? 4 : 2) : (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;   // k-groups (two: 512 threads for the one-block-per-CU layers)
+    const int nthr = br ? 128 * KG : tm64 ? 128 : tm256 ? 512 : 256 * KG;
     if (p.cap_rows > nthr) return SAR_EINVAL;                                      // one thread per row of the row table
     const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel layers (one block per CU anyway) get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
-    const size_t ring_bytes = (size_t)p.rd * WN * 8 * 1024;
+    const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * 8 * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
     patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
     p.patch_bytes = (int)patch_bytes;
@@ -1181,6 +1256,17 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     static const kern_t kerns2[2][3][2] = {{CV2(1, 1), CV2(1, 2), CV2(1, 4)}, {CV2(2, 1), CV2(2, 2), CV2(2, 4)}};
 #undef CV2
     static bool attr2[2][3][2];
+    if (br) {
+#define CVB(NKC_, NH_, KG_) {conv_bf16_kernel<2, NKC_, NH_, KG_, 2, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, 2, true>}
+        static const kern_t kernsb[3][2] = {CVB(4, 1, 2), CVB(8, 1, 4), CVB(8, 2, 4)};
+#undef CVB
+        static bool attrb[3][2];
+        const kern_t kern = kernsb[ki - 1][k3];
+        if (!attrb[ki - 1][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[ki - 1][k3] = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     if (KG == 2) {
         if (PFB && p.rd != 4) return SAR_EINVAL;                                    // the prefetching k-phase (experiment) runs a four-slot ring
         const kern_t kern = kerns2[WN - 1][ki - 2][k3];

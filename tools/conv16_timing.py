@@ -37,10 +37,25 @@ for name, H, W, Cin, Cout, k in SHAPES:
     bins = torch.zeros(16, 2, Cout, device="cuda")
     if mode == "wgrad":
         continue
+    elif mode == "fwd1":
+        # the second conv of a residual block as the train step issues it: BatchNorm + ReLU of the producer in the fill (constants from
+        # the statistic bins), the activated operand written back (side), residual add, statistics of the output
+        class BN(ctypes.Structure):
+            _fields_ = [(n, vp) for n in ("gamma", "beta", "bins", "bbins", "saved", "mm", "mv", "dgamma", "dbeta")] + \
+                       [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ci), ("ginv", ctypes.c_float), ("det", ci), ("pad_", ci)]
+        n = B * H * W
+        gam = torch.ones(Cin, device="cuda"); bet = torch.zeros(Cin, device="cuda"); saved = torch.zeros(4, Cin, device="cuda")
+        fbins = torch.zeros(16, 2, Cin, device="cuda"); fbins[0, 1] = float(n)      # mean 0, variance 1
+        res = torch.randn(B, H, W, Cout, device="cuda").to(BF); side = torch.empty_like(x)
+        bn = BN(gam.data_ptr(), bet.data_ptr(), fbins.data_ptr(), None, saved.data_ptr(), None, None, None, None, 1.0 / n, 1.0, 1e-3, 0.99, 0, 1.0, 0, 0)
+        keepalive = (gam, bet, saved, fbins, res, side, bn)
+        fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wf.data_ptr(), None, res.data_ptr(), y.data_ptr(), side.data_ptr(), B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
+                                         1, ctypes.byref(bn), 1, bins.data_ptr(), None, None, st)
     else:
         wp = wf if mode == "fwd" else wd
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
                                          0, None, 1, bins.data_ptr(), None, None, st)
+    if mode != "wgrad":
         names = {"  entry->epi loads": (1, 11), "  ->dma issued": (11, 12), "  ->row table": (12, 13), "  ->bn prologue": (13, 14), "  ->barrier": (14, 2),
                  "prologue": (1, 2), "fill": (2, 3), "  k first half": (4, 8), "fill sync": (3, 4), "k-phase": (4, 5), "epilogue": (5, 6), "stats": (6, 7), "total": (1, 7)}
     tb = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
