@@ -156,19 +156,21 @@ __device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
 // Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
 // per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
 // source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
-template <int MODE, int TM, int U, int NTHR>
+// `mid` runs ONCE, behind the issue of the first pieces' loads and in front of their transform: the caller finishes the BatchNorm constants
+// there (trunk16.h: bn_finish), so the bins' round trip, this function's address arithmetic and the pieces' round trip overlap.  Every
+// thread runs every trip (pieces past the end are branch-free no-ops), so `mid` may hold barriers.
+template <int MODE, int TM, int U, int NTHR, typename MID>
 __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
-                                           unsigned nrows, unsigned m0, int tid) {
+                                           unsigned nrows, unsigned m0, int tid, MID&& mid) {
     const unsigned pc = 1u << lg_pc, total = (nrows * g.Wp) << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
     const unsigned c8 = tid & (pc - 1);                            // NTHR % pc == 0: a thread keeps its channel group
     const int dm = g.d - 1, ssh = g.s - 1;
     const bool do_side = side != nullptr && blockIdx.y == 0;       // block-uniform
     Cst8 k;
-    if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
-    for (unsigned i0 = tid; i0 < total; i0 += U * NTHR) {          // U pieces in flight per thread
-        uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
+    uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
+    auto issue = [&](unsigned i0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const unsigned i = i0 + NTHR * j, pos = i >> lg_pc;
@@ -178,19 +180,26 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
             const bool ok = (i < total) & (rt.x != NONE) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
             off[j] = ok ? rt.x + (unsigned)vs * g.Cin + c8 * 8 : NONE;
             own[j] = rt.y + (dm ? 2u * vs : (unsigned)vs >> ssh) - m0;   // < TM: this block owns the source pixel
-            lo[j] = pos * rs + c8 * 16;
+            lo[j] = i < total ? pos * rs + c8 * 16 : dummy;              // branch-free: pieces past the end land in a scratch slot
             const unsigned o = ok ? off[j] : 0u;
             q[j] = *reinterpret_cast<const uint4*>(x + o);
             if constexpr (MODE >= 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
             if constexpr (MODE == 3) q3[j] = *reinterpret_cast<const uint4*>(x3 + o); else q3[j] = q[j];
         }
+    };
+    auto finish = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);                 // branch-free: pieces past the end land in a scratch slot
-            *reinterpret_cast<uint4*>(patch + (i0 + NTHR * j < total ? lo[j] : dummy)) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
+            const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);
+            *reinterpret_cast<uint4*>(patch + lo[j]) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
             if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
         }
-    }
+    };
+    issue(tid);                                                    // trip 0, peeled: `mid` between its loads and their use
+    mid();
+    if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
+    finish();
+    for (unsigned base = U * NTHR; base < total; base += U * NTHR) { issue(base + tid); finish(); }   // U pieces in flight per thread
 }
 
 template <int NKC>
@@ -224,6 +233,9 @@ __device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char
 constexpr bool PFB = SAR_KP_PFB != 0;
 // Barriers of the epilogue: LDS traffic only.  __syncthreads() also drains vmcnt(0): behind the k-phase that is the round trip of the
 // epilogue operands requested a moment earlier (eight-wave form), behind the output stores their write acknowledgements.
+#ifndef SAR_BN_COOP
+#define SAR_BN_COOP 2      // BatchNorm constants of the fill: 2 whole block, bins requested at entry and summed behind the row table (trunk16.h: bn_issue / bn_finish); 3 finished inside the fill (experiment); 1 whole block, in place (bn_prologue_coop); 0 round 2's one-thread-per-channel walk
+#endif
 #ifndef SAR_BR_PD
 #define SAR_BR_PD 8        // BR form: weight fragments in flight ahead of the MFMA that consumes them
 #endif
@@ -323,6 +335,11 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
         if (KG == 2 && PFB && NST > 3) issue_stage(3, 3);          // B fragments read one stage ahead (k-phase below)
     }
     TSTAMP(12);
+#if SAR_BN_COOP >= 2
+    BnRaw braw;
+    constexpr int CIN = NKC < 8 ? 16 * NKC : 128 * NH;             // source channels of this instantiation (the launcher's table)
+    if (p.fill) bn_issue<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, braw);
+#endif
 
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
@@ -340,23 +357,52 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
         rowtab[tid] = rt;
     }
     TSTAMP(13);
+#if SAR_BN_COOP == 2
+    // the bins were requested in front of the row table: their round trip ran underneath it
+    if (p.fill) bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, braw, reinterpret_cast<double*>(patch));
+    TSTAMP(14);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wg_barrier();
+    TSTAMP(2);
+    auto mid = [&]() __attribute__((always_inline)) {};
+#elif SAR_BN_COOP == 3
+    // (EXPERIMENT: the constants finished inside the fill, behind the issue of its first loads -- the pieces held across it cost the
+    // 128- and 168-register forms 75-90 spilled registers)
+    TSTAMP(14);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // raw barrier (no vmcnt drain): the row table is complete
+    wg_barrier();
+    auto mid = [&]() __attribute__((always_inline)) {
+        if (p.fill) {
+            bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, braw, reinterpret_cast<double*>(patch));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wg_barrier();
+        }
+        TSTAMP(2);
+    };
+#else
+#if SAR_BN_COOP
+    if (p.fill) bn_prologue_coop<NTHR>(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, reinterpret_cast<double*>(patch));
+#else
     if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, NTHR);
+#endif
     if constexpr (BR) { if (SAR_BR_WHEN == 1) load_b0(); }
     TSTAMP(14);
     // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wg_barrier();
     TSTAMP(2);
+    auto mid = [&]() __attribute__((always_inline)) {};
+#endif
 
     // (Issuing the patch loads in front of the BatchNorm prologue -- row table, barrier, loads, prologue, barrier, transform + store --
     // was built and measured: no gain.  What the fill costs is its address arithmetic, ~1 400 cycles before the first load leaves,
     // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
     constexpr int FU = NG == 8 ? 2 : 4;                            // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers)
     // ---- fill: the padded patch, all input channels, transformed once
-    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);
-    else fill_patch<3, TM, (FU < 2 ? FU : 2), NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid);   // three tensors: two pieces in flight
+    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, mid);
+    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, mid);
+    else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, mid);
+    else fill_patch<3, TM, (FU < 2 ? FU : 2), NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, mid);   // three tensors: two pieces in flight
     // ---- per-lane A address
     unsigned a_lane;
     {
@@ -1239,6 +1285,8 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
     const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * 8 * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
+    if (patch_bytes < (size_t)nthr * 32) patch_bytes = (size_t)nthr * 32;      // bn_prologue_coop's scratch: G x 4 x Cin x 8 bytes, G x Cin <= threads
+    if (Cin > nthr) return SAR_EINVAL;
     patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
     p.patch_bytes = (int)patch_bytes;
     const size_t lds = (size_t)6 * Cin * 4 + ROWTAB_BYTES + patch_bytes + ring_bytes;

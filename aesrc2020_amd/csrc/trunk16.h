@@ -135,6 +135,163 @@ __device__ __forceinline__ void bn_prologue(const BnP& bn, int mode, int C, int 
     }
 }
 
+// The same constants, computed by the WHOLE block (round 3; conv_bf16_kernel).  bn_prologue above has thread c walk all 16 bins of
+// channel c alone: 32 loads (64 in mode 2) and as many fp64 adds on C threads while the rest of the block waits at the barrier behind it --
+// 2 800 cycles of a stage-2 block's 20 400, 8 700 of a stage-0 block's 27 000 (32 channels: half a wave works, 500 blocks wait on the
+// same 64 cache lines).  Here G = min(NTHR / C, 4) threads share a channel: thread (c, q) sums the bins q, q + G, ... (NB / G loads per
+// sum, one round trip, coalesced), the partial sums meet in LDS scratch `scr` (G x 4 x C x 8 bytes: the patch region, not yet filled), and
+// thread c finishes the channel.  Summation order is fixed (bins of a group ascending, groups ascending), the integer path exact.
+template <int G>
+__device__ __forceinline__ void bn_partials(const BnP& bn, int mode, bool fwd_bins, int C, int c, int q, double* scr) {
+    if (fwd_bins) {
+        if (bn.det) {                                                // kernel-uniform
+            const long long* qb = reinterpret_cast<const long long*>(bn.bins);
+            long long q1 = 0, q2 = 0;
+#pragma unroll
+            for (int b = 0; b < NB / G; ++b) { q1 += qb[((q + b * G) * 2) * C + c]; q2 += qb[((q + b * G) * 2 + 1) * C + c]; }
+            reinterpret_cast<long long*>(scr)[(q * 2) * C + c] = q1; reinterpret_cast<long long*>(scr)[(q * 2 + 1) * C + c] = q2;
+        } else {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int b = 0; b < NB / G; ++b) { s1 += (double)bn.bins[((q + b * G) * 2) * C + c]; s2 += (double)bn.bins[((q + b * G) * 2 + 1) * C + c]; }
+            scr[(q * 2) * C + c] = s1; scr[(q * 2 + 1) * C + c] = s2;
+        }
+    }
+    if (mode == 2) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB / G; ++b) { s1 += (double)bn.bbins[((q + b * G) * 2) * C + c]; s2 += (double)bn.bbins[((q + b * G) * 2 + 1) * C + c]; }
+        scr[(2 * G + q * 2) * C + c] = s1; scr[(2 * G + q * 2 + 1) * C + c] = s2;
+    }
+}
+__device__ __forceinline__ void bn_finalize(const BnP& bn, int mode, bool fwd_bins, int G, int C, float* cst, int cs, bool owner, const double* scr) {
+    const int tid = threadIdx.x;
+    if (tid < C) {
+        const int c = tid;
+        float mean, rstd, scale, shift;
+        if (fwd_bins) {
+            double s1 = 0.0, s2 = 0.0;
+            if (bn.det) {
+                long long q1 = 0, q2 = 0;
+                for (int q = 0; q < G; ++q) { q1 += reinterpret_cast<const long long*>(scr)[(q * 2) * C + c]; q2 += reinterpret_cast<const long long*>(scr)[(q * 2 + 1) * C + c]; }
+                s1 = (double)q1 * FIX28_INV; s2 = (double)q2 * FIX28_INV;
+            } else {
+                for (int q = 0; q < G; ++q) { s1 += scr[(q * 2) * C + c]; s2 += scr[(q * 2 + 1) * C + c]; }
+            }
+            const double mu = s1 * (double)bn.inv_n;
+            double var = s2 * (double)bn.inv_n - mu * mu;
+            var = var > 0.0 ? var : 0.0;
+            mean = (float)mu; rstd = 1.0f / sqrtf((float)var + bn.eps);
+            scale = bn.gamma[c] * rstd; shift = bn.beta[c] - mean * scale;
+            if (owner && bn.write) {
+                bn.saved[c] = mean; bn.saved[C + c] = rstd; bn.saved[2 * C + c] = scale; bn.saved[3 * C + c] = shift;
+                if (bn.moving_mean != nullptr) {
+                    bn.moving_mean[c] = bn.moving_mean[c] * bn.momentum + mean * (1.f - bn.momentum);
+                    bn.moving_var[c] = bn.moving_var[c] * bn.momentum + (float)var * bn.unbias * (1.f - bn.momentum);
+                }
+            }
+        } else {
+            mean = bn.saved[c]; rstd = bn.saved[C + c]; scale = bn.saved[2 * C + c]; shift = bn.saved[3 * C + c];
+        }
+        cst[c] = scale; cst[cs + c] = shift; cst[2 * cs + c] = mean; cst[3 * cs + c] = rstd;
+        if (mode == 2) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int q = 0; q < G; ++q) { s1 += scr[(2 * G + q * 2) * C + c]; s2 += scr[(2 * G + q * 2 + 1) * C + c]; }
+            cst[4 * cs + c] = (float)(s1 * (double)bn.inv_n); cst[5 * cs + c] = (float)(s2 * (double)bn.inv_n);
+            if (owner && bn.write && bn.dgamma != nullptr) { bn.dgamma[c] += (float)s2 * bn.ginv; bn.dbeta[c] += (float)s1 * bn.ginv; }
+        }
+    }}
+
+template <int NTHR>
+__device__ __forceinline__ void bn_prologue_coop(const BnP& bn, int mode, int C, float* cst, int cs, bool owner, double* scr) {
+    const int tid = threadIdx.x;
+    const bool fwd_bins = mode == 1 && bn.bins != nullptr;
+    const int G = NTHR / C >= 4 ? 4 : NTHR / C >= 2 ? 2 : 1;         // C is a power of two <= NTHR (the launcher checks)
+    if (fwd_bins || mode == 2) {
+        const int c = tid & (C - 1), q = tid / C;
+        if (q < G) {
+            if (G == 4) bn_partials<4>(bn, mode, fwd_bins, C, c, q, scr);
+            else if (G == 2) bn_partials<2>(bn, mode, fwd_bins, C, c, q, scr);
+            else bn_partials<1>(bn, mode, fwd_bins, C, c, q, scr);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    bn_finalize(bn, mode, fwd_bins, G, C, cst, cs, owner, scr);
+}
+
+// bn_prologue_coop in two halves, so that the round trip of the bins (written by the producer's atomics: never in this XCD's L2, ~2 800
+// cycles) runs underneath the row table, the fill's address arithmetic and the round trip of the fill's own first loads: bn_issue requests
+// this thread's share of the bins into registers at kernel entry, bn_finish (called by the fill behind the issue of its first pieces) sums,
+// meets the other groups in LDS and writes the constants.  G = 1 (a channel per thread and no spare threads) loads late, in bn_finish.
+// (floats: sums 1 in a, sums 2 in b; 64-bit integers: sums 1 as pairs in a then b, sums 2 in c then d.  Forward and backward bins are never
+// both read by one launch.)
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+struct BnRaw { u32x8 a, b, c, d; };   // (vector VALUES, not arrays: nothing an alloca could be made of.)  v[0..7] = a, v[8..15] = b, v[16..23] = c, v[24..31] = d
+// (ONE float path for the forward and the backward bins -- the base pointer is selected, not the code: with two look-alike branches the
+// optimiser sank their stores into one with a selected ARRAY INDEX, and `r` went to scratch)
+template <int G>
+__device__ __forceinline__ void bn_issue_g(const BnP& bn, int mode, bool fwd_bins, int C, int c, int q, BnRaw& r) {
+    if (fwd_bins && bn.det) {
+        const long long* qp = reinterpret_cast<const long long*>(bn.bins);
+#pragma unroll
+        for (int b = 0; b < NB / G; ++b) {
+            const uint2 t1 = *reinterpret_cast<const uint2*>(qp + ((q + b * G) * 2) * C + c), t2 = *reinterpret_cast<const uint2*>(qp + ((q + b * G) * 2 + 1) * C + c);
+            if (b < 4) { r.a[2 * b] = t1.x; r.a[2 * b + 1] = t1.y; r.c[2 * b] = t2.x; r.c[2 * b + 1] = t2.y; }
+            else { r.b[2 * b - 8] = t1.x; r.b[2 * b - 7] = t1.y; r.d[2 * b - 8] = t2.x; r.d[2 * b - 7] = t2.y; }
+        }
+    } else {
+        const float* src = mode == 2 ? bn.bbins : bn.bins;
+#pragma unroll
+        for (int b = 0; b < NB / G; ++b) { r.a[b] = __float_as_uint(src[((q + b * G) * 2) * C + c]); r.b[b] = __float_as_uint(src[((q + b * G) * 2 + 1) * C + c]); }
+    }
+}
+template <int G>
+__device__ __forceinline__ void bn_sum_g(const BnP& bn, int mode, bool fwd_bins, int C, int c, int q, const BnRaw& r, double* scr) {
+    if (fwd_bins && bn.det) {
+        long long q1 = 0, q2 = 0;
+#pragma unroll
+        for (int b = 0; b < NB / G; ++b) {
+            if (b < 4) { q1 += (long long)(((unsigned long long)r.a[2 * b + 1] << 32) | r.a[2 * b]); q2 += (long long)(((unsigned long long)r.c[2 * b + 1] << 32) | r.c[2 * b]); }
+            else { q1 += (long long)(((unsigned long long)r.b[2 * b - 7] << 32) | r.b[2 * b - 8]); q2 += (long long)(((unsigned long long)r.d[2 * b - 7] << 32) | r.d[2 * b - 8]); }
+        }
+        reinterpret_cast<long long*>(scr)[(q * 2) * C + c] = q1; reinterpret_cast<long long*>(scr)[(q * 2 + 1) * C + c] = q2;
+    } else {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB / G; ++b) { s1 += (double)__uint_as_float(r.a[b]); s2 += (double)__uint_as_float(r.b[b]); }
+        const int o = mode == 2 ? 2 * G : 0;
+        scr[(o + q * 2) * C + c] = s1; scr[(o + q * 2 + 1) * C + c] = s2;
+    }
+}
+template <int NTHR>
+__device__ __forceinline__ int bn_groups(int C) { return NTHR / C >= 4 ? 4 : NTHR / C >= 2 ? 2 : 1; }
+// (C is a compile-time constant of the calling kernel: with G chosen at run time, parts of `r` ended up in scratch -- and a wait for the
+// loaded value in front of the scratch store, i.e. no early issue at all)
+template <int NTHR, int C>
+__device__ __forceinline__ void bn_issue(const BnP& bn, int mode, BnRaw& r) {
+    constexpr int G = NTHR / C >= 4 ? 4 : NTHR / C >= 2 ? 2 : 1;
+    const bool fwd_bins = mode == 1 && bn.bins != nullptr;
+    const int tid = threadIdx.x, c = tid & (C - 1), q = tid / C;
+    if constexpr (G > 1) {
+        if ((fwd_bins || mode == 2) && q < G) bn_issue_g<G>(bn, mode, fwd_bins, C, c, q, r);
+    }
+}
+template <int NTHR, int C>
+__device__ __forceinline__ void bn_finish(const BnP& bn, int mode, float* cst, int cs, bool owner, const BnRaw& r, double* scr) {
+    constexpr int G = NTHR / C >= 4 ? 4 : NTHR / C >= 2 ? 2 : 1;
+    const int tid = threadIdx.x;
+    const bool fwd_bins = mode == 1 && bn.bins != nullptr;
+    if (fwd_bins || mode == 2) {
+        const int c = tid & (C - 1), q = tid / C;
+        if (q < G) {
+            if constexpr (G > 1) bn_sum_g<G>(bn, mode, fwd_bins, C, c, q, r, scr);
+            else bn_partials<1>(bn, mode, fwd_bins, C, c, q, scr);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    bn_finalize(bn, mode, fwd_bins, G, C, cst, cs, owner, scr);
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
 __device__ __forceinline__ s16x4 lds_tr(const unsigned char* base, unsigned off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off));
