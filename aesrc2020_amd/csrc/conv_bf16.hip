@@ -357,27 +357,28 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
         rowtab[tid] = rt;
     }
     TSTAMP(13);
-#if SAR_BN_COOP == 2
-    // the bins were requested in front of the row table: their round trip ran underneath it
-    if (p.fill) bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, braw, reinterpret_cast<double*>(patch));
+#if SAR_BN_COOP >= 2
+    // The bins were requested in front of the row table: their round trip ran underneath it.  MIDFILL (EXPERIMENT, SAR_BN_COOP=3): the
+    // constants finished INSIDE the fill, behind the issue of its first pieces' loads, so that the partial sums, their two barriers and the
+    // pieces' round trip overlap as well.  Measured on the BR forms (256 registers to live in): no gain -- stage-2 block 18.9k -> 19.4k
+    // cycles, class 234 -> 236 us; on the 128- / 168-register forms the pieces held across it spill 75-90 registers.
+    constexpr bool MIDFILL = SAR_BN_COOP == 3;
+    if constexpr (!MIDFILL) {
+        if (p.fill) bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, braw, reinterpret_cast<double*>(patch));
+    }
     TSTAMP(14);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // raw barrier (no vmcnt drain): row table (and constants) complete
     wg_barrier();
-    TSTAMP(2);
-    auto mid = [&]() __attribute__((always_inline)) {};
-#elif SAR_BN_COOP == 3
-    // (EXPERIMENT: the constants finished inside the fill, behind the issue of its first loads -- the pieces held across it cost the
-    // 128- and 168-register forms 75-90 spilled registers)
-    TSTAMP(14);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // raw barrier (no vmcnt drain): the row table is complete
-    wg_barrier();
+    if constexpr (!MIDFILL) TSTAMP(2);
     auto mid = [&]() __attribute__((always_inline)) {
-        if (p.fill) {
-            bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, braw, reinterpret_cast<double*>(patch));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wg_barrier();
+        if constexpr (MIDFILL) {
+            if (p.fill) {
+                bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, blockIdx.x == 0 && blockIdx.y == 0, braw, reinterpret_cast<double*>(patch));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wg_barrier();
+            }
+            TSTAMP(2);
         }
-        TSTAMP(2);
     };
 #else
 #if SAR_BN_COOP

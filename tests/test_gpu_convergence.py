@@ -15,9 +15,12 @@ Measured (round 3, four runs of this script over two batch pools): control 0.08 
 worst window (all in the steep second to fourth windows, where a few steps of lead or lag are a large relative difference -- and two
 bf16x3 runs of the same pool differ by 1.4 % in their FIRST window already: fp32 atomics); last window within 3 % of the reference
 in every run (1.00 .. 1.03); accuracy 1.0 everywhere.  The 2-byte runs are no further from the reference than the fp32 control's chaos level allows one to
-resolve.  (The bands are 1.0 / 0.15 since one full-suite run of round 3 saw the fp32 CONTROL leave the first bands, 0.5 / 0.05, that the
-four measured runs had suggested: a run that stalls or diverges is off by multiples in the steep windows -- 36 against 3.7 -- and
-by tens of per cent at the end, which these bands still catch; chaos between two fp32-class runs they no longer trip on.)  Trajectories are not compared parameter by parameter: Adam's first steps move every weight by +-lr whatever the gradient's
+resolve.  (The bands are 1.0 / 0.3: eight further script runs in round 3 -- 32 trainings -- put the spread of the REFERENCE itself on record.  Its loss
+floor is ~1.00 with excursions to 1.05-1.2 that any run can be in the middle of when the last window closes (bf16x3 1.145 against 1.00-1.03
+for the other three; f32 control 1.196 against bf16x3 1.045: 0.145), and in the steep windows two runs of ANY mode are up to 0.66 apart
+(bf16 2.71 against 1.63 in window three of one run; the f32 control 0.31).  A run that stalls or diverges is off by multiples in the steep
+windows -- 36 against 3.7 -- and stays there; these bands catch that and no longer trip on the chaos between two healthy runs, which the
+first bands, 0.5 / 0.05, did twice in five full-suite runs.)  Trajectories are not compared parameter by parameter: Adam's first steps move every weight by +-lr whatever the gradient's
 magnitude, so two runs that differ in the last bit decorrelate -- what has to agree is the learning curve.
 
     python tests/test_gpu_convergence.py          prints the curves (the numbers DESIGN.md quotes)
@@ -37,7 +40,7 @@ KW = dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim
           disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", lr=float(os.environ.get("CONV_LR", 1e-3)))
 B, STEPS, POOL, WIN = 8, int(os.environ.get("CONV_STEPS", 400)), 48, int(os.environ.get("CONV_WIN", 50))
 AMP = float(os.environ.get("CONV_AMP", 0.10))
-BAND_LOSS, BAND_FINAL, BAND_ACC = 1.0, 0.15, 0.1
+BAND_LOSS, BAND_FINAL, BAND_ACC = 1.0, 0.3, 0.1
 MODES = {"bf16x3": ("fp32", "bf16x3", "fp32"), "f32": ("fp32", "fp32", "fp32"), "fp16": ("fp16", "bf16x3", "bf16"), "bf16": ("bf16", "bf16x3", "bf16")}
 
 
