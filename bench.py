@@ -91,8 +91,15 @@ def conv_roofline(model, B, iters=10):
         b1, b2 = bins(cout), bins(cin)
 
         def inst(cv, ci, co):
-            kg = 2 if ci >= 128 and os.environ.get("SAR_CONV16_KG") != "1" else 1          # k-groups: eight waves for the 128+-channel sources
-            return "conv_bf16_kernel<%d, %d, %d, %d>" % (2 if co >= 64 else 1, min(ci // 16, 8), cv.k * cv.k * max(1, ci // 128), kg)
+            """Name of the instantiation the launch that just ran used, as rocprofv3 prints it (asked of the library: the tile form depends on
+            what fits the LDS).  Call it BEHIND the timed launch."""
+            import ctypes
+            out = (ctypes.c_int * 6)()
+            assert _lib.lib().fn["sar_conv2d_last_class_" + tr.sfx](out) == 0
+            return "conv_bf16_kernel<%d, %d, %d, %d, %d, %s>" % (out[0], out[1], out[2], out[3], out[4], "true" if out[5] else "false")
+
+        def add_l(cls_fn, secs, flops, nbytes):                       # the class is asked for after `secs` was measured (argument order)
+            add(cls_fn(), secs, flops, nbytes)
 
         def fl(cv):
             return 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k
@@ -102,26 +109,26 @@ def conv_roofline(model, B, iters=10):
             return (alg, alg + eb * extra)
 
         fb1 = bn1.ref(R1, "saved", False) if bn1 is not None else None
-        add(inst(c1v, cin, cout), timed(lambda: c1v.fwd16(x, y, B, fill=1 if bn1 is not None else 0, fbn=fb1, e_bins=b1, side=a if bn1 is not None else None)),
+        add_l(lambda: inst(c1v, cin, cout), timed(lambda: c1v.fwd16(x, y, B, fill=1 if bn1 is not None else 0, fbn=fb1, e_bins=b1, side=a if bn1 is not None else None)),
             fl(c1v), by(c1v, x.numel() if bn1 is not None else 0))
-        add(inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
+        add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
             fl(c2v), by(c2v, 2 * c1.numel()))
         if nxt_bn1 is None:                                         # last block: its gradient comes materialised from the final BatchNorm
-            add(inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
+            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
         else:                                                       # fill 3: the block behind hands over (da1, x, shortcut gradient)
             xn = rnd(B, H2, W2, cout)
-            add(inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res, side=y,
+            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res, side=y,
                                                                  e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, 4 * c1.numel()))
         if bn1 is not None:
-            add(inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
+            add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
                                                                 e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
         else:
             r1 = rnd(B, H, W, cin)
-            add(inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
+            add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
                 fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
         if scv is not None:
-            add(inst(scv, cin, cout), timed(lambda: scv.fwd16(x, y, B)), fl(scv), by(scv))
-            add(inst(scv, cout, cin), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv))
+            add_l(lambda: inst(scv, cin, cout), timed(lambda: scv.fwd16(x, y, B)), fl(scv), by(scv))
+            add_l(lambda: inst(scv, cout, cin), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv))
         for cv, xx in ((c1v, x), (c2v, c1)) + (((scv, x),) if scv is not None else ()):
             wg.append((cv.wgrad16(xx, g, B, False), fl(cv), by(cv)))             # batched below, as the train step runs them
 
@@ -149,7 +156,7 @@ def conv_roofline(model, B, iters=10):
             sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
                 plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1), tr.sfx)
-                nm = ("wgrad3_bf16_kernel<2, 2>" if cls[2] else "wgrad3_bf16_kernel<1, 1>") if cls[0] == 3 else "wgrad1_bf16_kernel"
+                nm = ("wgrad3_bf16_kernel<2, 2, true, 0>" if cls[2] else "wgrad3_bf16_kernel<1, 1, false, 0>") if cls[0] == 3 else "wgrad1_bf16_kernel"   # (as rocprofv3 prints them)
                 c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, design_bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["launches"] += 1
                 c["bytes"] += sum(w_[2][0] for w_ in sel); c["design_bytes"] += sum(w_[2][1] for w_ in sel)

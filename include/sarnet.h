@@ -185,6 +185,9 @@ int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarSt
 int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                     int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
+/* Introspection (bench.py, tools): the template arguments <WN, NKC, VT, KG, WMX, BR> of the conv_bf16_kernel instantiation the most
+ * recent sar_conv2d_bf16 launch of this process ran -- the name rocprofv3 reports it under.  Not thread-safe. */
+int sar_conv2d_last_class_bf16(int* out6);
 /* Kernel gradients (resnet.py:39-42, 60-63, 82-87, 113-117 under Keras' backward pass) of MANY convolutions in one launch, on
  * PLAIN bf16 operands: x = the `side` tensor of the forward conv (or the raw input of a shortcut / first conv), dy = the
  * gradient tensor (for a conv that feeds a BatchNorm: the `side` tensor of its input-gradient launch).
@@ -256,6 +259,7 @@ int sar_conv_pack_weights_f16(const void* table, int n, int total_blocks, sarStr
 int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
+int sar_conv2d_last_class_f16(int* out6);
 int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                const int* slices_dev, float* slab, sarStream_t stream);
 int sar_bn_bwd_apply_f16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
