@@ -122,6 +122,7 @@ struct ConvP {
     int cap_rows;               // patch rows the LDS allocation holds
     int patch_bytes;            // LDS bytes of the patch region (incl. the 1 KiB scratch slot); the weight ring follows
     int rd;                     // depth of the weight ring: 3, or 4 where the LDS has room (128+-channel stride-1 layers)
+    int cw; unsigned mg_cw;     // 16-byte pieces of a patch row (padded width x Cin / 8) and the magic number of the division by it
 };
 constexpr int ROWTAB_BYTES = 1024;   // per patch row {source row base offset | NONE, owner pixel of the row's first column}
 
@@ -159,10 +160,62 @@ __device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
 // `mid` runs ONCE, behind the issue of the first pieces' loads and in front of their transform: the caller finishes the BatchNorm constants
 // there (trunk16.h: bn_finish), so the bins' round trip, this function's address arithmetic and the pieces' round trip overlap.  Every
 // thread runs every trip (pieces past the end are branch-free no-ops), so `mid` may hold barriers.
+#if SAR_FILL_ROWS
+// Round 3: a thread keeps ONE column piece (padded column wp, channel group c8) and walks the patch rows: the column test, the channel
+// offset and the LDS column offset are per-thread constants, a piece costs one row-table read and ~10 instructions.  (Round 2 dealt the
+// pieces out linearly -- piece i of the patch to thread i % NTHR: a division by the padded width, the column test and three products per
+// piece, ~40 instructions; PMC: ~800 VALU instructions per wave and stage-0 launch, the SIMDs issue-bound.)  cw = Wp * pieces per position
+// threads share a row, NTHR / cw rows are in flight per trip (the launcher checks cw <= NTHR); the threads beyond run no-op pieces.
 template <int MODE, int TM, int U, int NTHR, typename MID>
 __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
-                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, MID&& mid) {
+                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, MID&& mid) {
+    const unsigned pc = 1u << lg_pc;
+    const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
+    const unsigned rsub = udiv((unsigned)tid, mg_cw, cw), col = tid - rsub * cw, rpi = udiv((unsigned)NTHR, mg_cw, cw);   // row of the trip, column piece, rows per trip
+    const unsigned wp = col >> lg_pc, c8 = col & (pc - 1);
+    const int dm = g.d - 1, ssh = g.s - 1;
+    const int v = (int)wp - g.pl, vs = v >> dm;
+    const bool ok_col = (rsub < rpi) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
+    const unsigned coloff = (unsigned)vs * g.Cin + c8 * 8, own_col = (dm ? 2u * vs : (unsigned)vs >> ssh) - m0, lo_col = wp * rs + c8 * 16;
+    const unsigned rowbytes = g.Wp * rs;
+    const bool do_side = side != nullptr && first_ntile;           // block-uniform
+    Cst8 k;
+    uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
+    auto issue = [&](unsigned r0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const unsigned prow = r0 + rpi * j, pr = min(prow, nrows - 1);
+            const uint2 rt = rowtab[pr];
+            const bool in = (prow < nrows) & (rsub < rpi), ok = ok_col & (prow < nrows) & (rt.x != NONE);
+            off[j] = ok ? rt.x + coloff : NONE;
+            own[j] = rt.y + own_col;                               // < TM: this block owns the source pixel
+            lo[j] = in ? pr * rowbytes + lo_col : dummy;           // branch-free: pieces past the end land in a scratch slot
+            const unsigned o = ok ? off[j] : 0u;
+            q[j] = *reinterpret_cast<const uint4*>(x + o);
+            if constexpr (MODE >= 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
+            if constexpr (MODE == 3) q3[j] = *reinterpret_cast<const uint4*>(x3 + o); else q3[j] = q[j];
+        }
+    };
+    auto finish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);
+            *reinterpret_cast<uint4*>(patch + lo[j]) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
+            if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
+        }
+    };
+    issue(rsub);                                                   // trip 0, peeled: `mid` between its loads and their use
+    mid();
+    if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
+    finish();
+    for (unsigned base = U * rpi; base < nrows; base += U * rpi) { issue(base + rsub); finish(); }   // U rows in flight per thread
+}
+#else
+template <int MODE, int TM, int U, int NTHR, typename MID>
+__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
+                                           int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
+                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, MID&& mid) {
     const unsigned pc = 1u << lg_pc, total = (nrows * g.Wp) << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
     const unsigned c8 = tid & (pc - 1);                            // NTHR % pc == 0: a thread keeps its channel group
@@ -202,6 +255,8 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
     for (unsigned base = U * NTHR; base < total; base += U * NTHR) { issue(base + tid); finish(); }   // U pieces in flight per thread
 }
 
+#endif
+
 template <int NKC>
 __device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char* patch, unsigned addr) {
 #pragma unroll
@@ -233,11 +288,14 @@ __device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char
 constexpr bool PFB = SAR_KP_PFB != 0;
 // Barriers of the epilogue: LDS traffic only.  __syncthreads() also drains vmcnt(0): behind the k-phase that is the round trip of the
 // epilogue operands requested a moment earlier (eight-wave form), behind the output stores their write acknowledgements.
+#ifndef SAR_FILL_ROWS
+#define SAR_FILL_ROWS 1    // patch fill: 1 a thread keeps a column piece and walks the rows (round 3); 0 pieces dealt out linearly (round 2)
+#endif
 #ifndef SAR_CONV_XCD
 #define SAR_CONV_XCD 1     // XCD-aware tile order of conv_bf16_kernel (0: dispatch order)
 #endif
 #ifndef SAR_BN_COOP
-#define SAR_BN_COOP 2      // BatchNorm constants of the fill: 2 whole block, bins requested at entry and summed behind the row table (trunk16.h: bn_issue / bn_finish); 3 finished inside the fill (experiment); 1 whole block, in place (bn_prologue_coop); 0 round 2's one-thread-per-channel walk
+#define SAR_BN_COOP 4      // BatchNorm constants of the fill: 2 whole block, bins requested at entry and summed behind the row table (trunk16.h: bn_issue / bn_finish); 3 finished inside the fill (experiment); 1 whole block, in place (bn_prologue_coop); 0 round 2's one-thread-per-channel walk
 #endif
 #ifndef SAR_BR_PD
 #define SAR_BR_PD 8        // BR form: weight fragments in flight ahead of the MFMA that consumes them
@@ -262,7 +320,7 @@ constexpr bool PFB = SAR_KP_PFB != 0;
 template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
     static_assert(BR || KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
-    static_assert(!BR || (WN == 2 && WMX == 2 && NKC / KG == 2), "BR: 64 x 64 tiles, two fragments per virtual tap and wave");
+    static_assert(!BR || (WN == 2 && (WMX == 2 || WMX == 1) && NKC / KG == 2), "BR: 64 (or 32: WMX = 1, the 512-channel sources whose 64-pixel patch does not fit the LDS) x 64 tiles, two fragments per virtual tap and wave");
     constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
     constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
     static_assert(BR || (WN * 8) % NW == 0, "stage DMA must divide evenly");
@@ -372,7 +430,7 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
     // constants finished INSIDE the fill, behind the issue of its first pieces' loads, so that the partial sums, their two barriers and the
     // pieces' round trip overlap as well.  Measured on the BR forms (256 registers to live in): no gain -- stage-2 block 18.9k -> 19.4k
     // cycles, class 234 -> 236 us; on the 128- / 168-register forms the pieces held across it spill 75-90 registers.
-    constexpr bool MIDFILL = SAR_BN_COOP == 3;
+    constexpr bool MIDFILL = SAR_BN_COOP == 3 || (SAR_BN_COOP == 4 && BR);
     if constexpr (!MIDFILL) {
         if (p.fill) bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, bx == 0 && by == 0, braw, reinterpret_cast<double*>(patch));
     }
@@ -410,10 +468,10 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
     // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
     constexpr int FU = NG == 8 ? 2 : 4;                            // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers)
     // ---- fill: the padded patch, all input channels, transformed once
-    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else fill_patch<3, TM, (FU < 2 ? FU : 2), NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight
+    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);
+    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);
+    else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);
+    else fill_patch<3, TM, (FU < 2 ? FU : 2), NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);   // three tensors: two pieces in flight
     // ---- per-lane A address
     unsigned a_lane;
     {
@@ -437,8 +495,8 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
     const unsigned char* bmine = bring + (wn * 8 + kg * KPF) * 1024 + lane * 16;
     if constexpr (BR) {
         // acc: pixels 0-31 of the tile, acc2: pixels 32-63; both on this wave's 32 channels and its share of every tap's channels
-        unsigned a_hi;
-        {
+        unsigned a_hi = 0;
+        if constexpr (WMX == 2) {
             unsigned Rp, wq;
             pix_rp(g, min(m0 + 32 + (lane & 31), M - 1), Rp, wq);
             unsigned prow = Rp - Rp_lo;
@@ -454,17 +512,18 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
             return (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32) + j * 32);
         };
         h16x8 a0[2], a1[2];
-        a0[0] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(0)); a1[0] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(0));
+        a0[0] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(0));
+        if constexpr (WMX == 2) a1[0] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(0));
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             if (i == NF / 2) TSTAMP(8);
             if (i + NF0 < NF) breg[i + NF0] = wmine[(((i + NF0) / KPF) * NKC + ((i + NF0) % KPF)) * 64];   // the stream stays NF0 fragments ahead
             if (i + 1 < NF) {
                 a0[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(i + 1));
-                a1[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(i + 1));
+                if constexpr (WMX == 2) a1[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(i + 1));
             }
             acc = MFMA16(a0[i & 1], breg[i], acc, 0, 0, 0);
-            acc2 = MFMA16(a1[i & 1], breg[i], acc2, 0, 0, 0);
+            if constexpr (WMX == 2) acc2 = MFMA16(a1[i & 1], breg[i], acc2, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);                     // (the scheduler otherwise sinks the stream's loads to their uses: distance 1-2 instead of NF0)
         }
     } else if constexpr (KG == 2 && PFB) {
@@ -557,7 +616,7 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             ot[row * TN + col] = acc[r];
-            if constexpr (BR) ot[(row + 32) * TN + col] = acc2[r];
+            if constexpr (BR && WMX == 2) ot[(row + 32) * TN + col] = acc2[r];
         }
     }
     EPI_BARRIER();
@@ -1273,6 +1332,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     p.fill = fill; if (fbn) p.fb = *fbn;
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;
     p.lg_pc = ilog2(Cin / 8); p.rs = Cin * 2 + 16;
+    p.cw = p.g.Wp * (Cin / 8); p.mg_cw = magic(p.cw);
     p.Fs = K * K * Cin / 16 + 8;
     const int WN = Cout >= 64 ? 2 : 1, TN = 32 * WN;
     // 32 output channels from up to 64 source channels (stage 0 and its gradients): 64-pixel tiles on two waves (SAR_CONV16_TM64=0: 128 / four)
@@ -1289,13 +1349,20 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
         tm256 = tm_env == 256 || (size_t)6 * Cin * 4 + ROWTAB_BYTES * 2 + ((pb + 1023) & ~(size_t)1023) + 3 * 8 * 1024 <= 80 * 1024;
     }
     const bool tm64 = tm_env == 64 && narrow;
-    const int TM = tm64 ? 64 : tm256 ? 256 : 32 * (4 / WN);
+    // BR form (weight fragments in registers, no ring): 64+ source channels into 64+ output channels -- stages 1-3.  SAR_CONV16_BR=0: round 2's forms
+    static const bool br_env = !(getenv("SAR_CONV16_BR") && atoi(getenv("SAR_CONV16_BR")) == 0);
+    const bool br = br_env && WN == 2 && Cin >= 64;
+    // 256 / 512 source channels whose 64-pixel patch does not fit the LDS (res_filters = 64: the 512-channel stage exceeds 160 KB by 1.3 KB, its
+    // stride-2 entry from 256 channels by more): 32-pixel tiles
+    bool br32 = false;
+    if (br && Cin >= 256) {
+        const size_t pb64 = (size_t)patch_rows_bound(p.g, 64 < p.g.M ? 64 : p.g.M) * p.g.Wp * p.rs + 1024;
+        br32 = Cin == 512 || (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((pb64 + 1023) & ~(size_t)1023) > 160 * 1024;   // (512: the 32-pixel form is the only instantiation)
+    }
+    const int TM = br32 ? 32 : tm64 ? 64 : tm256 ? 256 : 32 * (4 / WN);
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
-    // BR form (weight fragments in registers, no ring): 64+ source channels into 64+ output channels -- stages 1-3.  SAR_CONV16_BR=0: round 2's forms
-    static const bool br_env = !(getenv("SAR_CONV16_BR") && atoi(getenv("SAR_CONV16_BR")) == 0);
-    const bool br = br_env && WN == 2 && Cin >= 64 && Cin <= 256;      // (512 source channels: 36 fragments per wave would spill)
     const int KG = br ? (Cin >= 128 ? 4 : 2) : (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;   // k-groups (two: 512 threads for the one-block-per-CU layers)
     const int nthr = br ? 128 * KG : tm64 ? 128 : tm256 ? 512 : 256 * KG;
     if (p.cap_rows > nthr) return SAR_EINVAL;                                      // one thread per row of the row table
@@ -1305,7 +1372,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * 8 * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
     if (patch_bytes < (size_t)nthr * 32) patch_bytes = (size_t)nthr * 32;      // bn_prologue_coop's scratch: G x 4 x Cin x 8 bytes, G x Cin <= threads
-    if (Cin > nthr) return SAR_EINVAL;
+    if (Cin > nthr || (SAR_FILL_ROWS && p.cw > nthr)) return SAR_EINVAL;   // (a patch row wider than the block: no such layer in the model's range)
     patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
     p.patch_bytes = (int)patch_bytes;
     const size_t lds = (size_t)6 * Cin * 4 + ROWTAB_BYTES + patch_bytes + ring_bytes;
@@ -1313,7 +1380,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     const dim3 grid((unsigned)cdiv(p.g.M, TM), (unsigned)(Cout / TN));
     // template arguments of the instantiation this launch runs, as rocprofv3 prints them (bench.py classes its conv timings by them)
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
-    g_last_class[3] = KG; g_last_class[4] = br ? 2 : tm64 ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
+    g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm64 ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
     // instantiations: [WN][NKC in {2,4,8}][K == 3]; Cin = 256 / 512 run NKC = 8 with 2 / 4 channel parts per tap
     typedef void (*kern_t)(const ConvP);
 #define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
@@ -1328,11 +1395,14 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     static bool attr2[2][3][2];
     if (br) {
 #define CVB(NKC_, NH_, KG_) {conv_bf16_kernel<2, NKC_, NH_, KG_, 2, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, 2, true>}
-        static const kern_t kernsb[3][2] = {CVB(4, 1, 2), CVB(8, 1, 4), CVB(8, 2, 4)};
+        static const kern_t kernsb[5][2] = {CVB(4, 1, 2), CVB(8, 1, 4), CVB(8, 2, 4), {conv_bf16_kernel<2, 8, 2, 4, 1, true>, conv_bf16_kernel<2, 8, 18, 4, 1, true>},
+                                            {conv_bf16_kernel<2, 8, 4, 4, 1, true>, conv_bf16_kernel<2, 8, 36, 4, 1, true>}};
 #undef CVB
-        static bool attrb[3][2];
-        const kern_t kern = kernsb[ki - 1][k3];
-        if (!attrb[ki - 1][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[ki - 1][k3] = true; }
+        static bool attrb[5][2];
+        if (Cin == 512 && !br32) return SAR_EINVAL;                                   // (no 64-pixel instantiation for 512 source channels)
+        const int kb = br32 ? (Cin == 256 ? 3 : 4) : ki - 1;
+        const kern_t kern = kernsb[kb][k3];
+        if (!attrb[kb][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[kb][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;

@@ -197,9 +197,9 @@ class ResNetTrunk(Layer):
         self._gscale_cfg = _lib.get_trunk_gscale() if self.half else 1.0      # 0: automatic, 64 x batch (_set_gscale)
         self.gscale = self.ginv = 1.0
         self.det = self.bf16 and _lib.get_bn_deterministic()                 # forward BatchNorm sums in 64-bit fixed point (SAR_BN_DET=1)
-        if self.bf16 and (filters != 32 or stem_c not in (32, 64)):
-            raise ValueError("2-byte trunk: res_filters must be 32 (the reference's train.py:54 default; channel counts are powers of two "
-                             "in [32, 256], the 512-channel stage of F=64 does not fit the LDS patch); got %d" % filters)
+        if self.bf16 and (filters not in (32, 64) or stem_c not in (32, 64)):
+            raise ValueError("2-byte trunk: res_filters must be 32 (the reference's train.py:54 default) or 64 (SAR_Net's own default, model.py:204): "
+                             "channel counts are powers of two in [32, 512]; got %d" % filters)
         self.stem = _Conv(st, st.auto_name("conv2d"), 7, 1, stem_c, 2, "same")
         self.stem_bn = _BN(st, st.auto_name("batch_normalization"), stem_c)
         self.blocks = []

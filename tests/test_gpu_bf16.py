@@ -205,6 +205,9 @@ SHAPES = [
     (2, 11, 20, 32, 64, 3, 2, "same"),               # odd height, stride 2
     (2, 10, 6, 64, 128, 1, 2, "valid"),
     (1, 4, 4, 512, 512, 3, 1, "same"),               # two channel halves per tap
+    (6, 13, 3, 512, 512, 3, 1, "same"),              # res_filters = 64 (round 3): stage 3 on 32-pixel tiles (the 64-pixel patch of 512 channels exceeds the LDS)
+    (4, 25, 5, 256, 512, 3, 2, "same"),              # ... its entry: forward from 256 channels, input gradient from 512
+    (4, 25, 5, 256, 512, 1, 2, "valid"),
     (64, 100, 20, 64, 32, 3, 1, "same"),             # stage 0, block 0 conv1
     (64, 100, 20, 64, 32, 1, 1, "valid"),            # stage 0 shortcut
     (64, 100, 20, 32, 32, 3, 1, "same"),             # stage 0
@@ -223,7 +226,7 @@ def _ids(shapes):
 
 
 IDS = _ids(SHAPES)
-SOME = SHAPES[:6] + SHAPES[6::4]                  # the fill variants: all small cases + every fourth bench shape
+SOME = SHAPES[:9] + SHAPES[9::4]                  # the fill variants: all small cases + every fourth bench shape
 IDS_SOME = _ids(SOME)
 
 

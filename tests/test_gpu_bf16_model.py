@@ -35,6 +35,9 @@ CASES = {
                             vlad_clusters=8, ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=50,
                             max_ctc_len=8, metric_loss="circleloss", B=8),
     "res18_avg": dict(input_shape=[136, 80, 1], res_type="res18", res_filters=32, hidden_dim=32, mto="avg", B=6),
+    # res_filters = 64 (SAR_Net's own default, model.py:204; round 3): 64 / 128 / 256 / 512 channels, the 512-channel stage on 32-pixel tiles
+    "res34_f64_gvlad": dict(input_shape=[136, 80, 1], res_type="res34", res_filters=64, hidden_dim=32, mto="gvlad", vlad_clusters=4,
+                            ghost_clusters=1, disc_enable=True, metric_loss="cosface", B=4),
 }
 
 

@@ -17,12 +17,15 @@ with contextlib.redirect_stdout(io.StringIO()):
     model, tm = SAR_Net(shape, lr=0.01, gpus=1, seed=0, use_graph=True, **kw)
 xi, yi = synthetic_batch(shape, B, False, True, seed=1234)
 d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in {**xi, **yi}.items()}
-for _ in range(4):
+for _ in range(4 + (150 if os.environ.get("CV_STEP_ONLY") else 0)):
     tm.set_device_batch(d); tm.train_step_device()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20):
+NS = int(os.environ.get("CV_STEPS", 20))
+for _ in range(NS):
     tm.set_device_batch(d); tm.train_step_device()
-torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 20 * 1e3
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / NS * 1e3
+if os.environ.get("CV_STEP_ONLY"):                                  # in-step A/B of two builds: several hundred steps, no isolated replays
+    print("%-28s step %.4f ms (%d steps)" % (os.path.basename(os.environ.get("SAR_LIB_PATH", "default")), ms, NS)); sys.exit(0)
 r = bench.conv_roofline(model, B)
 print("%-28s step %.3f ms conv_total %.1f us | %s" % (os.path.basename(os.environ.get("SAR_LIB_PATH", "default")), ms, r["conv_total_us_per_step"],
       " ".join("%s=%.1f" % (k.replace("conv_bf16_kernel", "c").replace("wgrad", "w").replace("_bf16_kernel", "").replace(" ", ""), v["us_per_step"]) for k, v in r["conv_classes"].items())))
