@@ -13,6 +13,10 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDP = 68;  // LDP: padded row (floats), keeps 16-B alignment
 
+// tanh on v_exp_f32 + v_rcp_f32 (absolute error ~1e-7; libm's tanhf is ~100 instructions per value, 16 values per lane in the epilogue of a
+// launch whose whole block lives ~6 us: the tanh Dense layers cost 8.1 us against 6.8 for the same GEMM without it)
+__device__ __forceinline__ float fast_tanh(float a) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.88539008f * a)); }
+
 template <bool KC>
 __device__ __forceinline__ void load_tile(float (&r)[4], const float* __restrict__ P, int ld, int mn0, int k0,
                                           int MN, int K, int tid, bool vec_ok) {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmBatch gb, int M
         if (splitk > 1) {
             atomicAdd(dst, v);
         } else {
-            if (act == ACT_TANH) v = tanhf(v);
+            if (act == ACT_TANH) v = fast_tanh(v);
             else if (act == ACT_RELU) v = fmaxf(v, 0.f);
             if (accumulate) v += *dst;
             *dst = v;
@@ -203,6 +207,9 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
 // and its weight gradient cost the grouped launch 17 us where it had cost 11.7 alone; those problems stay on the fp32 kernel.)
 // One 64 x 64 output tile (tile column bx, tile row by, split-K slice kz); the LDS comes from the calling kernel, so that a kernel
 // which holds several instantiations (the grouped weight-gradient launch below) still has ONE set of buffers.
+#ifndef SAR_GEMM_UPFRONT
+#define SAR_GEMM_UPFRONT 1
+#endif
 struct GemmLds { unsigned char As[2][64 * GB_RS]; unsigned char Bs[2][64 * GB_RS]; float csum[4][64]; };
 template <bool A_KC, bool B_KC, bool TAIL>
 __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
@@ -215,7 +222,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
     const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
     // staging: thread -> (row = tid / 4 of the tile as stored, 16 consecutive elements (tid % 4) * 16 of that row)
     const int srow = tid >> 2, sseg = (tid & 3) * 16;
-    float4 ra[2][4], rb[2][4];
+    float4 ra[4][4], rb[4][4];                           // two rotating sets (long k-loops) or all four k-tiles of a short one (below)
     auto gload = [&](int set, int kt) __attribute__((always_inline)) {
         const int k0 = min(kt, kt1 - 1) * GB_K;
         if constexpr (!TAIL) {
@@ -286,7 +293,21 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     };
-    if (kt0 < kt1) {
+    if (SAR_GEMM_UPFRONT && kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
+        // Short k-loops (K = 256 per slice: every Dense / GRU-projection GEMM of the model at hidden_dim 256): ALL k-tiles are requested at
+        // once -- one round trip.  The rotating form below keeps two tiles in flight, so a slice of four tiles pays the latency of an operand
+        // that the previous kernel left behind the fabric (~2 800 cycles: nothing a launch reads first is in its XCD's L2) twice over.
+        gload(0, kt0); gload(1, kt0 + 1); gload(2, kt0 + 2); gload(3, kt0 + 3);   // (tiles past the slice: clamped address, staged as zeros)
+        gstore(0, 0, kt0);
+        __syncthreads();
+        gmma(0); gstore(1, 1, kt0 + 1);
+        __syncthreads();
+        gmma(1); gstore(2, 0, kt0 + 2);
+        __syncthreads();
+        gmma(0); gstore(3, 1, kt0 + 3);
+        __syncthreads();
+        gmma(1);
+    } else if (kt0 < kt1) {
         gload(0, kt0); gload(1, kt0 + 1);
         gstore(0, 0, kt0); gload(0, kt0 + 2);
         __syncthreads();
@@ -321,7 +342,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
         if (splitk > 1) {
             atomicAdd(dst, v);
         } else {
-            if (act == ACT_TANH) v = tanhf(v);
+            if (act == ACT_TANH) v = fast_tanh(v);
             else if (act == ACT_RELU) v = fmaxf(v, 0.f);
             if (accumulate) v += *dst;
             *dst = v;

@@ -92,9 +92,13 @@ class RcclComm:
             raise RuntimeError("sar_comm_init failed (rank %d of %d)" % (rank, world))
         self.stream = torch.cuda.Stream()
 
-    def allreduce(self, t):
+    def allreduce(self, t, scratch16=None):
+        """scratch16 (a bf16 tensor of t's length): the bucket travels as bf16 (sar_allreduce_bucket_bf16), the sum lands in t as fp32."""
         self.stream.wait_stream(torch.cuda.current_stream())
-        if self.fn["sar_allreduce_bucket_f32"](self.handle, t.data_ptr(), t.numel(), self.stream.cuda_stream) != 0:
+        if scratch16 is not None:
+            if self.fn["sar_allreduce_bucket_bf16"](self.handle, t.data_ptr(), scratch16.data_ptr(), t.numel(), self.stream.cuda_stream) != 0:
+                raise RuntimeError("sar_allreduce_bucket_bf16 failed")
+        elif self.fn["sar_allreduce_bucket_f32"](self.handle, t.data_ptr(), t.numel(), self.stream.cuda_stream) != 0:
             raise RuntimeError("sar_allreduce_bucket_f32 failed")
         return self._Work(self.stream)
 
@@ -102,6 +106,19 @@ class RcclComm:
         if self.handle:
             torch.cuda.synchronize()
             self.fn["sar_comm_destroy"](self.handle); self.handle = None
+
+
+class _Bf16Work:
+    """Work handle of a bucket that travelled as bf16 through torch.distributed: wait() = wait for the collective, then widen the sum
+    back into the fp32 gradient range (stream-ordered, in front of whatever reads the gradients next)."""
+
+    def __init__(self, work, dst32, src16):
+        self.work, self.dst32, self.src16 = work, dst32, src16
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.dst32.copy_(self.src16)
 
 
 class DataParallel:
@@ -128,6 +145,12 @@ class DataParallel:
             self.bounds = [self.bounds[0]] + lo_hi
         # SAR_DP_COLLECTIVE=cabi: the gradient buckets go through the library's own RCCL entry point instead of torch.distributed's
         self.cabi = RcclComm() if (self.enabled and os.environ.get("SAR_DP_COLLECTIVE") == "cabi" and store.grads.is_cuda) else None
+        # SAR_DP_GRAD_DTYPE=bf16 (off by default): the buckets cross the links as bf16 -- half the bytes, 17 MB instead
+        # of 34 at F = 32 -- and the sum is widened back into the fp32 gradient buffer that Adam reads.  Every hop of a ring all-reduce then
+        # rounds its partial sum to 8 mantissa bits: a bandwidth / precision trade for link-bound configurations, to be judged on hardware.
+        self.grad16 = None
+        if self.enabled and os.environ.get("SAR_DP_GRAD_DTYPE", "fp32") == "bf16":
+            self.grad16 = torch.empty(store.n, dtype=torch.bfloat16, device=store.grads.device)
         if self.enabled:
             self.broadcast_params()
 
@@ -139,7 +162,25 @@ class DataParallel:
 
     def allreduce_grads(self):
         if self.enabled:
-            allreduce_flat(self.store.grads, self.bounds)
+            for lo, hi in self.bounds:
+                [w.wait() for w in self._reduce(lo, hi, False)]
+
+    def _reduce(self, lo, hi, async_op):
+        """Sum-all-reduce of grads[lo:hi] by the configured route; returns the work handles still to be waited for."""
+        g = self.store.grads[lo:hi]
+        if self.cabi is not None:
+            w = self.cabi.allreduce(g, None if self.grad16 is None else self.grad16[lo:hi])
+            if not async_op:
+                w.wait()
+            return [w] if async_op else []
+        if self.grad16 is not None:
+            t = self.grad16[lo:hi]
+            t.copy_(g)                                                  # fp32 -> bf16, round to nearest even
+            w = _Bf16Work(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op), g, t)
+            if not async_op:
+                w.wait()
+            return [w] if async_op else []
+        return [w for w in allreduce_flat(self.store.grads, [(lo, hi)], async_op=async_op) if w is not None]
 
     def allreduce_bucket(self, i, async_op=True):
         """Launch the sum-all-reduce of bucket i (0 = tail: heads/GRUs, complete first in backward; 1.. = conv stack, late
@@ -149,21 +190,11 @@ class DataParallel:
         A model without post-trunk parameters has a single bucket: index 1 is then empty."""
         if not self.enabled or i >= len(self.bounds):
             return []
-        if self.cabi is not None:
-            lo, hi = self.bounds[i]
-            w = self.cabi.allreduce(self.store.grads[lo:hi])
-            if not async_op:
-                w.wait()
-            return [w] if async_op else []
-        return [w for w in allreduce_flat(self.store.grads, [self.bounds[i]], async_op=async_op) if w is not None]
+        lo, hi = self.bounds[i]
+        return self._reduce(lo, hi, async_op) if hi > lo else []
 
     def allreduce_range(self, lo, hi, async_op=True):
         """Sum-all-reduce of grads[lo:hi] (several adjacent buckets as one collective); same stream semantics as allreduce_bucket."""
         if not self.enabled or hi <= lo:
             return []
-        if self.cabi is not None:
-            w = self.cabi.allreduce(self.store.grads[lo:hi])
-            if not async_op:
-                w.wait()
-            return [w] if async_op else []
-        return [w for w in allreduce_flat(self.store.grads, [(lo, hi)], async_op=async_op) if w is not None]
+        return self._reduce(lo, hi, async_op)

@@ -403,6 +403,7 @@ def main():
         dist.all_reduce(ones)
         if rank == 0:
             res["config"]["collective_backend"] = dist.get_backend()
+            res["config"]["grad_bucket_dtype"] = os.environ.get("SAR_DP_GRAD_DTYPE", "fp32")     # bf16: half the bytes on the links (parallel.DataParallel)
             res["config"]["rccl_ranks" if dist.get_backend() == "nccl" else "collective_ranks"] = int(ones.item())
     del model
     torch.cuda.empty_cache()

@@ -413,6 +413,10 @@ int sar_transpose_f32(const float* x, float* y, int R, int C, sarStream_t stream
 int sar_comm_unique_id(void* out128);
 int sar_comm_init(void** comm, const void* id128, int nranks, int rank);
 int sar_allreduce_bucket_f32(void* comm, float* buf, long count, sarStream_t stream);
+/* The same bucket in half the bytes (optional; DataParallel: SAR_DP_GRAD_DTYPE=bf16): buf is rounded to bf16 into scratch16 (count
+ * 2-byte elements), summed over the ranks by RCCL in bf16, and widened back into buf (the fp32 master gradient).  A bandwidth /
+ * precision trade: every hop of the ring rounds its partial sum to 8 mantissa bits. */
+int sar_allreduce_bucket_bf16(void* comm, float* buf, void* scratch16, long count, sarStream_t stream);
 int sar_comm_destroy(void* comm);
 
 /* ---- Adam(lr, decay=2e-4) + l2 regularisers + unit_norm: model.py:197, 35-48, 163.

@@ -24,7 +24,9 @@ STEPS = 3
 GRAPHS = {"3": ["adam", "heads_s32", "trunk_s10"], "5": ["adam", "heads", "trunk0", "trunk1", "trunk2"]}   # SAR_DP_SEGMENTS -> captured graphs
 
 
-def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", segments="3"):
+def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", segments="3", grad16=False):
+    if grad16:
+        os.environ["SAR_DP_GRAD_DTYPE"] = "bf16"               # the buckets cross the ranks as bf16 (parallel.DataParallel)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), SAR_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", SAR_DP_SEGMENTS=segments)
     sys.path.insert(0, ROOT)
@@ -61,10 +63,11 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", s
 
 @pytest.mark.parametrize("backend,via_gpus,mode,segments", [("gloo", False, "fp32", "3"), ("gloo", True, "fp32", "3"), ("nccl", True, "fp32", "3"),
                                                             ("gloo", True, "bf16", "3"), ("nccl", True, "bf16", "3"), ("gloo", True, "fp32", "5"),
-                                                            ("gloo", True, "bf16", "5")],
+                                                            ("gloo", True, "bf16", "5"), ("gloo", True, "fp32+g16", "3")],
                          ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16-mode", "rccl-bf16-mode",
-                              "gloo-five-graphs", "gloo-bf16-five-graphs"])
+                              "gloo-five-graphs", "gloo-bf16-five-graphs", "gloo-bf16-gradient-buckets"])
 def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, segments):
+    grad16 = mode.endswith("+g16"); mode = mode.split("+")[0]      # "+g16": SAR_DP_GRAD_DTYPE=bf16 -- the reduced buffer is the sum of the bf16-rounded shard gradients
     import torch.multiprocessing as mp
     from aesrc2020_amd import parallel
     from aesrc2020_amd.model import SAR_Net
@@ -73,7 +76,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
     ctx = mp.get_context("spawn")
     q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus) + 3 * len(mode) + 13 * int(segments)) % 2000
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus, mode, segments)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus, mode, segments, grad16)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
     [p.join(120) for p in ps]
@@ -108,7 +111,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         # (observed: 1e-6 typically, up to 5e-3 when a flip happens on these 3-utterance shards; a missed or doubled bucket
         # would show as O(1))
         err = float(np.linalg.norm(a["grads"] - gsum) / np.linalg.norm(gsum))
-        assert err < tol, (i, err)
+        assert err < (max(tol, 8e-3) if grad16 else tol), (i, err)      # bf16 buckets: + 2^-9 relative per element, twice
         # per parameter: the gamma / beta gradients of the first BatchNorm of stages 3 and 2, which the bf16 trunk writes one backward
         # part later than the rest of their block (ResNetTrunk.bucket_split_names) -- reduced after an early all-reduce they would come
         # back without any rank's contribution (the whole-vector L2 above cannot see two missing BatchNorm vectors)
@@ -145,6 +148,11 @@ def _worker_one_rank(port, q, mode, collective="torch", segments="3"):
         probe = torch.arange(1000, dtype=torch.float32, device="cuda")
         model.dp.cabi.allreduce(probe).wait(); torch.cuda.synchronize()
         assert torch.equal(probe.cpu(), torch.arange(1000, dtype=torch.float32))
+        # ... and its bf16 form (sar_allreduce_bucket_bf16): cast, RCCL all-reduce in bf16, cast back -- one rank: the bf16 rounding of the input
+        probe = torch.randn(100003, device="cuda"); want = probe.to(torch.bfloat16).to(torch.float32).cpu()
+        s16 = torch.empty(100003, dtype=torch.bfloat16, device="cuda")
+        model.dp.cabi.allreduce(probe, s16).wait(); torch.cuda.synchronize()
+        assert torch.equal(probe.cpu(), want)
     cfg = MT.Cfg(**kw)
     out = []
     for i in range(STEPS + 1):

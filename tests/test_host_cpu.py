@@ -256,6 +256,16 @@ def _dp_worker(rank, world, port, q):
     [wk.wait() for wk in works]
     dpres = (dp.bounds, dp.world, st.params.numpy().copy(), st.grads.numpy().copy(), st.state_refs[0].w.numpy().copy(),
              len(works), dp.allreduce_bucket(2))
+    # the same buckets as bf16 on the wire (SAR_DP_GRAD_DTYPE=bf16): values exact in bf16 must come back as the exact fp32 sum, values
+    # that are not come back rounded to bf16 BEFORE the sum (what halving the bytes costs)
+    os.environ["SAR_DP_GRAD_DTYPE"] = "bf16"
+    st2 = Store(); st2.n = 512; st2.refs = st.refs; st2.params = torch.zeros(512); st2.state_refs = []
+    st2.grads = torch.full((512,), 1.5 * (rank + 1)); st2.grads[:4] = 1.0 + 2.0 ** -10 * (rank + 1)          # 1 + k / 1024: not on the bf16 grid
+    dp2 = parallel.DataParallel(st2)
+    w2 = dp2.allreduce_bucket(0, async_op=True) + dp2.allreduce_bucket(1, async_op=True)
+    [wk.wait() for wk in w2]
+    del os.environ["SAR_DP_GRAD_DTYPE"]
+    dpres = dpres + (dp2.grad16 is not None, st2.grads.numpy().copy())
     q.put((rank, flat.numpy().copy(), params.numpy().copy(), sh["y"].tolist(), bounds, dpres))
     dist.barrier(); dist.destroy_process_group()
 
@@ -269,7 +279,9 @@ def test_data_parallel_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
     for rank, flat, params, ys, bounds, dpres in res:
-        dbounds, dworld, dparams, dgrads, dstate, nworks, extra = dpres
+        dbounds, dworld, dparams, dgrads, dstate, nworks, extra, has16, g16 = dpres
+        assert has16 and g16.dtype == np.float32 and np.all(g16[4:] == 4.5)    # 1.5 + 3.0: exact in bf16, summed once, widened back to fp32
+        assert np.all(g16[:4] == 2.0)                                          # 1 + 1/1024 and 1 + 2/1024 round to 1.0 in bf16 before the sum
         assert dbounds == [(256, 512), (0, 256)] and dworld == 2 and nworks == 2 and extra == []
         assert np.all(dparams == 0.0) and np.all(dstate == 5.0)            # rank-0 weights and BN moving statistics everywhere
         assert np.all(dgrads == 3.0)                                       # both buckets summed exactly once
