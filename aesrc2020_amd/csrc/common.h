@@ -19,6 +19,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// A "done once" flag that is per DEVICE, not per process: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device
+// attribute, so a process that touches a second device has to raise the cap there as well.  Reads / assigns like the `static bool` it replaces.
+struct PerDeviceFlag {
+    unsigned long long seen = 0;
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    operator bool() const { return (seen & bit()) != 0; }
+    PerDeviceFlag& operator=(bool v) { if (v) seen |= bit(); else seen &= ~bit(); return *this; }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): inside a recurrence whose steps store to (or
 // atomically update) global memory, every step then waits for the write acknowledgements of the step before (~1 us each) although the
 // threads only exchange data through LDS.  (An asm statement with a memory clobber: the s_barrier builtin alone does not keep LDS

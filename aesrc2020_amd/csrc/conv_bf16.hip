@@ -1387,18 +1387,18 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     static const kern_t kerns[2][5][2] = {{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
                                           {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}};
 #undef CV
-    static bool attr[2][5][2];
+    static PerDeviceFlag attr[2][5][2];
     const int ki = ilog2(Cin / 16) - 1, k3 = K == 3 ? 1 : 0;
 #define CV2(WN_, NH_) {conv_bf16_kernel<WN_, 8, NH_, 2>, conv_bf16_kernel<WN_, 8, 9 * NH_, 2>}
     static const kern_t kerns2[2][3][2] = {{CV2(1, 1), CV2(1, 2), CV2(1, 4)}, {CV2(2, 1), CV2(2, 2), CV2(2, 4)}};
 #undef CV2
-    static bool attr2[2][3][2];
+    static PerDeviceFlag attr2[2][3][2];
     if (br) {
 #define CVB(NKC_, NH_, KG_) {conv_bf16_kernel<2, NKC_, NH_, KG_, 2, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, 2, true>}
         static const kern_t kernsb[5][2] = {CVB(4, 1, 2), CVB(8, 1, 4), CVB(8, 2, 4), {conv_bf16_kernel<2, 8, 2, 4, 1, true>, conv_bf16_kernel<2, 8, 18, 4, 1, true>},
                                             {conv_bf16_kernel<2, 8, 4, 4, 1, true>, conv_bf16_kernel<2, 8, 36, 4, 1, true>}};
 #undef CVB
-        static bool attrb[5][2];
+        static PerDeviceFlag attrb[5][2];
         if (Cin == 512 && !br32) return SAR_EINVAL;                                   // (no 64-pixel instantiation for 512 source channels)
         const int kb = br32 ? (Cin == 256 ? 3 : 4) : ki - 1;
         const kern_t kern = kernsb[kb][k3];
@@ -1419,7 +1419,7 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
 #define CVX(NKC_, WMX_) {conv_bf16_kernel<1, NKC_, 1, 1, WMX_>, conv_bf16_kernel<1, NKC_, 9, 1, WMX_>}
         static const kern_t kernsx[2][2][2] = {{CVX(2, 2), CVX(4, 2)}, {CVX(2, 8), CVX(4, 8)}};
 #undef CVX
-        static bool attrx[2][2][2];
+        static PerDeviceFlag attrx[2][2][2];
         const int wx = tm256 ? 1 : 0;
         const kern_t kern = kernsx[wx][ki][k3];
         if (!attrx[wx][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[wx][ki][k3] = true; }
@@ -1595,10 +1595,10 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
         static const bool ldr = getenv("SAR_WG_LOADERS") && atoi(getenv("SAR_WG_LOADERS")) == 1;
         static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2, true>}};
         static const k3_t k3l[2] = {wgrad3_bf16_kernel<1, 1, false, 1>, wgrad3_bf16_kernel<2, 2, true, 2>};
-        static bool attr3[2][2], attrl[2];
+        static PerDeviceFlag attr3[2][2], attrl[2];
         const bool sq = tci == tco, usel = ldr && sq;
         const k3_t kern = usel ? k3l[tci - 1] : k3[tci - 1][tco - 1];
-        bool& at = usel ? attrl[tci - 1] : attr3[tci - 1][tco - 1];
+        PerDeviceFlag& at = usel ? attrl[tci - 1] : attr3[tci - 1][tco - 1];
         if (!at) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at = true; }
         const int threads = (tci == 2 && tco == 2 ? 768 : 576) + (usel ? 64 * tci : 0);
         hipLaunchKernelGGL(kern, dim3(n_items), dim3(threads), lds_bytes, stream, a);
@@ -1607,7 +1607,7 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
                                static_cast<const WgTile*>(tiles_dev), slices_dev, slab, tci, tco);
     } else {
         if (tci != 1 || tco != 1 || nbuf != WG_NBUF || lds_bytes != WG_NW1 * WG_NBUF * 8192) return SAR_EINVAL;
-        static bool attr1 = false;
+        static PerDeviceFlag attr1;
         if (!attr1) { if (!allow_lds(wgrad1_bf16_kernel, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
         hipLaunchKernelGGL(wgrad1_bf16_kernel, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
                            static_cast<const WgItem*>(items_dev), zero_page, slab);

@@ -92,6 +92,12 @@ __global__ __launch_bounds__(CTC_NT) void ctc_fwd_kernel(const float* __restrict
     __syncthreads();
     // (3) alpha recursion: four waves are plenty for <= 145 states, and a barrier among four is cheaper than among sixteen -- the waves
     // that only served the parallel phases leave (a finished wave does not take part in later barriers)
+    // (gfx9 ISA: s_barrier counts the waves of the workgroup that have not terminated; this is hardware behaviour, not HIP's programming
+    // model -- the guard below keeps the file from being built for a target where it has not been checked, tests/test_gpu_ops.py::test_ctc
+    // runs S > 256 and T = 1 through it)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "ctc.hip: early wave exit in front of workgroup barriers is verified on gfx950 only"
+#endif
     if (tid >= 256) return;
     for (int s_ = tid; s_ < S; s_ += 256) {
         const float a = (s_ < 2 && T > 0) ? (LDS_E ? e_s[s_] : ew[s_]) : -INFINITY;

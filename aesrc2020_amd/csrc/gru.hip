@@ -255,7 +255,7 @@ extern "C" int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const
         return SAR_EINVAL;
     if (H > 256 || H % 4) return SAR_EINVAL;
     const size_t lds = sizeof(float) * (GR * H + NW * GR * 12 * 64);
-    static bool attr_f = false;
+    static PerDeviceFlag attr_f;
     if (!attr_f) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

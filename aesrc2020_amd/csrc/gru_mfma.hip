@@ -469,13 +469,13 @@ extern "C" int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, cons
                                   float* out, float* gates, float* hprev, int B, int L, int H, hipStream_t stream) {
     if (!xa_fwd || !xa_bwd || !pack || !bh_fwd || !bh_bwd || !out || !gates || !hprev || H != GH || B < 1 || L < 1) return SAR_EINVAL;
     const size_t lds = (size_t)GNW * (GFR - GREG) * 1024 + 2 * GNR * HS_STRIDE + GH3 * 4;
-    static bool attr = false;
+    static PerDeviceFlag attr;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
         attr = true;
     }
     const int rows = gru_rows(B);
-    static bool attr4 = false;
+    static PerDeviceFlag attr4;
     if (rows <= 4 && !attr4) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_fwd4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_fwd4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
@@ -493,13 +493,13 @@ extern "C" int sar_bigru_bwd_bf16(const float* dout, const float* gates, const f
                                   int B, int L, int H, hipStream_t stream) {
     if (!dout || !gates || !hprev || !pack || !dai || !dah || H != GH || B < 1 || L < 1) return SAR_EINVAL;
     const size_t lds = (size_t)GNW * (GFR - GREG) * 1024 + GNR * AS_STRIDE;
-    static bool attr = false;
+    static PerDeviceFlag attr;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
         attr = true;
     }
     const int rows = gru_rows(B);
-    static bool attr4 = false;
+    static PerDeviceFlag attr4;
     if (rows <= 4 && !attr4) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_bwd4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_bwd4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;

@@ -203,7 +203,7 @@ extern "C" int sar_accent_classifier_f32(const float* x, const float* W1, const 
     FusedHeadP p{x, W1, b1, W2, b2, W3, b3, y_true, dloss, h1, h2, probs, loss, dW1, db1, dW2, db2, dW3, db3, dx, B, H, D1, D2, A};
     const size_t lds = ((size_t)H * (D1 + 1) + (size_t)D1 * (D2 + 1) + (size_t)D2 * (A + 1) + (size_t)FH_ROWS * H) * sizeof(float);
     if (lds > 140 * 1024) return SAR_EINVAL;               // H <= 480 at D1 = 64
-    static bool attr = false;
+    static PerDeviceFlag attr;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(accent_classifier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024) != hipSuccess)
             return SAR_ELAUNCH;

@@ -521,7 +521,7 @@ extern "C" int sar_vlad_fwd_f32(const float* feat, const float* score, const flo
     if (D <= 256 && K <= 64 && KG <= 128) {             // MFMA formulation
         const int Kt = (K + 31) / 32, Dt = (D + 31) / 32, KGP = KG > Kt * 32 ? KG : Kt * 32;
         const size_t ldsm = sizeof(float) * ((size_t)VF_LC * KGP + (size_t)VF_LC * Dt * 32 + KGP + 64);
-        static bool attr_set = false;  // raise the dynamic-LDS cap once (host-side attribute, not a stream op)
+        static PerDeviceFlag attr_set;  // raise the dynamic-LDS cap once (host-side attribute, not a stream op)
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
             attr_set = true;
@@ -550,7 +550,7 @@ extern "C" int sar_vlad_bwd_f32(const float* dout, const float* feat, const floa
     if (D <= 256 && K <= 64) {                          // MFMA formulation
         const int Kt = (K + 31) / 32, Dt = (D + 31) / 32, KP = Kt * 32, DP1 = Dt * 32 + 1, KGP1 = (KG > KP ? KG : KP) | 1;
         const size_t ldsm = sizeof(float) * ((size_t)KP * DP1 + (size_t)VB_LC * DP1 + (size_t)VB_LC * KGP1 + (size_t)VB_LC * (KP + 1) + KG + 2 * K);
-        static bool attr_set = false;
+        static PerDeviceFlag attr_set;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
             attr_set = true;

@@ -726,10 +726,20 @@ class SARNetModel:
                 acc = vec.clone() if acc is None else acc.add_(vec)
                 if verbose > 1 and (step % log_every == 0):
                     print("  step %d/%d loss %.4f" % (step + 1, steps_per_epoch, float(vec[0].item())))
-            mean = (acc / steps_per_epoch).cpu().numpy()
+            mean_dev = acc / steps_per_epoch
+            if self.dp.enabled and self.dp.world > 1:
+                # every rank saw its own shard: the callbacks (ReduceLROnPlateau, EarlyStopping, checkpoints on 'loss' / 'acc') must decide
+                # on the SAME numbers everywhere, or the replicas take different learning rates / stop in different epochs and the next
+                # collective hangs.  One small all-reduce per epoch: the mean over the ranks = the global-batch metrics.
+                import torch.distributed as dist
+                dist.all_reduce(mean_dev); mean_dev = mean_dev / self.dp.world
+            mean = mean_dev.cpu().numpy()
             logs = {k: float(v) for k, v in zip(self._logs_device_names(), mean)}
             if validation_data is not None:
                 vl = self.evaluate(validation_data[0], validation_data[1])
+                if self.dp.enabled and self.dp.world > 1:                        # the same validation data on every rank, but be explicit: rank 0's numbers
+                    import torch.distributed as dist
+                    obj = [vl]; dist.broadcast_object_list(obj, src=0); vl = obj[0]
                 logs.update({"val_" + k: v for k, v in vl.items()})
             logs["lr"] = self.store.get_lr()
             if verbose:
