@@ -687,7 +687,7 @@ def test_ctc(L, B, Lq, V, maxU, Umax):
     rng = np.random.default_rng(V)
     p, lab, il, ll = _ctc_inputs(B, Lq, V, maxU, rng, Umax)
     lab[0, 1] = lab[0, 0]; ll[0] = max(ll[0], 2)            # a repeated label
-    il[1] = Lq - 3                                           # a shorter input
+    il[1] = max(Lq - 3, 1)                                   # a shorter input
     if B > 2:
         ll[2] = min(maxU, Lq + 1); lab[2, :ll[2, 0]] = rng.integers(0, V - 1, ll[2, 0])   # infeasible: U > T
     loss_ref, grad_ref = O.ctc_batch_cost_fwd_bwd(p, lab, il, ll)
