@@ -211,12 +211,20 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
 #define SAR_GEMM_UPFRONT 1
 #endif
 struct GemmLds { unsigned char As[2][64 * GB_RS]; unsigned char Bs[2][64 * GB_RS]; float csum[4][64]; };
-template <bool A_KC, bool B_KC, bool TAIL>
+// NGRP = 2 (round 3 EXPERIMENT, off: SAR_GEMM_GROUPS=2.  Measured: 2496 x 256 x 256 7.39 -> 7.15 us isolated, but 2496 x 768 x 256 9.9 -> 12.9 and the
+// train step 1.981 -> 1.996 ms -- the launches with more than 256 tiles already had two blocks per CU): 512 threads = two groups of four waves that take the even / the odd k-tiles of the slice,
+// each through its own pair of LDS buffers, in lockstep (the block-wide barriers serve both), and meet in LDS in front of the epilogue.  A
+// launch of the model's Dense / GRU-projection GEMMs is 156-468 tiles for 256 CUs, one block per CU with ONE wave per SIMD: nothing covers
+// a wave's waits (PMC: 46 % of its cycles in s_waitcnt / barriers, 32 % waiting to issue); two waves per SIMD and half the dependent
+// k-tile steps per wave do.
+template <bool A_KC, bool B_KC, bool TAIL, int NGRP = 1>
 __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                const float* __restrict__ bias, float* __restrict__ colsum, int M, int N, int K, int lda, int ldb,
-                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLds& L) {
+                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLds* Ls) {
+    const int grp = NGRP == 2 ? (int)(threadIdx.x >> 8) : 0;
+    GemmLds& L = Ls[grp];
     unsigned char (&As)[2][64 * GB_RS] = L.As; unsigned char (&Bs)[2][64 * GB_RS] = L.Bs; float (&csum)[4][64] = L.csum;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = by * BM, n0 = bx * BN;
     const int nkt = (K + GB_K - 1) / GB_K, per = (nkt + splitk - 1) / splitk;
     const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
@@ -293,7 +301,15 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     };
-    if (SAR_GEMM_UPFRONT && kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
+    constexpr int KS = NGRP;                                          // this group's k-tiles: kt0 + grp, + KS, + 2 KS, ...
+    if (NGRP == 2 && kt1 - kt0 <= 4) {
+        gload(0, kt0 + grp); gload(1, kt0 + grp + 2);                  // both tiles of the group at once (tiles past the slice: staged as zeros)
+        gstore(0, 0, kt0 + grp);
+        __syncthreads();
+        gmma(0); gstore(1, 1, kt0 + grp + 2);
+        __syncthreads();
+        gmma(1);
+    } else if (NGRP == 1 && SAR_GEMM_UPFRONT && kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
         // Short k-loops (K = 256 per slice: every Dense / GRU-projection GEMM of the model at hidden_dim 256): ALL k-tiles are requested at
         // once -- one round trip.  The rotating form below keeps two tiles in flight, so a slice of four tiles pays the latency of an operand
         // that the previous kernel left behind the fabric (~2 800 cycles: nothing a launch reads first is in its XCD's L2) twice over.
@@ -308,18 +324,36 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
         __syncthreads();
         gmma(1);
     } else if (kt0 < kt1) {
-        gload(0, kt0); gload(1, kt0 + 1);
-        gstore(0, 0, kt0); gload(0, kt0 + 2);
+        const int k0 = kt0 + grp;
+        gload(0, k0); gload(1, k0 + KS);
+        gstore(0, 0, k0); gload(0, k0 + 2 * KS);
         __syncthreads();
-        for (int kt = kt0; kt < kt1; kt += 2) {
-            gmma(0); gstore(1, 1, kt + 1); gload(1, kt + 3);
+        for (int kt = kt0; kt < kt1; kt += 2 * KS) {                  // (the bound is the same for both groups: their barriers are shared)
+            const int kg = kt + grp;
+            gmma(0); gstore(1, 1, kg + KS); gload(1, kg + 3 * KS);
             __syncthreads();
-            gmma(1); gstore(0, 0, kt + 2); gload(0, kt + 4);
+            gmma(1); gstore(0, 0, kg + 2 * KS); gload(0, kg + 4 * KS);
             __syncthreads();
         }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    if constexpr (NGRP == 2) {                                       // the odd-tile group hands its accumulators over: [4 register quads][wave][lane] float4
+        __syncthreads();                                              // (every wave is done with the operand buffers)
+        float4* mg = reinterpret_cast<float4*>(Ls[1].As[0]);
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mg[(i * 4 + wave) * 64 + lane] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = mg[(i * 4 + wave) * 64 + lane];
+                acc[4 * i] += v.x; acc[4 * i + 1] += v.y; acc[4 * i + 2] += v.z; acc[4 * i + 3] += v.w;
+            }
+        }
+    }
     if (do_colsum) {                                  // threads with equal tid % 4 hold the same 16 columns
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -328,8 +362,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             if (lane < 4) csum[wave][lane * 16 + i] = v;
         }
         __syncthreads();
-        if (tid < 64 && (!TAIL || n0 + tid < N)) atomicAdd(colsum + n0 + tid, csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid]);
+        if (grp == 0 && tid < 64 && (!TAIL || n0 + tid < N)) {
+            float v = csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid];
+            if constexpr (NGRP == 2) v += Ls[1].csum[0][tid] + Ls[1].csum[1][tid] + Ls[1].csum[2][tid] + Ls[1].csum[3][tid];
+            atomicAdd(colsum + n0 + tid, v);
+        }
     }
+    if (NGRP == 2 && grp == 1) return;                                // the epilogue is the even-tile group's
     const int col = n0 + wn * 32 + (lane & 31);
     if (TAIL && col >= N) return;
     const float bv = (bias != nullptr && kz == 0) ? bias[col] : 0.f;
@@ -360,16 +399,16 @@ __device__ __forceinline__ unsigned xcd_order(unsigned l, unsigned total) {
     return l < body ? (l & 7u) * chunk + (l >> 3) : l;
 }
 
-template <bool A_KC, bool B_KC, bool TAIL = false>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
+template <bool A_KC, bool B_KC, bool TAIL = false, int NGRP = 1>
+__global__ __launch_bounds__(256 * NGRP) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
                                                         int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
     const unsigned nbx = gridDim.x, nby = gridDim.y;
     const unsigned t = xcd_order(blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z), nbx * nby * gridDim.z);
     const int bx = (int)(t % nbx), by = (int)(t / nbx % nby), z = (int)(t / (nbx * nby));
     const int bz = z / splitk, kz = z - bz * splitk;
-    __shared__ __attribute__((aligned(16))) GemmLds L;
-    gemm_bf16_tile<A_KC, B_KC, TAIL>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
-                                     bx, by, kz, L);
+    __shared__ __attribute__((aligned(16))) GemmLds L[NGRP];
+    gemm_bf16_tile<A_KC, B_KC, TAIL, NGRP>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
+                                           bx, by, kz, L);
 }
 
 // Weight gradients of MANY Dense / GRU kernels in one launch (they are off the critical path of the backward pass: the host collects
@@ -391,8 +430,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
     const int local = (int)xcd_order(blockIdx.x - p.first_block, (unsigned)(nbx * nby * p.splitk));   // first_block % 8 == 0 (the plan pads)
     const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
     if (kz >= p.splitk) return;                                      // padding blocks of the plan
-    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
-    else gemm_bf16_tile<false, false, false>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
+    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, &L);
+    else gemm_bf16_tile<false, false, false>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, &L);
 }
 
 }  // namespace
@@ -400,6 +439,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = bf16 MFMA with fp32 accumulate for 64-aligned problems (the "bf16" mode of
 // BASELINE configs[1]; SAR_GEMM_MATH=bf16).  Host-side, process-wide.
 static int g_gemm_math = (getenv("SAR_GEMM_MATH") && !strcmp(getenv("SAR_GEMM_MATH"), "bf16")) ? 1 : 0;
+static const int g_gemm_groups = (getenv("SAR_GEMM_GROUPS") && atoi(getenv("SAR_GEMM_GROUPS")) == 2) ? 2 : 1;   // k-groups of the bf16 single-problem launches (2: the 512-thread experiment below, measured slower)
 extern "C" int sar_set_gemm_math(int mode) { if (mode < 0 || mode > 1) return SAR_EINVAL; g_gemm_math = mode; return SAR_OK; }
 extern "C" int sar_get_gemm_math(void) { return g_gemm_math; }
 
@@ -423,7 +463,8 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     if (tail16) {
         grid.x = cdiv(N, 64); grid.y = cdiv(M, 64);
 #define LAUNCH16T(AK, BK_)                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)
+    do { if (g_gemm_groups == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true, 2>), grid, dim3(512), 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); \
+         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); } while (0)
         if (a_kc && b_kc) LAUNCH16T(true, true);
         else if (a_kc && !b_kc) LAUNCH16T(true, false);
         else if (!a_kc && b_kc) LAUNCH16T(false, true);
@@ -434,7 +475,8 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     }
     if (g_gemm_math == 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && aligned && K / 64 >= splitk) {
 #define LAUNCH16(AK, BK_)                                                                                            \
-    hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk)
+    do { if (g_gemm_groups == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, false, 2>), grid, dim3(512), 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); \
+         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); } while (0)
         if (a_kc && b_kc) LAUNCH16(true, true);
         else if (a_kc && !b_kc) LAUNCH16(true, false);
         else if (!a_kc && b_kc) LAUNCH16(false, true);
