@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmBatch gb, int M
     const int nkt = (K + BK - 1) / BK;
     const int per = (nkt + splitk - 1) / splitk;
     const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
+    const int bcol = n0 + wn * 32 + (lane & 31);                      // bias requested up front (see gemm_bf16_tile)
+    const float bv = (bias != nullptr && kz == 0 && bcol < N) ? bias[bcol] : 0.f;
     const bool a_vec = ((lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b_vec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
 
@@ -161,7 +163,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmBatch gb, int M
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col >= N) return;
-    const float bv = (bias != nullptr && kz == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -228,6 +229,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
     const int m0 = by * BM, n0 = bx * BN;
     const int nkt = (K + GB_K - 1) / GB_K, per = (nkt + splitk - 1) / splitk;
     const int kt0 = kz * per, kt1 = min(nkt, kt0 + per);
+    // The bias of this lane's column is requested HERE: behind the k-loop (where it is used, and where the barriers keep the compiler from
+    // moving it up) it was a dependent round trip in front of the stores -- tools/gemm_bench.py: a launch costs 6.5 us for K = 64, 128 and 256
+    // alike; what bounds these GEMMs is the fixed chain kernel arguments -> first operands -> ... -> bias -> stores -> write-back, not K.
+    const int bcol = n0 + wn * 32 + (lane & 31);
+    const float bv = (bias != nullptr && kz == 0 && (!TAIL || bcol < N)) ? bias[bcol] : 0.f;
     // staging: thread -> (row = tid / 4 of the tile as stored, 16 consecutive elements (tid % 4) * 16 of that row)
     const int srow = tid >> 2, sseg = (tid & 3) * 16;
     float4 ra[4][4], rb[4][4];                           // two rotating sets (long k-loops) or all four k-tiles of a short one (below)
@@ -371,7 +377,6 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
     if (NGRP == 2 && grp == 1) return;                                // the epilogue is the even-tile group's
     const int col = n0 + wn * 32 + (lane & 31);
     if (TAIL && col >= N) return;
-    const float bv = (bias != nullptr && kz == 0) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

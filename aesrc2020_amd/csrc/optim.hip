@@ -23,12 +23,22 @@ __global__ void adam_prepare_kernel(SarAdamState* st) {
     }
 }
 
+// FUSED (sar_adam_l2_update_f32, round 3): the step-size bookkeeping of adam_prepare_kernel rides in this launch -- every block derives
+// lr_t from the iteration count it finds, and the LAST block to finish (a ticket: every block draws one at its end, so whoever draws the
+// last knows that all blocks have read the count) advances it.  A one-thread kernel costs 4.6 us of the step's timeline here: kernel
+// arguments, its load and the write-back of its store are three dependent trips behind the fabric, whatever it computes.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
-                                                      const float* __restrict__ chunk_l2, const SarAdamState* st,
+                                                      const float* __restrict__ chunk_l2, SarAdamState* st, unsigned* ticket,
                                                       float* __restrict__ l2_loss, long nchunks) {
     __shared__ float red[16];
-    const float lr_t = st->lr_t, b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
+    const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
+    float lr_t = st->lr_t;
+    if constexpr (FUSED) {
+        const float it = (float)st->iterations, lr = st->lr / (1.f + st->decay * it), t = it + 1.f;
+        lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+    }
     float lacc = 0.f;
     // one wave per 256-element chunk, float4 per lane (16-byte accesses: the scalar version ran at 3.4 TB/s), two chunks per
     // trip so that 14 loads are in flight per lane
@@ -65,6 +75,12 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
     if (l2_loss) {
         lacc = block_sum(lacc, red);
         if (threadIdx.x == 0) atomicAdd(l2_loss, lacc);
+    }
+    if constexpr (FUSED) {
+        if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {   // every block has read the iteration count
+            *ticket = 0u;
+            st->lr_t = lr_t; st->iterations += 1;
+        }
     }
 }
 
@@ -107,8 +123,22 @@ extern "C" int sar_adam_l2_step_f32(float* params, const float* grads, float* m,
     const long nchunks = n / 256;
     const long nb4 = (nchunks + 3) / 4;                                // a block = 4 waves = 4 chunks per trip
     const int nb = (int)(nb4 < 2048 ? nb4 : 2048);
-    hipLaunchKernelGGL(adam_l2_kernel, dim3(nb), dim3(256), 0, stream, params, grads, m, v, chunk_l2,
-                       static_cast<const SarAdamState*>(state), l2_loss, nchunks);
+    hipLaunchKernelGGL(adam_l2_kernel<false>, dim3(nb), dim3(256), 0, stream, params, grads, m, v, chunk_l2,
+                       static_cast<SarAdamState*>(const_cast<void*>(state)), static_cast<unsigned*>(nullptr), l2_loss, nchunks);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// sar_adam_prepare + sar_adam_l2_step_f32 in ONE launch.  `ticket`: one zero-initialised 32-bit word the caller owns (it is zero again when the
+// launch has finished).
+extern "C" int sar_adam_l2_update_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
+                                      void* state, void* ticket, float* l2_loss, long n, hipStream_t stream) {
+    if (!params || !grads || !m || !v || !chunk_l2 || !state || !ticket || (n % 256)) return SAR_EINVAL;
+    const long nchunks = n / 256;
+    const long nb4 = (nchunks + 3) / 4;
+    const int nb = (int)(nb4 < 2048 ? (nb4 > 0 ? nb4 : 1) : 2048);
+    hipLaunchKernelGGL(adam_l2_kernel<true>, dim3(nb), dim3(256), 0, stream, params, grads, m, v, chunk_l2,
+                       static_cast<SarAdamState*>(state), static_cast<unsigned*>(ticket), l2_loss, nchunks);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

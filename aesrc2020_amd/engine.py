@@ -186,9 +186,10 @@ class ParamStore:
             _lib.call("sar_fill_f32", self.l2_loss, 0.0, 1)
         self._zeroed_this_step = False                                       # the step is over: later forwards (evaluate) zero for themselves
         self._zero_table_sync()                                              # buffers registered during this (eager) step join the table now
-        _lib.call("sar_adam_prepare", self.adam_state)
-        _lib.call("sar_adam_l2_step_f32", self.params, self.grads, self.m, self.v, self.chunk_l2, self.adam_state,
-                  self.l2_loss, self.n)
+        if self.__dict__.get("_adam_ticket") is None:
+            self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=self.params.device)
+        _lib.call("sar_adam_l2_update_f32", self.params, self.grads, self.m, self.v, self.chunk_l2, self.adam_state, self._adam_ticket,
+                  self.l2_loss, self.n)                                      # step-size bookkeeping + update in one launch
         for r in self.refs:
             if r.constraint == "unit_norm":
                 _lib.call("sar_unit_norm_f32", r.w, r.shape[0], r.shape[1])

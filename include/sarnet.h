@@ -424,6 +424,10 @@ int sar_comm_destroy(void* comm);
 int sar_adam_prepare(void* state, sarStream_t stream);
 int sar_adam_l2_step_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                          const void* state, float* l2_loss, long n, sarStream_t stream);
+/* sar_adam_prepare + sar_adam_l2_step_f32 in one launch (round 3): every block derives lr_t from the iteration count it finds, the last
+ * block to finish advances it.  ticket: one zero-initialised 32-bit word of the caller's (zero again when the launch has finished). */
+int sar_adam_l2_update_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2, void* state, void* ticket,
+                           float* l2_loss, long n, sarStream_t stream);
 /* ---- data feeder: utils.py:35-36 feat_norm (sklearn MinMaxScaler.fit_transform per utterance: every
  * feature column scaled to [0,1] over ALL frames of the utterance; constant column -> 0) + utils.py:39-46 feat_reshape
  * (truncate / zero-pad to T frames).  frames = the batch's utterances back to back (sum_n, D) f32; offsets (B+1) i32 frame

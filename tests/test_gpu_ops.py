@@ -803,5 +803,14 @@ def test_adam_l2_unitnorm(L):
         pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, it, lr=0.01)
         check(p, pr, 1e-5, "adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
     assert int(st.view(torch.int32)[6]) == 3
+    # the one-launch form (round 3): prepare + step, the last block advances the iteration count; three further steps continue the run
+    tick = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for it in range(3, 6):
+        l2l.zero_()
+        L.call("sar_adam_l2_update_f32", p, dev(g), m, v, dev(l2), st, tick, l2l, n)
+        ref_l2 = (l2e * pr * pr).sum()
+        pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, it, lr=0.01)
+        check(p, pr, 1e-5, "fused adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
+        assert int(tick.item()) == 0 and int(st.view(torch.int32)[6]) == it + 1
     w = rng.standard_normal((256, 8)); wd = dev(w)
     L.call("sar_unit_norm_f32", wd, 256, 8); check(wd, O.unit_norm(w), 1e-5, "unit_norm")

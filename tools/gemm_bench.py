@@ -12,6 +12,8 @@ R = 2496
 # (label, M, N, K, a_kc, b_kc, act)   forward: C = tanh(A (M,K) . B (K,N) + b); input gradient: dX = dY (M,K) . W^T, W stored (N,K)
 CASES = [("fwd 256->256 tanh", R, 256, 256, 1, 0, 1), ("fwd 256->768", R, 768, 256, 1, 0, 0), ("fwd 512->256 tanh", R, 256, 512, 1, 0, 1),
          ("dgrad 256<-256", R, 256, 256, 1, 1, 0), ("dgrad 256<-768", R, 256, 768, 1, 1, 0), ("dgrad 512<-256", R, 512, 256, 1, 1, 0)]
+if os.environ.get("GEMM_KSWEEP"):                                   # fixed cost vs cost per 64-wide k-tile
+    CASES = [("dgrad K=%d" % k, R, 256, k, 1, 1, 0) for k in (64, 128, 256, 512, 1024)] + [("fwd K=%d" % k, R, 256, k, 1, 0, 0) for k in (64, 256, 1024)]
 for label, M, N, K, akc, bkc, act in CASES:
     A = z(M, K); B = z(N, K) if bkc else z(K, N); C = torch.empty(M, N, device="cuda"); bias = z(N)
     fn = lambda: call("sar_gemm_f32", A, B, C, bias, M, N, K, K, K if bkc else N, N, akc, bkc, act, 0, 1)
