@@ -208,6 +208,11 @@ class WgradConv(ctypes.Structure):
                [(n, ctypes.c_int) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "s", "pt", "pl")] + [("ginv", ctypes.c_float)]
 
 
+class WgradReduce(ctypes.Structure):
+    """include/sarnet.h: sarWgradReduce."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("convs_dev", "tiles_dev", "slices_dev", "slab")] + [(n, ctypes.c_int) for n in ("n_tiles", "K", "tile_ci", "tile_co")]
+
+
 class WgradPlan:
     """Device tables of one batched weight-gradient launch (sar_wgrad_plan_bf16 runs on the host; uploaded once)."""
     MAX_ITEMS = 16384
@@ -254,12 +259,29 @@ class WgradPlan:
         self.slices = torch.frombuffer(bytearray(slices), dtype=torch.uint8).cuda() if self.n_slabs else None
         self.slab = torch.empty(self.n_slabs * self.slab_floats, dtype=torch.float32, device="cuda") if self.n_slabs else None
 
-    def launch(self):
+    def launch(self, defer_reduce=False):
+        """defer_reduce: the partial tiles stay in the slabs; the caller sums them for several plans at once (reduce_multi)."""
         import torch
+        self.launch4[7] = 1 if defer_reduce else 0
         rc = lib().fn[self.entry](self.convs.data_ptr(), self.items.data_ptr(), self.n_items, self.K, self.launch4, ptr(self.tiles), ptr(self.slices),
                                   ptr(self.slab), torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError("%s failed with status %d" % (self.entry, rc))
+
+    @staticmethod
+    def reduce_multi(plans, sfx="bf16"):
+        """ONE reduction launch for the plans launched with defer_reduce (sar_wgrad_reduce_multi_*; four plans per launch)."""
+        import torch
+        todo = [p for p in plans if p.n_tiles]
+        for i in range(0, len(todo), 4):
+            grp = todo[i:i + 4]
+            arr = (WgradReduce * len(grp))()
+            for a, p in zip(arr, grp):
+                a.convs_dev, a.tiles_dev, a.slices_dev, a.slab = p.convs.data_ptr(), p.tiles.data_ptr(), p.slices.data_ptr(), p.slab.data_ptr()
+                a.n_tiles, a.K, a.tile_ci, a.tile_co = p.n_tiles, p.K, p.launch4[3] >> 4, p.launch4[3] & 15
+            rc = lib().fn["sar_wgrad_reduce_multi_" + sfx](arr, len(grp), torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError("sar_wgrad_reduce_multi_%s failed with status %d" % (sfx, rc))
 
 
 def bn_bins():

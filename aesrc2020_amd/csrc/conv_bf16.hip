@@ -1065,14 +1065,14 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
 // Sum of the partial tiles of every multi-slice gradient tile, in slice order (deterministic), added into the gradient: grid
 // (tiles, 32 x 32 sub-tiles of a tile = taps x TCI x TCO), 256 threads x float4.  K3: slabs in accumulator-register order (above).
 template <bool K3>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const unsigned char* __restrict__ convs, const WgTile* __restrict__ tiles,
-                                                           const int* __restrict__ slices, const float* __restrict__ slab, int tci, int tco) {
-    const WgTile t = tiles[blockIdx.x];
+__device__ __forceinline__ void wgrad_reduce_body(const unsigned char* __restrict__ convs, const WgTile* __restrict__ tiles,
+                                                  const int* __restrict__ slices, const float* __restrict__ slab, int tci, int tco, int tile, int sub, int nsub) {
+    const WgTile t = tiles[tile];
     const WgConv* cvp = reinterpret_cast<const WgConv*>(convs + (size_t)t.conv * 128);
     const int Cin = cvp->g.Cin, Cout = cvp->Cout;
     const float ginv = cvp->ginv;
     float* dwp = cvp->dw;
-    const int sub = blockIdx.y, nsub = gridDim.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const float4* base = reinterpret_cast<const float4*>(slab) + (size_t)sub * 256 + tid;
     const size_t per = (size_t)nsub * 256;                                           // float4 per slab
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
@@ -1098,6 +1098,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const unsigned char* 
         v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
         *o = v;
     }
+}
+
+template <bool K3>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const unsigned char* __restrict__ convs, const WgTile* __restrict__ tiles,
+                                                           const int* __restrict__ slices, const float* __restrict__ slab, int tci, int tco) {
+    wgrad_reduce_body<K3>(convs, tiles, slices, slab, tci, tco, blockIdx.x, blockIdx.y, gridDim.y);
+}
+// The reductions of SEVERAL batched launches (the step's four tile classes) in ONE launch: a launch inside the step costs ~4.5 us before it
+// does anything, and three of the four reductions are 10-17 us of it.  Block b belongs to plan i with first[i] <= b < first[i+1].
+struct RedPlan { const unsigned char* convs; const WgTile* tiles; const int* slices; const float* slab; int n_tiles, k3, tci, tco; };
+struct RedPlans { RedPlan p[4]; int first[5]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedPlans P) {
+    const int b = blockIdx.x;
+    const int i = (b >= P.first[1]) + (b >= P.first[2]) + (b >= P.first[3]);
+    const RedPlan& q = P.p[i];
+    const int local = b - P.first[i], nsub = q.k3 ? 9 * q.tci * q.tco : 1, tile = local / nsub, sub = local - tile * nsub;
+    if (q.k3) wgrad_reduce_body<true>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
+    else wgrad_reduce_body<false>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
 }
 
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
@@ -1602,7 +1620,7 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
         if (!at) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at = true; }
         const int threads = (tci == 2 && tco == 2 ? 768 : 576) + (usel ? 64 * tci : 0);
         hipLaunchKernelGGL(kern, dim3(n_items), dim3(threads), lds_bytes, stream, a);
-        if (n_tiles > 0)
+        if (n_tiles > 0 && !launch4[7])                                             // launch4[7]: the caller reduces (sar_wgrad_reduce_multi_*)
             hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(n_tiles, 9 * tci * tco), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
                                static_cast<const WgTile*>(tiles_dev), slices_dev, slab, tci, tco);
     } else {
@@ -1611,10 +1629,35 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
         if (!attr1) { if (!allow_lds(wgrad1_bf16_kernel, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
         hipLaunchKernelGGL(wgrad1_bf16_kernel, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),
                            static_cast<const WgItem*>(items_dev), zero_page, slab);
-        if (n_tiles > 0)
+        if (n_tiles > 0 && !launch4[7])
             hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(n_tiles, 1), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
                                static_cast<const WgTile*>(tiles_dev), slices_dev, slab, 1, 1);
     }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// One reduction launch for up to four batched weight-gradient launches that ran with launch4[7] = 1 (mirrors include/sarnet.h: sarWgradReduce).
+struct sarWgradReduce { const void* convs_dev; const void* tiles_dev; const int* slices_dev; const float* slab; int n_tiles, K, tile_ci, tile_co; };
+int SAR_T16(sar_wgrad_reduce_multi_)(const sarWgradReduce* plans, int n, hipStream_t stream) {
+    if (plans == nullptr || n < 1 || n > 4) return SAR_EINVAL;
+    RedPlans P;
+    memset(&P, 0, sizeof(P));
+    int blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        P.first[i] = blocks;
+        if (i >= n) continue;
+        const sarWgradReduce& r = plans[i];
+        if (r.n_tiles < 0 || (r.K != 1 && r.K != 3) || r.tile_ci < 1 || r.tile_ci > 2 || r.tile_co < 1 || r.tile_co > 2) return SAR_EINVAL;
+        if (r.n_tiles > 0 && (!r.convs_dev || !r.tiles_dev || !r.slices_dev || !r.slab)) return SAR_EINVAL;
+        P.p[i] = RedPlan{static_cast<const unsigned char*>(r.convs_dev), static_cast<const WgTile*>(r.tiles_dev), r.slices_dev, r.slab, r.n_tiles,
+                         r.K == 3 ? 1 : 0, r.tile_ci, r.tile_co};
+        blocks += r.n_tiles * (r.K == 3 ? 9 * r.tile_ci * r.tile_co : 1);
+    }
+    P.first[4] = blocks;
+    for (int i = n; i < 4; ++i) P.first[i] = blocks;                                // (no block falls into an absent plan)
+    if (blocks == 0) return SAR_OK;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, stream, P);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -475,8 +475,13 @@ class ResNetTrunk(Layer):
                 for p in plans[key]:
                     p.launch()
         else:
+            # the partial tiles of all classes are summed by ONE launch behind the last batch (a launch costs ~4.5 us of the step before it
+            # does anything: DESIGN 5.0); SAR_WG_REDUCE_MULTI=0: one reduction behind every batch
+            multi = os.environ.get("SAR_WG_REDUCE_MULTI", "1") != "0" and len(plans[key]) > 1
             for p in plans[key]:
-                p.launch()
+                p.launch(defer_reduce=multi)
+            if multi:
+                _lib.WgradPlan.reduce_multi(plans[key], self.sfx)
 
     # stem of the bf16 trunk (csrc/stem_bf16.hip): the 7x7 conv is recomputed wherever its output is needed, so only the pooled map
     # (bf16) and its argmax slots exist in HBM -- no (B, T/2, D/2, C0) tensor, forward or backward

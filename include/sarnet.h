@@ -214,6 +214,10 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
                         void* items_out, int max_items, int* n_items, int* launch4, void* tiles_out, int* slices_out);
 int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                 const int* slices_dev, float* slab, sarStream_t stream);
+/* The reductions of up to four batched launches in ONE launch (round 3): run the batches with launch4[7] = 1 (they then leave their partial
+ * tiles in their slabs) and describe each here by its tables, n_tiles = launch4[4], K and the tile class it was planned with. */
+typedef struct sarWgradReduce { const void* convs_dev; const void* tiles_dev; const int* slices_dev; const float* slab; int n_tiles, K, tile_ci, tile_co; } sarWgradReduce;
+int sar_wgrad_reduce_multi_bf16(const sarWgradReduce* plans, int n, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
 int sar_bn_bwd_apply_bf16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
                           int C, int relu, float out_scale, sarStream_t stream);   /* out_scale multiplies the result (1 in the bf16 trunk) */
@@ -260,6 +264,7 @@ int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const vo
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
 int sar_conv2d_last_class_f16(int* out6);
+int sar_wgrad_reduce_multi_f16(const sarWgradReduce* plans, int n, sarStream_t stream);
 int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                const int* slices_dev, float* slab, sarStream_t stream);
 int sar_bn_bwd_apply_f16(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,

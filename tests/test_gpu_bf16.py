@@ -389,6 +389,32 @@ def test_conv_wgrad_many_convolutions_in_one_launch(L):
         assert (np.diff(items[:, 4]) <= 0).all(), "longest items first"
 
 
+def test_wgrad_reductions_of_several_plans_in_one_launch(L):
+    """sar_wgrad_reduce_multi_*: three plans of different tile classes (64-wide 3x3, 32-wide 3x3, 1x1) run with their reductions deferred
+    (launch4[7] = 1), then ONE launch sums the partial tiles of all of them -- same gradients as each plan reducing for itself."""
+    rng = np.random.default_rng(77)
+    cases = [((16, 50, 10, 64, 64, 3, 1, "same"), (2, 2)), ((16, 50, 20, 32, 32, 3, 1, "same"), (1, 1)), ((16, 50, 10, 64, 128, 1, 2, "valid"), (1, 1))]   # >= 32 chunks of 64 pixels each: the planner cuts runs of >= 16
+    plans, outs = [], []
+    for shape, tile in cases:
+        B, H, W, Cin, Cout, k, s, pad = shape
+        cv = Conv(L, rng.standard_normal((k, k, Cin, Cout)), s, pad)
+        ho, wo, _, _ = cv.geo(H, W)
+        x = rbf(grid(rng, (B, H, W, Cin)) + 0.4); dy = grid(rng, (B, ho, wo, Cout))
+        _, cache = O.conv2d_fwd(x, cv.wq, np.zeros(Cout), (s, s), pad)
+        _, dw_ref, db_ref = O.conv2d_bwd(dy, cache)
+        dw = torch.ones(k, k, Cin, Cout, device="cuda"); db = torch.zeros(Cout, device="cuda")
+        plan = L.WgradPlan([cv.desc(dbf(x), dbf(dy), dw, db)], 48, tile, SFX)       # 48 items: every gradient tile is shared by several
+        assert plan.n_tiles > 0 and plan.n_slabs > plan.n_tiles
+        plans.append(plan); outs.append((dw, db, dw_ref, db_ref))
+    for p_ in plans:
+        p_.launch(defer_reduce=True)
+    for dw, _, _, _ in outs:                                                          # nothing has reached the gradients yet
+        assert float((dw - 1.0).abs().max()) == 0.0
+    L.WgradPlan.reduce_multi(plans, SFX)
+    for dw, db, dw_ref, db_ref in outs:
+        check(dw - 1.0, dw_ref, TOL_F32, "dw (multi-plan reduction)"); check(db, db_ref, TOL_F32, "db")
+
+
 @pytest.mark.parametrize("R,C", [(2496, 256), (77, 32), (128000, 32), (8000, 128), (5, 512)])
 def test_batchnorm_passes(L, R, C):
     rng = np.random.default_rng(R + C)
