@@ -1237,7 +1237,20 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const u16* __restric
 // forward: output = co, reduction = ci, tap as stored;  dgrad: output = ci, reduction = co, taps flipped.
 struct PackRow { const float* w; u16* wf; u16* wd; long taps, Cin, Cout, first_block, pad_; };
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __restrict__ tab, int n) {
+// (zt != nullptr: the blocks past `pblocks` zero the step's accumulators -- the rows {address, 32-bit words} of sar_zero_ranges' table, every
+// block striding over every range -- so that the two launches every train step begins with are one: each costs ~4.5 us before it does
+// anything)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __restrict__ tab, int n, int pblocks, const long long* __restrict__ zt, int nz) {
+    if ((int)blockIdx.x >= pblocks) {
+        const long long zb = blockIdx.x - pblocks, nzb = gridDim.x - pblocks;
+        for (int r = 0; r < nz; ++r) {
+            uint4* p = reinterpret_cast<uint4*>(zt[2 * r]);
+            const long long nw = zt[2 * r + 1], n4 = nw >> 2;
+            for (long long i = zb * 256 + threadIdx.x; i < n4; i += 256LL * nzb) p[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (zb == 0 && threadIdx.x < (nw & 3)) reinterpret_cast<unsigned*>(p)[n4 * 4 + threadIdx.x] = 0u;
+        }
+        return;
+    }
     // the row of this block: rows are sorted by first_block; every lane tests one row (one load round trip for up to 64 rows -- a scan
     // was up to n dependent L2 round trips in front of the last convolutions' blocks, most of this kernel's 25 us)
     int r = -1;
@@ -1322,7 +1335,16 @@ int SAR_T16(sar_conv2d_last_class_)(int* out6) {
 
 int SAR_T16(sar_conv_pack_weights_)(const void* table, int n, int total_blocks, hipStream_t stream) {
     if (table == nullptr || n < 1 || total_blocks < 1) return SAR_EINVAL;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const PackRow*>(table), n);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const PackRow*>(table), n, total_blocks,
+                       static_cast<const long long*>(nullptr), 0);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+// sar_zero_ranges(zero_table, nz) and sar_conv_pack_weights_*(table, n, total_blocks) in ONE launch: what a train step of the 2-byte trunk begins with.
+int SAR_T16(sar_conv_pack_weights_zero_)(const void* table, int n, int total_blocks, const void* zero_table, int nz, hipStream_t stream) {
+    if (table == nullptr || n < 1 || total_blocks < 1 || zero_table == nullptr || nz < 1 || nz > 65535) return SAR_EINVAL;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(total_blocks + 2048), dim3(256), 0, stream, static_cast<const PackRow*>(table), n, total_blocks,
+                       static_cast<const long long*>(zero_table), nz);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

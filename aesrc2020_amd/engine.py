@@ -175,10 +175,20 @@ class ParamStore:
         for q in grp[1]:
             _lib.call("sar_gemm_wgrad_f32", *q)
 
-    def zero_grads(self):
+    def zero_grads(self, defer=False):
+        """defer: the caller promises that the table this returns is zeroed by the very next launch (the 2-byte trunk's weight packing takes
+        it along: sar_conv_pack_weights_zero_*) -- one launch fewer at the start of every step."""
         tab = self._zero_table_sync()
-        _lib.call("sar_zero_ranges", tab, tab.shape[0])
         self._zeroed_this_step = True
+        if defer:
+            self._deferred_zero = tab
+            return tab
+        _lib.call("sar_zero_ranges", tab, tab.shape[0])
+        return None
+
+    def take_deferred_zero(self):
+        tab = self.__dict__.get("_deferred_zero"); self._deferred_zero = None
+        return tab
 
     def adam_step(self):
         """L2 gradient + Keras Adam over the whole flat buffer, then the unit_norm constraints."""

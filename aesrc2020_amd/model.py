@@ -485,8 +485,12 @@ class SARNetModel:
         """Backward of the ResNet trunk: completes the head bucket (conv stack) of the flat gradient buffer."""
         self.trunk.backward(g)
 
+    def _zero_at_step_start(self):
+        # 2-byte trunk: the first launch of the forward pass is the trunk's weight packing, and it takes the zeroing along
+        self.store.zero_grads(defer=bool(getattr(self.trunk, "bf16", False)) and os.environ.get("SAR_STEP_BEGIN_MERGE", "1") != "0")
+
     def _device_step(self, update=True):
-        self.store.zero_grads()
+        self._zero_at_step_start()
         self._forward("train"); self._losses_forward(); self._backward()
         if update:
             self.store.adam_step()
@@ -494,7 +498,7 @@ class SARNetModel:
             self.store._zeroed_this_step = False  # (the data-parallel two-graph form runs adam_step as its next segment)
 
     def _seg_heads(self):
-        self.store.zero_grads()
+        self._zero_at_step_start()
         self._forward("train"); self._losses_forward(); self._backward_heads()
 
     def _seg_trunk(self, part):

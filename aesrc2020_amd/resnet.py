@@ -310,7 +310,11 @@ class ResNetTrunk(Layer):
         if self.half:
             self._set_gscale(B)
         training = self.store.training
-        _call("sar_conv_pack_weights_" + self.sfx, self._pack_table, self._pack_table.shape[0], self._pack_blocks)
+        ztab = self.store.take_deferred_zero()                              # the step-start zeroing rides in the packing launch (model._device_step)
+        if ztab is not None:
+            _call("sar_conv_pack_weights_zero_" + self.sfx, self._pack_table, self._pack_table.shape[0], self._pack_blocks, ztab, ztab.shape[0])
+        else:
+            _call("sar_conv_pack_weights_" + self.sfx, self._pack_table, self._pack_table.shape[0], self._pack_blocks)
         if training:
             if not self.store.zero_at_step_start(self._arena):              # the step-start launch covers it from the second step on
                 _call("sar_fill_f32", self._arena, 0.0, self._arena.numel())
@@ -478,6 +482,20 @@ class ResNetTrunk(Layer):
             # the partial tiles of all classes are summed by ONE launch behind the last batch (a launch costs ~4.5 us of the step before it
             # does anything: DESIGN 5.0); SAR_WG_REDUCE_MULTI=0: one reduction behind every batch
             multi = os.environ.get("SAR_WG_REDUCE_MULTI", "1") != "0" and len(plans[key]) > 1
+            if multi and os.environ.get("SAR_WG_FORK", "0") == "1":
+                # (EXPERIMENT: the classes are independent of each other -- the first on this stream, the rest on a second one, joined in
+                # front of the reduction; inside a HIP-graph capture a parallel branch)
+                main = torch.cuda.current_stream()
+                if getattr(self, "_wg_stream", None) is None:
+                    self._wg_stream = torch.cuda.Stream()
+                self._wg_stream.wait_stream(main)
+                plans[key][0].launch(defer_reduce=True)
+                with torch.cuda.stream(self._wg_stream):
+                    for p in plans[key][1:]:
+                        p.launch(defer_reduce=True)
+                main.wait_stream(self._wg_stream)
+                _lib.WgradPlan.reduce_multi(plans[key], self.sfx)
+                return
             for p in plans[key]:
                 p.launch(defer_reduce=multi)
             if multi:

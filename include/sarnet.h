@@ -169,6 +169,9 @@ int sar_bn_bins(void);
  * Cout, first_block, 0}; stream sizes: wf = (Cout/32)*(KH*KW*Cin/16 + 8)*1024 bytes, wd = (Cin/32)*(KH*KW*Cout/16 + 8)*1024;
  * blocks per row = ceil((wf + wd bytes)/16/256), first_block = running sum.  Once per optimiser step. */
 int sar_conv_pack_weights_bf16(const void* table, int n, int total_blocks, sarStream_t stream);
+/* sar_zero_ranges(zero_table, nz) and sar_conv_pack_weights_bf16(table, n, total_blocks) in one launch (round 3): the two launches a
+ * train step of the 2-byte trunk begins with. */
+int sar_conv_pack_weights_zero_bf16(const void* table, int n, int total_blocks, const void* zero_table, int nz, sarStream_t stream);
 /* Generic bf16 convolution, forward (resnet.py:39-42, 60-63, 82-87, 113-117) and input gradient in one kernel:
  *   y[B*Ho*Wo][Cout] = sum_taps T(src)[padded position] * wpk (+ bias) (+ res)
  * fill 0: T = identity; 1: T = relu(bn(.)) of fbn (statistics from fbn->bins, or fbn->saved when bins is NULL: inference /
@@ -260,6 +263,7 @@ int sar_stem16_wgrad(const float* x, const float* w, const float* bias, const vo
  * final BatchNorm, resnet.py:178) and ginv = 1/S wherever parameter gradients leave (sarBnRef.ginv, sarWgradConv.ginv); everything
  * in between is linear in the gradient. */
 int sar_conv_pack_weights_f16(const void* table, int n, int total_blocks, sarStream_t stream);
+int sar_conv_pack_weights_zero_f16(const void* table, int n, int total_blocks, const void* zero_table, int nz, sarStream_t stream);
 int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
