@@ -157,6 +157,37 @@ class BnRef(ctypes.Structure):
             self.ginv = 1.0                                                  # no gradient scale unless the caller sets one
 
 
+class ConvArgs(ctypes.Structure):
+    """include/sarnet.h: sarConvArgs -- the arguments of one sar_conv2d_* call (sar_conv2d_pair_* takes two)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("src", "src2", "src3", "wpk", "bias", "res", "y", "side")] + \
+               [(n, ctypes.c_int) for n in ("B", "Hs", "Ws", "Cin", "Ho", "Wo", "Cout", "K", "s", "d", "pt", "pl", "fill")] + \
+               [("fbn", ctypes.c_void_p), ("epi", ctypes.c_int), ("e_bins", ctypes.c_void_p), ("e_y", ctypes.c_void_p), ("e_saved", ctypes.c_void_p)]
+
+    @classmethod
+    def of(cls, *args):
+        """From the positional arguments of sar_conv2d_* (tensors, None, ints, a BnRef or None) -- keeps what it points to alive."""
+        a = cls()
+        a.keep = [x for x in args if hasattr(x, "data_ptr") or isinstance(x, ctypes.Structure)]
+        for (name, _), v in zip(cls._fields_, args):
+            if hasattr(v, "data_ptr"):
+                v = v.data_ptr()
+            elif isinstance(v, ctypes.Structure):
+                v = ctypes.addressof(v)
+            setattr(a, name, v)
+        return a
+
+
+def conv_pair(a, b, sfx="bf16"):
+    """sar_conv2d_pair_*: both convolutions in one launch -> True; False (nothing launched) when their instantiations do not pair up."""
+    import torch
+    rc = lib().fn["sar_conv2d_pair_" + sfx](ctypes.byref(a), ctypes.byref(b), torch.cuda.current_stream().cuda_stream)
+    if rc == -1:
+        return False
+    if rc != 0:
+        raise RuntimeError("sar_conv2d_pair_%s failed with status %d" % (sfx, rc))
+    return True
+
+
 class GemmBatch(ctypes.Structure):
     """include/sarnet.h: sarGemmBatch -- up to four (A, B, C, bias) pointer sets of equal-shape GEMMs for one launch."""
     _fields_ = [(n, ctypes.c_void_p * 4) for n in ("A", "B", "C", "bias")]

@@ -317,8 +317,10 @@ constexpr bool PFB = SAR_KP_PFB != 0;
 // straight from the packed stream into registers: requested at kernel entry (18 per wave; the other 18 of the 256+-channel layers behind
 // the fill), consumed ~3 us later.  No weight ring, no DMA, no barrier inside the k-phase, and HALF the LDS reads per MFMA (an A fragment
 // feeds one MFMA, a B fragment two; round 2's k-phase was bound by LDS reads 2 : 1 -- 2 KB per MFMA -- and by a barrier per 8 fragments).
+// (the body is a device function: conv_bf16_kernel runs it for one convolution, conv_bf16_pair_kernel for TWO independent ones in one launch.
+// lin / ntot / nty: this block's linear index among the ntot blocks of ITS convolution, of which nty are channel tiles per pixel tile)
 template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
-__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
+__device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, const unsigned ntot, const unsigned nty) {
     static_assert(BR || KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
     static_assert(!BR || (WN == 2 && (WMX == 2 || WMX == 1) && NKC / KG == 2), "BR: 64 (or 32: WMX = 1, the 512-channel sources whose 64-pixel patch does not fit the LDS) x 64 tiles, two fragments per virtual tap and wave");
     constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
@@ -342,9 +344,8 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
     // dispatch order the channel tiles of one pixel tile -- which fill the SAME patch -- and neighbouring pixel tiles -- which share halo
     // rows -- sat on different L2s, and each fetched those rows from the fabric again (PMC: 17.4 MB per stage-2 launch for 4.4 MB of
     // tensors).  Here XCD c takes the c-th contiguous eighth of the sequence (channel tile fastest, then pixel tile).
-    const unsigned nty = gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y, ntot = gridDim.x * nty;
     const unsigned chunk8 = ntot >> 3, tord = SAR_CONV_XCD && lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
-    const unsigned bx = SAR_CONV_XCD ? tord >> __builtin_ctz(nty) : blockIdx.x, by = SAR_CONV_XCD ? tord & (nty - 1) : blockIdx.y;   // Cout / TN: a power of two
+    const unsigned bx = tord >> __builtin_ctz(nty), by = tord & (nty - 1);   // Cout / TN: a power of two
     const unsigned m0 = bx * TM;
     const int n0 = by * TN;
     const unsigned M = (unsigned)g.M;
@@ -678,6 +679,24 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
         atomicAdd(p.e_bins + ((bx % NB) * 2 + which) * p.Cout + n0 + cc, s);
     }
     TSTAMP(7); TSTAMP(15);
+}
+
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
+__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
+    conv_body<WN, NKC, VT, KG, WMX, BR>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, gridDim.y);
+}
+
+// TWO independent convolutions of equal block size in ONE launch (round 3): the 1x1 shortcut of a residual block that changes the shape
+// (resnet.py:82-87) next to the block's first 3x3 conv -- same input, different outputs -- forward, and their input gradients backward.
+// A launch inside the step costs ~4.5 us before it does anything, the shortcut launches are 7-20 us of mostly that, and the
+// 3x3 launches of the stages they sit in front of leave CUs idle.  Blocks [0, na) run the first convolution, the rest the second (1x1:
+// same WN / NKC / KG / WMX / BR, VT = channel parts of ONE tap); LDS and registers are the larger of the two.
+template <int WN, int NKC, int VT, int KG, int WMX, bool BR>
+__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1)
+void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, const unsigned ntya, const unsigned nb, const unsigned ntyb) {
+    const unsigned na8 = (na + 7u) & ~7u;                             // the second convolution starts on XCD 0 as well (its XCD-aware tile order)
+    if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR>(pa, blockIdx.x, na, ntya);
+    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMX, BR>(pb, blockIdx.x - na8, nb, ntyb);
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
@@ -1326,6 +1345,9 @@ extern "C" {
 typedef BnP sarBnRef;
 
 static int g_last_class[6];
+// sar_conv2d_pair_* runs sar_conv2d_* twice with this set: the launcher then hands back what it would have launched instead of launching it
+struct ConvLaunch { ConvP p; dim3 grid; int nthr; size_t lds; int cls[6]; };
+static ConvLaunch* g_capture = nullptr;
 // <WN, NKC, VT, KG, WMX, BR> of the most recent sar_conv2d_* launch of this process (introspection for bench.py / tools; not thread-safe)
 int SAR_T16(sar_conv2d_last_class_)(int* out6) {
     if (out6 == nullptr) return SAR_EINVAL;
@@ -1421,6 +1443,12 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     // template arguments of the instantiation this launch runs, as rocprofv3 prints them (bench.py classes its conv timings by them)
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
     g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm64 ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
+    if (g_capture != nullptr) {
+        if (Cin == 512 && br && !br32) return SAR_EINVAL;
+        g_capture->p = p; g_capture->grid = grid; g_capture->nthr = nthr; g_capture->lds = lds;
+        for (int i = 0; i < 6; ++i) g_capture->cls[i] = g_last_class[i];
+        return SAR_OK;
+    }
     // instantiations: [WN][NKC in {2,4,8}][K == 3]; Cin = 256 / 512 run NKC = 8 with 2 / 4 channel parts per tap
     typedef void (*kern_t)(const ConvP);
 #define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
@@ -1470,6 +1498,45 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     const kern_t kern = kerns[WN - 1][ki][k3];
     if (!attr[WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[WN - 1][ki][k3] = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// The arguments of one sar_conv2d_* call (include/sarnet.h: sarConvArgs).
+struct sarConvArgs { const void *src, *src2, *src3, *wpk; const float* bias; const void* res; void* y; void* side;
+                     int B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill; const sarBnRef* fbn; int epi; float* e_bins; const void* e_y; const float* e_saved; };
+// Two independent convolutions in ONE launch: a = a 3x3 convolution, b = a 1x1 convolution of the same channel classes and block size (the first
+// conv of a shape-changing residual block and its shortcut, or their input gradients).  Returns SAR_EINVAL -- and launches NOTHING -- when the
+// two do not run on instantiations that pair up; the caller then issues them one after the other.
+int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStream_t stream) {
+    if (a == nullptr || b == nullptr) return SAR_EINVAL;
+    static ConvLaunch la, lb;                                                       // (host-side scratch; one caller thread, like g_last_class)
+    const sarConvArgs* q[2] = {a, b};
+    ConvLaunch* l[2] = {&la, &lb};
+    for (int i = 0; i < 2; ++i) {
+        g_capture = l[i];
+        const int rc = SAR_T16(sar_conv2d_)(q[i]->src, q[i]->src2, q[i]->src3, q[i]->wpk, q[i]->bias, q[i]->res, q[i]->y, q[i]->side, q[i]->B, q[i]->Hs, q[i]->Ws,
+                                            q[i]->Cin, q[i]->Ho, q[i]->Wo, q[i]->Cout, q[i]->K, q[i]->s, q[i]->d, q[i]->pt, q[i]->pl, q[i]->fill, q[i]->fbn, q[i]->epi,
+                                            q[i]->e_bins, q[i]->e_y, q[i]->e_saved, stream);
+        g_capture = nullptr;
+        if (rc != SAR_OK) return rc;
+    }
+    const int* ca = la.cls; const int* cb = lb.cls;
+    // same WN, NKC, KG, WMX, BR and block size; a: nine taps, b: one
+    if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || ca[4] != cb[4] || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
+    typedef void (*pair_t)(const ConvP, const ConvP, unsigned, unsigned, unsigned, unsigned);
+    pair_t kern = nullptr;
+    static PerDeviceFlag at[4];
+    int ki = -1;
+    if (ca[0] == 2 && ca[1] == 2 && ca[2] == 9 && ca[3] == 1 && ca[4] == 2 && !ca[5]) { kern = conv_bf16_pair_kernel<2, 2, 9, 1, 2, false>; ki = 0; }
+    else if (ca[0] == 2 && ca[1] == 4 && ca[2] == 9 && ca[3] == 2 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 4, 9, 2, 2, true>; ki = 1; }
+    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 9, 4, 2, true>; ki = 2; }
+    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 18, 4, 2, true>; ki = 3; }
+    if (kern == nullptr) return SAR_EINVAL;
+    if (!at[ki]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at[ki] = true; }
+    const unsigned na = la.grid.x * la.grid.y, nb = lb.grid.x * lb.grid.y, na8 = (na + 7u) & ~7u;
+    const size_t lds = la.lds > lb.lds ? la.lds : lb.lds;
+    hipLaunchKernelGGL(kern, dim3(na8 + nb), dim3(la.nthr), lds, stream, la.p, lb.p, na, la.grid.y, nb, lb.grid.y);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

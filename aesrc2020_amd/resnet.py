@@ -122,17 +122,23 @@ class _Conv:
         self.wd = b.get(self.name + "/wd16", (nd,), self.t16)
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
-    def fwd16(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
-        _call("sar_conv2d_" + self.sfx, x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
-              self.k, self.stride, 1, self.pt, self.pl, fill, fbn, self.epi_fwd if e_bins is not None else 0, e_bins, None, None)
+    def fwd16_args(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
+        return (x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
+                self.k, self.stride, 1, self.pt, self.pl, fill, fbn, self.epi_fwd if e_bins is not None else 0, e_bins, None, None)
+
+    def fwd16(self, x, y, B, **kw):
+        _call("sar_conv2d_" + self.sfx, *self.fwd16_args(x, y, B, **kw))
 
     def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
         """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2, + dy3 when fill == 3
         (written back to `side` for the weight gradient and the other consumers of that gradient); the epilogue leaves the backward
         sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
-        _call("sar_conv2d_" + self.sfx, dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
-              self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
-              e_bins, e_y, e_saved)
+        _call("sar_conv2d_" + self.sfx, *self.dgrad16_args(dy, dy2, dx, B, fill, fbn, res, e_bins, e_y, e_saved, side, dy3))
+
+    def dgrad16_args(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
+        return (dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
+                self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
+                e_bins, e_y, e_saved)
 
     def wgrad16(self, x, dy, B, bias_grad):
         """Descriptor of this conv's weight gradient on plain operands (include/sarnet.h: sarWgradConv); the trunk batches them
@@ -333,12 +339,17 @@ class ResNetTrunk(Layer):
             # training: the activated operands relu(bn(.)) the fills compute are written back (a, a1) for the weight gradients
             blk["a"] = self._buf16("b%d_a" % n, tuple(cur.shape)) if (training and bn1 is not None) else None
             blk["a1"] = self._buf16("b%d_a1" % n, (B, H2, W2, cout)) if training else None
-            blk["conv1"].fwd16(cur, c1, B, fill=1 if bn1 is not None else 0, fbn=bn1.ref(B * H * W, st, training) if bn1 is not None else None,
-                               e_bins=bn2.bins if training else None, side=blk["a"])
+            a1 = blk["conv1"].fwd16_args(cur, c1, B, fill=1 if bn1 is not None else 0, fbn=bn1.ref(B * H * W, st, training) if bn1 is not None else None,
+                                         e_bins=bn2.bins if training else None, side=blk["a"])
             if blk["sc"] is not None:
+                # the block's first conv and its 1x1 shortcut read the same tensor and write different ones: ONE launch where their
+                # instantiations pair up (sar_conv2d_pair_*), else one after the other
                 sc = self._buf16("b%d_sc" % n, (B, H2, W2, cout))
-                blk["sc"].fwd16(cur, sc, B)
+                a2 = blk["sc"].fwd16_args(cur, sc, B)
+                if not self._pair(a1, a2):
+                    _call("sar_conv2d_" + self.sfx, *a1); _call("sar_conv2d_" + self.sfx, *a2)
             else:
+                _call("sar_conv2d_" + self.sfx, *a1)
                 sc = cur
             y = self._buf16("b%d_y" % n, (B, H2, W2, cout))
             nxt = self.blocks[n + 1]["bn1"] if n + 1 < nblk else self.final_bn
@@ -400,9 +411,12 @@ class ResNetTrunk(Layer):
             # the weight gradients run at the end of the part (_wgrad16), so their gradient operands -- the block's incoming
             # gradient and dc1 -- live in per-block buffers, not in recycled scratch
             gin = self._buf16("b%d_gin" % n, (B, H, W, cin))
+            sc_args = None
             if blk["sc"] is not None:
                 dsc = gin if bn1 is None else self._buf16("b%d_dsc" % n, (B, H, W, cin))
-                blk["sc"].dgrad16(g, None, dsc, B)
+                sc_args = blk["sc"].dgrad16_args(g, None, dsc, B)
+                if bn1 is None:                                       # (conv1's input gradient below adds dsc: one after the other)
+                    _call("sar_conv2d_" + self.sfx, *sc_args); sc_args = None
                 red.append(blk["sc"].wgrad16(x, g, B, bias_grad=True))
             else:
                 dsc = g
@@ -411,7 +425,13 @@ class ResNetTrunk(Layer):
             dc1 = self._buf16("b%d_dc1" % n, (B, H2, W2, cout))
             if bn1 is not None:
                 da1 = self._buf16("b%d_da1" % n, (B, H, W, cin))
-                blk["conv1"].dgrad16(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
+                c1_args = blk["conv1"].dgrad16_args(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
+                # the input gradients of the first conv and of the shortcut are independent (their sum is formed in the fill of the block in
+                # front, fill 3): one launch where they pair up
+                if sc_args is None or not self._pair(c1_args, sc_args):
+                    if sc_args is not None:
+                        _call("sar_conv2d_" + self.sfx, *sc_args)
+                    _call("sar_conv2d_" + self.sfx, *c1_args)
                 pend = (da1, x, dsc, bn1, R1, (n, g, da2.clone()) if tap is not None else None)
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
@@ -457,6 +477,13 @@ class ResNetTrunk(Layer):
     # chain.  Measured slower (cfg2: 3.14 vs 2.90 ms per step): the batched launch is bound by the memory system and takes it
     # away from the chain's fills; default = one batch at the end of the backward call, on the main stream.
     WGRAD_OVERLAP = os.environ.get("SAR_WGRAD_OVERLAP", "0") == "1"
+    PAIR = os.environ.get("SAR_CONV_PAIR", "1") != "0"
+
+    def _pair(self, a3x3, b1x1):
+        """Both convolutions (argument tuples of sar_conv2d_*) in one launch; False: nothing was launched."""
+        if not self.PAIR:
+            return False
+        return _lib.conv_pair(_lib.ConvArgs.of(*a3x3), _lib.ConvArgs.of(*b1x1), self.sfx)
 
     def _wgrad16(self, part, side=False):
         """The weight gradients of every conv collected in self._wg16 (a backward part, or one stage): one launch per class,

@@ -188,6 +188,15 @@ int sar_conv_pack_weights_zero_bf16(const void* table, int n, int total_blocks, 
 int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                     int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                     const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
+/* TWO independent convolutions in ONE launch (round 3): a = a 3x3 convolution, b = a 1x1 convolution of the same channel classes -- the first
+ * conv of a shape-changing residual block and its shortcut (resnet.py:82-87, 113-117: same input, different outputs), or their input
+ * gradients.  sarConvArgs holds the arguments of one sar_conv2d_bf16 call.  Returns SAR_EINVAL and launches NOTHING when the two do not run
+ * on instantiations that pair up (the caller then issues them one after the other). */
+typedef struct sarConvArgs {
+    const void *src, *src2, *src3, *wpk; const float* bias; const void* res; void* y; void* side;
+    int B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill; const sarBnRef* fbn; int epi; float* e_bins; const void* e_y; const float* e_saved;
+} sarConvArgs;
+int sar_conv2d_pair_bf16(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
 /* Introspection (bench.py, tools): the template arguments <WN, NKC, VT, KG, WMX, BR> of the conv_bf16_kernel instantiation the most
  * recent sar_conv2d_bf16 launch of this process ran -- the name rocprofv3 reports it under.  Not thread-safe. */
 int sar_conv2d_last_class_bf16(int* out6);
@@ -268,6 +277,7 @@ int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const vo
                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
 int sar_conv2d_last_class_f16(int* out6);
+int sar_conv2d_pair_f16(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
 int sar_wgrad_reduce_multi_f16(const sarWgradReduce* plans, int n, sarStream_t stream);
 int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                const int* slices_dev, float* slab, sarStream_t stream);

@@ -389,6 +389,51 @@ def test_conv_wgrad_many_convolutions_in_one_launch(L):
         assert (np.diff(items[:, 4]) <= 0).all(), "longest items first"
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(64, 50, 10, 64, 128), (64, 25, 5, 128, 256), (64, 100, 20, 32, 64), (5, 9, 7, 64, 128), (4, 25, 5, 256, 512)])
+def test_conv_and_its_shortcut_in_one_launch(L, B, H, W, Cin, Cout):
+    """sar_conv2d_pair_*: the stride-2 3x3 conv of a shape-changing block (BatchNorm + ReLU in its fill, statistics out) and the block's
+    1x1 shortcut in ONE launch give exactly what the two launches give one after the other; the same for their input gradients.  The last
+    shape (256 -> 512: the 3x3 runs on 32-pixel tiles, the 1x1 on 64) does not pair up: the call says so and launches nothing."""
+    rng = np.random.default_rng(B + Cin)
+    c3 = Conv(L, 0.05 * rng.standard_normal((3, 3, Cin, Cout)), 2, "same"); c1 = Conv(L, 0.1 * rng.standard_normal((1, 1, Cin, Cout)), 2, "valid")
+    x = dbf(grid(rng, (B, H, W, Cin)))
+    ho, wo, pt, pl = c3.geo(H, W); assert c1.geo(H, W)[:2] == (ho, wo)
+    bias3, bias1 = dev(rng.standard_normal(Cout)), dev(rng.standard_normal(Cout))
+
+    def fwd_args(cv, y, bias, bins):
+        _, _, pt_, pl_ = cv.geo(H, W)
+        return (x, None, None, cv.wf, bias, None, y, None, B, H, W, Cin, ho, wo, Cout, cv.k, 2, 1, pt_, pl_, 0, None, 1 if bins is not None else 0, bins, None, None)
+
+    mk = lambda: torch.full((B, ho, wo, Cout), 7.0, dtype=BF, device="cuda")
+    y3a, y1a, y3b, y1b = mk(), mk(), mk(), mk()
+    binsa, binsb = torch.zeros(L.bn_bins(), 2, Cout, device="cuda"), torch.zeros(L.bn_bins(), 2, Cout, device="cuda")
+    L.call("sar_conv2d_" + SFX, *fwd_args(c3, y3a, bias3, binsa)); L.call("sar_conv2d_" + SFX, *fwd_args(c1, y1a, bias1, None))
+    paired = L.conv_pair(L.ConvArgs.of(*fwd_args(c3, y3b, bias3, binsb)), L.ConvArgs.of(*fwd_args(c1, y1b, bias1, None)), SFX)
+    torch.cuda.synchronize()
+    if Cin == 256:
+        assert not paired and float((y3b.float() - 7.0).abs().max()) == 0.0      # nothing was launched
+        return
+    assert paired
+    assert torch.equal(y3a, y3b) and torch.equal(y1a, y1b)
+    check(binsb.sum(0), val(binsa.sum(0)), 1e-5, "statistics out of the paired launch")
+    # input gradients: source = the block's output gradient (Cout channels), stride-2 convs as stride-1 convs over the dilated gradient
+    g = dbf(grid(rng, (B, ho, wo, Cout)))
+
+    def dgrad_args(cv, dx):
+        _, _, pt_, pl_ = cv.geo(H, W)
+        return (g, None, None, cv.wd, None, None, dx, None, B, ho, wo, Cout, H, W, Cin, cv.k, 1, 2, cv.k - 1 - pt_, cv.k - 1 - pl_, 0, None, 0, None, None, None)
+
+    mkx = lambda: torch.full((B, H, W, Cin), 7.0, dtype=BF, device="cuda")
+    d3a, d1a, d3b, d1b = mkx(), mkx(), mkx(), mkx()
+    L.call("sar_conv2d_" + SFX, *dgrad_args(c3, d3a)); L.call("sar_conv2d_" + SFX, *dgrad_args(c1, d1a))
+    paired = L.conv_pair(L.ConvArgs.of(*dgrad_args(c3, d3b)), L.ConvArgs.of(*dgrad_args(c1, d1b)), SFX)
+    torch.cuda.synchronize()
+    if paired:                                                                     # (32 output channels: the 3x3 and the 1x1 run on different block sizes)
+        assert torch.equal(d3a, d3b) and torch.equal(d1a, d1b)
+    else:
+        assert Cin <= 32 and float((d3b.float() - 7.0).abs().max()) == 0.0
+
+
 def test_wgrad_reductions_of_several_plans_in_one_launch(L):
     """sar_wgrad_reduce_multi_*: three plans of different tile classes (64-wide 3x3, 32-wide 3x3, 1x1) run with their reductions deferred
     (launch4[7] = 1), then ONE launch sums the partial tiles of all of them -- same gradients as each plan reducing for itself."""

@@ -107,7 +107,7 @@ def test_hand_counted_vmcnt_kernels_use_no_scratch():
     seen = 0
     for blk in md.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        if "conv_bf16_kernel" in name or "wgrad1_bf16_kernel" in name or "wgrad3_bf16_kernel" in name:
+        if "conv_bf16_kernel" in name or "conv_bf16_pair_kernel" in name or "wgrad1_bf16_kernel" in name or "wgrad3_bf16_kernel" in name:
             seen += 1
             assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
             assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
