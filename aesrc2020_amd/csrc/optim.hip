@@ -40,10 +40,18 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
         lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     }
     float lacc = 0.f;
+    // ticket[1] != 0 (fp16 trunk): a gradient element that is not finite is DROPPED (treated as zero) and counted in ticket[2].  The fp16
+    // trunk carries its activation gradients times a static scale (64 x batch); an element past 65504 / scale -- seen once in ~2 000 steps of
+    // the diverging synthetic cfg3 run, in the gradient of the pooled map -- is inf there, its channel of the stem's kernel gradient NaN, and
+    // without this guard one such step poisons the weights for good.  (The fp32-class and bf16 modes run with the guard off: a non-finite
+    // gradient there is a bug to be seen, not an overflow to be survived.)
+    const bool guard = FUSED && ticket[1] != 0u;
+    unsigned dropped = 0u;
     // one wave per 256-element chunk, float4 per lane (16-byte accesses: the scalar version ran at 3.4 TB/s), two chunks per
     // trip so that 14 loads are in flight per lane
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     auto upd = [&](float w, float gi, float& mi, float& vi, float l2) {
+        if (guard && !(fabsf(gi) <= 3.0e38f)) { gi = 0.f; ++dropped; }
         const float gr = fmaf(2.f * l2, w, gi * gs);
         lacc = fmaf(l2 * w, w, lacc);
         mi = b1 * mi + (1.f - b1) * gr;
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
         if (threadIdx.x == 0) atomicAdd(l2_loss, lacc);
     }
     if constexpr (FUSED) {
+        if (dropped) atomicAdd(ticket + 2, dropped);
         if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {   // every block has read the iteration count
             *ticket = 0u;
             st->lr_t = lr_t; st->iterations += 1;
@@ -129,8 +138,9 @@ extern "C" int sar_adam_l2_step_f32(float* params, const float* grads, float* m,
     return SAR_OK;
 }
 
-// sar_adam_prepare + sar_adam_l2_step_f32 in ONE launch.  `ticket`: one zero-initialised 32-bit word the caller owns (it is zero again when the
-// launch has finished).
+// sar_adam_prepare + sar_adam_l2_step_f32 in ONE launch.  `ticket`: FOUR 32-bit words the caller owns, zero-initialised: [0] the block ticket
+// (zero again when the launch has finished), [1] the caller's switch "drop gradient elements that are not finite" (fp16 trunk), [2] how many
+// were dropped so far, [3] spare.
 extern "C" int sar_adam_l2_update_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                                       void* state, void* ticket, float* l2_loss, long n, hipStream_t stream) {
     if (!params || !grads || !m || !v || !chunk_l2 || !state || !ticket || (n % 256)) return SAR_EINVAL;

@@ -186,6 +186,17 @@ class ParamStore:
         _lib.call("sar_zero_ranges", tab, tab.shape[0])
         return None
 
+    def set_adam_guard(self, on=True):
+        """fp16 trunk: gradient elements that are not finite (an activation gradient past fp16's range) are dropped by the optimiser instead
+        of poisoning the weights; dropped_gradient_elements() counts them."""
+        self._adam_guard = bool(on)
+        if self.__dict__.get("_adam_ticket") is not None:
+            self._adam_ticket[1] = 1 if on else 0
+
+    def dropped_gradient_elements(self):
+        t = self.__dict__.get("_adam_ticket")
+        return 0 if t is None else int(t[2].item())
+
     def take_deferred_zero(self):
         tab = self.__dict__.get("_deferred_zero"); self._deferred_zero = None
         return tab
@@ -197,7 +208,9 @@ class ParamStore:
         self._zeroed_this_step = False                                       # the step is over: later forwards (evaluate) zero for themselves
         self._zero_table_sync()                                              # buffers registered during this (eager) step join the table now
         if self.__dict__.get("_adam_ticket") is None:
-            self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=self.params.device)
+            self._adam_ticket = torch.zeros(4, dtype=torch.int32, device=self.params.device)      # [ticket, guard switch, dropped count, spare]
+            if self.__dict__.get("_adam_guard", False):
+                self._adam_ticket[1] = 1
         _lib.call("sar_adam_l2_update_f32", self.params, self.grads, self.m, self.v, self.chunk_l2, self.adam_state, self._adam_ticket,
                   self.l2_loss, self.n)                                      # step-size bookkeeping + update in one launch
         for r in self.refs:

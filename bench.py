@@ -339,9 +339,14 @@ def run_workload(name, args, rank, world, with_extras, batch=None):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     logs = train_model._logs()
-    assert np.isfinite(logs["loss"]), logs
+    if not np.isfinite(logs["loss"]):                      # say where the non-finite value sits before giving up
+        st_ = model.store
+        diag = {k: int((~torch.isfinite(getattr(st_, k))).sum().item()) for k in ("params", "grads", "m", "v")}
+        where = [(r.name, int((~torch.isfinite(r.g)).sum().item()), int(torch.isinf(r.g).sum().item())) for r in st_.refs if not bool(torch.isfinite(r.g).all())]
+        raise AssertionError((name, args.dtype, B, logs, "l2_loss", float(st_.l2_loss.item()), "non-finite", diag, "gradients (name, non-finite, inf)", where[:8]))
     res = dict(value=round(world * B * args.steps / dt, 2), ms_per_step=round(dt / args.steps * 1e3, 4), workload=wl["desc"], B=B, T=T,
-               params=model.count_params(), final_loss=round(logs["loss"], 4), kw=kw, input_shape=input_shape)
+               params=model.count_params(), final_loss=round(logs["loss"], 4), kw=kw, input_shape=input_shape,
+               dropped=model.store.dropped_gradient_elements())      # fp16 trunk: gradient elements past fp16's range, dropped by the optimiser
     return res, model
 
 
@@ -393,7 +398,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": r["workload"], "batch_per_gpu": r["B"], "global_batch": r["B"] * world, "frames": r["T"], "feat_dim": 80,
                        "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "settle_steps": max(args.settle, 0), "params": r["params"],
-                       "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"],
+                       "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"], "nonfinite_gradient_elements_dropped": r["dropped"],
                        # BASELINE configs[1] names bf16 for this workload; the default here is fp16 -- the same 2 bytes and MFMA rate with three
                        # more mantissa bits (3-4x closer to the float64 oracle), i.e. not a reduced precision; the bf16 build of the
                        # same kernels is timed in the same run (also.cfg2_bf16) and is one flag away (--dtype bf16)
@@ -422,7 +427,7 @@ def main():
                 set_dtype(dt)
                 ra, m2 = run_workload(name, args, rank, world, False, batch=batch)
                 also[key] = {"value": ra["value"], "unit": "utterances/sec", "ms_per_step": ra["ms_per_step"], "batch_per_gpu": ra["B"],
-                             "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"]}
+                             "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"], "nonfinite_gradient_elements_dropped": ra["dropped"]}
                 del m2
                 torch.cuda.empty_cache()
             other16 = "bf16" if args.dtype != "bf16" else "fp16"

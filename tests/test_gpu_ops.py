@@ -804,13 +804,21 @@ def test_adam_l2_unitnorm(L):
         check(p, pr, 1e-5, "adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
     assert int(st.view(torch.int32)[6]) == 3
     # the one-launch form (round 3): prepare + step, the last block advances the iteration count; three further steps continue the run
-    tick = torch.zeros(1, dtype=torch.int32, device="cuda")
+    tick = torch.zeros(4, dtype=torch.int32, device="cuda")
     for it in range(3, 6):
         l2l.zero_()
         L.call("sar_adam_l2_update_f32", p, dev(g), m, v, dev(l2), st, tick, l2l, n)
         ref_l2 = (l2e * pr * pr).sum()
         pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, it, lr=0.01)
         check(p, pr, 1e-5, "fused adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
-        assert int(tick.item()) == 0 and int(st.view(torch.int32)[6]) == it + 1
+        assert int(tick[0].item()) == 0 and int(tick[2].item()) == 0 and int(st.view(torch.int32)[6]) == it + 1
+    # the overflow guard (tick[1] = 1, the fp16 trunk): elements whose gradient is not finite are treated as zero and counted
+    tick[1] = 1
+    gbad = g.copy(); gbad[[3, 700, 5000]] = [np.inf, -np.inf, np.nan]
+    gz = g.copy(); gz[[3, 700, 5000]] = 0.0
+    l2l.zero_()
+    L.call("sar_adam_l2_update_f32", p, dev(gbad), m, v, dev(l2), st, tick, l2l, n)
+    pr, mr, vr = O.adam_step(pr, 0.5 * gz + 2 * l2e * pr, mr, vr, 6, lr=0.01)
+    check(p, pr, 1e-5, "guarded adam"); assert int(tick[2].item()) == 3 and bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
     w = rng.standard_normal((256, 8)); wd = dev(w)
     L.call("sar_unit_norm_f32", wd, 256, 8); check(wd, O.unit_norm(w), 1e-5, "unit_norm")
