@@ -301,7 +301,7 @@ constexpr bool PFB = SAR_KP_PFB != 0;
 #define SAR_BR_PD 8        // BR form: weight fragments in flight ahead of the MFMA that consumes them
 #endif
 #ifndef SAR_BR_WHEN
-#define SAR_BR_WHEN 0      // BR form: where the first 18 weight fragments are requested: 0 kernel entry, 1 behind the BatchNorm prologue, 2 behind the fill
+#define SAR_BR_WHEN 0      // BR form: where the first SAR_BR_PD weight fragments are requested: 0 kernel entry, 1 behind the BatchNorm prologue, 2 behind the fill
 #endif
 #ifndef SAR_EPI_SYNC
 #define SAR_EPI_SYNC 0
@@ -314,8 +314,9 @@ constexpr bool PFB = SAR_KP_PFB != 0;
 // BR ("B in registers", round 3; the 64+-channel sources with 64+ output channels: stages 1-3): the block is still 64 pixels x 64 channels,
 // but its waves are 2 channel halves x KG k-groups, a wave owns BOTH 32-pixel halves of its 32 channels (two accumulators) on a 1/KG share
 // of every tap's channels (two fragments per virtual tap), and its weight fragments -- which no other wave of the block needs -- come
-// straight from the packed stream into registers: requested at kernel entry (18 per wave; the other 18 of the 256+-channel layers behind
-// the fill), consumed ~3 us later.  No weight ring, no DMA, no barrier inside the k-phase, and HALF the LDS reads per MFMA (an A fragment
+// straight from the packed stream into registers as a stream that stays SAR_BR_PD (8) fragments ahead of the MFMA that consumes them: the
+// first eight requested at kernel entry, one more per k-step (the whole set at entry -- 18 / 36 per wave -- stalled the prologue behind
+// 144 KB per CU on the 64 B/clk L2 port).  No weight ring, no DMA, no barrier inside the k-phase, and HALF the LDS reads per MFMA (an A fragment
 // feeds one MFMA, a B fragment two; round 2's k-phase was bound by LDS reads 2 : 1 -- 2 KB per MFMA -- and by a barrier per 8 fragments).
 // (the body is a device function: conv_bf16_kernel runs it for one convolution, conv_bf16_pair_kernel for TWO independent ones in one launch.
 // lin / ntot / nty: this block's linear index among the ntot blocks of ITS convolution, of which nty are channel tiles per pixel tile)
