@@ -109,6 +109,27 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint
     return pack8(o);
 }
 
+// Statistic bins keyed by XCD (round 3 EXPERIMENT, off: -DSAR_STAT_XCD=1).  Phase removal inside the step (SAR_EPV): the statistics of the
+// conv epilogues cost 130 us of a 1.92 ms step -- 78 us the atomics themselves (32 000 per launch into 16 bins, each a read-modify-write
+// behind the fabric: the launch is not over until the last has come back), 50 us the partial sums' way through LDS.  Here a block adds
+// into the bins of the XCD it RUNS on (HW_REG_XCC_ID; two bins per XCD) with workgroup-scope atomics, in the hope that they execute in that
+// XCD's L2.  Correct (parity green) and exactly as slow, 1.9258 vs 1.9261 ms: the ISA of the two scopes is the same
+// (`global_atomic_add_f32 ... off`, no sc1 either way) -- where an atomic on this memory executes is not the instruction's choice.
+#ifndef SAR_STAT_XCD
+#define SAR_STAT_XCD 0
+#endif
+__device__ __forceinline__ unsigned stat_bin(unsigned bx) {
+    if (!SAR_STAT_XCD) return bx % NB;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;            // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+    return xcc + 8u * (bx & 1u);
+}
+template <typename T>
+__device__ __forceinline__ void stat_add(T* addr, T v) {
+    if (SAR_EPV == 4) return;                                        // (phase removal: everything but the atomics themselves)
+    if (SAR_STAT_XCD) (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(addr, v);
+}
+
 // ---------------------------------------------------------------------------------------------------- conv (fwd / dgrad)
 struct ConvP {
     Geo g; int Cout;
@@ -617,8 +638,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            ot[row * TN + col] = acc[r];
-            if constexpr (BR && WMX == 2) ot[(row + 32) * TN + col] = acc2[r];
+            if (SAR_EPV != 2 || r == 0) ot[row * TN + col] = acc[r];
+            if constexpr (BR && WMX == 2) { if (SAR_EPV != 2 || r == 0) ot[(row + 32) * TN + col] = acc2[r]; }
         }
     }
     EPI_BARRIER();
@@ -637,7 +658,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         float v0 = a.x + b0 + h_lo(rv[i]), v1 = a.y + b1 + h_hi(rv[i]);
         const unsigned pk = pack2(v0, v1);
         if (m < M) {
-            __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
+            if (SAR_EPV != 1) __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
             // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
             if (p.epi == 1) { v0 = h_lo(pk); v1 = h_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
@@ -653,7 +674,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         }
     }
     TSTAMP(6);
-    if (p.epi == 0) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
+    if (p.epi == 0 || SAR_EPV == 3) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
     if (p.epi == 3) {                                              // integer partials, integer atomics: order-independent
         long long* partq = reinterpret_cast<long long*>(part);
         partq[(rg * TN + 2 * cp) * 2 + 0] = q10; partq[(rg * TN + 2 * cp) * 2 + 1] = q20;
@@ -664,7 +685,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             long long s = 0;
 #pragma unroll
             for (int r = 0; r < RG; ++r) s += partq[(r * TN + cc) * 2 + which];
-            atomicAdd(reinterpret_cast<unsigned long long*>(p.e_bins) + ((bx % NB) * 2 + which) * p.Cout + n0 + cc, (unsigned long long)s);
+            stat_add(reinterpret_cast<unsigned long long*>(p.e_bins) + (stat_bin(bx) * 2 + which) * p.Cout + n0 + cc, (unsigned long long)s);
         }
         TSTAMP(7); TSTAMP(15);
         return;
@@ -677,7 +698,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < RG; ++r) s += part[(r * TN + cc) * 2 + which];
-        atomicAdd(p.e_bins + ((bx % NB) * 2 + which) * p.Cout + n0 + cc, s);
+        stat_add(p.e_bins + (stat_bin(bx) * 2 + which) * p.Cout + n0 + cc, s);
     }
     TSTAMP(7); TSTAMP(15);
 }
