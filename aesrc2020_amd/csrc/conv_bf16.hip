@@ -115,6 +115,9 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint
 // into the bins of the XCD it RUNS on (HW_REG_XCC_ID; two bins per XCD) with workgroup-scope atomics, in the hope that they execute in that
 // XCD's L2.  Correct (parity green) and exactly as slow, 1.9258 vs 1.9261 ms: the ISA of the two scopes is the same
 // (`global_atomic_add_f32 ... off`, no sc1 either way) -- where an atomic on this memory executes is not the instruction's choice.
+#ifndef SAR_EPV
+#define SAR_EPV 0          // phase-removal variants of the epilogue (results wrong by construction): 1 no output stores, 2 no staging stores, 3 no statistics, 4 no statistic atomics
+#endif
 #ifndef SAR_STAT_XCD
 #define SAR_STAT_XCD 0
 #endif
