@@ -121,8 +121,11 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint
 #ifndef SAR_STAT_XCD
 #define SAR_STAT_XCD 0
 #endif
+#ifndef SAR_STAT_BINS
+#define SAR_STAT_BINS NB
+#endif
 __device__ __forceinline__ unsigned stat_bin(unsigned bx) {
-    if (!SAR_STAT_XCD) return bx % NB;
+    if (!SAR_STAT_XCD) return bx % SAR_STAT_BINS;                    // (SAR_STAT_BINS < NB: contention experiment; consumers sum all NB bins)
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;            // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
     return xcc + 8u * (bx & 1u);
 }
