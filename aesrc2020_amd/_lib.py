@@ -103,14 +103,17 @@ def get_gemm_math():
     return {v: k for k, v in GEMM_MATH.items()}[lib().fn["sar_get_gemm_math"]()]
 
 
-# ---- activation storage of the conv trunk: "fp32" (round-1 kernels, conv math per set_conv_math) or "bf16" (conv_bf16.hip:
-# 2-byte activations / activation gradients, single-pass bf16 MFMA, fp32 statistics and weights).  Read when a model is built.
+# ---- activation storage of the conv trunk: "fp32" (round-1 kernels, conv math per set_conv_math), "bf16" / "fp16" (conv_bf16.hip:
+# 2-byte activations / activation gradients, single-pass MFMA, fp32 statistics and weights) or "bf16x3" (the same kernels in split
+# precision, csrc/trunk16.h SAR_X3: every 2-byte tensor a (hi, lo) pair of bf16 planes, three MFMAs per product block -- the
+# fp32-class mode that holds north_star's 1e-3).  Read when a model is built.
 _TRUNK_DTYPE = [os.environ.get("SAR_TRUNK_DTYPE", "fp32")]
+TRUNK_DTYPES = ("fp32", "bf16", "fp16", "bf16x3")
 
 
 def set_trunk_dtype(dtype):
-    if dtype not in ("fp32", "bf16", "fp16"):
-        raise ValueError("trunk dtype must be 'fp32', 'bf16' or 'fp16', got %r" % (dtype,))
+    if dtype not in TRUNK_DTYPES:
+        raise ValueError("trunk dtype must be one of %r, got %r" % (TRUNK_DTYPES, dtype))
     _TRUNK_DTYPE[0] = dtype
 
 
@@ -161,7 +164,8 @@ class ConvArgs(ctypes.Structure):
     """include/sarnet.h: sarConvArgs -- the arguments of one sar_conv2d_* call (sar_conv2d_pair_* takes two)."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("src", "src2", "src3", "wpk", "bias", "res", "y", "side")] + \
                [(n, ctypes.c_int) for n in ("B", "Hs", "Ws", "Cin", "Ho", "Wo", "Cout", "K", "s", "d", "pt", "pl", "fill")] + \
-               [("fbn", ctypes.c_void_p), ("epi", ctypes.c_int), ("e_bins", ctypes.c_void_p), ("e_y", ctypes.c_void_p), ("e_saved", ctypes.c_void_p)]
+               [("fbn", ctypes.c_void_p), ("epi", ctypes.c_int), ("e_bins", ctypes.c_void_p), ("e_y", ctypes.c_void_p), ("e_saved", ctypes.c_void_p)] + \
+               [("side2", ctypes.c_void_p), ("side_scale", ctypes.c_float)]           # sar_conv2d_x3's two extra arguments (absent: NULL / 0)
 
     @classmethod
     def of(cls, *args):

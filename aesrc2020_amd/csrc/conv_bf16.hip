@@ -79,19 +79,26 @@ __device__ __forceinline__ void load_cst8(const float* cst, int cs, int ch, int 
         if (mode == 2) { k.mu[j] = cst[2 * cs + ch + j]; k.rs[j] = cst[3 * cs + ch + j]; k.c2[j] = cst[4 * cs + ch + j]; k.c3[j] = cst[5 * cs + ch + j]; }
     }
 }
+// One 16-byte piece (eight channels) of a tensor: `h` from its (hi) plane; SAR_X3: `l` from the lo plane as well.  (Plain uint4 values,
+// never a struct of them: arrays of structs written in unrolled loops went to scratch.)
+__device__ __forceinline__ void pc_values(const uint4 h, const uint4 l, float (&f)[8]) {
+    if constexpr (X3) join8(h, l, f); else unpack8(h, f);
+}
 // MODE 0: copy; 1: relu(x*scale+shift); 2: BatchNorm(+ReLU) backward  dx = scale*(dz - c2 - xhat*c3), dz = da*[z>0];
-// 3: mode 2 + a third tensor (the shortcut gradient of the residual block behind this BatchNorm)
+// 3: mode 2 + a third tensor (the shortcut gradient of the residual block behind this BatchNorm).  fp32 in, fp32 out.
 template <int MODE>
-__device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint4 q3, const Cst8& k) {
-    if constexpr (MODE == 0) return q;
-    float a[8], o[8];
-    unpack8(q, a);
-    if constexpr (MODE == 1) {
+__device__ __forceinline__ void xform(const uint4 qh, const uint4 ql, const uint4 q2h, const uint4 q2l, const uint4 q3h, const uint4 q3l, const Cst8& k, float (&o)[8]) {
+    float a[8];
+    pc_values(qh, ql, a);
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = a[j];
+    } else if constexpr (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(a[j], k.sc[j], k.sh[j]), 0.f);
     } else {
         float y[8];
-        unpack8(q2, y);
+        pc_values(q2h, q2l, y);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float z = fmaf(y[j], k.sc[j], k.sh[j]);
@@ -101,39 +108,11 @@ __device__ __forceinline__ uint4 xform(const uint4 q, const uint4 q2, const uint
         }
         if constexpr (MODE == 3) {
             float ad[8];
-            unpack8(q3, ad);
+            pc_values(q3h, q3l, ad);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += ad[j];
         }
     }
-    return pack8(o);
-}
-
-// Statistic bins keyed by XCD (round 3 EXPERIMENT, off: -DSAR_STAT_XCD=1).  Phase removal inside the step (SAR_EPV): the statistics of the
-// conv epilogues cost 130 us of a 1.92 ms step -- 78 us the atomics themselves (32 000 per launch into 16 bins, each a read-modify-write
-// behind the fabric: the launch is not over until the last has come back), 50 us the partial sums' way through LDS.  Here a block adds
-// into the bins of the XCD it RUNS on (HW_REG_XCC_ID; two bins per XCD) with workgroup-scope atomics, in the hope that they execute in that
-// XCD's L2.  Correct (parity green) and exactly as slow, 1.9258 vs 1.9261 ms: the ISA of the two scopes is the same
-// (`global_atomic_add_f32 ... off`, no sc1 either way) -- where an atomic on this memory executes is not the instruction's choice.
-#ifndef SAR_EPV
-#define SAR_EPV 0          // phase-removal variants of the epilogue (results wrong by construction): 1 no output stores, 2 no staging stores, 3 no statistics, 4 no statistic atomics
-#endif
-#ifndef SAR_STAT_XCD
-#define SAR_STAT_XCD 0
-#endif
-#ifndef SAR_STAT_BINS
-#define SAR_STAT_BINS NB
-#endif
-__device__ __forceinline__ unsigned stat_bin(unsigned bx) {
-    if (!SAR_STAT_XCD) return bx % SAR_STAT_BINS;                    // (SAR_STAT_BINS < NB: contention experiment; consumers sum all NB bins)
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;            // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
-    return xcc + 8u * (bx & 1u);
-}
-template <typename T>
-__device__ __forceinline__ void stat_add(T* addr, T v) {
-    if (SAR_EPV == 4) return;                                        // (phase removal: everything but the atomics themselves)
-    if (SAR_STAT_XCD) (void)__hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else atomicAdd(addr, v);
 }
 
 // ---------------------------------------------------------------------------------------------------- conv (fwd / dgrad)
@@ -141,13 +120,18 @@ struct ConvP {
     Geo g; int Cout;
     const u16* x; const u16* x2; const u16* x3; const h16x8* wpk; const float* bias; const u16* res; u16* y;
     u16* side;                  // nullable: the fill transform T(x) written back to HBM (same shape as x) for the weight gradient
+                                // (SAR_X3: as ONE fp16 tensor, fp16(T(x) * side_scale))
+    u16* side2;                 // SAR_X3 only, nullable: T(x) as a plane pair (the materialised gradient of fill 3, which further convs read)
+    float side_scale;
+    unsigned xs, ys;            // SAR_X3: element offset of the lo plane of source-shaped (x, x2, x3, side2) / output-shaped (res, y, e_y) tensors
+    int lplane;                 // SAR_X3: byte offset of the lo plane of the LDS patch
     int fill; BnP fb;
     int epi; float* e_bins; const u16* e_y; const float* e_saved;
     int lg_pc;                  // log2(Cin/8): 16-byte pieces per position
     int rs;                     // LDS row stride in bytes = Cin*2 + 16 (conflict-free ds_read_b128 across rows)
-    int Fs;                     // fragment stride of the weight stream per 32 output channels: K*K*Cin/16 + 8 (zero tail)
+    int Fs;                     // fragment stride of the weight stream per 32 output channels: NPL*K*K*Cin/16 + 8 (zero tail)
     int cap_rows;               // patch rows the LDS allocation holds
-    int patch_bytes;            // LDS bytes of the patch region (incl. the 1 KiB scratch slot); the weight ring follows
+    int patch_bytes;            // LDS bytes of the patch region (all planes, incl. a 1 KiB scratch slot each); the weight ring follows
     int rd;                     // depth of the weight ring: 3, or 4 where the LDS has room (128+-channel stride-1 layers)
     int cw; unsigned mg_cw;     // 16-byte pieces of a patch row (padded width x Cin / 8) and the magic number of the division by it
 };
@@ -182,19 +166,46 @@ __device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
 }
 
 // Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
-// per 16-byte piece: one table read, the column test, the transform, one LDS store -- and, for the block that owns the
-// source pixel (the output pixel m_own lies in this block's tile, first channel tile only), one store of T(x) to `side`.
+// per 16-byte piece: one table read, the column test, the transform, one LDS store (SAR_X3: one per plane) -- and, for the block that
+// owns the source pixel (the output pixel m_own lies in this block's tile, first channel tile only), the store of T(x) to `side`.
 // `mid` runs ONCE, behind the issue of the first pieces' loads and in front of their transform: the caller finishes the BatchNorm constants
 // there (trunk16.h: bn_finish), so the bins' round trip, this function's address arithmetic and the pieces' round trip overlap.  Every
 // thread runs every trip (pieces past the end are branch-free no-ops), so `mid` may hold barriers.
-#if SAR_FILL_ROWS
-// Round 3: a thread keeps ONE column piece (padded column wp, channel group c8) and walks the patch rows: the column test, the channel
-// offset and the LDS column offset are per-thread constants, a piece costs one row-table read and ~10 instructions.  (Round 2 dealt the
-// pieces out linearly -- piece i of the patch to thread i % NTHR: a division by the padded width, the column test and three products per
-// piece, ~40 instructions; PMC: ~800 VALU instructions per wave and stage-0 launch, the SIMDs issue-bound.)  cw = Wp * pieces per position
+// A thread keeps ONE column piece (padded column wp, channel group c8) and walks the patch rows: the column test, the channel offset and
+// the LDS column offset are per-thread constants, a piece costs one row-table read and ~10 instructions.  cw = Wp * pieces per position
 // threads share a row, NTHR / cw rows are in flight per trip (the launcher checks cw <= NTHR); the threads beyond run no-op pieces.
+// The single-plane builds (bf16, fp16) keep round 3's fill verbatim (fill_patch16 / xform16: the merged form below cost them 13 registers,
+// i.e. spills on the 128- and 168-register instantiations); fill_patch below is the SAR_X3 form and dispatches.
+template <int MODE>
+__device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const uint4 q3, const Cst8& k) {
+    if constexpr (MODE == 0) return q;
+    float a[8], o[8];
+    unpack8(q, a);
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(a[j], k.sc[j], k.sh[j]), 0.f);
+    } else {
+        float y[8];
+        unpack8(q2, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float z = fmaf(y[j], k.sc[j], k.sh[j]);
+            const float dz = z > 0.f ? a[j] : 0.f;
+            const float xh = (y[j] - k.mu[j]) * k.rs[j];
+            o[j] = k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]);
+        }
+        if constexpr (MODE == 3) {
+            float ad[8];
+            unpack8(q3, ad);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += ad[j];
+        }
+    }
+    return pack8(o);
+}
+
 template <int MODE, int TM, int U, int NTHR, typename MID>
-__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
+__device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, MID&& mid) {
     const unsigned pc = 1u << lg_pc;
@@ -227,7 +238,7 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
     auto finish = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);
+            const uint4 r = xform16<MODE>(q[j], q2[j], q3[j], k);
             *reinterpret_cast<uint4*>(patch + lo[j]) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
             if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
         }
@@ -238,110 +249,99 @@ __device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__
     finish();
     for (unsigned base = U * rpi; base < nrows; base += U * rpi) { issue(base + rsub); finish(); }   // U rows in flight per thread
 }
-#else
 template <int MODE, int TM, int U, int NTHR, typename MID>
-__device__ __forceinline__ void fill_patch(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
-                                           int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
-                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, MID&& mid) {
-    const unsigned pc = 1u << lg_pc, total = (nrows * g.Wp) << lg_pc;
-    const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
-    const unsigned c8 = tid & (pc - 1);                            // NTHR % pc == 0: a thread keeps its channel group
+__device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch, const float* cst, const uint2* rowtab,
+                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, MID&& mid) {
+    if constexpr (!X3) {
+        fill_patch16<MODE, TM, U, NTHR>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, mid);
+        return;
+    }
+    const Geo& g = p.g;
+    const u16* __restrict__ x = p.x; const u16* __restrict__ x2 = p.x2; const u16* __restrict__ x3 = p.x3;
+    u16* __restrict__ side = p.side; u16* __restrict__ side2 = p.side2;
+    const int lg_pc = p.lg_pc, rs = p.rs;
+    const unsigned cw = (unsigned)p.cw, mg_cw = p.mg_cw, xs = p.xs;
+    const unsigned pc = 1u << lg_pc;
+    const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch plane (the launcher allocates it)
+    const unsigned rsub = udiv((unsigned)tid, mg_cw, cw), col = tid - rsub * cw, rpi = udiv((unsigned)NTHR, mg_cw, cw);   // row of the trip, column piece, rows per trip
+    const unsigned wp = col >> lg_pc, c8 = col & (pc - 1);
     const int dm = g.d - 1, ssh = g.s - 1;
-    const bool do_side = side != nullptr && first_ntile;           // block-uniform
+    const int v = (int)wp - g.pl, vs = v >> dm;
+    const bool ok_col = (rsub < rpi) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
+    const unsigned coloff = (unsigned)vs * g.Cin + c8 * 8, own_col = (dm ? 2u * vs : (unsigned)vs >> ssh) - m0, lo_col = wp * rs + c8 * 16;
+    const unsigned rowbytes = g.Wp * rs;
+    const bool do_side = (side != nullptr || (X3 && side2 != nullptr)) && first_ntile;           // block-uniform
     Cst8 k;
-    uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
-    auto issue = [&](unsigned i0) __attribute__((always_inline)) {
+    uint4 qh[U], ql[U], q2h[U], q2l[U], q3h[U], q3l[U]; unsigned off[U], lo[U], own[U];
+    auto issue = [&](unsigned r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const unsigned i = i0 + NTHR * j, pos = i >> lg_pc;
-            const unsigned prow = min(udiv(pos, g.mg_wp, (unsigned)g.Wp), nrows - 1), wp = pos - prow * g.Wp;
-            const uint2 rt = rowtab[prow];
-            const int v = (int)wp - g.pl, vs = v >> dm;
-            const bool ok = (i < total) & (rt.x != NONE) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
-            off[j] = ok ? rt.x + (unsigned)vs * g.Cin + c8 * 8 : NONE;
-            own[j] = rt.y + (dm ? 2u * vs : (unsigned)vs >> ssh) - m0;   // < TM: this block owns the source pixel
-            lo[j] = i < total ? pos * rs + c8 * 16 : dummy;              // branch-free: pieces past the end land in a scratch slot
+            const unsigned prow = r0 + rpi * j, pr = min(prow, nrows - 1);
+            const uint2 rt = rowtab[pr];
+            const bool in = (prow < nrows) & (rsub < rpi), ok = ok_col & (prow < nrows) & (rt.x != NONE);
+            off[j] = ok ? rt.x + coloff : NONE;
+            own[j] = rt.y + own_col;                               // < TM: this block owns the source pixel
+            lo[j] = in ? pr * rowbytes + lo_col : dummy;           // branch-free: pieces past the end land in a scratch slot
             const unsigned o = ok ? off[j] : 0u;
-            q[j] = *reinterpret_cast<const uint4*>(x + o);
-            if constexpr (MODE >= 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
-            if constexpr (MODE == 3) q3[j] = *reinterpret_cast<const uint4*>(x3 + o); else q3[j] = q[j];
+            qh[j] = *reinterpret_cast<const uint4*>(x + o);
+            if constexpr (X3) ql[j] = *reinterpret_cast<const uint4*>(x + xs + o);
+            if constexpr (MODE >= 2) { q2h[j] = *reinterpret_cast<const uint4*>(x2 + o); if constexpr (X3) q2l[j] = *reinterpret_cast<const uint4*>(x2 + xs + o); }
+            if constexpr (MODE == 3) { q3h[j] = *reinterpret_cast<const uint4*>(x3 + o); if constexpr (X3) q3l[j] = *reinterpret_cast<const uint4*>(x3 + xs + o); }
         }
     };
     auto finish = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint4 r = xform<MODE>(q[j], q2[j], q3[j], k);
-            *reinterpret_cast<uint4*>(patch + lo[j]) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
-            if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
+            const bool none = off[j] == NONE;
+            const uint4 z4 = make_uint4(0, 0, 0, 0);
+            const bool sd = do_side && !none && own[j] < (unsigned)TM;
+            {
+                float o[8];
+                uint4 rh, rl = z4;
+                if constexpr (MODE == 0) { rh = qh[j]; rl = ql[j]; if (do_side) pc_values(qh[j], ql[j], o); }      // (planes as they are; values only for the fp16 copy)
+                else {
+                    if constexpr (MODE == 1) xform<MODE>(qh[j], X3 ? ql[j] : z4, z4, z4, z4, z4, k, o);
+                    else if constexpr (MODE == 2) xform<MODE>(qh[j], X3 ? ql[j] : z4, q2h[j], X3 ? q2l[j] : z4, z4, z4, k, o);
+                    else xform<MODE>(qh[j], X3 ? ql[j] : z4, q2h[j], X3 ? q2l[j] : z4, q3h[j], X3 ? q3l[j] : z4, k, o);
+                    if constexpr (X3) split8(o, rh, rl); else rh = pack8(o);
+                }
+                *reinterpret_cast<uint4*>(patch + lo[j]) = none ? make_uint4(0, 0, 0, 0) : rh;
+                if constexpr (X3) *reinterpret_cast<uint4*>(patch + p.lplane + lo[j]) = none ? make_uint4(0, 0, 0, 0) : rl;
+                if (sd) {
+                    if constexpr (X3) {
+                        if (side != nullptr) nt_store16(side + off[j], pack8_half(o, p.side_scale));
+                        if (side2 != nullptr) { nt_store16(side2 + off[j], rh); nt_store16(side2 + xs + off[j], rl); }
+                    } else nt_store16(side + off[j], rh);
+                }
+            }
         }
     };
-    issue(tid);                                                    // trip 0, peeled: `mid` between its loads and their use
+    issue(rsub);                                                   // trip 0, peeled: `mid` between its loads and their use
     mid();
     if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
     finish();
-    for (unsigned base = U * NTHR; base < total; base += U * NTHR) { issue(base + tid); finish(); }   // U pieces in flight per thread
-}
-
-#endif
-
-template <int NKC>
-__device__ __forceinline__ void load_afrags(h16x8 (&a)[NKC], const unsigned char* patch, unsigned addr) {
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) a[kc] = *reinterpret_cast<const h16x8*>(patch + addr + kc * 32);
+    for (unsigned base = U * rpi; base < nrows; base += U * rpi) { issue(base + rsub); finish(); }   // U rows in flight per thread
 }
 
 // WN: waves along the output channels (tile 32*(4/WN) pixels x 32*WN channels); NKC: 16-channel blocks per virtual tap
 // (2, 4, 8); VT: virtual taps = K*K x channel parts of 128 (Cin = 256: two parts per tap, 512: four): 1, 2, 4, 9, 18, 36.
-// Weights: the packed fragment stream of this block's channels is brought into an LDS ring (3 deep; 4 for the 128+-channel
-// layers, whose long k-loops run one block per CU) by LDS-DMA in stages of 8 fragments per channel tile (one barrier per stage),
-// so all four waves share one copy and no VGPR or VALU instruction is spent on the B operand.  A stage is WAITED FOR ONE
-// BARRIER BEFORE IT IS READ.  Waiting right in front of the barrier that releases its readers is not enough: with a wait that
-// usually had to stall (2-deep ring) single waves read stale fragments about once in 300 launches -- one wave's 32 x 32 tile
+// Ring forms (BR = false: up to 64 source channels into 32 output channels, 32 source channels into 64+): the packed fragment stream
+// of this block's channels is brought into an LDS ring (3 deep; 4 where the LDS has room) by LDS-DMA in stages of 8 fragments per
+// channel tile (one barrier per stage), so all waves share one copy and no VGPR or VALU instruction is spent on the B operand.  A stage
+// is WAITED FOR ONE BARRIER BEFORE IT IS READ.  Waiting right in front of the barrier that releases its readers is not enough: with a
+// wait that usually had to stall (2-deep ring) single waves read stale fragments about once in 300 launches -- one wave's 32 x 32 tile
 // wrong, the other waves of the block right (tools/conv16_race.py).  A read-back of the wave's own pieces between vmcnt and the
 // barrier cured it (so a piece that has left the issuing wave's vmcnt is ordered against that wave's LDS reads, not yet against
 // every other wave's), at 5 % of the step; one full stage of margin costs nothing once the ring is a stage deeper.
-// KG = 2 (NKC = 8 only: the 128+-channel layers, whose tiles are one block per CU or fewer): eight waves -- two groups of four that
-// split every virtual tap's eight fragments between them (channels 0-63 / 64-127 of the part) and meet in the output staging tile.
-// Twice the waves per SIMD for the LDS latency of the k-phase, twice the threads for prologue, fill and epilogue.
-// WMX: waves along the pixels (default 4 / WN: four waves per k-group).  WMX = 2 with WN = 1 -- 64-pixel tiles on TWO waves -- is the
-// form of the 32-channel layers since round 3: at B = 64 their 128-pixel tiles were 1 000 blocks for 768 resident slots (1.3 rounds,
-// the second a third full); 2 000 half-size blocks pack the rounds.
-#ifndef SAR_KP_PFB
-#define SAR_KP_PFB 0
-#endif
-#ifndef SAR_KPV
-#define SAR_KPV 0          // phase-removal variants of the k-phase for tools/conv16_timing.py (results wrong by construction): 1 no MFMAs, 2 no
-#endif                     // ring refill, 3 no stage barriers, 4 no B-fragment reads, 5 no A-fragment reads
-constexpr bool PFB = SAR_KP_PFB != 0;
-// Barriers of the epilogue: LDS traffic only.  __syncthreads() also drains vmcnt(0): behind the k-phase that is the round trip of the
-// epilogue operands requested a moment earlier (eight-wave form), behind the output stores their write acknowledgements.
-#ifndef SAR_FILL_ROWS
-#define SAR_FILL_ROWS 1    // patch fill: 1 a thread keeps a column piece and walks the rows (round 3); 0 pieces dealt out linearly (round 2)
-#endif
-#ifndef SAR_CONV_XCD
-#define SAR_CONV_XCD 1     // XCD-aware tile order of conv_bf16_kernel (0: dispatch order)
-#endif
-#ifndef SAR_BN_COOP
-#define SAR_BN_COOP 4      // BatchNorm constants of the fill: 2 whole block, bins requested at entry and summed behind the row table (trunk16.h: bn_issue / bn_finish); 3 finished inside the fill (experiment); 1 whole block, in place (bn_prologue_coop); 0 round 2's one-thread-per-channel walk
-#endif
-#ifndef SAR_BR_PD
-#define SAR_BR_PD 8        // BR form: weight fragments in flight ahead of the MFMA that consumes them
-#endif
-#ifndef SAR_BR_WHEN
-#define SAR_BR_WHEN 0      // BR form: where the first SAR_BR_PD weight fragments are requested: 0 kernel entry, 1 behind the BatchNorm prologue, 2 behind the fill
-#endif
-#ifndef SAR_EPI_SYNC
-#define SAR_EPI_SYNC 0
-#endif
-#if SAR_EPI_SYNC
-#define EPI_BARRIER() __syncthreads()
-#else
-#define EPI_BARRIER() lds_barrier()
-#endif
+// WMX: waves along the pixels (default 4 / WN: four waves).  WMX = 8 with WN = 1 -- 256-pixel tiles on eight waves -- is the form of the
+// 32-channel layers since round 3 where two such blocks fit a CU.
+// SAR_X3: the stream interleaves the hi and the lo fragment of every 16-channel block (fragment 2f, 2f + 1), a ring stage is four such
+// pairs, and a k-step is three MFMAs: lo x hi, hi x lo, hi x hi.
+constexpr int BR_PD = X3 ? 4 : 8;    // BR form: k-steps of weight fragments in flight ahead of the MFMA that consumes them (4-16 measured: +-1 %; SAR_X3: two fragments a step)
 // BR ("B in registers", round 3; the 64+-channel sources with 64+ output channels: stages 1-3): the block is still 64 pixels x 64 channels,
 // but its waves are 2 channel halves x KG k-groups, a wave owns BOTH 32-pixel halves of its 32 channels (two accumulators) on a 1/KG share
 // of every tap's channels (two fragments per virtual tap), and its weight fragments -- which no other wave of the block needs -- come
-// straight from the packed stream into registers as a stream that stays SAR_BR_PD (8) fragments ahead of the MFMA that consumes them: the
+// straight from the packed stream into registers as a stream that stays BR_PD (8) k-steps ahead of the MFMA that consumes them: the
 // first eight requested at kernel entry, one more per k-step (the whole set at entry -- 18 / 36 per wave -- stalled the prologue behind
 // 144 KB per CU on the 64 B/clk L2 port).  No weight ring, no DMA, no barrier inside the k-phase, and HALF the LDS reads per MFMA (an A fragment
 // feeds one MFMA, a B fragment two; round 2's k-phase was bound by LDS reads 2 : 1 -- 2 KB per MFMA -- and by a barrier per 8 fragments).
@@ -349,15 +349,15 @@ constexpr bool PFB = SAR_KP_PFB != 0;
 // lin / ntot / nty: this block's linear index among the ntot blocks of ITS convolution, of which nty are channel tiles per pixel tile)
 template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
 __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, const unsigned ntot, const unsigned nty) {
-    static_assert(BR || KG == 1 || (KG == 2 && NKC == 8), "two k-groups split the eight fragments of a 128-channel tap");
-    static_assert(!BR || (WN == 2 && (WMX == 2 || WMX == 1) && NKC / KG == 2), "BR: 64 (or 32: WMX = 1, the 512-channel sources whose 64-pixel patch does not fit the LDS) x 64 tiles, two fragments per virtual tap and wave");
+    static_assert(BR || KG == 1, "k-groups exist in the BR form only");
+    static_assert(!BR || (WN == 2 && (WMX == 2 || WMX == 1) && NKC / KG == 2), "BR: 64 (or 32: WMX = 1, the sources whose 64-pixel patch does not fit the LDS) x 64 tiles, two fragments per virtual tap and wave");
     constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
     constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
     static_assert(BR || (WN * 8) % NW == 0, "stage DMA must divide evenly");
     static_assert(NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "epilogue maps must divide evenly");
     constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
-    constexpr int F = VT * NKC, NST = (F + 7) / 8;                 // weight fragments per channel tile, ring stages
+    constexpr int F = VT * NKC * NPL, NST = (F + 7) / 8;           // weight fragments per channel tile (SAR_X3: hi, lo interleaved), ring stages
     constexpr int SJ = WN * 8, PW = SJ / NW;                       // DMA wave-instructions per stage: block / per wave
     const int RD = p.rd;                                           // ring depth, 3 or 4 (launcher: 4 where the LDS has room for it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -372,7 +372,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // dispatch order the channel tiles of one pixel tile -- which fill the SAME patch -- and neighbouring pixel tiles -- which share halo
     // rows -- sat on different L2s, and each fetched those rows from the fabric again (PMC: 17.4 MB per stage-2 launch for 4.4 MB of
     // tensors).  Here XCD c takes the c-th contiguous eighth of the sequence (channel tile fastest, then pixel tile).
-    const unsigned chunk8 = ntot >> 3, tord = SAR_CONV_XCD && lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
+    const unsigned chunk8 = ntot >> 3, tord = lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
     const unsigned bx = tord >> __builtin_ctz(nty), by = tord & (nty - 1);   // Cout / TN: a power of two
     const unsigned m0 = bx * TM;
     const int n0 = by * TN;
@@ -394,14 +394,17 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // 32-channel layers' LDS at 40 KB, i.e. a 2-deep weight ring: see the ring comment; with the 3-deep ring they fit three per CU
     // and the variant was slower, 23 vs 17 us per stage-0 launch)
     constexpr bool EARLY = NG != 8;                                 // (the eight-wave form lives on 128 registers: operands loaded behind the k-phase)
-    unsigned rv[RPT], yv[RPT];
+    unsigned rv[RPT][NPL], yv[RPT][NPL];
     auto load_epi = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const unsigned m = min(m0 + rg + RG * i, M - 1);
             const size_t o = (size_t)m * p.Cout + c;
-            rv[i] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
-            yv[i] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                rv[i][pl] = p.res ? *reinterpret_cast<const unsigned*>(p.res + (size_t)pl * p.ys + o) : 0u;
+                yv[i][pl] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + (size_t)pl * p.ys + o) : 0u;
+            }
         }
     };
     if constexpr (EARLY) load_epi();
@@ -416,27 +419,28 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)((slot * SJ + j) * 1024));
         }
     };
-    constexpr int NF = BR ? VT * KPF : 1, NF0 = NF < SAR_BR_PD ? NF : SAR_BR_PD; // BR: this wave's k-steps (= weight fragments); those requested ahead of the k-phase
-    h16x8 breg[NF];
-    const h16x8* wmine = p.wpk + ((size_t)(by * WN + wn) * p.Fs + kg * KPF) * 64 + lane;
-    auto load_b0 = [&]() __attribute__((always_inline)) {
+    constexpr int NF = BR ? VT * KPF : 1, NF0 = NF < BR_PD ? NF : BR_PD; // BR: this wave's k-steps; those whose weight fragments are requested ahead of the k-phase
+    h16x8 breg[NF][NPL];
+    const h16x8* wmine = p.wpk + ((size_t)(by * WN + wn) * p.Fs + kg * KPF * NPL) * 64 + lane;
+    auto load_b = [&](int i) __attribute__((always_inline)) {      // k-step i: fragment (i / KPF) * NKC + i % KPF of this group's share, every plane
 #pragma unroll
-        for (int i = 0; i < NF0; ++i) breg[i] = wmine[((i / KPF) * NKC + (i % KPF)) * 64];
+        for (int pl = 0; pl < NPL; ++pl) breg[i][pl] = wmine[(((i / KPF) * NKC + (i % KPF)) * NPL + pl) * 64];
     };
     if constexpr (BR) {
-        if (SAR_BR_WHEN == 0) load_b0();
+#pragma unroll
+        for (int i = 0; i < NF0; ++i) load_b(i);
     } else {
         issue_stage(0, 0);
         if (NST > 1) issue_stage(1, 1);
         if (RD > 3 && NST > 2) issue_stage(2, 2);
-        if (KG == 2 && PFB && NST > 3) issue_stage(3, 3);          // B fragments read one stage ahead (k-phase below)
     }
     TSTAMP(12);
-#if SAR_BN_COOP >= 2
+    // BatchNorm constants of the fill by the WHOLE block (trunk16.h): the bins are requested here, in front of the row table, and summed
+    // behind it (ring forms) or inside the fill, behind the issue of its first pieces' loads (BR forms: 256 registers to hold them in; on
+    // the 128- / 168-register forms the pieces held across it spill)
     BnRaw braw;
     constexpr int CIN = NKC < 8 ? 16 * NKC : 128 * NH;             // source channels of this instantiation (the launcher's table)
     if (p.fill) bn_issue<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, braw);
-#endif
 
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
@@ -454,12 +458,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         rowtab[tid] = rt;
     }
     TSTAMP(13);
-#if SAR_BN_COOP >= 2
-    // The bins were requested in front of the row table: their round trip ran underneath it.  MIDFILL (EXPERIMENT, SAR_BN_COOP=3): the
-    // constants finished INSIDE the fill, behind the issue of its first pieces' loads, so that the partial sums, their two barriers and the
-    // pieces' round trip overlap as well.  Measured on the BR forms (256 registers to live in): no gain -- stage-2 block 18.9k -> 19.4k
-    // cycles, class 234 -> 236 us; on the 128- / 168-register forms the pieces held across it spill 75-90 registers.
-    constexpr bool MIDFILL = SAR_BN_COOP == 3 || (SAR_BN_COOP == 4 && BR);
+    constexpr bool MIDFILL = BR;
     if constexpr (!MIDFILL) {
         if (p.fill) bn_finish<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, cst, g.Cin, bx == 0 && by == 0, braw, reinterpret_cast<double*>(patch));
     }
@@ -477,62 +476,38 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             TSTAMP(2);
         }
     };
-#else
-#if SAR_BN_COOP
-    if (p.fill) bn_prologue_coop<NTHR>(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, cst, g.Cin, bx == 0 && by == 0, reinterpret_cast<double*>(patch));
-#else
-    if (p.fill) bn_prologue(p.fb, p.fill >= 2 ? 2 : 1, g.Cin, 0, g.Cin, cst, g.Cin, bx == 0 && by == 0, NTHR);
-#endif
-    if constexpr (BR) { if (SAR_BR_WHEN == 1) load_b0(); }
-    TSTAMP(14);
-    // raw barrier: hipcc's __syncthreads() would drain vmcnt(0) here, i.e. wait for the epilogue operands requested above
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wg_barrier();
-    TSTAMP(2);
-    auto mid = [&]() __attribute__((always_inline)) {};
-#endif
 
     // (Issuing the patch loads in front of the BatchNorm prologue -- row table, barrier, loads, prologue, barrier, transform + store --
     // was built and measured: no gain.  What the fill costs is its address arithmetic, ~1 400 cycles before the first load leaves,
     // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
     constexpr int FU = NG == 8 ? 2 : 4;                            // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers)
     // ---- fill: the padded patch, all input channels, transformed once
-    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);
-    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);
-    else if (p.fill == 2) fill_patch<2, TM, FU, NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);
-    else fill_patch<3, TM, (FU < 2 ? FU : 2), NTHR>(g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, by == 0, (unsigned)p.cw, p.mg_cw, mid);   // three tensors: two pieces in flight
+    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    else if (p.fill == 2) fill_patch<2, TM, (X3 && FU > 2 ? 2 : FU), NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
     // ---- per-lane A address
-    unsigned a_lane;
-    {
+    auto a_addr = [&](unsigned pix0) __attribute__((always_inline)) {
         unsigned Rp, wq;
-        pix_rp(g, min(m0 + wm * 32 + (lane & 31), M - 1), Rp, wq);
+        pix_rp(g, min(pix0 + (lane & 31), M - 1), Rp, wq);
         unsigned prow = Rp - Rp_lo;
         if (prow + g.K > nrows) prow = 0;                          // only with the clamp above
-        a_lane = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16 + kg * (KPF * 32);   // + the group's channel half of every tap
-    }
+        return (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16 + kg * (KPF * 32);   // + the group's channel half of every tap
+    };
+    const unsigned a_lane = a_addr(m0 + wm * 32);
     TSTAMP(3);
 
-    // ---- k-phase, straight-line.  Per stage: wait for its fragments, barrier (also: every wave is done with the ring slot
-    // refilled next; on stage 0: the patch is complete), start the DMA of stage + 2, read the stage's 8 B fragments, then 8
-    // MFMAs; the A fragments of the NEXT virtual tap are read from the patch while the current tap's MFMAs issue.
-    // two accumulators (even / odd fragments): an instruction between two MFMAs on the SAME accumulator costs ~43 cycles, on
-    // different ones ~6 (MI355X_MICROARCH.md, per-instruction constants) -- and every MFMA here has LDS reads next to it
+    // ---- k-phase, straight-line.
+    // two accumulators: an instruction between two MFMAs on the SAME accumulator costs ~43 cycles, on different ones ~6
+    // (MI355X_MICROARCH.md, per-instruction constants) -- and every MFMA here has LDS reads next to it
     f32x16 acc, acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
-    h16x8 afr[2][KPF], bfr[BR ? 1 : 8 / KG];
-    const unsigned char* bmine = bring + (wn * 8 + kg * KPF) * 1024 + lane * 16;
     if constexpr (BR) {
-        // acc: pixels 0-31 of the tile, acc2: pixels 32-63; both on this wave's 32 channels and its share of every tap's channels
+        // acc: pixels 0-31 of the tile, acc2: pixels 32-63 (WMX = 2); both on this wave's 32 channels and its share of every tap's channels.
+        // WMX = 1 (32-pixel tiles): acc2 takes the small terms of SAR_X3 (and nothing otherwise).
         unsigned a_hi = 0;
-        if constexpr (WMX == 2) {
-            unsigned Rp, wq;
-            pix_rp(g, min(m0 + 32 + (lane & 31), M - 1), Rp, wq);
-            unsigned prow = Rp - Rp_lo;
-            if (prow + g.K > nrows) prow = 0;
-            a_hi = (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16 + kg * (KPF * 32);
-        }
-        if (SAR_BR_WHEN == 2) load_b0();
+        if constexpr (WMX == 2) a_hi = a_addr(m0 + 32);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's patch stores
         wg_barrier();
         TSTAMP(4);
@@ -540,103 +515,94 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             const int v = i / KPF, j = i % KPF, tap = v / NH, hh = v % NH, dy = tap / KS, dx = tap % KS;
             return (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32) + j * 32);
         };
-        h16x8 a0[2], a1[2];
-        a0[0] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(0));
-        if constexpr (WMX == 2) a1[0] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(0));
+        h16x8 a0[2][NPL], a1[2][NPL];
+        auto lda = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                a0[i & 1][pl] = *reinterpret_cast<const h16x8*>(patch + pl * p.lplane + a_lane + a_off(i));
+                if constexpr (WMX == 2) a1[i & 1][pl] = *reinterpret_cast<const h16x8*>(patch + pl * p.lplane + a_hi + a_off(i));
+            }
+        };
+        lda(0);
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             if (i == NF / 2) TSTAMP(8);
-            if (i + NF0 < NF) breg[i + NF0] = wmine[(((i + NF0) / KPF) * NKC + ((i + NF0) % KPF)) * 64];   // the stream stays NF0 fragments ahead
-            if (i + 1 < NF) {
-                a0[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_lane + a_off(i + 1));
-                if constexpr (WMX == 2) a1[(i + 1) & 1] = *reinterpret_cast<const h16x8*>(patch + a_hi + a_off(i + 1));
+            if (i + NF0 < NF) load_b(i + NF0);                     // the stream stays NF0 k-steps ahead
+            if (i + 1 < NF) lda(i + 1);
+            if constexpr (!X3) {
+                acc = MFMA16(a0[i & 1][0], breg[i][0], acc, 0, 0, 0);
+                if constexpr (WMX == 2) acc2 = MFMA16(a1[i & 1][0], breg[i][0], acc2, 0, 0, 0);
+            } else if constexpr (WMX == 2) {                       // small terms first; the two accumulators alternate
+                acc = MFMA16(a0[i & 1][NPL - 1], breg[i][0], acc, 0, 0, 0);
+                acc2 = MFMA16(a1[i & 1][NPL - 1], breg[i][0], acc2, 0, 0, 0);
+                acc = MFMA16(a0[i & 1][0], breg[i][NPL - 1], acc, 0, 0, 0);
+                acc2 = MFMA16(a1[i & 1][0], breg[i][NPL - 1], acc2, 0, 0, 0);
+                acc = MFMA16(a0[i & 1][0], breg[i][0], acc, 0, 0, 0);
+                acc2 = MFMA16(a1[i & 1][0], breg[i][0], acc2, 0, 0, 0);
+            } else {
+                acc2 = MFMA16(a0[i & 1][NPL - 1], breg[i][0], acc2, 0, 0, 0);
+                acc = MFMA16(a0[i & 1][0], breg[i][0], acc, 0, 0, 0);
+                acc2 = MFMA16(a0[i & 1][0], breg[i][NPL - 1], acc2, 0, 0, 0);
             }
-            acc = MFMA16(a0[i & 1], breg[i], acc, 0, 0, 0);
-            if constexpr (WMX == 2) acc2 = MFMA16(a1[i & 1], breg[i], acc2, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);                     // (the scheduler otherwise sinks the stream's loads to their uses: distance 1-2 instead of NF0)
         }
-    } else if constexpr (KG == 2 && PFB) {
-        // (EXPERIMENT, off: -DSAR_KP_PFB=1.  Measured SLOWER: k-phase of the stage-2 block 6 370 -> 6 780 cycles.)  Two k-groups (the 128+-channel layers; a stage = one virtual tap = four fragments per wave; RD = 4, the launcher sees to it).
-        // Round 2 read a stage's B fragments right behind the stage's barrier and multiplied at once: ~200 cycles of LDS latency in
-        // front of the MFMAs of EVERY stage, 9 (stage 2) or 18 (stage 3) times per block.  Here the fragments of stage st+1 are read
-        // at boundary st, behind the issue of the MFMAs' predecessors, into the other register set.  The ring runs one stage further
-        // ahead to keep the landed-one-barrier-before-read margin: at boundary st stage st+2 has landed, st+3 is in flight, st+4 is
-        // issued into the slot of stage st (whose fragments every wave read at boundary st-1, completed by the lgkmcnt(0) below).
-        h16x8 bpf[2][KPF];
+    } else {
+        // Per stage: wait for its fragments, barrier (also: every wave is done with the ring slot refilled next; on stage 0: the patch is
+        // complete), start the DMA of stage + 2, read the stage's 8 B fragments, then its MFMAs; the A fragments of the NEXT virtual tap
+        // are read from the patch while the current tap's MFMAs issue.
+        h16x8 afr[2][NKC][NPL], bfr[8];
+        const unsigned char* bmine = bring + (wn * 8) * 1024 + lane * 16;
+        auto load_afrags = [&](int s, unsigned addr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) afr[s][kc][pl] = *reinterpret_cast<const h16x8*>(patch + pl * p.lplane + addr + kc * 32);
+        };
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
-            const int st = v;
-            if (st + 2 < NST) { if (st + 3 < NST) wait_vm<PW>(); else wait_vm<0>(); }
-            else if (st == 0) wait_vm<0>();                        // one or two stages in all: everything has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // own patch stores (st 0); own reads of the slot refilled below
-            wg_barrier();
-            if (st == 0) {
-                TSTAMP(4);
-                load_afrags<KPF>(afr[0], patch, a_lane);
 #pragma unroll
-                for (int i = 0; i < KPF; ++i) bpf[0][i] = *reinterpret_cast<const h16x8*>(bmine + i * 1024);
-            }
-            if (st == NST / 2) TSTAMP(8);
-            if (st + 4 < NST) issue_stage(st + 4, st & 3);
-            if (st + 1 < NST) {
-#pragma unroll
-                for (int i = 0; i < KPF; ++i) bpf[(st + 1) & 1][i] = *reinterpret_cast<const h16x8*>(bmine + (((st + 1) & 3) * SJ + i) * 1024);
-            }
-            if (v + 1 < VT) {
-                const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
-                load_afrags<KPF>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
-            }
-#pragma unroll
-            for (int kc = 0; kc < KPF; ++kc) {
-                if (kc & 1) acc2 = MFMA16(afr[v & 1][kc], bpf[st & 1][kc], acc2, 0, 0, 0);
-                else acc = MFMA16(afr[v & 1][kc], bpf[st & 1][kc], acc, 0, 0, 0);
-            }
-        }
-    } else {
-#pragma unroll
-    for (int v = 0; v < VT; ++v) {
-#pragma unroll
-        for (int kc = 0; kc < KPF; ++kc) {
-            const int f = v * NKC + kc;                            // group 0's fragment; the wave's own is f + kg * KPF
-            if (f % 8 == 0) {
-                const int st = f / 8;
-                // stages <= st+1 have landed -- stage st one whole stage and a barrier ago (see above); RD = 4: stage st+2 in flight
-                if (RD == 4 && st + 2 < NST) wait_vm<PW>(); else wait_vm<0>();      // (kernel-uniform branch)
-                // stage 0: this wave's patch stores must have completed before the others read them (gfx950 inserts no
-                // implicit wait in front of a bare s_barrier)
-                if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (SAR_KPV != 3 || st == 0) wg_barrier();
-                if (st == 0) { TSTAMP(4); load_afrags<KPF>(afr[0], patch, a_lane); }
-                if (st == NST / 2) TSTAMP(8);
-                if (SAR_KPV != 2) {
+            for (int kc = 0; kc < NKC; ++kc) {
+                const int f = (v * NKC + kc) * NPL;                // first fragment of this k-step in the stream
+                if (f % 8 == 0) {
+                    const int st = f / 8;
+                    // stages <= st+1 have landed -- stage st one whole stage and a barrier ago (see above); RD = 4: stage st+2 in flight
+                    if (RD == 4 && st + 2 < NST) wait_vm<PW>(); else wait_vm<0>();      // (kernel-uniform branch)
+                    // stage 0: this wave's patch stores must have completed before the others read them (gfx950 inserts no
+                    // implicit wait in front of a bare s_barrier)
+                    if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wg_barrier();
+                    if (st == 0) { TSTAMP(4); load_afrags(0, a_lane); }
+                    if (st == NST / 2) TSTAMP(8);
                     if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
                     else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
-                }
-                const int slot = RD == 4 ? (st & 3) : (st % 3);
-                if (SAR_KPV != 4 || st == 0) {
+                    const int slot = RD == 4 ? (st & 3) : (st % 3);
 #pragma unroll
-                    for (int i = 0; i < 8 / KG; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
+                    for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
+                }
+                if (kc == 0 && v + 1 < VT) {
+                    const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
+                    load_afrags((v + 1) & 1, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
+                }
+                if constexpr (!X3) {
+                    if (f & 1) acc2 = MFMA16(afr[v & 1][kc][0], bfr[f % 8], acc2, 0, 0, 0);
+                    else acc = MFMA16(afr[v & 1][kc][0], bfr[f % 8], acc, 0, 0, 0);
+                } else {
+                    acc2 = MFMA16(afr[v & 1][kc][NPL - 1], bfr[f % 8], acc2, 0, 0, 0);
+                    acc = MFMA16(afr[v & 1][kc][0], bfr[f % 8], acc, 0, 0, 0);
+                    acc2 = MFMA16(afr[v & 1][kc][0], bfr[(f + NPL - 1) % 8], acc2, 0, 0, 0);
                 }
             }
-            if (kc == 0 && v + 1 < VT && SAR_KPV != 5) {
-                const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
-                load_afrags<KPF>(afr[(v + 1) & 1], patch, a_lane + (unsigned)((dy * g.Wp + dx) * p.rs + hh * (NKC * 32)));
-            }
-            if (SAR_KPV == 1) { if (f == 0) acc = MFMA16(afr[0][0], bfr[0], acc, 0, 0, 0); continue; }
-            if (f & 1) acc2 = MFMA16(afr[v & 1][kc], bfr[f % 8], acc2, 0, 0, 0);
-            else acc = MFMA16(afr[v & 1][kc], bfr[f % 8], acc, 0, 0, 0);
         }
     }
-    }
-    if constexpr (!BR) {
+    if constexpr (!(BR && WMX == 2)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     }
     TSTAMP(5);
     if constexpr (!EARLY) load_epi();
-    EPI_BARRIER();                                               // the patch is dead: reuse it as the output staging tile
+    lds_barrier();                                                 // the patch is dead: reuse it as the output staging tile
 
-    // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), bf16 stores, statistics
+    // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), 2-byte stores, statistics
     float* ot = reinterpret_cast<float*>(patch) + kg * (TM * TN);  // [KG][TM][TN]: each k-group stages its partial tile
     float* part = reinterpret_cast<float*>(patch) + KG * TM * TN;  // [RG][TN][2]
     {
@@ -644,11 +610,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (SAR_EPV != 2 || r == 0) ot[row * TN + col] = acc[r];
-            if constexpr (BR && WMX == 2) { if (SAR_EPV != 2 || r == 0) ot[(row + 32) * TN + col] = acc2[r]; }
+            ot[row * TN + col] = acc[r];
+            if constexpr (BR && WMX == 2) ot[(row + 32) * TN + col] = acc2[r];
         }
     }
-    EPI_BARRIER();
+    lds_barrier();
     float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
     long long q10 = 0, q11 = 0, q20 = 0, q21 = 0;                  // epi 3: the same sums in 64-bit fixed point (trunk16.h: fix28)
 #pragma unroll
@@ -661,56 +627,66 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + kk * (TM * TN) + row * TN + 2 * cp);
             a.x += a2.x; a.y += a2.y;
         }
-        float v0 = a.x + b0 + h_lo(rv[i]), v1 = a.y + b1 + h_hi(rv[i]);
-        const unsigned pk = pack2(v0, v1);
+        float v0 = a.x + b0 + h_lo(rv[i][0]), v1 = a.y + b1 + h_hi(rv[i][0]);
+        if constexpr (X3) { v0 += h_lo(rv[i][NPL - 1]); v1 += h_hi(rv[i][NPL - 1]); }
+        unsigned pk, pkl = 0u;
+        if constexpr (X3) split2(v0, v1, pk, pkl); else pk = pack2(v0, v1);
         if (m < M) {
-            if (SAR_EPV != 1) __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
+            __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
+            if constexpr (X3) __builtin_nontemporal_store(pkl, reinterpret_cast<unsigned*>(p.y + (size_t)p.ys + (size_t)m * p.Cout + c));
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
             // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
-            if (p.epi == 1) { v0 = h_lo(pk); v1 = h_hi(pk); s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
-            if (p.epi == 3) {
+            if (p.epi == 1 || p.epi == 3) {
                 v0 = h_lo(pk); v1 = h_hi(pk);
-                q10 += fix28(v0); q11 += fix28(v1); q20 += fix28(fminf(v0 * v0, 8.0e6f)); q21 += fix28(fminf(v1 * v1, 8.0e6f));
+                if constexpr (X3) { v0 += h_lo(pkl); v1 += h_hi(pkl); }
+                if (p.epi == 1) { s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
+                else { q10 += fix28(v0); q11 += fix28(v1); q20 += fix28(fminf(v0 * v0, 8.0e6f)); q21 += fix28(fminf(v1 * v1, 8.0e6f)); }
             }
             if (p.epi == 2) {
-                const float y0 = h_lo(yv[i]), y1 = h_hi(yv[i]);
+                float y0 = h_lo(yv[i][0]), y1 = h_hi(yv[i][0]);
+                if constexpr (X3) { y0 += h_lo(yv[i][NPL - 1]); y1 += h_hi(yv[i][NPL - 1]); }
                 const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
                 s10 += d0; s11 += d1; s20 += d0 * (y0 - mu0) * rs0; s21 += d1 * (y1 - mu1) * rs1;
             }
         }
     }
     TSTAMP(6);
-    if (p.epi == 0 || SAR_EPV == 3) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
+    if (p.epi == 0) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
     if (p.epi == 3) {                                              // integer partials, integer atomics: order-independent
         long long* partq = reinterpret_cast<long long*>(part);
         partq[(rg * TN + 2 * cp) * 2 + 0] = q10; partq[(rg * TN + 2 * cp) * 2 + 1] = q20;
         partq[(rg * TN + 2 * cp + 1) * 2 + 0] = q11; partq[(rg * TN + 2 * cp + 1) * 2 + 1] = q21;
-        EPI_BARRIER();
+        lds_barrier();
         if (tid < 2 * TN) {
             const int cc = tid >> 1, which = tid & 1;
             long long s = 0;
 #pragma unroll
             for (int r = 0; r < RG; ++r) s += partq[(r * TN + cc) * 2 + which];
-            stat_add(reinterpret_cast<unsigned long long*>(p.e_bins) + (stat_bin(bx) * 2 + which) * p.Cout + n0 + cc, (unsigned long long)s);
+            atomicAdd(reinterpret_cast<unsigned long long*>(p.e_bins) + ((bx % NB) * 2 + which) * p.Cout + n0 + cc, (unsigned long long)s);
         }
         TSTAMP(7); TSTAMP(15);
         return;
     }
     part[(rg * TN + 2 * cp) * 2 + 0] = s10; part[(rg * TN + 2 * cp) * 2 + 1] = s20;
     part[(rg * TN + 2 * cp + 1) * 2 + 0] = s11; part[(rg * TN + 2 * cp + 1) * 2 + 1] = s21;
-    EPI_BARRIER();
+    lds_barrier();
     if (tid < 2 * TN) {
         const int cc = tid >> 1, which = tid & 1;
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < RG; ++r) s += part[(r * TN + cc) * 2 + which];
-        stat_add(p.e_bins + (stat_bin(bx) * 2 + which) * p.Cout + n0 + cc, s);
+        atomicAdd(p.e_bins + ((bx % NB) * 2 + which) * p.Cout + n0 + cc, s);
     }
     TSTAMP(7); TSTAMP(15);
 }
 
+// waves per SIMD the register budget is set for.  BR: 1 (KG = 4: 512 threads, one block per CU) or 2; ring forms: 3 (two waves), 4 (eight
+// waves: 128 registers, two blocks per CU), 2 otherwise.  SAR_X3 doubles the fragments a wave holds and its LDS admits one eight-wave block
+// (or two four-wave blocks) per CU anyway: 2 for every ring form.
+#define CONV_OCC (BR ? (KG == 4 ? 1 : 2) : X3 ? 2 : (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2))
+
 template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
-__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1) void conv_bf16_kernel(const ConvP p) {
+__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv_bf16_kernel(const ConvP p) {
     conv_body<WN, NKC, VT, KG, WMX, BR>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, gridDim.y);
 }
 
@@ -720,7 +696,7 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 :
 // 3x3 launches of the stages they sit in front of leave CUs idle.  Blocks [0, na) run the first convolution, the rest the second (1x1:
 // same WN / NKC / KG / WMX / BR, VT = channel parts of ONE tap); LDS and registers are the larger of the two.
 template <int WN, int NKC, int VT, int KG, int WMX, bool BR>
-__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, BR ? (KG == 4 ? 1 : 2) : KG == 1 ? (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2) : 1)
+__global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC)
 void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, const unsigned ntya, const unsigned nb, const unsigned ntyb) {
     const unsigned na8 = (na + 7u) & ~7u;                             // the second convolution starts on XCD 0 as well (its XCD-aware tile order)
     if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR>(pa, blockIdx.x, na, ntya);
@@ -728,6 +704,7 @@ void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, co
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
+#if !SAR_X3   // (the SAR_X3 mode runs the fp16 build's weight-gradient kernels on fp16 operands: trunk16.h)
 // dw[tap][ci][co] += sum over pixels of A[pixel + tap][ci] * dY[pixel][co] on PLAIN bf16 operands: A = the activated tensor the
 // forward conv's fill wrote back (ConvP::side; the raw tensor for shortcuts / the first conv), dY = the gradient tensor (for
 // conv1 of a block: the BatchNorm-backward the input-gradient conv's fill wrote back).  Both arrive by LDS-DMA in 64-pixel
@@ -878,15 +855,12 @@ struct Wg3Args { const unsigned char* convs; const WgItem* items; const uint4* z
 // whole tile).  Nine waves sit 3-2-2-2 on the four SIMDs, so a chunk's 144 MFMAs cost 1 536 cycles on the fullest SIMD and the other
 // six waves wait for it at the chunk's barrier; twelve sit 3-3-3-3 (1 152 cycles), and the DMA issue of a chunk is dealt to twelve.
 // Per wave and 16-pixel step: three A fragments (one activation plane at three consecutive positions) and ONE gradient fragment.
-// NL > 0 (experiment, SAR_WG_LOADERS=1; NOT the default): NL extra LOADER waves issue all of the block's LDS-DMA and keep the pixel ->
-// position table, the NWV compute waves only read LDS and multiply.  Measured SLOWER (64-wide launch 125 -> 141 us, 32-wide 52 -> 63):
-// with the issue off their hands the compute waves wait 3 300-3 900 cycles per chunk for the loaders' data instead of 1 400 -- what a
-// chunk waits for is the ARRIVAL of ~17 KB of 64 / 128-byte pieces per CU (the launch moves ~400 MB at ~1.5 TB/s with three chunks
-// in flight per block: latency x bytes in flight, not instruction issue and not the MFMAs, 1 152 of ~3 700 cycles per chunk).
-template <int TCI, int TCO, bool W12 = false, int NL = 0>
-__global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kernel(const Wg3Args a) {
+// (Negative: extra LOADER waves that issue all of the block's LDS-DMA while the compute waves only read LDS and multiply -- 64-wide launch
+// 125 -> 141 us: what a chunk waits for is the ARRIVAL of ~17 KB of 64 / 128-byte pieces per CU, not instruction issue.)
+template <int TCI, int TCO, bool W12 = false>
+__global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3Args a) {
     static_assert(!W12 || (TCI == 2 && TCO == 2), "twelve waves: three tap rows x the four sub-tiles of a 64 x 64 tile");
-    constexpr int NWV = W12 ? 12 : 9, NTHR = (NWV + NL) * 64;
+    constexpr int NWV = W12 ? 12 : 9, NTHR = NWV * 64;
     constexpr int NA = W12 ? 3 : TCI, NBF = W12 ? 1 : TCO, NJ = W12 ? 3 : TCI * TCO;   // A / B fragments per step, MFMAs per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const WgItem it = a.items[blockIdx.x];
@@ -900,7 +874,6 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
     const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M, NP = a.np, mask = a.np - 1;
     const int c_first = it.c_first, nmine = it.c_count, nbuf = a.nbuf;
-    const bool loader = NL > 0 && w >= NWV;                                        // wave-uniform
     unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [2][64]: absolute patch position of every pixel
     unsigned* soff = qring + 128;                                                  // [tab_pos]: source element offset of every position of this item (NONE: zero)
     unsigned char* dyr = smem + 512 + (size_t)a.tab_pos * 4;                       // [nbuf][TCO][64 px][64 B]
@@ -909,7 +882,7 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
     constexpr int MAXNI = 4;
 
     auto tables = [&](int lc) __attribute__((always_inline)) {
-        if (NL > 0 ? w == NWV : tid < 64) {                                        // the first loader wave, or wave 0
+        if (tid < 64) {
             const unsigned mc0 = (unsigned)(c_first + lc) * 64;
             unsigned Rp, wq;
             pix_rp(g, min(mc0 + lane, M - 1), Rp, wq);                             // past the batch: the last pixel's position; its dY row is zero
@@ -948,7 +921,7 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
         const unsigned Gh = ((Rpl + g.K) * g.Wp + 15) >> 4;                        // every position in front of (last row + K) * Wp
         const int npg = Gh > Gn ? (int)(Gh - Gn) : 0;
         const int total = 4 * TCO + npg * TCI;
-        const int NI = NL > 0 ? (loader ? (total - (w - NWV) + NL - 1) / NL : 0) : (total + NWV - 1) / NWV;
+        const int NI = (total + NWV - 1) / NWV;
         const unsigned dyslot = dyr0 + (unsigned)(lc % nbuf) * (TCO * 4096);
         // (Computing the addresses of a batch first and issuing its DMA instructions back to back -- dma16's memory clobber keeps the
         // next instruction's table read behind it -- was measured: 125 -> 134 us for the 64-wide launch.  Issue order is not the limit.)
@@ -966,24 +939,13 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
                 dst = pr0a + (unsigned)pl * (NP * 64) + ((gi * 16) & mask) * 64;
             }
         };
-        if constexpr (NL > 0) {                                                    // loader waves: their share of the chunk, four at a time
-            for (int i0 = 0; i0 < NI; i0 += 4) {
-                const void* src[4]; unsigned dst[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) addr(min((w - NWV) + NL * (i0 + u), total - 1), src[u], dst[u]);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u < NI) dma16(src[u], dst[u]);
+        for (int i = 0; i < MAXNI; ++i)                                            // every wave issues, at most MAXNI each
+            if (i < NI) {
+                const void* src; unsigned dst;
+                addr(min(w + NWV * i, total - 1), src, dst);
+                dma16(src, dst);
             }
-        } else {                                                                   // every wave issues, at most MAXNI each
-#pragma unroll
-            for (int i = 0; i < MAXNI; ++i)
-                if (i < NI) {
-                    const void* src; unsigned dst;
-                    addr(min(w + NWV * i, total - 1), src, dst);
-                    dma16(src, dst);
-                }
-        }
         if (Gh > Gn) Gn = Gh;
         return NI;
     };
@@ -1029,7 +991,6 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
         TACC(t_issue, if (lc + LA < nmine) qn = issue(lc + LA));   // dY slot of chunk lc+LA-nbuf <= lc-1; ring positions behind chunk lc
         if (LA == 3) q3 = qn; else if (LA == 2) q2 = qn; else q1 = qn;
         if (lc + 1 < nmine) tables(lc + 1);
-        if (loader) { q1 = q2; q2 = q3; q3 = 0; continue; }                        // (wave-uniform) loader waves: back to the next chunk's wait
         const unsigned* qtab = qring + (lc & 1) * 64;
         const unsigned char* dyt = dyr + (size_t)(lc % nbuf) * (TCO * 4096);
         h16x8 A[2][NA], Bm[2][NBF];
@@ -1075,7 +1036,7 @@ __global__ __launch_bounds__((W12 ? 768 : 576) + 64 * NL) void wgrad3_bf16_kerne
     }
 #endif
     // ---- flush
-    if (!loader) {
+    {
         const int col = lane & 31;
 #pragma unroll
         for (int k = 0; k < NJ; ++k) {
@@ -1165,11 +1126,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedPlans 
     else wgrad_reduce_body<false>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
 }
 
+#endif  // !SAR_X3
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
+// eight consecutive values of a 2-byte tensor at element e (SAR_X3: hi + lo plane, `ps` elements apart)
+__device__ __forceinline__ void load8(const u16* __restrict__ t, long e, long ps, float (&f)[8]) {
+    if constexpr (X3) join8(*reinterpret_cast<const uint4*>(t + e), *reinterpret_cast<const uint4*>(t + ps + e), f);
+    else unpack8(*reinterpret_cast<const uint4*>(t + e), f);
+}
+__device__ __forceinline__ void store8(u16* __restrict__ t, long e, long ps, const float (&f)[8]) {
+    if constexpr (X3) { uint4 h, l; split8(f, h, l); *reinterpret_cast<uint4*>(t + e) = h; *reinterpret_cast<uint4*>(t + ps + e) = l; }
+    else *reinterpret_cast<uint4*>(t + e) = pack8(f);
+}
 // Residual-stream gradient: out = BN(+ReLU) backward of `dact` through the BatchNorm whose input was x (+ add).
 template <typename DT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const DT* __restrict__ dact, const u16* __restrict__ x, const BnP bn,
-                                                                const u16* __restrict__ add, u16* __restrict__ out, long R, int C, int relu, float out_scale) {
+                                                                const u16* __restrict__ add, u16* __restrict__ out, u16* __restrict__ out16, long R, int C, int relu,
+                                                                float out_scale) {
+    // (SAR_X3: `out` is a plane pair in true units, out16 -- nullable -- the same values times out_scale as ONE fp16 tensor, the operand of the weight gradients)
     __shared__ float cst[6 * CMAX];
     bn_prologue(bn, 2, C, 0, C, cst, CMAX, blockIdx.x == 0, 256);
     __syncthreads();
@@ -1181,21 +1154,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const DT* __rest
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long e = i * 8;
         float a[8], y[8], o[8], ad[8];
-        if constexpr (sizeof(DT) == 2) unpack8(*reinterpret_cast<const uint4*>(dact + e), a);
+        const long ps = R * C;
+        if constexpr (sizeof(DT) == 2) load8(reinterpret_cast<const u16*>(dact), e, ps, a);
         else {
             const float4 f0 = *reinterpret_cast<const float4*>(dact + e), f1 = *reinterpret_cast<const float4*>(dact + e + 4);
             a[0] = f0.x; a[1] = f0.y; a[2] = f0.z; a[3] = f0.w; a[4] = f1.x; a[5] = f1.y; a[6] = f1.z; a[7] = f1.w;
         }
-        unpack8(*reinterpret_cast<const uint4*>(x + e), y);
-        if (add) unpack8(*reinterpret_cast<const uint4*>(add + e), ad);
+        load8(x, e, ps, y);
+        if (add) load8(add, e, ps, ad);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float z = fmaf(y[j], k.sc[j], k.sh[j]);
             const float dz = (!relu || z > 0.f) ? a[j] : 0.f;
             const float xh = (y[j] - k.mu[j]) * k.rs[j];
-            o[j] = (k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]) + (add ? ad[j] : 0.f)) * out_scale;
+            o[j] = (k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]) + (add ? ad[j] : 0.f)) * (X3 ? 1.f : out_scale);
         }
-        *reinterpret_cast<uint4*>(out + e) = pack8(o);
+        store8(out, e, ps, o);
+        if constexpr (X3) { if (out16 != nullptr) *reinterpret_cast<uint4*>(out16 + e) = pack8_half(o, out_scale); }
     }
 }
 
@@ -1216,12 +1191,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const DT* __res
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long e = i * 8;
         float a[8], y[8];
-        if constexpr (sizeof(DT) == 2) unpack8(*reinterpret_cast<const uint4*>(dact + e), a);
+        if constexpr (sizeof(DT) == 2) load8(reinterpret_cast<const u16*>(dact), e, R * C, a);
         else {
             const float4 f0 = *reinterpret_cast<const float4*>(dact + e), f1 = *reinterpret_cast<const float4*>(dact + e + 4);
             a[0] = f0.x; a[1] = f0.y; a[2] = f0.z; a[3] = f0.w; a[4] = f1.x; a[5] = f1.y; a[6] = f1.z; a[7] = f1.w;
         }
-        unpack8(*reinterpret_cast<const uint4*>(x + e), y);
+        load8(x, e, R * C, y);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float z = fmaf(y[j], sc[j], sh[j]);
@@ -1254,7 +1229,7 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_f32_kernel(const u16* __res
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long e = i * 8;
         float y[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + e), y);
+        load8(x, e, R * C, y);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { y[j] = fmaf(y[j], k.sc[j], k.sh[j]); if (relu) y[j] = fmaxf(y[j], 0.f); }
         *reinterpret_cast<float4*>(out + e) = make_float4(y[0], y[1], y[2], y[3]);
@@ -1262,16 +1237,19 @@ __global__ __launch_bounds__(256) void bn_apply_bf16_f32_kernel(const u16* __res
     }
 }
 
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, long n8) {
+// (SAR_X3: the 2-byte side is a plane pair, n8 * 8 elements apart; y16 -- nullable -- the same values times `scale` as ONE fp16 tensor)
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, u16* __restrict__ y16, float scale, long n8) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const float4 a = *reinterpret_cast<const float4*>(x + i * 8), b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
-        *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        store8(y, i * 8, n8 * 8, f);
+        if constexpr (X3) { if (y16 != nullptr) *reinterpret_cast<uint4*>(y16 + i * 8) = pack8_half(f, scale); }
     }
 }
 __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const u16* __restrict__ x, float* __restrict__ y, long n8) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + i * 8), f);
+        load8(x, i * 8, n8 * 8, f);
         *reinterpret_cast<float4*>(y + i * 8) = make_float4(f[0], f[1], f[2], f[3]);
         *reinterpret_cast<float4*>(y + i * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
     }
@@ -1309,7 +1287,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __rest
     r = __builtin_amdgcn_readfirstlane(r);
     const PackRow row = tab[r];
     const int taps = (int)row.taps, Cin = (int)row.Cin, Cout = (int)row.Cout;
-    const int Ff = taps * Cin / 16, Ffp = Ff + 8, Fd = taps * Cout / 16, Fdp = Fd + 8;
+    // (SAR_X3: the stream interleaves the hi and the lo fragment of every 16-channel block)
+    const int Ff = NPL * taps * Cin / 16, Ffp = Ff + 8, Fd = NPL * taps * Cout / 16, Fdp = Fd + 8;
     const long nf = (long)(Cout / 32) * Ffp * 64, nd = (long)(Cin / 32) * Fdp * 64;    // 16-byte pieces
     long i = ((long)blockIdx.x - row.first_block) * 256 + threadIdx.x;
     if (i >= nf + nd) return;
@@ -1323,13 +1302,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
     if (f < F) {
-        const int nk = Cred / 16, tap = f / nk, kc = f % nk;
+        const int fl = f / NPL, nk = Cred / 16, tap = fl / nk, kc = fl % nk;
         const int oc = nt * 32 + (lane & 31), rc = kc * 16 + 8 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             v[j] = fwd ? row.w[((long)tap * Cin + rc + j) * Cout + oc] : row.w[((long)(taps - 1 - tap) * Cin + oc) * Cout + rc + j];
     }
-    *reinterpret_cast<uint4*>((fwd ? row.wf : row.wd) + i * 8) = pack8(v);
+    uint4 o = pack8(v);
+    if constexpr (X3) { uint4 lo; split8(v, o, lo); if (f % NPL) o = lo; }
+    *reinterpret_cast<uint4*>((fwd ? row.wf : row.wd) + i * 8) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -1359,12 +1340,6 @@ template <typename KT>
 static bool allow_lds(KT kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
-// k-groups of the 128+-channel conv launches: 2 (default) or 1 (SAR_CONV16_KG=1: the four-wave kernel for every layer)
-static int conv16_kgroups() {
-    static const int v = [] { const char* e = getenv("SAR_CONV16_KG"); return e && atoi(e) == 1 ? 1 : 2; }();
-    return v;
-}
-
 }  // namespace
 
 extern "C" {
@@ -1399,15 +1374,16 @@ int SAR_T16(sar_conv_pack_weights_zero_)(const void* table, int n, int total_blo
     return SAR_OK;
 }
 
-// Generic bf16 convolution: y[M][Cout] = sum over taps, channels of T(src)[padded position] * wpk (+ bias) (+ res), with
+// Generic 2-byte convolution: y[M][Cout] = sum over taps, channels of T(src)[padded position] * wpk (+ bias) (+ res), with
 //   fill 0: T = identity; 1: T = relu(bn(.)) of `fbn` (forward statistics from fbn->bins, or fbn->saved when bins is null);
 //        2: T = BatchNorm(+ReLU) backward of (da = src, y = src2) through `fbn`;  3: the same + src3 (the shortcut gradient).
 //   side (nullable): T(src) written back to HBM (shape of src) -- the plain operand of the matching weight gradient.
-//   epi  0: none; 1: sum / sum of squares of y into e_bins; 2: BatchNorm-backward sums of y (= da) against (e_y, e_saved).
+//   epi  0: none; 1: sum / sum of squares of y into e_bins; 2: BatchNorm-backward sums of y (= da) against (e_y, e_saved); 3: epi 1 in fixed point.
 // Forward: d = 1, s = stride, pads as TF.  Input gradient: src = dy, d = stride, s = 1, pt = K-1-pad_top, wpk = dgrad stream.
-int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
-                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
-                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, hipStream_t stream) {
+// SAR_X3 (sar_conv2d_x3): every 2-byte tensor is a plane pair, `side` ONE fp16 tensor = fp16(T(src) * side_scale), side2 (nullable) T(src) as planes.
+static int conv2d_impl(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                       int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                       const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, void* side2, float side_scale, hipStream_t stream) {
     ConvP p;
     memset(&p, 0, sizeof(p));
     if (!make_geo(p.g, B, Hs, Ws, Cin, Ho, Wo, K, s, d, pt, pl)) return SAR_EINVAL;
@@ -1415,17 +1391,21 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     if (fill < 0 || fill > 3 || epi < 0 || epi > 3 || (fill && fbn == nullptr) || (fill >= 2 && src2 == nullptr) || (fill == 3 && src3 == nullptr)) return SAR_EINVAL;
     if (epi && e_bins == nullptr) return SAR_EINVAL;
     if (epi == 2 && (e_y == nullptr || e_saved == nullptr)) return SAR_EINVAL;
-    if ((long)B * Hs * Ws * Cin >= (1L << 31) || (long)p.g.M * Cout >= (1L << 31)) return SAR_EINVAL;
+    if ((long)B * Hs * Ws * Cin >= (1L << 31) / NPL || (long)p.g.M * Cout >= (1L << 31) / NPL) return SAR_EINVAL;
+    if (!X3 && side2 != nullptr) return SAR_EINVAL;
     p.Cout = Cout;
     p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.x3 = static_cast<const u16*>(src3); p.wpk = static_cast<const h16x8*>(wpk);
     p.bias = bias; p.res = static_cast<const u16*>(res); p.y = static_cast<u16*>(y); p.side = static_cast<u16*>(side);
+    p.side2 = static_cast<u16*>(side2); p.side_scale = side_scale != 0.f ? side_scale : 1.f;
+    p.xs = X3 ? (unsigned)((long)B * Hs * Ws * Cin) : 0u; p.ys = X3 ? (unsigned)((long)p.g.M * Cout) : 0u;
     p.fill = fill; if (fbn) p.fb = *fbn;
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;
     p.lg_pc = ilog2(Cin / 8); p.rs = Cin * 2 + 16;
     p.cw = p.g.Wp * (Cin / 8); p.mg_cw = magic(p.cw);
-    p.Fs = K * K * Cin / 16 + 8;
+    p.Fs = NPL * K * K * Cin / 16 + 8;
     const int WN = Cout >= 64 ? 2 : 1, TN = 32 * WN;
-    // 32 output channels from up to 64 source channels (stage 0 and its gradients): 64-pixel tiles on two waves (SAR_CONV16_TM64=0: 128 / four)
+    // LDS bytes of the patch: every plane + a 1 KiB scratch slot behind it (the fill's branch-free no-op pieces land there)
+    auto plane_bytes = [&](int tm) { return (size_t)patch_rows_bound(p.g, tm < p.g.M ? tm : p.g.M) * p.g.Wp * p.rs + 1024; };
     // Pixel tile of the 32-output-channel launches (stage 0, its shortcut and gradients).  Round 2 ran them as 128-pixel tiles on four
     // waves: 1 000 blocks at B = 64 for 768 resident slots -- 1.3 rounds, the second a third full.  256 pixels on EIGHT waves (128
     // registers, two blocks per CU) are 500 blocks = ONE round: the ten stage-0 launches 171 -> 128 us.  Taken where two such blocks fit
@@ -1435,34 +1415,34 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     const bool narrow = WN == 1 && Cin <= 64;
     bool tm256 = false;
     if (narrow && (tm_env == 0 || tm_env == 256)) {
-        const size_t pb = (size_t)patch_rows_bound(p.g, 256 < p.g.M ? 256 : p.g.M) * p.g.Wp * p.rs + 1024;
+        const size_t pb = NPL * plane_bytes(256);
         tm256 = tm_env == 256 || (size_t)6 * Cin * 4 + ROWTAB_BYTES * 2 + ((pb + 1023) & ~(size_t)1023) + 3 * 8 * 1024 <= 80 * 1024;
     }
     const bool tm64 = tm_env == 64 && narrow;
-    // BR form (weight fragments in registers, no ring): 64+ source channels into 64+ output channels -- stages 1-3.  SAR_CONV16_BR=0: round 2's forms
-    static const bool br_env = !(getenv("SAR_CONV16_BR") && atoi(getenv("SAR_CONV16_BR")) == 0);
-    const bool br = br_env && WN == 2 && Cin >= 64;
-    // 256 / 512 source channels whose 64-pixel patch does not fit the LDS (res_filters = 64: the 512-channel stage exceeds 160 KB by 1.3 KB, its
-    // stride-2 entry from 256 channels by more): 32-pixel tiles
+    // BR form (weight fragments in registers, no ring): 64+ source channels into 64+ output channels -- stages 1-3
+    const bool br = WN == 2 && Cin >= 64;
+    // sources whose 64-pixel patch does not fit the LDS (res_filters = 64: the 512-channel stage exceeds 160 KB by 1.3 KB, its stride-2 entry
+    // from 256 channels by more; SAR_X3, twice the patch: the 256-channel stage as well): 32-pixel tiles
     bool br32 = false;
-    if (br && Cin >= 256) {
-        const size_t pb64 = (size_t)patch_rows_bound(p.g, 64 < p.g.M ? 64 : p.g.M) * p.g.Wp * p.rs + 1024;
+    if (br) {
+        const size_t pb64 = NPL * plane_bytes(64);
         br32 = Cin == 512 || (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((pb64 + 1023) & ~(size_t)1023) > 160 * 1024;   // (512: the 32-pixel form is the only instantiation)
     }
     const int TM = br32 ? 32 : tm64 ? 64 : tm256 ? 256 : 32 * (4 / WN);
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
-    size_t patch_bytes = (size_t)p.cap_rows * p.g.Wp * p.rs + 1024;
-    const int KG = br ? (Cin >= 128 ? 4 : 2) : (Cin >= 128 && conv16_kgroups() == 2) ? 2 : 1;   // k-groups (two: 512 threads for the one-block-per-CU layers)
-    const int nthr = br ? 128 * KG : tm64 ? 128 : tm256 ? 512 : 256 * KG;
+    p.lplane = (int)plane_bytes(TM);
+    size_t patch_bytes = (size_t)NPL * p.lplane;
+    const int KG = br ? (Cin >= 128 ? 4 : 2) : 1;                                  // k-groups (BR: eight waves at 128+ source channels, four at 64)
+    const int nthr = br ? 128 * KG : tm64 ? 128 : tm256 ? 512 : 256;
     if (p.cap_rows > nthr) return SAR_EINVAL;                                      // one thread per row of the row table
     const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
-    // the long k-loops of the 128+-channel layers (one block per CU anyway) get a 4-deep weight ring where it fits
+    // the long k-loops of the 128+-channel ring layers get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
     const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * 8 * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
-    if (patch_bytes < (size_t)nthr * 32) patch_bytes = (size_t)nthr * 32;      // bn_prologue_coop's scratch: G x 4 x Cin x 8 bytes, G x Cin <= threads
-    if (Cin > nthr || (SAR_FILL_ROWS && p.cw > nthr)) return SAR_EINVAL;   // (a patch row wider than the block: no such layer in the model's range)
+    if (patch_bytes < (size_t)nthr * 32) patch_bytes = (size_t)nthr * 32;      // bn_finish's scratch: G x 4 x Cin x 8 bytes, G x Cin <= threads
+    if (Cin > nthr || p.cw > nthr) return SAR_EINVAL;   // (a patch row wider than the block: no such layer in the model's range)
     patch_bytes = (patch_bytes + 1023) & ~(size_t)1023;
     p.patch_bytes = (int)patch_bytes;
     const size_t lds = (size_t)6 * Cin * 4 + ROWTAB_BYTES + patch_bytes + ring_bytes;
@@ -1472,42 +1452,23 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
     g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm64 ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
     if (g_capture != nullptr) {
-        if (Cin == 512 && br && !br32) return SAR_EINVAL;
         g_capture->p = p; g_capture->grid = grid; g_capture->nthr = nthr; g_capture->lds = lds;
         for (int i = 0; i < 6; ++i) g_capture->cls[i] = g_last_class[i];
         return SAR_OK;
     }
     // instantiations: [WN][NKC in {2,4,8}][K == 3]; Cin = 256 / 512 run NKC = 8 with 2 / 4 channel parts per tap
     typedef void (*kern_t)(const ConvP);
-#define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
-    static const kern_t kerns[2][5][2] = {{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
-                                          {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}};
-#undef CV
-    static PerDeviceFlag attr[2][5][2];
     const int ki = ilog2(Cin / 16) - 1, k3 = K == 3 ? 1 : 0;
-#define CV2(WN_, NH_) {conv_bf16_kernel<WN_, 8, NH_, 2>, conv_bf16_kernel<WN_, 8, 9 * NH_, 2>}
-    static const kern_t kerns2[2][3][2] = {{CV2(1, 1), CV2(1, 2), CV2(1, 4)}, {CV2(2, 1), CV2(2, 2), CV2(2, 4)}};
-#undef CV2
-    static PerDeviceFlag attr2[2][3][2];
     if (br) {
-#define CVB(NKC_, NH_, KG_) {conv_bf16_kernel<2, NKC_, NH_, KG_, 2, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, 2, true>}
-        static const kern_t kernsb[5][2] = {CVB(4, 1, 2), CVB(8, 1, 4), CVB(8, 2, 4), {conv_bf16_kernel<2, 8, 2, 4, 1, true>, conv_bf16_kernel<2, 8, 18, 4, 1, true>},
-                                            {conv_bf16_kernel<2, 8, 4, 4, 1, true>, conv_bf16_kernel<2, 8, 36, 4, 1, true>}};
+        // 64-pixel tiles: 64 | 128 | 256 source channels; 32-pixel tiles: 64 | 128 | 256 | 512
+#define CVB(NKC_, NH_, KG_, WMX_) {conv_bf16_kernel<2, NKC_, NH_, KG_, WMX_, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, WMX_, true>}
+        static const kern_t kernsb[7][2] = {CVB(4, 1, 2, 2), CVB(8, 1, 4, 2), CVB(8, 2, 4, 2), CVB(4, 1, 2, 1), CVB(8, 1, 4, 1), CVB(8, 2, 4, 1), CVB(8, 4, 4, 1)};
 #undef CVB
-        static PerDeviceFlag attrb[5][2];
-        if (Cin == 512 && !br32) return SAR_EINVAL;                                   // (no 64-pixel instantiation for 512 source channels)
-        const int kb = br32 ? (Cin == 256 ? 3 : 4) : ki - 1;
+        static PerDeviceFlag attrb[7][2];
+        const int kb = br32 ? ki + 2 : ki - 1;
         const kern_t kern = kernsb[kb][k3];
         if (!attrb[kb][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[kb][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
-        SAR_CHECK_LAUNCH();
-        return SAR_OK;
-    }
-    if (KG == 2) {
-        if (PFB && p.rd != 4) return SAR_EINVAL;                                    // the prefetching k-phase (experiment) runs a four-slot ring
-        const kern_t kern = kerns2[WN - 1][ki - 2][k3];
-        if (!attr2[WN - 1][ki - 2][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr2[WN - 1][ki - 2][k3] = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
@@ -1523,6 +1484,11 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
+#define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
+    static const kern_t kerns[2][5][2] = {{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
+                                          {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}};
+#undef CV
+    static PerDeviceFlag attr[2][5][2];
     const kern_t kern = kerns[WN - 1][ki][k3];
     if (!attr[WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[WN - 1][ki][k3] = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
@@ -1530,9 +1496,24 @@ int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, co
     return SAR_OK;
 }
 
-// The arguments of one sar_conv2d_* call (include/sarnet.h: sarConvArgs).
+#if SAR_X3
+int sar_conv2d_x3(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                  int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                  const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, void* side2, float side_scale, hipStream_t stream) {
+    return conv2d_impl(src, src2, src3, wpk, bias, res, y, side, B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill, fbn, epi, e_bins, e_y, e_saved, side2, side_scale, stream);
+}
+#else
+int SAR_T16(sar_conv2d_)(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, hipStream_t stream) {
+    return conv2d_impl(src, src2, src3, wpk, bias, res, y, side, B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill, fbn, epi, e_bins, e_y, e_saved, nullptr, 1.f, stream);
+}
+#endif
+
+// The arguments of one sar_conv2d_* call (include/sarnet.h: sarConvArgs; side2 / side_scale: sar_conv2d_x3 only, 0 elsewhere).
 struct sarConvArgs { const void *src, *src2, *src3, *wpk; const float* bias; const void* res; void* y; void* side;
-                     int B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill; const sarBnRef* fbn; int epi; float* e_bins; const void* e_y; const float* e_saved; };
+                     int B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill; const sarBnRef* fbn; int epi; float* e_bins; const void* e_y; const float* e_saved;
+                     void* side2; float side_scale; };
 // Two independent convolutions in ONE launch: a = a 3x3 convolution, b = a 1x1 convolution of the same channel classes and block size (the first
 // conv of a shape-changing residual block and its shortcut, or their input gradients).  Returns SAR_EINVAL -- and launches NOTHING -- when the
 // two do not run on instantiations that pair up; the caller then issues them one after the other.
@@ -1543,9 +1524,9 @@ int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStr
     ConvLaunch* l[2] = {&la, &lb};
     for (int i = 0; i < 2; ++i) {
         g_capture = l[i];
-        const int rc = SAR_T16(sar_conv2d_)(q[i]->src, q[i]->src2, q[i]->src3, q[i]->wpk, q[i]->bias, q[i]->res, q[i]->y, q[i]->side, q[i]->B, q[i]->Hs, q[i]->Ws,
-                                            q[i]->Cin, q[i]->Ho, q[i]->Wo, q[i]->Cout, q[i]->K, q[i]->s, q[i]->d, q[i]->pt, q[i]->pl, q[i]->fill, q[i]->fbn, q[i]->epi,
-                                            q[i]->e_bins, q[i]->e_y, q[i]->e_saved, stream);
+        const int rc = conv2d_impl(q[i]->src, q[i]->src2, q[i]->src3, q[i]->wpk, q[i]->bias, q[i]->res, q[i]->y, q[i]->side, q[i]->B, q[i]->Hs, q[i]->Ws,
+                                   q[i]->Cin, q[i]->Ho, q[i]->Wo, q[i]->Cout, q[i]->K, q[i]->s, q[i]->d, q[i]->pt, q[i]->pl, q[i]->fill, q[i]->fbn, q[i]->epi,
+                                   q[i]->e_bins, q[i]->e_y, q[i]->e_saved, q[i]->side2, q[i]->side_scale, stream);
         g_capture = nullptr;
         if (rc != SAR_OK) return rc;
     }
@@ -1554,12 +1535,13 @@ int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStr
     if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || ca[4] != cb[4] || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
     typedef void (*pair_t)(const ConvP, const ConvP, unsigned, unsigned, unsigned, unsigned);
     pair_t kern = nullptr;
-    static PerDeviceFlag at[4];
+    static PerDeviceFlag at[5];
     int ki = -1;
     if (ca[0] == 2 && ca[1] == 2 && ca[2] == 9 && ca[3] == 1 && ca[4] == 2 && !ca[5]) { kern = conv_bf16_pair_kernel<2, 2, 9, 1, 2, false>; ki = 0; }
     else if (ca[0] == 2 && ca[1] == 4 && ca[2] == 9 && ca[3] == 2 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 4, 9, 2, 2, true>; ki = 1; }
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 9, 4, 2, true>; ki = 2; }
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 18, 4, 2, true>; ki = 3; }
+    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 1 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 18, 4, 1, true>; ki = 4; }
     if (kern == nullptr) return SAR_EINVAL;
     if (!at[ki]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at[ki] = true; }
     const unsigned na = la.grid.x * la.grid.y, nb = lb.grid.x * lb.grid.y, na8 = (na + 7u) & ~7u;
@@ -1569,10 +1551,11 @@ int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStr
     return SAR_OK;
 }
 
+#if !SAR_X3
 // One convolution of a batched weight-gradient launch as the caller describes it (include/sarnet.h: sarWgradConv).
 struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; int B, H, W, Cin, Ho, Wo, Cout, K, s, pt, pl; float ginv; };
 
-#if !SAR_HALF
+#if !SAR_HALF && !SAR_X3
 // Host-only planning (no device access; shared by both builds of this file): the device tables of ONE launch over `n` convolutions of equal K (1 or 3) and equal
 // channel-tile class -- convs_out: n rows of 128 bytes, items_out: up to max_items rows of 32 bytes, longest first -- plus the
 // launch parameters launch4 = {dynamic LDS bytes, positions of the patch ring (3x3), chunk buffers, tile_ci << 4 | tile_co}.
@@ -1702,7 +1685,7 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
     return launch4[0] <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
 }
 
-#endif  // !SAR_HALF
+#endif  // !SAR_HALF && !SAR_X3
 
 // Weight gradients of many convolutions, one launch: tables and launch4 from sar_wgrad_plan_bf16 (tables uploaded by the caller),
 // K = kernel size of the planned convolutions.  dw += x^T (*) dy per tap, dbias (where given) += column sums of dy.
@@ -1725,17 +1708,13 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
         if (launch4[6] != 9 * tci * tco * 1024) return SAR_EINVAL;
         Wg3Args a{static_cast<const unsigned char*>(convs_dev), static_cast<const WgItem*>(items_dev), zero_page, (unsigned)np, nbuf, tab_bytes / 4, slab};
         typedef void (*k3_t)(const Wg3Args);
-        // 64 x 64 tiles run the twelve-wave form (SAR_WG_W12=0: the nine-wave kernel, for A/B timing)
-        // 64 x 64 tiles: the twelve-wave form.  SAR_WG_LOADERS=1: the loader-wave experiment (12 + 2 / 9 + 1 waves; slower, see the kernel)
-        static const bool ldr = getenv("SAR_WG_LOADERS") && atoi(getenv("SAR_WG_LOADERS")) == 1;
+        // 64 x 64 tiles: the twelve-wave form
         static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2, true>}};
-        static const k3_t k3l[2] = {wgrad3_bf16_kernel<1, 1, false, 1>, wgrad3_bf16_kernel<2, 2, true, 2>};
-        static PerDeviceFlag attr3[2][2], attrl[2];
-        const bool sq = tci == tco, usel = ldr && sq;
-        const k3_t kern = usel ? k3l[tci - 1] : k3[tci - 1][tco - 1];
-        PerDeviceFlag& at = usel ? attrl[tci - 1] : attr3[tci - 1][tco - 1];
+        static PerDeviceFlag attr3[2][2];
+        const k3_t kern = k3[tci - 1][tco - 1];
+        PerDeviceFlag& at = attr3[tci - 1][tco - 1];
         if (!at) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at = true; }
-        const int threads = (tci == 2 && tco == 2 ? 768 : 576) + (usel ? 64 * tci : 0);
+        const int threads = tci == 2 && tco == 2 ? 768 : 576;
         hipLaunchKernelGGL(kern, dim3(n_items), dim3(threads), lds_bytes, stream, a);
         if (n_tiles > 0 && !launch4[7])                                             // launch4[7]: the caller reduces (sar_wgrad_reduce_multi_*)
             hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(n_tiles, 9 * tci * tco), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
@@ -1779,6 +1758,8 @@ int SAR_T16(sar_wgrad_reduce_multi_)(const sarWgradReduce* plans, int n, hipStre
     return SAR_OK;
 }
 
+#endif  // !SAR_X3
+
 static int bn_grid(long R, int C) {
     const long pieces = R * (C / 8);
     long nb = (pieces + 256 * 4 - 1) / (256 * 4);
@@ -1787,20 +1768,32 @@ static int bn_grid(long R, int C) {
     return (int)nb;
 }
 
-// out_scale: multiplies the result (the fp16 trunk's static gradient scale enters here, at the final BatchNorm; 1 otherwise)
-int SAR_T16(sar_bn_bwd_apply_)(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
-                          int C, int relu, float out_scale, hipStream_t stream) {
+// out_scale: multiplies the result (the fp16 trunk's static gradient scale enters here, at the final BatchNorm; 1 otherwise).
+// sar_bn_bwd_apply_x3: `out` (a plane pair) stays in true units; out16 (nullable) = fp16(result * out_scale), the weight gradients' operand.
+static int bn_bwd_apply_impl(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, void* out16, long R,
+                             int C, int relu, float out_scale, hipStream_t stream) {
     if (bn == nullptr || !pow2(C) || C < 8 || C > CMAX || R < 1) return SAR_EINVAL;
     const dim3 grid(bn_grid(R, C));
     if (dact_f32)
         hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float*>(dact), static_cast<const u16*>(x), *bn,
-                           static_cast<const u16*>(add), static_cast<u16*>(out), R, C, relu, out_scale);
+                           static_cast<const u16*>(add), static_cast<u16*>(out), static_cast<u16*>(out16), R, C, relu, out_scale);
     else
         hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel<u16>, grid, dim3(256), 0, stream, static_cast<const u16*>(dact), static_cast<const u16*>(x), *bn,
-                           static_cast<const u16*>(add), static_cast<u16*>(out), R, C, relu, out_scale);
+                           static_cast<const u16*>(add), static_cast<u16*>(out), static_cast<u16*>(out16), R, C, relu, out_scale);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
+#if SAR_X3
+int sar_bn_bwd_apply_x3(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, void* out16, long R,
+                        int C, int relu, float out_scale, hipStream_t stream) {
+    return bn_bwd_apply_impl(dact, dact_f32, x, bn, add, out, out16, R, C, relu, out_scale, stream);
+}
+#else
+int SAR_T16(sar_bn_bwd_apply_)(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, long R,
+                          int C, int relu, float out_scale, hipStream_t stream) {
+    return bn_bwd_apply_impl(dact, dact_f32, x, bn, add, out, nullptr, R, C, relu, out_scale, stream);
+}
+#endif
 
 int SAR_T16(sar_bn_bwd_reduce_)(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
                            hipStream_t stream) {
@@ -1817,6 +1810,9 @@ int SAR_T16(sar_bn_bwd_reduce_)(const void* dact, int dact_f32, const void* x, c
 #if SAR_HALF
 #define sar_bn_apply_T16_f32 sar_bn_apply_f16_f32
 #define sar_cast_T16_f32 sar_cast_f16_f32
+#elif SAR_X3
+#define sar_bn_apply_T16_f32 sar_bn_apply_x3_f32
+#define sar_cast_T16_f32 sar_cast_x3_f32
 #else
 #define sar_bn_apply_T16_f32 sar_bn_apply_bf16_f32
 #define sar_cast_T16_f32 sar_cast_bf16_f32
@@ -1828,10 +1824,16 @@ int sar_bn_apply_T16_f32(const void* x, const sarBnRef* bn, float* out, long R, 
     return SAR_OK;
 }
 
+// fp32 -> the trunk's 2-byte type (sar_cast_f32_x3: a plane pair of n elements each, + y16 (nullable) = fp16(x * scale))
+#if SAR_X3
+int sar_cast_f32_x3(const float* x, void* y, void* y16, float scale, long n, hipStream_t stream) {
+#else
 int SAR_T16(sar_cast_f32_)(const float* x, void* y, long n, hipStream_t stream) {
+    void* y16 = nullptr; const float scale = 1.f;
+#endif
     if (n < 8 || n % 8) return SAR_EINVAL;
     long nb = (n / 8 + 1023) / 1024; if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, static_cast<u16*>(y), n / 8);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, static_cast<u16*>(y), static_cast<u16*>(y16), scale, n / 8);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -1843,7 +1845,7 @@ int sar_cast_T16_f32(const void* x, float* y, long n, hipStream_t stream) {
     return SAR_OK;
 }
 
-#if !SAR_HALF
+#if !SAR_HALF && !SAR_X3
 int sar_bn_bins(void) { return NB; }
 #endif
 

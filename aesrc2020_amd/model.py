@@ -100,7 +100,7 @@ class SARNetModel:
                 print("======= ERROR: please specify cnn in res-[18,34,50,101,152] ======")
                 raise ValueError("res_type")
             self.trunk = fn[c["res_type"]](inputs, filters=c["res_filters"])
-            if getattr(self.trunk, "half", False):
+            if getattr(self.trunk, "half", False) or getattr(self.trunk, "x3", False):
                 self.store.set_adam_guard(True)                   # fp16 activation gradients can overflow: see csrc/optim.hip
             Tp, Dp = self.trunk.out_hw
             self.L = Tp * Dp

@@ -115,30 +115,37 @@ class _Conv:
     def streams16(self):
         """Packed bf16 weight streams (forward, input gradient) + this conv's row of the pack table."""
         taps = self.k * self.k
-        nf = (self.cout // 32) * (taps * self.cin // 16 + 8) * 512          # bf16 elements
-        nd = (self.cin // 32) * (taps * self.cout // 16 + 8) * 512
+        npl = 2 if self.sfx == "x3" else 1                                  # split precision: hi and lo fragment of every 16-channel block
+        nf = (self.cout // 32) * (npl * taps * self.cin // 16 + 8) * 512    # 2-byte elements
+        nd = (self.cin // 32) * (npl * taps * self.cout // 16 + 8) * 512
         b = self.store.bufs
         self.wf = b.get(self.name + "/wf16", (nf,), self.t16)
         self.wd = b.get(self.name + "/wd16", (nd,), self.t16)
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
-    def fwd16_args(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None):
+    def _x3_tail(self, side2, side_scale):
+        """sar_conv2d_x3's two extra arguments: the fill's result as a plane pair (side2), the scale of its fp16 copy (side)."""
+        return (side2, float(side_scale)) if self.sfx == "x3" else ()
+
+    def fwd16_args(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None, side2=None, side_scale=1.0):
         return (x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
-                self.k, self.stride, 1, self.pt, self.pl, fill, fbn, self.epi_fwd if e_bins is not None else 0, e_bins, None, None)
+                self.k, self.stride, 1, self.pt, self.pl, fill, fbn, self.epi_fwd if e_bins is not None else 0, e_bins, None, None) + \
+            self._x3_tail(side2, side_scale)
 
     def fwd16(self, x, y, B, **kw):
         _call("sar_conv2d_" + self.sfx, *self.fwd16_args(x, y, B, **kw))
 
-    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
+    def dgrad16(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None, side2=None, side_scale=1.0):
         """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2, + dy3 when fill == 3
         (written back to `side` for the weight gradient and the other consumers of that gradient); the epilogue leaves the backward
         sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
-        _call("sar_conv2d_" + self.sfx, *self.dgrad16_args(dy, dy2, dx, B, fill, fbn, res, e_bins, e_y, e_saved, side, dy3))
+        _call("sar_conv2d_" + self.sfx, *self.dgrad16_args(dy, dy2, dx, B, fill, fbn, res, e_bins, e_y, e_saved, side, dy3, side2, side_scale))
 
-    def dgrad16_args(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
+    def dgrad16_args(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None, side2=None,
+                     side_scale=1.0):
         return (dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
                 self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
-                e_bins, e_y, e_saved)
+                e_bins, e_y, e_saved) + self._x3_tail(side2, side_scale)
 
     def wgrad16(self, x, dy, B, bias_grad):
         """Descriptor of this conv's weight gradient on plain operands (include/sarnet.h: sarWgradConv); the trunk batches them
@@ -198,12 +205,21 @@ class ResNetTrunk(Layer):
         # 2-byte trunk (csrc/conv_bf16.hip, stem_bf16.hip; compiled for bf16 and for fp16): `bf16` keeps its round-2 name and means
         # "2-byte storage"; `half` tells the two apart.  fp16 carries a static gradient scale through the trunk (include/sarnet.h)
         dt = _lib.get_trunk_dtype()
-        self.bf16, self.half = dt in ("bf16", "fp16"), dt == "fp16"
-        self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("bf16", torch.bfloat16)
-        self._gscale_cfg = _lib.get_trunk_gscale() if self.half else 1.0      # 0: automatic, 64 x batch (_set_gscale)
+        if dt == "bf16x3" and (filters != 32 or stem_c not in (32, 64)):
+            # split precision on the 2-byte kernels exists for the reference's width (train.py:54); other widths run the fp32-storage
+            # kernels -- the same fp32-class arithmetic (bf16x3 products) on round 1's kernels
+            dt = "fp32"
+        # `x3`: split precision (csrc/trunk16.h SAR_X3): every 2-byte tensor is a (hi, lo) pair of bf16 planes -- shape (2, ...) -- and the
+        # operands only the weight gradients read are single fp16 tensors (gradients times the static scale of the fp16 build)
+        self.x3 = dt == "bf16x3"
+        self.bf16, self.half = dt in ("bf16", "fp16", "bf16x3"), dt == "fp16"
+        self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("x3", torch.bfloat16) if self.x3 else ("bf16", torch.bfloat16)
+        self.wsfx = "f16" if self.x3 else self.sfx                           # build whose weight-gradient kernels run
+        self.t_side = torch.float16 if self.x3 else self.t16                 # the tensors the fills write back for them
+        self._gscale_cfg = _lib.get_trunk_gscale() if (self.half or self.x3) else 1.0      # 0: automatic, 64 x batch (_set_gscale)
         self.gscale = self.ginv = 1.0
         self.det = self.bf16 and _lib.get_bn_deterministic()                 # forward BatchNorm sums in 64-bit fixed point (SAR_BN_DET=1)
-        if self.bf16 and (filters not in (32, 64) or stem_c not in (32, 64)):
+        if self.bf16 and not self.x3 and (filters not in (32, 64) or stem_c not in (32, 64)):
             raise ValueError("2-byte trunk: res_filters must be 32 (the reference's train.py:54 default) or 64 (SAR_Net's own default, model.py:204): "
                              "channel counts are powers of two in [32, 512]; got %d" % filters)
         self.stem = _Conv(st, st.auto_name("conv2d"), 7, 1, stem_c, 2, "same")
@@ -304,16 +320,21 @@ class ResNetTrunk(Layer):
             off = bn.prepare16(self._arena, off, self.det)
 
     def _buf16(self, key, shape):
-        return self.buf(key, shape, self.t16)
+        """A 2-byte activation / gradient tensor of the trunk (split precision: its plane pair, shape (2, ...))."""
+        return self.buf(key, ((2,) + tuple(shape)) if self.x3 else shape, self.t16)
+
+    def _side16(self, key, shape):
+        """An operand only the weight gradients read (the fills write it back): the trunk's 2-byte type; split precision: ONE fp16 tensor."""
+        return self.buf(key, shape, self.t_side)
 
     def _stem_fn(self, name):
         return name + "_f16" if self.half else name
 
     def _forward16(self, x, B):
-        """Same graph as forward() on bf16 activations: one launch per conv (BN+ReLU of the producer evaluated in the conv's
-        patch fill from the statistic bins; statistics of the consumer BN out of the epilogue), stem on the fp32 kernels."""
+        """Same graph as forward() on 2-byte activations: one launch per conv (BN+ReLU of the producer evaluated in the conv's
+        patch fill from the statistic bins; statistics of the consumer BN out of the epilogue), the stem in recompute form."""
         self._setup16()
-        if self.half:
+        if self.half or self.x3:
             self._set_gscale(B)
         training = self.store.training
         ztab = self.store.take_deferred_zero()                              # the step-start zeroing rides in the packing launch (model._device_step)
@@ -332,20 +353,25 @@ class ResNetTrunk(Layer):
         nblk = len(self.blocks)
         for n, blk in enumerate(self.blocks):
             H, W = blk["in_hw"]; H2, W2 = blk["out_hw"]
-            cout = blk["cout"]
+            cin, cout = blk["cin"], blk["cout"]
             blk["x"] = cur
             bn1, bn2 = blk["bn1"], blk["bn2"]
             c1 = self._buf16("b%d_c1" % n, (B, H2, W2, cout))
             # training: the activated operands relu(bn(.)) the fills compute are written back (a, a1) for the weight gradients
-            blk["a"] = self._buf16("b%d_a" % n, tuple(cur.shape)) if (training and bn1 is not None) else None
-            blk["a1"] = self._buf16("b%d_a1" % n, (B, H2, W2, cout)) if training else None
+            blk["a"] = self._side16("b%d_a" % n, (B, H, W, cin)) if (training and bn1 is not None) else None
+            blk["a1"] = self._side16("b%d_a1" % n, (B, H2, W2, cout)) if training else None
+            # split precision: the RAW block input as the weight gradients read it (the shortcut's, the first conv's): one fp16 tensor, written
+            # by the fill of the shortcut conv (fill 0 + side = a copy); the first block's comes out of the stem's pooling pass
+            blk["x16"] = cur
+            if self.x3 and training and (bn1 is None or blk["sc"] is not None):
+                blk["x16"] = self.pooled_h if n == 0 else self._side16("b%d_x16" % n, (B, H, W, cin))
             a1 = blk["conv1"].fwd16_args(cur, c1, B, fill=1 if bn1 is not None else 0, fbn=bn1.ref(B * H * W, st, training) if bn1 is not None else None,
                                          e_bins=bn2.bins if training else None, side=blk["a"])
             if blk["sc"] is not None:
                 # the block's first conv and its 1x1 shortcut read the same tensor and write different ones: ONE launch where their
                 # instantiations pair up (sar_conv2d_pair_*), else one after the other
                 sc = self._buf16("b%d_sc" % n, (B, H2, W2, cout))
-                a2 = blk["sc"].fwd16_args(cur, sc, B)
+                a2 = blk["sc"].fwd16_args(cur, sc, B, side=blk["x16"] if (self.x3 and training and n > 0) else None)
                 if not self._pair(a1, a2):
                     _call("sar_conv2d_" + self.sfx, *a1); _call("sar_conv2d_" + self.sfx, *a2)
             else:
@@ -365,18 +391,26 @@ class ResNetTrunk(Layer):
 
     def _backward16(self, dy, part):
         B = self.B
+        x3 = self.x3
+        # split precision: the gradient stream (g, da, dsc: plane pairs) is in TRUE units; only the fp16 copies the weight gradients read
+        # (g16, dc1) carry the static scale, which their descriptors' ginv undoes.  fp16 build: the whole stream is scaled.
+        gi = 1.0 if x3 else self.ginv
         if part in (None, 0, "01"):
             H, W = self.out_hw
             fb = self.final_bn
             R = B * H * W
-            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t16)
+            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), ((2,) if x3 else ()) + (B, H, W, self.out_c), self.t16)
+            g16 = self.scratch("res16_g16_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_side) if x3 else g
             # the gradient enters the trunk here: fp32 sums and constants, the result times the fp16 build's gradient scale (1 for bf16)
             _call("sar_bn_bwd_reduce_" + self.sfx, dy, 1, self.pre_final, fb.saved, fb.bbins, R, self.out_c, 1)
-            _call("sar_bn_bwd_apply_" + self.sfx, dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1, self.gscale)
+            if x3:
+                _call("sar_bn_bwd_apply_x3", dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, g16, R, self.out_c, 1, self.gscale)
+            else:
+                _call("sar_bn_bwd_apply_" + self.sfx, dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1, self.gscale)
         else:
-            g = self._g_part
+            g, g16 = self._g_part
         stages = {None: (3, 2, 1, 0), 0: (3,), 1: (2,), 2: (1, 0), "01": (3, 2)}[part]
-        bf, gi = self.t16, self.ginv
+        bf = self.t16
         self._wg16 = []
         overlap = part is None and self.WGRAD_OVERLAP
         if overlap and getattr(self, "_wg_stream", None) is None:
@@ -397,35 +431,41 @@ class ResNetTrunk(Layer):
             # conv2: operand a1 = relu(bn2(c1)) (written back by the forward fill); its input gradient da2 leaves the two sums of
             # bn2's backward in bn2.bbins
             red = []
-            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), bf)
+            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), ((2,) if x3 else ()) + (B, H2, W2, cout), bf)
             if pend is None:
                 blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
             else:
                 p_da1, p_x, p_dsc, p_bn, p_R, p_tap = pend
-                blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True, gi), dy3=p_dsc, side=g,
-                                     e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
+                if x3:                                                # g as planes (side2) for the convs, as scaled fp16 (side) for the weight gradients
+                    blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True, gi), dy3=p_dsc, side=g16, side2=g,
+                                         side_scale=self.gscale, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
+                else:
+                    blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True, gi), dy3=p_dsc, side=g,
+                                         e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
                 if p_tap is not None:                                 # tests: (block, its g, its da2 copy) + the now materialised gin
                     tap(p_tap[0], p_tap[1], p_tap[2], g)
                 pend = None
-            red.append(blk["conv2"].wgrad16(blk["a1"], g, B, bias_grad=True))
+            red.append(blk["conv2"].wgrad16(blk["a1"], g16, B, bias_grad=True))
             # the weight gradients run at the end of the part (_wgrad16), so their gradient operands -- the block's incoming
             # gradient and dc1 -- live in per-block buffers, not in recycled scratch
             gin = self._buf16("b%d_gin" % n, (B, H, W, cin))
+            gin16 = self._side16("b%d_gin16" % n, (B, H, W, cin)) if (x3 and bn1 is not None) else gin
             sc_args = None
             if blk["sc"] is not None:
                 dsc = gin if bn1 is None else self._buf16("b%d_dsc" % n, (B, H, W, cin))
                 sc_args = blk["sc"].dgrad16_args(g, None, dsc, B)
                 if bn1 is None:                                       # (conv1's input gradient below adds dsc: one after the other)
                     _call("sar_conv2d_" + self.sfx, *sc_args); sc_args = None
-                red.append(blk["sc"].wgrad16(x, g, B, bias_grad=True))
+                red.append(blk["sc"].wgrad16(blk["x16"], g16, B, bias_grad=True))
             else:
                 dsc = g
             # conv1's output gradient dc1 = BN+ReLU backward of (da2, c1): evaluated in the fill of conv1's input-gradient launch
             # (which owns bn2's parameter gradients) and written back for the weight gradient
-            dc1 = self._buf16("b%d_dc1" % n, (B, H2, W2, cout))
+            dc1 = self._side16("b%d_dc1" % n, (B, H2, W2, cout))
             if bn1 is not None:
                 da1 = self._buf16("b%d_da1" % n, (B, H, W, cin))
-                c1_args = blk["conv1"].dgrad16_args(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved, side=dc1)
+                c1_args = blk["conv1"].dgrad16_args(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved,
+                                                    side=dc1, side_scale=self.gscale)
                 # the input gradients of the first conv and of the shortcut are independent (their sum is formed in the fill of the block in
                 # front, fill 3): one launch where they pair up
                 if sc_args is None or not self._pair(c1_args, sc_args):
@@ -435,12 +475,12 @@ class ResNetTrunk(Layer):
                 pend = (da1, x, dsc, bn1, R1, (n, g, da2.clone()) if tap is not None else None)
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
-                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), res=dsc, side=dc1)
+                blk["conv1"].dgrad16(da2, c1, gin, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), res=dsc, side=dc1, side_scale=self.gscale)
                 if tap is not None:
                     tap(n, g, da2, gin)
-            red.append(blk["conv1"].wgrad16(blk["a"] if bn1 is not None else x, dc1, B, bias_grad=False))
+            red.append(blk["conv1"].wgrad16(blk["a"] if bn1 is not None else blk["x16"], dc1, B, bias_grad=False))
             self._wg16.extend(red)
-            g = gin
+            g, g16 = gin, gin16
             # whole backward in one call: a finished stage's weight gradients start on the side stream while the next stage's
             # input-gradient chain (short, latency-bound launches that leave most of every CU idle) runs on the main stream
             if overlap and (n == 0 or self.blocks[n - 1]["stage"] != blk["stage"]):
@@ -448,7 +488,7 @@ class ResNetTrunk(Layer):
                 self._wg16 = []
         self._pend16 = pend
         assert pend is None or part in (0, 1, "01"), "the first block's conv1 takes the pooled tensor directly (resnet.py:111-117)"
-        self._g_part = g
+        self._g_part = (g, g16)
         if not overlap:
             self._wgrad16(part)
         if part in (0, 1, "01"):
@@ -498,7 +538,7 @@ class ResNetTrunk(Layer):
             for cls, target in self.WGRAD_CLASSES:
                 ds = [d for d in self._wg16 if self._wgrad_class(d) == cls]
                 if ds:
-                    ps.append(_lib.WgradPlan(ds, target, (2, 2) if cls[2] else (1, 1), self.sfx))
+                    ps.append(_lib.WgradPlan(ds, target, (2, 2) if cls[2] else (1, 1), self.wsfx))
             plans[key] = ps
         if side:
             self._wg_stream.wait_stream(torch.cuda.current_stream())
@@ -521,12 +561,12 @@ class ResNetTrunk(Layer):
                     for p in plans[key][1:]:
                         p.launch(defer_reduce=True)
                 main.wait_stream(self._wg_stream)
-                _lib.WgradPlan.reduce_multi(plans[key], self.sfx)
+                _lib.WgradPlan.reduce_multi(plans[key], self.wsfx)
                 return
             for p in plans[key]:
                 p.launch(defer_reduce=multi)
             if multi:
-                _lib.WgradPlan.reduce_multi(plans[key], self.sfx)
+                _lib.WgradPlan.reduce_multi(plans[key], self.wsfx)
 
     # stem of the bf16 trunk (csrc/stem_bf16.hip): the 7x7 conv is recomputed wherever its output is needed, so only the pooled map
     # (bf16) and its argmax slots exist in HBM -- no (B, T/2, D/2, C0) tensor, forward or backward
@@ -536,6 +576,14 @@ class ResNetTrunk(Layer):
         return (B, T, D, H, W, self.stem.cout, self.stem.pt, self.stem.pl), (Hp, Wp, self.pool_pt, self.pool_pl)
 
     def _stem_forward16(self, x, B, st):
+        if self.x3:
+            # (interim) split precision: round 1's fp32 stem (full-resolution map), its pooled map cast to planes + the fp16 copy the first
+            # block's weight gradients read
+            p32 = self._stem_forward(x, B)
+            Hp, Wp = self.pool_hw; c0 = self.stem.cout
+            self.pooled16 = self._buf16("pooled16", (B, Hp, Wp, c0)); self.pooled_h = self._side16("pooled_h", (B, Hp, Wp, c0))
+            _call("sar_cast_f32_x3", p32, self.pooled16, self.pooled_h, 1.0, p32.numel())
+            return self.pooled16
         conv, pool = self._stem_geo(B)
         H, W = self.stem_hw; Hp, Wp = self.pool_hw; c0 = self.stem.cout
         sb, cv = self.stem_bn, self.stem
@@ -548,6 +596,10 @@ class ResNetTrunk(Layer):
 
     def _stem_backward16(self, g, B):
         """g: gradient of the pooled map (bf16).  BatchNorm sums from (g, pooled, slots), then the 7x7 kernel gradient."""
+        if self.x3:
+            g32 = self.scratch("stem_g32", tuple(g.shape[1:]))
+            _call("sar_cast_x3_f32", g, g32, g32.numel())
+            return self._stem_backward(g32, B)
         conv, pool = self._stem_geo(B)
         H, W = self.stem_hw
         sb, cv = self.stem_bn, self.stem

@@ -195,6 +195,7 @@ int sar_conv2d_bf16(const void* src, const void* src2, const void* src3, const v
 typedef struct sarConvArgs {
     const void *src, *src2, *src3, *wpk; const float* bias; const void* res; void* y; void* side;
     int B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill; const sarBnRef* fbn; int epi; float* e_bins; const void* e_y; const float* e_saved;
+    void* side2; float side_scale;   /* sar_conv2d_x3 only (below); NULL / 0 elsewhere */
 } sarConvArgs;
 int sar_conv2d_pair_bf16(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
 /* Introspection (bench.py, tools): the template arguments <WN, NKC, VT, KG, WMX, BR> of the conv_bf16_kernel instantiation the most
@@ -298,6 +299,31 @@ int sar_stem16_bwd_reduce_f16(const void* g_pooled, const void* pooled, const ui
 int sar_stem16_wgrad_f16(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
                          const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
                          int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
+
+/* ---- split-precision trunk (round 4; the fp32-class mode: north_star's "logits within 1e-3" of the reference's fp32 graph,
+ * model.py:197, resnet.py:113-122): the SAME kernels compiled with -DSAR_X3 (csrc/trunk16.h).  Every 2-byte `void*` tensor of the
+ * functions below is a PAIR OF bf16 PLANES, hi = bf16(x) and lo = bf16(x - hi), the lo plane following the hi plane of the same
+ * allocation (n elements each); a product block is three MFMAs (lo*hi + hi*lo + hi*hi), weights are packed as interleaved hi / lo
+ * fragments.  Arguments and semantics are those of the _bf16 function of the same name, except:
+ *   sar_conv2d_x3: `side` is ONE fp16 tensor = fp16(T(src) * side_scale) -- the operand of the weight gradient, which this mode runs
+ *     through sar_conv2d_wgrad_batch_f16 (gradient operands carry the fp16 build's static scale, sarWgradConv.ginv undoes it) -- and
+ *     side2 (nullable) receives T(src) as a plane pair (the materialised block gradient of fill 3, which further convs read);
+ *   sar_bn_bwd_apply_x3: `out` is a plane pair in TRUE units, out16 (nullable) = fp16(result * out_scale);
+ *   sar_cast_f32_x3: y a plane pair, y16 (nullable) = fp16(x * scale). */
+int sar_conv_pack_weights_x3(const void* table, int n, int total_blocks, sarStream_t stream);
+int sar_conv_pack_weights_zero_x3(const void* table, int n, int total_blocks, const void* zero_table, int nz, sarStream_t stream);
+int sar_conv2d_x3(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                  int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                  const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, void* side2, float side_scale, sarStream_t stream);
+int sar_conv2d_last_class_x3(int* out6);
+int sar_conv2d_pair_x3(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
+int sar_bn_bwd_apply_x3(const void* dact, int dact_f32, const void* x, const sarBnRef* bn, const void* add, void* out, void* out16, long R,
+                        int C, int relu, float out_scale, sarStream_t stream);
+int sar_bn_bwd_reduce_x3(const void* dact, int dact_f32, const void* x, const float* saved, float* bbins, long R, int C, int relu,
+                         sarStream_t stream);
+int sar_bn_apply_x3_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, sarStream_t stream);
+int sar_cast_f32_x3(const float* x, void* y, void* y16, float scale, long n, sarStream_t stream);
+int sar_cast_x3_f32(const void* x, float* y, long n, sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a
