@@ -89,12 +89,14 @@ def get_conv_math():
     return {v: k for k, v in CONV_MATH.items()}[lib().fn["sar_get_conv_math"]()]
 
 
-GEMM_MATH = {"fp32": 0, "bf16": 1}
+GEMM_MATH = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 
 
 def set_gemm_math(mode):
-    """'fp32' (default) or 'bf16' (operands rounded to bf16 in the staging, bf16 MFMA, fp32 accumulate) for the Dense / GRU
-    projection GEMMs whose dimensions are multiples of 64; host-side, process-wide."""
+    """'fp32' (default), 'bf16' (operands rounded to bf16 in the staging, bf16 MFMA, fp32 accumulate) or 'bf16x3' (operands split into
+    hi / lo bf16 planes in the staging, three MFMAs per product block: fp32-class) for the Dense / GRU projection GEMMs whose extents
+    are multiples of 4 from 64 up; 'bf16' / 'bf16x3' also put the hidden_dim-256 GRU recurrence on the MFMA kernels (bf16 / fp16
+    operands); host-side, process-wide."""
     if lib().fn["sar_set_gemm_math"](GEMM_MATH[mode]) != 0:
         raise RuntimeError("sar_set_gemm_math failed")
 

@@ -211,20 +211,22 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
 #ifndef SAR_GEMM_UPFRONT
 #define SAR_GEMM_UPFRONT 1
 #endif
-struct GemmLds { unsigned char As[2][64 * GB_RS]; unsigned char Bs[2][64 * GB_RS]; float csum[4][64]; };
-// NGRP = 2 (round 3 EXPERIMENT, off: SAR_GEMM_GROUPS=2.  Measured: 2496 x 256 x 256 7.39 -> 7.15 us isolated, but 2496 x 768 x 256 9.9 -> 12.9 and the
-// train step 1.981 -> 1.996 ms -- the launches with more than 256 tiles already had two blocks per CU): 512 threads = two groups of four waves that take the even / the odd k-tiles of the slice,
-// each through its own pair of LDS buffers, in lockstep (the block-wide barriers serve both), and meet in LDS in front of the epilogue.  A
-// launch of the model's Dense / GRU-projection GEMMs is 156-468 tiles for 256 CUs, one block per CU with ONE wave per SIMD: nothing covers
-// a wave's waits (PMC: 46 % of its cycles in s_waitcnt / barriers, 32 % waiting to issue); two waves per SIMD and half the dependent
-// k-tile steps per wave do.
-template <bool A_KC, bool B_KC, bool TAIL, int NGRP = 1>
+// X3 (sar_set_gemm_math(2), the fp32-class "bf16x3" mode): the fp32 operands are split into hi = bf16(x) and lo = bf16(x - hi) while they are
+// staged (two LDS planes per operand) and a product block is three MFMAs, lo*hi + hi*lo + hi*hi -- 2^-17 relative per operand instead of
+// 2^-9.  Single-pass 2-byte operands in these GEMMs alone cost 1e-3 (fp16) / 7e-3 (bf16) on the accent probabilities
+// (tools/recipe_emulator.py: gemm_x / gemm_w), the whole of north_star's tolerance.
+template <bool X3> struct GemmLdsT { unsigned char As[2][X3 ? 2 : 1][64 * GB_RS]; unsigned char Bs[2][X3 ? 2 : 1][64 * GB_RS]; float csum[4][64]; };
+typedef GemmLdsT<false> GemmLds;
+// (Negative, round 3: 512-thread blocks -- two groups of four waves on the even / odd k-tiles, meeting in LDS -- 7.39 -> 7.15 us for the
+// 156-tile launch but 9.9 -> 12.9 for the 468-tile one and the step 1.981 -> 1.996 ms: the launches with more than 256 tiles already had two
+// blocks per CU.)
+template <bool A_KC, bool B_KC, bool TAIL, bool X3 = false>
 __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                const float* __restrict__ bias, float* __restrict__ colsum, int M, int N, int K, int lda, int ldb,
-                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLds* Ls) {
-    const int grp = NGRP == 2 ? (int)(threadIdx.x >> 8) : 0;
-    GemmLds& L = Ls[grp];
-    unsigned char (&As)[2][64 * GB_RS] = L.As; unsigned char (&Bs)[2][64 * GB_RS] = L.Bs; float (&csum)[4][64] = L.csum;
+                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLdsT<X3>* Ls) {
+    constexpr int NPL = X3 ? 2 : 1;
+    GemmLdsT<X3>& L = *Ls;
+    unsigned char (&As)[2][NPL][64 * GB_RS] = L.As; unsigned char (&Bs)[2][NPL][64 * GB_RS] = L.Bs; float (&csum)[4][64] = L.csum;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = by * BM, n0 = bx * BN;
     const int nkt = (K + GB_K - 1) / GB_K, per = (nkt + splitk - 1) / splitk;
@@ -268,23 +270,32 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
         // a k-tile past the slice (the pipeline's second half-step when the slice has an odd number of tiles) is staged as zeros: a
         // block-uniform branch -- as a multiplier on every element it was 32 of the ~90 VALU instructions a thread spends per k-tile,
         // and this kernel is bound by exactly those (tools/gemm_group_bench.py: ~500 cycles per k-tile and SIMD for 128 of MFMA)
-        unsigned wa[8], wb[8];
+        unsigned wa[8], wb[8], la[8], lb[8];
+        // X3: the lo word of two neighbours = bf16 of what the hi word left over
+        auto lo2 = [](float x, float y, unsigned h) __attribute__((always_inline)) { return gpack2(x - __uint_as_float(h << 16), y - __uint_as_float(h & 0xffff0000u)); };
         if (kt < kt1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 a = ra[set][i], b = rb[set][i];
                 wa[2 * i] = gpack2(a.x, a.y); wa[2 * i + 1] = gpack2(a.z, a.w);
                 wb[2 * i] = gpack2(b.x, b.y); wb[2 * i + 1] = gpack2(b.z, b.w);
+                if constexpr (X3) {
+                    la[2 * i] = lo2(a.x, a.y, wa[2 * i]); la[2 * i + 1] = lo2(a.z, a.w, wa[2 * i + 1]);
+                    lb[2 * i] = lo2(b.x, b.y, wb[2 * i]); lb[2 * i + 1] = lo2(b.z, b.w, wb[2 * i + 1]);
+                }
                 if (do_colsum) { cs[4 * i] += b.x; cs[4 * i + 1] += b.y; cs[4 * i + 2] += b.z; cs[4 * i + 3] += b.w; }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { wa[i] = 0u; wb[i] = 0u; }
+            for (int i = 0; i < 8; ++i) { wa[i] = 0u; wb[i] = 0u; la[i] = 0u; lb[i] = 0u; }
         }
-        unsigned char* da = As[buf] + srow * GB_RS + sseg * 2;
-        unsigned char* db = Bs[buf] + srow * GB_RS + sseg * 2;
-        *reinterpret_cast<uint4*>(da) = make_uint4(wa[0], wa[1], wa[2], wa[3]); *reinterpret_cast<uint4*>(da + 16) = make_uint4(wa[4], wa[5], wa[6], wa[7]);
-        *reinterpret_cast<uint4*>(db) = make_uint4(wb[0], wb[1], wb[2], wb[3]); *reinterpret_cast<uint4*>(db + 16) = make_uint4(wb[4], wb[5], wb[6], wb[7]);
+        const unsigned so = srow * GB_RS + sseg * 2;
+        *reinterpret_cast<uint4*>(As[buf][0] + so) = make_uint4(wa[0], wa[1], wa[2], wa[3]); *reinterpret_cast<uint4*>(As[buf][0] + so + 16) = make_uint4(wa[4], wa[5], wa[6], wa[7]);
+        *reinterpret_cast<uint4*>(Bs[buf][0] + so) = make_uint4(wb[0], wb[1], wb[2], wb[3]); *reinterpret_cast<uint4*>(Bs[buf][0] + so + 16) = make_uint4(wb[4], wb[5], wb[6], wb[7]);
+        if constexpr (X3) {
+            *reinterpret_cast<uint4*>(As[buf][NPL - 1] + so) = make_uint4(la[0], la[1], la[2], la[3]); *reinterpret_cast<uint4*>(As[buf][NPL - 1] + so + 16) = make_uint4(la[4], la[5], la[6], la[7]);
+            *reinterpret_cast<uint4*>(Bs[buf][NPL - 1] + so) = make_uint4(lb[0], lb[1], lb[2], lb[3]); *reinterpret_cast<uint4*>(Bs[buf][NPL - 1] + so + 16) = make_uint4(lb[4], lb[5], lb[6], lb[7]);
+        }
     };
     f32x16 acc, acc2;
 #pragma unroll
@@ -302,20 +313,17 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
     auto gmma = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const gbf16x8 a = frag(As[buf], A_KC, wm, ks), b = frag(Bs[buf], B_KC, wn, ks);
-            if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
+            const gbf16x8 a = frag(As[buf][0], A_KC, wm, ks), b = frag(Bs[buf][0], B_KC, wn, ks);
+            if constexpr (X3) {                                      // small terms first; the two accumulators alternate
+                const gbf16x8 al = frag(As[buf][NPL - 1], A_KC, wm, ks), bl = frag(Bs[buf][NPL - 1], B_KC, wn, ks);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc2, 0, 0, 0);
+            } else if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     };
-    constexpr int KS = NGRP;                                          // this group's k-tiles: kt0 + grp, + KS, + 2 KS, ...
-    if (NGRP == 2 && kt1 - kt0 <= 4) {
-        gload(0, kt0 + grp); gload(1, kt0 + grp + 2);                  // both tiles of the group at once (tiles past the slice: staged as zeros)
-        gstore(0, 0, kt0 + grp);
-        __syncthreads();
-        gmma(0); gstore(1, 1, kt0 + grp + 2);
-        __syncthreads();
-        gmma(1);
-    } else if (NGRP == 1 && SAR_GEMM_UPFRONT && kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
+    if (SAR_GEMM_UPFRONT && kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
         // Short k-loops (K = 256 per slice: every Dense / GRU-projection GEMM of the model at hidden_dim 256): ALL k-tiles are requested at
         // once -- one round trip.  The rotating form below keeps two tiles in flight, so a slice of four tiles pays the latency of an operand
         // that the previous kernel left behind the fabric (~2 800 cycles: nothing a launch reads first is in its XCD's L2) twice over.
@@ -330,36 +338,18 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
         __syncthreads();
         gmma(1);
     } else if (kt0 < kt1) {
-        const int k0 = kt0 + grp;
-        gload(0, k0); gload(1, k0 + KS);
-        gstore(0, 0, k0); gload(0, k0 + 2 * KS);
+        gload(0, kt0); gload(1, kt0 + 1);
+        gstore(0, 0, kt0); gload(0, kt0 + 2);
         __syncthreads();
-        for (int kt = kt0; kt < kt1; kt += 2 * KS) {                  // (the bound is the same for both groups: their barriers are shared)
-            const int kg = kt + grp;
-            gmma(0); gstore(1, 1, kg + KS); gload(1, kg + 3 * KS);
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            gmma(0); gstore(1, 1, kt + 1); gload(1, kt + 3);
             __syncthreads();
-            gmma(1); gstore(0, 0, kg + 2 * KS); gload(0, kg + 4 * KS);
+            gmma(1); gstore(0, 0, kt + 2); gload(0, kt + 4);
             __syncthreads();
         }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
-    if constexpr (NGRP == 2) {                                       // the odd-tile group hands its accumulators over: [4 register quads][wave][lane] float4
-        __syncthreads();                                              // (every wave is done with the operand buffers)
-        float4* mg = reinterpret_cast<float4*>(Ls[1].As[0]);
-        if (grp == 1) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mg[(i * 4 + wave) * 64 + lane] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
-        }
-        __syncthreads();
-        if (grp == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = mg[(i * 4 + wave) * 64 + lane];
-                acc[4 * i] += v.x; acc[4 * i + 1] += v.y; acc[4 * i + 2] += v.z; acc[4 * i + 3] += v.w;
-            }
-        }
-    }
     if (do_colsum) {                                  // threads with equal tid % 4 hold the same 16 columns
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -368,13 +358,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             if (lane < 4) csum[wave][lane * 16 + i] = v;
         }
         __syncthreads();
-        if (grp == 0 && tid < 64 && (!TAIL || n0 + tid < N)) {
-            float v = csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid];
-            if constexpr (NGRP == 2) v += Ls[1].csum[0][tid] + Ls[1].csum[1][tid] + Ls[1].csum[2][tid] + Ls[1].csum[3][tid];
+        if (tid < 64 && (!TAIL || n0 + tid < N)) {
+            const float v = csum[0][tid] + csum[1][tid] + csum[2][tid] + csum[3][tid];
             atomicAdd(colsum + n0 + tid, v);
         }
     }
-    if (NGRP == 2 && grp == 1) return;                                // the epilogue is the even-tile group's
     const int col = n0 + wn * 32 + (lane & 31);
     if (TAIL && col >= N) return;
 #pragma unroll
@@ -404,16 +392,22 @@ __device__ __forceinline__ unsigned xcd_order(unsigned l, unsigned total) {
     return l < body ? (l & 7u) * chunk + (l >> 3) : l;
 }
 
-template <bool A_KC, bool B_KC, bool TAIL = false, int NGRP = 1>
-__global__ __launch_bounds__(256 * NGRP) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
+// (X3: 73 KB of LDS -- past the 64 KB a static allocation may have: the launcher passes it as dynamic LDS)
+extern __shared__ __attribute__((aligned(16))) unsigned char gemm_dyn_lds[];
+template <bool X3> __device__ __forceinline__ GemmLdsT<X3>* gemm_lds() {
+    if constexpr (X3) return reinterpret_cast<GemmLdsT<true>*>(gemm_dyn_lds);
+    else { __shared__ __attribute__((aligned(16))) GemmLdsT<false> L; return &L; }
+}
+template <bool A_KC, bool B_KC, bool TAIL = false, bool X3 = false>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
                                                         int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
     const unsigned nbx = gridDim.x, nby = gridDim.y;
     const unsigned t = xcd_order(blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z), nbx * nby * gridDim.z);
     const int bx = (int)(t % nbx), by = (int)(t / nbx % nby), z = (int)(t / (nbx * nby));
     const int bz = z / splitk, kz = z - bz * splitk;
-    __shared__ __attribute__((aligned(16))) GemmLds L[NGRP];
-    gemm_bf16_tile<A_KC, B_KC, TAIL, NGRP>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
-                                           bx, by, kz, L);
+    GemmLdsT<X3>* L = gemm_lds<X3>();
+    gemm_bf16_tile<A_KC, B_KC, TAIL, X3>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
+                                         bx, by, kz, L);
 }
 
 // Weight gradients of MANY Dense / GRU kernels in one launch (they are off the critical path of the backward pass: the host collects
@@ -422,8 +416,9 @@ __global__ __launch_bounds__(256 * NGRP) void gemm_bf16_kernel(const GemmBatch g
 // pack_weights_kernel), then runs the same tile code as sar_gemm_wgrad_f32.  Launches of 7-35 us that each filled a fraction of
 // the chip become one.
 struct WgRow { const float* X; const float* dY; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk, first_block; };   // 64 bytes
+template <bool X3>
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow* __restrict__ tab, int n) {
-    __shared__ __attribute__((aligned(16))) GemmLds L;
+    GemmLdsT<X3>* L = gemm_lds<X3>();
     int r = -1;
     for (int base = 0; base < n; base += 64) {
         const int q = base + (threadIdx.x & 63);
@@ -435,17 +430,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
     const int local = (int)xcd_order(blockIdx.x - p.first_block, (unsigned)(nbx * nby * p.splitk));   // first_block % 8 == 0 (the plan pads)
     const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
     if (kz >= p.splitk) return;                                      // padding blocks of the plan
-    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, &L);
-    else gemm_bf16_tile<false, false, false>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, &L);
+    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true, X3>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
+    else gemm_bf16_tile<false, false, false, X3>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
 }
 
 }  // namespace
 
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = bf16 MFMA with fp32 accumulate for 64-aligned problems (the "bf16" mode of
-// BASELINE configs[1]; SAR_GEMM_MATH=bf16).  Host-side, process-wide.
-static int g_gemm_math = (getenv("SAR_GEMM_MATH") && !strcmp(getenv("SAR_GEMM_MATH"), "bf16")) ? 1 : 0;
-static const int g_gemm_groups = (getenv("SAR_GEMM_GROUPS") && atoi(getenv("SAR_GEMM_GROUPS")) == 2) ? 2 : 1;   // k-groups of the bf16 single-problem launches (2: the 512-thread experiment below, measured slower)
-extern "C" int sar_set_gemm_math(int mode) { if (mode < 0 || mode > 1) return SAR_EINVAL; g_gemm_math = mode; return SAR_OK; }
+// BASELINE configs[1]; SAR_GEMM_MATH=bf16), 2 = the same kernels in split precision (three bf16 MFMAs per product block; the
+// fp32-class "bf16x3" mode; SAR_GEMM_MATH=bf16x3).  Host-side, process-wide.
+static int g_gemm_math = !getenv("SAR_GEMM_MATH") ? 0 : !strcmp(getenv("SAR_GEMM_MATH"), "bf16") ? 1 : !strcmp(getenv("SAR_GEMM_MATH"), "bf16x3") ? 2 : 0;
+extern "C" int sar_set_gemm_math(int mode) { if (mode < 0 || mode > 2) return SAR_EINVAL; g_gemm_math = mode; return SAR_OK; }
+// launch of an X3 instantiation: its LDS is dynamic and past 64 KB (raised once per device)
+template <typename KT, typename... Args>
+static int launch_x3(KT kern, PerDeviceFlag& flag, dim3 grid, hipStream_t stream, Args... args) {
+    const size_t lds = sizeof(GemmLdsT<true>);
+    if (!flag) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SAR_ELAUNCH;
+        flag = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, args...);
+    return SAR_OK;
+}
 extern "C" int sar_get_gemm_math(void) { return g_gemm_math; }
 
 // C-ABI: see include/sarnet.h
@@ -464,11 +470,12 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     // bf16 MFMA path with tails: extents and row strides that are multiples of 4, from 64 up (smaller problems keep the fp32 kernel)
     const bool pieces = ((M | N | K | lda | ldb) & 3) == 0 && aligned;
     const bool whole = pieces && M % 64 == 0 && N % 64 == 0 && K % 64 == 0;
-    const bool tail16 = g_gemm_math == 1 && pieces && !whole && M >= 64 && N >= 64 && K >= 64 && (K + 63) / 64 >= splitk;
+    const bool tail16 = g_gemm_math >= 1 && pieces && !whole && M >= 64 && N >= 64 && K >= 64 && (K + 63) / 64 >= splitk;
+    const bool x3 = g_gemm_math == 2;
     if (tail16) {
         grid.x = cdiv(N, 64); grid.y = cdiv(M, 64);
 #define LAUNCH16T(AK, BK_)                                                                                           \
-    do { if (g_gemm_groups == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true, 2>), grid, dim3(512), 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); \
+    do { if (x3) { static PerDeviceFlag fl; const int rc = launch_x3(gemm_bf16_kernel<AK, BK_, true, true>, fl, grid, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); if (rc != SAR_OK) return rc; } \
          else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); } while (0)
         if (a_kc && b_kc) LAUNCH16T(true, true);
         else if (a_kc && !b_kc) LAUNCH16T(true, false);
@@ -478,9 +485,9 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
-    if (g_gemm_math == 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && aligned && K / 64 >= splitk) {
+    if (g_gemm_math >= 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && aligned && K / 64 >= splitk) {
 #define LAUNCH16(AK, BK_)                                                                                            \
-    do { if (g_gemm_groups == 2) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, false, 2>), grid, dim3(512), 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); \
+    do { if (x3) { static PerDeviceFlag fl; const int rc = launch_x3(gemm_bf16_kernel<AK, BK_, false, true>, fl, grid, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); if (rc != SAR_OK) return rc; } \
          else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); } while (0)
         if (a_kc && b_kc) LAUNCH16(true, true);
         else if (a_kc && !b_kc) LAUNCH16(true, false);
@@ -544,7 +551,7 @@ extern "C" int sar_gemm_wgrad_batched_f32(const sarGemmBatch* b, int nbatch, int
 // the caller then launches them one by one) and writes the device table rows (64 bytes each) + the grid size.
 struct sarGemmWgrad { const float* X; const float* dY; float* dW; float* db; int in_dim, out_dim, R, lda, ldb, ldc, splitk, pad_; };
 extern "C" int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void* table_out, int* total_blocks) {
-    if (!probs || n < 1 || n > 4096 || !table_out || !total_blocks || g_gemm_math != 1) return SAR_EINVAL;
+    if (!probs || n < 1 || n > 4096 || !table_out || !total_blocks || g_gemm_math < 1) return SAR_EINVAL;
     WgRow* rows = static_cast<WgRow*>(table_out);
     long blk = 0;
     for (int i = 0; i < n; ++i) {
@@ -563,8 +570,14 @@ extern "C" int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void*
     return SAR_OK;
 }
 extern "C" int sar_gemm_wgrad_group_f32(const void* table_dev, int n, int total_blocks, hipStream_t stream) {
-    if (!table_dev || n < 1 || total_blocks < 1 || g_gemm_math != 1) return SAR_EINVAL;
-    hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel, dim3(total_blocks), dim3(256), 0, stream, static_cast<const WgRow*>(table_dev), n);
+    if (!table_dev || n < 1 || total_blocks < 1 || g_gemm_math < 1) return SAR_EINVAL;
+    if (g_gemm_math == 2) {
+        static PerDeviceFlag fl;
+        const int rc = launch_x3(gemm_bf16_wgrad_group_kernel<true>, fl, dim3(total_blocks), stream, static_cast<const WgRow*>(table_dev), n);
+        if (rc != SAR_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel<false>, dim3(total_blocks), dim3(256), 0, stream, static_cast<const WgRow*>(table_dev), n);
+    }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -17,8 +17,26 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// The 2-byte type of the two MFMA operands.  This file is compiled twice: as it is (bf16: the "bf16" GEMM mode; sar_bigru_*_bf16) and with
+// -DSAR_GRU_HALF=1 (IEEE fp16: the fp32-class "bf16x3" mode; sar_bigru_*_f16).  |U| <= 1 (orthogonal init, model.py:44-50) and |h| < 1, so
+// fp16's range is no issue forward and its 11-bit mantissa puts 1.3e-4 on the accent probabilities where bf16 puts 1.1e-3
+// (tools/recipe_emulator.py: gru_u / gru_h) -- a single-pass recurrence inside north_star's 1e-3, with U still resident on chip (hi / lo
+// planes of U would not fit one CU).  BPTT's operand, the pre-activation gradients, is small (1e-6 .. 1e-2): the fp16 build multiplies it
+// by the caller's power-of-two scale `gs` on its way into LDS and the product by 1 / gs.
+#ifndef SAR_GRU_HALF
+#define SAR_GRU_HALF 0
+#endif
+#if SAR_GRU_HALF
+typedef _Float16 g16;
+#define GRU_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define GRU_ENTRY(name) name##_f16
+#else
+typedef __bf16 g16;
+#define GRU_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define GRU_ENTRY(name) name##_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) g16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) g16 bf16x2;
 
 constexpr int GH = 256, GH3 = 768;      // hidden units, gate columns
 constexpr int GNR = 16;                 // batch rows per workgroup (the N of the 16x16x32 MFMA)
@@ -29,7 +47,7 @@ constexpr int HS_STRIDE = GH * 2 + 16;  // bytes per row of the bf16 h image (16
 constexpr int AS_STRIDE = GH3 * 2 + 16; // bytes per row of the bf16 pre-activation-gradient image
 
 __device__ __forceinline__ unsigned pk2(float a, float b) {
-    bf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+    bf16x2 p; p[0] = (g16)a; p[1] = (g16)b;
     return __builtin_bit_cast(unsigned, p);
 }
 // sigmoid / tanh on v_exp_f32 + v_rcp_f32 (~1e-7 relative): a lane owns 8 (row, unit) pairs per step here, and libm's expf / tanhf
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(512) void gru_mfma_fwd_kernel(const float* __restri
             for (int tl = 0; tl < 6; ++tl) {                    // tile tl = u*3 + g
                 const int f = tl * 8 + ks;
                 const bf16x8 Af = f < GREG ? A[f < GREG ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GREG) * 64 + lane]);
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[tl], 0, 0, 0);
+                acc[tl] = GRU_MFMA(Af, Bf, acc[tl], 0, 0, 0);
             }
         }
         // gate math in the accumulator layout
@@ -152,7 +170,7 @@ __global__ __launch_bounds__(512) void gru_mfma_fwd_kernel(const float* __restri
 // dynamic LDS: A-fragments [8][16][64][16 B] (128 KB) | As [16 rows][AS_STRIDE]
 __global__ __launch_bounds__(512) void gru_mfma_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
                                                            const float* __restrict__ hprev, const uint4* __restrict__ pack,
-                                                           float* __restrict__ dai, float* __restrict__ dah, int B, int L, int rows) {
+                                                           float* __restrict__ dai, float* __restrict__ dah, int B, int L, int rows, float gs, float gsi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * rows, n = lane & 15, q4 = lane >> 4, b = b0 + n;
@@ -216,9 +234,9 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd_kernel(const float* __restri
                 *reinterpret_cast<f32x4*>(dah_d + oo) = daz; *reinterpret_cast<f32x4*>(dah_d + oo + GH) = dar; *reinterpret_cast<f32x4*>(dah_d + oo + 2 * GH) = a2;
             }
             unsigned char* ar = As + n * AS_STRIDE + (jl + 16 * u) * 2;
-            *reinterpret_cast<uint2*>(ar) = make_uint2(pk2(daz[0], daz[1]), pk2(daz[2], daz[3]));
-            *reinterpret_cast<uint2*>(ar + GH * 2) = make_uint2(pk2(dar[0], dar[1]), pk2(dar[2], dar[3]));
-            *reinterpret_cast<uint2*>(ar + 2 * GH * 2) = make_uint2(pk2(a2[0], a2[1]), pk2(a2[2], a2[3]));
+            *reinterpret_cast<uint2*>(ar) = make_uint2(pk2(daz[0] * gs, daz[1] * gs), pk2(daz[2] * gs, daz[3] * gs));
+            *reinterpret_cast<uint2*>(ar + GH * 2) = make_uint2(pk2(dar[0] * gs, dar[1] * gs), pk2(dar[2] * gs, dar[3] * gs));
+            *reinterpret_cast<uint2*>(ar + 2 * GH * 2) = make_uint2(pk2(a2[0] * gs, a2[1] * gs), pk2(a2[2] * gs, a2[3] * gs));
         }
         wg_sync();
         fetch(s - 1, cur);                                        // the saved activations of the next step: in flight under the MFMAs
@@ -230,13 +248,13 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd_kernel(const float* __restri
             for (int u = 0; u < 2; ++u) {
                 const int f = u * 24 + ks;
                 const bf16x8 Af = f < GREG ? A[f < GREG ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GREG) * 64 + lane]);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[u], 0, 0, 0);
+                acc[u] = GRU_MFMA(Af, Bf, acc[u], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dh[u][r] += acc[u][r];
+            for (int r = 0; r < 4; ++r) dh[u][r] += acc[u][r] * gsi;
         wg_sync();                                                // everyone is done with As before the next step rewrites it
     }
 }
@@ -257,7 +275,7 @@ __device__ __forceinline__ float compact4(const f32x4 a) {
     v = __builtin_amdgcn_update_dpp(v, __float_as_int(a[3]), 0x11C, 0xf, 0x8, false);
     return __builtin_bit_cast(float, v);
 }
-__device__ __forceinline__ unsigned short bf1(float a) { return __builtin_bit_cast(unsigned short, (__bf16)a); }
+__device__ __forceinline__ unsigned short bf1(float a) { return __builtin_bit_cast(unsigned short, (g16)a); }
 
 // ALL: every lane's batch row exists (rows == 4, B % 4 == 0): the stores are unconditional, so the compiler can count them -- behind a
 // divergent `if (row_ok)` it cannot, and waits for vmcnt(0) wherever it needs the prefetched loads.
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(512) void gru_mfma_fwd4_kernel(const float* __restr
             for (int tl = 0; tl < 6; ++tl) {
                 const int f = tl * 8 + ks;
                 const bf16x8 Af = f < GR4F ? A[f < GR4F ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GR4F) * 64 + lane]);
-                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[tl], 0, 0, 0);
+                acc[tl] = GRU_MFMA(Af, Bf, acc[tl], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(512) void gru_mfma_fwd4_kernel(const float* __restr
 template <bool ALL>
 __global__ __launch_bounds__(512) void gru_mfma_bwd4_kernel(const float* __restrict__ dout, const float* __restrict__ gates,
                                                             const float* __restrict__ hprev, const uint4* __restrict__ pack,
-                                                            float* __restrict__ dai, float* __restrict__ dah, int B, int L, int rows) {
+                                                            float* __restrict__ dai, float* __restrict__ dah, int B, int L, int rows, float gs, float gsi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int d = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * rows, n = lane & 15, q4 = lane >> 4;
@@ -420,9 +438,9 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd4_kernel(const float* __restr
                 dah_d[oo] = daz; dah_d[oo + GH] = dar; dah_d[oo + 2 * GH] = a2;
             }
             unsigned char* ar = As + (size_t)(s & 1) * 5 * AS_STRIDE + nb * AS_STRIDE + (j0 + 16 * u) * 2;
-            *reinterpret_cast<unsigned short*>(ar) = bf1(daz);
-            *reinterpret_cast<unsigned short*>(ar + GH * 2) = bf1(dar);
-            *reinterpret_cast<unsigned short*>(ar + 2 * GH * 2) = bf1(a2);
+            *reinterpret_cast<unsigned short*>(ar) = bf1(daz * gs);
+            *reinterpret_cast<unsigned short*>(ar + GH * 2) = bf1(dar * gs);
+            *reinterpret_cast<unsigned short*>(ar + 2 * GH * 2) = bf1(a2 * gs);
         }
         wg_sync();
         f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};   // [u][k-step parity]: four chains of 12
@@ -434,11 +452,11 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd4_kernel(const float* __restr
             for (int u = 0; u < 2; ++u) {
                 const int f = u * 24 + ks;
                 const bf16x8 Af = f < GR4B ? A[f < GR4B ? f : 0] : __builtin_bit_cast(bf16x8, Al[(f - GR4B) * 64 + lane]);
-                acc[u][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Af, Bf, acc[u][ks & 1], 0, 0, 0);
+                acc[u][ks & 1] = GRU_MFMA(Af, Bf, acc[u][ks & 1], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { dh[u] += compact4(acc[u][0] + acc[u][1]); cur[u] = nxt[u]; }
+        for (int u = 0; u < 2; ++u) { dh[u] += compact4(acc[u][0] + acc[u][1]) * gsi; cur[u] = nxt[u]; }
     }
 }
 
@@ -457,7 +475,7 @@ static int gru_rows(int B) {
 
 // U (H, 3H) fp32 of both directions -> the bf16 A-fragment streams of the two kernels below; once per optimiser step.
 // pack: 2 * 2 * 3H * H bf16 (1.5 MB at H = 256).
-extern "C" int sar_bigru_pack_bf16(const float* U_fwd, const float* U_bwd, void* pack, int H, hipStream_t stream) {
+extern "C" int GRU_ENTRY(sar_bigru_pack)(const float* U_fwd, const float* U_bwd, void* pack, int H, hipStream_t stream) {
     if (!U_fwd || !U_bwd || !pack || H != GH) return SAR_EINVAL;
     hipLaunchKernelGGL(gru_pack_kernel, dim3(2 * 2 * GNW * GFR * 64 / 256), dim3(256), 0, stream, U_fwd, U_bwd, static_cast<uint4*>(pack));
     SAR_CHECK_LAUNCH();
@@ -465,7 +483,7 @@ extern "C" int sar_bigru_pack_bf16(const float* U_fwd, const float* U_bwd, void*
 }
 
 // Same contract as sar_bigru_fwd_f32 (H = 256 only) with the recurrent matmul on bf16 MFMA from the packed kernel.
-extern "C" int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, const void* pack, const float* bh_fwd, const float* bh_bwd,
+extern "C" int GRU_ENTRY(sar_bigru_fwd)(const float* xa_fwd, const float* xa_bwd, const void* pack, const float* bh_fwd, const float* bh_bwd,
                                   float* out, float* gates, float* hprev, int B, int L, int H, hipStream_t stream) {
     if (!xa_fwd || !xa_bwd || !pack || !bh_fwd || !bh_bwd || !out || !gates || !hprev || H != GH || B < 1 || L < 1) return SAR_EINVAL;
     const size_t lds = (size_t)GNW * (GFR - GREG) * 1024 + 2 * GNR * HS_STRIDE + GH3 * 4;
@@ -489,8 +507,17 @@ extern "C" int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, cons
 }
 
 // Same contract as sar_bigru_bwd_f32 (H = 256 only; no transposed kernels needed: the pack holds both orientations).
+#if SAR_GRU_HALF
+// gscale: power-of-two scale of the pre-activation gradients as the fp16 MFMA sees them (the caller's static gradient scale, e.g. 64 x batch)
+extern "C" int sar_bigru_bwd_f16(const float* dout, const float* gates, const float* hprev, const void* pack, float* dai, float* dah,
+                                 int B, int L, int H, float gscale, hipStream_t stream) {
+    if (!(gscale > 0.f)) return SAR_EINVAL;
+    const float gs = gscale, gsi = 1.f / gscale;
+#else
 extern "C" int sar_bigru_bwd_bf16(const float* dout, const float* gates, const float* hprev, const void* pack, float* dai, float* dah,
                                   int B, int L, int H, hipStream_t stream) {
+    const float gs = 1.f, gsi = 1.f;
+#endif
     if (!dout || !gates || !hprev || !pack || !dai || !dah || H != GH || B < 1 || L < 1) return SAR_EINVAL;
     const size_t lds = (size_t)GNW * (GFR - GREG) * 1024 + GNR * AS_STRIDE;
     static PerDeviceFlag attr;
@@ -507,7 +534,7 @@ extern "C" int sar_bigru_bwd_bf16(const float* dout, const float* gates, const f
     }
     const bool all = rows == 4 && B % 4 == 0;
     hipLaunchKernelGGL(rows > 4 ? gru_mfma_bwd_kernel : all ? gru_mfma_bwd4_kernel<true> : gru_mfma_bwd4_kernel<false>, dim3(cdiv(B, rows), 2), dim3(512), lds, stream, dout, gates, hprev, static_cast<const uint4*>(pack),
-                       dai, dah, B, L, rows);
+                       dai, dah, B, L, rows, gs, gsi);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

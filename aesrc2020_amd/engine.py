@@ -136,7 +136,7 @@ class ParamStore:
     # mode the layers hand them over here and ONE grouped launch (csrc/gemm.hip: gemm_bf16_wgrad_group_kernel) runs them behind the
     # last input gradient -- 5 (cfg2) to 10 (cfg3) launches of 7-35 us that each filled a fraction of the chip
     def begin_deferred_wgrads(self):
-        self._defer = [] if (self.training and _lib.get_gemm_math() == "bf16" and os.environ.get("SAR_WGRAD_GROUP", "1") == "1") else None
+        self._defer = [] if (self.training and _lib.get_gemm_math() in ("bf16", "bf16x3") and os.environ.get("SAR_WGRAD_GROUP", "1") == "1") else None
 
     def deferring_wgrads(self):
         return self.__dict__.get("_defer") is not None

@@ -158,11 +158,14 @@ class BiGRU(Layer):
         self.out = self.buf("out", (B, L, 2 * H)); self.gates = self.buf("gates", (2, B, L, 4, H)); self.hprev = self.buf("hprev", (2, B, L, H))
         (kf, uf, bf), (kb, ub, bb) = self.p["forward"], self.p["backward"]
         # "bf16" mode at the reference's hidden_dim: recurrent kernels packed as bf16 MFMA fragments, resident on chip (gru_mfma.hip)
-        self.mfma = H == 256 and _lib.get_gemm_math() == "bf16"
+        # "bf16x3" (fp32-class) mode: the same kernels with fp16 operands (|U| <= 1, |h| < 1: 1.3e-4 on the outputs, tools/recipe_emulator.py)
+        gm = _lib.get_gemm_math()
+        self.mfma = H == 256 and gm in ("bf16", "bf16x3")
+        self.msfx = "f16" if gm == "bf16x3" else "bf16"
         if self.mfma:
-            self.pack = self.buf("u_pack", (2 * 2 * 3 * H * H,), torch.bfloat16)
-            _call("sar_bigru_pack_bf16", uf.w, ub.w, self.pack, H)
-            _call("sar_bigru_fwd_bf16", xa[0], xa[1], self.pack, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
+            self.pack = self.buf("u_pack", (2 * 2 * 3 * H * H,), torch.float16 if self.msfx == "f16" else torch.bfloat16)
+            _call("sar_bigru_pack_" + self.msfx, uf.w, ub.w, self.pack, H)
+            _call("sar_bigru_fwd_" + self.msfx, xa[0], xa[1], self.pack, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
         else:
             _call("sar_bigru_fwd_f32", xa[0], xa[1], uf.w, ub.w, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
         if self.seq:
@@ -184,7 +187,10 @@ class BiGRU(Layer):
             dai = self.buf("dai", (2, B, L, 3 * H)); dah = self.buf("dah", (2, B, L, 3 * H))
         else:
             dai = self.scratch("gru_dai%d_%d_%d" % (B, L, H), (2, B, L, 3 * H)); dah = self.scratch("gru_dah%d_%d_%d" % (B, L, H), (2, B, L, 3 * H))
-        if self.mfma:
+        if self.mfma and self.msfx == "f16":
+            # fp16 operands: the pre-activation gradients enter the MFMA times a power-of-two scale (the trunk's rule: 64 x batch)
+            _call("sar_bigru_bwd_f16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H, float(2 ** int(round(np.log2(64.0 * max(B, 1))))))
+        elif self.mfma:
             _call("sar_bigru_bwd_bf16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H)
         else:
             UT = [self.scratch("gru_UT0_%d" % H, (3 * H, H)), self.scratch("gru_UT1_%d" % H, (3 * H, H))]

@@ -356,8 +356,9 @@ DTYPES = {
                                        "Dense / GRU-projection GEMMs), fp32 accumulate, statistics, recurrence, losses and master weights"),
     "fp16": ("fp16", "bf16x3", "bf16", "fp16 activations / activation gradients of the conv trunk in HBM (static gradient scale), single-pass fp16 MFMA in the "
                                        "convs; bf16 MFMA in the Dense / GRU-projection GEMMs; fp32 accumulate, statistics, recurrence, losses and master weights"),
-    "bf16x3": ("bf16x3", "bf16x3", "fp32", "split precision on the 2-byte kernel architecture: every trunk tensor a (hi, lo) pair of bf16 planes in HBM, three bf16 MFMAs per "
-                                           "product block (2^-17 relative per operand), fp32 accumulate, statistics, losses and master weights; weight gradients single-pass fp16 on fp16 copies"),
+    "bf16x3": ("bf16x3", "bf16x3", "bf16x3", "split precision on the 2-byte kernel architecture: every trunk tensor a (hi, lo) pair of bf16 planes in HBM, three bf16 MFMAs per "
+                                           "product block (2^-17 relative per operand) in the convs and the Dense / GRU-projection GEMMs, fp32 accumulate, statistics, losses and master weights; "
+                                             "conv weight gradients and the GRU recurrence single-pass fp16"),
     "bf16x3_r1": ("fp32", "bf16x3", "fp32", "round 1's kernels: fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),
     "f32": ("fp32", "fp32", "fp32", "fp32 in HBM, fp32 MFMA"),
 }

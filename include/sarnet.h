@@ -384,6 +384,15 @@ int sar_bigru_fwd_bf16(const float* xa_fwd, const float* xa_bwd, const void* pac
                        float* out, float* gates, float* hprev, int B, int L, int H, sarStream_t stream);
 int sar_bigru_bwd_bf16(const float* dout, const float* gates, const float* hprev, const void* pack, float* dai, float* dah,
                        int B, int L, int H, sarStream_t stream);
+/* The same recurrence with IEEE fp16 as the two MFMA operands' type (csrc/gru_mfma.hip compiled with -DSAR_GRU_HALF; the fp32-class
+ * "bf16x3" mode): |U| <= 1 and |h| < 1, so fp16's 11-bit mantissa costs 1.3e-4 on the accent probabilities where bf16 costs 1.1e-3
+ * (tools/recipe_emulator.py) and U still fits on chip in one pass.  BPTT's pre-activation gradients enter the MFMA times `gscale` (a power
+ * of two, e.g. 64 x batch; the product is divided by it again) because fp16 has five exponent bits. */
+int sar_bigru_pack_f16(const float* U_fwd, const float* U_bwd, void* pack, int H, sarStream_t stream);
+int sar_bigru_fwd_f16(const float* xa_fwd, const float* xa_bwd, const void* pack, const float* bh_fwd, const float* bh_bwd,
+                      float* out, float* gates, float* hprev, int B, int L, int H, sarStream_t stream);
+int sar_bigru_bwd_f16(const float* dout, const float* gates, const float* hprev, const void* pack, float* dai, float* dah,
+                      int B, int L, int H, float gscale, sarStream_t stream);
 int sar_bigru_last_fwd_f32(const float* out, float* y, int B, int L, int H, sarStream_t stream); /* seq=False, model.py:128 */
 int sar_bigru_last_bwd_f32(const float* dy, float* dout, int B, int L, int H, sarStream_t stream);
 

@@ -40,7 +40,7 @@ CASES = {
     "b4_t200": dict(input_shape=[200, 80, 1], res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8,
                     ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=50, max_ctc_len=8, metric_loss="circleloss", B=4),
 }
-MODES = {"x3": ("bf16x3", "bf16x3", "fp32"), "f32": ("fp32", "fp32", "fp32"), "bf16x3": ("fp32", "bf16x3", "fp32"), "bf16": ("bf16", "bf16x3", "bf16"), "fp16": ("fp16", "bf16x3", "bf16"),
+MODES = {"x3": ("bf16x3", "bf16x3", "bf16x3"), "x3+g32": ("bf16x3", "bf16x3", "fp32"), "f32": ("fp32", "fp32", "fp32"), "bf16x3": ("fp32", "bf16x3", "fp32"), "bf16": ("bf16", "bf16x3", "bf16"), "fp16": ("fp16", "bf16x3", "bf16"),
          "bf16+g32": ("bf16", "bf16x3", "fp32"), "fp16+g32": ("fp16", "bf16x3", "fp32")}
 
 
