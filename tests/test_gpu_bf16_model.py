@@ -25,7 +25,11 @@ from oracle import model_torch as MT
 pytestmark = pytest.mark.gpu
 
 # per recipe: max |d prob| accent, disc; CTC relative; min gradient cosine; flat-gradient relative L2
-BOUNDS = {"fp16": dict(accent=2e-2, disc=4e-2, ctc=4e-3, cos=0.98, l2=1.6e-1),
+# "bf16x3" (round 4): the same kernels in split precision (hi / lo bf16 planes, three MFMAs per product block; Dense / GRU-projection GEMMs
+# likewise, GRU recurrence on fp16 operands) -- the fp32-class mode, held to north_star's 1e-3 on the outputs.  Measured: accent 3e-5 .. 9e-5,
+# disc 2e-5 .. 9e-5, CTC 1e-5 .. 3e-5, gradient cosine >= 0.9996, flat gradient 5e-3 (ReLU / max-pool decisions that flip at 2^-17).
+BOUNDS = {"bf16x3": dict(accent=1e-3, disc=1e-3, ctc=1e-3, cos=0.998, l2=3e-2),
+          "fp16": dict(accent=2e-2, disc=4e-2, ctc=4e-3, cos=0.98, l2=1.6e-1),
           "bf16": dict(accent=6e-2, disc=1.2e-1, ctc=8e-3, cos=0.85, l2=4.5e-1)}   # (1 - cos measured up to 0.10 from run to run)
 
 CASES = {
@@ -71,15 +75,21 @@ def cosine(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
 
 
-@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+GEMM_MATH = {"bf16x3": "bf16x3", "fp16": "bf16", "bf16": "bf16"}    # the Dense / GRU-projection arithmetic each bench mode pairs its trunk with
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16", "bf16"])
 @pytest.mark.parametrize("case", list(CASES))
 def test_bf16_trunk_forward_backward_against_oracle(case, mode):
     cfg, ref, model, _, batch = build(CASES[case], mode)
     bnd = BOUNDS[mode]
-    assert model.trunk.bf16 and model.trunk.half == (mode == "fp16")
+    if mode == "bf16x3" and CASES[case]["res_filters"] != 32:
+        assert not model.trunk.bf16                      # other widths: the fp32-storage kernels (the same fp32-class arithmetic)
+    else:
+        assert model.trunk.bf16 and model.trunk.half == (mode == "fp16") and model.trunk.x3 == (mode == "bf16x3")
     out, total, parts, G = ref.forward_backward(batch)
     from aesrc2020_amd import _lib
-    _lib.set_gemm_math("bf16")                          # the whole "bf16" bench mode: bf16 trunk + bf16-MFMA Dense / GRU projections
+    _lib.set_gemm_math(GEMM_MATH[mode])                 # the whole bench mode: the trunk + its Dense / GRU-projection arithmetic
     try:
         model.forward_backward_only(batch, batch)
         torch.cuda.synchronize()
@@ -117,7 +127,7 @@ def test_bf16_trunk_forward_backward_against_oracle(case, mode):
     assert l2 < bnd["l2"], (case, l2)
 
 
-@pytest.mark.parametrize("mode", ["fp16", "bf16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "fp16", "bf16"])
 def test_bf16_trunk_train_steps_graph_replay_and_inference(mode):
     """Three optimiser steps (2-3 from the captured HIP graph) stay finite and track the fp32-storage model started from the
     same weights; predict() (moving averages folded into the conv fills) agrees between the two storage modes."""
@@ -128,7 +138,7 @@ def test_bf16_trunk_train_steps_graph_replay_and_inference(mode):
     l16, l32 = [], []
     for i, b in enumerate(batches):
         from aesrc2020_amd import _lib
-        _lib.set_gemm_math("bf16")
+        _lib.set_gemm_math(GEMM_MATH[mode])
         try:
             l16.append(t16.train_on_batch(b, b)["loss"])
         finally:
