@@ -36,10 +36,38 @@ WORKLOADS = {
     "cfg5": dict(desc="cfg5: long utterance 2000x80, ResNet34(F=32), GhostVLAD(64+2), ArcFace",
                  kw=dict(res_type="res34", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=64, ghost_clusters=2,
                          disc_enable=True, ctc_enable=False, metric_loss="arcface", margin=0.3)),
+    # /root/reference/train.py:49-75 as shipped: 1200-frame inputs (L = 114), B = 32, res34 / F = 32, Bi-GRU pooling, plain softmax disc head, CTC on
+    "train_py": dict(desc="train.py default: ResNet34(F=32)+BiGRU encoder, CTC bpe1k branch + Bi-GRU pooling + softmax heads, 1200x80 fbank, B=32",
+                     kw=dict(res_type="res34", res_filters=32, hidden_dim=256, mto="bigru", disc_enable=True, ctc_enable=True, metric_loss="softmax",
+                             margin=0.3, bpe_classes=1000, max_ctc_len=72), frames=1200, batch=32),
 }
 
 
-def conv_roofline(model, B, iters=10):
+def kernel_times_in_step(step, n=6):
+    """Per-kernel GPU time INSIDE the train step, measured live in this process: `n` replays of the captured step under torch.profiler
+    (roctracer activity records: every kernel of a replayed HIP graph gets its own begin / end timestamps) -> {kernel name: (calls per
+    step, average microseconds per call)}.  This is what rocprofv3 --kernel-trace --stats reports for the same command (profiles/)."""
+    from torch.profiler import profile, ProfilerActivity
+    import warnings
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(n):
+                step(i)
+            torch.cuda.synchronize()
+    agg = {}
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CUDA:
+            t = getattr(e, "device_time", None)
+            t = e.cuda_time if t is None else t
+            a = agg.setdefault(e.name, [0, 0.0]); a[0] += 1; a[1] += float(t)
+    return {k: (v[0] / n, v[1] / v[0]) for k, v in agg.items() if v[0] >= n}
+
+
+def conv_roofline(model, B, iters=10, in_step=None):
     """Time every conv launch of the ResNet trunk in isolation (HIP events on the launch stream), class them by kernel and
     return the dominant class: achieved = algorithmic FLOPs per launch / average launch duration."""
     from aesrc2020_amd import _lib
@@ -69,7 +97,8 @@ def conv_roofline(model, B, iters=10):
         c["time"] += secs; c["flops"] += flops; c["bytes"] += alg; c["design_bytes"] += design; c["launches"] += 1
 
     bf16 = getattr(tr, "bf16", False)
-    eb = 2.0 if bf16 else 4.0
+    x3t = getattr(tr, "x3", False)                                     # split precision: plane pairs (4 bytes per element), fp16 side tensors
+    eb = 2.0 if (bf16 and not x3t) else 4.0
     wg = []
     def bf16_block(blk, nxt_bn1):
         """The six conv launches of one residual block exactly as ResNetTrunk._forward16 / _backward16 issue them (same fills,
@@ -82,12 +111,15 @@ def conv_roofline(model, B, iters=10):
         R1, R2 = B * H * W, B * H2 * W2
         bn1, bn2, c1v, c2v, scv = blk["bn1"], blk["bn2"], blk["conv1"], blk["conv2"], blk["sc"]
         x, c1 = blk["x"], blk["c1"]
-        rnd = lambda *s: torch.randn(*s, device="cuda").to(BF)
-        emp = lambda *s: torch.empty(*s, device="cuda", dtype=BF)
+        pl = (2,) if x3t else ()                                        # split precision: (hi, lo) planes; the lo plane of random data is noise of the right size
+        rnd = lambda *s: (torch.randn(*(pl + s), device="cuda") * (torch.tensor([1.0, 2.0 ** -9], device="cuda").view(2, 1, 1, 1, 1) if x3t else 1.0)).to(BF)
+        emp = lambda *s: torch.empty(*(pl + s), device="cuda", dtype=BF)
+        sde = lambda *s: torch.empty(*s, device="cuda", dtype=tr.t_side)   # what the fills write back for the weight gradients
         bins = lambda c: torch.zeros(_lib.bn_bins() * 2 * c, device="cuda")
         g, da2, res = rnd(B, H2, W2, cout), rnd(B, H2, W2, cout), rnd(B, H2, W2, cout)
-        y, a1, dx2, dc1 = emp(B, H2, W2, cout), emp(B, H2, W2, cout), emp(B, H2, W2, cout), emp(B, H2, W2, cout)
-        a, dx1 = emp(B, H, W, cin), emp(B, H, W, cin)
+        y, a1, dx2, dc1 = emp(B, H2, W2, cout), sde(B, H2, W2, cout), emp(B, H2, W2, cout), sde(B, H2, W2, cout)
+        a, dx1 = sde(B, H, W, cin), emp(B, H, W, cin)
+        g16 = sde(B, H2, W2, cout) if x3t else None
         b1, b2 = bins(cout), bins(cin)
 
         def inst(cv, ci, co):
@@ -110,27 +142,31 @@ def conv_roofline(model, B, iters=10):
 
         fb1 = bn1.ref(R1, "saved", False) if bn1 is not None else None
         add_l(lambda: inst(c1v, cin, cout), timed(lambda: c1v.fwd16(x, y, B, fill=1 if bn1 is not None else 0, fbn=fb1, e_bins=b1, side=a if bn1 is not None else None)),
-            fl(c1v), by(c1v, x.numel() if bn1 is not None else 0))
+            fl(c1v), by(c1v, (x.numel() if bn1 is not None else 0) // len(pl + (1,))))
         add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
-            fl(c2v), by(c2v, 2 * c1.numel()))
+            fl(c2v), by(c2v, 2 * c1.numel() // len(pl + (1,))))
         if nxt_bn1 is None:                                         # last block: its gradient comes materialised from the final BatchNorm
-            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
+            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel() // len(pl + (1,))))
         else:                                                       # fill 3: the block behind hands over (da1, x, shortcut gradient)
             xn = rnd(B, H2, W2, cout)
-            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res, side=y,
-                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, 4 * c1.numel()))
+            s3 = dict(side=g16, side2=y, side_scale=tr.gscale) if x3t else dict(side=y)
+            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res,
+                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved, **s3)), fl(c2v), by(c2v, 4 * c1.numel() // len(pl + (1,))))
         if bn1 is not None:
             add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
-                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
+                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, (2 * c1.numel() + x.numel()) // len(pl + (1,))))
         else:
             r1 = rnd(B, H, W, cin)
             add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
-                fl(c1v), by(c1v, 2 * c1.numel() + x.numel()))
+                fl(c1v), by(c1v, (2 * c1.numel() + x.numel()) // len(pl + (1,))))
         if scv is not None:
             add_l(lambda: inst(scv, cin, cout), timed(lambda: scv.fwd16(x, y, B)), fl(scv), by(scv))
             add_l(lambda: inst(scv, cout, cin), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv))
-        for cv, xx in ((c1v, x), (c2v, c1)) + (((scv, x),) if scv is not None else ()):
-            wg.append((cv.wgrad16(xx, g, B, False), fl(cv), by(cv)))             # batched below, as the train step runs them
+        # the weight gradients read single 2-byte tensors in every mode (split precision: fp16 copies), batched below as the train step runs them
+        gw = g16 if x3t else g
+        for cv, xx in ((c1v, a if bn1 is not None else blk.get("x16", x)), (c2v, a1)) + (((scv, blk.get("x16", x)),) if scv is not None else ()):
+            alg2 = 2.0 * (B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout)) + 4.0 * cv.k * cv.k * cv.cin * cv.cout
+            wg.append((cv.wgrad16(xx, gw if cv is not c1v else dc1, B, False), fl(cv), (alg2, alg2)))
 
     for n, blk in enumerate(tr.blocks):
         if bf16:
@@ -155,73 +191,82 @@ def conv_roofline(model, B, iters=10):
         for cls, target in tr.WGRAD_CLASSES:
             sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
-                plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1), tr.sfx)
-                nm = ("wgrad3_bf16_kernel<2, 2, true, 0>" if cls[2] else "wgrad3_bf16_kernel<1, 1, false, 0>") if cls[0] == 3 else "wgrad1_bf16_kernel"   # (as rocprofv3 prints them)
+                plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1), tr.wsfx)
+                nm = ("wgrad3_bf16_kernel<2, 2, true>" if cls[2] else "wgrad3_bf16_kernel<1, 1, false>") if cls[0] == 3 else "wgrad1_bf16_kernel"   # (as rocprofv3 prints them)
                 c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, design_bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["launches"] += 1
                 c["bytes"] += sum(w_[2][0] for w_ in sel); c["design_bytes"] += sum(w_[2][1] for w_ in sel)
     total = sum(c["time"] for c in classes.values())
-    name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
-    ach = dom["flops"] / dom["time"] / 1e12
+    # In-step durations, measured live (kernel_times_in_step): the isolated replays above see a warm L2 and no neighbours, the step does not.
+    # A class is matched to the profiler's kernel names by its instantiation string.
+    # (the step runs a shape-changing block's first conv and its shortcut as ONE launch, conv_bf16_pair_kernel: such launches count in the
+    # conv total but belong to no class of the isolated pass)
+    conv_in_step = {k: v for k, v in (in_step or {}).items() if any(t in k for t in ("conv_bf16_kernel<", "conv_bf16_pair_kernel<", "wgrad3_bf16_kernel<", "wgrad1_bf16_kernel(", "wgrad_reduce"))}
+    for cname, c in classes.items():
+        hit = [v for k, v in conv_in_step.items() if cname + "(" in k]
+        if hit:
+            c["in_step_calls"] = sum(h[0] for h in hit); c["in_step_us"] = sum(h[0] * h[1] for h in hit) / c["in_step_calls"]
+    matched = {k: c for k, c in classes.items() if "in_step_us" in c}
+    have_in_step = bool(matched)
+    if have_in_step:
+        name, dom = max(matched.items(), key=lambda kv: kv[1]["in_step_us"] * kv[1]["in_step_calls"])
+    else:
+        name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
+    ach_iso = dom["flops"] / dom["time"] / 1e12
+    t_launch = dom["in_step_us"] * 1e-6 if have_in_step else dom["time"] / dom["launches"]      # seconds per launch of the dominant class
+    ach = dom["flops"] / dom["launches"] / t_launch / 1e12
     x3 = (not bf16) and _lib.get_conv_math() == "bf16x3"
-    # which MFMA pipe the dominant class runs on: bf16 trunk = single-pass bf16 MFMA; fp32 storage: Cout (Cin for dgrad) <= 32
-    # tiles keep the fp32 kernels, the rest run bf16x3
-    dom_x3 = x3 and name.endswith("n64")
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_F32_MFMA_TFLOPS)
+    # which MFMA pipe the dominant class runs on: 2-byte trunk = single-pass MFMA; split precision (the x3 trunk, or fp32 storage with Cout --
+    # Cin for dgrad -- > 32): three bf16 MFMAs per product block, ceiling 2500 / 3; the rest of the fp32-storage kernels: fp32 MFMA
+    dom_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad"))
+    peak = PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     # bound of the dominant class on this chip: time its algorithmic FLOPs need on the pipe vs its algorithmic bytes on HBM
     t_mfma, t_hbm = dom["flops"] / (peak * 1e12), dom["bytes"] / (PEAK_HBM_GBS * 1e9)
     bound = "mfma" if t_mfma >= t_hbm else "hbm"
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
-    # correction applied by tools/pmc_to_traffic.py); null when no measurement exists for this kernel class
+    # correction applied by tools/pmc_to_traffic.py); null when no measurement exists for this kernel class in this mode
     traffic, tsrc = None, None
     try:
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-        key = ("bf16:" if bf16 else "") + name
+        key = ("x3:" if x3t else "bf16:" if bf16 else "") + name
         if key in pj:
             traffic, tsrc = pj[key]["traffic_bytes"], pj["source"]
     except (OSError, ValueError, KeyError):
         pass
-    # the same class's average duration INSIDE the train step, from the committed rocprofv3 --kernel-trace --stats summary (profiles/):
-    # the isolated replays above see a warm L2 and no neighbours; frac_in_step is what reproduces from profiles/
-    in_step_us, in_step_src = None, None
-    try:
-        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        tag = "fp16" if getattr(tr, "half", False) else ("bf16" if bf16 else "bf16x3")
-        cands = sorted(fn for fn in os.listdir(pdir) if fn.startswith("r3_") and fn.endswith("%s_cfg2_kernel_stats.txt" % tag))
-        if cands:
-            for line in open(os.path.join(pdir, cands[-1])):
-                if name.split("(")[0] in line:
-                    cols = line.split()
-                    in_step_us, in_step_src = float(cols[-4]), "profiles/" + cands[-1]
-                    break
-    except (OSError, ValueError, IndexError):
-        pass
-    math = ("single-pass fp16 MFMA (v_mfma_f32_32x32x16_f16), fp16 activations in HBM, fp32 accumulate" if getattr(tr, "half", False) else
+    math = ("split precision: every trunk tensor a (hi, lo) pair of bf16 planes, 3 x v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate" if x3t else
+            "single-pass fp16 MFMA (v_mfma_f32_32x32x16_f16), fp16 activations in HBM, fp32 accumulate" if getattr(tr, "half", False) else
             "single-pass bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM, fp32 accumulate" if bf16 else
             "bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate" if dom_x3 else
             "fp32 MFMA (v_mfma_f32_32x32x2_f32)")
+    per_launch_bytes = dom["bytes"] / dom["launches"]
     if bound == "hbm":
-        ach_v, peak_v, unit = dom["bytes"] / dom["time"] / 1e9, PEAK_HBM_GBS, "GB/s"
+        ach_v, iso_v, peak_v, unit = per_launch_bytes / t_launch / 1e9, dom["bytes"] / dom["time"] / 1e9, PEAK_HBM_GBS, "GB/s"
     else:
-        ach_v, peak_v, unit = ach, peak, "TFLOP/s"
+        ach_v, iso_v, peak_v, unit = ach, ach_iso, peak, "TFLOP/s"
     # T_roof of the 36 non-stem convs = 3 x (52.9 - 8.7) us per train step at B=64, T=400 (bf16 activations, 2.5 PFLOP/s,
     # 8 TB/s); scaled by this workload's conv FLOPs (1.2263 GFLOP/utt forward for those 36 layers)
     all_flops = sum(c["flops"] for c in classes.values())
     t_roof_us = 132.6 * all_flops / (3 * 64 * 1.2263e9) if all_flops else None
+    total_in_step = sum(v[0] * v[1] for v in conv_in_step.values()) if have_in_step else None
     return dict(bound=bound, kernel=name, achieved=round(ach_v, 2), peak=round(peak_v, 1), unit=unit,
-                frac=round(ach_v / peak_v, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
-                algorithmic_bytes=int(dom["bytes"] / dom["launches"]), design_bytes=int(dom["design_bytes"] / dom["launches"]),
+                # frac: the dominant class as it runs INSIDE the train step (measured live in this run, torch.profiler = roctracer kernel records;
+                # profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command); frac_isolated: L2-warm graph replays of the class alone
+                frac=round(ach_v / peak_v, 4), frac_isolated=round(iso_v / peak_v, 4),
+                frac_source="in-step, live (torch.profiler)" if have_in_step else "isolated graph replays (no in-step measurement in this run)",
+                traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
+                algorithmic_bytes=int(per_launch_bytes), design_bytes=int(dom["design_bytes"] / dom["launches"]),
                 launches_per_step=dom["launches"],
-                avg_launch_us=round(dom["time"] / dom["launches"] * 1e6, 2), in_step_avg_launch_us=in_step_us, in_step_source=in_step_src,
-                frac_in_step=(round((dom["bytes"] if bound == "hbm" else dom["flops"] / 1e3) / dom["launches"] / (in_step_us * 1e-6) / 1e9 / peak_v, 4)
-                              if in_step_us else None), math=math,
+                avg_launch_us=round(t_launch * 1e6, 2), avg_launch_us_isolated=round(dom["time"] / dom["launches"] * 1e6, 2), math=math,
                 achieved_tflops=round(ach, 2), frac_of_bf16_dense_peak=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                 frac_of_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                algorithmic_hbm_gbs=round(dom["bytes"] / dom["time"] / 1e9, 1),
-                conv_classes={k: dict(us_per_step=round(v["time"] * 1e6, 1), tflops=round(v["flops"] / v["time"] / 1e12, 2),
-                                      launches=v["launches"]) for k, v in sorted(classes.items())},
-                conv_total_us_per_step=round(total * 1e6, 1),
-                conv_t_roof_over_t_measured=round(t_roof_us / (total * 1e6), 4) if t_roof_us else None)
+                algorithmic_hbm_gbs=round(per_launch_bytes / t_launch / 1e9, 1),
+                conv_classes={k: dict(us_per_step_isolated=round(v["time"] * 1e6, 1), tflops_isolated=round(v["flops"] / v["time"] / 1e12, 2), launches=v["launches"],
+                                      **({"us_per_step": round(v["in_step_us"] * v["in_step_calls"], 1), "launches_in_step": round(v["in_step_calls"], 2),
+                                          "avg_launch_us": round(v["in_step_us"], 2)} if "in_step_us" in v else {}))
+                              for k, v in sorted(classes.items())},
+                conv_total_us_per_step=round(total_in_step, 1) if have_in_step else round(total * 1e6, 1),
+                conv_total_us_per_step_isolated=round(total * 1e6, 1),
+                conv_t_roof_over_t_measured=round(t_roof_us / (total_in_step if have_in_step else total * 1e6), 4) if t_roof_us else None)
 
 
 def cpu_baseline(kw, input_shape, B, warm=3, steps=10):
@@ -292,8 +337,8 @@ def run_workload(name, args, rank, world, with_extras, batch=None):
     from aesrc2020_amd.utils import synthetic_batch
     import torch.distributed as dist
     wl = WORKLOADS[name]
-    T = args.frames or (2000 if name == "cfg5" else 400)
-    B = batch or args.batch or 64
+    T = args.frames or wl.get("frames") or (2000 if name == "cfg5" else 400)
+    B = batch or args.batch or wl.get("batch") or 64
     input_shape = [T, 80, 1]
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -346,7 +391,8 @@ def run_workload(name, args, rank, world, with_extras, batch=None):
         raise AssertionError((name, args.dtype, B, logs, "l2_loss", float(st_.l2_loss.item()), "non-finite", diag, "gradients (name, non-finite, inf)", where[:8]))
     res = dict(value=round(world * B * args.steps / dt, 2), ms_per_step=round(dt / args.steps * 1e3, 4), workload=wl["desc"], B=B, T=T,
                params=model.count_params(), final_loss=round(logs["loss"], 4), kw=kw, input_shape=input_shape,
-               dropped=model.store.dropped_gradient_elements())      # fp16 trunk: gradient elements past fp16's range, dropped by the optimiser
+               dropped=model.store.dropped_gradient_elements())      # fp16 operands: optimiser steps skipped because a gradient was not finite
+    res["in_step"] = kernel_times_in_step(step) if (with_extras and rank == 0 and not args.no_graph and not args.no_roofline) else None
     return res, model
 
 
@@ -370,9 +416,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--settle", type=int, default=150, help="untimed set-up replays in front of the warm-up steps (clock ramp of an idle box)")
-    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
-    ap.add_argument("--dtype", default=os.environ.get("SAR_BENCH_DTYPE", "fp16"), choices=list(DTYPES),
-                    help="arithmetic of the conv trunk: bf16 (BASELINE configs[1]), fp16 (configs[4]), bf16x3 (fp32-class), f32")
+    ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))   # cfg2 = BASELINE configs[1]: the configuration the metric is quoted on
+    ap.add_argument("--dtype", default=os.environ.get("SAR_BENCH_DTYPE", "bf16x3"), choices=list(DTYPES),
+                    help="arithmetic: bf16x3 (default: split precision, the fp32-class mode that holds north_star's 1e-3), bf16 (BASELINE configs[1]'s "
+                         "name), fp16 (configs[4]), bf16x3_r1 (round 1's fp32-storage kernels), f32")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64)")
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true")
@@ -402,14 +449,14 @@ def main():
             "config": {"workload": r["workload"], "batch_per_gpu": r["B"], "global_batch": r["B"] * world, "frames": r["T"], "feat_dim": 80,
                        "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "settle_steps": max(args.settle, 0), "params": r["params"],
                        "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"], "nonfinite_gradient_elements_dropped": r["dropped"],
-                       # BASELINE configs[1] names bf16 for this workload; the default here is fp16 -- the same 2 bytes and MFMA rate with three
-                       # more mantissa bits (3-4x closer to the float64 oracle), i.e. not a reduced precision; the bf16 build of the
-                       # same kernels is timed in the same run (also.cfg2_bf16) and is one flag away (--dtype bf16)
-                       "dtype_note": ("configs[1] names bf16: fp16 = same bytes and MFMA rate, 3 more mantissa bits; bf16 line: also.cfg2_bf16"
-                                      if args.dtype == "fp16" and args.workload == "cfg2" else None)},
+                       # BASELINE configs[1] names bf16 for this workload and north_star bounds the outputs at 1e-3 of the reference's fp32 graph: the
+                       # default is the mode that holds that bound (also.parity: ~5e-5); the single-pass bf16 / fp16 builds of the same kernels
+                       # (2e-2 / 6e-3 off) are timed in the same run (also.cfg2_bf16, also.cfg2_fp16) and are one flag away
+                       "dtype_note": ("bf16x3 = bf16 operands in split precision (hi + lo planes, 3 MFMAs per product): the arithmetic that meets north_star's "
+                                      "1e-3; single-pass lines: also.cfg2_bf16, also.cfg2_fp16" if args.dtype == "bf16x3" and args.workload == "cfg2" else None)},
         }
         if not args.no_roofline:
-            res["roofline"] = conv_roofline(model, r["B"])
+            res["roofline"] = conv_roofline(model, r["B"], in_step=r["in_step"])
     if dist.is_initialized():
         # how many ranks the collective backend really connected: an all-reduce of ones (the driver can check N against it)
         ones = torch.ones(1, device="cuda")
@@ -433,12 +480,14 @@ def main():
                              "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"], "nonfinite_gradient_elements_dropped": ra["dropped"]}
                 del m2
                 torch.cuda.empty_cache()
-            other16 = "bf16" if args.dtype != "bf16" else "fp16"
-            for key, name, dt, batch in (("cfg3", "cfg3", args.dtype, None), ("cfg5", "cfg5", args.dtype, 64), ("cfg5_b32", "cfg5", args.dtype, 32),
-                                         ("cfg2_" + other16, "cfg2", other16, None), ("cfg2_bf16x3", "cfg2", "bf16x3", None),
-                                         ("cfg3_bf16x3", "cfg3", "bf16x3", None)):
+            others = [d for d in ("bf16x3", "bf16", "fp16") if d != args.dtype]
+            # cfg5: BASELINE configs[4] names fp16 -- timed in fp16 next to this run's dtype; train_py: the reference's shipped configuration
+            for key, name, dt, batch in [("cfg3", "cfg3", args.dtype, None), ("cfg5", "cfg5", args.dtype, 64), ("cfg5_b32", "cfg5", args.dtype, 32),
+                                         ("train_py_default", "train_py", args.dtype, None)] + \
+                                        [("cfg2_" + d, "cfg2", d, None) for d in others] + [("cfg3_" + d, "cfg3", d, None) for d in others] + \
+                                        ([("cfg5_fp16", "cfg5", "fp16", 64)] if args.dtype != "fp16" else []) + [("cfg2_bf16x3_r1", "cfg2", "bf16x3_r1", None)]:
                 timed(key, name, dt, batch)
-            also["parity"] = parity_probe([args.dtype, other16, "bf16x3"])
+            also["parity"] = parity_probe([args.dtype] + others + ["bf16x3_r1"])
             set_dtype(args.dtype)
             res["also"] = also
         if world == 1 and not args.no_cpu_baseline:
