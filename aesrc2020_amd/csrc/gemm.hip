@@ -208,9 +208,6 @@ __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned o
 // and its weight gradient cost the grouped launch 17 us where it had cost 11.7 alone; those problems stay on the fp32 kernel.)
 // One 64 x 64 output tile (tile column bx, tile row by, split-K slice kz); the LDS comes from the calling kernel, so that a kernel
 // which holds several instantiations (the grouped weight-gradient launch below) still has ONE set of buffers.
-#ifndef SAR_GEMM_UPFRONT
-#define SAR_GEMM_UPFRONT 1
-#endif
 // X3 (sar_set_gemm_math(2), the fp32-class "bf16x3" mode): the fp32 operands are split into hi = bf16(x) and lo = bf16(x - hi) while they are
 // staged (two LDS planes per operand) and a product block is three MFMAs, lo*hi + hi*lo + hi*hi -- 2^-17 relative per operand instead of
 // 2^-9.  Single-pass 2-byte operands in these GEMMs alone cost 1e-3 (fp16) / 7e-3 (bf16) on the accent probabilities
@@ -323,7 +320,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
     };
-    if (SAR_GEMM_UPFRONT && kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
+    if (kt1 - kt0 >= 3 && kt1 - kt0 <= 4) {
         // Short k-loops (K = 256 per slice: every Dense / GRU-projection GEMM of the model at hidden_dim 256): ALL k-tiles are requested at
         // once -- one round trip.  The rotating form below keeps two tiles in flight, so a slice of four tiles pays the latency of an operand
         // that the previous kernel left behind the fabric (~2 800 cycles: nothing a launch reads first is in its XCD's L2) twice over.

@@ -40,18 +40,18 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
         lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
     }
     float lacc = 0.f;
-    // ticket[1] != 0 (fp16 trunk): a gradient element that is not finite is DROPPED (treated as zero) and counted in ticket[2].  The fp16
-    // trunk carries its activation gradients times a static scale (64 x batch); an element past 65504 / scale -- seen once in ~2 000 steps of
-    // the diverging synthetic cfg3 run, in the gradient of the pooled map -- is inf there, its channel of the stem's kernel gradient NaN, and
-    // without this guard one such step poisons the weights for good.  (The fp32-class and bf16 modes run with the guard off: a non-finite
-    // gradient there is a bug to be seen, not an overflow to be survived.)
-    const bool guard = FUSED && ticket[1] != 0u;
-    unsigned dropped = 0u;
+    // Loss-scaling guard (ticket[1] != 0: the modes with fp16 operands -- the fp16 trunk, and the split-precision mode's fp16 weight-gradient
+    // operands and GRU gradients).  Those carry gradients times a static power-of-two scale; a value past 65504 / scale is inf there and NaN in
+    // the parameter gradients it feeds.  sar_grads_check_f32, launched in front of this kernel, has set ticket[3] when ANY gradient element
+    // is not finite: the WHOLE update is then skipped -- weights, m, v and the iteration count stay as they are (round 3 dropped only the bad
+    // elements and applied the rest: earlier layers got a zero-gradient update, later ones a real one) -- and ticket[2] counts the
+    // skipped step.  The host reads that counter with its logs, warns, halves the scale and re-captures the step (model.SARModel).  The
+    // modes without fp16 operands run with the guard off: a non-finite gradient there is a bug to be seen, not an overflow to be survived.
+    const bool skip = FUSED && ticket[1] != 0u && ticket[3] != 0u;
     // one wave per 256-element chunk, float4 per lane (16-byte accesses: the scalar version ran at 3.4 TB/s), two chunks per
     // trip so that 14 loads are in flight per lane
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     auto upd = [&](float w, float gi, float& mi, float& vi, float l2) {
-        if (guard && !(fabsf(gi) <= 3.0e38f)) { gi = 0.f; ++dropped; }
         const float gr = fmaf(2.f * l2, w, gi * gs);
         lacc = fmaf(l2 * w, w, lacc);
         mi = b1 * mi + (1.f - b1) * gr;
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
     auto one = [&](long c, float4 w, float4 gg, float4 mm, float4 vv, float l2) {
         w.x = upd(w.x, gg.x, mm.x, vv.x, l2); w.y = upd(w.y, gg.y, mm.y, vv.y, l2);
         w.z = upd(w.z, gg.z, mm.z, vv.z, l2); w.w = upd(w.w, gg.w, mm.w, vv.w, l2);
+        if (skip) return;                                           // (block-uniform: the l2 sum above is of the unchanged weights)
         const long i = c * 256 + lane * 4;
         *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv; *reinterpret_cast<float4*>(p + i) = w;
     };
@@ -85,12 +86,25 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
         if (threadIdx.x == 0) atomicAdd(l2_loss, lacc);
     }
     if constexpr (FUSED) {
-        if (dropped) atomicAdd(ticket + 2, dropped);
+        __syncthreads();                                            // every thread of this block has read the state and the skip flag (ADVICE r3:
+                                                                    // without l2_loss nothing else orders those reads in front of the ticket)
         if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {   // every block has read the iteration count
             *ticket = 0u;
-            st->lr_t = lr_t; st->iterations += 1;
+            if (skip) { ticket[2] += 1u; ticket[3] = 0u; }          // a skipped step: nothing advances
+            else { st->lr_t = lr_t; st->iterations += 1; }
         }
     }
+}
+
+// ticket[3] = 1 when any of the n gradient elements is not finite (see adam_l2_kernel: the loss-scaling guard).  One read of the flat
+// gradient buffer (34 MB at F = 32: ~10 us), only in the modes with fp16 operands.
+__global__ __launch_bounds__(256) void grads_check_kernel(const float4* __restrict__ g, long n4, unsigned* __restrict__ ticket) {
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 a = g[i];
+        bad |= !(fabsf(a.x) <= 3.0e38f) | !(fabsf(a.y) <= 3.0e38f) | !(fabsf(a.z) <= 3.0e38f) | !(fabsf(a.w) <= 3.0e38f);
+    }
+    if (bad) ticket[3] = 1u;
 }
 
 // sum of the l2(1e-4) regularisers for the current weights, without an update (evaluate(): Keras adds them to `loss`)
@@ -138,9 +152,20 @@ extern "C" int sar_adam_l2_step_f32(float* params, const float* grads, float* m,
     return SAR_OK;
 }
 
+// Loss-scaling guard, first half: sets ticket[3] when any element of grads is not finite; sar_adam_l2_update_f32 (ticket[1] != 0) then skips the step.
+extern "C" int sar_grads_check_f32(const float* grads, void* ticket, long n, hipStream_t stream) {
+    if (!grads || !ticket || n < 4 || (n % 4)) return SAR_EINVAL;
+    const long n4 = n / 4;
+    const long nb = (n4 + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(grads_check_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, stream, reinterpret_cast<const float4*>(grads), n4,
+                       static_cast<unsigned*>(ticket));
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
 // sar_adam_prepare + sar_adam_l2_step_f32 in ONE launch.  `ticket`: FOUR 32-bit words the caller owns, zero-initialised: [0] the block ticket
-// (zero again when the launch has finished), [1] the caller's switch "drop gradient elements that are not finite" (fp16 trunk), [2] how many
-// were dropped so far, [3] spare.
+// (zero again when the launch has finished), [1] the caller's switch "loss-scaling guard on" (modes with fp16 operands), [2] how many steps
+// were skipped so far because a gradient was not finite, [3] the flag sar_grads_check_f32 sets (cleared here).
 extern "C" int sar_adam_l2_update_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                                       void* state, void* ticket, float* l2_loss, long n, hipStream_t stream) {
     if (!params || !grads || !m || !v || !chunk_l2 || !state || !ticket || (n % 256)) return SAR_EINVAL;

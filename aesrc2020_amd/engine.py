@@ -187,15 +187,22 @@ class ParamStore:
         return None
 
     def set_adam_guard(self, on=True):
-        """fp16 trunk: gradient elements that are not finite (an activation gradient past fp16's range) are dropped by the optimiser instead
-        of poisoning the weights; dropped_gradient_elements() counts them."""
+        """Modes with fp16 operands (the fp16 trunk; the split-precision mode's fp16 weight-gradient operands and GRU gradients): a step whose
+        gradient holds a non-finite element (a scaled value past fp16's range) is SKIPPED as a whole by the optimiser -- weights, m, v and
+        the iteration count stay -- and counted; skipped_steps() reads the counter, the model halves the gradient scale when it moves."""
         self._adam_guard = bool(on)
         if self.__dict__.get("_adam_ticket") is not None:
             self._adam_ticket[1] = 1 if on else 0
 
-    def dropped_gradient_elements(self):
+    # power-of-two exponent (<= 0) applied on top of the static gradient scale of the fp16 operands (64 x batch): lowered by the model when
+    # a step overflowed, raised again after 2 000 clean steps (dynamic loss scaling at the cadence of the host's log reads: no per-step sync)
+    gscale_shift = 0
+
+    def skipped_steps(self):
         t = self.__dict__.get("_adam_ticket")
         return 0 if t is None else int(t[2].item())
+
+    dropped_gradient_elements = skipped_steps                                # (round 3's name, kept for callers)
 
     def take_deferred_zero(self):
         tab = self.__dict__.get("_deferred_zero"); self._deferred_zero = None
@@ -211,6 +218,8 @@ class ParamStore:
             self._adam_ticket = torch.zeros(4, dtype=torch.int32, device=self.params.device)      # [ticket, guard switch, dropped count, spare]
             if self.__dict__.get("_adam_guard", False):
                 self._adam_ticket[1] = 1
+        if self.__dict__.get("_adam_guard", False):                          # any non-finite gradient element -> the update below skips the step
+            _lib.call("sar_grads_check_f32", self.grads, self._adam_ticket, self.n)
         _lib.call("sar_adam_l2_update_f32", self.params, self.grads, self.m, self.v, self.chunk_l2, self.adam_state, self._adam_ticket,
                   self.l2_loss, self.n)                                      # step-size bookkeeping + update in one launch
         for r in self.refs:

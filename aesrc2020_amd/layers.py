@@ -189,7 +189,7 @@ class BiGRU(Layer):
             dai = self.scratch("gru_dai%d_%d_%d" % (B, L, H), (2, B, L, 3 * H)); dah = self.scratch("gru_dah%d_%d_%d" % (B, L, H), (2, B, L, 3 * H))
         if self.mfma and self.msfx == "f16":
             # fp16 operands: the pre-activation gradients enter the MFMA times a power-of-two scale (the trunk's rule: 64 x batch)
-            _call("sar_bigru_bwd_f16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H, float(2 ** int(round(np.log2(64.0 * max(B, 1))))))
+            _call("sar_bigru_bwd_f16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H, float(2 ** (int(round(np.log2(64.0 * max(B, 1)))) + self.store.gscale_shift)))
         elif self.mfma:
             _call("sar_bigru_bwd_bf16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H)
         else:

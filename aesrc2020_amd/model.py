@@ -602,9 +602,49 @@ class SARNetModel:
     def train_on_batch(self, x, y=None, return_dict=True, sync=True):
         self._upload(x, y)
         self.train_step_device()
+        self._steps_run = getattr(self, "_steps_run", 0) + 1
         if not sync:
             return None
-        return self._logs()
+        logs = self._logs()
+        self._overflow_policy(logs)
+        return logs
+
+    # ---- dynamic loss scaling of the modes with fp16 operands (fp16 trunk; the split-precision mode's fp16 weight-gradient operands and GRU
+    # gradients).  The optimiser SKIPS a step whose gradient is not finite (csrc/optim.hip) and counts it on the device; here, wherever the
+    # host reads logs anyway (every synchronous train_on_batch, every epoch of fit_generator -- never an extra sync), the counter is
+    # looked at: a skipped step is reported (RuntimeWarning + `nonfinite_steps_skipped` in the logs), the gradient scale is halved and the
+    # step re-captured; 2 000 clean steps double it again (never past the static 64 x batch); MAX_CONSEC_SKIPS consecutive skipped steps
+    # raise -- the reference's Keras trainer would show a NaN loss there.
+    MAX_CONSEC_SKIPS = 16
+    GROW_AFTER = 2000
+
+    def _overflow_policy(self, logs=None):
+        st = self.store
+        if not st.__dict__.get("_adam_guard", False):
+            return
+        run = getattr(self, "_steps_run", 0)
+        skipped = st.skipped_steps()
+        seen, at = getattr(self, "_skips_seen", 0), getattr(self, "_skips_checked_at", 0)
+        new, steps = skipped - seen, run - at
+        self._skips_seen, self._skips_checked_at = skipped, run
+        if logs is not None:
+            logs["nonfinite_steps_skipped"] = skipped
+        if new > 0:
+            import warnings
+            self._consec_skips = getattr(self, "_consec_skips", 0) + new if new >= steps else new
+            self._clean_since = run
+            if self._consec_skips >= self.MAX_CONSEC_SKIPS:
+                raise FloatingPointError("%d consecutive optimiser steps skipped: the gradient is not finite at gradient scale 2^%d x (64 x batch) "
+                                         "-- the training has diverged (the reference's Keras trainer would report a NaN loss)" % (self._consec_skips, st.gscale_shift))
+            st.gscale_shift -= 1
+            self.graph = None; self._eager_done = 0              # the scale is a kernel argument: the next step runs eagerly, the one after re-captures
+            warnings.warn("%d optimiser step(s) skipped (%d in all): a gradient element was not finite; gradient scale of the fp16 operands halved "
+                          "to 2^%d x (64 x batch)" % (new, skipped, st.gscale_shift), RuntimeWarning)
+        else:
+            self._consec_skips = 0
+            if st.gscale_shift < 0 and run - getattr(self, "_clean_since", 0) >= self.GROW_AFTER:
+                st.gscale_shift += 1; self._clean_since = run
+                self.graph = None; self._eager_done = 0
 
     def _logs(self):
         """Host-side scalars (forces a device sync): Keras-style loss / per-output losses / accuracies."""
@@ -741,6 +781,7 @@ class SARNetModel:
                 dist.all_reduce(mean_dev); mean_dev = mean_dev / self.dp.world
             mean = mean_dev.cpu().numpy()
             logs = {k: float(v) for k, v in zip(self._logs_device_names(), mean)}
+            self._overflow_policy(logs)                                      # (the .cpu() above was this epoch's sync: the skip counter is current)
             if validation_data is not None:
                 vl = self.evaluate(validation_data[0], validation_data[1])
                 if self.dp.enabled and self.dp.world > 1:                        # the same validation data on every rank, but be explicit: rank 0's numbers

@@ -250,6 +250,7 @@ class ResNetTrunk(Layer):
     def _set_gscale(self, B):
         """fp16 trunk: the static gradient scale for batches of B utterances (a power of two; see _lib._TRUNK_GSCALE)."""
         s = self._gscale_cfg if self._gscale_cfg > 0 else float(2 ** int(round(np.log2(64.0 * max(B, 1)))))
+        s *= 2.0 ** self.store.gscale_shift                                  # lowered by the model after a step that overflowed (engine.ParamStore)
         if s != self.gscale:
             self.gscale, self.ginv = s, 1.0 / s
             for cv in self._all_convs():

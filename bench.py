@@ -448,7 +448,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": r["workload"], "batch_per_gpu": r["B"], "global_batch": r["B"] * world, "frames": r["T"], "feat_dim": 80,
                        "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "settle_steps": max(args.settle, 0), "params": r["params"],
-                       "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"], "nonfinite_gradient_elements_dropped": r["dropped"],
+                       "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"], "nonfinite_gradient_steps_skipped": r["dropped"],
                        # BASELINE configs[1] names bf16 for this workload and north_star bounds the outputs at 1e-3 of the reference's fp32 graph: the
                        # default is the mode that holds that bound (also.parity: ~5e-5); the single-pass bf16 / fp16 builds of the same kernels
                        # (2e-2 / 6e-3 off) are timed in the same run (also.cfg2_bf16, also.cfg2_fp16) and are one flag away
@@ -477,7 +477,7 @@ def main():
                 set_dtype(dt)
                 ra, m2 = run_workload(name, args, rank, world, False, batch=batch)
                 also[key] = {"value": ra["value"], "unit": "utterances/sec", "ms_per_step": ra["ms_per_step"], "batch_per_gpu": ra["B"],
-                             "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"], "nonfinite_gradient_elements_dropped": ra["dropped"]}
+                             "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"], "nonfinite_gradient_steps_skipped": ra["dropped"]}
                 del m2
                 torch.cuda.empty_cache()
             others = [d for d in ("bf16x3", "bf16", "fp16") if d != args.dtype]

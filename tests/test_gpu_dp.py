@@ -24,6 +24,22 @@ STEPS = 3
 GRAPHS = {"3": ["adam", "heads_s32", "trunk_s10"], "5": ["adam", "heads", "trunk0", "trunk1", "trunk2"]}   # SAR_DP_SEGMENTS -> captured graphs
 
 
+def _set_mode(mode):
+    """The trunk / GEMM arithmetic of a test mode: "bf16" = the single-pass 2-byte trunk with DETERMINISTIC forward statistics (SAR_BN_DET: the
+    same utterances give bit-identical BatchNorm constants however the batch is cut, so the two-rank step can be held tightly against the
+    shard-by-shard reference), "bf16x3" = the split-precision default of the bench."""
+    from aesrc2020_amd import _lib
+    if mode == "bf16":
+        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16"); _lib.set_bn_deterministic(True)
+    elif mode == "bf16x3":
+        _lib.set_trunk_dtype("bf16x3"); _lib.set_gemm_math("bf16x3")
+
+
+def _reset_mode():
+    from aesrc2020_amd import _lib
+    _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32"); _lib.set_bn_deterministic(False)
+
+
 def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", segments="3", grad16=False):
     if grad16:
         os.environ["SAR_DP_GRAD_DTYPE"] = "bf16"               # the buckets cross the ranks as bf16 (parallel.DataParallel)
@@ -36,10 +52,8 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", s
     from oracle import model_torch as MT                     # test infrastructure: synthetic batch generator only
     if not via_gpus:
         parallel.init_from_env()
-    kw = KW16 if mode == "bf16" else KW
-    if mode == "bf16":
-        from aesrc2020_amd import _lib
-        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    kw = KW16 if mode in ("bf16", "bf16x3") else KW
+    _set_mode(mode)
     with contextlib.redirect_stdout(io.StringIO()):
         # different seeds: rank 0's weights must win (broadcast).  via_gpus: the reference's own switch (model.py:193-194) --
         # SAR_Net joins the process group itself and the train_model shards the GLOBAL batch
@@ -62,10 +76,11 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", s
 
 
 @pytest.mark.parametrize("backend,via_gpus,mode,segments", [("gloo", False, "fp32", "3"), ("gloo", True, "fp32", "3"), ("nccl", True, "fp32", "3"),
+                                                            ("gloo", True, "bf16x3", "3"), ("nccl", True, "bf16x3", "3"),
                                                             ("gloo", True, "bf16", "3"), ("nccl", True, "bf16", "3"), ("gloo", True, "fp32", "5"),
                                                             ("gloo", True, "bf16", "5"), ("gloo", True, "fp32+g16", "3")],
-                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16-mode", "rccl-bf16-mode",
-                              "gloo-five-graphs", "gloo-bf16-five-graphs", "gloo-bf16-gradient-buckets"])
+                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16x3-mode", "rccl-bf16x3-mode", "gloo-bf16-mode",
+                              "rccl-bf16-mode", "gloo-five-graphs", "gloo-bf16-five-graphs", "gloo-bf16-gradient-buckets"])
 def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, segments):
     grad16 = mode.endswith("+g16"); mode = mode.split("+")[0]      # "+g16": SAR_DP_GRAD_DTYPE=bf16 -- the reduced buffer is the sum of the bf16-rounded shard gradients
     import torch.multiprocessing as mp
@@ -83,11 +98,13 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
     (_, r0, g0, late), (_, r1, g1, _) = res
     assert g0 == GRAPHS[segments] and g1 == g0                 # steps 2.. ran from the captured graphs of the chosen form
     from aesrc2020_amd import _lib
-    kw = KW16 if mode == "bf16" else KW
-    # bf16 mode: the shard runs of the reference see other atomic orders in the statistic bins -- agreement to bf16 noise
-    tol = 3.5e-1 if mode == "bf16" else 2e-2              # (bf16: 2.5e-1 until one full-suite run of round 3 tripped on it; a missed bucket shows as O(1))
-    if mode == "bf16":
-        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    kw = KW16 if mode in ("bf16", "bf16x3") else KW
+    # "bf16" runs with deterministic forward statistics (VERDICT r3 / ADVICE: round 3 tolerated 3.5e-1 here because the statistic bins are
+    # order-dependent and a 2-byte rounding flips on them; with SAR_BN_DET the BatchNorm constants of a shard are bit-identical in both runs
+    # and what is left is the fp32 atomic order of the BACKWARD sums feeding 2-byte roundings).  A missed or doubled bucket shows as O(1), a
+    # late BatchNorm vector reduced without one rank's contribution as ~0.5.
+    tol = 2e-2
+    _set_mode(mode)
     try:
         single, _ = SAR_Net(seed=99, **kw)
     finally:
@@ -101,11 +118,12 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         # reference: one process, the two shards one after the other, from the same weights
         st.params.copy_(torch.from_numpy(a["p_before"]).cuda())
         gb = MT.synthetic_batch(cfg, GLOBAL_B, seed=300 + i)
-        gsum = np.zeros_like(a["grads"])
+        gsum = np.zeros_like(a["grads"]); gshard = []
         for r in range(2):
             sh = parallel.shard_batch(gb, r, 2)
             single.forward_backward_only(sh, sh)
-            gsum += st.grads.detach().cpu().numpy()
+            gshard.append(st.grads.detach().cpu().numpy().copy())
+            gsum += gshard[-1]
         # flat-vector L2 (not max-abs): the two computations differ only in fp32 summation order (split-K atomics), but a
         # pre-activation within that noise of zero flips a ReLU and changes single gradient elements discretely
         # (observed: 1e-6 typically, up to 5e-3 when a flip happens on these 3-utterance shards; a missed or doubled bucket
@@ -119,9 +137,12 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         for off, size in late:
             ga, gs = a["grads"][off:off + size], gsum[off:off + size]
             e1 = float(np.linalg.norm(ga - gs) / np.linalg.norm(gs))
-            assert e1 < (6e-1 if mode == "bf16" else 5e-2) and np.linalg.norm(ga) > 0.5 * np.linalg.norm(gs), (i, off, e1)
+            assert e1 < 5e-2 and np.linalg.norm(ga) > 0.9 * np.linalg.norm(gs), (i, off, e1)
+            # closer to the SUM of the shard gradients than to either shard's own (a vector that holds one rank's contribution only)
+            for r in range(2):
+                assert e1 < float(np.linalg.norm(ga - gshard[r][off:off + size]) / np.linalg.norm(gs)), (i, off, r)
         assert not np.array_equal(a["p_before"], a["p_after"])
-    _lib.set_gemm_math("fp32")
+    _reset_mode()
 
 
 def _worker_one_rank(port, q, mode, collective="torch", segments="3"):
@@ -137,9 +158,8 @@ def _worker_one_rank(port, q, mode, collective="torch", segments="3"):
     parallel.init_from_env()
     import torch.distributed as dist
     assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
-    kw = KW16 if mode == "bf16" else KW
-    if mode == "bf16":
-        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    kw = KW16 if mode in ("bf16", "bf16x3") else KW
+    _set_mode(mode)
     with contextlib.redirect_stdout(io.StringIO()):
         model, tm = SAR_Net(seed=21, **kw)
     assert model.dp.enabled and model.dp.world == 1 and len(model.dp.bounds) == model.trunk.N_PARTS + 1
@@ -166,10 +186,10 @@ def _worker_one_rank(port, q, mode, collective="torch", segments="3"):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,collective,segments", [("fp32", "torch", "3"), ("bf16", "torch", "3"), ("bf16", "cabi", "3"), ("bf16", "torch", "5"),
-                                                      ("bf16", "cabi", "5")],
-                         ids=["fp32-torch.distributed", "bf16-torch.distributed", "bf16-sar_allreduce_bucket", "bf16-five-graphs",
-                              "bf16-five-graphs-sar_allreduce_bucket"])
+@pytest.mark.parametrize("mode,collective,segments", [("fp32", "torch", "3"), ("bf16x3", "torch", "3"), ("bf16x3", "cabi", "3"), ("bf16", "torch", "3"),
+                                                      ("bf16", "cabi", "3"), ("bf16", "torch", "5"), ("bf16", "cabi", "5")],
+                         ids=["fp32-torch.distributed", "bf16x3-torch.distributed", "bf16x3-sar_allreduce_bucket", "bf16-torch.distributed",
+                              "bf16-sar_allreduce_bucket", "bf16-five-graphs", "bf16-five-graphs-sar_allreduce_bucket"])
 def test_rccl_one_rank_segmented_step(mode, collective, segments):
     """RCCL itself on this box: a process group of one rank over backend nccl, the data-parallel step forced on (SAR_DP_FORCE=1).
     Communicator set-up, the all-reduces on RCCL's stream between replays of the five captured graphs and the stream-ordered
@@ -185,9 +205,8 @@ def test_rccl_one_rank_segmented_step(mode, collective, segments):
     out, graphs = q.get(timeout=600)
     p.join(120)
     assert graphs == GRAPHS[segments]
-    kw = KW16 if mode == "bf16" else KW
-    if mode == "bf16":
-        _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16")
+    kw = KW16 if mode in ("bf16", "bf16x3") else KW
+    _set_mode(mode)
     try:
         single, tm = SAR_Net(seed=21, **kw)
         assert not single.dp.enabled
@@ -205,7 +224,7 @@ def test_rccl_one_rank_segmented_step(mode, collective, segments):
             single.forward_backward_only(b, b)
             g = st.grads.detach().cpu().numpy()
             err = float(np.linalg.norm(a["grads"] - g) / np.linalg.norm(g))
-            assert np.all(np.isfinite(a["p_after"])) and err < (3.5e-1 if mode == "bf16" else 2e-2), (i, err)
+            assert np.all(np.isfinite(a["p_after"])) and err < 2e-2, (i, err)
             assert not np.array_equal(a["p_before"], a["p_after"])
     finally:
-        _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32")
+        _reset_mode()

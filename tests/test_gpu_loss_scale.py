@@ -1,0 +1,83 @@
+"""The loss-scaling guard of the modes with fp16 operands (fp16 trunk; the split-precision mode's fp16 weight-gradient operands and GRU
+gradients; csrc/optim.hip, model.SARModel._overflow_policy): a step whose gradient is not finite is skipped AS A WHOLE -- weights, Adam
+moments and the iteration count stay (round 3 dropped the bad elements and applied the rest) -- it is counted, reported, the
+gradient scale halves and the step is re-captured; persistent overflow raises instead of training on silently."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_torch as MT
+
+pytestmark = pytest.mark.gpu
+KW = dict(input_shape=[64, 80, 1], res_type="res18", res_filters=32, hidden_dim=32, mto="avg", disc_enable=True, metric_loss="softmax")
+
+
+@pytest.fixture(params=["bf16x3", "fp16"])
+def guarded(request):
+    from aesrc2020_amd import _lib
+    from aesrc2020_amd.model import SAR_Net
+    _lib.set_trunk_dtype(request.param); _lib.set_gemm_math("bf16x3" if request.param == "bf16x3" else "bf16")
+    try:
+        model, tm = SAR_Net(seed=4, **KW)
+    finally:
+        _lib.set_trunk_dtype("fp32")
+    yield model, tm
+    _lib.set_gemm_math("fp32")
+
+
+def test_nonfinite_gradient_skips_the_whole_step_and_lowers_the_scale(guarded):
+    model, tm = guarded
+    st = model.store
+    assert st.__dict__.get("_adam_guard", False)
+    cfg = MT.Cfg(**KW)
+    b = MT.synthetic_batch(cfg, 4, seed=1)
+    logs = tm.train_on_batch(b, b)                                   # a clean step
+    assert np.isfinite(logs["loss"]) and logs["nonfinite_steps_skipped"] == 0 and st.iterations() == 1
+    snap = lambda: (st.params.clone(), st.m.clone(), st.v.clone())
+    p0, m0, v0 = snap()
+    # a gradient with ONE inf (what an fp16 operand past 65504 / scale leaves in a kernel gradient): the optimiser must leave everything as it is
+    model.forward_backward_only(b, b)
+    st.grads[12345 % st.n] = float("inf")
+    st.adam_step(); torch.cuda.synchronize()
+    p1, m1, v1 = snap()
+    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert st.iterations() == 1 and st.skipped_steps() == 1
+    # ... and a NaN likewise
+    model.forward_backward_only(b, b)
+    st.grads[7] = float("nan")
+    st.adam_step(); torch.cuda.synchronize()
+    assert torch.equal(p0, st.params) and st.iterations() == 1 and st.skipped_steps() == 2
+    # the host's policy, where it reads logs: a warning, the counter in the logs, half the scale, the graph dropped
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lg = {}
+        model._overflow_policy(lg)
+    assert lg["nonfinite_steps_skipped"] == 2 and st.gscale_shift == -1 and model.graph is None
+    assert any(issubclass(x.category, RuntimeWarning) and "skipped" in str(x.message) for x in w)
+    # the next steps run at the halved scale (eager, then re-captured) and train again
+    for i in range(3):
+        logs = tm.train_on_batch(b, b)
+    assert np.isfinite(logs["loss"]) and st.iterations() == 4 and logs["nonfinite_steps_skipped"] == 2
+    assert not torch.equal(p0, st.params)
+    if getattr(model.trunk, "bf16", False):
+        assert model.trunk.gscale == 2.0 ** int(round(np.log2(64.0 * 4))) / 2
+
+
+def test_persistent_overflow_raises(guarded):
+    model, tm = guarded
+    st = model.store
+    cfg = MT.Cfg(**KW)
+    b = MT.synthetic_batch(cfg, 4, seed=2)
+    tm.train_on_batch(b, b)
+    model.MAX_CONSEC_SKIPS = 3
+    with pytest.raises(FloatingPointError):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in range(6):
+                model.forward_backward_only(b, b)
+                st.grads[3] = float("inf")
+                st.adam_step()
+                model._steps_run += 1
+                model._overflow_policy({})
