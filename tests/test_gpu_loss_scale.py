@@ -34,7 +34,7 @@ def test_nonfinite_gradient_skips_the_whole_step_and_lowers_the_scale(guarded):
     cfg = MT.Cfg(**KW)
     b = MT.synthetic_batch(cfg, 4, seed=1)
     logs = tm.train_on_batch(b, b)                                   # a clean step
-    assert np.isfinite(logs["loss"]) and logs["nonfinite_steps_skipped"] == 0 and st.iterations() == 1
+    assert np.isfinite(logs["loss"]) and logs["nonfinite_steps_skipped"] == 0 and st.iterations == 1
     snap = lambda: (st.params.clone(), st.m.clone(), st.v.clone())
     p0, m0, v0 = snap()
     # a gradient with ONE inf (what an fp16 operand past 65504 / scale leaves in a kernel gradient): the optimiser must leave everything as it is
@@ -43,12 +43,12 @@ def test_nonfinite_gradient_skips_the_whole_step_and_lowers_the_scale(guarded):
     st.adam_step(); torch.cuda.synchronize()
     p1, m1, v1 = snap()
     assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
-    assert st.iterations() == 1 and st.skipped_steps() == 1
+    assert st.iterations == 1 and st.skipped_steps() == 1
     # ... and a NaN likewise
     model.forward_backward_only(b, b)
     st.grads[7] = float("nan")
     st.adam_step(); torch.cuda.synchronize()
-    assert torch.equal(p0, st.params) and st.iterations() == 1 and st.skipped_steps() == 2
+    assert torch.equal(p0, st.params) and st.iterations == 1 and st.skipped_steps() == 2
     # the host's policy, where it reads logs: a warning, the counter in the logs, half the scale, the graph dropped
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
@@ -59,7 +59,7 @@ def test_nonfinite_gradient_skips_the_whole_step_and_lowers_the_scale(guarded):
     # the next steps run at the halved scale (eager, then re-captured) and train again
     for i in range(3):
         logs = tm.train_on_batch(b, b)
-    assert np.isfinite(logs["loss"]) and st.iterations() == 4 and logs["nonfinite_steps_skipped"] == 2
+    assert np.isfinite(logs["loss"]) and st.iterations == 4 and logs["nonfinite_steps_skipped"] == 2
     assert not torch.equal(p0, st.params)
     if getattr(model.trunk, "bf16", False):
         assert model.trunk.gscale == 2.0 ** int(round(np.log2(64.0 * 4))) / 2
