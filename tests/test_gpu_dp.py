@@ -103,7 +103,8 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
     # order-dependent and a 2-byte rounding flips on them; with SAR_BN_DET the BatchNorm constants of a shard are bit-identical in both runs
     # and what is left is the fp32 atomic order of the BACKWARD sums feeding 2-byte roundings).  A missed or doubled bucket shows as O(1), a
     # late BatchNorm vector reduced without one rank's contribution as ~0.5.
-    tol = 2e-2
+    tol = 1e-3 if mode == "bf16" else 2e-2                # bf16 + deterministic statistics: VERDICT r3's bound
+    late_tol = 1e-2 if mode == "bf16" else 5e-2
     _set_mode(mode)
     try:
         single, _ = SAR_Net(seed=99, **kw)
@@ -129,6 +130,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         # (observed: 1e-6 typically, up to 5e-3 when a flip happens on these 3-utterance shards; a missed or doubled bucket
         # would show as O(1))
         err = float(np.linalg.norm(a["grads"] - gsum) / np.linalg.norm(gsum))
+        print("two-rank step %d, mode %s: reduced gradient vs sum of shard gradients, relative L2 %.3e" % (i, mode, err))
         assert err < (max(tol, 8e-3) if grad16 else tol), (i, err)      # bf16 buckets: + 2^-9 relative per element, twice
         # per parameter: the gamma / beta gradients of the first BatchNorm of stages 3 and 2, which the bf16 trunk writes one backward
         # part later than the rest of their block (ResNetTrunk.bucket_split_names) -- reduced after an early all-reduce they would come
@@ -137,7 +139,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         for off, size in late:
             ga, gs = a["grads"][off:off + size], gsum[off:off + size]
             e1 = float(np.linalg.norm(ga - gs) / np.linalg.norm(gs))
-            assert e1 < 5e-2 and np.linalg.norm(ga) > 0.9 * np.linalg.norm(gs), (i, off, e1)
+            assert e1 < late_tol and np.linalg.norm(ga) > 0.9 * np.linalg.norm(gs), (i, off, e1)
             # closer to the SUM of the shard gradients than to either shard's own (a vector that holds one rank's contribution only)
             for r in range(2):
                 assert e1 < float(np.linalg.norm(ga - gshard[r][off:off + size]) / np.linalg.norm(gs)), (i, off, r)
