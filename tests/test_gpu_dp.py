@@ -103,8 +103,10 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
     # order-dependent and a 2-byte rounding flips on them; with SAR_BN_DET the BatchNorm constants of a shard are bit-identical in both runs
     # and what is left is the fp32 atomic order of the BACKWARD sums feeding 2-byte roundings).  A missed or doubled bucket shows as O(1), a
     # late BatchNorm vector reduced without one rank's contribution as ~0.5.
-    tol = 1e-3 if mode == "bf16" else 2e-2                # bf16 + deterministic statistics: VERDICT r3's bound
-    late_tol = 1e-2 if mode == "bf16" else 5e-2
+    # measured: fp32 1e-5 .. 5e-3 (one ReLU flip on a 3-utterance shard), bf16x3 1e-4, bf16 + deterministic statistics 6e-3 (round 3, statistics
+    # by float atomics: up to 2.5e-1, bound 3.5e-1)
+    tol = {"bf16": 1.5e-2, "bf16x3": 2e-3}.get(mode, 2e-2)
+    late_tol = {"bf16": 3e-2, "bf16x3": 1e-2}.get(mode, 5e-2)
     _set_mode(mode)
     try:
         single, _ = SAR_Net(seed=99, **kw)
