@@ -44,7 +44,8 @@ struct StemG {
     int TR;                     // rows per tile: conv rows (stats, wgrad) / pooled rows (pool)
     int tiles;                  // tiles per image
     int pld;                    // patch row pitch in bf16 elements (even): 2*(Wo-1) + 8
-    int patch_bytes;            // LDS bytes reserved for the patch
+    int patch_bytes;            // LDS bytes reserved for the patch (SAR_X3: three planes -- hi, lo, and the fp16 image the weight gradient multiplies)
+    int ppe;                    // SAR_X3: elements (2-byte) from one patch plane to the next
     int fast;                   // D and pl even, pld <= 128: the patch fill may use 8-byte loads, one column pair per thread
     unsigned mg_wo, mg_wp;
 };
@@ -82,13 +83,20 @@ __device__ __forceinline__ void stem_w_store(const WStage<NT>& ws, unsigned char
     for (int i = 0; i < NT; ++i) {
         const int fl = tid + 256 * i, f = fl >> 6, ln = fl & 63, s = f & 3;
         const bool ok = 2 * s + (ln >> 5) < 7;
-        h16x8 o;
+        h16x8 o, ol;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) o[j] = (h16)(ok ? ws.v[i][j] : 0.f);
+        for (int j = 0; j < 7; ++j) {
+            const float v = ok ? ws.v[i][j] : 0.f;
+            o[j] = (h16)v;
+            if constexpr (X3) ol[j] = (h16)(v - (float)o[j]);
+        }
         o[7] = (h16)0.f;
         *reinterpret_cast<h16x8*>(wfr + fl * 16) = o;
+        if constexpr (X3) { ol[7] = (h16)0.f; *reinterpret_cast<h16x8*>(wfr + NT * 4096 + fl * 16) = ol; }   // the lo fragments follow the NT*4 hi ones
     }
 }
+// the (hi) fragments into registers.  (SAR_X3: the lo fragments stay in LDS, behind the hi ones, and stem_mtile reads them where it uses
+// them -- held in registers as well they spilled the 64-channel weight-gradient kernel)
 template <int NT>
 __device__ __forceinline__ void stem_w_frags(h16x8 (&wa)[NT][4], const unsigned char* wfr, int lane) {
 #pragma unroll
@@ -114,17 +122,26 @@ __device__ __forceinline__ void stem_x_load(XStage<ITER>& xs, const float* __res
         xs.v[i] = ok ? v : make_float2(0.f, 0.f);
     }
 }
+// two neighbouring input values into the patch: the 2-byte pair; SAR_X3: + the pair of the lo plane and the fp16 pair of the third plane
+__device__ __forceinline__ void stem_put2(u16* dst, int ppe, float a, float b) {
+    const unsigned hw = pack2(a, b);
+    *reinterpret_cast<unsigned*>(dst) = hw;
+    if constexpr (X3) {
+        *reinterpret_cast<unsigned*>(dst + ppe) = pack2(a - h_lo(hw), b - h_hi(hw));
+        *reinterpret_cast<unsigned*>(dst + 2 * ppe) = wpack2(a, b);
+    }
+}
 template <int ITER>
 __device__ __forceinline__ void stem_x_store(const XStage<ITER>& xs, u16* patch, const StemG& g, int nprow, int tid) {
     const int c = 2 * (tid & 63);
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         const int r = (tid >> 6) + 4 * i;
-        if (r < nprow && c < g.pld) *reinterpret_cast<unsigned*>(patch + r * g.pld + c) = pack2(xs.v[i].x, xs.v[i].y);
+        if (r < nprow && c < g.pld) stem_put2(patch + r * g.pld + c, g.ppe, xs.v[i].x, xs.v[i].y);
     }
 }
 // general form: any D / padding, two columns per thread, one row group at a time
-__device__ __noinline__ void stem_fill_slow(u16* patch, const float* __restrict__ x, int T, int D, int pl, int pld, int n, int row0, int nprow, int tid) {
+__device__ __noinline__ void stem_fill_slow(u16* patch, int ppe, const float* __restrict__ x, int T, int D, int pl, int pld, int n, int row0, int nprow, int tid) {
     const float* xb = x + (size_t)n * T * D;
     const int cp = tid & 63;
     for (int r = tid >> 6; r < nprow; r += 4) {
@@ -135,7 +152,7 @@ __device__ __noinline__ void stem_fill_slow(u16* patch, const float* __restrict_
             const int w0 = c - pl, w1 = w0 + 1;
             const bool ok0 = rok && w0 >= 0 && w0 < D, ok1 = rok && w1 >= 0 && w1 < D;
             const float v0 = xr[ok0 ? w0 : 0], v1 = xr[ok1 ? w1 : 0];
-            *reinterpret_cast<unsigned*>(patch + r * pld + c) = pack2(ok0 ? v0 : 0.f, ok1 ? v1 : 0.f);
+            stem_put2(patch + r * pld + c, ppe, ok0 ? v0 : 0.f, ok1 ? v1 : 0.f);
         }
     }
 }
@@ -150,23 +167,37 @@ __device__ __forceinline__ void stem_stage(unsigned char* wfr, u16* patch, const
     mid();
     if (with_w) stem_w_store<NT>(ws, wfr, tid);
     if (fast) stem_x_store<ITER>(xs, patch, g, nprow, tid);
-    else stem_fill_slow(patch, x, g.T, g.D, g.pl, g.pld, n, row0, nprow, tid);
+    else stem_fill_slow(patch, g.ppe, x, g.T, g.D, g.pl, g.pld, n, row0, nprow, tid);
 }
 
 // One 32-pixel column block: acc[ct] += W(ct) * patches for ct in [CT0, CT0 + NC); boff = (2*ty + h) * pld + 2*tx (bf16 index of
 // the lane's first element); lanes of pixels past the tile multiply zeros
 template <int NT, int CT0, int NC>
-__device__ __forceinline__ void stem_mtile(const h16x8 (&wa)[NT][4], const u16* patch, int pld, unsigned boff, bool valid, f32x16 (&acc)[NC], h16x8 (&bfr)[4]) {
+__device__ __forceinline__ void stem_mtile(const h16x8 (&wa)[NT][4], const unsigned char* wfr, int lane, const u16* patch, int ppe, int pld, unsigned boff, bool valid,
+                                           f32x16 (&acc)[NC], h16x8 (&bfr)[4]) {
+    h16x8 bl[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const unsigned* q = reinterpret_cast<const unsigned*>(patch + boff + 2 * s * pld);
         const uint4 v = make_uint4(q[0], q[1], q[2], q[3]);
         bfr[s] = __builtin_bit_cast(h16x8, valid ? v : make_uint4(0u, 0u, 0u, 0u));
+        if constexpr (X3) {
+            const unsigned* ql = reinterpret_cast<const unsigned*>(patch + ppe + boff + 2 * s * pld);
+            const uint4 vl = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+            bl[s] = __builtin_bit_cast(h16x8, valid ? vl : make_uint4(0u, 0u, 0u, 0u));
+        }
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = MFMA16(wa[CT0 + c][s], bfr[s], acc[c], 0, 0, 0);
+        for (int c = 0; c < NC; ++c) {
+            if constexpr (X3) {                                      // small terms first
+                const h16x8 wl = *reinterpret_cast<const h16x8*>(wfr + NT * 4096 + (((CT0 + c) * 4 + s) * 64 + lane) * 16);
+                acc[c] = MFMA16(wl, bfr[s], acc[c], 0, 0, 0);
+                acc[c] = MFMA16(wa[CT0 + c][s], bl[s], acc[c], 0, 0, 0);
+            }
+            acc[c] = MFMA16(wa[CT0 + c][s], bfr[s], acc[c], 0, 0, 0);
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------- forward pass 1: statistics
@@ -175,9 +206,9 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
                                                            float* __restrict__ bins, const StemG g, int det) {
     constexpr int C0 = NT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* wfr = smem;                                                       // [NT*4][64][16 B]
-    u16* patch = reinterpret_cast<u16*>(smem + NT * 4096);
-    float* red = reinterpret_cast<float*>(smem + NT * 4096 + g.patch_bytes);         // [4 waves x 2 lane rows][2][C0]
+    unsigned char* wfr = smem;                                                       // [NPL][NT*4][64][16 B]
+    u16* patch = reinterpret_cast<u16*>(smem + NPL * NT * 4096);
+    float* red = reinterpret_cast<float*>(smem + NPL * NT * 4096 + g.patch_bytes);   // [4 waves x 2 lane rows][2][C0]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int n = blockIdx.x / g.tiles, tr = blockIdx.x % g.tiles;
     const int r0 = tr * g.TR, nr = min(g.TR, g.Ho - r0), npix = nr * g.Wo;
@@ -200,7 +231,7 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-        stem_mtile<NT, 0, NT>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, p < npix, acc, bfr);
+        stem_mtile<NT, 0, NT>(wa, wfr, lane, patch, g.ppe, g.pld, (2 * ty + h) * g.pld + 2 * tx, p < npix, acc, bfr);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
@@ -245,13 +276,14 @@ __global__ __launch_bounds__(256) void stem16_stats_kernel(const float* __restri
 // ~1 % of the windows pick a neighbour of the true maximum, a 7 % error of the kernel gradient against the float64 oracle.
 template <int NT>
 __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                          const BnP bn, u16* __restrict__ pooled, uint8_t* __restrict__ idx, const StemG g) {
+                                                          const BnP bn, u16* __restrict__ pooled, u16* __restrict__ pooled_h, uint8_t* __restrict__ idx, const StemG g) {
+    // (SAR_X3: `pooled` is a plane pair, pooled_h -- nullable -- the same map as ONE fp16 tensor: the operand of the first block's weight gradients)
     constexpr int C0 = NT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cst = reinterpret_cast<float*>(smem);                                     // [4][C0]: scale, shift (+ scale*bias), mean, rstd
     unsigned char* wfr = smem + 4 * C0 * 4;
-    u16* patch = reinterpret_cast<u16*>(wfr + NT * 4096);
-    unsigned char* zt = wfr + NT * 4096 + g.patch_bytes;                             // [pixel][ZP bytes]
+    u16* patch = reinterpret_cast<u16*>(wfr + NPL * NT * 4096);
+    unsigned char* zt = wfr + NPL * NT * 4096 + g.patch_bytes;                       // [pixel][ZP bytes]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
     const int n = blockIdx.x / g.tiles, tile = blockIdx.x % g.tiles;
     const int i0 = tile * g.TR, npr = min(g.TR, g.Hp - i0);
@@ -276,7 +308,7 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
             f32x16 acc[1]; h16x8 bfr[4];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-            stem_mtile<NT, CT, 1>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
+            stem_mtile<NT, CT, 1>(wa, wfr, lane, patch, g.ppe, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int cl = 8 * gq + 4 * h, ch0 = CT * 32 + cl;
@@ -303,8 +335,16 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
                     k0 = max(k0, (q.x & m) | cd); k1 = max(k1, (q.y & m) | cd); k2 = max(k2, (q.z & m) | cd); k3 = max(k3, (q.w & m) | cd);
                 }
             const size_t o = (((size_t)n * g.Hp + i0 + pi) * g.Wp + pj) * C0 + CT * 32 + g4 * 4;
-            *reinterpret_cast<uint2*>(pooled + o) = make_uint2(pack2(__uint_as_float(k0 & ~15u), __uint_as_float(k1 & ~15u)),
-                                                               pack2(__uint_as_float(k2 & ~15u), __uint_as_float(k3 & ~15u)));
+            const float v0 = __uint_as_float(k0 & ~15u), v1 = __uint_as_float(k1 & ~15u), v2 = __uint_as_float(k2 & ~15u), v3 = __uint_as_float(k3 & ~15u);
+            if constexpr (X3) {
+                unsigned h0, l0, h1, l1;
+                split2(v0, v1, h0, l0); split2(v2, v3, h1, l1);
+                *reinterpret_cast<uint2*>(pooled + o) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(pooled + (size_t)g.B * g.Hp * g.Wp * C0 + o) = make_uint2(l0, l1);
+                if (pooled_h != nullptr) *reinterpret_cast<uint2*>(pooled_h + o) = make_uint2(wpack2(v0, v1), wpack2(v2, v3));
+            } else {
+                *reinterpret_cast<uint2*>(pooled + o) = make_uint2(pack2(v0, v1), pack2(v2, v3));
+            }
             *reinterpret_cast<unsigned*>(idx + o) = (15u - (k0 & 15u)) | ((15u - (k1 & 15u)) << 8) | ((15u - (k2 & 15u)) << 16) | ((15u - (k3 & 15u)) << 24);
         }
     };
@@ -353,9 +393,14 @@ __global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __res
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
     for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
         const size_t o = (size_t)pix * C0 + cv * 8;
-        const uint4 av = *reinterpret_cast<const uint4*>(pooled + o), gv = *reinterpret_cast<const uint4*>(gp + o);
         float a[8], gg[8];
-        unpack8(av, a); unpack8(gv, gg);
+        if constexpr (X3) {                                                          // plane pairs, npix * C0 elements apart
+            const size_t ps = (size_t)npix * C0;
+            join8(*reinterpret_cast<const uint4*>(pooled + o), *reinterpret_cast<const uint4*>(pooled + ps + o), a);
+            join8(*reinterpret_cast<const uint4*>(gp + o), *reinterpret_cast<const uint4*>(gp + ps + o), gg);
+        } else {
+            unpack8(*reinterpret_cast<const uint4*>(pooled + o), a); unpack8(*reinterpret_cast<const uint4*>(gp + o), gg);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (a[k] > 0.f) {
@@ -400,20 +445,23 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                               const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
                                                               const BnP bn, int* __restrict__ counter, float* __restrict__ part, const StemG g, int ntiles,
-                                                              int dz_bytes) {
+                                                              int dz_bytes, float gs) {
+    // SAR_X3: gp / pooled are plane pairs in TRUE units; the conv is recomputed in split precision; the scattered gradient image, dy and the
+    // im2col image are fp16 (w16) and carry the scale gs (the fp16 product's range; stem16_wsum divides by it), so E and F take it too
     constexpr int C0 = NT * 32, SCR = 3 * PLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_tile;
     float* cst = reinterpret_cast<float*>(smem);                                     // [6][C0] from the prologue, then [3][C0]: A, E, F
     float* aef = cst + 6 * C0;
     unsigned char* wfr = smem + 9 * C0 * 4;
-    u16* patch = reinterpret_cast<u16*>(wfr + NT * 4096);
-    unsigned char* dz = wfr + NT * 4096 + g.patch_bytes;                             // [pixel][DZP]
+    u16* patch = reinterpret_cast<u16*>(wfr + NPL * NT * 4096);
+    unsigned char* dz = wfr + NPL * NT * 4096 + g.patch_bytes;                       // [pixel][DZP]
     unsigned char* scr0 = dz + dz_bytes + 256;                                       // [4 waves][SCR]: P planes 0, 1, dy plane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
     unsigned char* scr = scr0 + wave * SCR;
     h16x8 wa[NT][4];
     f32x16 accw[2][NT];
+    const size_t pps = X3 ? (size_t)g.B * g.Hp * g.Wp * C0 : 0;                      // SAR_X3: elements between the planes of gp / pooled
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
@@ -432,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
         for (int i = tid; i < C0; i += 256) {
             const float scale = cst[i], mean = cst[2 * C0 + i], rstd = cst[3 * C0 + i], c2 = cst[4 * C0 + i], c3 = cst[5 * C0 + i];
             const float xb = (bias[i] - mean) * rstd, Cc = -scale * c3;
-            aef[i] = scale; aef[C0 + i] = Cc * rstd; aef[2 * C0 + i] = -scale * c2 + Cc * xb;
+            aef[i] = scale; aef[C0 + i] = Cc * rstd * gs; aef[2 * C0 + i] = (-scale * c2 + Cc * xb) * gs;
         }
         stem_w_store<NT>(ws, wfr, tid);
         for (int i = tid * 16; i < dz_bytes; i += 256 * 16) *reinterpret_cast<uint4*>(dz + i) = make_uint4(0u, 0u, 0u, 0u);
@@ -461,28 +509,39 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
             t_a = __builtin_amdgcn_s_memtime();
 #endif
             auto scatter = [&]() __attribute__((always_inline)) {
-                uint4 pv[2], gv[2]; uint2 iv[2];
+                uint4 pv[2], gv[2], gl[2]; uint2 iv[2];
+                // the gradient pair of channel k as the dz image takes it: the raw 16 bits; SAR_X3: fp16((hi + lo) * gs)
+                auto gbits = [&](const uint4 hq, const uint4 lq, int k) __attribute__((always_inline)) -> unsigned {
+                    const unsigned hs[4] = {hq.x, hq.y, hq.z, hq.w}, sh = 16 * (k & 1);
+                    if constexpr (X3) {
+                        const unsigned ls[4] = {lq.x, lq.y, lq.z, lq.w};
+                        const float v = ((k & 1) ? h_hi(hs[k >> 1]) + h_hi(ls[k >> 1]) : h_lo(hs[k >> 1]) + h_lo(ls[k >> 1])) * gs;
+                        return (unsigned)__builtin_bit_cast(unsigned short, (w16)v);
+                    } else return (hs[k >> 1] >> sh) & 0xffffu;
+                };
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int it = min(tid + 256 * u, nitems - 1), cg = it & 3, pp = it >> 2;
                     const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
                     pv[u] = *reinterpret_cast<const uint4*>(pooled + o); gv[u] = *reinterpret_cast<const uint4*>(gp + o);
+                    if constexpr (X3) gl[u] = *reinterpret_cast<const uint4*>(gp + pps + o); else gl[u] = gv[u];
                     iv[u] = *reinterpret_cast<const uint2*>(idx + o);
                 }
                 for (int it0 = tid + 512; it0 < nitems; it0 += 256) {               // tiles with more than 512 items (wide inputs): one at a time
                     const int cg = it0 & 3, pp = it0 >> 2;
                     const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
                     const uint4 p1 = *reinterpret_cast<const uint4*>(pooled + o), g1 = *reinterpret_cast<const uint4*>(gp + o);
+                    const uint4 g1l = X3 ? *reinterpret_cast<const uint4*>(gp + pps + o) : g1;
                     const uint2 i1 = *reinterpret_cast<const uint2*>(idx + o);
                     const int wi = pp / g.Wp, wj = pp - wi * g.Wp;
-                    const unsigned ps[4] = {p1.x, p1.y, p1.z, p1.w}, gs[4] = {g1.x, g1.y, g1.z, g1.w};
+                    const unsigned ps[4] = {p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = (gs[k >> 1] >> sh) & 0xffffu;
+                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = gbits(g1, g1l, k);
                         const int slot = ((k < 4 ? i1.x : i1.y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
                         const int r = 2 * (i_lo + wi) - g.ppt + kh - r0, c = 2 * wj - g.ppl + kw;
                         if (pz != 0u && r >= 0 && r < nr) {
-                            lds_pk_add(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2, gz << sh);
+                            lds_pk_add_w(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2, gz << sh);
                         }
                     }
                 }
@@ -490,17 +549,17 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                 for (int u = 0; u < 2; ++u) {
                     const int it = tid + 256 * u, cg = it & 3, pp = it >> 2;
                     const int wi = (int)udiv((unsigned)pp, g.mg_wp, (unsigned)g.Wp), wj = pp - wi * g.Wp;
-                    const unsigned ps[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+                    const unsigned ps[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
                     const int rb = 2 * (i_lo + wi) - g.ppt - r0, cbase = 2 * wj - g.ppl;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         // pooled >= 0 always (ReLU): positive <=> non-zero magnitude bits.  (A branch-free form -- misses add 0 to a dummy
                         // word -- doubled the phase: it is the LDS atomics that cost, not the branches.)
-                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = (gs[k >> 1] >> sh) & 0xffffu;
+                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = gbits(gv[u], gl[u], k);
                         const int slot = ((k < 4 ? iv[u].x : iv[u].y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
                         const int r = rb + kh, c = cbase + kw;
                         if (it < nitems && pz != 0u && r >= 0 && r < nr) {
-                            lds_pk_add(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2, gz << sh);
+                            lds_pk_add_w(dz + (size_t)(r * g.Wo + c) * DZP + (cg * 8 + (k & ~1)) * 2, gz << sh);
                         }
                     }
                 }
@@ -519,11 +578,17 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                 f32x16 acc[1]; h16x8 bfr[4];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
-                stem_mtile<NT, CT, 1>(wa, patch, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
+                stem_mtile<NT, CT, 1>(wa, wfr, lane, patch, g.ppe, g.pld, (2 * ty + h) * g.pld + 2 * tx, valid, acc, bfr);
                 // the lane's B fragments ARE its pixel's im2col row (taps (2s+h)*8 .. +8): plane (2s+h)/4, 16 bytes at ((2s+h)%4)*16
+                // (SAR_X3: the same four dwords of the patch's fp16 plane)
 #pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-                    *reinterpret_cast<h16x8*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = bfr[s2];
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    if constexpr (X3) {
+                        const unsigned* qw = reinterpret_cast<const unsigned*>(patch + 2 * g.ppe + (2 * ty + h) * g.pld + 2 * tx + 2 * s2 * g.pld);
+                        const uint4 vw = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+                        *reinterpret_cast<uint4*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = valid ? vw : make_uint4(0u, 0u, 0u, 0u);
+                    } else *reinterpret_cast<h16x8*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = bfr[s2];
+                }
                 unsigned char* dzp = dz + (size_t)pc * DZP + 8 * h;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
@@ -534,29 +599,29 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                     const float4 A4 = *reinterpret_cast<const float4*>(aef + ch0), E4 = *reinterpret_cast<const float4*>(aef + C0 + ch0),
                                  F4 = *reinterpret_cast<const float4*>(aef + 2 * C0 + ch0);
                     // lanes past the tile: acc = 0 and dz = 0, so F alone has to be masked
-                    const float d0 = fmaf(A4.x, h_lo(dv.x), fmaf(E4.x, acc[0][gq * 4 + 0], valid ? F4.x : 0.f));
-                    const float d1 = fmaf(A4.y, h_hi(dv.x), fmaf(E4.y, acc[0][gq * 4 + 1], valid ? F4.y : 0.f));
-                    const float d2 = fmaf(A4.z, h_lo(dv.y), fmaf(E4.z, acc[0][gq * 4 + 2], valid ? F4.z : 0.f));
-                    const float d3 = fmaf(A4.w, h_hi(dv.y), fmaf(E4.w, acc[0][gq * 4 + 3], valid ? F4.w : 0.f));
-                    *reinterpret_cast<uint2*>(scr + 2 * PLANE + q * IP + cl * 2) = make_uint2(pack2(d0, d1), pack2(d2, d3));
+                    const float d0 = fmaf(A4.x, w_lo(dv.x), fmaf(E4.x, acc[0][gq * 4 + 0], valid ? F4.x : 0.f));
+                    const float d1 = fmaf(A4.y, w_hi(dv.x), fmaf(E4.y, acc[0][gq * 4 + 1], valid ? F4.y : 0.f));
+                    const float d2 = fmaf(A4.z, w_lo(dv.y), fmaf(E4.z, acc[0][gq * 4 + 2], valid ? F4.z : 0.f));
+                    const float d3 = fmaf(A4.w, w_hi(dv.y), fmaf(E4.w, acc[0][gq * 4 + 3], valid ? F4.w : 0.f));
+                    *reinterpret_cast<uint2*>(scr + 2 * PLANE + q * IP + cl * 2) = make_uint2(wpack2(d0, d1), wpack2(d2, d3));
                 }
                 // the wave's own LDS stores are ordered in front of its own reads (same queue); keep the compiler from reordering them
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const unsigned o0 = (16 * ks + prb) * IP + colb, o1 = o0 + 4 * IP;
-                    h16x8 Af[2], Bf;
+                    w16x8 Af[2], Bf;
 #pragma unroll
                     for (int tp = 0; tp < 2; ++tp) {
                         const s16x4 lo = lds_tr(scr + tp * PLANE, o0), hi = lds_tr(scr + tp * PLANE, o1);
-                        Af[tp] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        Af[tp] = __builtin_bit_cast(w16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
                     {
                         const s16x4 lo = lds_tr(scr + 2 * PLANE, o0), hi = lds_tr(scr + 2 * PLANE, o1);
-                        Bf = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                        Bf = __builtin_bit_cast(w16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                     }
 #pragma unroll
-                    for (int tp = 0; tp < 2; ++tp) accw[tp][CT] = MFMA16(Af[tp], Bf, accw[tp][CT], 0, 0, 0);
+                    for (int tp = 0; tp < 2; ++tp) accw[tp][CT] = MFMA16W(Af[tp], Bf, accw[tp][CT], 0, 0, 0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // the transpose-reads are done before the images are rewritten
             }
@@ -638,7 +703,8 @@ static bool stem_geo(StemG& g, int B, int T, int D, int Ho, int Wo, int C0, int 
 }
 static void stem_tiles(StemG& g, int TR, int rows, int conv_rows_per_tile) {
     g.TR = TR; g.tiles = (rows + TR - 1) / TR;
-    g.patch_bytes = (((2 * (conv_rows_per_tile - 1) + 8) * g.pld * 2) + 15) & ~15;
+    const int plane = (((2 * (conv_rows_per_tile - 1) + 8) * g.pld * 2) + 15) & ~15;
+    g.ppe = plane / 2; g.patch_bytes = (X3 ? 3 : 1) * plane;
 }
 template <typename KT>
 static bool allow_lds(KT kernel, size_t bytes) {
@@ -661,7 +727,7 @@ int SAR_STEM(sar_stem16_stats)(const float* x, const float* w, const float* bias
     if (!x || !w || !bias || !bins || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, 1, 1, 0, 0)) return SAR_EINVAL;
     int TR = env_int("SAR_STEM_STATS_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
     stem_tiles(g, TR, Ho, TR);
-    const size_t lds = (size_t)(C0 / 32) * 4096 + g.patch_bytes + 8 * 2 * C0 * 4;
+    const size_t lds = (size_t)NPL * (C0 / 32) * 4096 + g.patch_bytes + 8 * 2 * C0 * 4;
     if (lds > 160 * 1024) return SAR_EINVAL;
     const int nblk = B * g.tiles;
     if (C0 == 64) {
@@ -678,22 +744,29 @@ int SAR_STEM(sar_stem16_stats)(const float* x, const float* w, const float* bias
 // Forward pass 2: pooled (B,Hp,Wp,C0) bf16 = maxpool3x3/2(relu(bn(conv(x) + bias))), idx (same shape, u8) = window slot kh*3+kw of the
 // first maximum.  bn: statistics from bn->bins (training; the launch with bn->write also stores saved / moving statistics) or
 // bn->saved (bins null: inference with folded moving averages).
+// (sar_stem16_pool_fwd_x3: pooled = a plane pair, pooled_h -- nullable -- the same map as one fp16 tensor)
+#if SAR_X3
+int sar_stem16_pool_fwd_x3(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, void* pooled_h, uint8_t* idx, int B, int T, int D,
+                           int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+#else
 int SAR_STEM(sar_stem16_pool_fwd)(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
                         int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+    void* pooled_h = nullptr;
+#endif
     StemG g;
     if (!x || !w || !bias || !bn || !pooled || !idx || !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
     int TR = env_int("SAR_STEM_POOL_ROWS", 3); TR = TR < 1 ? 1 : (TR > Hp ? Hp : TR);
     const int crows = 2 * TR + 1;
     stem_tiles(g, TR, Hp, crows);
-    const size_t lds = (size_t)4 * C0 * 4 + (size_t)(C0 / 32) * 4096 + g.patch_bytes + (size_t)crows * Wo * ZP;
+    const size_t lds = (size_t)4 * C0 * 4 + (size_t)NPL * (C0 / 32) * 4096 + g.patch_bytes + (size_t)crows * Wo * ZP;
     if (lds > 160 * 1024) return SAR_EINVAL;
     const int nblk = B * g.tiles;
     if (C0 == 64) {
         if (!allow_lds(stem16_pool_kernel<2>, lds)) return SAR_ELAUNCH;
-        hipLaunchKernelGGL(stem16_pool_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, *bn, static_cast<u16*>(pooled), idx, g);
+        hipLaunchKernelGGL(stem16_pool_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, *bn, static_cast<u16*>(pooled), static_cast<u16*>(pooled_h), idx, g);
     } else {
         if (!allow_lds(stem16_pool_kernel<1>, lds)) return SAR_ELAUNCH;
-        hipLaunchKernelGGL(stem16_pool_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, *bn, static_cast<u16*>(pooled), idx, g);
+        hipLaunchKernelGGL(stem16_pool_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, *bn, static_cast<u16*>(pooled), static_cast<u16*>(pooled_h), idx, g);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -718,7 +791,7 @@ int SAR_STEM(sar_stem16_bwd_reduce)(const void* g_pooled, const void* pooled, co
     return SAR_OK;
 }
 
-#if !SAR_HALF
+#if !SAR_HALF && !SAR_X3
 size_t sar_stem16_wgrad_workspace_bytes(int C0) { return 64 + (size_t)WG_MAX_BLOCKS * 64 * C0 * sizeof(float); }
 #endif
 
@@ -732,11 +805,13 @@ int SAR_STEM(sar_stem16_wgrad)(const float* x, const float* w, const float* bias
     StemG g;
     if (!x || !w || !bias || !g_pooled || !pooled || !idx || !bn || !bn->bbins || !bn->saved || !dw || !work ||
         !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
-    int TR = env_int("SAR_STEM_WG_ROWS", 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
+    // tile height: 8 conv rows (4 / 5 / 6 / 8 / 10 measured within 0.4 % of each other, round 3); split precision: 6, so that two blocks still fit a
+    // CU's LDS (three patch planes, two sets of kernel fragments)
+    int TR = env_int("SAR_STEM_WG_ROWS", X3 ? 6 : 8); TR = TR < 1 ? 1 : (TR > Ho ? Ho : TR);
     stem_tiles(g, TR, Ho, TR);
     const int NT = C0 / 32;
     const int dz_bytes = (TR * Wo * DZP + 15) & ~15;                  // + 256 bytes behind it: the scatter's per-lane dummy words
-    size_t lds = (size_t)9 * C0 * 4 + (size_t)NT * 4096 + g.patch_bytes + dz_bytes + 256 + 4 * 3 * PLANE;
+    size_t lds = (size_t)9 * C0 * 4 + (size_t)NPL * NT * 4096 + g.patch_bytes + dz_bytes + 256 + 4 * 3 * PLANE;
     const size_t merge = (size_t)9 * C0 * 4 + 64 * C0 * 4;
     if (lds < merge) lds = merge;
     if (lds > 160 * 1024) return SAR_EINVAL;
@@ -744,14 +819,19 @@ int SAR_STEM(sar_stem16_wgrad)(const float* x, const float* w, const float* bias
     const int nblk = ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS;
     int* counter = reinterpret_cast<int*>(work);
     float* part = work + 16;
+    // SAR_X3: g_pooled and the BatchNorm sums are in true units (the kernel's BatchNorm gets ginv = 1); bn->ginv = 1 / (the scale the
+    // gradient takes on its way into the fp16 product), undone by stem16_wsum
+    sarBnRef bnk = *bn;
+    float gs = 1.f;
+    if (X3) { gs = bn->ginv > 0.f ? 1.f / bn->ginv : 1.f; bnk.ginv = 1.f; }
     if (C0 == 64) {
         if (!allow_lds(stem16_wgrad_kernel<2>, lds)) return SAR_ELAUNCH;
         hipLaunchKernelGGL(stem16_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
-                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, dz_bytes);
+                           static_cast<const u16*>(pooled), idx, bnk, counter, part, g, ntiles, dz_bytes, gs);
     } else {
         if (!allow_lds(stem16_wgrad_kernel<1>, lds)) return SAR_ELAUNCH;
         hipLaunchKernelGGL(stem16_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),
-                           static_cast<const u16*>(pooled), idx, *bn, counter, part, g, ntiles, dz_bytes);
+                           static_cast<const u16*>(pooled), idx, bnk, counter, part, g, ntiles, dz_bytes, gs);
     }
     hipLaunchKernelGGL(stem16_wsum_kernel, dim3(49, WS_SLICES), dim3(256), 0, stream, part, nblk, dw, C0, counter, bn->ginv);
     SAR_CHECK_LAUNCH();

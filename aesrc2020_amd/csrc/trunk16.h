@@ -72,6 +72,28 @@ __device__ __forceinline__ void lds_pk_add(unsigned char* dst, unsigned val) {  
     __builtin_amdgcn_ds_atomic_fadd_v2bf16((__attribute__((address_space(3))) s16x2*)dst, __builtin_bit_cast(s16x2, val));
 }
 #endif
+// The 2-byte type of the STEM weight gradient's MFMA operands (scattered gradient image, dy image, im2col image; stem_bf16.hip): the
+// build's own type, except in split precision, where that product runs single-pass on fp16 like the other weight gradients.
+#if SAR_X3
+typedef _Float16 w16;
+#define MFMA16W __builtin_amdgcn_mfma_f32_32x32x16_f16
+__device__ __forceinline__ void lds_pk_add_w(unsigned char* dst, unsigned val) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+    __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) f16x2_*)dst, __builtin_bit_cast(f16x2_, val));
+}
+#else
+typedef h16 w16;
+#define MFMA16W MFMA16
+__device__ __forceinline__ void lds_pk_add_w(unsigned char* dst, unsigned val) { lds_pk_add(dst, val); }
+#endif
+typedef __attribute__((ext_vector_type(8))) w16 w16x8;
+typedef __attribute__((ext_vector_type(2))) w16 w16x2;
+__device__ __forceinline__ float w_lo(unsigned u) { return (float)__builtin_bit_cast(w16x2, u)[0]; }
+__device__ __forceinline__ float w_hi(unsigned u) { return (float)__builtin_bit_cast(w16x2, u)[1]; }
+__device__ __forceinline__ unsigned wpack2(float a, float b) {
+    w16x2 p; p[0] = (w16)a; p[1] = (w16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     h16x2 p; p[0] = (h16)a; p[1] = (h16)b;                  // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (RNE)
     return __builtin_bit_cast(unsigned, p);

@@ -329,7 +329,7 @@ class ResNetTrunk(Layer):
         return self.buf(key, shape, self.t_side)
 
     def _stem_fn(self, name):
-        return name + "_f16" if self.half else name
+        return name + ("_f16" if self.half else "_x3" if self.x3 else "")
 
     def _forward16(self, x, B):
         """Same graph as forward() on 2-byte activations: one launch per conv (BN+ReLU of the producer evaluated in the conv's
@@ -518,6 +518,7 @@ class ResNetTrunk(Layer):
     # chain.  Measured slower (cfg2: 3.14 vs 2.90 ms per step): the batched launch is bound by the memory system and takes it
     # away from the chain's fills; default = one batch at the end of the backward call, on the main stream.
     WGRAD_OVERLAP = os.environ.get("SAR_WGRAD_OVERLAP", "0") == "1"
+    STEM_X3 = os.environ.get("SAR_STEM_X3", "1") != "0"           # split precision: the recompute-form stem (0: round 1's fp32 stem + casts)
     PAIR = os.environ.get("SAR_CONV_PAIR", "1") != "0"
 
     def _pair(self, a3x3, b1x1):
@@ -577,8 +578,8 @@ class ResNetTrunk(Layer):
         return (B, T, D, H, W, self.stem.cout, self.stem.pt, self.stem.pl), (Hp, Wp, self.pool_pt, self.pool_pl)
 
     def _stem_forward16(self, x, B, st):
-        if self.x3:
-            # (interim) split precision: round 1's fp32 stem (full-resolution map), its pooled map cast to planes + the fp16 copy the first
+        if self.x3 and not self.STEM_X3:
+            # (SAR_STEM_X3=0, for A/B runs) round 1's fp32 stem (full-resolution map), its pooled map cast to planes + the fp16 copy the first
             # block's weight gradients read
             p32 = self._stem_forward(x, B)
             Hp, Wp = self.pool_hw; c0 = self.stem.cout
@@ -592,12 +593,17 @@ class ResNetTrunk(Layer):
         if training:
             _call(self._stem_fn("sar_stem16_stats"), x, cv.kernel.w, cv.bias.w, sb.bins, *conv, int(self.det))
         self.pooled16 = self._buf16("pooled16", (B, Hp, Wp, c0)); self.pool_idx = self.buf("pool_idx", (B, Hp, Wp, c0), torch.uint8)
+        if self.x3:                                                          # + the pooled map as one fp16 tensor: what the first block's weight gradients read
+            self.pooled_h = self._side16("pooled_h", (B, Hp, Wp, c0))
+            _call("sar_stem16_pool_fwd_x3", x, cv.kernel.w, cv.bias.w, sb.ref(B * H * W, st, training), self.pooled16, self.pooled_h if training else None,
+                  self.pool_idx, *conv, *pool)
+            return self.pooled16
         _call(self._stem_fn("sar_stem16_pool_fwd"), x, cv.kernel.w, cv.bias.w, sb.ref(B * H * W, st, training), self.pooled16, self.pool_idx, *conv, *pool)
         return self.pooled16
 
     def _stem_backward16(self, g, B):
         """g: gradient of the pooled map (bf16).  BatchNorm sums from (g, pooled, slots), then the 7x7 kernel gradient."""
-        if self.x3:
+        if self.x3 and not self.STEM_X3:
             g32 = self.scratch("stem_g32", tuple(g.shape[1:]))
             _call("sar_cast_x3_f32", g, g32, g32.numel())
             return self._stem_backward(g32, B)

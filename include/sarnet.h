@@ -324,6 +324,21 @@ int sar_bn_bwd_reduce_x3(const void* dact, int dact_f32, const void* x, const fl
 int sar_bn_apply_x3_f32(const void* x, const sarBnRef* bn, float* out, long R, int C, int relu, sarStream_t stream);
 int sar_cast_f32_x3(const float* x, void* y, void* y16, float scale, long n, sarStream_t stream);
 int sar_cast_x3_f32(const void* x, float* y, long n, sarStream_t stream);
+/* The recompute-form stem in split precision: the 7x7 conv is evaluated with hi / lo planes of the input patch and of the kernel fragments
+ * (three MFMAs per block) wherever its output is needed.  pooled: a plane pair; pooled_h (nullable): the same map as ONE fp16 tensor, the
+ * operand of the first residual block's weight gradients.  sar_stem16_wgrad_x3: g_pooled a plane pair in true units; the final product
+ * dW = im2col^T dy runs single-pass on fp16 operands that carry the scale 1 / bn->ginv (bn->ginv: applied to dW only; the BatchNorm's own
+ * parameter gradients come from the true-unit sums of sar_stem16_bwd_reduce_x3). */
+int sar_stem16_stats_x3(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
+                        int pad_top, int pad_left, int det, sarStream_t stream);
+int sar_stem16_pool_fwd_x3(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, void* pooled_h, uint8_t* idx, int B, int T, int D,
+                           int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
+int sar_stem16_bwd_reduce_x3(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                             const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                             int pool_pad_top, int pool_pad_left, sarStream_t stream);
+int sar_stem16_wgrad_x3(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
+                        const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
+                        int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
 
 /* ---- BatchNormalization, training mode, eps 1e-3, momentum .99: resnet.py:25; model.py:29-30,286,289.
  * x is viewed (R, C).  sums = workspace of sar_bn_workspace_bytes(C): fp64 totals[2C] (sum dz, sum dz*xhat after a
