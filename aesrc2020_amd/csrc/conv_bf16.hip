@@ -1409,32 +1409,35 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     // Pixel tile of the 32-output-channel launches (stage 0, its shortcut and gradients).  Round 2 ran them as 128-pixel tiles on four
     // waves: 1 000 blocks at B = 64 for 768 resident slots -- 1.3 rounds, the second a third full.  256 pixels on EIGHT waves (128
     // registers, two blocks per CU) are 500 blocks = ONE round: the ten stage-0 launches 171 -> 128 us.  Taken where two such blocks fit
-    // a CU's LDS.  64 pixels on two waves went the other way (169 -> 270 us: twice the blocks pay the fixed prologue / statistics phases,
-    // 1.5x the halo rows).  SAR_CONV16_TM = 64 | 128 | 256 forces one form.
+    // a CU's LDS.  (64 pixels on two waves went the other way, 169 -> 270 us: twice the blocks pay the fixed prologue / statistics phases,
+    // 1.5x the halo rows.)  SAR_X3: the doubled patch admits ONE eight-wave block per CU, or two four-wave blocks of 128 pixels; the step
+    // measures 2.586 ms with the former, 2.637 with the latter: taken wherever it fits at all.  SAR_CONV16_TM = 128 | 256 forces one form.
     static const int tm_env = getenv("SAR_CONV16_TM") ? atoi(getenv("SAR_CONV16_TM")) : 0;
     const bool narrow = WN == 1 && Cin <= 64;
     bool tm256 = false;
     if (narrow && (tm_env == 0 || tm_env == 256)) {
         const size_t pb = NPL * plane_bytes(256);
-        tm256 = tm_env == 256 || (size_t)6 * Cin * 4 + ROWTAB_BYTES * 2 + ((pb + 1023) & ~(size_t)1023) + 3 * 8 * 1024 <= 80 * 1024;
+        tm256 = tm_env == 256 || (size_t)6 * Cin * 4 + ROWTAB_BYTES * 2 + ((pb + 1023) & ~(size_t)1023) + 3 * 8 * 1024 <= (X3 ? 160 : 80) * 1024;
     }
-    const bool tm64 = tm_env == 64 && narrow;
     // BR form (weight fragments in registers, no ring): 64+ source channels into 64+ output channels -- stages 1-3
     const bool br = WN == 2 && Cin >= 64;
     // sources whose 64-pixel patch does not fit the LDS (res_filters = 64: the 512-channel stage exceeds 160 KB by 1.3 KB, its stride-2 entry
     // from 256 channels by more; SAR_X3, twice the patch: the 256-channel stage as well): 32-pixel tiles
+    // (Negative, round 4 -- VERDICT r3 item 2a: half tiles for the 128-channel sources, 32 pixels on FOUR waves (2 channel halves x 2 k-groups,
+    // four fragments per tap and wave) so that a stage-2 launch is 500 blocks, two co-resident per CU whose serial phases could overlap:
+    // 2.6525 vs 2.6507 ms per step in split precision, 1.956 vs 1.936 in fp16.  Twice the blocks pay the fixed prologue; not kept.)
     bool br32 = false;
     if (br) {
         const size_t pb64 = NPL * plane_bytes(64);
         br32 = Cin == 512 || (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((pb64 + 1023) & ~(size_t)1023) > 160 * 1024;   // (512: the 32-pixel form is the only instantiation)
     }
-    const int TM = br32 ? 32 : tm64 ? 64 : tm256 ? 256 : 32 * (4 / WN);
+    const int TM = br32 ? 32 : tm256 ? 256 : 32 * (4 / WN);
     p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     p.lplane = (int)plane_bytes(TM);
     size_t patch_bytes = (size_t)NPL * p.lplane;
     const int KG = br ? (Cin >= 128 ? 4 : 2) : 1;                                  // k-groups (BR: eight waves at 128+ source channels, four at 64)
-    const int nthr = br ? 128 * KG : tm64 ? 128 : tm256 ? 512 : 256;
+    const int nthr = br ? 128 * KG : tm256 ? 512 : 256;
     if (p.cap_rows > nthr) return SAR_EINVAL;                                      // one thread per row of the row table
     const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel ring layers get a 4-deep weight ring where it fits
@@ -1450,7 +1453,7 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     const dim3 grid((unsigned)cdiv(p.g.M, TM), (unsigned)(Cout / TN));
     // template arguments of the instantiation this launch runs, as rocprofv3 prints them (bench.py classes its conv timings by them)
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
-    g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm64 ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
+    g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
     if (g_capture != nullptr) {
         g_capture->p = p; g_capture->grid = grid; g_capture->nthr = nthr; g_capture->lds = lds;
         for (int i = 0; i < 6; ++i) g_capture->cls[i] = g_last_class[i];
@@ -1472,14 +1475,13 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
-    if (tm64 || tm256) {
+    if (tm256) {
 #define CVX(NKC_, WMX_) {conv_bf16_kernel<1, NKC_, 1, 1, WMX_>, conv_bf16_kernel<1, NKC_, 9, 1, WMX_>}
-        static const kern_t kernsx[2][2][2] = {{CVX(2, 2), CVX(4, 2)}, {CVX(2, 8), CVX(4, 8)}};
+        static const kern_t kernsx[2][2] = {CVX(2, 8), CVX(4, 8)};
 #undef CVX
-        static PerDeviceFlag attrx[2][2][2];
-        const int wx = tm256 ? 1 : 0;
-        const kern_t kern = kernsx[wx][ki][k3];
-        if (!attrx[wx][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[wx][ki][k3] = true; }
+        static PerDeviceFlag attrx[2][2];
+        const kern_t kern = kernsx[ki][k3];
+        if (!attrx[ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[ki][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
