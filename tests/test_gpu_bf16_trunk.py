@@ -156,7 +156,8 @@ def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T, mode):
         da2, dw2, db2 = O.conv2d_bwd(g, cache2)
         chk("b%d da2" % n, da2_dev, rbf(da2), ta)
         chk("b%d conv2 dw" % n, G[c2v.kernel.name], dw2, 5e-3)
-        assert np.abs(G[c2v.bias.name] - db2).max() < 1e-4 * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6, "b%d conv2 db" % n
+        tb = 1e-3 if X3 else 1e-4                                   # (split precision: column sums of the fp16 copy of g, 2^-12 per element)
+        assert np.abs(G[c2v.bias.name] - db2).max() < tb * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6, "b%d conv2 db" % n
         dc1, dg2, dbt2 = bn2.bwd(da2_dev, da2)                       # the STORED da2, as the fills read it; sums over the accumulators
         chk("b%d bn2 dgamma" % n, G[blk["bn2"].gamma.name], dg2, 5e-3); chk("b%d bn2 dbeta" % n, G[blk["bn2"].beta.name], dbt2, 5e-3)
         dc1 = rbf(dc1)
@@ -166,7 +167,7 @@ def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T, mode):
         if scv is not None:
             dsc, dws, dbs = O.conv2d_bwd(g, caches)
             chk("b%d shortcut dw" % n, G[scv.kernel.name], dws, 5e-3)
-            assert np.abs(G[scv.bias.name] - dbs).max() < 1e-4 * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6
+            assert np.abs(G[scv.bias.name] - dbs).max() < tb * np.abs(g).reshape(-1, g.shape[-1]).sum(0).max() + 1e-6
             dsc = rbf(dsc)
         else:
             dsc = g
