@@ -46,6 +46,10 @@ class _Lib:
             f = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
             f.restype = ret; f.argtypes = at
             self.fn[name] = f
+        # The library's own default for the Dense / GRU-projection GEMMs is fp32 MFMA (sar_set_gemm_math(0)); the PACKAGE's default is the
+        # fp32-class fast mode, like the trunk's (DEFAULT_MODE below): split precision, unless SAR_GEMM_MATH says otherwise.
+        if "SAR_GEMM_MATH" not in os.environ:
+            self.fn["sar_set_gemm_math"](GEMM_MATH[DEFAULT_MODE[1]])
 
 
 _lib = None
@@ -109,7 +113,11 @@ def get_gemm_math():
 # 2-byte activations / activation gradients, single-pass MFMA, fp32 statistics and weights) or "bf16x3" (the same kernels in split
 # precision, csrc/trunk16.h SAR_X3: every 2-byte tensor a (hi, lo) pair of bf16 planes, three MFMAs per product block -- the
 # fp32-class mode that holds north_star's 1e-3).  Read when a model is built.
-_TRUNK_DTYPE = [os.environ.get("SAR_TRUNK_DTYPE", "fp32")]
+# The package default (round 4): "bf16x3" for the trunk AND the GEMMs -- what a SAR_Net(...) built by the reference's train.py runs in: outputs
+# within north_star's 1e-3 of the fp32 graph (measured ~1e-4) at 0.6x the step time of the fp32-storage kernels.  Widths the 2-byte kernels
+# do not take (res_filters != 32) fall back to those kernels inside ResNetTrunk.  SAR_TRUNK_DTYPE / SAR_GEMM_MATH override.
+DEFAULT_MODE = ("bf16x3", "bf16x3")
+_TRUNK_DTYPE = [os.environ.get("SAR_TRUNK_DTYPE", DEFAULT_MODE[0])]
 TRUNK_DTYPES = ("fp32", "bf16", "fp16", "bf16x3")
 
 

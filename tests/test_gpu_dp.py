@@ -33,6 +33,8 @@ def _set_mode(mode):
         _lib.set_trunk_dtype("bf16"); _lib.set_gemm_math("bf16"); _lib.set_bn_deterministic(True)
     elif mode == "bf16x3":
         _lib.set_trunk_dtype("bf16x3"); _lib.set_gemm_math("bf16x3")
+    else:                                                            # (a freshly spawned worker starts from the package default, not from the tests' baseline)
+        _lib.set_trunk_dtype("fp32"); _lib.set_gemm_math("fp32")
 
 
 def _reset_mode():

@@ -90,6 +90,16 @@ def test_wgrad_plan_covers_every_tile_and_chunk_once():
         _lib.WgradPlan.plan_host([dict(descs[0], Cin=48)], 64)
 
 
+def test_package_default_is_the_split_precision_mode():
+    """What a train.py that imports this package gets without setting anything: the fp32-class fast mode for the trunk and the GEMMs."""
+    code = ("from aesrc2020_amd import _lib; _lib.lib(); print(_lib.get_trunk_dtype(), _lib.get_gemm_math())")
+    env = {k: v for k, v in os.environ.items() if k not in ("SAR_TRUNK_DTYPE", "SAR_GEMM_MATH")}
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env).decode().split()
+    assert out == ["bf16x3", "bf16x3"], out
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(env, SAR_TRUNK_DTYPE="fp16", SAR_GEMM_MATH="bf16")).decode().split()
+    assert out == ["fp16", "bf16"], out
+
+
 def test_no_experiment_switches_in_the_trunk_kernels():
     """the measured-negative variants and the phase-removal builds ("results wrong by construction") are gone from the
     product sources -- a default build cannot pick one up by accident, and the file compiles one code path per build."""
