@@ -812,13 +812,25 @@ def test_adam_l2_unitnorm(L):
         pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, it, lr=0.01)
         check(p, pr, 1e-5, "fused adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
         assert int(tick[0].item()) == 0 and int(tick[2].item()) == 0 and int(st.view(torch.int32)[6]) == it + 1
-    # the overflow guard (tick[1] = 1, the fp16 trunk): elements whose gradient is not finite are treated as zero and counted
+    # the loss-scaling guard (tick[1] = 1: the modes with fp16 operands; round 4): sar_grads_check_f32 flags a gradient with a non-finite
+    # element and the update then SKIPS the whole step -- weights, moments, iteration count unchanged, tick[2] counts it, the flag is cleared
     tick[1] = 1
     gbad = g.copy(); gbad[[3, 700, 5000]] = [np.inf, -np.inf, np.nan]
-    gz = g.copy(); gz[[3, 700, 5000]] = 0.0
+    p_before, m_before, v_before = p.clone(), m.clone(), v.clone()
     l2l.zero_()
-    L.call("sar_adam_l2_update_f32", p, dev(gbad), m, v, dev(l2), st, tick, l2l, n)
-    pr, mr, vr = O.adam_step(pr, 0.5 * gz + 2 * l2e * pr, mr, vr, 6, lr=0.01)
-    check(p, pr, 1e-5, "guarded adam"); assert int(tick[2].item()) == 3 and bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
+    gd = dev(gbad)
+    L.call("sar_grads_check_f32", gd, tick, n)
+    assert int(tick[3].item()) == 1
+    L.call("sar_adam_l2_update_f32", p, gd, m, v, dev(l2), st, tick, l2l, n)
+    assert torch.equal(p, p_before) and torch.equal(m, m_before) and torch.equal(v, v_before)
+    assert int(tick[2].item()) == 1 and int(tick[3].item()) == 0 and int(tick[0].item()) == 0 and int(st.view(torch.int32)[6]) == 6
+    check(l2l, [(l2e * pr * pr).sum()], 1e-4, "l2 loss of a skipped step")       # still the penalty of the (unchanged) weights
+    # a clean gradient behind it: the check leaves the flag alone and the step proceeds as step 6
+    l2l.zero_()
+    L.call("sar_grads_check_f32", dev(g), tick, n)
+    assert int(tick[3].item()) == 0
+    L.call("sar_adam_l2_update_f32", p, dev(g), m, v, dev(l2), st, tick, l2l, n)
+    pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, 6, lr=0.01)
+    check(p, pr, 1e-5, "guarded adam, clean step"); assert int(tick[2].item()) == 1 and int(st.view(torch.int32)[6]) == 7
     w = rng.standard_normal((256, 8)); wd = dev(w)
     L.call("sar_unit_norm_f32", wd, 256, 8); check(wd, O.unit_norm(w), 1e-5, "unit_norm")
