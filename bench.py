@@ -230,7 +230,7 @@ def conv_roofline(model, B, iters=10, in_step=None):
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
         key = ("x3:" if x3t else "bf16:" if bf16 else "") + name
         if key in pj:
-            traffic, tsrc = pj[key]["traffic_bytes"], pj["source"]
+            traffic, tsrc = pj[key]["traffic_bytes"], pj[key].get("source", pj["source"])
     except (OSError, ValueError, KeyError):
         pass
     math = ("split precision: every trunk tensor a (hi, lo) pair of bf16 planes, 3 x v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate" if x3t else
