@@ -378,6 +378,15 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     const int n0 = by * TN;
     const unsigned M = (unsigned)g.M;
     TSTAMP(0); TSTAMP(1);
+    // ---- BatchNorm constants of the fill by the WHOLE block (trunk16.h).  The bins were written by the producer's atomics -- behind the fabric,
+    // never in this XCD's L2: ~2 800 cycles -- and the fill cannot transform a piece without them, so they are the FIRST thing this kernel
+    // requests (round 4: in-kernel stamps of the split-precision stage-2 block showed them requested 3 500 cycles after entry, behind the
+    // epilogue operands and the weight fragments, and the block waiting for them in the fill: prologue 9 000 of 30 600 cycles).  They are
+    // summed behind the row table (ring forms) or inside the fill, behind the issue of its first pieces' loads (BR forms: 256 registers to
+    // hold them in; on the 128- / 168-register forms the pieces held across it spill).
+    BnRaw braw;
+    constexpr int CIN = NKC < 8 ? 16 * NKC : 128 * NH;             // source channels of this instantiation (the launcher's table)
+    if (p.fill) bn_issue<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, braw);
 
     // ---- epilogue operands that do not depend on the accumulators (bias, residual, BatchNorm constants and input of the
     // backward sums): requested first, consumed ~10 us later
@@ -407,7 +416,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             }
         }
     };
-    if constexpr (EARLY) load_epi();
+    // (when they are requested: consumed behind the k-phase, ~8 000 cycles of work, so nothing is gained by asking first -- and their
+    // address arithmetic, 2 x RPT x planes loads, was the first 2 500 cycles of every block.  BR forms: behind the fill; ring forms, whose
+    // hand-counted vmcnt waits in the k-phase would otherwise wait for them: behind the weight requests, in front of the row table.)
     TSTAMP(11);
     // ---- weight ring: stages 0 and 1 on their way before anything else
     const h16x8* wsrc = p.wpk + (size_t)(by * WN) * p.Fs * 64 + lane;
@@ -434,13 +445,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         if (NST > 1) issue_stage(1, 1);
         if (RD > 3 && NST > 2) issue_stage(2, 2);
     }
+    if constexpr (EARLY && !BR) load_epi();
     TSTAMP(12);
-    // BatchNorm constants of the fill by the WHOLE block (trunk16.h): the bins are requested here, in front of the row table, and summed
-    // behind it (ring forms) or inside the fill, behind the issue of its first pieces' loads (BR forms: 256 registers to hold them in; on
-    // the 128- / 168-register forms the pieces held across it spill)
-    BnRaw braw;
-    constexpr int CIN = NKC < 8 ? 16 * NKC : 128 * NH;             // source channels of this instantiation (the launcher's table)
-    if (p.fill) bn_issue<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, braw);
 
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
@@ -480,12 +486,15 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // (Issuing the patch loads in front of the BatchNorm prologue -- row table, barrier, loads, prologue, barrier, transform + store --
     // was built and measured: no gain.  What the fill costs is its address arithmetic, ~1 400 cycles before the first load leaves,
     // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
-    constexpr int FU = NG == 8 ? 2 : 4;                            // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers)
+    // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers).  (Eight in the BR forms, to cover the fill's loads in
+    // one round trip: 2.626 vs 2.594 ms per split-precision step, same box, 300-step runs -- the registers cost more than the round trip.)
+    constexpr int FU = NG == 8 ? 2 : 4;
     // ---- fill: the padded patch, all input channels, transformed once
     if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
     else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
     else if (p.fill == 2) fill_patch<2, TM, (X3 && FU > 2 ? 2 : FU), NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
     else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
+    if constexpr (EARLY && BR) load_epi();
     // ---- per-lane A address
     auto a_addr = [&](unsigned pix0) __attribute__((always_inline)) {
         unsigned Rp, wq;

@@ -15,22 +15,31 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-lib = ctypes.CDLL(os.environ.get("TIMING16_LIB") or os.path.join(HERE, "libsarnet_timing16.so"))
+X3 = os.environ.get("TIMING_X3", "0") == "1"                   # the split-precision build (make timing builds tools/libsarnet_timing16_x3.so)
+lib = ctypes.CDLL(os.environ.get("TIMING16_LIB") or os.path.join(HERE, "libsarnet_timing16_x3.so" if X3 else "libsarnet_timing16.so"))
 vp, ci = ctypes.c_void_p, ctypes.c_int
-lib.sar_conv2d_bf16.argtypes = [vp] * 8 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
-lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
+if X3:
+    lib.sar_conv2d_x3.argtypes = [vp] * 8 + [ci] * 13 + [vp, ci, vp, vp, vp, vp, ctypes.c_float, vp]
+    lib.sar_conv_pack_weights_x3.argtypes = [vp, ci, ci, vp]
+    _conv = lambda *a: lib.sar_conv2d_x3(*a[:-1], None, 1.0, a[-1])
+    lib.sar_conv2d_bf16 = _conv; lib.sar_conv_pack_weights_bf16 = lib.sar_conv_pack_weights_x3
+else:
+    lib.sar_conv2d_bf16.argtypes = [vp] * 8 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
+    lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
 lib.sar_dbg_set_timing_buffer16.argtypes = [vp]
 BF = torch.bfloat16
+NPL = 2 if X3 else 1
+planes = lambda t: torch.stack([t.to(BF), (t - t.to(BF).float()).to(BF)]) if X3 else t.to(BF)
 mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 B = int(os.environ.get("CB", 64))
 SHAPES = [("s0 3x3 32->32", 100, 20, 32, 32, 3), ("s1 3x3 64->64", 50, 10, 64, 64, 3), ("s2 3x3 128->128", 25, 5, 128, 128, 3),
           ("s3 3x3 256->256", 13, 3, 256, 256, 3)]
 st = torch.cuda.current_stream().cuda_stream
 for name, H, W, Cin, Cout, k in SHAPES:
-    x = torch.randn(B, H, W, Cin, device="cuda").to(BF); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
-    y = torch.zeros(B, H, W, Cout, device="cuda", dtype=BF); dw = torch.zeros_like(w)
+    x = planes(torch.randn(B, H, W, Cin, device="cuda")); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
+    y = torch.zeros(*(((2,) if X3 else ()) + (B, H, W, Cout)), device="cuda", dtype=BF); dw = torch.zeros_like(w)
     taps = k * k
-    nf = (Cout // 32) * (taps * Cin // 16 + 8) * 512; nd = (Cin // 32) * (taps * Cout // 16 + 8) * 512
+    nf = (Cout // 32) * (NPL * taps * Cin // 16 + 8) * 512; nd = (Cin // 32) * (NPL * taps * Cout // 16 + 8) * 512
     wf = torch.zeros(nf, dtype=BF, device="cuda"); wd = torch.zeros(nd, dtype=BF, device="cuda")
     tab = torch.tensor([[w.data_ptr(), wf.data_ptr(), wd.data_ptr(), taps, Cin, Cout, 0, 0]], dtype=torch.int64, device="cuda")
     lib.sar_conv_pack_weights_bf16(tab.data_ptr(), 1, -(-(nf + nd) // 8 // 256), st)
@@ -46,7 +55,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
         n = B * H * W
         gam = torch.ones(Cin, device="cuda"); bet = torch.zeros(Cin, device="cuda"); saved = torch.zeros(4, Cin, device="cuda")
         fbins = torch.zeros(16, 2, Cin, device="cuda"); fbins[0, 1] = float(n)      # mean 0, variance 1
-        res = torch.randn(B, H, W, Cout, device="cuda").to(BF); side = torch.empty_like(x)
+        res = planes(torch.randn(B, H, W, Cout, device="cuda")); side = torch.empty(B, H, W, Cin, device="cuda", dtype=torch.float16 if X3 else BF)
         bn = BN(gam.data_ptr(), bet.data_ptr(), fbins.data_ptr(), None, saved.data_ptr(), None, None, None, None, 1.0 / n, 1.0, 1e-3, 0.99, 0, 1.0, 0, 0)
         keepalive = (gam, bet, saved, fbins, res, side, bn)
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wf.data_ptr(), None, res.data_ptr(), y.data_ptr(), side.data_ptr(), B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
