@@ -461,7 +461,43 @@ def main():
         # how many ranks the collective backend really connected: an all-reduce of ones (the driver can check N against it)
         ones = torch.ones(1, device="cuda")
         dist.all_reduce(ones)
+        # what the data-parallel step moves and what of it is exposed: the gradient buckets in the order backward completes
+        # them, the all-reduce of the buckets that overlap the rest of backward and of the last one timed ALONE (20 repetitions each, every
+        # rank), and the replay time of the backward graph the first one runs underneath -- exposed = what does not fit under it + the last bucket
+        dp_info = None
+        dp = getattr(model, "dp", None)
+        if dp is not None and dp.enabled and len(dp.bounds) >= 2:
+            g = model.store.grads
+            def t_ar(lo, hi, reps=20):
+                if hi <= lo:
+                    return 0.0
+                for _ in range(3):
+                    dist.all_reduce(g[lo:hi])
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    dist.all_reduce(g[lo:hi])
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e6
+            lo_ov, hi_ov = dp.bounds[-2][0] if len(dp.bounds) > 2 else dp.bounds[0][0], dp.bounds[0][1]
+            lo_last, hi_last = dp.bounds[-1]
+            t_ov, t_last = t_ar(lo_ov, hi_ov), t_ar(lo_last, hi_last)
+            t_g2 = None
+            if isinstance(model.graph, dict) and "trunk_s10" in model.graph:
+                gr = model.graph["trunk_s10"]
+                gr.replay(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    gr.replay()
+                torch.cuda.synchronize()
+                t_g2 = (time.perf_counter() - t0) / 20 * 1e6
+            dp_info = {"graphs_per_step": sorted(model.graph) if isinstance(model.graph, dict) else None,
+                       "bucket_bytes": [4 * (hi - lo) for lo, hi in dp.bounds], "overlapped_allreduce_bytes": 4 * (hi_ov - lo_ov),
+                       "overlapped_allreduce_us_alone": round(t_ov, 1), "last_bucket_allreduce_us_alone": round(t_last, 1),
+                       "backward_graph_under_it_us": round(t_g2, 1) if t_g2 else None,
+                       "exposed_wait_us_estimate": round(max(0.0, t_ov - (t_g2 or 0.0)) + t_last, 1)}
         if rank == 0:
+            res["config"]["data_parallel"] = dp_info
             res["config"]["collective_backend"] = dist.get_backend()
             res["config"]["grad_bucket_dtype"] = os.environ.get("SAR_DP_GRAD_DTYPE", "fp32")     # bf16: half the bytes on the links (parallel.DataParallel)
             res["config"]["rccl_ranks" if dist.get_backend() == "nccl" else "collective_ranks"] = int(ones.item())
