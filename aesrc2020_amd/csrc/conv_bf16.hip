@@ -125,6 +125,8 @@ struct ConvP {
     float side_scale;
     unsigned xs, ys;            // SAR_X3: element offset of the lo plane of source-shaped (x, x2, x3, side2) / output-shaped (res, y, e_y) tensors
     int lplane;                 // SAR_X3: byte offset of the lo plane of the LDS patch
+    int tmv;                    // output pixels a block OWNS (= its tile height, except the 32-pixel BR form on 16: SAR_X3 sources whose 32-pixel patch
+                                // does not fit the LDS -- the MFMA rows past tmv recompute the next block's pixels and are dropped)
     int fill; BnP fb;
     int epi; float* e_bins; const u16* e_y; const float* e_saved;
     int lg_pc;                  // log2(Cin/8): 16-byte pieces per position
@@ -294,7 +296,7 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
         for (int j = 0; j < U; ++j) {
             const bool none = off[j] == NONE;
             const uint4 z4 = make_uint4(0, 0, 0, 0);
-            const bool sd = do_side && !none && own[j] < (unsigned)TM;
+            const bool sd = do_side && !none && own[j] < (unsigned)p.tmv;
             {
                 float o[8];
                 uint4 rh, rl = z4;
@@ -374,7 +376,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // tensors).  Here XCD c takes the c-th contiguous eighth of the sequence (channel tile fastest, then pixel tile).
     const unsigned chunk8 = ntot >> 3, tord = lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
     const unsigned bx = tord >> __builtin_ctz(nty), by = tord & (nty - 1);   // Cout / TN: a power of two
-    const unsigned m0 = bx * TM;
+    const unsigned TMV = (BR && WMX == 1) ? (unsigned)p.tmv : (unsigned)TM;   // pixels this block owns
+    const unsigned m0 = bx * TMV;
     const int n0 = by * TN;
     const unsigned M = (unsigned)g.M;
     TSTAMP(0); TSTAMP(1);
@@ -450,7 +453,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
 
     unsigned Rp_lo, Rp_hi, wtmp;
     pix_rp(g, m0, Rp_lo, wtmp);
-    pix_rp(g, min(m0 + TM - 1, M - 1), Rp_hi, wtmp);
+    pix_rp(g, min(m0 + TMV - 1, M - 1), Rp_hi, wtmp);
     Rp_hi += g.K - 1;
     unsigned nrows = Rp_hi - Rp_lo + 1;
     if (nrows > (unsigned)p.cap_rows) nrows = p.cap_rows;          // never taken: the launcher sizes cap_rows as an upper bound
@@ -640,7 +643,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         if constexpr (X3) { v0 += h_lo(rv[i][NPL - 1]); v1 += h_hi(rv[i][NPL - 1]); }
         unsigned pk, pkl = 0u;
         if constexpr (X3) split2(v0, v1, pk, pkl); else pk = pack2(v0, v1);
-        if (m < M) {
+        if (m < M && (unsigned)row < TMV) {
             __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
             if constexpr (X3) __builtin_nontemporal_store(pkl, reinterpret_cast<unsigned*>(p.y + (size_t)p.ys + (size_t)m * p.Cout + c));
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
@@ -1441,9 +1444,13 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
         br32 = Cin == 512 || (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((pb64 + 1023) & ~(size_t)1023) > 160 * 1024;   // (512: the 32-pixel form is the only instantiation)
     }
     const int TM = br32 ? 32 : tm256 ? 256 : 32 * (4 / WN);
-    p.cap_rows = patch_rows_bound(p.g, TM < p.g.M ? TM : p.g.M);
+    // split precision, sources whose 32-pixel patch still does not fit (res_filters = 64: the 512-channel stage and its stride-2 entry from 256
+    // channels): the 32-pixel form on SIXTEEN owned pixels per block
+    p.tmv = TM;
+    if (X3 && br32 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((NPL * plane_bytes(32) + 1023) & ~(size_t)1023) > 160 * 1024) p.tmv = 16;
+    p.cap_rows = patch_rows_bound(p.g, p.tmv < p.g.M ? p.tmv : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
-    p.lplane = (int)plane_bytes(TM);
+    p.lplane = (int)plane_bytes(p.tmv);
     size_t patch_bytes = (size_t)NPL * p.lplane;
     const int KG = br ? (Cin >= 128 ? 4 : 2) : 1;                                  // k-groups (BR: eight waves at 128+ source channels, four at 64)
     const int nthr = br ? 128 * KG : tm256 ? 512 : 256;
@@ -1459,7 +1466,7 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     p.patch_bytes = (int)patch_bytes;
     const size_t lds = (size_t)6 * Cin * 4 + ROWTAB_BYTES + patch_bytes + ring_bytes;
     if (lds > 160 * 1024) return SAR_EINVAL;
-    const dim3 grid((unsigned)cdiv(p.g.M, TM), (unsigned)(Cout / TN));
+    const dim3 grid((unsigned)cdiv(p.g.M, p.tmv), (unsigned)(Cout / TN));
     // template arguments of the instantiation this launch runs, as rocprofv3 prints them (bench.py classes its conv timings by them)
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
     g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;

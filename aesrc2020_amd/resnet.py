@@ -205,9 +205,9 @@ class ResNetTrunk(Layer):
         # 2-byte trunk (csrc/conv_bf16.hip, stem_bf16.hip; compiled for bf16 and for fp16): `bf16` keeps its round-2 name and means
         # "2-byte storage"; `half` tells the two apart.  fp16 carries a static gradient scale through the trunk (include/sarnet.h)
         dt = _lib.get_trunk_dtype()
-        if dt == "bf16x3" and (filters != 32 or stem_c not in (32, 64)):
-            # split precision on the 2-byte kernels exists for the reference's width (train.py:54); other widths run the fp32-storage
-            # kernels -- the same fp32-class arithmetic (bf16x3 products) on round 1's kernels
+        if dt == "bf16x3" and (filters not in (32, 64) or stem_c not in (32, 64)):
+            # split precision on the 2-byte kernels exists for the widths those kernels take (32: the reference's train.py:54; 64: SAR_Net's own
+            # default, model.py:204); other widths run the fp32-storage kernels -- the same fp32-class arithmetic on round 1's kernels
             dt = "fp32"
         # `x3`: split precision (csrc/trunk16.h SAR_X3): every 2-byte tensor is a (hi, lo) pair of bf16 planes -- shape (2, ...) -- and the
         # operands only the weight gradients read are single fp16 tensors (gradients times the static scale of the fp16 build)

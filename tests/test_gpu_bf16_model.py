@@ -83,10 +83,7 @@ GEMM_MATH = {"bf16x3": "bf16x3", "fp16": "bf16", "bf16": "bf16"}    # the Dense 
 def test_bf16_trunk_forward_backward_against_oracle(case, mode):
     cfg, ref, model, _, batch = build(CASES[case], mode)
     bnd = BOUNDS[mode]
-    if mode == "bf16x3" and CASES[case]["res_filters"] != 32:
-        assert not model.trunk.bf16                      # other widths: the fp32-storage kernels (the same fp32-class arithmetic)
-    else:
-        assert model.trunk.bf16 and model.trunk.half == (mode == "fp16") and model.trunk.x3 == (mode == "bf16x3")
+    assert model.trunk.bf16 and model.trunk.half == (mode == "fp16") and model.trunk.x3 == (mode == "bf16x3")
     out, total, parts, G = ref.forward_backward(batch)
     from aesrc2020_amd import _lib
     _lib.set_gemm_math(GEMM_MATH[mode])                 # the whole bench mode: the trunk + its Dense / GRU-projection arithmetic
