@@ -722,7 +722,11 @@ class SARNetModel:
     def load_weights(self, path, by_name=True, skip_mismatch=True):
         """model.py:181-183 warm start.  .npz checkpoints of this package, or a Keras .h5 (names mapped by keras_compat; needs
         h5py -- otherwise the error says how to convert the file once)."""
-        if str(path).lower().endswith((".h5", ".hdf5")):
+        if str(path).lower().endswith((".h5", ".hdf5")) and os.path.exists(str(path) + ".npz") and not os.path.exists(str(path)):
+            # what THIS package's save() wrote for that name (train.py:35 saves '%03d.h5'; without h5py the file is '<name>.h5.npz'): the
+            # reference's own save -> raw_model round trip works unchanged
+            d = dict(np.load(str(path) + ".npz"))
+        elif str(path).lower().endswith((".h5", ".hdf5")):
             from .keras_compat import load_h5
             d = load_h5(path)
         else:
