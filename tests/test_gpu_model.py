@@ -188,6 +188,12 @@ def test_save_load_roundtrip_and_predict(tmp_path):
     after = m2.predict(batch, batch_size=4)
     for a, b in zip(before, after):
         np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)      # split-K atomics: fp32 sums are order-dependent run to run
+    # train.py:35 saves '<epoch>.h5' and model.py:181-183 warm-starts from that name: the same name resolves to the file save() wrote
+    h5 = str(tmp_path / "003.h5")
+    model.save(h5)
+    m3, _ = SAR_Net(seed=6, raw_model=h5, **kw)
+    for a, b in zip(before, m3.predict(batch, batch_size=4)):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
     dec = ctc_pred(model, {"x_data": batch["x_data"]}, 4, 12)
     assert isinstance(dec, np.ndarray) and dec.ndim == 2 and dec.shape[0] == 4 and dec.dtype.kind == "i"   # dense, -1 padded (K.ctc_decode)
     assert model.get_layer("CRNN").name == "CRNN" and model.count_params() == sum(v.numel() for v in ref.P.values())
