@@ -246,7 +246,79 @@ __global__ void bigru_last_bwd_kernel(const float* __restrict__ dy, float* __res
     }
 }
 
+// ---- any hidden_dim (round 4): ONE TIME STEP of both directions.  The persistent kernels above end at 256 units (a lane owns four of
+// 64 x 4; at 512 units the recurrent kernels are 3 MB per direction and no CU holds or streams them in a step's time).  Larger layers run
+// the recurrence as L x (one batched GEMM launch for ha = h U of both directions + this gate kernel) -- launch-bound (two launches per
+// step), but the reference takes any hidden_dim (model.py:204-224) and so does this.  Same saved tensors and layouts as gru_fwd_kernel.
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restrict__ xa_f, const float* __restrict__ xa_b, const float* __restrict__ ha,
+                                                           const float* __restrict__ bh_f, const float* __restrict__ bh_b, float* __restrict__ h,
+                                                           float* __restrict__ out, float* __restrict__ gates, float* __restrict__ hprev, int B, int L,
+                                                           int H, int s) {
+    const long n = 2L * B * H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % H), b = (int)(i / H % B), d = (int)(i / ((long)H * B));
+        const int t = d ? (L - 1 - s) : s;
+        const float* xa = d ? xa_b : xa_f; const float* bh = d ? bh_b : bh_f;
+        const long xo = ((long)b * L + t) * 3 * H, ho = ((long)d * B + b) * 3 * H;
+        const float z = sigmoidf_(xa[xo + j] + (ha[ho + j] + bh[j]));
+        const float rr = sigmoidf_(xa[xo + H + j] + (ha[ho + H + j] + bh[H + j]));
+        const float q = ha[ho + 2 * H + j] + bh[2 * H + j];
+        const float hh = tanhf(xa[xo + 2 * H + j] + rr * q);
+        const float hold = h[i];
+        const float hn = z * hold + (1.f - z) * hh;
+        float* g = gates + ((((long)d * B + b) * L + t) * 4) * H;
+        g[j] = z; g[H + j] = rr; g[2 * H + j] = hh; g[3 * H + j] = q;
+        hprev[(((long)d * B + b) * L + t) * H + j] = hold;
+        out[((long)b * L + t) * 2 * H + d * H + j] = hn;
+        h[i] = hn;
+    }
+}
+// BPTT step s (the caller walks s = L-1 .. 0): dh holds the gradient flowing into h_s from step s+1; on return dh = its direct path into
+// h_{s-1} (g * z) and dstep = this step's recurrent-side pre-activation gradients, which the caller multiplies by U^T and adds to dh.
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ gates, const float* __restrict__ hprev,
+                                                           float* __restrict__ dh, float* __restrict__ dai, float* __restrict__ dah, float* __restrict__ dstep,
+                                                           int B, int L, int H, int s) {
+    const long n = 2L * B * H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % H), b = (int)(i / H % B), d = (int)(i / ((long)H * B));
+        const int t = d ? (L - 1 - s) : s;
+        const float* g4 = gates + ((((long)d * B + b) * L + t) * 4) * H;
+        const float z = g4[j], rr = g4[H + j], hh = g4[2 * H + j], q = g4[3 * H + j];
+        const float hp = hprev[(((long)d * B + b) * L + t) * H + j];
+        const float g = dh[i] + dout[((long)b * L + t) * 2 * H + d * H + j];
+        dh[i] = g * z;
+        const float dahh = g * (1.f - z) * (1.f - hh * hh);
+        const float daz = g * (hp - hh) * z * (1.f - z);
+        const float dar = dahh * q * rr * (1.f - rr);
+        const float a2 = dahh * rr;
+        const long oo = (((long)d * B + b) * L + t) * 3 * H, so = ((long)d * B + b) * 3 * H;
+        dai[oo + j] = daz; dai[oo + H + j] = dar; dai[oo + 2 * H + j] = dahh;
+        dah[oo + j] = daz; dah[oo + H + j] = dar; dah[oo + 2 * H + j] = a2;
+        dstep[so + j] = daz; dstep[so + H + j] = dar; dstep[so + 2 * H + j] = a2;
+    }
+}
+
 }  // namespace
+
+// One time step s of the recurrence of BOTH directions for any hidden_dim (see gru_step_fwd_kernel): ha (2, B, 3H) = h U computed by the caller
+// (sar_gemm_batched_f32), h (2, B, H) the running state (zero in front of step 0), the other tensors as sar_bigru_fwd_f32.
+extern "C" int sar_bigru_step_fwd_f32(const float* xa_fwd, const float* xa_bwd, const float* ha, const float* bh_fwd, const float* bh_bwd, float* h,
+                                      float* out, float* gates, float* hprev, int B, int L, int H, int s, hipStream_t stream) {
+    if (!xa_fwd || !xa_bwd || !ha || !bh_fwd || !bh_bwd || !h || !out || !gates || !hprev || B < 1 || L < 1 || H < 1 || s < 0 || s >= L) return SAR_EINVAL;
+    long nb = (2L * B * H + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, xa_fwd, xa_bwd, ha, bh_fwd, bh_bwd, h, out, gates, hprev, B, L, H, s);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+// BPTT step s (s = L-1 .. 0): dh (2, B, H) in / out, dstep (2, B, 3H) out; the caller then adds dstep U^T to dh (sar_gemm_batched_f32, accumulate).
+extern "C" int sar_bigru_step_bwd_f32(const float* dout, const float* gates, const float* hprev, float* dh, float* dai, float* dah, float* dstep,
+                                      int B, int L, int H, int s, hipStream_t stream) {
+    if (!dout || !gates || !hprev || !dh || !dai || !dah || !dstep || B < 1 || L < 1 || H < 1 || s < 0 || s >= L) return SAR_EINVAL;
+    long nb = (2L * B * H + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dout, gates, hprev, dh, dai, dah, dstep, B, L, H, s);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
 
 extern "C" int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const float* U_fwd, const float* U_bwd,
                                  const float* bh_fwd, const float* bh_bwd, float* out, float* gates, float* hprev, int B,

@@ -166,6 +166,14 @@ class BiGRU(Layer):
             self.pack = self.buf("u_pack", (2 * 2 * 3 * H * H,), torch.float16 if self.msfx == "f16" else torch.bfloat16)
             _call("sar_bigru_pack_" + self.msfx, uf.w, ub.w, self.pack, H)
             _call("sar_bigru_fwd_" + self.msfx, xa[0], xa[1], self.pack, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
+        elif H > 256:
+            # past the persistent kernels' 256 units: one batched GEMM (ha = h U, both directions) + one gate launch per time step (csrc/gru.hip)
+            h = self.buf("h_state", (2, B, H)); ha = self.buf("ha", (2, B, 3 * H))
+            _call("sar_fill_f32", h, 0.0, h.numel())
+            gb = _lib.GemmBatch([(h[0], uf.w, ha[0], None), (h[1], ub.w, ha[1], None)])
+            for s in range(L):
+                _call("sar_gemm_batched_f32", gb, 2, B, 3 * H, H, H, 3 * H, 3 * H, 1, 0, 0, 0, 1)
+                _call("sar_bigru_step_fwd_f32", xa[0], xa[1], ha, bf.w[3 * H:], bb.w[3 * H:], h, self.out, self.gates, self.hprev, B, L, H, s)
         else:
             _call("sar_bigru_fwd_f32", xa[0], xa[1], uf.w, ub.w, bf.w[3 * H:], bb.w[3 * H:], self.out, self.gates, self.hprev, B, L, H)
         if self.seq:
@@ -192,6 +200,14 @@ class BiGRU(Layer):
             _call("sar_bigru_bwd_f16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H, float(2 ** (int(round(np.log2(64.0 * max(B, 1)))) + self.store.gscale_shift)))
         elif self.mfma:
             _call("sar_bigru_bwd_bf16", dout, self.gates, self.hprev, self.pack, dai, dah, B, L, H)
+        elif H > 256:
+            dh = self.buf("dh_state", (2, B, H)); dstep = self.buf("dstep", (2, B, 3 * H))
+            _call("sar_fill_f32", dh, 0.0, dh.numel())
+            gb = _lib.GemmBatch([(dstep[0], self.p["forward"][1].w, dh[0], None), (dstep[1], self.p["backward"][1].w, dh[1], None)])
+            for s in range(L - 1, -1, -1):
+                _call("sar_bigru_step_bwd_f32", dout, self.gates, self.hprev, dh, dai, dah, dstep, B, L, H, s)
+                if s > 0:                                              # dh_{s-1} += dstep U^T (U stored (H, 3H): the [N][K] operand)
+                    _call("sar_gemm_batched_f32", gb, 2, B, H, 3 * H, 3 * H, 3 * H, H, 1, 1, 0, 1, 1)
         else:
             UT = [self.scratch("gru_UT0_%d" % H, (3 * H, H)), self.scratch("gru_UT1_%d" % H, (3 * H, H))]
             for i, d in enumerate(("forward", "backward")):

@@ -89,9 +89,10 @@ class SARNetModel:
         self.name = c["name"] or "model"
         T, D, _ = c["input_shape"]
         H, A = c["hidden_dim"], c["accent_classes"]
-        if H < 1 or H > 256 or H % 4:
-            raise ValueError("hidden_dim must be a multiple of 4 in [4, 256] for the gfx950 GRU kernels (got %r; the reference's "
-                             "default is 256, model.py:204)" % (H,))
+        if H < 4 or H % 4:
+            raise ValueError("hidden_dim must be a positive multiple of 4 (16-byte rows of the Dense / GRU kernels; got %r; the reference's "
+                             "default is 256, model.py:204).  Up to 256 the recurrence runs on the persistent kernels (256: on MFMA), "
+                             "above that one GEMM + one gate launch per time step" % (H,))
         with store_scope(self.store):
             inputs = Input(shape=c["input_shape"], name="x_data")
             fn = {"res18": resnet18_, "res34": resnet34_, "res50": resnet50_, "res101": resnet101_, "res152": resnet152_}

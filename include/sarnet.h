@@ -388,6 +388,14 @@ int sar_bigru_fwd_f32(const float* xa_fwd, const float* xa_bwd, const float* U_f
                       int H, sarStream_t stream);
 int sar_bigru_bwd_f32(const float* dout, const float* gates, const float* hprev, const float* UT_fwd,
                       const float* UT_bwd, float* dai, float* dah, int B, int L, int H, sarStream_t stream);
+/* Any hidden_dim (round 4; the kernels above end at 256 units): ONE time step s of both directions.  The caller computes ha (2,B,3H) = h U with
+ * sar_gemm_batched_f32 and calls sar_bigru_step_fwd_f32 (h (2,B,H): the running state, zero in front of step 0); backward, for s = L-1 .. 0:
+ * sar_bigru_step_bwd_f32 (dh (2,B,H) in / out, dstep (2,B,3H) out), then dh += dstep U^T by sar_gemm_batched_f32 with accumulate.  Same saved
+ * tensors as sar_bigru_fwd_f32.  Launch-bound (two launches per step); model.py:204-224 takes any hidden_dim, so does this. */
+int sar_bigru_step_fwd_f32(const float* xa_fwd, const float* xa_bwd, const float* ha, const float* bh_fwd, const float* bh_bwd, float* h,
+                           float* out, float* gates, float* hprev, int B, int L, int H, int s, sarStream_t stream);
+int sar_bigru_step_bwd_f32(const float* dout, const float* gates, const float* hprev, float* dh, float* dai, float* dah, float* dstep,
+                           int B, int L, int H, int s, sarStream_t stream);
 /* The recurrence of the "bf16" mode at hidden_dim 256 (model.py:44-50, train.py default): the recurrent kernels are rounded to
  * bf16 and packed once per optimiser step (pack: 2 directions x 2 orientations x 3H x H bf16 = 1.5 MB), then stay on chip for all
  * L steps -- registers + LDS of 16-row workgroups, v_mfma_f32_16x16x32_bf16 -- instead of streaming from L2 every step.  State,

@@ -27,6 +27,9 @@ SWEEP = [
          disc_enable=True, metric_loss="arcface", margin=0.5, accent_classes=5, B=7),
     dict(input_shape=[100, 80, 1], res_type="res18", res_filters=64, hidden_dim=32, mto="vlad", vlad_clusters=4, disc_enable=True,
          metric_loss="arcface", B=2),
+    # hidden_dim past the persistent GRU kernels' 256 units (round 4: one GEMM + one gate launch per time step), two Bi-GRUs + Bi-GRU pooling
+    dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=320, mto="bigru", disc_enable=True, ctc_enable=True,
+         bpe_classes=13, max_ctc_len=4, metric_loss="cosface", B=3),
 ]
 
 
