@@ -145,6 +145,12 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
+// the same with a wave-uniform base (SGPR pair) and a 32-bit per-lane byte offset: no 64-bit per-lane address to keep alive across the kernel
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 // Workgroup barrier WITHOUT the vmcnt(0) drain of __syncthreads().  It has to be an asm statement with a memory clobber: the
 // s_barrier builtin is IntrNoMem, so the compiler may move LDS reads from behind it to in front of it (observed once the
@@ -355,12 +361,16 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     static_assert(!BR || (WN == 2 && (WMX == 2 || WMX == 1) && NKC / KG == 2), "BR: 64 (or 32: WMX = 1, the sources whose 64-pixel patch does not fit the LDS) x 64 tiles, two fragments per virtual tap and wave");
     constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
     constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
-    static_assert(BR || (WN * 8) % NW == 0, "stage DMA must divide evenly");
+    static_assert(BR || (WN * 8) % NW == 0 || (X3 && WN * 4 < NW), "stage DMA must divide evenly");
     static_assert(NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "epilogue maps must divide evenly");
     constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
-    constexpr int F = VT * NKC * NPL, NST = (F + 7) / 8;           // weight fragments per channel tile (SAR_X3: hi, lo interleaved), ring stages
-    constexpr int SJ = WN * 8, PW = SJ / NW;                       // DMA wave-instructions per stage: block / per wave
+    // fragments per ring stage and channel tile: 8; 4 in the split-precision eight-wave form of the 32-channel layers (CO2 below: a 12 KB
+    // ring leaves room for TWO such blocks, 2 x 77.8 KB, in a CU's LDS)
+    constexpr bool CO2 = X3 && !BR && WMX * WN == 8 && NKC == 2;
+    constexpr int SF = CO2 ? 4 : 8;
+    constexpr int F = VT * NKC * NPL, NST = (F + SF - 1) / SF;     // weight fragments per channel tile (SAR_X3: hi, lo interleaved), ring stages
+    constexpr int SJ = WN * SF, PW = (SJ + NW - 1) / NW;           // DMA wave-instructions per stage: block / per wave (SJ < NW: the first SJ waves issue one each)
     const int RD = p.rd;                                           // ring depth, 3 or 4 (launcher: 4 where the LDS has room for it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* cst = reinterpret_cast<float*>(smem);
@@ -376,7 +386,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // tensors).  Here XCD c takes the c-th contiguous eighth of the sequence (channel tile fastest, then pixel tile).
     const unsigned chunk8 = ntot >> 3, tord = lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
     const unsigned bx = tord >> __builtin_ctz(nty), by = tord & (nty - 1);   // Cout / TN: a power of two
-    const unsigned TMV = (BR && WMX == 1) ? (unsigned)p.tmv : (unsigned)TM;   // pixels this block owns
+    const unsigned TMV = (X3 || (BR && WMX == 1)) ? (unsigned)p.tmv : (unsigned)TM;   // pixels this block owns
     const unsigned m0 = bx * TMV;
     const int n0 = by * TN;
     const unsigned M = (unsigned)g.M;
@@ -395,19 +405,21 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // backward sums): requested first, consumed ~10 us later
     const int cp = tid % CP, rg = tid / CP;
     const int c = n0 + 2 * cp;
-    const float b0 = p.bias ? p.bias[c] : 0.f, b1 = p.bias ? p.bias[c + 1] : 0.f;
-    float sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f, mu0 = 0.f, mu1 = 0.f, rs0 = 0.f, rs1 = 0.f;
-    if (p.epi == 2) {
-        const float* sv = p.e_saved; const int C = p.Cout;
-        mu0 = sv[c]; mu1 = sv[c + 1]; rs0 = sv[C + c]; rs1 = sv[C + c + 1];
-        sc0 = sv[2 * C + c]; sc1 = sv[2 * C + c + 1]; sh0 = sv[3 * C + c]; sh1 = sv[3 * C + c + 1];
-    }
+    // (the per-channel constants travel with the per-pixel operands in load_epi: held from kernel entry, the eight-wave forms -- 128 registers --
+    // spilled them behind a vmcnt(0) at the top of the kernel)
+    float b0 = 0.f, b1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f, mu0 = 0.f, mu1 = 0.f, rs0 = 0.f, rs1 = 0.f;
     // (a 128-register variant for four blocks per CU -- these loads after the k-phase, two fill pieces in flight -- needs the
     // 32-channel layers' LDS at 40 KB, i.e. a 2-deep weight ring: see the ring comment; with the 3-deep ring they fit three per CU
     // and the variant was slower, 23 vs 17 us per stage-0 launch)
     constexpr bool EARLY = NG != 8;                                 // (the eight-wave form lives on 128 registers: operands loaded behind the k-phase)
     unsigned rv[RPT][NPL], yv[RPT][NPL];
     auto load_epi = [&]() __attribute__((always_inline)) {
+        if (p.bias) { b0 = p.bias[c]; b1 = p.bias[c + 1]; }
+        if (p.epi == 2) {
+            const float* sv = p.e_saved; const int C = p.Cout;
+            mu0 = sv[c]; mu1 = sv[c + 1]; rs0 = sv[C + c]; rs1 = sv[C + c + 1];
+            sc0 = sv[2 * C + c]; sc1 = sv[2 * C + c + 1]; sh0 = sv[3 * C + c]; sh1 = sv[3 * C + c + 1];
+        }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const unsigned m = min(m0 + rg + RG * i, M - 1);
@@ -424,13 +436,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // hand-counted vmcnt waits in the k-phase would otherwise wait for them: behind the weight requests, in front of the row table.)
     TSTAMP(11);
     // ---- weight ring: stages 0 and 1 on their way before anything else
-    const h16x8* wsrc = p.wpk + (size_t)(by * WN) * p.Fs * 64 + lane;
+    const h16x8* wsrc = p.wpk + (size_t)(by * WN) * p.Fs * 64;    // (wave-uniform; the lane's 16 bytes are the DMA's offset operand)
     const unsigned ring0 = lds_addr(bring);
     auto issue_stage = [&](int st, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int j = w + NW * i, nt = j >> 3, f8 = j & 7;
-            dma16(wsrc + ((size_t)nt * p.Fs + st * 8 + f8) * 64, ring0 + (unsigned)((slot * SJ + j) * 1024));
+            const int j = w + NW * i, nt = j / SF, f8 = j % SF;
+            if (SJ % NW == 0 || j < SJ)                            // (wave-uniform)
+                dma16s(wsrc + ((size_t)nt * p.Fs + st * SF + f8) * 64, (unsigned)lane * 16u, ring0 + (unsigned)((slot * SJ + j) * 1024));
         }
     };
     constexpr int NF = BR ? VT * KPF : 1, NF0 = NF < BR_PD ? NF : BR_PD; // BR: this wave's k-steps; those whose weight fragments are requested ahead of the k-phase
@@ -562,8 +575,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         // Per stage: wait for its fragments, barrier (also: every wave is done with the ring slot refilled next; on stage 0: the patch is
         // complete), start the DMA of stage + 2, read the stage's 8 B fragments, then its MFMAs; the A fragments of the NEXT virtual tap
         // are read from the patch while the current tap's MFMAs issue.
-        h16x8 afr[2][NKC][NPL], bfr[8];
-        const unsigned char* bmine = bring + (wn * 8) * 1024 + lane * 16;
+        // (SAR_X3: the stage's fragments are read a k-step -- one hi / lo pair -- at a time, one k-step ahead: 16 registers instead of 32,
+        // which is what lets the eight-wave 32-channel form live on 128 registers, two blocks per CU)
+        h16x8 afr[2][NKC][NPL], bfr[X3 ? 4 : 8];
+        const unsigned char* bmine = bring + (wn * SF) * 1024 + lane * 16;
         auto load_afrags = [&](int s, unsigned addr) __attribute__((always_inline)) {
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc)
@@ -575,8 +590,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
 #pragma unroll
             for (int kc = 0; kc < NKC; ++kc) {
                 const int f = (v * NKC + kc) * NPL;                // first fragment of this k-step in the stream
-                if (f % 8 == 0) {
-                    const int st = f / 8;
+                if (f % SF == 0) {
+                    const int st = f / SF;
                     // stages <= st+1 have landed -- stage st one whole stage and a barrier ago (see above); RD = 4: stage st+2 in flight
                     if (RD == 4 && st + 2 < NST) wait_vm<PW>(); else wait_vm<0>();      // (kernel-uniform branch)
                     // stage 0: this wave's patch stores must have completed before the others read them (gfx950 inserts no
@@ -588,8 +603,21 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
                     if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
                     else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
                     const int slot = RD == 4 ? (st & 3) : (st % 3);
+                    if constexpr (!X3) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
+                        for (int i = 0; i < 8; ++i) bfr[i] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + i) * 1024);
+                    } else {
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) bfr[((f / NPL) & 1) * NPL + pl] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + pl) * 1024);
+                    }
+                }
+                if constexpr (X3) {                                // the next k-step's pair, while it is in the same stage
+                    if ((f + NPL) % SF != 0 && f + NPL < F) {
+                        const int st = f / SF, slot = RD == 4 ? (st & 3) : (st % 3);
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl)
+                            bfr[((f / NPL + 1) & 1) * NPL + pl] = *reinterpret_cast<const h16x8*>(bmine + (slot * SJ + (f + NPL) % SF + pl) * 1024);
+                    }
                 }
                 if (kc == 0 && v + 1 < VT) {
                     const int tap = (v + 1) / NH, hh = (v + 1) % NH, dy = tap / KS, dx = tap % KS;
@@ -599,9 +627,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
                     if (f & 1) acc2 = MFMA16(afr[v & 1][kc][0], bfr[f % 8], acc2, 0, 0, 0);
                     else acc = MFMA16(afr[v & 1][kc][0], bfr[f % 8], acc, 0, 0, 0);
                 } else {
-                    acc2 = MFMA16(afr[v & 1][kc][NPL - 1], bfr[f % 8], acc2, 0, 0, 0);
-                    acc = MFMA16(afr[v & 1][kc][0], bfr[f % 8], acc, 0, 0, 0);
-                    acc2 = MFMA16(afr[v & 1][kc][0], bfr[(f + NPL - 1) % 8], acc2, 0, 0, 0);
+                    constexpr int NP1 = NPL - 1;
+                    const int bq = ((f / NPL) & 1) * NPL;
+                    acc2 = MFMA16(afr[v & 1][kc][NP1], bfr[bq], acc2, 0, 0, 0);
+                    acc = MFMA16(afr[v & 1][kc][0], bfr[bq], acc, 0, 0, 0);
+                    acc2 = MFMA16(afr[v & 1][kc][0], bfr[bq + NP1], acc2, 0, 0, 0);
                 }
             }
         }
@@ -695,7 +725,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
 // waves per SIMD the register budget is set for.  BR: 1 (KG = 4: 512 threads, one block per CU) or 2; ring forms: 3 (two waves), 4 (eight
 // waves: 128 registers, two blocks per CU), 2 otherwise.  SAR_X3 doubles the fragments a wave holds and its LDS admits one eight-wave block
 // (or two four-wave blocks) per CU anyway: 2 for every ring form.
-#define CONV_OCC (BR ? (KG == 4 ? 1 : 2) : X3 ? 2 : (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2))
+#define CONV_OCC (BR ? (KG == 4 ? 1 : 2) : X3 ? (WMX * WN == 8 && NKC == 2 ? 4 : 2) : (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2))
 
 template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv_bf16_kernel(const ConvP p) {
@@ -1415,7 +1445,11 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     p.lg_pc = ilog2(Cin / 8); p.rs = Cin * 2 + 16;
     p.cw = p.g.Wp * (Cin / 8); p.mg_cw = magic(p.cw);
     p.Fs = NPL * K * K * Cin / 16 + 8;
-    const int WN = Cout >= 64 ? 2 : 1, TN = 32 * WN;
+    // (SAR_X3, 32 source channels into 64 at stride 1 -- the input gradients of the first block's conv and shortcut, 128 000 pixels at B = 64:
+    // as TWO 32-channel tiles of the co-resident eight-wave form, 1 000 blocks in two rounds, instead of 2 000 four-wave blocks of 64 x 64 in
+    // four: 71 + 25 -> see DESIGN 5.00)
+    const bool split64 = X3 && Cin == 32 && Cout == 64 && s == 1 && d == 1 && getenv("SAR_CONV16_TM") == nullptr;
+    const int WN = (Cout >= 64 && !split64) ? 2 : 1, TN = 32 * WN;
     // LDS bytes of the patch: every plane + a 1 KiB scratch slot behind it (the fill's branch-free no-op pieces land there)
     auto plane_bytes = [&](int tm) { return (size_t)patch_rows_bound(p.g, tm < p.g.M ? tm : p.g.M) * p.g.Wp * p.rs + 1024; };
     // Pixel tile of the 32-output-channel launches (stage 0, its shortcut and gradients).  Round 2 ran them as 128-pixel tiles on four
@@ -1458,7 +1492,8 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel ring layers get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
-    const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * 8 * 1024;
+    const int SF = (X3 && tm256 && Cin == 32) ? 4 : 8;                             // fragments per ring stage (conv_body: CO2)
+    const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * SF * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
     if (patch_bytes < (size_t)nthr * 32) patch_bytes = (size_t)nthr * 32;      // bn_finish's scratch: G x 4 x Cin x 8 bytes, G x Cin <= threads
     if (Cin > nthr || p.cw > nthr) return SAR_EINVAL;   // (a patch row wider than the block: no such layer in the model's range)
