@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0)
     a = ap.parse_args()
     bench.set_dtype(a.dtype)
+    from aesrc2020_amd import parallel
+    parallel.init_from_env()                                            # SAR_DP_FORCE=1 (+ MASTER_ADDR / MASTER_PORT): the data-parallel step on one rank
     from aesrc2020_amd.model import SAR_Net
     from aesrc2020_amd.utils import synthetic_batch
     wl = bench.WORKLOADS[a.workload]
