@@ -18,24 +18,30 @@ BF, SFX = torch.bfloat16, "bf16"
 TOL_BF, TOL_F32 = 4e-3, 1e-3
 
 
-@pytest.fixture(scope="module", autouse=True, params=["bf16", "fp16"])
+X3 = False                                                           # the split-precision build: every 2-byte tensor a (hi, lo) pair of bf16 planes
+
+
+@pytest.fixture(scope="module", autouse=True, params=["bf16", "fp16", "x3"])
 def two_byte_type(request):
     """The module runs twice: against the bf16 build of the trunk kernels (entry points sar_*_bf16) and against the fp16 build
     (sar_*_f16: the same sources with IEEE half as the 2-byte type, csrc/trunk16.h).  Inputs are drawn on the grid of the type under
     test; a stored tensor is within half an ulp of the float64 oracle: 2^-9 (bf16) / 2^-12 (fp16) relative, bounded at twice that of
     the reference's max-abs."""
-    global BF, SFX, TOL_BF
-    old = (BF, SFX, TOL_BF)
-    BF, SFX, TOL_BF = (torch.float16, "f16", 5e-4) if request.param == "fp16" else (torch.bfloat16, "bf16", 4e-3)
+    global BF, SFX, TOL_BF, X3
+    old = (BF, SFX, TOL_BF, X3)
+    # "x3" (round 4, the package default): the split-precision build (entry points sar_*_x3) -- a stored tensor is hi + lo, 2^-17 relative; the
+    # conv forward / input-gradient tests run in it on every shape (its weight gradients are the fp16 build's: those tests skip).
+    BF, SFX, TOL_BF, X3 = {"fp16": (torch.float16, "f16", 5e-4, False), "bf16": (torch.bfloat16, "bf16", 4e-3, False),
+                           "x3": (torch.bfloat16, "x3", 3e-5, True)}[request.param]
     yield request.param
-    BF, SFX, TOL_BF = old
+    BF, SFX, TOL_BF, X3 = old
 
 
 def bench_shape_only_bf16(shape):
     """The full-size (B = 64) shapes run once, in the bf16 build; the fp16 build -- the same code with another element type -- takes
     the small cases and every fourth bench shape."""
     if SFX == "f16" and shape not in SOME:
-        pytest.skip("full-size shape list: bf16 build only")
+        pytest.skip("full-size shape list: bf16 and split-precision builds only")
 
 
 @pytest.fixture(scope="module")
@@ -47,12 +53,40 @@ def L():
 
 
 def rbf(a):
-    """numpy -> values rounded to the bf16 grid (float64)."""
-    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).to(BF).double().numpy()
+    """numpy -> values rounded to the bf16 grid (float64); split precision: to the hi + lo grid."""
+    t = torch.tensor(np.ascontiguousarray(a), dtype=torch.float32)
+    hi = t.to(BF)
+    if X3:
+        return (hi.double() + (t - hi.float()).to(BF).double()).numpy()
+    return hi.double().numpy()
 
 
 def dbf(a):
-    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32).to(BF).cuda()
+    """-> the device tensor of the build under test (split precision: the plane pair, shape (2, ...))."""
+    t = torch.tensor(np.ascontiguousarray(a), dtype=torch.float32)
+    hi = t.to(BF)
+    if X3:
+        return torch.stack([hi, (t - hi.float()).to(BF)]).cuda()
+    return hi.cuda()
+
+
+def empty16(*shape):
+    return torch.empty(*(((2,) if X3 else ()) + tuple(shape)), dtype=BF, device="cuda")
+
+
+def side16(shape):
+    """A `side` tensor (the operand copy the fills write for the weight gradients): the build's 2-byte type; split precision: ONE fp16 tensor."""
+    return torch.full(tuple(shape), float("nan"), dtype=torch.float16 if X3 else BF, device="cuda")
+
+
+def x3_tail(side2=None, side_scale=1.0):
+    """sar_conv2d_x3's two extra arguments (the fill's result as planes; the scale of the fp16 `side`)."""
+    return (side2, float(side_scale)) if X3 else ()
+
+
+def no_x3(what):
+    if X3:
+        pytest.skip("split precision: %s" % what)
 
 
 def dev(a):
@@ -60,7 +94,8 @@ def dev(a):
 
 
 def val(t):
-    return t.detach().float().cpu().double().numpy()
+    v = t.detach().float().cpu().double().numpy()
+    return v[0] + v[1] if (X3 and t.dtype == torch.bfloat16) else v   # (split precision: every bf16 tensor of these tests is a plane pair)
 
 
 def check(got, ref, tol, name):
@@ -80,8 +115,9 @@ class Conv:
         self.k, _, self.cin, self.cout = w.shape
         self.padding = padding
         taps = self.k * self.k
-        nf = (self.cout // 32) * (taps * self.cin // 16 + 8) * 512
-        nd = (self.cin // 32) * (taps * self.cout // 16 + 8) * 512
+        npl = 2 if X3 else 1
+        nf = (self.cout // 32) * (npl * taps * self.cin // 16 + 8) * 512
+        nd = (self.cin // 32) * (npl * taps * self.cout // 16 + 8) * 512
         self.wdev = dev(self.w)
         self.wf = torch.zeros(nf, dtype=BF, device="cuda"); self.wd = torch.zeros(nd, dtype=BF, device="cuda")
         nb = -(-(nf + nd) // 8 // 256)
@@ -97,20 +133,20 @@ class Conv:
             ho, wo, pt, pl = O.valid_out(H, self.k, self.s), O.valid_out(W, self.k, self.s), 0, 0
         return ho, wo, pt, pl
 
-    def fwd(self, x, bias=None, res=None, fill=0, fbn=None, e_bins=None, side=None):
-        B, H, W, _ = x.shape
+    def fwd(self, x, bias=None, res=None, fill=0, fbn=None, e_bins=None, side=None, side2=None, side_scale=1.0):
+        B, H, W, _ = x.shape[-4:]
         ho, wo, pt, pl = self.geo(H, W)
-        y = torch.empty(B, ho, wo, self.cout, dtype=BF, device="cuda")
+        y = empty16(B, ho, wo, self.cout)
         self.L.call("sar_conv2d_" + SFX, x, None, None, self.wf, bias, res, y, side, B, H, W, self.cin, ho, wo, self.cout, self.k, self.s, 1, pt, pl,
-                    fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None)
+                    fill, fbn, 1 if e_bins is not None else 0, e_bins, None, None, *x3_tail(side2, side_scale))
         return y
 
-    def dgrad(self, dy, H, W, dy2=None, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None):
-        B, ho, wo, _ = dy.shape
+    def dgrad(self, dy, H, W, dy2=None, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None, side2=None, side_scale=1.0):
+        B, ho, wo, _ = dy.shape[-4:]
         _, _, pt, pl = self.geo(H, W)
-        dx = torch.empty(B, H, W, self.cin, dtype=BF, device="cuda")
+        dx = empty16(B, H, W, self.cin)
         self.L.call("sar_conv2d_" + SFX, dy, dy2, dy3, self.wd, None, res, dx, side, B, ho, wo, self.cout, H, W, self.cin, self.k, 1, self.s,
-                    self.k - 1 - pt, self.k - 1 - pl, fill, fbn, 2 if e_bins is not None else 0, e_bins, e_y, e_saved)
+                    self.k - 1 - pt, self.k - 1 - pl, fill, fbn, 2 if e_bins is not None else 0, e_bins, e_y, e_saved, *x3_tail(side2, side_scale))
         return dx
 
     def desc(self, x, dy, dw, db):
@@ -120,6 +156,7 @@ class Conv:
 
     def wgrad(self, x, dy, bias=True, target_blocks=768, tile=(1, 1)):
         """One-convolution plan, added to a non-zero gradient buffer (the kernel accumulates)."""
+        assert not X3
         dw = torch.ones(self.k, self.k, self.cin, self.cout, device="cuda"); db = torch.zeros(self.cout, device="cuda")
         plan = self.L.WgradPlan([self.desc(x, dy, dw, db if bias else None)], target_blocks, tile, SFX)
         plan.launch()
@@ -264,11 +301,12 @@ def test_conv_fwd_with_batchnorm_relu_in_the_fill(L, shape):
     cv = Conv(L, w, s, pad); bn = BN(L, Cin, rng)
     bn.set_fwd_stats(x)
     ref, _ = O.conv2d_fwd(bn.act(x), cv.wq, None, (s, s), pad)
-    side = torch.full((B, H, W, Cin), float("nan"), dtype=BF, device="cuda")
-    y = cv.fwd(dbf(x), None, None, fill=1, fbn=bn.ref(bn.n, "fwd", True), side=side)
+    side = side16((B, H, W, Cin))
+    SC = 8.0 if X3 else 1.0                                       # split precision: side = fp16(relu(bn(x)) * side_scale)
+    y = cv.fwd(dbf(x), None, None, fill=1, fbn=bn.ref(bn.n, "fwd", True), side=side, side_scale=SC)
     check(y, ref, TOL_BF, "y")
     if not (k == 1 and s == 2):                                   # a strided 1x1 conv never touches the odd pixels (not a case the trunk has)
-        check(side, bn.act(x), TOL_BF, "side = relu(bn(x)) (every pixel written exactly once)")
+        check(side.float() / SC, bn.act(x), 6e-4 if X3 else TOL_BF, "side = relu(bn(x)) (every pixel written exactly once)")
     check(bn.d["saved"], np.stack([bn.mean, bn.rstd, bn.scale, bn.shift]), 1e-5, "saved mean/rstd/scale/shift")
     check(bn.d["mm"], (1 - BN.MOM) * bn.mean, 1e-5, "moving mean")
     check(bn.d["mv"], BN.MOM + (1 - BN.MOM) * bn.var * bn.n / (bn.n - 1.0), 1e-5, "moving variance (Bessel)")
@@ -317,23 +355,28 @@ def test_conv_dgrad_with_batchnorm_backward_in_the_fill(L, shape):
     bn.set_fwd_stats(yb); bn.set_saved(); bn.set_bwd_stats(da, yb)
     dyq = rbf(bn.dx(da, yb))                                    # what the fill writes to LDS
     ref = O.conv2d_bwd(dyq, cache)[0]
-    side = torch.full(da.shape, float("nan"), dtype=BF, device="cuda")
-    dx = cv.dgrad(dbf(da), H, W, dy2=dbf(yb), fill=2, fbn=bn.ref(bn.n, "bwd", True), side=side)
+    side = side16(da.shape)
+    SC = 64.0 if X3 else 1.0
+    dx = cv.dgrad(dbf(da), H, W, dy2=dbf(yb), fill=2, fbn=bn.ref(bn.n, "bwd", True), side=side, side_scale=SC)
     check(dx, ref, TOL_BF, "dx")
-    check(side, dyq, TOL_BF, "side = BatchNorm backward of (da, y)")
+    check(side.float() / SC, dyq, 6e-4 if X3 else TOL_BF, "side = BatchNorm backward of (da, y)")
     check(bn.d["dg"], bn.S2, 1e-5, "dgamma"); check(bn.d["db"], bn.S1, 1e-5, "dbeta")
     # fill 3: + the shortcut gradient -- the gradient a residual block hands to the block in front of it (resnet.py:96-125)
     add = grid(rng, da.shape)
     dyq3 = rbf(bn.dx(da, yb) + add)
     ref3 = O.conv2d_bwd(dyq3, cache)[0]
-    side3 = torch.full(da.shape, float("nan"), dtype=BF, device="cuda")
-    dx3 = cv.dgrad(dbf(da), H, W, dy2=dbf(yb), fill=3, fbn=bn.ref(bn.n, "bwd", False), side=side3, dy3=dbf(add))
-    check(dx3, ref3, TOL_BF, "dx (fill 3)"); check(side3, dyq3, TOL_BF, "side = BatchNorm backward + shortcut gradient")
+    side3 = side16(da.shape)
+    side23 = empty16(*da.shape) if X3 else None                   # split precision: the materialised gradient as planes, too
+    dx3 = cv.dgrad(dbf(da), H, W, dy2=dbf(yb), fill=3, fbn=bn.ref(bn.n, "bwd", False), side=side3, dy3=dbf(add), side2=side23, side_scale=SC)
+    check(dx3, ref3, TOL_BF, "dx (fill 3)"); check(side3.float() / SC, dyq3, 6e-4 if X3 else TOL_BF, "side = BatchNorm backward + shortcut gradient")
+    if X3:
+        check(side23, dyq3, TOL_BF, "side2 = the same as planes")
     check(bn.d["dg"], bn.S2, 1e-5, "dgamma untouched by a launch that does not own the side effects")
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)
 def test_conv_wgrad(L, shape):
+    no_x3("the weight gradients are the fp16 build's")
     bench_shape_only_bf16(shape)
     B, H, W, Cin, Cout, k, s, pad = shape
     rng = np.random.default_rng(4 + sum(shape[:7]))
@@ -366,6 +409,7 @@ def test_conv_wgrad(L, shape):
 
 def test_conv_wgrad_many_convolutions_in_one_launch(L):
     """The train step's form: the 3x3 stride-1 convs of several stages in one plan, the 1x1 convs in another."""
+    no_x3("the weight gradients are the fp16 build's")
     rng = np.random.default_rng(99)
     for k, tile, shapes in ((3, (1, 1), [(4, 25, 20, 32, 32, 1), (4, 13, 10, 64, 64, 1), (4, 7, 5, 128, 128, 1), (4, 4, 3, 256, 256, 1), (4, 25, 20, 64, 32, 1)]),
                             (3, (2, 2), [(4, 13, 10, 64, 64, 1), (4, 7, 5, 128, 128, 1), (4, 4, 3, 256, 256, 1), (5, 13, 3, 256, 256, 1)]),
@@ -402,15 +446,17 @@ def test_conv_and_its_shortcut_in_one_launch(L, B, H, W, Cin, Cout):
 
     def fwd_args(cv, y, bias, bins):
         _, _, pt_, pl_ = cv.geo(H, W)
-        return (x, None, None, cv.wf, bias, None, y, None, B, H, W, Cin, ho, wo, Cout, cv.k, 2, 1, pt_, pl_, 0, None, 1 if bins is not None else 0, bins, None, None)
+        return (x, None, None, cv.wf, bias, None, y, None, B, H, W, Cin, ho, wo, Cout, cv.k, 2, 1, pt_, pl_, 0, None, 1 if bins is not None else 0, bins, None, None) + x3_tail()
 
-    mk = lambda: torch.full((B, ho, wo, Cout), 7.0, dtype=BF, device="cuda")
+    mk = lambda: torch.full(((2,) if X3 else ()) + (B, ho, wo, Cout), 7.0, dtype=BF, device="cuda")
     y3a, y1a, y3b, y1b = mk(), mk(), mk(), mk()
     binsa, binsb = torch.zeros(L.bn_bins(), 2, Cout, device="cuda"), torch.zeros(L.bn_bins(), 2, Cout, device="cuda")
     L.call("sar_conv2d_" + SFX, *fwd_args(c3, y3a, bias3, binsa)); L.call("sar_conv2d_" + SFX, *fwd_args(c1, y1a, bias1, None))
     paired = L.conv_pair(L.ConvArgs.of(*fwd_args(c3, y3b, bias3, binsb)), L.ConvArgs.of(*fwd_args(c1, y1b, bias1, None)), SFX)
     torch.cuda.synchronize()
-    if Cin == 256:
+    # (which shapes do not pair up: the single-plane builds run the 3x3 from 256 channels on 32-pixel tiles and its 1x1 on 64; in split precision,
+    # twice the patch, that happens from 128 channels -- and from 256 both run the 32-pixel form and pair)
+    if Cin == (128 if X3 else 256):
         assert not paired and float((y3b.float() - 7.0).abs().max()) == 0.0      # nothing was launched
         return
     assert paired
@@ -421,9 +467,9 @@ def test_conv_and_its_shortcut_in_one_launch(L, B, H, W, Cin, Cout):
 
     def dgrad_args(cv, dx):
         _, _, pt_, pl_ = cv.geo(H, W)
-        return (g, None, None, cv.wd, None, None, dx, None, B, ho, wo, Cout, H, W, Cin, cv.k, 1, 2, cv.k - 1 - pt_, cv.k - 1 - pl_, 0, None, 0, None, None, None)
+        return (g, None, None, cv.wd, None, None, dx, None, B, ho, wo, Cout, H, W, Cin, cv.k, 1, 2, cv.k - 1 - pt_, cv.k - 1 - pl_, 0, None, 0, None, None, None) + x3_tail()
 
-    mkx = lambda: torch.full((B, H, W, Cin), 7.0, dtype=BF, device="cuda")
+    mkx = lambda: torch.full(((2,) if X3 else ()) + (B, H, W, Cin), 7.0, dtype=BF, device="cuda")
     d3a, d1a, d3b, d1b = mkx(), mkx(), mkx(), mkx()
     L.call("sar_conv2d_" + SFX, *dgrad_args(c3, d3a)); L.call("sar_conv2d_" + SFX, *dgrad_args(c1, d1a))
     paired = L.conv_pair(L.ConvArgs.of(*dgrad_args(c3, d3b)), L.ConvArgs.of(*dgrad_args(c1, d1b)), SFX)
@@ -431,12 +477,14 @@ def test_conv_and_its_shortcut_in_one_launch(L, B, H, W, Cin, Cout):
     if paired:                                                                     # (32 output channels: the 3x3 and the 1x1 run on different block sizes)
         assert torch.equal(d3a, d3b) and torch.equal(d1a, d1b)
     else:
-        assert Cin <= 32 and float((d3b.float() - 7.0).abs().max()) == 0.0
+        # (... and in split precision the gradients from 512 channels: the 3x3 owns sixteen pixels of its 32-pixel tile, the 1x1 all of them)
+        assert (Cin <= 32 or (X3 and Cin == 256)) and float((d3b.float() - 7.0).abs().max()) == 0.0
 
 
 def test_wgrad_reductions_of_several_plans_in_one_launch(L):
     """sar_wgrad_reduce_multi_*: three plans of different tile classes (64-wide 3x3, 32-wide 3x3, 1x1) run with their reductions deferred
     (launch4[7] = 1), then ONE launch sums the partial tiles of all of them -- same gradients as each plan reducing for itself."""
+    no_x3("the weight gradients are the fp16 build's")
     rng = np.random.default_rng(77)
     cases = [((16, 50, 10, 64, 64, 3, 1, "same"), (2, 2)), ((16, 50, 20, 32, 32, 3, 1, "same"), (1, 1)), ((16, 50, 10, 64, 128, 1, 2, "valid"), (1, 1))]   # >= 32 chunks of 64 pixels each: the planner cuts runs of >= 16
     plans, outs = [], []
@@ -478,8 +526,13 @@ def test_batchnorm_passes(L, R, C):
         S1, S2, _, _ = bn.bwd_sums(da, x)
         tot = val(bn.d["bbins"]).sum(0)
         check(tot[0], S1, 2e-4, "S1"); check(tot[1], S2, 2e-4, "S2")
-        g = torch.empty(R, C, dtype=BF, device="cuda")
-        L.call("sar_bn_bwd_apply_" + SFX, dd, f32, dbf(x), bn.ref(R, "bwd", True), dbf(add), g, R, C, 1, 1.0)
+        g = empty16(R, C)
+        if X3:                                                       # + the fp16 copy of the result times out_scale (the weight gradients' operand)
+            g16 = side16((R, C))
+            L.call("sar_bn_bwd_apply_x3", dd, f32, dbf(x), bn.ref(R, "bwd", True), dbf(add), g, g16, R, C, 1, 16.0)
+            check(g16.float() / 16.0, bn.dx(da, x) + add, 6e-4, "bn bwd apply, fp16 copy")
+        else:
+            L.call("sar_bn_bwd_apply_" + SFX, dd, f32, dbf(x), bn.ref(R, "bwd", True), dbf(add), g, R, C, 1, 1.0)
         check(g, bn.dx(da, x) + add, TOL_BF, "bn bwd apply")
         check(bn.d["dg"], S2, 2e-4, "dgamma"); check(bn.d["db"], S1, 2e-4, "dbeta")
 
@@ -487,6 +540,7 @@ def test_batchnorm_passes(L, R, C):
 def test_gradient_scale_enters_at_the_final_batchnorm_and_leaves_with_the_parameter_gradients(L):
     """The fp16 trunk's static gradient scale S (include/sarnet.h, "fp16 trunk"; the entry points of both builds take it): out_scale
     multiplies the gradient where it enters, sarBnRef.ginv / sarWgradConv.ginv = 1/S divide the parameter gradients where they leave."""
+    no_x3("the gradient stream is in true units; only the fp16 copies carry the scale (test_batchnorm_passes, the fill tests)")
     rng = np.random.default_rng(5)
     S = 256.0
     R, C = 640, 64
@@ -527,6 +581,16 @@ def test_gradient_scale_enters_at_the_final_batchnorm_and_leaves_with_the_parame
 def test_casts(L):
     rng = np.random.default_rng(0)
     a = rng.standard_normal(8 * 1000 + 8).astype(np.float32)
+    if X3:                                                           # planes + (nullable) the fp16 copy times a scale; back: hi + lo
+        y = empty16(a.size); y16 = side16((a.size,))
+        L.call("sar_cast_f32_x3", dev(a), y, y16, 4.0, a.size)
+        hi = torch.tensor(a).to(BF)
+        assert torch.equal(y[0].cpu(), hi) and torch.equal(y[1].cpu(), (torch.tensor(a) - hi.float()).to(BF))
+        assert torch.equal(y16.cpu(), (torch.tensor(a) * 4.0).to(torch.float16))
+        z = torch.empty(a.size, device="cuda")
+        L.call("sar_cast_x3_f32", y, z, a.size)
+        assert torch.equal(z.cpu(), y[0].cpu().float() + y[1].cpu().float())
+        return
     y = torch.empty(a.size, dtype=BF, device="cuda")
     L.call("sar_cast_f32_" + SFX, dev(a), y, a.size)
     assert torch.equal(y.cpu(), torch.tensor(a).to(BF))
