@@ -643,6 +643,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     TSTAMP(5);
     if constexpr (!EARLY) load_epi();
     lds_barrier();                                                 // the patch is dead: reuse it as the output staging tile
+    TSTAMP(10);
 
     // ---- epilogue: accumulators -> LDS (fp32) -> row-major pass: + bias (+ residual), 2-byte stores, statistics
     float* ot = reinterpret_cast<float*>(patch) + kg * (TM * TN);  // [KG][TM][TN]: each k-group stages its partial tile
@@ -657,6 +658,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         }
     }
     lds_barrier();
+    TSTAMP(9);
     float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
     long long q10 = 0, q11 = 0, q20 = 0, q21 = 0;                  // epi 3: the same sums in 64-bit fixed point (trunk16.h: fix28)
 #pragma unroll
