@@ -1380,6 +1380,16 @@ static int patch_rows_bound(const Geo& g, int tm) {
     return (drg / g.Ho + 1) * per_img + g.s * drg + g.K;
 }
 
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 template <typename KT>
 static bool allow_lds(KT kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
@@ -1484,6 +1494,19 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     // channels): the 32-pixel form on SIXTEEN owned pixels per block
     p.tmv = TM;
     if (X3 && br32 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((NPL * plane_bytes(32) + 1023) & ~(size_t)1023) > 160 * 1024) p.tmv = 16;
+    // SAR_X3, BR forms, a launch that does not fill the chip (stage 3 at B = 64: 39 pixel tiles x 4 channel tiles = 156 blocks on 256 CUs; every
+    // stage at smaller batches): FEWER owned pixels per block, as many pixel tiles as one round holds.  The MFMA rows past the owned pixels
+    // recompute the neighbour's and are dropped (the k-phase does not shrink), but the fill, the epilogue and the statistics -- two thirds of a
+    // block's life -- do, and the idle CUs take the extra tiles: stage 3 at 39 owned pixels = 256 blocks, 22.3 -> 21.1 us forward, 25-27 -> 23.4-24
+    // backward (a block's fixed latency chain, not its pixel count, is most of its life: DESIGN 5.00).
+    if (X3 && br && p.tmv == TM) {
+        const long tiles = cdiv(p.g.M, TM), nty = Cout / TN, cus = cu_count();
+        if (tiles * nty * 20 <= cus * 17) {                                        // at most 85 % of one round
+            const long slots = cus / nty;
+            const int t = slots > 0 ? (int)cdiv(p.g.M, (int)slots) : TM;
+            if (t < TM && t >= 8) p.tmv = t;
+        }
+    }
     p.cap_rows = patch_rows_bound(p.g, p.tmv < p.g.M ? p.tmv : p.g.M);
     if (p.cap_rows > 256 || p.cap_rows * 8 > ROWTAB_BYTES) return SAR_EINVAL;
     p.lplane = (int)plane_bytes(p.tmv);
