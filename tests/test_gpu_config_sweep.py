@@ -27,6 +27,10 @@ SWEEP = [
          disc_enable=True, metric_loss="arcface", margin=0.5, accent_classes=5, B=7),
     dict(input_shape=[100, 80, 1], res_type="res18", res_filters=64, hidden_dim=32, mto="vlad", vlad_clusters=4, disc_enable=True,
          metric_loss="arcface", B=2),
+    # other feature dimensions (the stage-0 map is 10 / 16 wide instead of 20: other patch geometries of every conv form)
+    dict(input_shape=[72, 40, 1], res_type="res18", res_filters=32, hidden_dim=32, mto="gvlad", vlad_clusters=4, ghost_clusters=1, disc_enable=True,
+         metric_loss="cosface", B=3),
+    dict(input_shape=[56, 64, 1], res_type="res34", res_filters=32, hidden_dim=32, mto="avg", disc_enable=True, metric_loss="softmax", B=2),
     # hidden_dim past the persistent GRU kernels' 256 units (round 4: one GEMM + one gate launch per time step), two Bi-GRUs + Bi-GRU pooling
     dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=320, mto="bigru", disc_enable=True, ctc_enable=True,
          bpe_classes=13, max_ctc_len=4, metric_loss="cosface", B=3),
