@@ -56,6 +56,20 @@ def test_gemm_layouts(L, a_kc, b_kc, M, N, K):
     check(C, A @ B + bias, name="gemm splitk")
 
 
+def test_gemm_tanh_epilogue_is_relative_accurate_and_odd(L):
+    """The Dense layers' tanh (DS(..., 'tanh'), model.py:35-42) is evaluated in the GEMM epilogue on v_exp / v_rcp: RELATIVE error <= 2e-6 from
+    |z| = 1e-6 to saturation (the first form cancelled near zero -- 1e-3 relative at 1e-4), and tanh(-z) = -tanh(z) bit for bit."""
+    z = np.concatenate([np.logspace(-6, 1.2, 2040), [0.0, 0.0625, 0.06249999, 0.5, 1.0, 20.0, 60.0, 88.0]]).astype(np.float32)
+    z = np.concatenate([z, -z]).reshape(64, 64)
+    A = dev(z); B = dev(np.eye(64)); C = zeros(64, 64)
+    L.call("sar_gemm_f32", A, B, C, None, 64, 64, 64, 64, 64, 64, 1, 0, 1, 0, 1)      # exact product with the identity: C = tanh(z)
+    got = C.cpu().double().numpy(); ref = np.tanh(z.astype(np.float64))
+    nz = ref != 0
+    assert np.abs(got[nz] / ref[nz] - 1.0).max() <= 2e-6 and np.all(got[~nz] == 0.0)
+    g = got.reshape(-1)
+    assert np.array_equal(g[:g.size // 2], -g[g.size // 2:])
+
+
 @pytest.mark.parametrize("R,I,N,sk", [(250, 64, 96, 1), (2496, 256, 768, 1), (77, 33, 10, 1), (2000, 48, 130, 4), (64, 8192, 256, 1)])
 def test_gemm_wgrad_with_fused_bias_gradient(L, R, I, N, sk):
     """Dense backward w.r.t. parameters in one launch: dW += X^T dY and db += column sums of dY (both accumulate)."""
