@@ -365,9 +365,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     static_assert(NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "epilogue maps must divide evenly");
     constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
-    // fragments per ring stage and channel tile: 8; 4 in the split-precision eight-wave form of the 32-channel layers (CO2 below: a 12 KB
-    // ring leaves room for TWO such blocks, 2 x 77.8 KB, in a CU's LDS)
-    constexpr bool CO2 = X3 && !BR && WMX * WN == 8 && NKC == 2;
+    // fragments per ring stage and channel tile: 8; 4 in the split-precision forms of the 32-channel sources (CO2 below: a 12 KB ring leaves
+    // room for TWO eight-wave blocks, 2 x 77.8 KB, in a CU's LDS; the four-wave forms -- the stride-2 entry of stage 1 and its shortcut -- likewise)
+    constexpr bool CO2 = X3 && !BR && NKC == 2;
     constexpr int SF = CO2 ? 4 : 8;
     constexpr int F = VT * NKC * NPL, NST = (F + SF - 1) / SF;     // weight fragments per channel tile (SAR_X3: hi, lo interleaved), ring stages
     constexpr int SJ = WN * SF, PW = (SJ + NW - 1) / NW;           // DMA wave-instructions per stage: block / per wave (SJ < NW: the first SJ waves issue one each)
@@ -1494,6 +1494,17 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     // channels): the 32-pixel form on SIXTEEN owned pixels per block
     p.tmv = TM;
     if (X3 && br32 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((NPL * plane_bytes(32) + 1023) & ~(size_t)1023) > 160 * 1024) p.tmv = 16;
+    // SAR_X3, the four-wave ring forms of the 32-channel sources (stage 1's stride-2 entry and its 1x1 shortcut: the patch of 64 output pixels is
+    // 17 + rows of the twice-as-large input, 2 x 30 KB): as many owned pixels -- whole output rows -- as leave room for TWO blocks per CU
+    // (with one, four waves have a CU to themselves and the pair launch is four rounds)
+    if (X3 && !br && !tm256 && Cin == 32 && p.g.Wo > 0 && p.g.Wo <= TM) {
+        auto lds_of = [&](int tmv) { return (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((NPL * plane_bytes(tmv) + 1023) & ~(size_t)1023) + (size_t)3 * WN * 4 * 1024; };
+        if (lds_of(TM) > 80 * 1024) {
+            int t = TM / p.g.Wo * p.g.Wo;
+            while (t > TM / 2 && lds_of(t) > 80 * 1024) t -= p.g.Wo;
+            if (t > TM / 2 && lds_of(t) <= 80 * 1024) p.tmv = t;
+        }
+    }
     // SAR_X3, BR forms, a launch that does not fill the chip (stage 3 at B = 64: 39 pixel tiles x 4 channel tiles = 156 blocks on 256 CUs; every
     // stage at smaller batches): FEWER owned pixels per block, as many pixel tiles as one round holds.  The MFMA rows past the owned pixels
     // recompute the neighbour's and are dropped (the k-phase does not shrink), but the fill, the epilogue and the statistics -- two thirds of a
@@ -1517,7 +1528,7 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel ring layers get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
-    const int SF = (X3 && tm256 && Cin == 32) ? 4 : 8;                             // fragments per ring stage (conv_body: CO2)
+    const int SF = (X3 && !br && Cin == 32) ? 4 : 8;                               // fragments per ring stage (conv_body: CO2)
     const size_t ring_bytes = br ? 0 : (size_t)p.rd * WN * SF * 1024;
     if (patch_bytes + ring_bytes < stage_bytes) patch_bytes = stage_bytes - ring_bytes;   // the staging tile overlays patch + ring
     if (patch_bytes < (size_t)nthr * 32) patch_bytes = (size_t)nthr * 32;      // bn_finish's scratch: G x 4 x Cin x 8 bytes, G x Cin <= threads
