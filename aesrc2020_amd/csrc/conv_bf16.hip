@@ -1497,8 +1497,9 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     // SAR_X3, the four-wave ring forms of the 32-channel sources (stage 1's stride-2 entry and its 1x1 shortcut: the patch of 64 output pixels is
     // 17 + rows of the twice-as-large input, 2 x 30 KB): as many owned pixels -- whole output rows -- as leave room for TWO blocks per CU
     // (with one, four waves have a CU to themselves and the pair launch is four rounds)
-    if (X3 && !br && !tm256 && Cin == 32 && p.g.Wo > 0 && p.g.Wo <= TM) {
-        auto lds_of = [&](int tmv) { return (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((NPL * plane_bytes(tmv) + 1023) & ~(size_t)1023) + (size_t)3 * WN * 4 * 1024; };
+    // (the same for the four-wave BR form of the 64-channel sources where its patch is past half a CU: the stride-2 entry of stage 2, 106 KB)
+    if (X3 && ((!br && !tm256 && Cin == 32) || (br && !br32 && Cin == 64)) && p.g.Wo > 0 && p.g.Wo <= TM) {
+        auto lds_of = [&](int tmv) { return (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((NPL * plane_bytes(tmv) + 1023) & ~(size_t)1023) + (br ? 0 : (size_t)3 * WN * 4 * 1024); };
         if (lds_of(TM) > 80 * 1024) {
             int t = TM / p.g.Wo * p.g.Wo;
             while (t > TM / 2 && lds_of(t) > 80 * 1024) t -= p.g.Wo;
