@@ -468,7 +468,10 @@ __global__ __launch_bounds__(512) void gru_mfma_bwd4_kernel(const float* __restr
 static int gru_rows(int B) {
     static const int knob = getenv("SAR_GRU_ROWS") ? atoi(getenv("SAR_GRU_ROWS")) : 0;
     if (knob >= 1 && knob <= GNR) return knob;
-    int rows = 4;
+    // (round 4: ONE row per workgroup wherever the chip has the workgroups -- 2 x B <= 256: a step's loads and stores, not its MFMAs, are what a
+    // workgroup waits for; rows 4 / 3 / 2 / 1 at B = 64, 39 steps: cfg2 2.476 / 2.500 / 2.468 / 2.463 ms, cfg3 3.011 -> 2.937; the reference's
+    // train.py configuration, B = 32 and 114 steps in three Bi-GRUs: 5.245 / 5.164 / 5.067 / 4.942 ms; 8 rows: 6.566)
+    int rows = 1;
     while (rows < GNR && cdiv(B, rows) * 2 > 256) rows *= 2;
     return rows;
 }
