@@ -11,7 +11,10 @@ namespace {
 
 constexpr float CTC_EPS = 1e-7f;
 constexpr int CTC_SMAX = 512;      // 2*max_label_len+1 (reference: 2*72+1 = 145)
-constexpr size_t CTC_LDS_CAP = 56 * 1024;   // dynamic LDS for the e / alpha staging (with the static arrays: < 64 KB, no attribute needed)
+// dynamic LDS for the e / alpha staging.  Round 4: up to 144 KB (the static arrays are < 12 KB; past 64 KB the launchers raise the kernels'
+// limit): the reference's shipped configuration -- 1200 frames, L = 114, 145 states: 66 KB forward, 132 KB backward -- ran the recursions on
+// the L2-resident workspace, one round trip per frame in their critical path: ctc_fwd 103 -> 64 us, ctc_bwd 166 -> 91 us at B = 32.
+constexpr size_t CTC_LDS_CAP = 144 * 1024;
 
 // log(exp(a) + exp(b)) for the recursions: m + log(1 + exp(-|a - b|)) on v_exp_f32 / v_log_f32 (one of each; ~1e-7 relative in the
 // probability domain).  common.h's lse2 is two libm expf and a logf, ~120 instructions -- with up to two of them per state and frame
@@ -253,6 +256,11 @@ extern "C" int sar_ctc_batch_cost_fwd_f32(const float* probs, const float* label
     float* ews = alpha + (size_t)B * L * Smax;
     float* logden = ews + (size_t)B * L * Smax;
     const size_t lds = sizeof(float) * (size_t)L * Smax;
+    static PerDeviceFlag attr;
+    if (lds > 48 * 1024 && lds <= CTC_LDS_CAP && !attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_LDS_CAP) != hipSuccess) return SAR_ELAUNCH;
+        attr = true;
+    }
     if (lds <= CTC_LDS_CAP)
         hipLaunchKernelGGL(ctc_fwd_kernel<true>, dim3(B), dim3(CTC_NT), lds, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
     else
@@ -273,6 +281,11 @@ extern "C" int sar_ctc_batch_cost_bwd_f32(const float* probs, const float* label
     const float* ews = alpha + (size_t)B * L * Smax;
     const float* logden = ews + (size_t)B * L * Smax;
     const size_t lds = 2 * sizeof(float) * (size_t)L * Smax;
+    static PerDeviceFlag attr;
+    if (lds > 48 * 1024 && lds <= CTC_LDS_CAP && !attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_LDS_CAP) != hipSuccess) return SAR_ELAUNCH;
+        attr = true;
+    }
     if (lds <= CTC_LDS_CAP)
         hipLaunchKernelGGL(ctc_bwd_kernel<true>, dim3(B), dim3(CTC_NT), lds, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
     else

@@ -696,7 +696,9 @@ def _ctc_inputs(B, Lq, V, maxU, rng, Umax):
 
 # (3, 300, 20, 140, 135): S = 2 U + 1 up to 271 states -- more than the 256 threads the recursion keeps (the waves that only serve
 # the parallel phases leave in front of the recursion's barriers); (3, 1, 7, 2, 1): a single frame
-@pytest.mark.parametrize("B,Lq,V,maxU,Umax", [(4, 12, 9, 8, 4), (64, 39, 1000, 72, 16), (3, 189, 50, 72, 60), (3, 300, 20, 140, 135), (3, 1, 7, 2, 1)])
+# (4, 114, 1000, 72, 40): the reference's shipped configuration (1200 frames): 66 / 132 KB of LDS staging, past the default 64 KB limit (round 4);
+# (3, 189, ...): forward staged in LDS, backward (219 KB) on the workspace; (3, 300, ...): both on the workspace
+@pytest.mark.parametrize("B,Lq,V,maxU,Umax", [(4, 12, 9, 8, 4), (64, 39, 1000, 72, 16), (4, 114, 1000, 72, 40), (3, 189, 50, 72, 60), (3, 300, 20, 140, 135), (3, 1, 7, 2, 1)])
 def test_ctc(L, B, Lq, V, maxU, Umax):
     rng = np.random.default_rng(V)
     p, lab, il, ll = _ctc_inputs(B, Lq, V, maxU, rng, Umax)
