@@ -1342,6 +1342,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __rest
     const int lane = (int)(i & 63);
     const long t = i >> 6;
     const int f = (int)(t % Fp), nt = (int)(t / Fp);
+    // (SAR_X3: the thread of the hi fragment writes the lo fragment -- the next one, 64 pieces on -- as well; the threads of the odd fragments have
+    // nothing to do: gathering the same eight values twice was half of this launch's loads)
+    if (X3 && (f & 1)) return;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -1353,8 +1356,13 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __rest
             v[j] = fwd ? row.w[((long)tap * Cin + rc + j) * Cout + oc] : row.w[((long)(taps - 1 - tap) * Cin + oc) * Cout + rc + j];
     }
     uint4 o = pack8(v);
-    if constexpr (X3) { uint4 lo; split8(v, o, lo); if (f % NPL) o = lo; }
-    *reinterpret_cast<uint4*>((fwd ? row.wf : row.wd) + i * 8) = o;
+    u16* dst = (fwd ? row.wf : row.wd) + i * 8;
+    if constexpr (X3) {
+        uint4 lo;
+        split8(v, o, lo);
+        *reinterpret_cast<uint4*>(dst + 64 * 8) = lo;                // fragment f + 1 of the same channel block (F and the padding are even)
+    }
+    *reinterpret_cast<uint4*>(dst) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------- host side

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aesrc2020_amd import _lib as L
-L.set_gemm_math("bf16")
+L.set_gemm_math(os.environ.get("GG_MATH", "bf16x3"))          # GG_MATH=bf16: the single-pass form
 z = lambda *s: torch.randn(*s, device="cuda") * 0.1
 R = 2496
 base = [(R, 768, 256), (R, 512, 256), (64, 8192, 256)] + [(R, 256, 768)] * 4       # (R, in, out)
