@@ -27,6 +27,63 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
     for (int i = threadIdx.x; i < N; i += blockDim.x) pr[i] *= inv;
 }
 
+// One WAVE per row, the row in registers (N % 4 == 0, N <= 1024: the bpe-1k CTC output layer, model.py:270): one pass over the row instead of
+// three, wave reductions instead of two block reductions, v_exp_f32 instead of libm's expf (round 4: 15.9 -> 5.9 us forward, 8.6 -> 6.7 us backward for 2 496 x 1 000).
+constexpr int SMW_V = 4;                       // float4 per lane
+__global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(const float* __restrict__ z, float* __restrict__ p, int rows, int N) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* zr = reinterpret_cast<const float4*>(z + (long)row * N); float4* pr = reinterpret_cast<float4*>(p + (long)row * N);
+    const int n4 = N >> 2;
+    float4 v[SMW_V];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SMW_V; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = i < n4 ? zr[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        m = fmaxf(m, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    constexpr float L2E = 1.44269504f;
+#pragma unroll
+    for (int j = 0; j < SMW_V; ++j) {
+        v[j].x = __builtin_amdgcn_exp2f((v[j].x - m) * L2E); v[j].y = __builtin_amdgcn_exp2f((v[j].y - m) * L2E);
+        v[j].z = __builtin_amdgcn_exp2f((v[j].z - m) * L2E); v[j].w = __builtin_amdgcn_exp2f((v[j].w - m) * L2E);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);              // (lanes past the row: exp2(-inf) = 0)
+    }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int j = 0; j < SMW_V; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n4) pr[i] = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+    }
+}
+__global__ __launch_bounds__(256) void softmax_bwd_wave_kernel(const float* __restrict__ dp, const float* __restrict__ p, float* __restrict__ dz, int rows, int N) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long o = (long)row * N;
+    const float4* dr = reinterpret_cast<const float4*>(dp + o); const float4* pr = reinterpret_cast<const float4*>(p + o);
+    float4* zr = reinterpret_cast<float4*>(dz + o);
+    const int n4 = N >> 2;
+    float4 d[SMW_V], q[SMW_V];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMW_V; ++j) {
+        const int i = lane + 64 * j;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        d[j] = i < n4 ? dr[i] : z4; q[j] = i < n4 ? pr[i] : z4;
+        s = fmaf(d[j].x, q[j].x, s); s = fmaf(d[j].y, q[j].y, s); s = fmaf(d[j].z, q[j].z, s); s = fmaf(d[j].w, q[j].w, s);
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int j = 0; j < SMW_V; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n4) zr[i] = make_float4(q[j].x * (d[j].x - s), q[j].y * (d[j].y - s), q[j].z * (d[j].z - s), q[j].w * (d[j].w - s));
+    }
+}
+
 // dz = p * (dp - sum(dp*p))
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ p,
                                                           float* __restrict__ dz, int N) {
@@ -171,12 +228,23 @@ extern "C" int sar_act_bwd_f32(const float* dy, const float* y, float* dz, long 
 }
 extern "C" int sar_softmax_fwd_f32(const float* z, float* p, int rows, int N, hipStream_t stream) {
     if (!z || !p || rows <= 0 || N <= 0) return SAR_EINVAL;
+    if (N % 4 == 0 && N > 64 && N <= 256 * SMW_V && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(p)) & 15) == 0) {
+        hipLaunchKernelGGL(softmax_fwd_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, z, p, rows, N);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(rows), dim3(N <= 64 ? 64 : 256), 0, stream, z, p, N);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
 extern "C" int sar_softmax_bwd_f32(const float* dp, const float* p, float* dz, int rows, int N, hipStream_t stream) {
     if (!dp || !p || !dz || rows <= 0 || N <= 0) return SAR_EINVAL;
+    if (N % 4 == 0 && N > 64 && N <= 256 * SMW_V &&
+        ((reinterpret_cast<uintptr_t>(dp) | reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0) {
+        hipLaunchKernelGGL(softmax_bwd_wave_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dp, p, dz, rows, N);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(N <= 64 ? 64 : 256), 0, stream, dp, p, dz, N);
     SAR_CHECK_LAUNCH();
     return SAR_OK;

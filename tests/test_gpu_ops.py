@@ -776,7 +776,7 @@ def test_circle_cce_softmax_misc(L):
     check(loss, l_ref, name="cce fwd")
     dp = zeros(B, A); L.call("sar_cce_bwd_f32", yd, pd, dev(g), dp, B, A)
     check(dp, dp_ref * g[:, None], name="cce bwd")
-    for N in (8, 1000):
+    for N in (8, 1000, 132, 1024, 1500):                          # 68 .. 1024 columns, multiples of 4: the one-wave-per-row kernels (round 4); others: a block per row
         z = rng.standard_normal((70, N)) * 3; zd = dev(z); q = zeros(70, N)
         L.call("sar_softmax_fwd_f32", zd, q, 70, N); check(q, O.softmax(z), name="softmax fwd")
         dq = rng.standard_normal((70, N)); sm = O.softmax(z); dz = zeros(70, N)
