@@ -1467,7 +1467,7 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     p.Fs = NPL * K * K * Cin / 16 + 8;
     // (SAR_X3, 32 source channels into 64 at stride 1 -- the input gradients of the first block's conv and shortcut, 128 000 pixels at B = 64:
     // as TWO 32-channel tiles of the co-resident eight-wave form, 1 000 blocks in two rounds, instead of 2 000 four-wave blocks of 64 x 64 in
-    // four: 71 + 25 -> see DESIGN 5.00)
+    // four: 71 + 25 -> 37 + 20 us)
     const bool split64 = X3 && Cin == 32 && Cout == 64 && s == 1 && d == 1 && getenv("SAR_CONV16_TM") == nullptr;
     const int WN = (Cout >= 64 && !split64) ? 2 : 1, TN = 32 * WN;
     // LDS bytes of the patch: every plane + a 1 KiB scratch slot behind it (the fill's branch-free no-op pieces land there)
