@@ -8,6 +8,19 @@
 
 namespace {
 
+// In-kernel phase timing (tools/vlad_timing.py; only with -DSAR_TIMING into tools/libsarnet_timing_vlad.so, never part of libsarnet_hip.so):
+// thread 0 of every block stamps s_memtime (shader clock) / s_memrealtime (100 MHz, device-wide: slots 0, 15).
+#ifdef SAR_TIMING
+__device__ unsigned long long* g_tbuf_vlad = nullptr;
+#define TSTAMP(slot)                                                                                                   \
+    do {                                                                                                               \
+        if (g_tbuf_vlad && threadIdx.x == 0)                                                                           \
+            g_tbuf_vlad[((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 16 + (slot)] = ((slot) == 0 || (slot) == 15) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TSTAMP(slot) do {} while (0)
+#endif
+
 constexpr int KC = 16;      // clusters accumulated per register pass
 constexpr int XB = 13;      // feature rows fetched per batch (independent loads in flight)
 
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_kernel(const float* __restrict__
 // B-operand lane -> (col lane&31, k lane>>5), acc[r] -> (row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31).
 // Stage `nrows` rows of a (rows, D) global matrix into an LDS tile [nrows_tile][ld] (ld >= round_up(D, 32)), zero-filling the
 // rows beyond `rows` and the columns beyond D: a wave per row, float4 global loads when the row is 16-byte aligned.
+template <int NWV = 4>
 __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, const float* __restrict__ src, int D, int rows,
                                            int nrows_tile, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -211,24 +225,26 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, con
     const bool vec = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     if (vec && Dpad <= 256) {                                         // one float4 per lane and row: eight rows per trip, loads first
         const int d = lane * 4;                                       // (row by row this was 8-16 dependent L2 round trips per chunk)
-        for (int r0 = wave; r0 < nrows_tile; r0 += 32) {
-            float4 v[8];
+        // (round 4: SIXTEEN rows per trip -- a 64-row tile in ONE round trip; the features were written by another XCD's launch, a trip to
+        // them is ~4 000 cycles: in-kernel stamps, tools/vlad_timing.py)
+        constexpr int RPT = 64 / NWV;                                 // rows per wave and trip
+        for (int r0 = wave; r0 < nrows_tile; r0 += 64) {
+            float4 v[RPT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = r0 + 4 * j;
+            for (int j = 0; j < RPT; ++j) {
+                const int r = r0 + NWV * j;
                 const bool ok = r < rows && d < D;
-                v[j] = *reinterpret_cast<const float4*>(src + (ok ? (long)r * D + d : 0));
-                if (!ok) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                v[j] = ok ? *reinterpret_cast<const float4*>(src + (long)r * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = r0 + 4 * j;
+            for (int j = 0; j < RPT; ++j) {
+                const int r = r0 + NWV * j;
                 if (r < nrows_tile && d < Dpad) { float* dst = tile + r * ld + d; dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w; }
             }
         }
         return;
     }
-    for (int r = wave; r < nrows_tile; r += 4) {
+    for (int r = wave; r < nrows_tile; r += NWV) {
         float* dst = tile + r * ld;
         if (r < rows && vec) {
             for (int d = lane * 4; d < Dpad; d += 256) {
@@ -244,7 +260,46 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, con
 constexpr int VF_LC = 64;           // rows of L per chunk, forward
 constexpr int VB_LC = 32;           // backward (two more LDS tiles live)
 
-__global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restrict__ feat, const float* __restrict__ score,
+// Softmax over the KG scores of the 64 rows of a chunk into A_c (zero beyond `rows` / KG) + the staging of the chunk's features (stage_rows),
+// whose loads go out between the score loads and their use.  SMX: columns per lane (KG <= 4 * SMX).
+template <int SMX, int NWV>
+__device__ __forceinline__ void assign_rows(float* __restrict__ A_c, int KGP, const float* __restrict__ sc, int KG, int l0, int rows,
+                                            float* __restrict__ X_c, int DP, const float* __restrict__ x, int D, int tid) {
+    const int srow_ = (tid & 255) >> 2, sq_ = tid & 3;
+    const bool on = tid < 256;                                       // (wave-uniform: the first four waves)
+    float sv[SMX];
+    float smax = -INFINITY;
+    const float* srp = sc + (long)(l0 + min(srow_, rows - 1)) * KG;
+#pragma unroll
+    for (int j = 0; j < SMX; ++j) {
+        const int k = sq_ + 4 * j;
+        sv[j] = (on && k < KG && srow_ < rows) ? srp[k] : -INFINITY;
+        smax = fmaxf(smax, sv[j]);
+    }
+    stage_rows<NWV>(X_c, DP, x + (long)l0 * D, D, rows, VF_LC, tid);
+    if (!on) return;
+    smax = fmaxf(smax, SAR_DPP_F(smax, 0xB1)); smax = fmaxf(smax, SAR_DPP_F(smax, 0x4E));
+    float ssum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMX; ++j) {
+        const float e = srow_ < rows ? __expf(sv[j] - smax) : 0.f;   // exp(-inf) = 0 for the columns past KG
+        sv[j] = e; ssum += e;
+    }
+    ssum += SAR_DPP_F(ssum, 0xB1); ssum += SAR_DPP_F(ssum, 0x4E);
+    const float sinv = srow_ < rows ? 1.f / ssum : 0.f;
+    for (int k = sq_; k < KGP; k += 4) A_c[srow_ * KGP + k] = 0.f;   // (columns KG .. KGP, and the rows past `rows`)
+#pragma unroll
+    for (int j = 0; j < SMX; ++j) {
+        const int k = sq_ + 4 * j;
+        if (k < KG) A_c[srow_ * KGP + k] = sv[j] * sinv;
+    }
+}
+
+// EIGHT waves, one 32-column tile of D each (round 4; was four waves with two tiles each): the kernel runs ONCE per step on 64 workgroups -- mostly
+// straight-line code with one wave per SIMD, ~8 cycles an instruction (tools/vlad_timing.py: 47 000 cycles for 5 900 instructions) -- so what a
+// wave does not have to execute is what it saves: half the staging, half the accumulator entries to turn into residuals, to reduce and to store.
+constexpr int VF_NT = 512, VF_NW = 8;
+__global__ __launch_bounds__(VF_NT) void vlad_fwd_mfma_kernel(const float* __restrict__ feat, const float* __restrict__ score,
                                                             const float* __restrict__ centers, float* __restrict__ out,
                                                             float* __restrict__ A_out, float* __restrict__ inv_out, int L,
                                                             int D, int K, int KG) {
@@ -258,11 +313,13 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
     const float* x = feat + (long)b * L * D;
     const float* sc = score + (long)b * L * KG;
     float* Ao = A_out + (long)b * L * KG;
-    for (int i = tid; i < KGP; i += 256) asum[i] = 0.f;
-    for (int i = tid; i < 64; i += 256) ss[i] = 0.f;
-    f32x16 acc[2][2];                    // [d-tile slot: wave, wave+4][k-tile]
+    TSTAMP(0); TSTAMP(1);
+    for (int i = tid; i < KGP; i += VF_NT) asum[i] = 0.f;
+    for (int i = tid; i < 64; i += VF_NT) ss[i] = 0.f;
+    f32x16 acc[1][2];                    // [d-tile slot: wave (+ 8: D <= 256 has none)][k-tile]
+    float cen[2][16][1];                 // centres at the accumulator entries [k-tile][r][d-tile slot] (constant indices only: registers)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 1; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -270,49 +327,50 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
     for (int l0 = 0; l0 < L; l0 += VF_LC) {
         const int rows = min(VF_LC, L - l0);
         __syncthreads();                                             // previous chunk's tiles are no longer read
-        for (int i = tid; i < VF_LC * KGP; i += 256) {
-            const int r = i / KGP, k = i - r * KGP;
-            A_c[i] = (r < rows && k < KG) ? sc[(long)(l0 + r) * KG + k] : -INFINITY;
-        }
-        stage_rows(X_c, DP, x + (long)l0 * D, D, rows, VF_LC, tid);
+        // Soft assignments: FOUR lanes per row (64 rows x 4 lanes: the first four waves), scores straight from global memory into registers,
+        // quad reductions on DPP -- requested in front of the feature staging so that both round trips overlap.  (Round 4: was scores -> LDS,
+        // barrier, ONE thread per row walking its columns three times through LDS.)  Instantiated for 36 / 64 / 128 columns: straight-line
+        // code costs this kernel ~8 cycles an instruction.
+        if (KG <= 36) assign_rows<9, VF_NW>(A_c, KGP, sc, KG, l0, rows, X_c, DP, x, D, tid);
+        else if (KG <= 64) assign_rows<16, VF_NW>(A_c, KGP, sc, KG, l0, rows, X_c, DP, x, D, tid);
+        else assign_rows<32, VF_NW>(A_c, KGP, sc, KG, l0, rows, X_c, DP, x, D, tid);
         __syncthreads();
-        if (tid < VF_LC) {                                           // softmax of one row (rows are short)
-            float* srow = A_c + tid * KGP;
-            if (tid < rows) {
-                float m = -INFINITY;
-                for (int k = 0; k < KG; ++k) m = fmaxf(m, srow[k]);
-                float sum = 0.f;
-                for (int k = 0; k < KG; ++k) { const float e = __expf(srow[k] - m); srow[k] = e; sum += e; }   // v_exp_f32 form: one thread walks a row
-                const float inv = 1.f / sum;
-                for (int k = 0; k < KG; ++k) srow[k] *= inv;
-                for (int k = KG; k < KGP; ++k) srow[k] = 0.f;
-            } else {
-                for (int k = 0; k < KGP; ++k) srow[k] = 0.f;
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < rows * KG; i += 256) { const int r = i / KG, k = i - r * KG; Ao[(long)(l0 + r) * KG + k] = A_c[r * KGP + k]; }
-        for (int i = tid; i < 4 * KG; i += 256) {                    // column sums: four row groups per column, LDS atomics (was one thread
+        TSTAMP(2);
+        for (int i = tid; i < rows * KG; i += VF_NT) { const int r = i / KG, k = i - r * KG; Ao[(long)(l0 + r) * KG + k] = A_c[r * KGP + k]; }
+        for (int i = tid; i < 4 * KG; i += VF_NT) {                    // column sums: four row groups per column, LDS atomics (was one thread
             const int kc = i >> 2, rg = i & 3;                       // per column walking all rows)
             float t = 0.f;
             for (int r = rg; r < rows; r += 4) t += A_c[r * KGP + kc];
             atomicAdd(&asum[kc], t);
         }
         const int i31 = lane & 31, kk = lane >> 5;
+        TSTAMP(3);
+        if (l0 == 0) {                                                // the centres of this lane's accumulator entries: requested under the MFMA loop
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int a = 0; a < 1; ++a) {
+                        const int k = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), d = (wave + VF_NW * a) * 32 + (lane & 31);
+                        cen[c][r][a] = (c < Kt && (wave + VF_NW * a) < Dt && d < D && k < K) ? centers[(long)k * D + d] : 0.f;
+                    }
+        }
         for (int r0 = 0; r0 < VF_LC; r0 += 2) {
             if (r0 >= rows) break;                                    // block-uniform; further rows are zero
-            float av[2], bv[2];
+            float av[2], bv[1];
 #pragma unroll
             for (int c = 0; c < 2; ++c) av[c] = c < Kt ? A_c[(r0 + kk) * KGP + c * 32 + i31] : 0.f;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) bv[a] = (wave + 4 * a) < Dt ? X_c[(r0 + kk) * DP + (wave + 4 * a) * 32 + i31] : 0.f;
+            for (int a = 0; a < 1; ++a) bv[a] = (wave + VF_NW * a) < Dt ? X_c[(r0 + kk) * DP + (wave + VF_NW * a) * 32 + i31] : 0.f;
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 1; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    if ((wave + 4 * a) < Dt && c < Kt) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[a], acc[a][c], 0, 0, 0);
+                    if ((wave + VF_NW * a) < Dt && c < Kt) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[a], acc[a][c], 0, 0, 0);
         }
     }
+    TSTAMP(4);
     __syncthreads();                                                 // asum complete
     // residuals in registers, squared row norms through one LDS atomic per (half-wave, row)
 #pragma unroll
@@ -323,21 +381,22 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
             const int k = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             float sq = 0.f;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int d = (wave + 4 * a) * 32 + (lane & 31);
+            for (int a = 0; a < 1; ++a) {
+                const int d = (wave + VF_NW * a) * 32 + (lane & 31);
                 float v = 0.f;
-                if ((wave + 4 * a) < Dt && d < D && k < K) v = acc[a][c][r] - asum[k] * centers[(long)k * D + d];
+                if ((wave + VF_NW * a) < Dt && d < D && k < K) v = acc[a][c][r] - asum[k] * cen[c][r][a];
                 acc[a][c][r] = v; sq = fmaf(v, v, sq);
             }
             // sum over the 32 lanes of a half-wave: four DPP steps give every lane its 16-lane row's sum, one cross-row exchange the rest
             // (five ds_bpermute round trips per value before, 160 per thread)
             sq += SAR_DPP_F(sq, 0xB1); sq += SAR_DPP_F(sq, 0x4E); sq += SAR_DPP_F(sq, 0x141); sq += SAR_DPP_F(sq, 0x140);
-            sq += __shfl_xor(sq, 16, 64);
-            if ((lane & 31) == 0 && k < K) atomicAdd(&ss[k], sq);
+            if ((lane & 15) == 0 && k < K) atomicAdd(&ss[k], sq);    // one LDS atomic per 16-lane row (the cross-row exchange was a ds_bpermute round trip per value)
         }
     }
+    TSTAMP(5);
     __syncthreads();
-    for (int k = tid; k < K; k += 256) {
+    TSTAMP(6);
+    for (int k = tid; k < K; k += VF_NT) {
         const float s2 = ss[k];
         const float iv = 1.f / sqrtf(fmaxf(s2, 1e-12f));
         inv_out[(long)b * K + k] = s2 >= 1e-12f ? iv : -iv;
@@ -352,12 +411,13 @@ __global__ __launch_bounds__(256) void vlad_fwd_mfma_kernel(const float* __restr
             if (k >= K) continue;
             const float iv = 1.f / sqrtf(fmaxf(ss[k], 1e-12f));
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const int d = (wave + 4 * a) * 32 + (lane & 31);
-                if ((wave + 4 * a) < Dt && d < D) o[(long)k * D + d] = acc[a][c][r] * iv;
+            for (int a = 0; a < 1; ++a) {
+                const int d = (wave + VF_NW * a) * 32 + (lane & 31);
+                if ((wave + VF_NW * a) < Dt && d < D) o[(long)k * D + d] = acc[a][c][r] * iv;
             }
         }
     }
+    TSTAMP(7); TSTAMP(15);
 }
 
 __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ feat,
@@ -526,7 +586,7 @@ extern "C" int sar_vlad_fwd_f32(const float* feat, const float* score, const flo
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_fwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(vlad_fwd_mfma_kernel, dim3(B), dim3(256), ldsm, stream, feat, score, centers, out, A, inv, L, D, K, KG);
+        hipLaunchKernelGGL(vlad_fwd_mfma_kernel, dim3(B), dim3(VF_NT), ldsm, stream, feat, score, centers, out, A, inv, L, D, K, KG);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
@@ -570,3 +630,9 @@ extern "C" int sar_vlad_bwd_f32(const float* dout, const float* feat, const floa
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
+
+#ifdef SAR_TIMING
+extern "C" int sar_dbg_set_timing_buffer_vlad(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tbuf_vlad), &buf, sizeof(buf)) == hipSuccess ? SAR_OK : SAR_ELAUNCH;
+}
+#endif
