@@ -420,7 +420,10 @@ __global__ __launch_bounds__(VF_NT) void vlad_fwd_mfma_kernel(const float* __res
     TSTAMP(7); TSTAMP(15);
 }
 
-__global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ feat,
+// (EIGHT waves like the forward kernel, round 4: every per-wave share -- clusters of the normalisation backward, d-steps of dA, the d-tile of
+// dfeat -- halves, and the softmax backward runs on sixteen lanes per row instead of one.)
+constexpr int VB_NT = 512, VB_NW = 8;
+__global__ __launch_bounds__(VB_NT) void vlad_bwd_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ feat,
                                                             const float* __restrict__ A, const float* __restrict__ centers,
                                                             const float* __restrict__ out, const float* __restrict__ inv,
                                                             float* __restrict__ dfeat, float* __restrict__ dscore,
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     const float* Ab = A + (long)b * L * KG;
     const float* dO = dout + (long)b * K * D;
     const float* n = out + (long)b * K * D;
-    for (int i = tid; i < KP * DP1; i += 256) dres[i] = 0.f;
+    for (int i = tid; i < KP * DP1; i += VB_NT) dres[i] = 0.f;
     // The prologue loops are chains of memory round trips (a workgroup per utterance: nothing else hides them), so they are
     // unrolled to keep independent loads in flight (as plain loops: 82 us for the kernel, unrolled 71 us)
     // One workgroup per (utterance, chunk of VB_LC frames): everything behind dres -- dA, the softmax backward, dfeat -- is private to a
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     // sums over ALL frames (128 workgroups adding into the same 8 192 addresses were half of this kernel: device-scope atomics on one
     // address serialise)
     const bool centres = blockIdx.y == 0;
-    for (int k = tid; k < KG; k += 256) {                            // column sums of the saved assignments (chunk 0 only)
+    for (int k = tid; k < KG; k += VB_NT) {                            // column sums of the saved assignments (chunk 0 only)
         float t = 0.f;
         if (centres) {
 #pragma unroll 13
@@ -463,11 +466,11 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     // l2-normalise backward; dcenters; dres . c -- a wave takes its clusters four at a time with every load of the four (n, dO, centres,
     // inv: 13 per lane and cluster) in flight at once, and keeps n . dO in registers (one pass, no barrier in between).  Cluster by
     // cluster this was 2 x K/4 dependent round trips in front of the MFMA work: ~40 of the kernel's 48 us.
-    for (int k0 = wave; k0 < K; k0 += 16) {
+    for (int k0 = wave; k0 < K; k0 += 4 * VB_NW) {
         float nv[4][4], dv[4][4], cv[4][4], ivv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int kk = k0 + 4 * j;
+            const int kk = k0 + VB_NW * j;
             const bool kv = kk < K;
             ivv[j] = kv ? inv[(long)b * K + kk] : 0.f;
 #pragma unroll
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int kk = k0 + 4 * j;
+            const int kk = k0 + VB_NW * j;
             if (kk >= K) break;                                      // wave-uniform
             float t = 0.f;
 #pragma unroll
@@ -506,12 +509,12 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
     {
         const int l0 = l_first, rows = l_end - l_first;
         __syncthreads();                                             // dres complete / previous chunk consumed
-        stage_rows(X_c, DP1, x + (long)l0 * D, D, rows, VB_LC, tid);
-        for (int i = tid; i < VB_LC * KGP1; i += 256) {
+        stage_rows<VB_NW>(X_c, DP1, x + (long)l0 * D, D, rows, VB_LC, tid);
+        for (int i = tid; i < VB_LC * KGP1; i += VB_NT) {
             const int r = i / KGP1, k = i - r * KGP1;
             A_c[i] = (r < rows && k < KG) ? Ab[(long)(l0 + r) * KG + k] : 0.f;
         }
-        for (int i = tid; i < VB_LC * (KP + 1); i += 256) dA_s[i] = 0.f;
+        for (int i = tid; i < VB_LC * (KP + 1); i += VB_NT) dA_s[i] = 0.f;
         __syncthreads();
         // dA[l][k] = sum_d X[l][d] dres[k][d]: each wave reduces a quarter of d, partial tiles meet in LDS
         {
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) pa[c][i] = 0.f;
-            const int dsteps = (Dt * 32) / 2, per = (dsteps + 3) / 4;
+            const int dsteps = (Dt * 32) / 2, per = (dsteps + VB_NW - 1) / VB_NW;
             for (int st = wave * per; st < min(dsteps, (wave + 1) * per); ++st) {
                 const int d = st * 2 + kk;
                 const float av = X_c[i31 * DP1 + d];
@@ -536,33 +539,37 @@ __global__ __launch_bounds__(256) void vlad_bwd_mfma_kernel(const float* __restr
                         atomicAdd(&dA_s[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * (KP + 1) + c * 32 + (lane & 31)], pa[c][r]);
         }
         __syncthreads();
-        if (tid < rows) {                                            // softmax backward of one row -> dscore
-            const float* arow = A_c + tid * KGP1;
-            const float* drow = dA_s + tid * (KP + 1);
+        {                                                            // softmax backward -> dscore: SIXTEEN lanes per row (32 rows x 16 = the block)
+            const int r = tid >> 4, q = tid & 15;
+            const float* arow = A_c + r * KGP1;
+            const float* drow = dA_s + r * (KP + 1);
             float t = 0.f;
-            for (int k = 0; k < K; ++k) t = fmaf(arow[k], drow[k] - cd[k], t);
-            float* ds = dscore + ((long)b * L + l0 + tid) * KG;
-            for (int k = 0; k < KG; ++k) ds[k] = arow[k] * ((k < K ? drow[k] - cd[k] : 0.f) - t);
+            for (int k2 = q; k2 < K; k2 += 16) t = fmaf(arow[k2], drow[k2] - cd[k2], t);
+            t += SAR_DPP_F(t, 0xB1); t += SAR_DPP_F(t, 0x4E); t += SAR_DPP_F(t, 0x141); t += SAR_DPP_F(t, 0x140);   // every lane: its 16-lane row's sum
+            if (r < rows) {
+                float* ds = dscore + ((long)b * L + l0 + r) * KG;
+                for (int k2 = q; k2 < KG; k2 += 16) ds[k2] = arow[k2] * ((k2 < K ? drow[k2] - cd[k2] : 0.f) - t);
+            }
         }
-        // dfeat[l][d] = sum_k A[l][k] dres[k][d]: d-tiles wave, wave+4; reduction over the K (padded) clusters
+        // dfeat[l][d] = sum_k A[l][k] dres[k][d]: d-tile `wave`; reduction over the K (padded) clusters
         {
-            f32x16 fa[2];
+            f32x16 fa[1];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 1; ++a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) fa[a][i] = 0.f;
             for (int k0 = 0; k0 < KP; k0 += 2) {
                 const float av = (k0 + kk) < K ? A_c[i31 * KGP1 + k0 + kk] : 0.f;
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    if ((wave + 4 * a) < Dt) fa[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dres[(k0 + kk) * DP1 + (wave + 4 * a) * 32 + i31], fa[a], 0, 0, 0);
+                for (int a = 0; a < 1; ++a)
+                    if ((wave + VB_NW * a) < Dt) fa[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dres[(k0 + kk) * DP1 + (wave + VB_NW * a) * 32 + i31], fa[a], 0, 0, 0);
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                if ((wave + 4 * a) < Dt)
+            for (int a = 0; a < 1; ++a)
+                if ((wave + VB_NW * a) < Dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int l = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), d = (wave + 4 * a) * 32 + (lane & 31);
+                        const int l = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), d = (wave + VB_NW * a) * 32 + (lane & 31);
                         if (l < rows && d < D) {
                             float* dst = dfeat + ((long)b * L + l0 + l) * D + d;
                             *dst = accumulate_dfeat ? *dst + fa[a][r] : fa[a][r];
@@ -615,7 +622,7 @@ extern "C" int sar_vlad_bwd_f32(const float* dout, const float* feat, const floa
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(vlad_bwd_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SAR_ELAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL(vlad_bwd_mfma_kernel, dim3(B, (L + VB_LC - 1) / VB_LC), dim3(256), ldsm, stream, dout, feat, A, centers, out, inv, dfeat, dscore, dcenters, L, D, K, KG, accumulate_dfeat);
+        hipLaunchKernelGGL(vlad_bwd_mfma_kernel, dim3(B, (L + VB_LC - 1) / VB_LC), dim3(VB_NT), ldsm, stream, dout, feat, A, centers, out, inv, dfeat, dscore, dcenters, L, D, K, KG, accumulate_dfeat);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
