@@ -82,7 +82,7 @@ __device__ __forceinline__ void load_cst8(const float* cst, int cs, int ch, int 
 // One 16-byte piece (eight channels) of a tensor: `h` from its (hi) plane; SAR_X3: `l` from the lo plane as well.  (Plain uint4 values,
 // never a struct of them: arrays of structs written in unrolled loops went to scratch.)
 __device__ __forceinline__ void pc_values(const uint4 h, const uint4 l, float (&f)[8]) {
-    if constexpr (X3) join8(h, l, f); else unpack8(h, f);
+    if constexpr (X3) f32x8_of(h, l, f); else unpack8(h, f);     // (SAR_X3: h, l = the two 16-byte pieces of eight fp32 elements)
 }
 // MODE 0: copy; 1: relu(x*scale+shift); 2: BatchNorm(+ReLU) backward  dx = scale*(dz - c2 - xhat*c3), dz = da*[z>0];
 // 3: mode 2 + a third tensor (the shortcut gradient of the residual block behind this BatchNorm).  fp32 in, fp32 out.
@@ -121,9 +121,9 @@ struct ConvP {
     const u16* x; const u16* x2; const u16* x3; const h16x8* wpk; const float* bias; const u16* res; u16* y;
     u16* side;                  // nullable: the fill transform T(x) written back to HBM (same shape as x) for the weight gradient
                                 // (SAR_X3: as ONE fp16 tensor, fp16(T(x) * side_scale))
-    u16* side2;                 // SAR_X3 only, nullable: T(x) as a plane pair (the materialised gradient of fill 3, which further convs read)
+    u16* side2;                 // SAR_X3 only, nullable: T(x) in the trunk's own format (the materialised gradient of fill 3, which further convs read)
     float side_scale;
-    unsigned xs, ys;            // SAR_X3: element offset of the lo plane of source-shaped (x, x2, x3, side2) / output-shaped (res, y, e_y) tensors
+                                // (SAR_X3: x, x2, x3, res, y, e_y, side2 are fp32 tensors -- trunk16.h -- behind the 2-byte pointer types of the other builds)
     int lplane;                 // SAR_X3: byte offset of the lo plane of the LDS patch
     int tmv;                    // output pixels a block OWNS (= its tile height, except the 32-pixel BR form on 16: SAR_X3 sources whose 32-pixel patch
                                 // does not fit the LDS -- the MFMA rows past tmv recompute the next block's pixels and are dropped)
@@ -268,7 +268,7 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
     const u16* __restrict__ x = p.x; const u16* __restrict__ x2 = p.x2; const u16* __restrict__ x3 = p.x3;
     u16* __restrict__ side = p.side; u16* __restrict__ side2 = p.side2;
     const int lg_pc = p.lg_pc, rs = p.rs;
-    const unsigned cw = (unsigned)p.cw, mg_cw = p.mg_cw, xs = p.xs;
+    const unsigned cw = (unsigned)p.cw, mg_cw = p.mg_cw;
     const unsigned pc = 1u << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch plane (the launcher allocates it)
     const unsigned rsub = udiv((unsigned)tid, mg_cw, cw), col = tid - rsub * cw, rpi = udiv((unsigned)NTHR, mg_cw, cw);   // row of the trip, column piece, rows per trip
@@ -291,10 +291,15 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
             own[j] = rt.y + own_col;                               // < TM: this block owns the source pixel
             lo[j] = in ? pr * rowbytes + lo_col : dummy;           // branch-free: pieces past the end land in a scratch slot
             const unsigned o = ok ? off[j] : 0u;
-            qh[j] = *reinterpret_cast<const uint4*>(x + o);
-            if constexpr (X3) ql[j] = *reinterpret_cast<const uint4*>(x + xs + o);
-            if constexpr (MODE >= 2) { q2h[j] = *reinterpret_cast<const uint4*>(x2 + o); if constexpr (X3) q2l[j] = *reinterpret_cast<const uint4*>(x2 + xs + o); }
-            if constexpr (MODE == 3) { q3h[j] = *reinterpret_cast<const uint4*>(x3 + o); if constexpr (X3) q3l[j] = *reinterpret_cast<const uint4*>(x3 + xs + o); }
+            if constexpr (X3) {                                    // fp32 tensors: elements o .. o+3 and o+4 .. o+7
+                qh[j] = ld16f(x, o); ql[j] = ld16f(x, o + 4);
+                if constexpr (MODE >= 2) { q2h[j] = ld16f(x2, o); q2l[j] = ld16f(x2, o + 4); }
+                if constexpr (MODE == 3) { q3h[j] = ld16f(x3, o); q3l[j] = ld16f(x3, o + 4); }
+            } else {
+                qh[j] = *reinterpret_cast<const uint4*>(x + o);
+                if constexpr (MODE >= 2) q2h[j] = *reinterpret_cast<const uint4*>(x2 + o);
+                if constexpr (MODE == 3) q3h[j] = *reinterpret_cast<const uint4*>(x3 + o);
+            }
         }
     };
     auto finish = [&]() __attribute__((always_inline)) {
@@ -306,8 +311,10 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
             {
                 float o[8];
                 uint4 rh, rl = z4;
-                if constexpr (MODE == 0) { rh = qh[j]; rl = ql[j]; if (do_side) pc_values(qh[j], ql[j], o); }      // (planes as they are; values only for the fp16 copy)
-                else {
+                if constexpr (MODE == 0) {
+                    if constexpr (X3) { pc_values(qh[j], ql[j], o); split8(o, rh, rl); }   // (fp32 in HBM: the LDS planes are split here)
+                    else rh = qh[j];
+                } else {
                     if constexpr (MODE == 1) xform<MODE>(qh[j], X3 ? ql[j] : z4, z4, z4, z4, z4, k, o);
                     else if constexpr (MODE == 2) xform<MODE>(qh[j], X3 ? ql[j] : z4, q2h[j], X3 ? q2l[j] : z4, z4, z4, k, o);
                     else xform<MODE>(qh[j], X3 ? ql[j] : z4, q2h[j], X3 ? q2l[j] : z4, q3h[j], X3 ? q3l[j] : z4, k, o);
@@ -318,7 +325,7 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
                 if (sd) {
                     if constexpr (X3) {
                         if (side != nullptr) nt_store16(side + off[j], pack8_half(o, p.side_scale));
-                        if (side2 != nullptr) { nt_store16(side2 + off[j], rh); nt_store16(side2 + xs + off[j], rl); }
+                        if (side2 != nullptr) st32f(side2, off[j], o, true);
                     } else nt_store16(side + off[j], rh);
                 }
             }
@@ -424,10 +431,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         for (int i = 0; i < RPT; ++i) {
             const unsigned m = min(m0 + rg + RG * i, M - 1);
             const size_t o = (size_t)m * p.Cout + c;
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) {
-                rv[i][pl] = p.res ? *reinterpret_cast<const unsigned*>(p.res + (size_t)pl * p.ys + o) : 0u;
-                yv[i][pl] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + (size_t)pl * p.ys + o) : 0u;
+            if constexpr (X3) {                                    // fp32 tensors: the column pair (c, c + 1) = eight bytes
+                const uint2 z2 = make_uint2(0u, 0u);
+                const uint2 r2 = p.res ? *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(p.res) + o) : z2;
+                const uint2 y2 = p.epi == 2 ? *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(p.e_y) + o) : z2;
+                rv[i][0] = r2.x; rv[i][NPL - 1] = r2.y; yv[i][0] = y2.x; yv[i][NPL - 1] = y2.y;
+            } else {
+                rv[i][0] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
+                yv[i][0] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
             }
         }
     };
@@ -671,24 +682,29 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + kk * (TM * TN) + row * TN + 2 * cp);
             a.x += a2.x; a.y += a2.y;
         }
-        float v0 = a.x + b0 + h_lo(rv[i][0]), v1 = a.y + b1 + h_hi(rv[i][0]);
-        if constexpr (X3) { v0 += h_lo(rv[i][NPL - 1]); v1 += h_hi(rv[i][NPL - 1]); }
-        unsigned pk, pkl = 0u;
-        if constexpr (X3) split2(v0, v1, pk, pkl); else pk = pack2(v0, v1);
+        float v0 = a.x + b0, v1 = a.y + b1;
+        if constexpr (X3) { v0 += __uint_as_float(rv[i][0]); v1 += __uint_as_float(rv[i][NPL - 1]); }
+        else { v0 += h_lo(rv[i][0]); v1 += h_hi(rv[i][0]); }
         if (m < M && (unsigned)row < TMV) {
-            __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
-            if constexpr (X3) __builtin_nontemporal_store(pkl, reinterpret_cast<unsigned*>(p.y + (size_t)p.ys + (size_t)m * p.Cout + c));
+            unsigned pk = 0u;
+            if constexpr (X3) {                                    // the fp32 pair as it is
+                typedef __attribute__((ext_vector_type(2))) float f2v;
+                __builtin_nontemporal_store(f2v{v0, v1}, reinterpret_cast<f2v*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.Cout + c));
+            } else {
+                pk = pack2(v0, v1);
+                __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
+            }
             // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
             // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
             if (p.epi == 1 || p.epi == 3) {
-                v0 = h_lo(pk); v1 = h_hi(pk);
-                if constexpr (X3) { v0 += h_lo(pkl); v1 += h_hi(pkl); }
+                if constexpr (!X3) { v0 = h_lo(pk); v1 = h_hi(pk); }
                 if (p.epi == 1) { s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
                 else { q10 += fix28(v0); q11 += fix28(v1); q20 += fix28(fminf(v0 * v0, 8.0e6f)); q21 += fix28(fminf(v1 * v1, 8.0e6f)); }
             }
             if (p.epi == 2) {
-                float y0 = h_lo(yv[i][0]), y1 = h_hi(yv[i][0]);
-                if constexpr (X3) { y0 += h_lo(yv[i][NPL - 1]); y1 += h_hi(yv[i][NPL - 1]); }
+                float y0, y1;
+                if constexpr (X3) { y0 = __uint_as_float(yv[i][0]); y1 = __uint_as_float(yv[i][NPL - 1]); }
+                else { y0 = h_lo(yv[i][0]); y1 = h_hi(yv[i][0]); }
                 const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
                 s10 += d0; s11 += d1; s20 += d0 * (y0 - mu0) * rs0; s21 += d1 * (y1 - mu1) * rs1;
             }
@@ -1174,11 +1190,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedPlans 
 // ---------------------------------------------------------------------------------------------------- BatchNorm passes
 // eight consecutive values of a 2-byte tensor at element e (SAR_X3: hi + lo plane, `ps` elements apart)
 __device__ __forceinline__ void load8(const u16* __restrict__ t, long e, long ps, float (&f)[8]) {
-    if constexpr (X3) join8(*reinterpret_cast<const uint4*>(t + e), *reinterpret_cast<const uint4*>(t + ps + e), f);
+    if constexpr (X3) f32x8_of(ld16f(t, e), ld16f(t, e + 4), f);   // (SAR_X3: an fp32 tensor; `ps` is unused)
     else unpack8(*reinterpret_cast<const uint4*>(t + e), f);
 }
 __device__ __forceinline__ void store8(u16* __restrict__ t, long e, long ps, const float (&f)[8]) {
-    if constexpr (X3) { uint4 h, l; split8(f, h, l); *reinterpret_cast<uint4*>(t + e) = h; *reinterpret_cast<uint4*>(t + ps + e) = l; }
+    if constexpr (X3) st32f(t, e, f);
     else *reinterpret_cast<uint4*>(t + e) = pack8(f);
 }
 // Residual-stream gradient: out = BN(+ReLU) backward of `dact` through the BatchNorm whose input was x (+ add).
@@ -1459,7 +1475,6 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     p.x = static_cast<const u16*>(src); p.x2 = static_cast<const u16*>(src2); p.x3 = static_cast<const u16*>(src3); p.wpk = static_cast<const h16x8*>(wpk);
     p.bias = bias; p.res = static_cast<const u16*>(res); p.y = static_cast<u16*>(y); p.side = static_cast<u16*>(side);
     p.side2 = static_cast<u16*>(side2); p.side_scale = side_scale != 0.f ? side_scale : 1.f;
-    p.xs = X3 ? (unsigned)((long)B * Hs * Ws * Cin) : 0u; p.ys = X3 ? (unsigned)((long)p.g.M * Cout) : 0u;
     p.fill = fill; if (fbn) p.fb = *fbn;
     p.epi = epi; p.e_bins = e_bins; p.e_y = static_cast<const u16*>(e_y); p.e_saved = e_saved;
     p.lg_pc = ilog2(Cin / 8); p.rs = Cin * 2 + 16;

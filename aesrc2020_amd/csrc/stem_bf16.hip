@@ -336,11 +336,8 @@ __global__ __launch_bounds__(256) void stem16_pool_kernel(const float* __restric
                 }
             const size_t o = (((size_t)n * g.Hp + i0 + pi) * g.Wp + pj) * C0 + CT * 32 + g4 * 4;
             const float v0 = __uint_as_float(k0 & ~15u), v1 = __uint_as_float(k1 & ~15u), v2 = __uint_as_float(k2 & ~15u), v3 = __uint_as_float(k3 & ~15u);
-            if constexpr (X3) {
-                unsigned h0, l0, h1, l1;
-                split2(v0, v1, h0, l0); split2(v2, v3, h1, l1);
-                *reinterpret_cast<uint2*>(pooled + o) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(pooled + (size_t)g.B * g.Hp * g.Wp * C0 + o) = make_uint2(l0, l1);
+            if constexpr (X3) {                                                      // the pooled map is an fp32 tensor (trunk16.h)
+                *reinterpret_cast<uint4*>(reinterpret_cast<float*>(pooled) + o) = make_uint4(k0 & ~15u, k1 & ~15u, k2 & ~15u, k3 & ~15u);
                 if (pooled_h != nullptr) *reinterpret_cast<uint2*>(pooled_h + o) = make_uint2(wpack2(v0, v1), wpack2(v2, v3));
             } else {
                 *reinterpret_cast<uint2*>(pooled + o) = make_uint2(pack2(v0, v1), pack2(v2, v3));
@@ -394,10 +391,9 @@ __global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __res
     for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
         const size_t o = (size_t)pix * C0 + cv * 8;
         float a[8], gg[8];
-        if constexpr (X3) {                                                          // plane pairs, npix * C0 elements apart
-            const size_t ps = (size_t)npix * C0;
-            join8(*reinterpret_cast<const uint4*>(pooled + o), *reinterpret_cast<const uint4*>(pooled + ps + o), a);
-            join8(*reinterpret_cast<const uint4*>(gp + o), *reinterpret_cast<const uint4*>(gp + ps + o), gg);
+        if constexpr (X3) {                                                          // fp32 tensors
+            f32x8_of(ld16f(pooled, o), ld16f(pooled, o + 4), a);
+            f32x8_of(ld16f(gp, o), ld16f(gp, o + 4), gg);
         } else {
             unpack8(*reinterpret_cast<const uint4*>(pooled + o), a); unpack8(*reinterpret_cast<const uint4*>(gp + o), gg);
         }
@@ -461,7 +457,6 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
     unsigned char* scr = scr0 + wave * SCR;
     h16x8 wa[NT][4];
     f32x16 accw[2][NT];
-    const size_t pps = X3 ? (size_t)g.B * g.Hp * g.Wp * C0 : 0;                      // SAR_X3: elements between the planes of gp / pooled
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
@@ -511,33 +506,57 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
             auto scatter = [&]() __attribute__((always_inline)) {
                 uint4 pv[2], gv[2], gl[2]; uint2 iv[2];
                 // the gradient pair of channel k as the dz image takes it: the raw 16 bits; SAR_X3: fp16((hi + lo) * gs)
+                // (SAR_X3: gp and pooled are fp32 tensors: hq / lq = elements 0-3 / 4-7 of the eight)
                 auto gbits = [&](const uint4 hq, const uint4 lq, int k) __attribute__((always_inline)) -> unsigned {
                     const unsigned hs[4] = {hq.x, hq.y, hq.z, hq.w}, sh = 16 * (k & 1);
                     if constexpr (X3) {
                         const unsigned ls[4] = {lq.x, lq.y, lq.z, lq.w};
-                        const float v = ((k & 1) ? h_hi(hs[k >> 1]) + h_hi(ls[k >> 1]) : h_lo(hs[k >> 1]) + h_lo(ls[k >> 1])) * gs;
+                        const float v = __uint_as_float(k < 4 ? hs[k & 3] : ls[k & 3]) * gs;
                         return (unsigned)__builtin_bit_cast(unsigned short, (w16)v);
                     } else return (hs[k >> 1] >> sh) & 0xffffu;
+                };
+                // which of the eight pooled values are positive (>= 0 always: non-zero magnitude bits), one bit each
+                auto pmask = [&](const uint4 a, const uint4 b) __attribute__((always_inline)) -> unsigned {
+                    if constexpr (X3) {
+                        const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        unsigned m = 0u;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) m |= ((w[k] & 0x7fffffffu) != 0u ? 1u : 0u) << k;
+                        return m;
+                    } else {
+                        const unsigned w[4] = {a.x, a.y, a.z, a.w};
+                        unsigned m = 0u;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) m |= ((((w[k >> 1] >> (16 * (k & 1))) & 0x7fffu) != 0u) ? 1u : 0u) << k;
+                        return m;
+                    }
                 };
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int it = min(tid + 256 * u, nitems - 1), cg = it & 3, pp = it >> 2;
                     const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
-                    pv[u] = *reinterpret_cast<const uint4*>(pooled + o); gv[u] = *reinterpret_cast<const uint4*>(gp + o);
-                    if constexpr (X3) gl[u] = *reinterpret_cast<const uint4*>(gp + pps + o); else gl[u] = gv[u];
+                    if constexpr (X3) {
+                        const uint4 pa = ld16f(pooled, o), pb = ld16f(pooled, o + 4);
+                        gv[u] = ld16f(gp, o); gl[u] = ld16f(gp, o + 4);
+                        pv[u] = make_uint4(pmask(pa, pb), 0u, 0u, 0u);
+                    } else {
+                        pv[u] = *reinterpret_cast<const uint4*>(pooled + o); gv[u] = *reinterpret_cast<const uint4*>(gp + o);
+                        gl[u] = gv[u];
+                        pv[u] = make_uint4(pmask(pv[u], pv[u]), 0u, 0u, 0u);
+                    }
                     iv[u] = *reinterpret_cast<const uint2*>(idx + o);
                 }
                 for (int it0 = tid + 512; it0 < nitems; it0 += 256) {               // tiles with more than 512 items (wide inputs): one at a time
                     const int cg = it0 & 3, pp = it0 >> 2;
                     const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
-                    const uint4 p1 = *reinterpret_cast<const uint4*>(pooled + o), g1 = *reinterpret_cast<const uint4*>(gp + o);
-                    const uint4 g1l = X3 ? *reinterpret_cast<const uint4*>(gp + pps + o) : g1;
+                    uint4 g1, g1l; unsigned pm;
+                    if constexpr (X3) { g1 = ld16f(gp, o); g1l = ld16f(gp, o + 4); pm = pmask(ld16f(pooled, o), ld16f(pooled, o + 4)); }
+                    else { const uint4 p1 = *reinterpret_cast<const uint4*>(pooled + o); g1 = *reinterpret_cast<const uint4*>(gp + o); g1l = g1; pm = pmask(p1, p1); }
                     const uint2 i1 = *reinterpret_cast<const uint2*>(idx + o);
                     const int wi = pp / g.Wp, wj = pp - wi * g.Wp;
-                    const unsigned ps[4] = {p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = gbits(g1, g1l, k);
+                        const unsigned sh = 16 * (k & 1), pz = (pm >> k) & 1u, gz = gbits(g1, g1l, k);
                         const int slot = ((k < 4 ? i1.x : i1.y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
                         const int r = 2 * (i_lo + wi) - g.ppt + kh - r0, c = 2 * wj - g.ppl + kw;
                         if (pz != 0u && r >= 0 && r < nr) {
@@ -549,13 +568,13 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                 for (int u = 0; u < 2; ++u) {
                     const int it = tid + 256 * u, cg = it & 3, pp = it >> 2;
                     const int wi = (int)udiv((unsigned)pp, g.mg_wp, (unsigned)g.Wp), wj = pp - wi * g.Wp;
-                    const unsigned ps[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+                    const unsigned pm = pv[u].x;                                    // (the positivity bits of the eight pooled values)
                     const int rb = 2 * (i_lo + wi) - g.ppt - r0, cbase = 2 * wj - g.ppl;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         // pooled >= 0 always (ReLU): positive <=> non-zero magnitude bits.  (A branch-free form -- misses add 0 to a dummy
                         // word -- doubled the phase: it is the LDS atomics that cost, not the branches.)
-                        const unsigned sh = 16 * (k & 1), pz = (ps[k >> 1] >> sh) & 0x7fffu, gz = gbits(gv[u], gl[u], k);
+                        const unsigned sh = 16 * (k & 1), pz = (pm >> k) & 1u, gz = gbits(gv[u], gl[u], k);
                         const int slot = ((k < 4 ? iv[u].x : iv[u].y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
                         const int r = rb + kh, c = cbase + kw;
                         if (it < nitems && pz != 0u && r >= 0 && r < nr) {

@@ -114,15 +114,20 @@ __device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo
     for (int j = 0; j < 8; ++j) r[j] = f[j] - h[j];
     lo = pack8(r);
 }
-__device__ __forceinline__ void join8(const uint4 hi, const uint4 lo, float (&f)[8]) {
-    float l[8];
-    unpack8(hi, f); unpack8(lo, l);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] += l[j];
+// SAR_X3, the HBM side (r4 v9): the trunk's activations and gradients are fp32 TENSORS -- the four bytes per element a (hi, lo) pair of bf16
+// planes took.  A producer stores what it has; the consumer's fill splits once, for the LDS planes the MFMAs read (the planes in HBM cost
+// a split in every epilogue and a join + split in every fill: 24 of a 16-byte piece's ~150 instructions, 24 per epilogue thread -- and a
+// block's life IS its instruction count).  Eight consecutive elements = two 16-byte pieces.
+__device__ __forceinline__ void f32x8_of(const uint4 a, const uint4 b, float (&f)[8]) {
+    f[0] = __uint_as_float(a.x); f[1] = __uint_as_float(a.y); f[2] = __uint_as_float(a.z); f[3] = __uint_as_float(a.w);
+    f[4] = __uint_as_float(b.x); f[5] = __uint_as_float(b.y); f[6] = __uint_as_float(b.z); f[7] = __uint_as_float(b.w);
 }
-// one 32-bit word of each plane (two neighbouring elements) <-> two fp32 values
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = pack2(a, b); lo = pack2(a - h_lo(hi), b - h_hi(hi));
+__device__ __forceinline__ uint4 ld16f(const u16* t, size_t e) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(t) + e); }   // four fp32 at element e
+__device__ __forceinline__ void st32f(u16* t, size_t e, const float (&f)[8], bool nt = false) {                                                          // eight fp32 at element e
+    typedef __attribute__((ext_vector_type(4))) float f4v;
+    f4v* d = reinterpret_cast<f4v*>(reinterpret_cast<float*>(t) + e);
+    const f4v a = {f[0], f[1], f[2], f[3]}, b = {f[4], f[5], f[6], f[7]};
+    if (nt) { __builtin_nontemporal_store(a, d); __builtin_nontemporal_store(b, d + 1); } else { d[0] = a; d[1] = b; }
 }
 // eight values times `scale` as IEEE fp16 (whatever this build's 2-byte type is): the weight-gradient operands of the SAR_X3 build
 __device__ __forceinline__ uint4 pack8_half(const float (&f)[8], float scale) {

@@ -209,13 +209,15 @@ class ResNetTrunk(Layer):
             # split precision on the 2-byte kernels exists for the widths those kernels take (32: the reference's train.py:54; 64: SAR_Net's own
             # default, model.py:204); other widths run the fp32-storage kernels -- the same fp32-class arithmetic on round 1's kernels
             dt = "fp32"
-        # `x3`: split precision (csrc/trunk16.h SAR_X3): every 2-byte tensor is a (hi, lo) pair of bf16 planes -- shape (2, ...) -- and the
-        # operands only the weight gradients read are single fp16 tensors (gradients times the static scale of the fp16 build)
+        # `x3`: split precision (csrc/trunk16.h SAR_X3): the trunk's activations / gradients are fp32 tensors in HBM (r4 v9; before: a (hi, lo)
+        # pair of bf16 planes -- the same bytes), split into hi / lo bf16 operands by the conv fills; the operands only the weight gradients
+        # read are single fp16 tensors (gradients times the static scale of the fp16 build)
         self.x3 = dt == "bf16x3"
         self.bf16, self.half = dt in ("bf16", "fp16", "bf16x3"), dt == "fp16"
         self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("x3", torch.bfloat16) if self.x3 else ("bf16", torch.bfloat16)
         self.wsfx = "f16" if self.x3 else self.sfx                           # build whose weight-gradient kernels run
         self.t_side = torch.float16 if self.x3 else self.t16                 # the tensors the fills write back for them
+        self.t_act = torch.float32 if self.x3 else self.t16                  # activations / gradients of the residual stream in HBM
         self._gscale_cfg = _lib.get_trunk_gscale() if (self.half or self.x3) else 1.0      # 0: automatic, 64 x batch (_set_gscale)
         self.gscale = self.ginv = 1.0
         self.det = self.bf16 and _lib.get_bn_deterministic()                 # forward BatchNorm sums in 64-bit fixed point (SAR_BN_DET=1)
@@ -321,8 +323,8 @@ class ResNetTrunk(Layer):
             off = bn.prepare16(self._arena, off, self.det)
 
     def _buf16(self, key, shape):
-        """A 2-byte activation / gradient tensor of the trunk (split precision: its plane pair, shape (2, ...))."""
-        return self.buf(key, ((2,) + tuple(shape)) if self.x3 else shape, self.t16)
+        """An activation / gradient tensor of the trunk: the build's 2-byte type; split precision: fp32."""
+        return self.buf(key, shape, self.t_act)
 
     def _side16(self, key, shape):
         """An operand only the weight gradients read (the fills write it back): the trunk's 2-byte type; split precision: ONE fp16 tensor."""
@@ -400,7 +402,7 @@ class ResNetTrunk(Layer):
             H, W = self.out_hw
             fb = self.final_bn
             R = B * H * W
-            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), ((2,) if x3 else ()) + (B, H, W, self.out_c), self.t16)
+            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_act)
             g16 = self.scratch("res16_g16_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_side) if x3 else g
             # the gradient enters the trunk here: fp32 sums and constants, the result times the fp16 build's gradient scale (1 for bf16)
             _call("sar_bn_bwd_reduce_" + self.sfx, dy, 1, self.pre_final, fb.saved, fb.bbins, R, self.out_c, 1)
@@ -432,7 +434,7 @@ class ResNetTrunk(Layer):
             # conv2: operand a1 = relu(bn2(c1)) (written back by the forward fill); its input gradient da2 leaves the two sums of
             # bn2's backward in bn2.bbins
             red = []
-            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), ((2,) if x3 else ()) + (B, H2, W2, cout), bf)
+            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), self.t_act)
             if pend is None:
                 blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
             else:

@@ -111,9 +111,9 @@ def conv_roofline(model, B, iters=10, in_step=None):
         R1, R2 = B * H * W, B * H2 * W2
         bn1, bn2, c1v, c2v, scv = blk["bn1"], blk["bn2"], blk["conv1"], blk["conv2"], blk["sc"]
         x, c1 = blk["x"], blk["c1"]
-        pl = (2,) if x3t else ()                                        # split precision: (hi, lo) planes; the lo plane of random data is noise of the right size
-        rnd = lambda *s: (torch.randn(*(pl + s), device="cuda") * (torch.tensor([1.0, 2.0 ** -9], device="cuda").view(2, 1, 1, 1, 1) if x3t else 1.0)).to(BF)
-        emp = lambda *s: torch.empty(*(pl + s), device="cuda", dtype=BF)
+        ACT = torch.float32 if x3t else BF                               # split precision: the residual stream is fp32 in HBM
+        rnd = lambda *s: torch.randn(*s, device="cuda").to(ACT)
+        emp = lambda *s: torch.empty(*s, device="cuda", dtype=ACT)
         sde = lambda *s: torch.empty(*s, device="cuda", dtype=tr.t_side)   # what the fills write back for the weight gradients
         bins = lambda c: torch.zeros(_lib.bn_bins() * 2 * c, device="cuda")
         g, da2, res = rnd(B, H2, W2, cout), rnd(B, H2, W2, cout), rnd(B, H2, W2, cout)

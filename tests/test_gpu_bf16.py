@@ -18,7 +18,7 @@ BF, SFX = torch.bfloat16, "bf16"
 TOL_BF, TOL_F32 = 4e-3, 1e-3
 
 
-X3 = False                                                           # the split-precision build: every 2-byte tensor a (hi, lo) pair of bf16 planes
+X3 = False                                                           # the split-precision build: fp32 tensors in HBM, (hi, lo) bf16 operands in the kernels
 
 
 @pytest.fixture(scope="module", autouse=True, params=["bf16", "fp16", "x3"])
@@ -29,8 +29,9 @@ def two_byte_type(request):
     the reference's max-abs."""
     global BF, SFX, TOL_BF, X3
     old = (BF, SFX, TOL_BF, X3)
-    # "x3" (round 4, the package default): the split-precision build (entry points sar_*_x3) -- a stored tensor is hi + lo, 2^-17 relative; the
-    # conv forward / input-gradient tests run in it on every shape (its weight gradients are the fp16 build's: those tests skip).
+    # "x3" (round 4, the package default): the split-precision build (entry points sar_*_x3) -- tensors are fp32 in HBM, an MFMA operand is
+    # hi + lo of what the fill produced, 2^-17 relative; the conv forward / input-gradient tests run in it on every shape (its weight gradients
+    # are the fp16 build's: those tests skip).
     BF, SFX, TOL_BF, X3 = {"fp16": (torch.float16, "f16", 5e-4, False), "bf16": (torch.bfloat16, "bf16", 4e-3, False),
                            "x3": (torch.bfloat16, "x3", 3e-5, True)}[request.param]
     yield request.param
@@ -62,16 +63,13 @@ def rbf(a):
 
 
 def dbf(a):
-    """-> the device tensor of the build under test (split precision: the plane pair, shape (2, ...))."""
+    """-> the device tensor of the build under test (split precision: fp32)."""
     t = torch.tensor(np.ascontiguousarray(a), dtype=torch.float32)
-    hi = t.to(BF)
-    if X3:
-        return torch.stack([hi, (t - hi.float()).to(BF)]).cuda()
-    return hi.cuda()
+    return t.cuda() if X3 else t.to(BF).cuda()
 
 
 def empty16(*shape):
-    return torch.empty(*(((2,) if X3 else ()) + tuple(shape)), dtype=BF, device="cuda")
+    return torch.empty(*shape, dtype=torch.float32 if X3 else BF, device="cuda")
 
 
 def side16(shape):
@@ -94,8 +92,7 @@ def dev(a):
 
 
 def val(t):
-    v = t.detach().float().cpu().double().numpy()
-    return v[0] + v[1] if (X3 and t.dtype == torch.bfloat16) else v   # (split precision: every bf16 tensor of these tests is a plane pair)
+    return t.detach().float().cpu().double().numpy()
 
 
 def check(got, ref, tol, name):
@@ -448,7 +445,7 @@ def test_conv_and_its_shortcut_in_one_launch(L, B, H, W, Cin, Cout):
         _, _, pt_, pl_ = cv.geo(H, W)
         return (x, None, None, cv.wf, bias, None, y, None, B, H, W, Cin, ho, wo, Cout, cv.k, 2, 1, pt_, pl_, 0, None, 1 if bins is not None else 0, bins, None, None) + x3_tail()
 
-    mk = lambda: torch.full(((2,) if X3 else ()) + (B, ho, wo, Cout), 7.0, dtype=BF, device="cuda")
+    mk = lambda: torch.full((B, ho, wo, Cout), 7.0, dtype=torch.float32 if X3 else BF, device="cuda")
     y3a, y1a, y3b, y1b = mk(), mk(), mk(), mk()
     binsa, binsb = torch.zeros(L.bn_bins(), 2, Cout, device="cuda"), torch.zeros(L.bn_bins(), 2, Cout, device="cuda")
     L.call("sar_conv2d_" + SFX, *fwd_args(c3, y3a, bias3, binsa)); L.call("sar_conv2d_" + SFX, *fwd_args(c1, y1a, bias1, None))
@@ -469,7 +466,7 @@ def test_conv_and_its_shortcut_in_one_launch(L, B, H, W, Cin, Cout):
         _, _, pt_, pl_ = cv.geo(H, W)
         return (g, None, None, cv.wd, None, None, dx, None, B, ho, wo, Cout, H, W, Cin, cv.k, 1, 2, cv.k - 1 - pt_, cv.k - 1 - pl_, 0, None, 0, None, None, None) + x3_tail()
 
-    mkx = lambda: torch.full(((2,) if X3 else ()) + (B, H, W, Cin), 7.0, dtype=BF, device="cuda")
+    mkx = lambda: torch.full((B, H, W, Cin), 7.0, dtype=torch.float32 if X3 else BF, device="cuda")
     d3a, d1a, d3b, d1b = mkx(), mkx(), mkx(), mkx()
     L.call("sar_conv2d_" + SFX, *dgrad_args(c3, d3a)); L.call("sar_conv2d_" + SFX, *dgrad_args(c1, d1a))
     paired = L.conv_pair(L.ConvArgs.of(*dgrad_args(c3, d3b)), L.ConvArgs.of(*dgrad_args(c1, d1b)), SFX)
@@ -581,15 +578,14 @@ def test_gradient_scale_enters_at_the_final_batchnorm_and_leaves_with_the_parame
 def test_casts(L):
     rng = np.random.default_rng(0)
     a = rng.standard_normal(8 * 1000 + 8).astype(np.float32)
-    if X3:                                                           # planes + (nullable) the fp16 copy times a scale; back: hi + lo
+    if X3:                                                           # the trunk's format is fp32: a copy + (nullable) the fp16 copy times a scale
         y = empty16(a.size); y16 = side16((a.size,))
         L.call("sar_cast_f32_x3", dev(a), y, y16, 4.0, a.size)
-        hi = torch.tensor(a).to(BF)
-        assert torch.equal(y[0].cpu(), hi) and torch.equal(y[1].cpu(), (torch.tensor(a) - hi.float()).to(BF))
+        assert torch.equal(y.cpu(), torch.tensor(a))
         assert torch.equal(y16.cpu(), (torch.tensor(a) * 4.0).to(torch.float16))
         z = torch.empty(a.size, device="cuda")
         L.call("sar_cast_x3_f32", y, z, a.size)
-        assert torch.equal(z.cpu(), y[0].cpu().float() + y[1].cpu().float())
+        assert torch.equal(z.cpu(), torch.tensor(a))
         return
     y = torch.empty(a.size, dtype=BF, device="cuda")
     L.call("sar_cast_f32_" + SFX, dev(a), y, a.size)

@@ -121,9 +121,8 @@ def test_bf16_trunk_block_by_block_against_oracle(res_type, B, T, mode):
     torch.cuda.synchronize()
     P = {r.name: r.w.detach().cpu().double().numpy() for r in store.refs}
     G = {r.name: r.g.detach().cpu().double().numpy() for r in store.refs}
-    def val(t):                                                     # (split precision: a 2-byte tensor of the trunk is its plane pair, shape (2, ...))
-        v = t.detach().float().cpu().double().numpy()
-        return v[0] + v[1] if (X3 and t.dtype == BF and t.dim() == 5) else v
+    def val(t):                                                     # (split precision: the trunk's tensors are fp32)
+        return t.detach().float().cpu().double().numpy()
     errs = {}
 
     def chk(name, got, ref, tol):
