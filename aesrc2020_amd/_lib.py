@@ -111,7 +111,7 @@ def get_gemm_math():
 
 # ---- activation storage of the conv trunk: "fp32" (round-1 kernels, conv math per set_conv_math), "bf16" / "fp16" (conv_bf16.hip:
 # 2-byte activations / activation gradients, single-pass MFMA, fp32 statistics and weights) or "bf16x3" (the same kernels in split
-# precision, csrc/trunk16.h SAR_X3: every 2-byte tensor a (hi, lo) pair of bf16 planes, three MFMAs per product block -- the
+# precision, csrc/trunk16.h SAR_X3: fp32 trunk tensors in HBM, every conv operand a (hi, lo) pair of bf16 planes in LDS, three MFMAs per product block -- the
 # fp32-class mode that holds north_star's 1e-3).  Read when a model is built.
 # The package default (round 4): "bf16x3" for the trunk AND the GEMMs -- what a SAR_Net(...) built by the reference's train.py runs in: outputs
 # within north_star's 1e-3 of the fp32 graph (measured ~1e-4) at 0.6x the step time of the fp32-storage kernels.  Widths the 2-byte kernels

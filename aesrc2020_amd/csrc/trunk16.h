@@ -18,10 +18,11 @@ typedef __attribute__((ext_vector_type(2))) short s16x2;
 // SAR_X3 -- split precision on the round-3 kernel architecture.  north_star wants logits within 1e-3 of the reference's fp32 graph
 // (model.py:197, resnet.py:113-122); single-pass 2-byte operands measure 6e-3 (fp16) / 2e-2 (bf16), and tools/recipe_emulator.py shows that
 // no partial recipe (exact weights, fp32 storage, ...) gets below 1.7e-3: BOTH operands of every trunk conv need fp32-class mantissas.  So
-// every 2-byte tensor of the trunk becomes a PAIR OF PLANES, hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits; the lo plane follows the
-// hi plane of the same allocation), and a product block is three MFMAs, lo*hi + hi*lo + hi*hi into one fp32 accumulator (the dropped lo*lo
-// term is 2^-18 relative).  Producers split once -- the epilogue of a conv, the fill's BatchNorm transform, the weight packing -- consumers
-// read planes: no conversion in any k-loop.  Operands that only the weight gradients read (the activated tensors the fills write back, the
+// every MFMA operand of the trunk is a PAIR OF PLANES, hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits), and a product block is three
+// MFMAs, lo*hi + hi*lo + hi*hi into one fp32 accumulator (the dropped lo*lo term is 2^-18 relative).  In HBM the trunk's activations and
+// gradients are fp32 tensors (r4 v9; until then they were plane pairs as well, the same bytes: every epilogue split, every fill joined,
+// transformed and split again); the conv fill splits what it has transformed into the two LDS planes of the patch, the weight packing
+// splits the kernels into interleaved hi / lo fragments: no conversion in any k-loop.  Operands that only the weight gradients read (the activated tensors the fills write back, the
 // BatchNorm-backward tensors) are kept as ONE fp16 tensor instead (gradient operands times the static scale the fp16 build uses), and the
 // weight gradients run the fp16 build's single-pass kernels on them: 2^-12 per product on a sum of ~10^5 products, far inside the 5e-3 the
 // parity tests allow a gradient tensor, at half the bytes of planes.

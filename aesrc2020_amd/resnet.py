@@ -124,7 +124,7 @@ class _Conv:
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
     def _x3_tail(self, side2, side_scale):
-        """sar_conv2d_x3's two extra arguments: the fill's result as a plane pair (side2), the scale of its fp16 copy (side)."""
+        """sar_conv2d_x3's two extra arguments: the fill's result as an fp32 tensor (side2), the scale of its fp16 copy (side)."""
         return (side2, float(side_scale)) if self.sfx == "x3" else ()
 
     def fwd16_args(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None, side2=None, side_scale=1.0):
@@ -395,7 +395,7 @@ class ResNetTrunk(Layer):
     def _backward16(self, dy, part):
         B = self.B
         x3 = self.x3
-        # split precision: the gradient stream (g, da, dsc: plane pairs) is in TRUE units; only the fp16 copies the weight gradients read
+        # split precision: the gradient stream (g, da, dsc: fp32 tensors) is in TRUE units; only the fp16 copies the weight gradients read
         # (g16, dc1) carry the static scale, which their descriptors' ginv undoes.  fp16 build: the whole stream is scaled.
         gi = 1.0 if x3 else self.ginv
         if part in (None, 0, "01"):
@@ -439,7 +439,7 @@ class ResNetTrunk(Layer):
                 blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
             else:
                 p_da1, p_x, p_dsc, p_bn, p_R, p_tap = pend
-                if x3:                                                # g as planes (side2) for the convs, as scaled fp16 (side) for the weight gradients
+                if x3:                                                # g as fp32 (side2) for the convs, as scaled fp16 (side) for the weight gradients
                     blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True, gi), dy3=p_dsc, side=g16, side2=g,
                                          side_scale=self.gscale, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
                 else:
@@ -581,7 +581,7 @@ class ResNetTrunk(Layer):
 
     def _stem_forward16(self, x, B, st):
         if self.x3 and not self.STEM_X3:
-            # (SAR_STEM_X3=0, for A/B runs) round 1's fp32 stem (full-resolution map), its pooled map cast to planes + the fp16 copy the first
+            # (SAR_STEM_X3=0, for A/B runs) round 1's fp32 stem (full-resolution map), its pooled map copied + the fp16 copy the first
             # block's weight gradients read
             p32 = self._stem_forward(x, B)
             Hp, Wp = self.pool_hw; c0 = self.stem.cout

@@ -97,7 +97,7 @@ def conv_roofline(model, B, iters=10, in_step=None):
         c["time"] += secs; c["flops"] += flops; c["bytes"] += alg; c["design_bytes"] += design; c["launches"] += 1
 
     bf16 = getattr(tr, "bf16", False)
-    x3t = getattr(tr, "x3", False)                                     # split precision: plane pairs (4 bytes per element), fp16 side tensors
+    x3t = getattr(tr, "x3", False)                                     # split precision: fp32 tensors (4 bytes per element), fp16 side tensors
     eb = 2.0 if (bf16 and not x3t) else 4.0
     wg = []
     def bf16_block(blk, nxt_bn1):
@@ -233,7 +233,7 @@ def conv_roofline(model, B, iters=10, in_step=None):
             traffic, tsrc = pj[key]["traffic_bytes"], pj[key].get("source", pj["source"])
     except (OSError, ValueError, KeyError):
         pass
-    math = ("split precision: every trunk tensor a (hi, lo) pair of bf16 planes, 3 x v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate" if x3t else
+    math = ("split precision: fp32 trunk tensors in HBM, every conv operand a (hi, lo) pair of bf16 planes in LDS, 3 x v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate" if x3t else
             "single-pass fp16 MFMA (v_mfma_f32_32x32x16_f16), fp16 activations in HBM, fp32 accumulate" if getattr(tr, "half", False) else
             "single-pass bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM, fp32 accumulate" if bf16 else
             "bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate" if dom_x3 else
@@ -402,7 +402,7 @@ DTYPES = {
                                        "Dense / GRU-projection GEMMs), fp32 accumulate, statistics, recurrence, losses and master weights"),
     "fp16": ("fp16", "bf16x3", "bf16", "fp16 activations / activation gradients of the conv trunk in HBM (static gradient scale), single-pass fp16 MFMA in the "
                                        "convs; bf16 MFMA in the Dense / GRU-projection GEMMs; fp32 accumulate, statistics, recurrence, losses and master weights"),
-    "bf16x3": ("bf16x3", "bf16x3", "bf16x3", "split precision on the 2-byte kernel architecture: every trunk tensor a (hi, lo) pair of bf16 planes in HBM, three bf16 MFMAs per "
+    "bf16x3": ("bf16x3", "bf16x3", "bf16x3", "split precision on the 2-byte kernel architecture: fp32 trunk tensors in HBM, every conv operand a (hi, lo) pair of bf16 planes in LDS, three bf16 MFMAs per "
                                            "product block (2^-17 relative per operand) in the convs and the Dense / GRU-projection GEMMs, fp32 accumulate, statistics, losses and master weights; "
                                              "conv weight gradients and the GRU recurrence single-pass fp16"),
     "bf16x3_r1": ("fp32", "bf16x3", "fp32", "round 1's kernels: fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),

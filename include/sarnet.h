@@ -301,15 +301,16 @@ int sar_stem16_wgrad_f16(const float* x, const float* w, const float* bias, cons
                          int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
 
 /* ---- split-precision trunk (round 4; the fp32-class mode: north_star's "logits within 1e-3" of the reference's fp32 graph,
- * model.py:197, resnet.py:113-122): the SAME kernels compiled with -DSAR_X3 (csrc/trunk16.h).  Every 2-byte `void*` tensor of the
- * functions below is a PAIR OF bf16 PLANES, hi = bf16(x) and lo = bf16(x - hi), the lo plane following the hi plane of the same
- * allocation (n elements each); a product block is three MFMAs (lo*hi + hi*lo + hi*hi), weights are packed as interleaved hi / lo
- * fragments.  Arguments and semantics are those of the _bf16 function of the same name, except:
+ * model.py:197, resnet.py:113-122): the SAME kernels compiled with -DSAR_X3 (csrc/trunk16.h).  Every `void*` activation / gradient
+ * tensor of the functions below is an FP32 tensor (r4 v9; before: a pair of bf16 planes, the same bytes); the conv fill splits every
+ * transformed operand into hi = bf16(x) and lo = bf16(x - hi) for the LDS planes the MFMAs read, a product block is three MFMAs
+ * (lo*hi + hi*lo + hi*hi), weights are packed as interleaved hi / lo fragments.  Arguments and semantics are those of the _bf16 function
+ * of the same name, except:
  *   sar_conv2d_x3: `side` is ONE fp16 tensor = fp16(T(src) * side_scale) -- the operand of the weight gradient, which this mode runs
  *     through sar_conv2d_wgrad_batch_f16 (gradient operands carry the fp16 build's static scale, sarWgradConv.ginv undoes it) -- and
- *     side2 (nullable) receives T(src) as a plane pair (the materialised block gradient of fill 3, which further convs read);
- *   sar_bn_bwd_apply_x3: `out` is a plane pair in TRUE units, out16 (nullable) = fp16(result * out_scale);
- *   sar_cast_f32_x3: y a plane pair, y16 (nullable) = fp16(x * scale). */
+ *     side2 (nullable) receives T(src) as fp32 (the materialised block gradient of fill 3, which further convs read);
+ *   sar_bn_bwd_apply_x3: `out` is fp32 in TRUE units, out16 (nullable) = fp16(result * out_scale);
+ *   sar_cast_f32_x3: y = x (a copy), y16 (nullable) = fp16(x * scale). */
 int sar_conv_pack_weights_x3(const void* table, int n, int total_blocks, sarStream_t stream);
 int sar_conv_pack_weights_zero_x3(const void* table, int n, int total_blocks, const void* zero_table, int nz, sarStream_t stream);
 int sar_conv2d_x3(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
@@ -325,8 +326,8 @@ int sar_bn_apply_x3_f32(const void* x, const sarBnRef* bn, float* out, long R, i
 int sar_cast_f32_x3(const float* x, void* y, void* y16, float scale, long n, sarStream_t stream);
 int sar_cast_x3_f32(const void* x, float* y, long n, sarStream_t stream);
 /* The recompute-form stem in split precision: the 7x7 conv is evaluated with hi / lo planes of the input patch and of the kernel fragments
- * (three MFMAs per block) wherever its output is needed.  pooled: a plane pair; pooled_h (nullable): the same map as ONE fp16 tensor, the
- * operand of the first residual block's weight gradients.  sar_stem16_wgrad_x3: g_pooled a plane pair in true units; the final product
+ * (three MFMAs per block) wherever its output is needed.  pooled: fp32; pooled_h (nullable): the same map as ONE fp16 tensor, the
+ * operand of the first residual block's weight gradients.  sar_stem16_wgrad_x3: g_pooled fp32 in true units; the final product
  * dW = im2col^T dy runs single-pass on fp16 operands that carry the scale 1 / bn->ginv (bn->ginv: applied to dW only; the BatchNorm's own
  * parameter gradients come from the true-unit sums of sar_stem16_bwd_reduce_x3). */
 int sar_stem16_stats_x3(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
