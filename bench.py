@@ -142,23 +142,23 @@ def conv_roofline(model, B, iters=10, in_step=None):
 
         fb1 = bn1.ref(R1, "saved", False) if bn1 is not None else None
         add_l(lambda: inst(c1v, cin, cout), timed(lambda: c1v.fwd16(x, y, B, fill=1 if bn1 is not None else 0, fbn=fb1, e_bins=b1, side=a if bn1 is not None else None)),
-            fl(c1v), by(c1v, (x.numel() if bn1 is not None else 0) // len(pl + (1,))))
+            fl(c1v), by(c1v, (x.numel() if bn1 is not None else 0)))
         add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
-            fl(c2v), by(c2v, 2 * c1.numel() // len(pl + (1,))))
+            fl(c2v), by(c2v, 2 * c1.numel()))
         if nxt_bn1 is None:                                         # last block: its gradient comes materialised from the final BatchNorm
-            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel() // len(pl + (1,))))
+            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
         else:                                                       # fill 3: the block behind hands over (da1, x, shortcut gradient)
             xn = rnd(B, H2, W2, cout)
             s3 = dict(side=g16, side2=y, side_scale=tr.gscale) if x3t else dict(side=y)
             add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res,
-                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved, **s3)), fl(c2v), by(c2v, 4 * c1.numel() // len(pl + (1,))))
+                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved, **s3)), fl(c2v), by(c2v, 4 * c1.numel()))
         if bn1 is not None:
             add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
-                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, (2 * c1.numel() + x.numel()) // len(pl + (1,))))
+                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, (2 * c1.numel() + x.numel())))
         else:
             r1 = rnd(B, H, W, cin)
             add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
-                fl(c1v), by(c1v, (2 * c1.numel() + x.numel()) // len(pl + (1,))))
+                fl(c1v), by(c1v, (2 * c1.numel() + x.numel())))
         if scv is not None:
             add_l(lambda: inst(scv, cin, cout), timed(lambda: scv.fwd16(x, y, B)), fl(scv), by(scv))
             add_l(lambda: inst(scv, cout, cin), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv))
