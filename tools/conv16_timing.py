@@ -29,7 +29,7 @@ else:
 lib.sar_dbg_set_timing_buffer16.argtypes = [vp]
 BF = torch.bfloat16
 NPL = 2 if X3 else 1
-planes = lambda t: torch.stack([t.to(BF), (t - t.to(BF).float()).to(BF)]) if X3 else t.to(BF)
+planes = lambda t: t.float().contiguous() if X3 else t.to(BF)            # split precision: the trunk's tensors are fp32 in HBM
 mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 B = int(os.environ.get("CB", 64))
 SHAPES = [("s0 3x3 32->32", 100, 20, 32, 32, 3), ("s1 3x3 64->64", 50, 10, 64, 64, 3), ("s2 3x3 128->128", 25, 5, 128, 128, 3),
@@ -37,7 +37,7 @@ SHAPES = [("s0 3x3 32->32", 100, 20, 32, 32, 3), ("s1 3x3 64->64", 50, 10, 64, 6
 st = torch.cuda.current_stream().cuda_stream
 for name, H, W, Cin, Cout, k in SHAPES:
     x = planes(torch.randn(B, H, W, Cin, device="cuda")); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
-    y = torch.zeros(*(((2,) if X3 else ()) + (B, H, W, Cout)), device="cuda", dtype=BF); dw = torch.zeros_like(w)
+    y = torch.zeros(B, H, W, Cout, device="cuda", dtype=torch.float32 if X3 else BF); dw = torch.zeros_like(w)
     taps = k * k
     nf = (Cout // 32) * (NPL * taps * Cin // 16 + 8) * 512; nd = (Cin // 32) * (NPL * taps * Cout // 16 + 8) * 512
     wf = torch.zeros(nf, dtype=BF, device="cuda"); wd = torch.zeros(nd, dtype=BF, device="cuda")
