@@ -498,6 +498,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     TSTAMP(14);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // raw barrier (no vmcnt drain): row table (and constants) complete
     wg_barrier();
+#ifdef SAR_TIMING_PROBE
+    TSTAMP(8);
+#endif
     if constexpr (!MIDFILL) TSTAMP(2);
     auto mid = [&]() __attribute__((always_inline)) {
         if constexpr (MIDFILL) {
@@ -562,7 +565,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         lda(0);
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
+#ifndef SAR_TIMING_PROBE
             if (i == NF / 2) TSTAMP(8);
+#endif
             if (i + NF0 < NF) load_b(i + NF0);                     // the stream stays NF0 k-steps ahead
             if (i + 1 < NF) lda(i + 1);
             if constexpr (!X3) {
@@ -610,7 +615,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
                     if (st == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     wg_barrier();
                     if (st == 0) { TSTAMP(4); load_afrags(0, a_lane); }
+#ifndef SAR_TIMING_PROBE
                     if (st == NST / 2) TSTAMP(8);
+#endif
                     if (RD == 4) { if (st + 3 < NST) issue_stage(st + 3, (st + 3) & 3); }
                     else if (st + 2 < NST) issue_stage(st + 2, (st + 2) % 3);
                     const int slot = RD == 4 ? (st & 3) : (st % 3);

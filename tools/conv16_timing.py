@@ -65,7 +65,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
                                          0, None, 1, bins.data_ptr(), None, None, st)
     if mode != "wgrad":
-        names = {"  entry->epi loads": (1, 11), "  ->dma issued": (11, 12), "  ->row table": (12, 13), "  ->bn prologue": (13, 14), "  ->barrier": (14, 2),
+        names = {"  entry->epi loads": (1, 11), "  ->dma issued": (11, 12), "  ->row table": (12, 13), "  ->bn prologue": (13, 14), "  ->barrier": (14, 2), "  (probe build: 14 -> first barrier passed)": (14, 8), "  (probe build: -> constants done)": (8, 2),
                  "prologue": (1, 2), "fill": (2, 3), "  k first half": (4, 8), "fill sync": (3, 4), "k-phase": (4, 5), "  epi: loads + barrier": (5, 10), "  epi: staging + barrier": (10, 9), "  epi: row pass": (9, 6), "epilogue": (5, 6), "stats": (6, 7), "total": (1, 7)}
     tb = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
     for it in range(3):
