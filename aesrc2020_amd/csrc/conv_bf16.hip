@@ -518,7 +518,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // not the round trip; and holding the pieces across the prologue puts the narrow layers past 170 registers.)
     // fill pieces per thread in flight (eight waves, two blocks per CU: 128 registers).  (Eight in the BR forms, to cover the fill's loads in
     // one round trip: 2.626 vs 2.594 ms per split-precision step, same box, 300-step runs -- the registers cost more than the round trip.)
-    constexpr int FU = NG == 8 ? 2 : 4;
+    constexpr int FU = (NG == 8 || X3) ? 2 : 4;                    // (SAR_X3: two 32-byte pieces are what four 16-byte ones were; 2.254 vs 2.259 ms)
     // ---- fill: the padded patch, all input channels, transformed once
     if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
     else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
