@@ -56,7 +56,7 @@ constexpr int NPL = X3 ? 2 : 1;  // planes per 2-byte tensor
 typedef __attribute__((ext_vector_type(8))) h16 h16x8;
 typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 
-constexpr int NB = 16;          // statistic bins per BatchNorm (fp32 atomics; contention = blocks / 16 per address)
+constexpr int NB = 32;          // statistic bins per BatchNorm (fp32 atomics; contention = blocks / 32 per address; r4 v9: 8 / 16 / 32 = 2.257 / 2.253 / 2.233 ms per step)
 constexpr int CMAX = 512;       // max channels of a BatchNorm / conv side
 
 #if SAR_HALF
@@ -303,42 +303,56 @@ __device__ __forceinline__ void bn_prologue_coop(const BnP& bn, int mode, int C,
 // cycles) runs underneath the row table, the fill's address arithmetic and the round trip of the fill's own first loads: bn_issue requests
 // this thread's share of the bins into registers at kernel entry, bn_finish (called by the fill behind the issue of its first pieces) sums,
 // meets the other groups in LDS and writes the constants.  G = 1 (a channel per thread and no spare threads) loads late, in bn_finish.
-// (floats: sums 1 in a, sums 2 in b; 64-bit integers: sums 1 as pairs in a then b, sums 2 in c then d.  Forward and backward bins are never
-// both read by one launch.)
+// (floats: sums 1 in a then b, sums 2 in c then d -- up to 16 bins per thread; 64-bit integers: sums 1 as pairs in a then b, sums 2 in c then d
+// -- up to 8 bins per thread, more are read late, in bn_sum_g.  Forward and backward bins are never both read by one launch.)
 typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
 struct BnRaw { u32x8 a, b, c, d; };   // (vector VALUES, not arrays: nothing an alloca could be made of.)  v[0..7] = a, v[8..15] = b, v[16..23] = c, v[24..31] = d
 // (ONE float path for the forward and the backward bins -- the base pointer is selected, not the code: with two look-alike branches the
 // optimiser sank their stores into one with a selected ARRAY INDEX, and `r` went to scratch)
 template <int G>
 __device__ __forceinline__ void bn_issue_g(const BnP& bn, int mode, bool fwd_bins, int C, int c, int q, BnRaw& r) {
+    static_assert(NB / G <= 16, "BnRaw holds sixteen bins per thread");
     if (fwd_bins && bn.det) {
-        const long long* qp = reinterpret_cast<const long long*>(bn.bins);
+        if constexpr (NB / G <= 8) {
+            const long long* qp = reinterpret_cast<const long long*>(bn.bins);
 #pragma unroll
-        for (int b = 0; b < NB / G; ++b) {
-            const uint2 t1 = *reinterpret_cast<const uint2*>(qp + ((q + b * G) * 2) * C + c), t2 = *reinterpret_cast<const uint2*>(qp + ((q + b * G) * 2 + 1) * C + c);
-            if (b < 4) { r.a[2 * b] = t1.x; r.a[2 * b + 1] = t1.y; r.c[2 * b] = t2.x; r.c[2 * b + 1] = t2.y; }
-            else { r.b[2 * b - 8] = t1.x; r.b[2 * b - 7] = t1.y; r.d[2 * b - 8] = t2.x; r.d[2 * b - 7] = t2.y; }
+            for (int b = 0; b < NB / G; ++b) {
+                const uint2 t1 = *reinterpret_cast<const uint2*>(qp + ((q + b * G) * 2) * C + c), t2 = *reinterpret_cast<const uint2*>(qp + ((q + b * G) * 2 + 1) * C + c);
+                if (b < 4) { r.a[2 * b] = t1.x; r.a[2 * b + 1] = t1.y; r.c[2 * b] = t2.x; r.c[2 * b + 1] = t2.y; }
+                else { r.b[2 * b - 8] = t1.x; r.b[2 * b - 7] = t1.y; r.d[2 * b - 8] = t2.x; r.d[2 * b - 7] = t2.y; }
+            }
         }
     } else {
         const float* src = mode == 2 ? bn.bbins : bn.bins;
 #pragma unroll
-        for (int b = 0; b < NB / G; ++b) { r.a[b] = __float_as_uint(src[((q + b * G) * 2) * C + c]); r.b[b] = __float_as_uint(src[((q + b * G) * 2 + 1) * C + c]); }
+        for (int b = 0; b < NB / G; ++b) {
+            const unsigned v1 = __float_as_uint(src[((q + b * G) * 2) * C + c]), v2 = __float_as_uint(src[((q + b * G) * 2 + 1) * C + c]);
+            if (b < 8) { r.a[b & 7] = v1; r.c[b & 7] = v2; } else { r.b[b & 7] = v1; r.d[b & 7] = v2; }
+        }
     }
 }
 template <int G>
 __device__ __forceinline__ void bn_sum_g(const BnP& bn, int mode, bool fwd_bins, int C, int c, int q, const BnRaw& r, double* scr) {
     if (fwd_bins && bn.det) {
         long long q1 = 0, q2 = 0;
+        if constexpr (NB / G <= 8) {
 #pragma unroll
-        for (int b = 0; b < NB / G; ++b) {
-            if (b < 4) { q1 += (long long)(((unsigned long long)r.a[2 * b + 1] << 32) | r.a[2 * b]); q2 += (long long)(((unsigned long long)r.c[2 * b + 1] << 32) | r.c[2 * b]); }
-            else { q1 += (long long)(((unsigned long long)r.b[2 * b - 7] << 32) | r.b[2 * b - 8]); q2 += (long long)(((unsigned long long)r.d[2 * b - 7] << 32) | r.d[2 * b - 8]); }
+            for (int b = 0; b < NB / G; ++b) {
+                if (b < 4) { q1 += (long long)(((unsigned long long)r.a[2 * b + 1] << 32) | r.a[2 * b]); q2 += (long long)(((unsigned long long)r.c[2 * b + 1] << 32) | r.c[2 * b]); }
+                else { q1 += (long long)(((unsigned long long)r.b[2 * b - 7] << 32) | r.b[2 * b - 8]); q2 += (long long)(((unsigned long long)r.d[2 * b - 7] << 32) | r.d[2 * b - 8]); }
+            }
+        } else {                                                    // (more 64-bit bins than BnRaw holds: read here)
+            const long long* qb = reinterpret_cast<const long long*>(bn.bins);
+#pragma unroll
+            for (int b = 0; b < NB / G; ++b) { q1 += qb[((q + b * G) * 2) * C + c]; q2 += qb[((q + b * G) * 2 + 1) * C + c]; }
         }
         reinterpret_cast<long long*>(scr)[(q * 2) * C + c] = q1; reinterpret_cast<long long*>(scr)[(q * 2 + 1) * C + c] = q2;
     } else {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int b = 0; b < NB / G; ++b) { s1 += (double)__uint_as_float(r.a[b]); s2 += (double)__uint_as_float(r.b[b]); }
+        for (int b = 0; b < NB / G; ++b) {
+            s1 += (double)__uint_as_float(b < 8 ? r.a[b & 7] : r.b[b & 7]); s2 += (double)__uint_as_float(b < 8 ? r.c[b & 7] : r.d[b & 7]);
+        }
         const int o = mode == 2 ? 2 * G : 0;
         scr[(o + q * 2) * C + c] = s1; scr[(o + q * 2 + 1) * C + c] = s2;
     }
