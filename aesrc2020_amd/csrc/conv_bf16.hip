@@ -352,7 +352,7 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
 // 32-channel layers since round 3 where two such blocks fit a CU.
 // SAR_X3: the stream interleaves the hi and the lo fragment of every 16-channel block (fragment 2f, 2f + 1), a ring stage is four such
 // pairs, and a k-step is three MFMAs: lo x hi, hi x lo, hi x hi.
-constexpr int BR_PD = X3 ? 2 : 8;    // BR form: k-steps of weight fragments in flight ahead of the MFMA that consumes them (single-plane builds: 4-16 measured: +-1 %; SAR_X3, two fragments a step, r4 v9: 1 / 2 / 3 / 4 / 6 = 2.461 / 2.306 / 2.323 / 2.336 / 2.350 ms per step)
+constexpr int BR_PD = X3 ? 2 : 4;    // BR form: k-steps of weight fragments in flight ahead of the MFMA that consumes them: FOUR fragments either way (r4 v10, per step: SAR_X3, two fragments a k-step, 1 / 2 / 3 / 4 / 6 steps = 2.461 / 2.306 / 2.323 / 2.336 / 2.350 ms; fp16 build 2 / 4 / 8 = 1.944 / 1.873 / 1.881 ms)
 // BR ("B in registers", round 3; the 64+-channel sources with 64+ output channels: stages 1-3): the block is still 64 pixels x 64 channels,
 // but its waves are 2 channel halves x KG k-groups, a wave owns BOTH 32-pixel halves of its 32 channels (two accumulators) on a 1/KG share
 // of every tap's channels (two fragments per virtual tap), and its weight fragments -- which no other wave of the block needs -- come
