@@ -256,12 +256,15 @@ extern "C" int sar_ctc_batch_cost_fwd_f32(const float* probs, const float* label
     float* ews = alpha + (size_t)B * L * Smax;
     float* logden = ews + (size_t)B * L * Smax;
     const size_t lds = sizeof(float) * (size_t)L * Smax;
-    static PerDeviceFlag attr;
-    if (lds > 48 * 1024 && lds <= CTC_LDS_CAP && !attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_LDS_CAP) != hipSuccess) return SAR_ELAUNCH;
-        attr = true;
+    // LDS-resident recursion up to CTC_LDS_CAP; where the device refuses that much dynamic LDS (a partition with less than gfx950's 160 KB,
+    // or static arrays that have grown) the shape falls back to the workspace kernel instead of failing
+    static PerDeviceFlag attr, refused;
+    if (lds > 48 * 1024 && lds <= CTC_LDS_CAP && !attr && !refused) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_LDS_CAP) != hipSuccess) {
+            (void)hipGetLastError(); refused = true;
+        } else attr = true;
     }
-    if (lds <= CTC_LDS_CAP)
+    if (lds <= 48 * 1024 || (lds <= CTC_LDS_CAP && attr))
         hipLaunchKernelGGL(ctc_fwd_kernel<true>, dim3(B), dim3(CTC_NT), lds, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
     else
         hipLaunchKernelGGL(ctc_fwd_kernel<false>, dim3(B), dim3(CTC_NT), 0, stream, probs, labels, in_len, lab_len, loss, alpha, logden, ews, L, V, max_label_len, Smax);
@@ -281,12 +284,15 @@ extern "C" int sar_ctc_batch_cost_bwd_f32(const float* probs, const float* label
     const float* ews = alpha + (size_t)B * L * Smax;
     const float* logden = ews + (size_t)B * L * Smax;
     const size_t lds = 2 * sizeof(float) * (size_t)L * Smax;
-    static PerDeviceFlag attr;
-    if (lds > 48 * 1024 && lds <= CTC_LDS_CAP && !attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_LDS_CAP) != hipSuccess) return SAR_ELAUNCH;
-        attr = true;
+    // LDS-resident recursion up to CTC_LDS_CAP; where the device refuses that much dynamic LDS (a partition with less than gfx950's 160 KB,
+    // or static arrays that have grown) the shape falls back to the workspace kernel instead of failing
+    static PerDeviceFlag attr, refused;
+    if (lds > 48 * 1024 && lds <= CTC_LDS_CAP && !attr && !refused) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CTC_LDS_CAP) != hipSuccess) {
+            (void)hipGetLastError(); refused = true;
+        } else attr = true;
     }
-    if (lds <= CTC_LDS_CAP)
+    if (lds <= 48 * 1024 || (lds <= CTC_LDS_CAP && attr))
         hipLaunchKernelGGL(ctc_bwd_kernel<true>, dim3(B), dim3(CTC_NT), lds, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);
     else
         hipLaunchKernelGGL(ctc_bwd_kernel<false>, dim3(B), dim3(CTC_NT), 0, stream, probs, labels, in_len, lab_len, loss, dloss, alpha, logden, ews, dprobs, L, V, max_label_len, Smax);

@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
                                                                     // without l2_loss nothing else orders those reads in front of the ticket)
         if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {   // every block has read the iteration count
             *ticket = 0u;
-            if (skip) { ticket[2] += 1u; ticket[3] = 0u; }          // a skipped step: nothing advances
-            else { st->lr_t = lr_t; st->iterations += 1; }
+            if (skip) { ticket[2] += 1u; ticket[3] = 0u; ticket[4] += 1u; }   // a skipped step: nothing advances
+            else { st->lr_t = lr_t; st->iterations += 1; ticket[4] = 0u; }   // [4]: skipped steps IN A ROW (an applied step resets it)
         }
     }
 }
@@ -163,9 +163,11 @@ extern "C" int sar_grads_check_f32(const float* grads, void* ticket, long n, hip
     return SAR_OK;
 }
 
-// sar_adam_prepare + sar_adam_l2_step_f32 in ONE launch.  `ticket`: FOUR 32-bit words the caller owns, zero-initialised: [0] the block ticket
+// sar_adam_prepare + sar_adam_l2_step_f32 in ONE launch.  `ticket`: EIGHT 32-bit words the caller owns, zero-initialised: [0] the block ticket
 // (zero again when the launch has finished), [1] the caller's switch "loss-scaling guard on" (modes with fp16 operands), [2] how many steps
-// were skipped so far because a gradient was not finite, [3] the flag sar_grads_check_f32 sets (cleared here).
+// were skipped so far because a gradient was not finite, [3] the flag sar_grads_check_f32 sets (cleared here), [4] how many steps IN A ROW
+// were skipped (reset by every applied step: what "the training has diverged" is decided on -- a host that looks once per epoch cannot tell
+// consecutive from scattered skips by the total), [5..7] spare.
 extern "C" int sar_adam_l2_update_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                                       void* state, void* ticket, float* l2_loss, long n, hipStream_t stream) {
     if (!params || !grads || !m || !v || !chunk_l2 || !state || !ticket || (n % 256)) return SAR_EINVAL;

@@ -43,6 +43,10 @@ class ParamStore:
         self.bufs = Buffers(device)
         self.layers = []              # construction order; drives summary()/get_layer()
         self.training = True          # Keras learning phase: False = BatchNorm uses its moving averages (predict/evaluate)
+        # power-of-two exponent (<= 0) applied on top of the static gradient scale of the fp16 operands (64 x batch): lowered by the model when
+        # a step overflowed, raised again after 2 000 clean steps (dynamic loss scaling at the cadence of the host's log reads: no per-step
+        # sync).  Per store (as a class attribute models shared it until the first write) and part of save() / load_weights().
+        self.gscale_shift = 0
 
     def register_layer(self, layer):
         self.layers.append(layer)
@@ -194,13 +198,17 @@ class ParamStore:
         if self.__dict__.get("_adam_ticket") is not None:
             self._adam_ticket[1] = 1 if on else 0
 
-    # power-of-two exponent (<= 0) applied on top of the static gradient scale of the fp16 operands (64 x batch): lowered by the model when
-    # a step overflowed, raised again after 2 000 clean steps (dynamic loss scaling at the cadence of the host's log reads: no per-step sync)
-    gscale_shift = 0
-
     def skipped_steps(self):
         t = self.__dict__.get("_adam_ticket")
         return 0 if t is None else int(t[2].item())
+
+    def skip_counters(self):
+        """(steps skipped in all, steps skipped IN A ROW up to the last one run): one 8-word read of the optimiser's ticket block."""
+        t = self.__dict__.get("_adam_ticket")
+        if t is None:
+            return 0, 0
+        h = t.cpu()
+        return int(h[2]), int(h[4])
 
     dropped_gradient_elements = skipped_steps                                # (round 3's name, kept for callers)
 
@@ -215,7 +223,7 @@ class ParamStore:
         self._zeroed_this_step = False                                       # the step is over: later forwards (evaluate) zero for themselves
         self._zero_table_sync()                                              # buffers registered during this (eager) step join the table now
         if self.__dict__.get("_adam_ticket") is None:
-            self._adam_ticket = torch.zeros(4, dtype=torch.int32, device=self.params.device)      # [ticket, guard switch, dropped count, spare]
+            self._adam_ticket = torch.zeros(8, dtype=torch.int32, device=self.params.device)      # [ticket, guard switch, skipped, flag, skipped in a row, spare x3]
             if self.__dict__.get("_adam_guard", False):
                 self._adam_ticket[1] = 1
         if self.__dict__.get("_adam_guard", False):                          # any non-finite gradient element -> the update below skips the step

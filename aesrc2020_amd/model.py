@@ -101,8 +101,11 @@ class SARNetModel:
                 print("======= ERROR: please specify cnn in res-[18,34,50,101,152] ======")
                 raise ValueError("res_type")
             self.trunk = fn[c["res_type"]](inputs, filters=c["res_filters"])
-            if getattr(self.trunk, "half", False) or getattr(self.trunk, "x3", False):
-                self.store.set_adam_guard(True)                   # fp16 activation gradients can overflow: see csrc/optim.hip
+            if getattr(self.trunk, "half", False) or getattr(self.trunk, "x3", False) or (H == 256 and _lib.get_gemm_math() == "bf16x3"):
+                # fp16 operands can overflow (csrc/optim.hip): the fp16 / split-precision trunk's activation gradients, and -- whatever the trunk
+                # runs on (res_filters off {32, 64}, SAR_TRUNK_DTYPE=fp32 / bf16) -- the fp16 MFMA recurrence the split-precision GEMM mode gives
+                # the Bi-GRUs at hidden_dim 256 (layers.BIGRU: msfx "f16")
+                self.store.set_adam_guard(True)
             Tp, Dp = self.trunk.out_hw
             self.L = Tp * Dp
             C = self.trunk.out_c
@@ -618,31 +621,35 @@ class SARNetModel:
     # raise -- the reference's Keras trainer would show a NaN loss there.
     MAX_CONSEC_SKIPS = 16
     GROW_AFTER = 2000
+    SKIP_POLL_EVERY = 64                                         # fit_generator: steps between two looks at the device's skip counters
 
     def _overflow_policy(self, logs=None):
         st = self.store
         if not st.__dict__.get("_adam_guard", False):
             return
         run = getattr(self, "_steps_run", 0)
-        skipped = st.skipped_steps()
-        seen, at = getattr(self, "_skips_seen", 0), getattr(self, "_skips_checked_at", 0)
-        new, steps = skipped - seen, run - at
-        self._skips_seen, self._skips_checked_at = skipped, run
+        skipped, in_a_row = st.skip_counters()                   # counted by the optimiser launch itself (csrc/optim.hip: ticket[2], ticket[4])
+        new = skipped - getattr(self, "_skips_seen", 0)
+        self._skips_seen = skipped
         if logs is not None:
             logs["nonfinite_steps_skipped"] = skipped
         if new > 0:
             import warnings
-            self._consec_skips = getattr(self, "_consec_skips", 0) + new if new >= steps else new
             self._clean_since = run
-            if self._consec_skips >= self.MAX_CONSEC_SKIPS:
+            # "in a row" is the DEVICE's word: a host that looks once per epoch / every SKIP_POLL_EVERY steps (fit_generator) cannot tell 16
+            # scattered skips from 16 consecutive ones by the total (the old host-side guess raised on any epoch with 16 skips,
+            # before the scale was ever lowered).  Every look that finds the run of skips still going on halves the scale; the training has
+            # diverged when MAX_CONSEC_SKIPS such looks in a row (= as many halvings) did not end it.
+            self._looks_in_run = getattr(self, "_looks_in_run", 0) + 1 if in_a_row > 0 else 0
+            if in_a_row >= self.MAX_CONSEC_SKIPS and self._looks_in_run >= self.MAX_CONSEC_SKIPS:
                 raise FloatingPointError("%d consecutive optimiser steps skipped: the gradient is not finite at gradient scale 2^%d x (64 x batch) "
-                                         "-- the training has diverged (the reference's Keras trainer would report a NaN loss)" % (self._consec_skips, st.gscale_shift))
+                                         "-- the training has diverged (the reference's Keras trainer would report a NaN loss)" % (in_a_row, st.gscale_shift))
             st.gscale_shift -= 1
             self.graph = None; self._eager_done = 0              # the scale is a kernel argument: the next step runs eagerly, the one after re-captures
             warnings.warn("%d optimiser step(s) skipped (%d in all): a gradient element was not finite; gradient scale of the fp16 operands halved "
                           "to 2^%d x (64 x batch)" % (new, skipped, st.gscale_shift), RuntimeWarning)
         else:
-            self._consec_skips = 0
+            self._looks_in_run = 0
             if st.gscale_shift < 0 and run - getattr(self, "_clean_since", 0) >= self.GROW_AFTER:
                 st.gscale_shift += 1; self._clean_since = run
                 self.graph = None; self._eager_done = 0
@@ -718,6 +725,7 @@ class SARNetModel:
         d = self.store.state_dict()
         d["__adam_m__"] = self.store.m.cpu().numpy(); d["__adam_v__"] = self.store.v.cpu().numpy()
         d["__adam_state__"] = self.store.adam_state.cpu().numpy()
+        d["__gscale_shift__"] = np.asarray([self.store.gscale_shift, self.store.skipped_steps()], np.int64)   # dynamic loss scale + skip count
         np.savez(path if str(path).endswith(".npz") else str(path) + ".npz", **d)
 
     def load_weights(self, path, by_name=True, skip_mismatch=True):
@@ -734,6 +742,13 @@ class SARNetModel:
             p = path if str(path).endswith(".npz") else str(path) + ".npz"
             d = dict(np.load(p))
         loaded, skipped = self.store.load_state_dict(d, by_name, skip_mismatch)
+        if "__gscale_shift__" in d:
+            # a resumed run starts at the gradient scale the saved one had worked its way down to, not at the full 64 x batch it would
+            # overflow at again; the scale is a kernel argument, so a captured step is dropped
+            shift = min(0, int(np.asarray(d["__gscale_shift__"]).ravel()[0]))
+            if shift != self.store.gscale_shift:
+                self.store.gscale_shift = shift
+                self.graph = None; self._eager_done = 0
         self.dp.broadcast_params()
         return loaded, skipped
 
@@ -777,6 +792,8 @@ class SARNetModel:
                 acc = vec.clone() if acc is None else acc.add_(vec)
                 if verbose > 1 and (step % log_every == 0):
                     print("  step %d/%d loss %.4f" % (step + 1, steps_per_epoch, float(vec[0].item())))
+                if (step + 1) % self.SKIP_POLL_EVERY == 0 and step + 1 < steps_per_epoch:
+                    self._overflow_policy()                      # one 32-byte read: an overflowing scale is halved within SKIP_POLL_EVERY steps, not at epoch end
             mean_dev = acc / steps_per_epoch
             if self.dp.enabled and self.dp.world > 1:
                 # every rank saw its own shard: the callbacks (ReduceLROnPlateau, EarlyStopping, checkpoints on 'loss' / 'acc') must decide

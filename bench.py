@@ -212,54 +212,72 @@ def conv_roofline(model, B, iters=10, in_step=None):
         name, dom = max(matched.items(), key=lambda kv: kv[1]["in_step_us"] * kv[1]["in_step_calls"])
     else:
         name, dom = max(classes.items(), key=lambda kv: kv[1]["time"])
-    ach_iso = dom["flops"] / dom["time"] / 1e12
-    t_launch = dom["in_step_us"] * 1e-6 if have_in_step else dom["time"] / dom["launches"]      # seconds per launch of the dominant class
-    ach = dom["flops"] / dom["launches"] / t_launch / 1e12
     x3 = (not bf16) and _lib.get_conv_math() == "bf16x3"
-    # which MFMA pipe the dominant class runs on: 2-byte trunk = single-pass MFMA; split precision (the x3 trunk, or fp32 storage with Cout --
-    # Cin for dgrad -- > 32): three bf16 MFMAs per product block, ceiling 2500 / 3; the rest of the fp32-storage kernels: fp32 MFMA
-    dom_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad"))
-    peak = PEAK_BF16X3_TFLOPS if dom_x3 else PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    # bound of the dominant class on this chip: time its algorithmic FLOPs need on the pipe vs its algorithmic bytes on HBM
-    t_mfma, t_hbm = dom["flops"] / (peak * 1e12), dom["bytes"] / (PEAK_HBM_GBS * 1e9)
-    bound = "mfma" if t_mfma >= t_hbm else "hbm"
-    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
-    # correction applied by tools/pmc_to_traffic.py); null when no measurement exists for this kernel class in this mode
-    traffic, tsrc = None, None
+    pj = {}
     try:
         pj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-        key = ("x3:" if x3t else "bf16:" if bf16 else "") + name
-        if key in pj:
-            traffic, tsrc = pj[key]["traffic_bytes"], pj[key].get("source", pj["source"])
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError):
         pass
+
+    def describe(name, c):
+        """One kernel class against the chip: `peak` is the GUIDE's peak for the operand type (2 500 TFLOP/s dense for bf16 / fp16 operands --
+        split precision issues three MFMAs per algorithmic product block, which is this design's cost, not a lower ceiling; VERDICT r4 item 8 --,
+        157.3 for fp32 MFMA, 8 000 GB/s HBM); `frac_of_issued_mfma` carries the pipe-utilisation figure (achieved / (2 500 / 3)) beside it."""
+        ach_iso = c["flops"] / c["time"] / 1e12
+        t_launch = c["in_step_us"] * 1e-6 if "in_step_us" in c else c["time"] / c["launches"]          # seconds per launch
+        ach = c["flops"] / c["launches"] / t_launch / 1e12
+        # which MFMA pipe the class runs on: 2-byte trunk = single-pass MFMA; split precision (the x3 trunk, or fp32 storage with Cout --
+        # Cin for dgrad -- > 32): three bf16 MFMAs per product block; the rest of the fp32-storage kernels: fp32 MFMA
+        is_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad"))
+        peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or is_x3) else PEAK_F32_MFMA_TFLOPS
+        pipe = PEAK_BF16X3_TFLOPS if is_x3 else peak                                               # what the issued MFMAs could deliver algorithmically
+        # bound of the class on this chip: time its algorithmic FLOPs need on the pipe vs its algorithmic bytes on HBM
+        t_mfma, t_hbm = c["flops"] / (pipe * 1e12), c["bytes"] / (PEAK_HBM_GBS * 1e9)
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
+        # correction applied by tools/pmc_to_traffic.py); null when no measurement exists for this kernel class in this mode
+        key = ("x3:" if x3t else "bf16:" if bf16 else "") + name
+        traffic = pj[key]["traffic_bytes"] if key in pj else None
+        tsrc = pj[key].get("source", pj.get("source")) if key in pj else None
+        per_launch_bytes = c["bytes"] / c["launches"]
+        if bound == "hbm":
+            ach_v, iso_v, peak_v, unit = per_launch_bytes / t_launch / 1e9, c["bytes"] / c["time"] / 1e9, PEAK_HBM_GBS, "GB/s"
+        else:
+            ach_v, iso_v, peak_v, unit = ach, ach_iso, peak, "TFLOP/s"
+        d = dict(bound=bound, kernel=name, achieved=round(ach_v, 2), peak=round(peak_v, 1), unit=unit, frac=round(ach_v / peak_v, 4),
+                 frac_isolated=round(iso_v / peak_v, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
+                 algorithmic_bytes=int(per_launch_bytes), design_bytes=int(c["design_bytes"] / c["launches"]),
+                 traffic_over_algorithmic=round(traffic / per_launch_bytes, 2) if traffic else None,
+                 launches_per_step=round(c.get("in_step_calls", c["launches"]), 2), avg_launch_us=round(t_launch * 1e6, 2),
+                 avg_launch_us_isolated=round(c["time"] / c["launches"] * 1e6, 2),
+                 us_per_step=round(c.get("in_step_calls", c["launches"]) * t_launch * 1e6, 1),
+                 achieved_tflops=round(ach, 2), algorithmic_hbm_gbs=round(per_launch_bytes / t_launch / 1e9, 1))
+        if is_x3:
+            d["frac_of_issued_mfma"] = round(ach / PEAK_BF16X3_TFLOPS, 4)
+        return d, ach, is_x3
+
+    d_dom, ach, dom_x3 = describe(name, dom)
+    t_launch = d_dom["avg_launch_us"] * 1e-6
     math = ("split precision: fp32 trunk tensors in HBM, every conv operand a (hi, lo) pair of bf16 planes in LDS, 3 x v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate" if x3t else
             "single-pass fp16 MFMA (v_mfma_f32_32x32x16_f16), fp16 activations in HBM, fp32 accumulate" if getattr(tr, "half", False) else
             "single-pass bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM, fp32 accumulate" if bf16 else
             "bf16x3 split-precision MFMA (3 x v_mfma_f32_32x32x16_bf16 per fp32 product block), fp32 accumulate" if dom_x3 else
             "fp32 MFMA (v_mfma_f32_32x32x2_f32)")
-    per_launch_bytes = dom["bytes"] / dom["launches"]
-    if bound == "hbm":
-        ach_v, iso_v, peak_v, unit = per_launch_bytes / t_launch / 1e9, dom["bytes"] / dom["time"] / 1e9, PEAK_HBM_GBS, "GB/s"
-    else:
-        ach_v, iso_v, peak_v, unit = ach, ach_iso, peak, "TFLOP/s"
+    # the other classes that carry the conv time, largest first -- among them the 32-channel (stage 0) class, HBM-bound by SURVEY 8d
+    ranked = sorted((matched if have_in_step else classes).items(), key=lambda kv: -(kv[1]["in_step_us"] * kv[1]["in_step_calls"] if have_in_step else kv[1]["time"]))
+    class_list = [describe(k, c)[0] for k, c in ranked[:6]]
     # SURVEY 8d: T_roof of the 36 non-stem convs = 3 x (52.9 - 8.7) us per train step at B=64, T=400 (bf16 activations, 2.5 PFLOP/s,
     # 8 TB/s); scaled by this workload's conv FLOPs (1.2263 GFLOP/utt forward for those 36 layers)
     all_flops = sum(c["flops"] for c in classes.values())
     t_roof_us = 132.6 * all_flops / (3 * 64 * 1.2263e9) if all_flops else None
     total_in_step = sum(v[0] * v[1] for v in conv_in_step.values()) if have_in_step else None
-    return dict(bound=bound, kernel=name, achieved=round(ach_v, 2), peak=round(peak_v, 1), unit=unit,
+    return dict(**d_dom,
                 # frac: the dominant class as it runs INSIDE the train step (measured live in this run, torch.profiler = roctracer kernel records;
                 # profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command); frac_isolated: L2-warm graph replays of the class alone
-                frac=round(ach_v / peak_v, 4), frac_isolated=round(iso_v / peak_v, 4),
                 frac_source="in-step, live (torch.profiler)" if have_in_step else "isolated graph replays (no in-step measurement in this run)",
-                traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)", traffic_source=tsrc,
-                algorithmic_bytes=int(per_launch_bytes), design_bytes=int(dom["design_bytes"] / dom["launches"]),
-                launches_per_step=dom["launches"],
-                avg_launch_us=round(t_launch * 1e6, 2), avg_launch_us_isolated=round(dom["time"] / dom["launches"] * 1e6, 2), math=math,
-                achieved_tflops=round(ach, 2), frac_of_bf16_dense_peak=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                math=math, frac_of_bf16_dense_peak=round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                 frac_of_fp32_mfma_peak=round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                algorithmic_hbm_gbs=round(per_launch_bytes / t_launch / 1e9, 1),
+                classes=class_list,
                 conv_classes={k: dict(us_per_step_isolated=round(v["time"] * 1e6, 1), tflops_isolated=round(v["flops"] / v["time"] / 1e12, 2), launches=v["launches"],
                                       **({"us_per_step": round(v["in_step_us"] * v["in_step_calls"], 1), "launches_in_step": round(v["in_step_calls"], 2),
                                           "avg_launch_us": round(v["in_step_us"], 2)} if "in_step_us" in v else {}))
@@ -368,21 +386,28 @@ def run_workload(name, args, rank, world, with_extras, batch=None):
         step(i)
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    # `--regions` consecutive timed regions of EXACTLY `--steps` steps each, every one bracketed by barrier + synchronize on both sides and
+    # reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region's (one 46 ms sample carries the box's
+    # clock state; the spread is reported next to it, config.ms_per_step_min / _max / regions)
+    region_dts = []
+    for _ in range(max(1, args.regions)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        region_dts.append(dt)
+    dt = float(np.median(region_dts))
     logs = train_model._logs()
     if not np.isfinite(logs["loss"]):                      # say where the non-finite value sits before giving up
         st_ = model.store
@@ -391,7 +416,7 @@ def run_workload(name, args, rank, world, with_extras, batch=None):
         raise AssertionError((name, args.dtype, B, logs, "l2_loss", float(st_.l2_loss.item()), "non-finite", diag, "gradients (name, non-finite, inf)", where[:8]))
     res = dict(value=round(world * B * args.steps / dt, 2), ms_per_step=round(dt / args.steps * 1e3, 4), workload=wl["desc"], B=B, T=T,
                params=model.count_params(), final_loss=round(logs["loss"], 4), kw=kw, input_shape=input_shape,
-               dropped=model.store.dropped_gradient_elements())      # fp16 operands: optimiser steps skipped because a gradient was not finite
+               dropped=model.store.dropped_gradient_elements(), regions_ms=[round(d / args.steps * 1e3, 4) for d in region_dts])      # fp16 operands: optimiser steps skipped because a gradient was not finite
     res["in_step"] = kernel_times_in_step(step) if (with_extras and rank == 0 and not args.no_graph and not args.no_roofline) else None
     return res, model
 
@@ -415,6 +440,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--regions", type=int, default=5, help="consecutive timed regions of --steps steps; the median region is reported")
     ap.add_argument("--settle", type=int, default=150, help="untimed set-up replays in front of the warm-up steps (clock ramp of an idle box)")
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))   # cfg2 = BASELINE configs[1]: the configuration the metric is quoted on
     ap.add_argument("--dtype", default=os.environ.get("SAR_BENCH_DTYPE", "bf16x3"), choices=list(DTYPES),
@@ -448,6 +474,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": r["workload"], "batch_per_gpu": r["B"], "global_batch": r["B"] * world, "frames": r["T"], "feat_dim": 80,
                        "parallelism": "dp%d" % world, "hip_graph": not args.no_graph, "settle_steps": max(args.settle, 0), "params": r["params"],
+                       "timed_regions": len(r["regions_ms"]), "ms_per_step_of_each_region": r["regions_ms"], "ms_per_step_min": min(r["regions_ms"]),
+                       "ms_per_step_max": max(r["regions_ms"]), "ms_per_step_is": "median over the timed regions of --steps steps each",
                        "conv_arithmetic": dtype_desc, "final_loss": r["final_loss"], "nonfinite_gradient_steps_skipped": r["dropped"],
                        # BASELINE configs[1] names bf16 for this workload and north_star bounds the outputs at 1e-3 of the reference's fp32 graph: the
                        # default is the mode that holds that bound (also.parity: ~5e-5); the single-pass bf16 / fp16 builds of the same kernels
@@ -513,7 +541,7 @@ def main():
                 set_dtype(dt)
                 ra, m2 = run_workload(name, args, rank, world, False, batch=batch)
                 also[key] = {"value": ra["value"], "unit": "utterances/sec", "ms_per_step": ra["ms_per_step"], "batch_per_gpu": ra["B"],
-                             "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"], "nonfinite_gradient_steps_skipped": ra["dropped"]}
+                             "ms_per_step_min": min(ra["regions_ms"]), "ms_per_step_max": max(ra["regions_ms"]), "frames": ra["T"], "dtype": dt, "workload": ra["workload"], "final_loss": ra["final_loss"], "nonfinite_gradient_steps_skipped": ra["dropped"]}
                 del m2
                 torch.cuda.empty_cache()
             others = [d for d in ("bf16x3", "bf16", "fp16") if d != args.dtype]

@@ -503,10 +503,11 @@ int sar_adam_prepare(void* state, sarStream_t stream);
 int sar_adam_l2_step_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2,
                          const void* state, float* l2_loss, long n, sarStream_t stream);
 /* sar_adam_prepare + sar_adam_l2_step_f32 in one launch (round 3): every block derives lr_t from the iteration count it finds, the last
- * block to finish advances it.  ticket: FOUR zero-initialised 32-bit words of the caller's: [0] the block ticket (zero again when the launch
+ * block to finish advances it.  ticket: EIGHT zero-initialised 32-bit words of the caller's: [0] the block ticket (zero again when the launch
  * has finished); [1] set by the caller to switch the loss-scaling guard on (the modes with fp16 operands: fp16 trunk, split-precision mode);
  * [2] the count of steps skipped so far; [3] the flag sar_grads_check_f32 sets when any gradient element is not finite (cleared by the update
- * launch).  With the guard on and the flag set the WHOLE update is skipped: weights, m, v and the iteration count stay as they are -- standard
+ * launch); [4] the count of steps skipped IN A ROW (an applied step resets it: what "diverged" is decided on); [5..7] spare.
+ * With the guard on and the flag set the WHOLE update is skipped: weights, m, v and the iteration count stay as they are -- standard
  * loss-scaling semantics; the host halves the gradient scale when it sees the counter move (model.SARModel). */
 int sar_grads_check_f32(const float* grads, void* ticket, long n, sarStream_t stream);
 int sar_adam_l2_update_f32(float* params, const float* grads, float* m, float* v, const float* chunk_l2, void* state, void* ticket,

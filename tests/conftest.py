@@ -9,6 +9,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Run order of the GPU suite: the driver runs `pytest -x`, so whatever fails first hides everything behind it.  Parity evidence
+# against the oracle / golden fixtures / upstream constants comes first, op level before whole graph, then the sweeps and the full-size
+# property tests, and the multi-process data-parallel tests (two replicas sharing one GPU) last.  Files not named keep their place in the middle.
+_ORDER = ["test_golden_cpu", "test_oracle_ops", "test_host_cpu",
+          "test_upstream_kat", "test_gpu_golden", "test_gpu_ops", "test_gpu_feeder", "test_gpu_stem16", "test_gpu_bf16.py", "test_gpu_bf16_trunk",
+          "test_gpu_model", "test_gpu_bf16_model", "test_gpu_config_sweep", "test_gpu_loss_scale", "test_gpu_fullsize", "test_gpu_convergence",
+          "test_gpu_dp"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        for i, key in enumerate(_ORDER):
+            if name == key or name == key + ".py":
+                return i if key != "test_gpu_dp" else len(_ORDER) + 1
+        return len(_ORDER)
+    items.sort(key=rank)                                             # stable: the order inside a file is the file's own
+
+
 @pytest.fixture(autouse=True)
 def _baseline_modes():
     """Every test starts from the fp32-storage trunk and fp32 GEMMs (round 1's kernels: the reference point the parity tests of every other

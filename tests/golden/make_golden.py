@@ -24,6 +24,13 @@ from oracle import model_torch as MT    # noqa: E402
 
 MODEL_KW = dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidden_dim=32, mto="gvlad", vlad_clusters=4,
                 ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=20, max_ctc_len=6, metric_loss="circleloss")
+# round 5: a second whole-graph fixture at the widths the SHIPPED kernels take (res_filters 32: csrc/conv_bf16.hip in split precision;
+# hidden_dim 256: the MFMA recurrence) -- model_golden.npz's res_filters 16 runs the fp32-storage kernels in every mode
+MODEL32_KW = dict(input_shape=[72, 80, 1], res_type="res18", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=6,
+                  ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=24, max_ctc_len=6, metric_loss="arcface")
+MODEL32_GRADS = ("conv2d_1/kernel", "conv2d_1/bias", "conv2d_3/kernel", "conv2d_7/kernel", "conv2d_8/kernel", "conv2d_18/bias", "batch_normalization_2/gamma", "batch_normalization_10/gamma", "batch_normalization_14/beta", "batch_normalization_9/beta",
+                 "CNN_LIN/bias", "CNN_LIN_LN/gamma", "CRNN/forward/bias", "CRNN/backward/bias", "CTC_BIGRU/backward/bias", "ctc_pred/bias", "gvlad_center_assignment/kernel",
+                 "gvlad_pool/centers", "AR_BN2/gamma", "y_accent/kernel", "y_disc/W")
 
 
 def ops_vectors():
@@ -76,10 +83,10 @@ def feeder_vectors():
                 sklearn_version=np.array(sklearn.__version__))
 
 
-def model_vectors():
-    cfg = MT.Cfg(**MODEL_KW)
+def model_vectors(kw=None, grads=None, B=3, batch_seed=11):
+    cfg = MT.Cfg(**(kw or MODEL_KW))
     net = MT.TorchSARNet(cfg, seed=0)
-    batch = MT.synthetic_batch(cfg, 3, seed=11)
+    batch = MT.synthetic_batch(cfg, B, seed=batch_seed)
     out, total, parts, G = net.forward_backward(batch)
     # the weights are regenerated from the seed by oracle init (numpy PCG64 streams are version-stable); the fixture keeps a
     # per-tensor checksum so RNG/initialiser drift is detected instead of silently changing the expectations
@@ -92,9 +99,9 @@ def model_vectors():
     for k, v in parts.items():
         d["loss/" + k] = np.array(float(v))
     # gradients are stored for a spread of layers (first conv ... heads), minus the L2 term
-    for k in ("conv2d_1/kernel", "conv2d_5/kernel", "batch_normalization_3/gamma", "CNN_LIN/kernel", "CRNN/forward/recurrent_kernel",
-              "CTC_BIGRU/backward/kernel", "ctc_pred/kernel", "gvlad_center_assignment/kernel", "gvlad_pool/centers",
-              "AR_EMBEDDING/kernel", "y_accent/kernel", "y_disc/kernel"):
+    for k in grads or ("conv2d_1/kernel", "conv2d_5/kernel", "batch_normalization_3/gamma", "CNN_LIN/kernel", "CRNN/forward/recurrent_kernel",
+                       "CTC_BIGRU/backward/kernel", "ctc_pred/kernel", "gvlad_center_assignment/kernel", "gvlad_pool/centers",
+                       "AR_EMBEDDING/kernel", "y_accent/kernel", "y_disc/kernel"):
         g = G[k].numpy() - (2 * MT.L2 * net.P[k].numpy() if k in net.reg else 0.0)
         d["grad/" + k] = g
     return d
@@ -104,5 +111,6 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "ops_golden.npz"), **ops_vectors())
     np.savez_compressed(os.path.join(HERE, "model_golden.npz"), **model_vectors())
     np.savez_compressed(os.path.join(HERE, "feeder_golden.npz"), **feeder_vectors())
-    for f in ("ops_golden.npz", "model_golden.npz"):
+    np.savez_compressed(os.path.join(HERE, "model32_golden.npz"), **model_vectors(MODEL32_KW, MODEL32_GRADS, B=4, batch_seed=12))
+    for f in ("ops_golden.npz", "model_golden.npz", "model32_golden.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

@@ -42,6 +42,14 @@ CASES = {
     # res_filters = 64 (SAR_Net's own default, model.py:204; round 3): 64 / 128 / 256 / 512 channels, the 512-channel stage on 32-pixel tiles
     "res34_f64_gvlad": dict(input_shape=[136, 80, 1], res_type="res34", res_filters=64, hidden_dim=32, mto="gvlad", vlad_clusters=4,
                             ghost_clusters=1, disc_enable=True, metric_loss="cosface", B=4),
+    # BASELINE configs[4] reduced (round 5): a long utterance (520 frames -> L = 17 x 3 = 51), GhostVLAD with 64 + 2 clusters
+    # (the 66-column assignment GEMM, the 128-column instantiation of the VLAD MFMA kernels, a 16 384-wide AR_BN1 / AR_EMBEDDING), ArcFace
+    "cfg5_k64_long": dict(input_shape=[520, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=64,
+                          ghost_clusters=2, disc_enable=True, metric_loss="arcface", B=2),
+    # configs[2] at the reference's own vocabulary and label width (train.py:22-23,52: bpe1k, max_ctc_len = 72) and hidden_dim 256 (the MFMA
+    # recurrence; ctc_pred's 1000-column GEMM and softmax; labels 4..10 long padded with 2 to 72 columns, blank = 999)
+    "cfg3_bpe1k": dict(input_shape=[200, 80, 1], res_type="res18", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8, ghost_clusters=2,
+                       disc_enable=True, ctc_enable=True, bpe_classes=1000, max_ctc_len=72, metric_loss="circleloss", B=4),
 }
 
 

@@ -37,23 +37,47 @@ SWEEP = [
 ]
 
 
-@pytest.fixture
-def conv_math(request):
-    from aesrc2020_amd import _lib
-    old = _lib.get_conv_math()
-    _lib.set_conv_math(request.param)
-    yield request.param
-    _lib.set_conv_math(old)
+# round 5: the widths the SHIPPED kernels take (res_filters 32: csrc/conv_bf16.hip in split precision) at the odd sizes --
+# TF-SAME padding on odd extents at every stride-2 layer (resnet.py:113-122), batches of 1 / 2 / 5 / 7, 40- and 64-bin features
+SWEEP += [
+    dict(input_shape=[33, 80, 1], res_type="res18", res_filters=32, hidden_dim=32, mto="avg", B=1),
+    dict(input_shape=[65, 80, 1], res_type="res34", res_filters=32, hidden_dim=32, mto="gvlad", vlad_clusters=4, ghost_clusters=2, disc_enable=True,
+         metric_loss="arcface", B=2),
+    dict(input_shape=[81, 40, 1], res_type="res18", res_filters=32, hidden_dim=64, mto="vlad", vlad_clusters=5, disc_enable=True,
+         metric_loss="circleloss", B=5),
+    dict(input_shape=[97, 64, 1], res_type="res34", res_filters=32, hidden_dim=32, mto="bigru", disc_enable=True, metric_loss="cosface", B=7),
+    dict(input_shape=[131, 80, 1], res_type="res18", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=8, ghost_clusters=2, disc_enable=True,
+         ctc_enable=True, bpe_classes=29, max_ctc_len=6, metric_loss="circleloss", B=2),       # hidden_dim 256: the fp16 MFMA recurrence
+    dict(input_shape=[131, 64, 1], res_type="res34", res_filters=32, hidden_dim=32, mto="avg", disc_enable=True, metric_loss="sphereface", margin=1.35, B=5),
+    dict(input_shape=[97, 40, 1], res_type="res18", res_filters=32, hidden_dim=32, mto="gvlad", vlad_clusters=3, ghost_clusters=1, disc_enable=True,
+         ctc_enable=True, bpe_classes=12, max_ctc_len=4, metric_loss="softmax", B=7),
+    dict(input_shape=[33, 64, 1], res_type="res18", res_filters=64, hidden_dim=32, mto="avg", disc_enable=True, metric_loss="cosface", B=2),
+    dict(input_shape=[65, 40, 1], res_type="res34", res_filters=32, hidden_dim=32, mto="vlad", vlad_clusters=2, disc_enable=True, metric_loss="arcface", B=1),
+    dict(input_shape=[81, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=8, ghost_clusters=2, disc_enable=True,
+         ctc_enable=True, bpe_classes=40, max_ctc_len=5, metric_loss="arcface", B=5),
+]
+
+# every case in the two fp32-storage modes of round 1; every case whose width the shipped kernels take (res_filters 32 / 64) ALSO in the
+# package default "x3" -- the mode that ships was the least swept
+CASES = [(i, m) for i in range(len(SWEEP)) for m in ("fp32", "bf16x3_r1")] + \
+        [(i, "x3") for i in range(len(SWEEP)) if SWEEP[i]["res_filters"] in (32, 64)]
 
 
-@pytest.mark.parametrize("conv_math", ["fp32", "bf16x3"], indirect=True)
-@pytest.mark.parametrize("i", range(len(SWEEP)))
-def test_config_sweep(i, conv_math):
+@pytest.mark.parametrize("i,mode_name", CASES, ids=["%d-%s" % c for c in CASES])
+def test_config_sweep(i, mode_name):
+    from tests._modes import mode
+    with mode(mode_name):
+        _config_sweep(i, mode_name)
+
+
+def _config_sweep(i, conv_math):
     from aesrc2020_amd.model import SAR_Net
+    from tests._modes import runs_shipped_kernels
     kw = dict(SWEEP[i]); B = kw.pop("B")
     cfg = MT.Cfg(**kw)
     ref = MT.TorchSARNet(cfg, seed=100 + i)
     model, _ = SAR_Net(seed=i, **kw)
+    assert runs_shipped_kernels(model) == (conv_math == "x3")
     model.set_weights_dict({k: v.numpy() for k, v in ref.P.items()})
     assert set(r.name for r in model.store.refs) == set(ref.P)
     batch = MT.synthetic_batch(cfg, B, seed=500 + i)
@@ -77,7 +101,10 @@ def test_config_sweep(i, conv_math):
     ref_g = {r.name: G[r.name].numpy() - (2 * MT.L2 * ref.P[r.name].numpy() if r.name in ref.reg else 0.0) for r in model.store.refs}
     num = sum(float(((r.g.cpu().double().numpy() - ref_g[r.name]) ** 2).sum()) for r in model.store.refs)
     den = sum(float((ref_g[r.name] ** 2).sum()) for r in model.store.refs)
-    assert num ** 0.5 <= (2e-3 if conv_math == "fp32" else 1e-2) * den ** 0.5, (i, conv_math, (num / den) ** 0.5)
+    # ("x3": conv weight gradients, the stem's last product and the hidden_dim-256 recurrence are single-pass fp16 under the loss scale, and more
+    # ReLU / max-pool decisions sit within the arithmetic's noise of zero: measured 1e-3 .. 8e-3, the whole-graph bound of tests/test_gpu_bf16_model.py)
+    print("sweep %d %s: flat gradient rel. L2 %.3e" % (i, conv_math, (num / den) ** 0.5))
+    assert num ** 0.5 <= {"fp32": 2e-3, "bf16x3_r1": 1e-2, "x3": 3e-2}[conv_math] * den ** 0.5, (i, conv_math, (num / den) ** 0.5)
     if conv_math == "fp32":
         med = float(np.median([np.abs(v).max() for v in ref_g.values()]))
         bad = []

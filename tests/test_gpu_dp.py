@@ -116,6 +116,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         _lib.set_trunk_dtype("fp32")
     cfg = MT.Cfg(**kw)
     st = single.store
+    discriminated = 0
     for i in range(STEPS):
         a, b = r0[i], r1[i]
         assert np.array_equal(a["p_before"], b["p_before"]) and np.array_equal(a["p_after"], b["p_after"])   # replicas stay identical
@@ -142,12 +143,25 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
         assert len(late) == 4
         for off, size in late:
             ga, gs = a["grads"][off:off + size], gsum[off:off + size]
-            e1 = float(np.linalg.norm(ga - gs) / np.linalg.norm(gs))
-            assert e1 < late_tol and np.linalg.norm(ga) > 0.9 * np.linalg.norm(gs), (i, off, e1)
-            # closer to the SUM of the shard gradients than to either shard's own (a vector that holds one rank's contribution only)
+            ngs = float(np.linalg.norm(gs))
+            e1 = float(np.linalg.norm(ga - gs)) / ngs
+            share = [float(np.linalg.norm(gshard[r][off:off + size])) / ngs for r in range(2)]
+            dist = [float(np.linalg.norm(ga - gshard[r][off:off + size])) / ngs for r in range(2)]
+            print("  late vector @%d step %d: e1 %.3e, |g_shard0|/|g_sum| %.3f, |g_shard1|/|g_sum| %.3f, distance to shard0 / shard1 %.3f / %.3f"
+                  % (off, i, e1, share[0], share[1], dist[0], dist[1]))
+            assert e1 < late_tol and np.linalg.norm(ga) > 0.9 * ngs, (i, off, e1)
+            # closer to the SUM of the shard gradients than to either shard's own (a vector that holds one rank's contribution only).
+            # A vector reduced WITHOUT rank q's contribution sits at distance share[q] from the sum, so e1 < late_tol above already rules that out
+            # whenever share[q] > late_tol; the comparison below adds something only where the other shard's share is well above the noise, and is
+            # ill-conditioned where it is not (GPUTEST_r04: a shard whose share of one vector is below 2 * e1 fails it by noise alone -- ADVICE r4).
             for r in range(2):
-                assert e1 < float(np.linalg.norm(ga - gshard[r][off:off + size]) / np.linalg.norm(gs)), (i, off, r)
+                if share[1 - r] > 4 * late_tol:
+                    assert e1 < dist[r], (i, off, r, e1, share, dist)
+                    discriminated += 1
         assert not np.array_equal(a["p_before"], a["p_after"])
+    # the batches are chosen so that BOTH shards carry a healthy part of every late vector: the closer-to-the-sum comparison must have run
+    # for (nearly) all of the 4 vectors x 3 steps x 2 ranks
+    assert discriminated >= 20, discriminated
     _reset_mode()
 
 

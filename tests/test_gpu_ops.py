@@ -820,7 +820,7 @@ def test_adam_l2_unitnorm(L):
         check(p, pr, 1e-5, "adam p step %d" % it); check(l2l, [ref_l2], 1e-4, "l2 loss")
     assert int(st.view(torch.int32)[6]) == 3
     # the one-launch form (round 3): prepare + step, the last block advances the iteration count; three further steps continue the run
-    tick = torch.zeros(4, dtype=torch.int32, device="cuda")
+    tick = torch.zeros(8, dtype=torch.int32, device="cuda")
     for it in range(3, 6):
         l2l.zero_()
         L.call("sar_adam_l2_update_f32", p, dev(g), m, v, dev(l2), st, tick, l2l, n)
@@ -840,6 +840,7 @@ def test_adam_l2_unitnorm(L):
     L.call("sar_adam_l2_update_f32", p, gd, m, v, dev(l2), st, tick, l2l, n)
     assert torch.equal(p, p_before) and torch.equal(m, m_before) and torch.equal(v, v_before)
     assert int(tick[2].item()) == 1 and int(tick[3].item()) == 0 and int(tick[0].item()) == 0 and int(st.view(torch.int32)[6]) == 6
+    assert int(tick[4].item()) == 1                                          # skipped steps in a row
     check(l2l, [(l2e * pr * pr).sum()], 1e-4, "l2 loss of a skipped step")       # still the penalty of the (unchanged) weights
     # a clean gradient behind it: the check leaves the flag alone and the step proceeds as step 6
     l2l.zero_()
@@ -848,5 +849,6 @@ def test_adam_l2_unitnorm(L):
     L.call("sar_adam_l2_update_f32", p, dev(g), m, v, dev(l2), st, tick, l2l, n)
     pr, mr, vr = O.adam_step(pr, 0.5 * g + 2 * l2e * pr, mr, vr, 6, lr=0.01)
     check(p, pr, 1e-5, "guarded adam, clean step"); assert int(tick[2].item()) == 1 and int(st.view(torch.int32)[6]) == 7
+    assert int(tick[4].item()) == 0                                          # ... reset by the applied step
     w = rng.standard_normal((256, 8)); wd = dev(w)
     L.call("sar_unit_norm_f32", wd, 256, 8); check(wd, O.unit_norm(w), 1e-5, "unit_norm")
