@@ -159,9 +159,12 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
                     assert e1 < dist[r], (i, off, r, e1, share, dist)
                     discriminated += 1
         assert not np.array_equal(a["p_before"], a["p_after"])
-    # the batches are chosen so that BOTH shards carry a healthy part of every late vector: the closer-to-the-sum comparison must have run
-    # for (nearly) all of the 4 vectors x 3 steps x 2 ranks
-    assert discriminated >= 20, discriminated
+    # profiles/r5_dp_late_vector_loop.log (20 runs of the bf16 and bf16x3 variants on one box): at steps 0 and 1 both shards carry 45-100 % of
+    # every late vector in every run, so the comparison runs for all 4 vectors x 2 steps x 2 ranks; at step 2 -- two Adam steps of +-lr per
+    # element into a run-to-run different trajectory -- ONE shard's share of all four vectors is anywhere between 0.2 % and 60 % (its three
+    # utterances saturate the s = 30 head), which is what failed GPUTEST_r04 by noise (e1 = 3e-3 against a share of 2e-3): measured e1 over the 20
+    # runs <= 6.0e-3 (bf16, bound 3e-2) / 3.2e-5 (bf16x3, bound 1e-2) in every step -- no late vector was ever reduced without a rank
+    assert discriminated >= 16, discriminated
     _reset_mode()
 
 
