@@ -184,8 +184,13 @@ __device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
 // threads share a row, NTHR / cw rows are in flight per trip (the launcher checks cw <= NTHR); the threads beyond run no-op pieces.
 // The single-plane builds (bf16, fp16) keep round 3's fill verbatim (fill_patch16 / xform16: the merged form below cost them 13 registers,
 // i.e. spills on the 128- and 168-register instantiations); fill_patch below is the SAR_X3 form and dispatches.
-template <int MODE>
-__device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const uint4 q3, const Cst8& k) {
+// A32 ("activations fp32", the mixed backward of the split-precision mode, round 5): the tensors of the FORWARD pass a gradient launch reads --
+// x2, the BatchNorm input of the fill's backward transform, and e_y, the BatchNorm input of the epilogue's backward sums -- are fp32 tensors
+// (what sar_conv2d_x3 left in HBM), while everything that is a gradient (x, x3, res, y, side) is this build's 2-byte type: the input-gradient
+// chain of the fp32-class mode runs single-pass on fp16 (tools/grad_recipe_emulator.py: flat gradient 9.6e-4 against 6.8e-4 with split-precision
+// input gradients -- the weight gradients' fp16 operands set both) at the fp16 build's cost.  q2 / q2b: the two 16-byte pieces of eight fp32.
+template <int MODE, bool A32 = false>
+__device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const uint4 q2b, const uint4 q3, const Cst8& k) {
     if constexpr (MODE == 0) return q;
     float a[8], o[8];
     unpack8(q, a);
@@ -194,7 +199,7 @@ __device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const ui
         for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(a[j], k.sc[j], k.sh[j]), 0.f);
     } else {
         float y[8];
-        unpack8(q2, y);
+        if constexpr (A32) f32x8_of(q2, q2b, y); else unpack8(q2, y);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float z = fmaf(y[j], k.sc[j], k.sh[j]);
@@ -212,7 +217,7 @@ __device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const ui
     return pack8(o);
 }
 
-template <int MODE, int TM, int U, int NTHR, typename MID>
+template <int MODE, int TM, int U, int NTHR, bool A32, typename MID>
 __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, MID&& mid) {
@@ -227,7 +232,7 @@ __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict
     const unsigned rowbytes = g.Wp * rs;
     const bool do_side = side != nullptr && first_ntile;           // block-uniform
     Cst8 k;
-    uint4 q[U], q2[U], q3[U]; unsigned off[U], lo[U], own[U];
+    uint4 q[U], q2[U], q2b[U], q3[U]; unsigned off[U], lo[U], own[U];
     auto issue = [&](unsigned r0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -239,14 +244,15 @@ __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict
             lo[j] = in ? pr * rowbytes + lo_col : dummy;           // branch-free: pieces past the end land in a scratch slot
             const unsigned o = ok ? off[j] : 0u;
             q[j] = *reinterpret_cast<const uint4*>(x + o);
-            if constexpr (MODE >= 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j];
+            if constexpr (MODE >= 2 && A32) { q2[j] = ld16f(x2, o); q2b[j] = ld16f(x2, o + 4); }
+            else { if constexpr (MODE >= 2) q2[j] = *reinterpret_cast<const uint4*>(x2 + o); else q2[j] = q[j]; q2b[j] = q2[j]; }
             if constexpr (MODE == 3) q3[j] = *reinterpret_cast<const uint4*>(x3 + o); else q3[j] = q[j];
         }
     };
     auto finish = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const uint4 r = xform16<MODE>(q[j], q2[j], q3[j], k);
+            const uint4 r = xform16<MODE, A32>(q[j], q2[j], q2b[j], q3[j], k);
             *reinterpret_cast<uint4*>(patch + lo[j]) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
             if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
         }
@@ -257,11 +263,11 @@ __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict
     finish();
     for (unsigned base = U * rpi; base < nrows; base += U * rpi) { issue(base + rsub); finish(); }   // U rows in flight per thread
 }
-template <int MODE, int TM, int U, int NTHR, typename MID>
+template <int MODE, int TM, int U, int NTHR, bool A32, typename MID>
 __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid, bool first_ntile, MID&& mid) {
     if constexpr (!X3) {
-        fill_patch16<MODE, TM, U, NTHR>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, mid);
+        fill_patch16<MODE, TM, U, NTHR, A32>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, mid);
         return;
     }
     const Geo& g = p.g;
@@ -362,9 +368,10 @@ constexpr int BR_PD = X3 ? 2 : 4;    // BR form: k-steps of weight fragments in 
 // feeds one MFMA, a B fragment two; round 2's k-phase was bound by LDS reads 2 : 1 -- 2 KB per MFMA -- and by a barrier per 8 fragments).
 // (the body is a device function: conv_bf16_kernel runs it for one convolution, conv_bf16_pair_kernel for TWO independent ones in one launch.
 // lin / ntot / nty: this block's linear index among the ntot blocks of ITS convolution, of which nty are channel tiles per pixel tile)
-template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false, bool A32 = false>
 __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, const unsigned ntot, const unsigned nty) {
     static_assert(BR || KG == 1, "k-groups exist in the BR form only");
+    static_assert(!(X3 && A32), "A32 (fp32 forward tensors beside 2-byte gradients) is a form of the single-plane builds");
     static_assert(!BR || (WN == 2 && (WMX == 2 || WMX == 1) && NKC / KG == 2), "BR: 64 (or 32: WMX = 1, the sources whose 64-pixel patch does not fit the LDS) x 64 tiles, two fragments per virtual tap and wave");
     constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
     constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
@@ -419,7 +426,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // 32-channel layers' LDS at 40 KB, i.e. a 2-deep weight ring: see the ring comment; with the 3-deep ring they fit three per CU
     // and the variant was slower, 23 vs 17 us per stage-0 launch)
     constexpr bool EARLY = NG != 8;                                 // (the eight-wave form lives on 128 registers: operands loaded behind the k-phase)
-    unsigned rv[RPT][NPL], yv[RPT][NPL];
+    constexpr int NYV = A32 ? 2 : NPL;                              // words of an e_y column pair: A32: two fp32 values
+    unsigned rv[RPT][NPL], yv[RPT][NYV];
     auto load_epi = [&]() __attribute__((always_inline)) {
         if (p.bias) { b0 = p.bias[c]; b1 = p.bias[c + 1]; }
         if (p.epi == 2) {
@@ -438,7 +446,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
                 rv[i][0] = r2.x; rv[i][NPL - 1] = r2.y; yv[i][0] = y2.x; yv[i][NPL - 1] = y2.y;
             } else {
                 rv[i][0] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
-                yv[i][0] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
+                if constexpr (A32) {                                // e_y: the forward pass's fp32 tensor
+                    const uint2 y2 = p.epi == 2 ? *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(p.e_y) + o) : make_uint2(0u, 0u);
+                    yv[i][0] = y2.x; yv[i][NYV - 1] = y2.y;
+                } else yv[i][0] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
             }
         }
     };
@@ -520,10 +531,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // one round trip: 2.626 vs 2.594 ms per split-precision step, same box, 300-step runs -- the registers cost more than the round trip.)
     constexpr int FU = (NG == 8 || X3) ? 2 : 4;                    // (SAR_X3: two 32-byte pieces are what four 16-byte ones were; 2.254 vs 2.259 ms)
     // ---- fill: the padded patch, all input channels, transformed once
-    if (p.fill == 0) fill_patch<0, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else if (p.fill == 2) fill_patch<2, TM, (X3 && FU > 2 ? 2 : FU), NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
+    // (A32: a piece of the gradient fills is three / four 16-byte loads -- two pieces in flight)
+    if (p.fill == 0) fill_patch<0, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    else if (p.fill == 2) fill_patch<2, TM, ((X3 || A32) && FU > 2 ? 2 : FU), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
     if constexpr (EARLY && BR) load_epi();
     // ---- per-lane A address
     auto a_addr = [&](unsigned pix0) __attribute__((always_inline)) {
@@ -710,7 +722,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
             }
             if (p.epi == 2) {
                 float y0, y1;
-                if constexpr (X3) { y0 = __uint_as_float(yv[i][0]); y1 = __uint_as_float(yv[i][NPL - 1]); }
+                if constexpr (X3 || A32) { y0 = __uint_as_float(yv[i][0]); y1 = __uint_as_float(yv[i][NYV - 1]); }
                 else { y0 = h_lo(yv[i][0]); y1 = h_hi(yv[i][0]); }
                 const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
                 s10 += d0; s11 += d1; s20 += d0 * (y0 - mu0) * rs0; s21 += d1 * (y1 - mu1) * rs1;
@@ -752,9 +764,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
 // (or two four-wave blocks) per CU anyway: 2 for every ring form.
 #define CONV_OCC (BR ? (KG == 4 ? 1 : 2) : X3 ? (WMX * WN == 8 && NKC == 2 ? 4 : 2) : (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2))
 
-template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false>
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false, bool A32 = false>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv_bf16_kernel(const ConvP p) {
-    conv_body<WN, NKC, VT, KG, WMX, BR>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, gridDim.y);
+    conv_body<WN, NKC, VT, KG, WMX, BR, A32>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, gridDim.y);
 }
 
 // TWO independent convolutions of equal block size in ONE launch (round 3): the 1x1 shortcut of a residual block that changes the shape
@@ -762,12 +774,12 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv
 // A launch inside the step costs ~4.5 us before it does anything, the shortcut launches are 7-20 us of mostly that, and the
 // 3x3 launches of the stages they sit in front of leave CUs idle.  Blocks [0, na) run the first convolution, the rest the second (1x1:
 // same WN / NKC / KG / WMX / BR, VT = channel parts of ONE tap); LDS and registers are the larger of the two.
-template <int WN, int NKC, int VT, int KG, int WMX, bool BR>
+template <int WN, int NKC, int VT, int KG, int WMX, bool BR, bool A32 = false>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC)
 void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, const unsigned ntya, const unsigned nb, const unsigned ntyb) {
     const unsigned na8 = (na + 7u) & ~7u;                             // the second convolution starts on XCD 0 as well (its XCD-aware tile order)
-    if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR>(pa, blockIdx.x, na, ntya);
-    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMX, BR>(pb, blockIdx.x - na8, nb, ntyb);
+    if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR, A32>(pa, blockIdx.x, na, ntya);
+    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMX, BR, A32>(pb, blockIdx.x - na8, nb, ntyb);
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
@@ -1236,7 +1248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const DT* __rest
             const float xh = (y[j] - k.mu[j]) * k.rs[j];
             o[j] = (k.sc[j] * (dz - k.c2[j] - xh * k.c3[j]) + (add ? ad[j] : 0.f)) * (X3 ? 1.f : out_scale);
         }
-        store8(out, e, ps, o);
+        if (!X3 || out != nullptr) store8(out, e, ps, o);            // (SAR_X3, the mixed backward: only the scaled fp16 tensor)
         if constexpr (X3) { if (out16 != nullptr) *reinterpret_cast<uint4*>(out16 + e) = pack8_half(o, out_scale); }
     }
 }
@@ -1354,32 +1366,40 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackRow* __rest
     r = __builtin_amdgcn_readfirstlane(r);
     const PackRow row = tab[r];
     const int taps = (int)row.taps, Cin = (int)row.Cin, Cout = (int)row.Cout;
-    // (SAR_X3: the stream interleaves the hi and the lo fragment of every 16-channel block)
-    const int Ff = NPL * taps * Cin / 16, Ffp = Ff + 8, Fd = NPL * taps * Cout / 16, Fdp = Fd + 8;
+    // (SAR_X3: the stream interleaves the hi and the lo fragment of every 16-channel block.  row.pad_ & 1, SAR_X3 only -- the mixed backward of
+    // round 5: the INPUT-GRADIENT stream is a single plane of IEEE fp16 fragments, the stream sar_conv2d_f16a reads)
+    const bool d16 = X3 && (row.pad_ & 1);
+    const int npd = d16 ? 1 : NPL;
+    const int Ff = NPL * taps * Cin / 16, Ffp = Ff + 8, Fd = npd * taps * Cout / 16, Fdp = Fd + 8;
     const long nf = (long)(Cout / 32) * Ffp * 64, nd = (long)(Cin / 32) * Fdp * 64;    // 16-byte pieces
     long i = ((long)blockIdx.x - row.first_block) * 256 + threadIdx.x;
     if (i >= nf + nd) return;
     const bool fwd = i < nf;
     if (!fwd) i -= nf;
     const int Fp = fwd ? Ffp : Fdp, F = fwd ? Ff : Fd, Cred = fwd ? Cin : Cout;
+    const int npl = (fwd || !d16) ? NPL : 1;
     const int lane = (int)(i & 63);
     const long t = i >> 6;
     const int f = (int)(t % Fp), nt = (int)(t / Fp);
     // (SAR_X3: the thread of the hi fragment writes the lo fragment -- the next one, 64 pieces on -- as well; the threads of the odd fragments have
     // nothing to do: gathering the same eight values twice was half of this launch's loads)
-    if (X3 && (f & 1)) return;
+    if (npl == 2 && (f & 1)) return;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
     if (f < F) {
-        const int fl = f / NPL, nk = Cred / 16, tap = fl / nk, kc = fl % nk;
+        const int fl = f / npl, nk = Cred / 16, tap = fl / nk, kc = fl % nk;
         const int oc = nt * 32 + (lane & 31), rc = kc * 16 + 8 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             v[j] = fwd ? row.w[((long)tap * Cin + rc + j) * Cout + oc] : row.w[((long)(taps - 1 - tap) * Cin + oc) * Cout + rc + j];
     }
-    uint4 o = pack8(v);
     u16* dst = (fwd ? row.wf : row.wd) + i * 8;
+    if (X3 && npl == 1) {                                            // the fp16 input-gradient stream of the mixed backward
+        *reinterpret_cast<uint4*>(dst) = pack8_half(v, 1.f);
+        return;
+    }
+    uint4 o = pack8(v);
     if constexpr (X3) {
         uint4 lo;
         split8(v, o, lo);
@@ -1434,7 +1454,7 @@ typedef BnP sarBnRef;
 
 static int g_last_class[6];
 // sar_conv2d_pair_* runs sar_conv2d_* twice with this set: the launcher then hands back what it would have launched instead of launching it
-struct ConvLaunch { ConvP p; dim3 grid; int nthr; size_t lds; int cls[6]; };
+struct ConvLaunch { ConvP p; dim3 grid; int nthr; size_t lds; int cls[6]; int act32; };
 static ConvLaunch* g_capture = nullptr;
 // <WN, NKC, VT, KG, WMX, BR> of the most recent sar_conv2d_* launch of this process (introspection for bench.py / tools; not thread-safe)
 int SAR_T16(sar_conv2d_last_class_)(int* out6) {
@@ -1466,11 +1486,20 @@ int SAR_T16(sar_conv_pack_weights_zero_)(const void* table, int n, int total_blo
 //   epi  0: none; 1: sum / sum of squares of y into e_bins; 2: BatchNorm-backward sums of y (= da) against (e_y, e_saved); 3: epi 1 in fixed point.
 // Forward: d = 1, s = stride, pads as TF.  Input gradient: src = dy, d = stride, s = 1, pt = K-1-pad_top, wpk = dgrad stream.
 // SAR_X3 (sar_conv2d_x3): every 2-byte tensor is a plane pair, `side` ONE fp16 tensor = fp16(T(src) * side_scale), side2 (nullable) T(src) as planes.
+// act32 (the fp16 build only; sar_conv2d_f16a): src2 and e_y -- tensors of the FORWARD pass -- are fp32, everything else this build's 2-byte type.
+#if SAR_HALF
+#define A32K(...) __VA_ARGS__, true>
+#else
+#define A32K(...) __VA_ARGS__, false>                                 // (no such instantiations in the other builds: the table rows alias the plain ones)
+#endif
 static int conv2d_impl(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                        int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
-                       const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, void* side2, float side_scale, hipStream_t stream) {
+                       const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, void* side2, float side_scale, hipStream_t stream,
+                       int act32 = 0) {
     ConvP p;
     memset(&p, 0, sizeof(p));
+    if (act32 && !SAR_HALF) return SAR_EINVAL;
+    const int a32 = act32 ? 1 : 0;
     if (!make_geo(p.g, B, Hs, Ws, Cin, Ho, Wo, K, s, d, pt, pl)) return SAR_EINVAL;
     if (!pow2(Cin) || !pow2(Cout) || Cin < 32 || Cout < 32 || Cin > CMAX || Cout > CMAX) return SAR_EINVAL;
     if (fill < 0 || fill > 3 || epi < 0 || epi > 3 || (fill && fbn == nullptr) || (fill >= 2 && src2 == nullptr) || (fill == 3 && src3 == nullptr)) return SAR_EINVAL;
@@ -1573,7 +1602,7 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
     g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
     if (g_capture != nullptr) {
-        g_capture->p = p; g_capture->grid = grid; g_capture->nthr = nthr; g_capture->lds = lds;
+        g_capture->p = p; g_capture->grid = grid; g_capture->nthr = nthr; g_capture->lds = lds; g_capture->act32 = a32;
         for (int i = 0; i < 6; ++i) g_capture->cls[i] = g_last_class[i];
         return SAR_OK;
     }
@@ -1583,34 +1612,43 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     if (br) {
         // 64-pixel tiles: 64 | 128 | 256 source channels; 32-pixel tiles: 64 | 128 | 256 | 512
 #define CVB(NKC_, NH_, KG_, WMX_) {conv_bf16_kernel<2, NKC_, NH_, KG_, WMX_, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, WMX_, true>}
-        static const kern_t kernsb[7][2] = {CVB(4, 1, 2, 2), CVB(8, 1, 4, 2), CVB(8, 2, 4, 2), CVB(4, 1, 2, 1), CVB(8, 1, 4, 1), CVB(8, 2, 4, 1), CVB(8, 4, 4, 1)};
+#define CVBA(NKC_, NH_, KG_, WMX_) {conv_bf16_kernel<A32K(2, NKC_, NH_, KG_, WMX_, true), conv_bf16_kernel<A32K(2, NKC_, 9 * NH_, KG_, WMX_, true)}
+        static const kern_t kernsb[2][7][2] = {{CVB(4, 1, 2, 2), CVB(8, 1, 4, 2), CVB(8, 2, 4, 2), CVB(4, 1, 2, 1), CVB(8, 1, 4, 1), CVB(8, 2, 4, 1), CVB(8, 4, 4, 1)},
+                                               {CVBA(4, 1, 2, 2), CVBA(8, 1, 4, 2), CVBA(8, 2, 4, 2), CVBA(4, 1, 2, 1), CVBA(8, 1, 4, 1), CVBA(8, 2, 4, 1), CVBA(8, 4, 4, 1)}};
 #undef CVB
-        static PerDeviceFlag attrb[7][2];
+#undef CVBA
+        static PerDeviceFlag attrb[2][7][2];
         const int kb = br32 ? ki + 2 : ki - 1;
-        const kern_t kern = kernsb[kb][k3];
-        if (!attrb[kb][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[kb][k3] = true; }
+        const kern_t kern = kernsb[a32][kb][k3];
+        if (!attrb[a32][kb][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[a32][kb][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
     if (tm256) {
 #define CVX(NKC_, WMX_) {conv_bf16_kernel<1, NKC_, 1, 1, WMX_>, conv_bf16_kernel<1, NKC_, 9, 1, WMX_>}
-        static const kern_t kernsx[2][2] = {CVX(2, 8), CVX(4, 8)};
+#define CVXA(NKC_, WMX_) {conv_bf16_kernel<A32K(1, NKC_, 1, 1, WMX_, false), conv_bf16_kernel<A32K(1, NKC_, 9, 1, WMX_, false)}
+        static const kern_t kernsx[2][2][2] = {{CVX(2, 8), CVX(4, 8)}, {CVXA(2, 8), CVXA(4, 8)}};
 #undef CVX
-        static PerDeviceFlag attrx[2][2];
-        const kern_t kern = kernsx[ki][k3];
-        if (!attrx[ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[ki][k3] = true; }
+#undef CVXA
+        static PerDeviceFlag attrx[2][2][2];
+        const kern_t kern = kernsx[a32][ki][k3];
+        if (!attrx[a32][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[a32][ki][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
 #define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
-    static const kern_t kerns[2][5][2] = {{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
-                                          {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}};
+#define CVA(WN_, NKC_, NH_) {conv_bf16_kernel<A32K(WN_, NKC_, NH_, 1, 4 / WN_, false), conv_bf16_kernel<A32K(WN_, NKC_, 9 * NH_, 1, 4 / WN_, false)}
+    static const kern_t kerns[2][2][5][2] = {{{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
+                                              {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}},
+                                             {{CVA(1, 2, 1), CVA(1, 4, 1), CVA(1, 8, 1), CVA(1, 8, 2), CVA(1, 8, 4)},
+                                              {CVA(2, 2, 1), CVA(2, 4, 1), CVA(2, 8, 1), CVA(2, 8, 2), CVA(2, 8, 4)}}};
 #undef CV
-    static PerDeviceFlag attr[2][5][2];
-    const kern_t kern = kerns[WN - 1][ki][k3];
-    if (!attr[WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[WN - 1][ki][k3] = true; }
+#undef CVA
+    static PerDeviceFlag attr[2][2][5][2];
+    const kern_t kern = kerns[a32][WN - 1][ki][k3];
+    if (!attr[a32][WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[a32][WN - 1][ki][k3] = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -1637,7 +1675,19 @@ struct sarConvArgs { const void *src, *src2, *src3, *wpk; const float* bias; con
 // Two independent convolutions in ONE launch: a = a 3x3 convolution, b = a 1x1 convolution of the same channel classes and block size (the first
 // conv of a shape-changing residual block and its shortcut, or their input gradients).  Returns SAR_EINVAL -- and launches NOTHING -- when the
 // two do not run on instantiations that pair up; the caller then issues them one after the other.
-int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStream_t stream) {
+static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act32, hipStream_t stream);
+int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStream_t stream) { return conv2d_pair_impl(a, b, 0, stream); }
+#if SAR_HALF
+// The mixed backward of the split-precision mode (round 5): sar_conv2d_f16 / sar_conv2d_pair_f16 with src2 and e_y -- the tensors of the forward pass
+// a gradient launch reads (model.py:197 trains in fp32; resnet.py:22-26 the BatchNorm whose backward they feed) -- as the fp32 tensors sar_conv2d_x3 wrote.
+int sar_conv2d_f16a(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, hipStream_t stream) {
+    return conv2d_impl(src, src2, src3, wpk, bias, res, y, side, B, Hs, Ws, Cin, Ho, Wo, Cout, K, s, d, pt, pl, fill, fbn, epi, e_bins, e_y, e_saved, nullptr, 1.f, stream, 1);
+}
+int sar_conv2d_pair_f16a(const sarConvArgs* a, const sarConvArgs* b, hipStream_t stream) { return conv2d_pair_impl(a, b, 1, stream); }
+#endif
+static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act32, hipStream_t stream) {
     if (a == nullptr || b == nullptr) return SAR_EINVAL;
     static ConvLaunch la, lb;                                                       // (host-side scratch; one caller thread, like g_last_class)
     const sarConvArgs* q[2] = {a, b};
@@ -1646,7 +1696,7 @@ int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStr
         g_capture = l[i];
         const int rc = conv2d_impl(q[i]->src, q[i]->src2, q[i]->src3, q[i]->wpk, q[i]->bias, q[i]->res, q[i]->y, q[i]->side, q[i]->B, q[i]->Hs, q[i]->Ws,
                                    q[i]->Cin, q[i]->Ho, q[i]->Wo, q[i]->Cout, q[i]->K, q[i]->s, q[i]->d, q[i]->pt, q[i]->pl, q[i]->fill, q[i]->fbn, q[i]->epi,
-                                   q[i]->e_bins, q[i]->e_y, q[i]->e_saved, q[i]->side2, q[i]->side_scale, stream);
+                                   q[i]->e_bins, q[i]->e_y, q[i]->e_saved, q[i]->side2, q[i]->side_scale, stream, act32);
         g_capture = nullptr;
         if (rc != SAR_OK) return rc;
     }
@@ -1655,13 +1705,17 @@ int SAR_T16(sar_conv2d_pair_)(const sarConvArgs* a, const sarConvArgs* b, hipStr
     if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || ca[4] != cb[4] || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
     typedef void (*pair_t)(const ConvP, const ConvP, unsigned, unsigned, unsigned, unsigned);
     pair_t kern = nullptr;
-    static PerDeviceFlag at[5];
+    static PerDeviceFlag at[10];
     int ki = -1;
-    if (ca[0] == 2 && ca[1] == 2 && ca[2] == 9 && ca[3] == 1 && ca[4] == 2 && !ca[5]) { kern = conv_bf16_pair_kernel<2, 2, 9, 1, 2, false>; ki = 0; }
-    else if (ca[0] == 2 && ca[1] == 4 && ca[2] == 9 && ca[3] == 2 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 4, 9, 2, 2, true>; ki = 1; }
-    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 9, 4, 2, true>; ki = 2; }
-    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 18, 4, 2, true>; ki = 3; }
-    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 1 && ca[5]) { kern = conv_bf16_pair_kernel<2, 8, 18, 4, 1, true>; ki = 4; }
+    const bool a32 = act32 != 0;
+#define PK(...) (a32 ? conv_bf16_pair_kernel<A32K(__VA_ARGS__) : conv_bf16_pair_kernel<__VA_ARGS__>)
+    if (ca[0] == 2 && ca[1] == 2 && ca[2] == 9 && ca[3] == 1 && ca[4] == 2 && !ca[5]) { kern = PK(2, 2, 9, 1, 2, false); ki = 0; }
+    else if (ca[0] == 2 && ca[1] == 4 && ca[2] == 9 && ca[3] == 2 && ca[4] == 2 && ca[5]) { kern = PK(2, 4, 9, 2, 2, true); ki = 1; }
+    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = PK(2, 8, 9, 4, 2, true); ki = 2; }
+    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = PK(2, 8, 18, 4, 2, true); ki = 3; }
+    else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 1 && ca[5]) { kern = PK(2, 8, 18, 4, 1, true); ki = 4; }
+#undef PK
+    if (a32 && ki >= 0) ki += 5;
     if (kern == nullptr) return SAR_EINVAL;
     if (!at[ki]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at[ki] = true; }
     const unsigned na = la.grid.x * la.grid.y, nb = lb.grid.x * lb.grid.y, na8 = (na + 7u) & ~7u;

@@ -391,9 +391,10 @@ __global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __res
     for (unsigned pix = blockIdx.x * npg + pg; pix < npix; pix += gridDim.x * npg) {
         const size_t o = (size_t)pix * C0 + cv * 8;
         float a[8], gg[8];
-        if constexpr (X3) {                                                          // fp32 tensors
+        if constexpr (X3) {                                                          // pooled: an fp32 tensor; gp: fp16, scaled (round 5: the mixed backward)
             f32x8_of(ld16f(pooled, o), ld16f(pooled, o + 4), a);
-            f32x8_of(ld16f(gp, o), ld16f(gp, o + 4), gg);
+            const uint4 gq = *reinterpret_cast<const uint4*>(gp + o);
+            gg[0] = w_lo(gq.x); gg[1] = w_hi(gq.x); gg[2] = w_lo(gq.y); gg[3] = w_hi(gq.y); gg[4] = w_lo(gq.z); gg[5] = w_hi(gq.z); gg[6] = w_lo(gq.w); gg[7] = w_hi(gq.w);
         } else {
             unpack8(*reinterpret_cast<const uint4*>(pooled + o), a); unpack8(*reinterpret_cast<const uint4*>(gp + o), gg);
         }
@@ -442,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                                                               const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
                                                               const BnP bn, int* __restrict__ counter, float* __restrict__ part, const StemG g, int ntiles,
                                                               int dz_bytes, float gs) {
-    // SAR_X3: gp / pooled are plane pairs in TRUE units; the conv is recomputed in split precision; the scattered gradient image, dy and the
-    // im2col image are fp16 (w16) and carry the scale gs (the fp16 product's range; stem16_wsum divides by it), so E and F take it too
+    // SAR_X3: pooled is an fp32 tensor, gp the SCALED fp16 gradient of the mixed backward (round 5; until then fp32 in true units, scaled by gs
+    // here); the conv is recomputed in split precision; the scattered gradient image, dy and the im2col image are fp16 (w16)
     constexpr int C0 = NT * 32, SCR = 3 * PLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_tile;
@@ -509,11 +510,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                 // (SAR_X3: gp and pooled are fp32 tensors: hq / lq = elements 0-3 / 4-7 of the eight)
                 auto gbits = [&](const uint4 hq, const uint4 lq, int k) __attribute__((always_inline)) -> unsigned {
                     const unsigned hs[4] = {hq.x, hq.y, hq.z, hq.w}, sh = 16 * (k & 1);
-                    if constexpr (X3) {
-                        const unsigned ls[4] = {lq.x, lq.y, lq.z, lq.w};
-                        const float v = __uint_as_float(k < 4 ? hs[k & 3] : ls[k & 3]) * gs;
-                        return (unsigned)__builtin_bit_cast(unsigned short, (w16)v);
-                    } else return (hs[k >> 1] >> sh) & 0xffffu;
+                    return (hs[k >> 1] >> sh) & 0xffffu;                              // (SAR_X3, round 5: gp is the scaled fp16 tensor the image takes as it is)
                 };
                 // which of the eight pooled values are positive (>= 0 always: non-zero magnitude bits), one bit each
                 auto pmask = [&](const uint4 a, const uint4 b) __attribute__((always_inline)) -> unsigned {
@@ -537,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                     const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
                     if constexpr (X3) {
                         const uint4 pa = ld16f(pooled, o), pb = ld16f(pooled, o + 4);
-                        gv[u] = ld16f(gp, o); gl[u] = ld16f(gp, o + 4);
+                        gv[u] = *reinterpret_cast<const uint4*>(gp + o); gl[u] = gv[u];
                         pv[u] = make_uint4(pmask(pa, pb), 0u, 0u, 0u);
                     } else {
                         pv[u] = *reinterpret_cast<const uint4*>(pooled + o); gv[u] = *reinterpret_cast<const uint4*>(gp + o);
@@ -550,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
                     const int cg = it0 & 3, pp = it0 >> 2;
                     const size_t o = (((size_t)n * g.Hp + i_lo) * g.Wp + pp) * C0 + CT * 32 + cg * 8;
                     uint4 g1, g1l; unsigned pm;
-                    if constexpr (X3) { g1 = ld16f(gp, o); g1l = ld16f(gp, o + 4); pm = pmask(ld16f(pooled, o), ld16f(pooled, o + 4)); }
+                    if constexpr (X3) { g1 = *reinterpret_cast<const uint4*>(gp + o); g1l = g1; pm = pmask(ld16f(pooled, o), ld16f(pooled, o + 4)); }
                     else { const uint4 p1 = *reinterpret_cast<const uint4*>(pooled + o); g1 = *reinterpret_cast<const uint4*>(gp + o); g1l = g1; pm = pmask(p1, p1); }
                     const uint2 i1 = *reinterpret_cast<const uint2*>(idx + o);
                     const int wi = pp / g.Wp, wj = pp - wi * g.Wp;
@@ -838,11 +835,10 @@ int SAR_STEM(sar_stem16_wgrad)(const float* x, const float* w, const float* bias
     const int nblk = ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS;
     int* counter = reinterpret_cast<int*>(work);
     float* part = work + 16;
-    // SAR_X3: g_pooled and the BatchNorm sums are in true units (the kernel's BatchNorm gets ginv = 1); bn->ginv = 1 / (the scale the
-    // gradient takes on its way into the fp16 product), undone by stem16_wsum
+    // SAR_X3 (round 5): g_pooled is the fp16 tensor the mixed backward's last input-gradient launches wrote, times the static scale 1 / bn->ginv,
+    // exactly as in the fp16 build: the BatchNorm sums carry the scale, bn->ginv undoes it in dgamma / dbeta and (stem16_wsum) in dw
     sarBnRef bnk = *bn;
-    float gs = 1.f;
-    if (X3) { gs = bn->ginv > 0.f ? 1.f / bn->ginv : 1.f; bnk.ginv = 1.f; }
+    const float gs = 1.f;
     if (C0 == 64) {
         if (!allow_lds(stem16_wgrad_kernel<2>, lds)) return SAR_ELAUNCH;
         hipLaunchKernelGGL(stem16_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, stream, x, w, bias, static_cast<const u16*>(g_pooled),

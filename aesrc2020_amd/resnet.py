@@ -102,6 +102,7 @@ class _Conv:
         self.use_planes = False
         # 2-byte trunk (ResNetTrunk sets them): entry-point suffix "bf16" | "f16", torch dtype, 1 / gradient scale
         self.sfx, self.t16, self.ginv = "bf16", torch.bfloat16, 1.0
+        self.bsfx = "bf16"                                                   # entry-point suffix of the INPUT-GRADIENT launches ("f16a": the mixed backward of the split-precision mode)
         self.epi_fwd = 1                                                     # 3: deterministic (fixed-point) statistics out of the epilogue
 
     def planes(self):
@@ -116,16 +117,17 @@ class _Conv:
         """Packed bf16 weight streams (forward, input gradient) + this conv's row of the pack table."""
         taps = self.k * self.k
         npl = 2 if self.sfx == "x3" else 1                                  # split precision: hi and lo fragment of every 16-channel block
+        npd = 1 if self.bsfx == "f16a" else npl                             # mixed backward: the input-gradient stream is one plane of fp16 fragments
         nf = (self.cout // 32) * (npl * taps * self.cin // 16 + 8) * 512    # 2-byte elements
-        nd = (self.cin // 32) * (npl * taps * self.cout // 16 + 8) * 512
+        nd = (self.cin // 32) * (npd * taps * self.cout // 16 + 8) * 512
         b = self.store.bufs
         self.wf = b.get(self.name + "/wf16", (nf,), self.t16)
-        self.wd = b.get(self.name + "/wd16", (nd,), self.t16)
+        self.wd = b.get(self.name + "/wd16", (nd,), torch.float16 if self.bsfx == "f16a" else self.t16)
         return [self.kernel.w.data_ptr(), self.wf.data_ptr(), self.wd.data_ptr(), taps, self.cin, self.cout], -(-(nf + nd) // 8 // 256)
 
-    def _x3_tail(self, side2, side_scale):
+    def _x3_tail(self, side2, side_scale, sfx=None):
         """sar_conv2d_x3's two extra arguments: the fill's result as an fp32 tensor (side2), the scale of its fp16 copy (side)."""
-        return (side2, float(side_scale)) if self.sfx == "x3" else ()
+        return (side2, float(side_scale)) if (sfx or self.sfx) == "x3" else ()
 
     def fwd16_args(self, x, y, B, fill=0, fbn=None, res=None, e_bins=None, side=None, side2=None, side_scale=1.0):
         return (x, None, None, self.wf, self.bias.w, res, y, side, B, self.H, self.W, self.cin, self.Ho, self.Wo, self.cout,
@@ -139,13 +141,13 @@ class _Conv:
         """dx = conv_transpose(T(dy)) (+ res); T = BatchNorm backward of (dy, dy2) through fbn when fill == 2, + dy3 when fill == 3
         (written back to `side` for the weight gradient and the other consumers of that gradient); the epilogue leaves the backward
         sums of the BatchNorm in FRONT of this conv (input e_y) in e_bins."""
-        _call("sar_conv2d_" + self.sfx, *self.dgrad16_args(dy, dy2, dx, B, fill, fbn, res, e_bins, e_y, e_saved, side, dy3, side2, side_scale))
+        _call("sar_conv2d_" + self.bsfx, *self.dgrad16_args(dy, dy2, dx, B, fill, fbn, res, e_bins, e_y, e_saved, side, dy3, side2, side_scale))
 
     def dgrad16_args(self, dy, dy2, dx, B, fill=0, fbn=None, res=None, e_bins=None, e_y=None, e_saved=None, side=None, dy3=None, side2=None,
                      side_scale=1.0):
         return (dy, dy2, dy3, self.wd, None, res, dx, side, B, self.Ho, self.Wo, self.cout, self.H, self.W, self.cin,
                 self.k, 1, self.stride, self.k - 1 - self.pt, self.k - 1 - self.pl, fill, fbn, 2 if e_bins is not None else 0,
-                e_bins, e_y, e_saved) + self._x3_tail(side2, side_scale)
+                e_bins, e_y, e_saved) + self._x3_tail(side2, side_scale, self.bsfx)
 
     def wgrad16(self, x, dy, B, bias_grad):
         """Descriptor of this conv's weight gradient on plain operands (include/sarnet.h: sarWgradConv); the trunk batches them
@@ -215,6 +217,14 @@ class ResNetTrunk(Layer):
         self.x3 = dt == "bf16x3"
         self.bf16, self.half = dt in ("bf16", "fp16", "bf16x3"), dt == "fp16"
         self.sfx, self.t16 = ("f16", torch.float16) if self.half else ("x3", torch.bfloat16) if self.x3 else ("bf16", torch.bfloat16)
+        # Mixed backward of the split-precision mode (round 5; SAR_X3_BWD=x3 keeps round 4's split-precision input gradients for A/B runs): the
+        # forward pass -- what north_star bounds at 1e-3 -- stays in split precision with fp32 tensors; the activation GRADIENTS are fp16 tensors
+        # under the static scale and the input-gradient convs run single-pass on fp16 (sar_conv2d_f16a: the fp16 build's kernels reading the forward
+        # tensors as fp32): tools/grad_recipe_emulator.py puts the flat parameter gradient at 9.6e-4 of the exact one against 6.8e-4 before (the
+        # weight gradients' fp16 operands set both), at a third of the MFMAs and half the gradient bytes.
+        self.bwd16 = self.x3 and os.environ.get("SAR_X3_BWD", "f16") != "x3"
+        self.bsfx = "f16a" if self.bwd16 else self.sfx                       # entry points of the input-gradient launches
+        self.t_grad = torch.float16 if self.bwd16 else (torch.float32 if self.x3 else self.t16)   # gradients of the residual stream in HBM
         self.wsfx = "f16" if self.x3 else self.sfx                           # build whose weight-gradient kernels run
         self.t_side = torch.float16 if self.x3 else self.t16                 # the tensors the fills write back for them
         self.t_act = torch.float32 if self.x3 else self.t16                  # activations / gradients of the residual stream in HBM
@@ -246,7 +256,7 @@ class ResNetTrunk(Layer):
         self.final_bn = _BN(st, st.auto_name("batch_normalization"), cin)
         self.out_c = cin
         for cv in self._all_convs():
-            cv.sfx, cv.t16, cv.epi_fwd = self.sfx, self.t16, (3 if self.det else 1)
+            cv.sfx, cv.bsfx, cv.t16, cv.epi_fwd = self.sfx, self.bsfx, self.t16, (3 if self.det else 1)
         self.plan(*input_hw)
 
     def _set_gscale(self, B):
@@ -312,7 +322,7 @@ class ResNetTrunk(Layer):
         rows, blk0 = [], 0
         for cv in self._all_convs():
             r, nb = cv.streams16()
-            rows.append(r + [blk0, 0]); blk0 += nb
+            rows.append(r + [blk0, 1 if self.bwd16 else 0]); blk0 += nb     # (bit 0: the input-gradient stream as fp16 fragments, csrc/conv_bf16.hip: PackRow)
         self._pack_table = torch.tensor(rows, dtype=torch.int64, device="cuda")
         self._pack_blocks = blk0
         bns = self._all_bns()
@@ -325,6 +335,10 @@ class ResNetTrunk(Layer):
     def _buf16(self, key, shape):
         """An activation / gradient tensor of the trunk: the build's 2-byte type; split precision: fp32."""
         return self.buf(key, shape, self.t_act)
+
+    def _gbuf16(self, key, shape):
+        """A gradient tensor of the residual stream (mixed backward: fp16 under the static scale; else the trunk's activation type)."""
+        return self.buf(key, shape, self.t_grad)
 
     def _side16(self, key, shape):
         """An operand only the weight gradients read (the fills write it back): the trunk's 2-byte type; split precision: ONE fp16 tensor."""
@@ -397,17 +411,20 @@ class ResNetTrunk(Layer):
         x3 = self.x3
         # split precision: the gradient stream (g, da, dsc: fp32 tensors) is in TRUE units; only the fp16 copies the weight gradients read
         # (g16, dc1) carry the static scale, which their descriptors' ginv undoes.  fp16 build: the whole stream is scaled.
-        gi = 1.0 if x3 else self.ginv
+        hyb = self.bwd16                                          # mixed backward: the fp16 build's gradient stream (scaled) beside the fp32 forward tensors
+        gi = 1.0 if (x3 and not hyb) else self.ginv
+        tg = self.t_grad
         if part in (None, 0, "01"):
             H, W = self.out_hw
             fb = self.final_bn
             R = B * H * W
-            g = self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_act)
-            g16 = self.scratch("res16_g16_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_side) if x3 else g
+            g16 = self.scratch("res16_g16_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_side) if x3 else None
+            g = g16 if hyb else self.scratch("res16_g_%dx%dx%d" % (H, W, self.out_c), (B, H, W, self.out_c), self.t_act)
+            g16 = g if g16 is None else g16
             # the gradient enters the trunk here: fp32 sums and constants, the result times the fp16 build's gradient scale (1 for bf16)
             _call("sar_bn_bwd_reduce_" + self.sfx, dy, 1, self.pre_final, fb.saved, fb.bbins, R, self.out_c, 1)
             if x3:
-                _call("sar_bn_bwd_apply_x3", dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, g16, R, self.out_c, 1, self.gscale)
+                _call("sar_bn_bwd_apply_x3", dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, None if hyb else g, g16, R, self.out_c, 1, self.gscale)
             else:
                 _call("sar_bn_bwd_apply_" + self.sfx, dy, 1, self.pre_final, fb.ref(R, "bwd", True), None, g, R, self.out_c, 1, self.gscale)
         else:
@@ -434,12 +451,12 @@ class ResNetTrunk(Layer):
             # conv2: operand a1 = relu(bn2(c1)) (written back by the forward fill); its input gradient da2 leaves the two sums of
             # bn2's backward in bn2.bbins
             red = []
-            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), self.t_act)
+            da2 = self.scratch("res16_da_%dx%dx%d" % (H2, W2, cout), (B, H2, W2, cout), tg)
             if pend is None:
                 blk["conv2"].dgrad16(g, None, da2, B, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
             else:
                 p_da1, p_x, p_dsc, p_bn, p_R, p_tap = pend
-                if x3:                                                # g as fp32 (side2) for the convs, as scaled fp16 (side) for the weight gradients
+                if x3 and not hyb:                                    # g as fp32 (side2) for the convs, as scaled fp16 (side) for the weight gradients
                     blk["conv2"].dgrad16(p_da1, p_x, da2, B, fill=3, fbn=p_bn.ref(p_R, "bwd", True, gi), dy3=p_dsc, side=g16, side2=g,
                                          side_scale=self.gscale, e_bins=bn2.bbins, e_y=c1, e_saved=bn2.saved)
                 else:
@@ -451,14 +468,14 @@ class ResNetTrunk(Layer):
             red.append(blk["conv2"].wgrad16(blk["a1"], g16, B, bias_grad=True))
             # the weight gradients run at the end of the part (_wgrad16), so their gradient operands -- the block's incoming
             # gradient and dc1 -- live in per-block buffers, not in recycled scratch
-            gin = self._buf16("b%d_gin" % n, (B, H, W, cin))
-            gin16 = self._side16("b%d_gin16" % n, (B, H, W, cin)) if (x3 and bn1 is not None) else gin
+            gin = self._gbuf16("b%d_gin" % n, (B, H, W, cin))
+            gin16 = self._side16("b%d_gin16" % n, (B, H, W, cin)) if (x3 and not hyb and bn1 is not None) else gin
             sc_args = None
             if blk["sc"] is not None:
-                dsc = gin if bn1 is None else self._buf16("b%d_dsc" % n, (B, H, W, cin))
+                dsc = gin if bn1 is None else self._gbuf16("b%d_dsc" % n, (B, H, W, cin))
                 sc_args = blk["sc"].dgrad16_args(g, None, dsc, B)
                 if bn1 is None:                                       # (conv1's input gradient below adds dsc: one after the other)
-                    _call("sar_conv2d_" + self.sfx, *sc_args); sc_args = None
+                    _call("sar_conv2d_" + self.bsfx, *sc_args); sc_args = None
                 red.append(blk["sc"].wgrad16(blk["x16"], g16, B, bias_grad=True))
             else:
                 dsc = g
@@ -466,15 +483,15 @@ class ResNetTrunk(Layer):
             # (which owns bn2's parameter gradients) and written back for the weight gradient
             dc1 = self._side16("b%d_dc1" % n, (B, H2, W2, cout))
             if bn1 is not None:
-                da1 = self._buf16("b%d_da1" % n, (B, H, W, cin))
+                da1 = self._gbuf16("b%d_da1" % n, (B, H, W, cin))
                 c1_args = blk["conv1"].dgrad16_args(da2, c1, da1, B, fill=2, fbn=bn2.ref(R2, "bwd", True, gi), e_bins=bn1.bbins, e_y=x, e_saved=bn1.saved,
                                                     side=dc1, side_scale=self.gscale)
                 # the input gradients of the first conv and of the shortcut are independent (their sum is formed in the fill of the block in
                 # front, fill 3): one launch where they pair up
-                if sc_args is None or not self._pair(c1_args, sc_args):
+                if sc_args is None or not self._pair(c1_args, sc_args, self.bsfx):
                     if sc_args is not None:
-                        _call("sar_conv2d_" + self.sfx, *sc_args)
-                    _call("sar_conv2d_" + self.sfx, *c1_args)
+                        _call("sar_conv2d_" + self.bsfx, *sc_args)
+                    _call("sar_conv2d_" + self.bsfx, *c1_args)
                 pend = (da1, x, dsc, bn1, R1, (n, g, da2.clone()) if tap is not None else None)
             else:
                 # first block of the first stage: conv1 consumes the pooled tensor directly (resnet.py:111-117)
@@ -523,11 +540,11 @@ class ResNetTrunk(Layer):
     STEM_X3 = os.environ.get("SAR_STEM_X3", "1") != "0"           # split precision: the recompute-form stem (0: round 1's fp32 stem + casts)
     PAIR = os.environ.get("SAR_CONV_PAIR", "1") != "0"
 
-    def _pair(self, a3x3, b1x1):
+    def _pair(self, a3x3, b1x1, sfx=None):
         """Both convolutions (argument tuples of sar_conv2d_*) in one launch; False: nothing was launched."""
         if not self.PAIR:
             return False
-        return _lib.conv_pair(_lib.ConvArgs.of(*a3x3), _lib.ConvArgs.of(*b1x1), self.sfx)
+        return _lib.conv_pair(_lib.ConvArgs.of(*a3x3), _lib.ConvArgs.of(*b1x1), sfx or self.sfx)
 
     def _wgrad16(self, part, side=False):
         """The weight gradients of every conv collected in self._wg16 (a backward part, or one stage): one launch per class,
@@ -612,6 +629,11 @@ class ResNetTrunk(Layer):
         conv, pool = self._stem_geo(B)
         H, W = self.stem_hw
         sb, cv = self.stem_bn, self.stem
+        if self.x3 and not self.bwd16:
+            # (SAR_X3_BWD=x3, A/B runs: the fp32 true-unit gradient of round 4's backward as the scaled fp16 tensor the stem kernels take since round 5)
+            g16 = self.scratch("stem_g16", tuple(g.shape), torch.float16); gcp = self.scratch("stem_gcp", tuple(g.shape), torch.float32)
+            _call("sar_cast_f32_x3", g, gcp, g16, self.gscale, g.numel())
+            g = g16
         ref = sb.ref(B * H * W, "bwd", True, self.ginv)
         work = self.scratch("stem16_work", (_lib.stem16_wgrad_workspace_bytes(cv.cout) // 4,))
         _call(self._stem_fn("sar_stem16_bwd_reduce"), g, self.pooled16, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)

@@ -112,23 +112,31 @@ def conv_roofline(model, B, iters=10, in_step=None):
         bn1, bn2, c1v, c2v, scv = blk["bn1"], blk["bn2"], blk["conv1"], blk["conv2"], blk["sc"]
         x, c1 = blk["x"], blk["c1"]
         ACT = torch.float32 if x3t else BF                               # split precision: the residual stream is fp32 in HBM
+        hyb = getattr(tr, "bwd16", False)                                # ... and its mixed backward: gradients fp16, input-gradient launches = sar_conv2d_f16a
+        GR = tr.t_grad if x3t else BF
         rnd = lambda *s: torch.randn(*s, device="cuda").to(ACT)
+        rndg = lambda *s: torch.randn(*s, device="cuda").to(GR)
         emp = lambda *s: torch.empty(*s, device="cuda", dtype=ACT)
+        empg = lambda *s: torch.empty(*s, device="cuda", dtype=GR)
         sde = lambda *s: torch.empty(*s, device="cuda", dtype=tr.t_side)   # what the fills write back for the weight gradients
         bins = lambda c: torch.zeros(_lib.bn_bins() * 2 * c, device="cuda")
-        g, da2, res = rnd(B, H2, W2, cout), rnd(B, H2, W2, cout), rnd(B, H2, W2, cout)
-        y, a1, dx2, dc1 = emp(B, H2, W2, cout), sde(B, H2, W2, cout), emp(B, H2, W2, cout), sde(B, H2, W2, cout)
-        a, dx1 = sde(B, H, W, cin), emp(B, H, W, cin)
+        g, da2, res, resg = rndg(B, H2, W2, cout), rndg(B, H2, W2, cout), rnd(B, H2, W2, cout), rndg(B, H2, W2, cout)
+        y, a1, dx2, dc1 = emp(B, H2, W2, cout), sde(B, H2, W2, cout), empg(B, H2, W2, cout), sde(B, H2, W2, cout)
+        yg = empg(B, H2, W2, cout)
+        a, dx1 = sde(B, H, W, cin), empg(B, H, W, cin)
         g16 = sde(B, H2, W2, cout) if x3t else None
         b1, b2 = bins(cout), bins(cin)
+        ebg = 2.0 if (hyb or not x3t) else 4.0                           # bytes per element of a gradient tensor
 
-        def inst(cv, ci, co):
+        def inst(cv, ci, co, bwd=False):
             """Name of the instantiation the launch that just ran used, as rocprofv3 prints it (asked of the library: the tile form depends on
-            what fits the LDS).  Call it BEHIND the timed launch."""
+            what fits the LDS).  Call it BEHIND the timed launch.  bwd: an input-gradient launch (the mixed backward runs those in the fp16 build)."""
             import ctypes
             out = (ctypes.c_int * 6)()
-            assert _lib.lib().fn["sar_conv2d_last_class_" + tr.sfx](out) == 0
-            return "conv_bf16_kernel<%d, %d, %d, %d, %d, %s>" % (out[0], out[1], out[2], out[3], out[4], "true" if out[5] else "false")
+            sfx = tr.bsfx.replace("f16a", "f16") if bwd else tr.sfx
+            assert _lib.lib().fn["sar_conv2d_last_class_" + sfx](out) == 0
+            return "conv_bf16_kernel<%d, %d, %d, %d, %d, %s, %s>" % (out[0], out[1], out[2], out[3], out[4], "true" if out[5] else "false",
+                                                                     "true" if (bwd and hyb) else "false")
 
         def add_l(cls_fn, secs, flops, nbytes):                       # the class is asked for after `secs` was measured (argument order)
             add(cls_fn(), secs, flops, nbytes)
@@ -136,8 +144,9 @@ def conv_roofline(model, B, iters=10, in_step=None):
         def fl(cv):
             return 2.0 * B * cv.Ho * cv.Wo * cv.cout * cv.cin * cv.k * cv.k
 
-        def by(cv, extra=0):
-            alg = eb * (B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + cv.k * cv.k * cv.cin * cv.cout)
+        def by(cv, extra=0, bwd=False):
+            e = ebg if bwd else eb
+            alg = e * (B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout) + cv.k * cv.k * cv.cin * cv.cout)
             return (alg, alg + eb * extra)
 
         fb1 = bn1.ref(R1, "saved", False) if bn1 is not None else None
@@ -146,24 +155,24 @@ def conv_roofline(model, B, iters=10, in_step=None):
         add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.fwd16(c1, y, B, fill=1, fbn=bn2.ref(R2, "saved", False), res=res, e_bins=b1, side=a1)),
             fl(c2v), by(c2v, 2 * c1.numel()))
         if nxt_bn1 is None:                                         # last block: its gradient comes materialised from the final BatchNorm
-            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel()))
+            add_l(lambda: inst(c2v, cout, cout, True), timed(lambda: c2v.dgrad16(g, None, dx2, B, e_bins=b1, e_y=c1, e_saved=bn2.saved)), fl(c2v), by(c2v, c1.numel(), True))
         else:                                                       # fill 3: the block behind hands over (da1, x, shortcut gradient)
             xn = rnd(B, H2, W2, cout)
-            s3 = dict(side=g16, side2=y, side_scale=tr.gscale) if x3t else dict(side=y)
-            add_l(lambda: inst(c2v, cout, cout), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=res,
-                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved, **s3)), fl(c2v), by(c2v, 4 * c1.numel()))
+            s3 = dict(side=yg) if (hyb or not x3t) else dict(side=g16, side2=y, side_scale=tr.gscale)
+            add_l(lambda: inst(c2v, cout, cout, True), timed(lambda: c2v.dgrad16(da2, xn, dx2, B, fill=3, fbn=nxt_bn1.ref(R2, "bwd", False), dy3=resg,
+                                                                 e_bins=b1, e_y=c1, e_saved=bn2.saved, **s3)), fl(c2v), by(c2v, 4 * c1.numel(), True))
         if bn1 is not None:
-            add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
-                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, (2 * c1.numel() + x.numel())))
+            add_l(lambda: inst(c1v, cout, cin, True), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), e_bins=b2, e_y=x,
+                                                                e_saved=bn1.saved, side=dc1)), fl(c1v), by(c1v, (2 * c1.numel() + x.numel()), True))
         else:
-            r1 = rnd(B, H, W, cin)
-            add_l(lambda: inst(c1v, cout, cin), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
-                fl(c1v), by(c1v, (2 * c1.numel() + x.numel())))
+            r1 = rndg(B, H, W, cin)
+            add_l(lambda: inst(c1v, cout, cin, True), timed(lambda: c1v.dgrad16(da2, c1, dx1, B, fill=2, fbn=bn2.ref(R2, "bwd", False), res=r1, side=dc1)),
+                fl(c1v), by(c1v, (2 * c1.numel() + x.numel()), True))
         if scv is not None:
             add_l(lambda: inst(scv, cin, cout), timed(lambda: scv.fwd16(x, y, B)), fl(scv), by(scv))
-            add_l(lambda: inst(scv, cout, cin), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv))
+            add_l(lambda: inst(scv, cout, cin, True), timed(lambda: scv.dgrad16(g, None, dx1, B)), fl(scv), by(scv, 0, True))
         # the weight gradients read single 2-byte tensors in every mode (split precision: fp16 copies), batched below as the train step runs them
-        gw = g16 if x3t else g
+        gw = g16 if (x3t and not hyb) else g
         for cv, xx in ((c1v, a if bn1 is not None else blk.get("x16", x)), (c2v, a1)) + (((scv, blk.get("x16", x)),) if scv is not None else ()):
             alg2 = 2.0 * (B * (cv.H * cv.W * cv.cin + cv.Ho * cv.Wo * cv.cout)) + 4.0 * cv.k * cv.k * cv.cin * cv.cout
             wg.append((cv.wgrad16(xx, gw if cv is not c1v else dc1, B, False), fl(cv), (alg2, alg2)))
@@ -228,7 +237,7 @@ def conv_roofline(model, B, iters=10, in_step=None):
         ach = c["flops"] / c["launches"] / t_launch / 1e12
         # which MFMA pipe the class runs on: 2-byte trunk = single-pass MFMA; split precision (the x3 trunk, or fp32 storage with Cout --
         # Cin for dgrad -- > 32): three bf16 MFMAs per product block; the rest of the fp32-storage kernels: fp32 MFMA
-        is_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad"))
+        is_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad") and not name.endswith(", true>"))   # (", true>": A32 = the mixed backward's single-pass fp16 launches)
         peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or is_x3) else PEAK_F32_MFMA_TFLOPS
         pipe = PEAK_BF16X3_TFLOPS if is_x3 else peak                                               # what the issued MFMAs could deliver algorithmically
         # bound of the class on this chip: time its algorithmic FLOPs need on the pipe vs its algorithmic bytes on HBM

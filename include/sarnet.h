@@ -279,6 +279,17 @@ int sar_conv2d_f16(const void* src, const void* src2, const void* src3, const vo
                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
 int sar_conv2d_last_class_f16(int* out6);
 int sar_conv2d_pair_f16(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
+/* The MIXED BACKWARD of the split-precision mode (round 5; the reference trains in fp32, model.py:197 -- what replaces its Conv2D input gradients,
+ * resnet.py:39-42,60-63,82-87,113-117, and the BatchNormalization backward in front of them, resnet.py:22-26): sar_conv2d_f16 / sar_conv2d_pair_f16
+ * with the two tensors of the FORWARD pass a gradient launch reads -- src2 (the BatchNorm input of the fill's backward transform, fill 2 / 3) and e_y
+ * (the BatchNorm input of the epilogue's backward sums, epi 2) -- as the FP32 tensors sar_conv2d_x3 left in HBM; src, src3, res, y, side are fp16
+ * gradients under the static scale, wpk the fp16 input-gradient stream (sar_conv_pack_weights_x3 with bit 0 of the table row's last word set).
+ * Forward outputs keep the split-precision arithmetic (north_star's 1e-3); tools/grad_recipe_emulator.py: the flat parameter gradient moves from
+ * 6.8e-4 (split-precision input gradients, fp16 weight-gradient operands) to 9.6e-4 of the exact one. */
+int sar_conv2d_f16a(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
+                    int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
+                    const sarBnRef* fbn, int epi, float* e_bins, const void* e_y, const float* e_saved, sarStream_t stream);
+int sar_conv2d_pair_f16a(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
 int sar_wgrad_reduce_multi_f16(const sarWgradReduce* plans, int n, sarStream_t stream);
 int sar_conv2d_wgrad_batch_f16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                const int* slices_dev, float* slab, sarStream_t stream);
@@ -309,7 +320,9 @@ int sar_stem16_wgrad_f16(const float* x, const float* w, const float* bias, cons
  *   sar_conv2d_x3: `side` is ONE fp16 tensor = fp16(T(src) * side_scale) -- the operand of the weight gradient, which this mode runs
  *     through sar_conv2d_wgrad_batch_f16 (gradient operands carry the fp16 build's static scale, sarWgradConv.ginv undoes it) -- and
  *     side2 (nullable) receives T(src) as fp32 (the materialised block gradient of fill 3, which further convs read);
- *   sar_bn_bwd_apply_x3: `out` is fp32 in TRUE units, out16 (nullable) = fp16(result * out_scale);
+ *   sar_bn_bwd_apply_x3: `out` (nullable since round 5) is fp32 in TRUE units, out16 (nullable) = fp16(result * out_scale);
+ *   sar_conv_pack_weights_x3: bit 0 of a table row's last word = the input-gradient stream of that convolution is a single plane of fp16
+ *     fragments (what sar_conv2d_f16a reads) instead of hi / lo bf16 pairs;
  *   sar_cast_f32_x3: y = x (a copy), y16 (nullable) = fp16(x * scale). */
 int sar_conv_pack_weights_x3(const void* table, int n, int total_blocks, sarStream_t stream);
 int sar_conv_pack_weights_zero_x3(const void* table, int n, int total_blocks, const void* zero_table, int nz, sarStream_t stream);
@@ -327,9 +340,9 @@ int sar_cast_f32_x3(const float* x, void* y, void* y16, float scale, long n, sar
 int sar_cast_x3_f32(const void* x, float* y, long n, sarStream_t stream);
 /* The recompute-form stem in split precision: the 7x7 conv is evaluated with hi / lo planes of the input patch and of the kernel fragments
  * (three MFMAs per block) wherever its output is needed.  pooled: fp32; pooled_h (nullable): the same map as ONE fp16 tensor, the
- * operand of the first residual block's weight gradients.  sar_stem16_wgrad_x3: g_pooled fp32 in true units; the final product
- * dW = im2col^T dy runs single-pass on fp16 operands that carry the scale 1 / bn->ginv (bn->ginv: applied to dW only; the BatchNorm's own
- * parameter gradients come from the true-unit sums of sar_stem16_bwd_reduce_x3). */
+ * operand of the first residual block's weight gradients.  sar_stem16_bwd_reduce_x3 / sar_stem16_wgrad_x3 (round 5): g_pooled is an FP16 tensor
+ * times the static scale 1 / bn->ginv -- what the mixed backward's last input-gradient launches (sar_conv2d_f16a) write -- exactly as in the fp16
+ * build; the final product dW = im2col^T dy runs single-pass on fp16 operands; bn->ginv undoes the scale in dgamma / dbeta and dW. */
 int sar_stem16_stats_x3(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
                         int pad_top, int pad_left, int det, sarStream_t stream);
 int sar_stem16_pool_fwd_x3(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, void* pooled_h, uint8_t* idx, int B, int T, int D,

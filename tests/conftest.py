@@ -13,7 +13,7 @@ def pytest_configure(config):
 # against the oracle / golden fixtures / upstream constants comes first, op level before whole graph, then the sweeps and the full-size
 # property tests, and the multi-process data-parallel tests (two replicas sharing one GPU) last.  Files not named keep their place in the middle.
 _ORDER = ["test_golden_cpu", "test_oracle_ops", "test_host_cpu",
-          "test_upstream_kat", "test_gpu_golden", "test_gpu_ops", "test_gpu_feeder", "test_gpu_stem16", "test_gpu_bf16.py", "test_gpu_bf16_trunk",
+          "test_upstream_kat", "test_gpu_golden", "test_gpu_ops", "test_gpu_feeder", "test_gpu_stem16", "test_gpu_bf16.py", "test_gpu_f16a", "test_gpu_bf16_trunk",
           "test_gpu_model", "test_gpu_bf16_model", "test_gpu_config_sweep", "test_gpu_loss_scale", "test_gpu_fullsize", "test_gpu_convergence",
           "test_gpu_dp"]
 

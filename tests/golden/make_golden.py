@@ -28,7 +28,7 @@ MODEL_KW = dict(input_shape=[64, 80, 1], res_type="res18", res_filters=16, hidde
 # hidden_dim 256: the MFMA recurrence) -- model_golden.npz's res_filters 16 runs the fp32-storage kernels in every mode
 MODEL32_KW = dict(input_shape=[72, 80, 1], res_type="res18", res_filters=32, hidden_dim=256, mto="gvlad", vlad_clusters=6,
                   ghost_clusters=2, disc_enable=True, ctc_enable=True, bpe_classes=24, max_ctc_len=6, metric_loss="arcface")
-MODEL32_GRADS = ("conv2d_1/kernel", "conv2d_1/bias", "conv2d_3/kernel", "conv2d_7/kernel", "conv2d_8/kernel", "conv2d_18/bias", "batch_normalization_2/gamma", "batch_normalization_10/gamma", "batch_normalization_14/beta", "batch_normalization_9/beta",
+MODEL32_GRADS = ("conv2d_1/kernel", "CTC_DS/bias", "conv2d_3/kernel", "conv2d_7/kernel", "conv2d_8/kernel", "conv2d_13/kernel", "batch_normalization_2/gamma", "batch_normalization_10/gamma", "batch_normalization_14/beta", "batch_normalization_9/beta",
                  "CNN_LIN/bias", "CNN_LIN_LN/gamma", "CRNN/forward/bias", "CRNN/backward/bias", "CTC_BIGRU/backward/bias", "ctc_pred/bias", "gvlad_center_assignment/kernel",
                  "gvlad_pool/centers", "AR_BN2/gamma", "y_accent/kernel", "y_disc/W")
 

@@ -104,7 +104,10 @@ def _config_sweep(i, conv_math):
     # ("x3": conv weight gradients, the stem's last product and the hidden_dim-256 recurrence are single-pass fp16 under the loss scale, and more
     # ReLU / max-pool decisions sit within the arithmetic's noise of zero: measured 1e-3 .. 8e-3, the whole-graph bound of tests/test_gpu_bf16_model.py)
     print("sweep %d %s: flat gradient rel. L2 %.3e" % (i, conv_math, (num / den) ** 0.5))
-    assert num ** 0.5 <= {"fp32": 2e-3, "bf16x3_r1": 1e-2, "x3": 3e-2}[conv_math] * den ** 0.5, (i, conv_math, (num / den) ** 0.5)
+    # (B = 1: the 2-D BatchNorms AR_BN1 / AR_BN2 see a batch of one -- their output is beta, every gradient in front of them is zero up to
+    # rounding, in the oracle and on the device: compared against the scale of the parameters' own gradients behind them, not against ~0)
+    floor = 1e-12 * max(float(np.abs(v).max()) for v in ref_g.values()) ** 2 * len(ref_g)
+    assert num ** 0.5 <= {"fp32": 2e-3, "bf16x3_r1": 1e-2, "x3": 3e-2}[conv_math] * max(den, floor) ** 0.5, (i, conv_math, (num / max(den, floor)) ** 0.5)
     if conv_math == "fp32":
         med = float(np.median([np.abs(v).max() for v in ref_g.values()]))
         bad = []
@@ -114,7 +117,7 @@ def _config_sweep(i, conv_math):
                 if not np.abs(g).max() < 1e-4 * med:
                     bad.append((r.name, "zero-grad tensor", 1.0))
                 continue
-            e = np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-3 * med)
+            e = np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-3 * med, 1e-30)
             if not e < 5e-3:
                 bad.append((r.name, float(e), float(np.abs(gr).max())))
         assert len(bad) <= 3 and all(b[1] != "zero-grad tensor" and b[1] < 0.1 for b in bad), (i, med, bad[:10])
