@@ -566,14 +566,51 @@ class SARNetModel:
             segs.append(("adam", self.store.adam_step, None))
             self._run_segments(segs)
             return
-        if os.environ.get("SAR_DP_SEGMENTS", "3") == "2":
+        seg_mode = os.environ.get("SAR_DP_SEGMENTS") or self._dp_default_segments()
+        if seg_mode == "1" and nparts == 3:
+            # ONE graph (round 5): the bucket all-reduces are captured INSIDE the step -- RCCL collectives are capturable; the
+            # collective's stream forks from the capturing stream where the all-reduce is issued and joins where its handle is waited for, so the
+            # replayed graph keeps the overlap of the three-graph form (the 33.6 MB range underneath the backward of stages 1-0 and the stem) without
+            # its host gaps (three graph launches, the host-side wait in front of Adam: +7 % on one rank).  Needs a capturable backend: "nccl"
+            # (= RCCL) or the library's own sar_allreduce_bucket_f32 (SAR_DP_COLLECTIVE=cabi); gloo reduces through the host and keeps three graphs.
+            def step_one():
+                self._seg_heads()
+                self._seg_trunk("01")
+                ws = []
+                lo, hi = self.dp.bounds[2][0], self.dp.bounds[0][1]
+                if hi > lo and all(self.dp.bounds[i][0] == self.dp.bounds[i + 1][1] for i in (0, 1)):
+                    ws.extend(self.dp.allreduce_range(lo, hi, async_op=True))
+                else:
+                    for i in (0, 1, 2):
+                        ws.extend(self.dp.allreduce_bucket(i, async_op=True))
+                self._seg_trunk(2)
+                ws.extend(self.dp.allreduce_bucket(3, async_op=True))
+                [w.wait() for w in ws]
+                self.store.adam_step()
+            if not getattr(self, "_dp_one_graph_failed", False):
+                try:
+                    self._run_segments([("step_dp", step_one, None)])
+                    return
+                except RuntimeError as e:
+                    # a collective that cannot be captured on this stack: say so once and run the three-graph form from here on (the failed capture
+                    # launched nothing; the eager step in front of it was complete)
+                    if self.graph is not None or not (self.use_graph and self._eager_done >= 1):
+                        raise
+                    import warnings
+                    warnings.warn("data-parallel step: capturing the collectives inside the step's HIP graph failed (%s); using three graphs" % (str(e).splitlines()[0],), RuntimeWarning)
+                    self._dp_one_graph_failed = True
+                    torch.cuda.synchronize()
+                    seg_mode = "3"
+            else:
+                seg_mode = "3"
+        if seg_mode == "2":
             # TWO graphs, no overlap: [the whole forward + backward] -> one all-reduce of the flat buffer, waited for -> [L2 + Adam]
             def after_all():
                 works.extend(self.dp.allreduce_range(0, self.store.n, async_op=True))
                 [w.wait() for w in works]
             self._run_segments([("fwd_bwd", (lambda: self._device_step(update=False)), after_all), ("adam", self.store.adam_step, None)])
             return
-        if os.environ.get("SAR_DP_SEGMENTS", "3") == "3" and nparts == 3:
+        if seg_mode in ("3", "1") and nparts == 3:
             # THREE graphs: [forward + heads / GRU backward + trunk backward down to stage 2] -> [stages 1-0 + stem] -> [L2 + Adam].  The
             # first all-reduce covers the tail, stage-3 and stage-2 buckets -- one contiguous 33.6 MB range of the 35 MB at F=32 -- and
             # runs underneath the second graph (~0.6 ms of backward); only the last 1.5 MB is exposed.  The five-graph form above it
@@ -602,6 +639,16 @@ class SARNetModel:
             segs.append(("trunk%d" % part, (lambda part=part: self._seg_trunk(part)), after))
         segs.append(("adam", self.store.adam_step, None))
         self._run_segments(segs)
+
+    def _dp_default_segments(self):
+        """How many HIP graphs the data-parallel step is captured as: "1" where the collectives can be captured with it (backend nccl = RCCL, or
+        the C-ABI collective), "3" otherwise (gloo: host-side reduction); SAR_DP_SEGMENTS overrides ("1" | "2" | "3" | "5")."""
+        import torch.distributed as dist
+        try:
+            capturable = self.dp.cabi is not None or dist.get_backend() == "nccl"
+        except Exception:
+            capturable = False
+        return "1" if (capturable and self.use_graph) else "3"
 
     def train_on_batch(self, x, y=None, return_dict=True, sync=True):
         self._upload(x, y)

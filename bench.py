@@ -463,6 +463,12 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the extra cfg3 / cfg5 timings of the default 1-GPU run")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: whatever else writes to file descriptor 1 -- RCCL prints a version banner there when a communicator
+    # is created, C stdio and all -- goes to stderr; the line itself is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from aesrc2020_amd import parallel
     rank, world, local = parallel.init_from_env()
     if world != args.gpus and world > 1:
@@ -565,7 +571,8 @@ def main():
             res["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(r["kw"], r["input_shape"], r["B"])
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if dist.is_initialized():                       # world > 1, or the forced one-rank data-parallel step (SAR_DP_FORCE=1)
         dist.barrier()
         dist.destroy_process_group()

@@ -21,7 +21,7 @@ GLOBAL_B = 6
 STEPS = 3
 
 
-GRAPHS = {"3": ["adam", "heads_s32", "trunk_s10"], "5": ["adam", "heads", "trunk0", "trunk1", "trunk2"]}   # SAR_DP_SEGMENTS -> captured graphs
+GRAPHS = {"3": ["adam", "heads_s32", "trunk_s10"], "5": ["adam", "heads", "trunk0", "trunk1", "trunk2"], "1": ["step_dp"]}   # SAR_DP_SEGMENTS -> captured graphs
 
 
 def _set_mode(mode):
@@ -78,11 +78,11 @@ def _worker(rank, world, port, q, backend="gloo", via_gpus=False, mode="fp32", s
 
 
 @pytest.mark.parametrize("backend,via_gpus,mode,segments", [("gloo", False, "fp32", "3"), ("gloo", True, "fp32", "3"), ("nccl", True, "fp32", "3"),
-                                                            ("gloo", True, "bf16x3", "3"), ("nccl", True, "bf16x3", "3"),
+                                                            ("gloo", True, "bf16x3", "3"), ("nccl", True, "bf16x3", "3"), ("nccl", True, "bf16x3", "1"),
                                                             ("gloo", True, "bf16", "3"), ("nccl", True, "bf16", "3"), ("gloo", True, "fp32", "5"),
                                                             ("gloo", True, "bf16", "5"), ("gloo", True, "fp32+g16", "3")],
-                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16x3-mode", "rccl-bf16x3-mode", "gloo-bf16-mode",
-                              "rccl-bf16-mode", "gloo-five-graphs", "gloo-bf16-five-graphs", "gloo-bf16-gradient-buckets"])
+                         ids=["gloo-launcher-sharded", "gloo-SAR_Net(gpus=2)", "rccl-SAR_Net(gpus=2)", "gloo-bf16x3-mode", "rccl-bf16x3-mode", "rccl-bf16x3-one-graph",
+                              "gloo-bf16-mode", "rccl-bf16-mode", "gloo-five-graphs", "gloo-bf16-five-graphs", "gloo-bf16-gradient-buckets"])
 def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, segments):
     grad16 = mode.endswith("+g16"); mode = mode.split("+")[0]      # "+g16": SAR_DP_GRAD_DTYPE=bf16 -- the reduced buffer is the sum of the bf16-rounded shard gradients
     import torch.multiprocessing as mp
@@ -210,13 +210,16 @@ def _worker_one_rank(port, q, mode, collective="torch", segments="3"):
 
 
 @pytest.mark.parametrize("mode,collective,segments", [("fp32", "torch", "3"), ("bf16x3", "torch", "3"), ("bf16x3", "cabi", "3"), ("bf16", "torch", "3"),
-                                                      ("bf16", "cabi", "3"), ("bf16", "torch", "5"), ("bf16", "cabi", "5")],
+                                                      ("bf16", "cabi", "3"), ("bf16", "torch", "5"), ("bf16", "cabi", "5"),
+                                                      ("bf16x3", "torch", "1"), ("bf16x3", "cabi", "1"), ("fp32", "torch", "1")],
                          ids=["fp32-torch.distributed", "bf16x3-torch.distributed", "bf16x3-sar_allreduce_bucket", "bf16-torch.distributed",
-                              "bf16-sar_allreduce_bucket", "bf16-five-graphs", "bf16-five-graphs-sar_allreduce_bucket"])
+                              "bf16-sar_allreduce_bucket", "bf16-five-graphs", "bf16-five-graphs-sar_allreduce_bucket",
+                              "bf16x3-one-graph", "bf16x3-one-graph-sar_allreduce_bucket", "fp32-one-graph"])
 def test_rccl_one_rank_segmented_step(mode, collective, segments):
     """RCCL itself on this box: a process group of one rank over backend nccl, the data-parallel step forced on (SAR_DP_FORCE=1).
     Communicator set-up, the all-reduces on RCCL's stream between replays of the five captured graphs and the stream-ordered
-    work.wait() all execute; a one-rank reduction is the identity, so parameters and losses must follow the single-graph step."""
+    work.wait() all execute; a one-rank reduction is the identity, so parameters and losses must follow the single-graph step.
+    segments "1" (round 5, the default over RCCL): the collectives captured INSIDE the one graph of the step."""
     import torch.multiprocessing as mp
     from aesrc2020_amd import _lib
     from aesrc2020_amd.model import SAR_Net
