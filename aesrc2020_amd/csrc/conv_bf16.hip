@@ -534,7 +534,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // (A32: a piece of the gradient fills is three / four 16-byte loads -- two pieces in flight)
     if (p.fill == 0) fill_patch<0, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
     else if (p.fill == 1) fill_patch<1, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else if (p.fill == 2) fill_patch<2, TM, ((X3 || A32) && FU > 2 ? 2 : FU), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+#ifndef SAR_A32_FU2
+#define SAR_A32_FU2 2
+#endif
+    else if (p.fill == 2) fill_patch<2, TM, (X3 && FU > 2 ? 2 : (A32 && FU > SAR_A32_FU2) ? SAR_A32_FU2 : FU), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
     else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
     if constexpr (EARLY && BR) load_epi();
     // ---- per-lane A address
