@@ -168,9 +168,44 @@ __device__ __forceinline__ void wait_vm_n(int n) {      // wave-uniform n in [0,
 }
 
 // 16-byte store that is not kept in the writer's L2 (nobody on this XCD reads it again before the launch ends)
+// SAR_ST_WT (experiment switch, 0 in the shipped build): 1 = the conv's output stores, 2 = also the fills' side stores, as sc1 write-through stores --
+// the bytes leave the XCD's L2 while the block still works instead of in the end-of-kernel write-back (guide: a boundary costs + dirty bytes / 6 TB/s)
+#ifndef SAR_ST_WT
+#define SAR_ST_WT 1
+#endif
+// Columns a thread owns in the epilogue's row pass (round 5: 4 -- one 16-byte read per k-group partial, a 16-byte residual load and ONE output
+// store of 16 bytes (fp32 tensors; 8 bytes in the 2-byte builds) per row instead of two 8-byte rounds: half the instructions of the row pass,
+// and write-through stores at the width where they cost what a plain store costs)
+#ifndef SAR_EPI_EV
+#define SAR_EPI_EV 4
+#endif
+template <int W> __device__ __forceinline__ void ld_words(const void* p, unsigned (&o)[W]) {
+    if constexpr (W == 1) o[0] = *reinterpret_cast<const unsigned*>(p);
+    else if constexpr (W == 2) { const uint2 t = *reinterpret_cast<const uint2*>(p); o[0] = t.x; o[1] = t.y; }
+    else { const uint4 t = *reinterpret_cast<const uint4*>(p); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+}
+// the conv's output store: W 32-bit words.  SAR_ST_WT >= 1: sc1 (write-through: the bytes leave this XCD's L2 while the block still works instead
+// of in the end-of-kernel write-back -- r5: 2.128 -> 2.106 ms per step with 8-byte stores); else non-temporal
+template <int W> __device__ __forceinline__ void st_out(void* dst, const unsigned (&v)[W]) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+#if SAR_ST_WT >= 1
+    if constexpr (W == 1) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(dst), "v"(v[0]) : "memory");
+    else if constexpr (W == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(u32x2_{v[0], v[1]}) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(u32x4_{v[0], v[1], v[2], v[3]}) : "memory");
+#else
+    if constexpr (W == 1) __builtin_nontemporal_store(v[0], reinterpret_cast<unsigned*>(dst));
+    else if constexpr (W == 2) __builtin_nontemporal_store(u32x2_{v[0], v[1]}, reinterpret_cast<u32x2_*>(dst));
+    else __builtin_nontemporal_store(u32x4_{v[0], v[1], v[2], v[3]}, reinterpret_cast<u32x4_*>(dst));
+#endif
+}
 __device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#if SAR_ST_WT >= 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(u32x4{v.x, v.y, v.z, v.w}) : "memory");
+#else
     __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(dst));
+#endif
 }
 
 // Patch fill.  rowtab[prow] = {element offset of the source row's first pixel (or NONE), owner output pixel of that pixel};
@@ -376,8 +411,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     constexpr int NG = BR ? WN : WMX * WN, NW = NG * KG, NTHR = 64 * NW, KPF = NKC / KG;   // waves per k-group, waves, threads, fragments per virtual tap and group
     constexpr int WM = WMX, TM = 32 * WM, TN = 32 * WN;
     static_assert(BR || (WN * 8) % NW == 0 || (X3 && WN * 4 < NW), "stage DMA must divide evenly");
-    static_assert(NTHR % (TN / 2) == 0 && TM % (NTHR / (TN / 2)) == 0, "epilogue maps must divide evenly");
-    constexpr int CP = TN / 2, RG = NTHR / CP, RPT = TM / RG;      // epilogue: column pairs, row groups, rows per thread
+    constexpr int EV = SAR_EPI_EV;                                 // columns per thread in the epilogue's row pass
+    static_assert(NTHR % (TN / EV) == 0 && TM % (NTHR / (TN / EV)) == 0, "epilogue maps must divide evenly");
+    constexpr int CP = TN / EV, RG = NTHR / CP, RPT = TM / RG;     // epilogue: column groups, row groups, rows per thread
     constexpr int KS = VT % 9 == 0 ? 3 : 1, NH = VT / (KS * KS);  // taps per side, channel parts per tap
     // fragments per ring stage and channel tile: 8; 4 in the split-precision forms of the 32-channel sources (CO2 below: a 12 KB ring leaves
     // room for TWO eight-wave blocks, 2 x 77.8 KB, in a CU's LDS; the four-wave forms -- the stride-2 entry of stage 1 and its shortcut -- likewise)
@@ -418,39 +454,42 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // ---- epilogue operands that do not depend on the accumulators (bias, residual, BatchNorm constants and input of the
     // backward sums): requested first, consumed ~10 us later
     const int cp = tid % CP, rg = tid / CP;
-    const int c = n0 + 2 * cp;
+    const int c = n0 + EV * cp;
     // (the per-channel constants travel with the per-pixel operands in load_epi: held from kernel entry, the eight-wave forms -- 128 registers --
     // spilled them behind a vmcnt(0) at the top of the kernel)
-    float b0 = 0.f, b1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f, mu0 = 0.f, mu1 = 0.f, rs0 = 0.f, rs1 = 0.f;
+    float bv[EV], scv[EV], shv[EV], muv[EV], rsv[EV];
+#pragma unroll
+    for (int j = 0; j < EV; ++j) { bv[j] = 0.f; scv[j] = 0.f; shv[j] = 0.f; muv[j] = 0.f; rsv[j] = 0.f; }
     // (a 128-register variant for four blocks per CU -- these loads after the k-phase, two fill pieces in flight -- needs the
     // 32-channel layers' LDS at 40 KB, i.e. a 2-deep weight ring: see the ring comment; with the 3-deep ring they fit three per CU
     // and the variant was slower, 23 vs 17 us per stage-0 launch)
     constexpr bool EARLY = NG != 8;                                 // (the eight-wave form lives on 128 registers: operands loaded behind the k-phase)
-    constexpr int NYV = A32 ? 2 : NPL;                              // words of an e_y column pair: A32: two fp32 values
-    unsigned rv[RPT][NPL], yv[RPT][NYV];
+    constexpr int WR = X3 ? EV : EV / 2;                            // 32-bit words of the EV residual values of a row (fp32 tensors / 2-byte pairs)
+    constexpr int WY = (X3 || A32) ? EV : EV / 2;                   // ... of the EV values of e_y (A32: the forward pass's fp32 tensor)
+    unsigned rv[RPT][WR], yv[RPT][WY];
     auto load_epi = [&]() __attribute__((always_inline)) {
-        if (p.bias) { b0 = p.bias[c]; b1 = p.bias[c + 1]; }
+        if (p.bias) {
+            unsigned t[EV]; ld_words<EV>(p.bias + c, t);
+#pragma unroll
+            for (int j = 0; j < EV; ++j) bv[j] = __uint_as_float(t[j]);
+        }
         if (p.epi == 2) {
             const float* sv = p.e_saved; const int C = p.Cout;
-            mu0 = sv[c]; mu1 = sv[c + 1]; rs0 = sv[C + c]; rs1 = sv[C + c + 1];
-            sc0 = sv[2 * C + c]; sc1 = sv[2 * C + c + 1]; sh0 = sv[3 * C + c]; sh1 = sv[3 * C + c + 1];
+            unsigned t0[EV], t1[EV], t2[EV], t3[EV];
+            ld_words<EV>(sv + c, t0); ld_words<EV>(sv + C + c, t1); ld_words<EV>(sv + 2 * C + c, t2); ld_words<EV>(sv + 3 * C + c, t3);
+#pragma unroll
+            for (int j = 0; j < EV; ++j) { muv[j] = __uint_as_float(t0[j]); rsv[j] = __uint_as_float(t1[j]); scv[j] = __uint_as_float(t2[j]); shv[j] = __uint_as_float(t3[j]); }
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const unsigned m = min(m0 + rg + RG * i, M - 1);
             const size_t o = (size_t)m * p.Cout + c;
-            if constexpr (X3) {                                    // fp32 tensors: the column pair (c, c + 1) = eight bytes
-                const uint2 z2 = make_uint2(0u, 0u);
-                const uint2 r2 = p.res ? *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(p.res) + o) : z2;
-                const uint2 y2 = p.epi == 2 ? *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(p.e_y) + o) : z2;
-                rv[i][0] = r2.x; rv[i][NPL - 1] = r2.y; yv[i][0] = y2.x; yv[i][NPL - 1] = y2.y;
-            } else {
-                rv[i][0] = p.res ? *reinterpret_cast<const unsigned*>(p.res + o) : 0u;
-                if constexpr (A32) {                                // e_y: the forward pass's fp32 tensor
-                    const uint2 y2 = p.epi == 2 ? *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(p.e_y) + o) : make_uint2(0u, 0u);
-                    yv[i][0] = y2.x; yv[i][NYV - 1] = y2.y;
-                } else yv[i][0] = p.epi == 2 ? *reinterpret_cast<const unsigned*>(p.e_y + o) : 0u;
-            }
+#pragma unroll
+            for (int j = 0; j < WR; ++j) rv[i][j] = 0u;
+#pragma unroll
+            for (int j = 0; j < WY; ++j) yv[i][j] = 0u;
+            if (p.res) { if constexpr (X3) ld_words<WR>(reinterpret_cast<const float*>(p.res) + o, rv[i]); else ld_words<WR>(p.res + o, rv[i]); }
+            if (p.epi == 2) { if constexpr (X3 || A32) ld_words<WY>(reinterpret_cast<const float*>(p.e_y) + o, yv[i]); else ld_words<WY>(p.e_y + o, yv[i]); }
         }
     };
     // (when they are requested: consumed behind the k-phase, ~8 000 cycles of work, so nothing is gained by asking first -- and their
@@ -692,43 +731,59 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     }
     lds_barrier();
     TSTAMP(9);
-    float s10 = 0.f, s11 = 0.f, s20 = 0.f, s21 = 0.f;
-    long long q10 = 0, q11 = 0, q20 = 0, q21 = 0;                  // epi 3: the same sums in 64-bit fixed point (trunk16.h: fix28)
+    float s1[EV], s2[EV];
+    long long q1[EV], q2[EV];                                      // epi 3: the same sums in 64-bit fixed point (trunk16.h: fix28)
+#pragma unroll
+    for (int j = 0; j < EV; ++j) { s1[j] = 0.f; s2[j] = 0.f; q1[j] = 0; q2[j] = 0; }
+    typedef __attribute__((ext_vector_type(EV))) float fEV;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int row = rg + RG * i;
         const unsigned m = m0 + row;
-        float2 a = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + row * TN + 2 * cp);
+        fEV a = *reinterpret_cast<const fEV*>(reinterpret_cast<const float*>(patch) + row * TN + EV * cp);
 #pragma unroll
-        for (int kk = 1; kk < KG; ++kk) {                           // the other k-groups' partial tiles
-            const float2 a2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(patch) + kk * (TM * TN) + row * TN + 2 * cp);
-            a.x += a2.x; a.y += a2.y;
+        for (int kk = 1; kk < KG; ++kk)                             // the other k-groups' partial tiles
+            a += *reinterpret_cast<const fEV*>(reinterpret_cast<const float*>(patch) + kk * (TM * TN) + row * TN + EV * cp);
+        float v[EV];
+#pragma unroll
+        for (int j = 0; j < EV; ++j) {
+            v[j] = a[j] + bv[j];
+            if constexpr (X3) v[j] += __uint_as_float(rv[i][j]);
+            else v[j] += (j & 1) ? h_hi(rv[i][j >> 1]) : h_lo(rv[i][j >> 1]);
         }
-        float v0 = a.x + b0, v1 = a.y + b1;
-        if constexpr (X3) { v0 += __uint_as_float(rv[i][0]); v1 += __uint_as_float(rv[i][NPL - 1]); }
-        else { v0 += h_lo(rv[i][0]); v1 += h_hi(rv[i][0]); }
         if (m < M && (unsigned)row < TMV) {
-            unsigned pk = 0u;
-            if constexpr (X3) {                                    // the fp32 pair as it is
-                typedef __attribute__((ext_vector_type(2))) float f2v;
-                __builtin_nontemporal_store(f2v{v0, v1}, reinterpret_cast<f2v*>(reinterpret_cast<float*>(p.y) + (size_t)m * p.Cout + c));
+            if constexpr (X3) {                                    // the fp32 values as they are
+                unsigned w[EV];
+#pragma unroll
+                for (int j = 0; j < EV; ++j) w[j] = __float_as_uint(v[j]);
+                st_out<EV>(reinterpret_cast<float*>(p.y) + (size_t)m * p.Cout + c, w);
             } else {
-                pk = pack2(v0, v1);
-                __builtin_nontemporal_store(pk, reinterpret_cast<unsigned*>(p.y + (size_t)m * p.Cout + c));
+                unsigned w[EV / 2];
+#pragma unroll
+                for (int j = 0; j < EV / 2; ++j) w[j] = pack2(v[2 * j], v[2 * j + 1]);
+                st_out<EV / 2>(p.y + (size_t)m * p.Cout + c, w);
+                // forward statistics: of what was stored (the consumer normalises the stored values)
+                if (p.epi == 1 || p.epi == 3) {
+#pragma unroll
+                    for (int j = 0; j < EV / 2; ++j) { v[2 * j] = h_lo(w[j]); v[2 * j + 1] = h_hi(w[j]); }
+                }
             }
-            // forward statistics: of what was stored (the consumer normalises the stored values); backward sums: of the fp32
-            // values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
-            if (p.epi == 1 || p.epi == 3) {
-                if constexpr (!X3) { v0 = h_lo(pk); v1 = h_hi(pk); }
-                if (p.epi == 1) { s10 += v0; s11 += v1; s20 += v0 * v0; s21 += v1 * v1; }
-                else { q10 += fix28(v0); q11 += fix28(v1); q20 += fix28(fminf(v0 * v0, 8.0e6f)); q21 += fix28(fminf(v1 * v1, 8.0e6f)); }
-            }
-            if (p.epi == 2) {
-                float y0, y1;
-                if constexpr (X3 || A32) { y0 = __uint_as_float(yv[i][0]); y1 = __uint_as_float(yv[i][NYV - 1]); }
-                else { y0 = h_lo(yv[i][0]); y1 = h_hi(yv[i][0]); }
-                const float d0 = fmaf(y0, sc0, sh0) > 0.f ? v0 : 0.f, d1 = fmaf(y1, sc1, sh1) > 0.f ? v1 : 0.f;
-                s10 += d0; s11 += d1; s20 += d0 * (y0 - mu0) * rs0; s21 += d1 * (y1 - mu1) * rs1;
+            // backward sums: of the fp32 values (they are parameter gradients -- near-cancelling sums that the 2^-9 storage rounding would dominate)
+            if (p.epi == 1) {
+#pragma unroll
+                for (int j = 0; j < EV; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            } else if (p.epi == 3) {
+#pragma unroll
+                for (int j = 0; j < EV; ++j) { q1[j] += fix28(v[j]); q2[j] += fix28(fminf(v[j] * v[j], 8.0e6f)); }
+            } else if (p.epi == 2) {
+#pragma unroll
+                for (int j = 0; j < EV; ++j) {
+                    float y;
+                    if constexpr (X3 || A32) y = __uint_as_float(yv[i][j]);
+                    else y = (j & 1) ? h_hi(yv[i][j >> 1]) : h_lo(yv[i][j >> 1]);
+                    const float d = fmaf(y, scv[j], shv[j]) > 0.f ? v[j] : 0.f;
+                    s1[j] += d; s2[j] += d * (y - muv[j]) * rsv[j];
+                }
             }
         }
     }
@@ -736,8 +791,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     if (p.epi == 0) { TSTAMP(7); TSTAMP(15); return; }              // kernel-uniform
     if (p.epi == 3) {                                              // integer partials, integer atomics: order-independent
         long long* partq = reinterpret_cast<long long*>(part);
-        partq[(rg * TN + 2 * cp) * 2 + 0] = q10; partq[(rg * TN + 2 * cp) * 2 + 1] = q20;
-        partq[(rg * TN + 2 * cp + 1) * 2 + 0] = q11; partq[(rg * TN + 2 * cp + 1) * 2 + 1] = q21;
+#pragma unroll
+        for (int j = 0; j < EV; ++j) { partq[(rg * TN + EV * cp + j) * 2 + 0] = q1[j]; partq[(rg * TN + EV * cp + j) * 2 + 1] = q2[j]; }
         lds_barrier();
         if (tid < 2 * TN) {
             const int cc = tid >> 1, which = tid & 1;
@@ -749,8 +804,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         TSTAMP(7); TSTAMP(15);
         return;
     }
-    part[(rg * TN + 2 * cp) * 2 + 0] = s10; part[(rg * TN + 2 * cp) * 2 + 1] = s20;
-    part[(rg * TN + 2 * cp + 1) * 2 + 0] = s11; part[(rg * TN + 2 * cp + 1) * 2 + 1] = s21;
+#pragma unroll
+    for (int j = 0; j < EV; ++j) { part[(rg * TN + EV * cp + j) * 2 + 0] = s1[j]; part[(rg * TN + EV * cp + j) * 2 + 1] = s2[j]; }
     lds_barrier();
     if (tid < 2 * TN) {
         const int cc = tid >> 1, which = tid & 1;
@@ -1588,7 +1643,7 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     const int KG = br ? (Cin >= 128 ? 4 : 2) : 1;                                  // k-groups (BR: eight waves at 128+ source channels, four at 64)
     const int nthr = br ? 128 * KG : tm256 ? 512 : 256;
     if (p.cap_rows > nthr) return SAR_EINVAL;                                      // one thread per row of the row table
-    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / 2) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
+    const size_t stage_bytes = (size_t)KG * TM * TN * 4 + (size_t)nthr / (TN / SAR_EPI_EV) * TN * 2 * 8;   // partial rows: 8 bytes per entry (epi 3)
     // the long k-loops of the 128+-channel ring layers get a 4-deep weight ring where it fits
     p.rd = (Cin >= 128 && (size_t)6 * Cin * 4 + ROWTAB_BYTES + ((patch_bytes + 1023) & ~(size_t)1023) + (size_t)4 * WN * 8 * 1024 <= 160 * 1024) ? 4 : 3;
     const int SF = (X3 && !br && Cin == 32) ? 4 : 8;                               // fragments per ring stage (conv_body: CO2)
