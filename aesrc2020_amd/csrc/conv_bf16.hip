@@ -255,7 +255,7 @@ __device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const ui
 template <int MODE, int TM, int U, int NTHR, bool A32, typename MID>
 __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
-                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, MID&& mid) {
+                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, unsigned tmv, MID&& mid) {
     const unsigned pc = 1u << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
     const unsigned rsub = udiv((unsigned)tid, mg_cw, cw), col = tid - rsub * cw, rpi = udiv((unsigned)NTHR, mg_cw, cw);   // row of the trip, column piece, rows per trip
@@ -289,7 +289,7 @@ __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict
         for (int j = 0; j < U; ++j) {
             const uint4 r = xform16<MODE, A32>(q[j], q2[j], q2b[j], q3[j], k);
             *reinterpret_cast<uint4*>(patch + lo[j]) = off[j] == NONE ? make_uint4(0, 0, 0, 0) : r;
-            if (do_side && off[j] != NONE && own[j] < (unsigned)TM) nt_store16(side + off[j], r);
+            if (do_side && off[j] != NONE && own[j] < tmv) nt_store16(side + off[j], r);   // (tmv: the pixels this block OWNS, <= TM)
         }
     };
     issue(rsub);                                                   // trip 0, peeled: `mid` between its loads and their use
@@ -302,7 +302,7 @@ template <int MODE, int TM, int U, int NTHR, bool A32, typename MID>
 __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch, const float* cst, const uint2* rowtab,
                                            unsigned nrows, unsigned m0, int tid, bool first_ntile, MID&& mid) {
     if constexpr (!X3) {
-        fill_patch16<MODE, TM, U, NTHR, A32>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, mid);
+        fill_patch16<MODE, TM, U, NTHR, A32>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, (unsigned)p.tmv, mid);
         return;
     }
     const Geo& g = p.g;
@@ -436,7 +436,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // tensors).  Here XCD c takes the c-th contiguous eighth of the sequence (channel tile fastest, then pixel tile).
     const unsigned chunk8 = ntot >> 3, tord = lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
     const unsigned bx = tord >> __builtin_ctz(nty), by = tord & (nty - 1);   // Cout / TN: a power of two
-    const unsigned TMV = (X3 || (BR && WMX == 1)) ? (unsigned)p.tmv : (unsigned)TM;   // pixels this block owns
+    const unsigned TMV = (X3 || BR) ? (unsigned)p.tmv : (unsigned)TM;   // pixels this block owns
     const unsigned m0 = bx * TMV;
     const int n0 = by * TN;
     const unsigned M = (unsigned)g.M;
@@ -1628,7 +1628,8 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     // recompute the neighbour's and are dropped (the k-phase does not shrink), but the fill, the epilogue and the statistics -- two thirds of a
     // block's life -- do, and the idle CUs take the extra tiles: stage 3 at 39 owned pixels = 256 blocks, 22.3 -> 21.1 us forward, 25-27 -> 23.4-24
     // backward (a block's fixed latency chain, not its pixel count, is most of its life: DESIGN 5.00).
-    if (X3 && br && p.tmv == TM) {
+    // (round 5: every build -- the mixed backward's input gradients of stage 3 run in the fp16 build)
+    if (br && p.tmv == TM) {
         const long tiles = cdiv(p.g.M, TM), nty = Cout / TN, cus = cu_count();
         if (tiles * nty * 20 <= cus * 17) {                                        // at most 85 % of one round
             const long slots = cus / nty;
