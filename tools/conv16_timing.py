@@ -43,7 +43,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
     wf = torch.zeros(nf, dtype=BF, device="cuda"); wd = torch.zeros(nd, dtype=BF, device="cuda")
     tab = torch.tensor([[w.data_ptr(), wf.data_ptr(), wd.data_ptr(), taps, Cin, Cout, 0, 0]], dtype=torch.int64, device="cuda")
     lib.sar_conv_pack_weights_bf16(tab.data_ptr(), 1, -(-(nf + nd) // 8 // 256), st)
-    bins = torch.zeros(16, 2, Cout, device="cuda")
+    bins = torch.zeros(32, 2, Cout, device="cuda")
     if mode == "wgrad":
         continue
     elif mode == "fwd1":
@@ -54,7 +54,7 @@ for name, H, W, Cin, Cout, k in SHAPES:
                        [(n, ctypes.c_float) for n in ("inv_n", "unbias", "eps", "momentum")] + [("write", ci), ("ginv", ctypes.c_float), ("det", ci), ("pad_", ci)]
         n = B * H * W
         gam = torch.ones(Cin, device="cuda"); bet = torch.zeros(Cin, device="cuda"); saved = torch.zeros(4, Cin, device="cuda")
-        fbins = torch.zeros(16, 2, Cin, device="cuda"); fbins[0, 1] = float(n)      # mean 0, variance 1
+        fbins = torch.zeros(32, 2, Cin, device="cuda"); fbins[0, 1] = float(n)      # mean 0, variance 1
         res = planes(torch.randn(B, H, W, Cout, device="cuda")); side = torch.empty(B, H, W, Cin, device="cuda", dtype=torch.float16 if X3 else BF)
         bn = BN(gam.data_ptr(), bet.data_ptr(), fbins.data_ptr(), None, saved.data_ptr(), None, None, None, None, 1.0 / n, 1.0, 1e-3, 0.99, 0, 1.0, 0, 0)
         keepalive = (gam, bet, saved, fbins, res, side, bn)
