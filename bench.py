@@ -43,7 +43,7 @@ WORKLOADS = {
 }
 
 
-def kernel_times_in_step(step, n=6):
+def kernel_times_in_step(step, n=6, record=True):
     """Per-kernel GPU time INSIDE the train step, measured live in this process: `n` replays of the captured step under torch.profiler
     (roctracer activity records: every kernel of a replayed HIP graph gets its own begin / end timestamps) -> {kernel name: (calls per
     step, average microseconds per call)}.  This is what rocprofv3 --kernel-trace --stats reports for the same command (profiles/)."""
@@ -52,6 +52,13 @@ def kernel_times_in_step(step, n=6):
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
+    if not record:
+        # N > 1: a data-parallel step holds collectives, so EVERY rank runs the same steps; only rank 0 records them (round 5: rank 0 alone stepping
+        # here hung / aborted the other ranks' collectives -- the N > 1 bench had never run with this measurement in it)
+        for i in range(n):
+            step(i)
+        torch.cuda.synchronize()
+        return None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -426,7 +433,7 @@ def run_workload(name, args, rank, world, with_extras, batch=None):
     res = dict(value=round(world * B * args.steps / dt, 2), ms_per_step=round(dt / args.steps * 1e3, 4), workload=wl["desc"], B=B, T=T,
                params=model.count_params(), final_loss=round(logs["loss"], 4), kw=kw, input_shape=input_shape,
                dropped=model.store.dropped_gradient_elements(), regions_ms=[round(d / args.steps * 1e3, 4) for d in region_dts])      # fp16 operands: optimiser steps skipped because a gradient was not finite
-    res["in_step"] = kernel_times_in_step(step) if (with_extras and rank == 0 and not args.no_graph and not args.no_roofline) else None
+    res["in_step"] = kernel_times_in_step(step, record=rank == 0) if (with_extras and not args.no_graph and not args.no_roofline) else None
     return res, model
 
 
