@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void margin_train_kernel(const float* __restric
                                                           const float* __restrict__ W, float* __restrict__ probs, float* __restrict__ loss,
                                                           float* __restrict__ inv_w, float* __restrict__ dx, float* __restrict__ dwn,
                                                           int D, int A, int mode, float s, float m, int accumulate_dx) {
-    margin_train_body<CACHE>(blockIdx.x, threadIdx.x, x, y, y_true, dloss, W, probs, loss, inv_w, dx, dwn, D, A, mode, s, m, accumulate_dx);
+    margin_train_body<CACHE>(blockIdx.x, threadIdx.x, x, y, y_true, dloss, W, probs, loss, inv_w, dx + (long)blockIdx.x * D, dwn, D, A, mode, s, m, accumulate_dx);
 }
 template <bool CLEAR>
 __global__ __launch_bounds__(64) void margin_wbwd_kernel(float* __restrict__ dwn, const float* __restrict__ W,

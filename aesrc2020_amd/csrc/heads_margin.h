@@ -8,66 +8,12 @@ namespace {
 enum { HEAD_SPHERE = 0, HEAD_COS = 1, HEAD_ARC = 2 };
 constexpr float KEPS = 1e-7f;
 
-// Forward + Keras categorical_crossentropy + backward of one sample in ONE wave (margin_fwd_kernel, cce_fwd / cce_bwd, margin_bwd_kernel
-// back to back on the same lanes: lane a < A owns class a): the training step's six launches around the head become two (this + the
-// column-normalisation backward).  grid = B, block = 64.  dwn (D,A): zero on entry (margin_wbwd_kernel<true> leaves it zero again).
-// CACHE: the wave keeps its slice of W in registers (A <= 8, D <= 256: the reference's 8 accents on a 256-wide embedding) -- every
-// operand of the sample is requested in ONE memory phase; looping over the classes with the loads inside was ~15 dependent round trips
-// (29 us for 4 KB of arithmetic).
-// DXA (round 5, the one-launch heads of heads_fused.hip): the input gradient is ADDED to dx with fp32 atomics (dx zero at step start; the accent
-// classifier's blocks of the same launch add theirs the same way: two addends per element, so the sum does not depend on their order).
-template <bool CACHE, bool DXA = false>
-__device__ __forceinline__ void margin_train_body(const int b, const int lane, const float* __restrict__ x, const float* __restrict__ y,
-                                                  const float* __restrict__ y_true, const float* __restrict__ dloss,
-                                                  const float* __restrict__ W, float* __restrict__ probs, float* __restrict__ loss,
-                                                  float* __restrict__ inv_w, float* __restrict__ dx, float* __restrict__ dwn,
-                                                  int D, int A, int mode, float s, float m, int accumulate_dx) {
-    const float* xr = x + (long)b * D;
-    float xv[4], wv[4][8], dxo[4];
-    if constexpr (CACHE) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int d = min(lane + 64 * i, D - 1);
-            xv[i] = lane + 64 * i < D ? xr[d] : 0.f;
-            dxo[i] = (!DXA && accumulate_dx) ? dx[(long)b * D + d] : 0.f;
-            const float4 w0 = *reinterpret_cast<const float4*>(W + (long)d * A), w1 = A > 4 ? *reinterpret_cast<const float4*>(W + (long)d * A + 4) : make_float4(0, 0, 0, 0);
-            const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int a = 0; a < 8; ++a) wv[i][a] = (lane + 64 * i < D && a < A) ? ws[a] : 0.f;
-        }
-    }
-    const float yy = lane < A ? y[(long)b * A + lane] : 0.f;
-    const float yt = lane < A ? y_true[(long)b * A + lane] : 0.f;
-    const float gl = dloss[b];
-    float sx = 0.f;
-    if constexpr (CACHE) { for (int i = 0; i < 4; ++i) sx = fmaf(xv[i], xv[i], sx); }
-    else for (int d = lane; d < D; d += 64) sx = fmaf(xr[d], xr[d], sx);
-    sx = wave_sum(sx);
-    const float ix = 1.f / sqrtf(fmaxf(sx, 1e-12f));
-    float my_logit = -INFINITY, c = 0.f, my_iw = 0.f;
-    auto fwd_class = [&](int a, float sw, float dot) __attribute__((always_inline)) {
-        sw = wave_sum(sw); dot = wave_sum(dot);
-        const float iw = 1.f / sqrtf(fmaxf(sw, 1e-12f));
-        if (lane == a) {
-            c = dot * ix * iw; my_iw = iw;
-            if (b == 0) inv_w[a] = sw >= 1e-12f ? iw : -iw;
-        }
-    };
-    if constexpr (CACHE) {
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            float sw = 0.f, dot = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { sw = fmaf(wv[i][a], wv[i][a], sw); dot = fmaf(xv[i], wv[i][a], dot); }
-            if (a < A) fwd_class(a, sw, dot);                       // wave-uniform
-        }
-    } else {
-        for (int a = 0; a < A; ++a) {
-            float sw = 0.f, dot = 0.f;
-            for (int d = lane; d < D; d += 64) { const float w = W[(long)d * A + a]; sw = fmaf(w, w, sw); dot = fmaf(xr[d], w, dot); }
-            fwd_class(a, sw, dot);
-        }
-    }
+// One sample's class-level arithmetic on one wave (lane a < A owns class a; c = its cosine): margin logits -> softmax -> Keras
+// categorical_crossentropy -> the backward of all three; writes probs / loss, returns d loss / d cos of the lane's class.
+__device__ __forceinline__ float margin_row_math(const int b, const int lane, const int A, const int mode, const float s, const float m,
+                                                 const float c, const float yy, const float yt, const float gl,
+                                                 float* __restrict__ probs, float* __restrict__ loss) {
+    float my_logit = -INFINITY;
     if (lane < A) {
         float t;
         if (mode == HEAD_COS) t = c - m;
@@ -104,6 +50,70 @@ __device__ __forceinline__ void margin_train_body(const int b, const int lane, c
         }
         dc = s * dlog * ((1.f - yy) + yy * dt);
     }
+    return dc;
+}
+
+// Forward + Keras categorical_crossentropy + backward of one sample in ONE wave (margin_fwd_kernel, cce_fwd / cce_bwd, margin_bwd_kernel
+// back to back on the same lanes: lane a < A owns class a): the training step's six launches around the head become two (this + the
+// column-normalisation backward).  grid = B, block = 64.  dwn (D,A): zero on entry (margin_wbwd_kernel<true> leaves it zero again).
+// CACHE: the wave keeps its slice of W in registers (A <= 8, D <= 256: the reference's 8 accents on a 256-wide embedding) -- every
+// operand of the sample is requested in ONE memory phase; looping over the classes with the loads inside was ~15 dependent round trips
+// (29 us for 4 KB of arithmetic).
+// dxrow: the sample's row of the input gradient; dwn: the (D,A) sum over the samples of the normalised-kernel gradient, added with fp32
+// atomics -- both may be LDS (heads_fused.hip, round 5: the accent classifier's workgroup runs the margin head of its rows on spare waves).
+template <bool CACHE>
+__device__ __forceinline__ void margin_train_body(const int b, const int lane, const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ y_true, const float* __restrict__ dloss,
+                                                  const float* __restrict__ W, float* __restrict__ probs, float* __restrict__ loss,
+                                                  float* __restrict__ inv_w, float* dxrow, float* dwn,
+                                                  int D, int A, int mode, float s, float m, int accumulate_dx) {
+    const float* xr = x + (long)b * D;
+    float xv[4], wv[4][8], dxo[4];
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = min(lane + 64 * i, D - 1);
+            xv[i] = lane + 64 * i < D ? xr[d] : 0.f;
+            dxo[i] = accumulate_dx ? dxrow[d] : 0.f;
+            const float4 w0 = *reinterpret_cast<const float4*>(W + (long)d * A), w1 = A > 4 ? *reinterpret_cast<const float4*>(W + (long)d * A + 4) : make_float4(0, 0, 0, 0);
+            const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int a = 0; a < 8; ++a) wv[i][a] = (lane + 64 * i < D && a < A) ? ws[a] : 0.f;
+        }
+    }
+    const float yy = lane < A ? y[(long)b * A + lane] : 0.f;
+    const float yt = lane < A ? y_true[(long)b * A + lane] : 0.f;
+    const float gl = dloss[b];
+    float sx = 0.f;
+    if constexpr (CACHE) { for (int i = 0; i < 4; ++i) sx = fmaf(xv[i], xv[i], sx); }
+    else for (int d = lane; d < D; d += 64) sx = fmaf(xr[d], xr[d], sx);
+    sx = wave_sum(sx);
+    const float ix = 1.f / sqrtf(fmaxf(sx, 1e-12f));
+    float c = 0.f, my_iw = 0.f;
+    auto fwd_class = [&](int a, float sw, float dot) __attribute__((always_inline)) {
+        sw = wave_sum(sw); dot = wave_sum(dot);
+        const float iw = 1.f / sqrtf(fmaxf(sw, 1e-12f));
+        if (lane == a) {
+            c = dot * ix * iw; my_iw = iw;
+            if (b == 0) inv_w[a] = sw >= 1e-12f ? iw : -iw;
+        }
+    };
+    if constexpr (CACHE) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            float sw = 0.f, dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sw = fmaf(wv[i][a], wv[i][a], sw); dot = fmaf(xv[i], wv[i][a], dot); }
+            if (a < A) fwd_class(a, sw, dot);                       // wave-uniform
+        }
+    } else {
+        for (int a = 0; a < A; ++a) {
+            float sw = 0.f, dot = 0.f;
+            for (int d = lane; d < D; d += 64) { const float w = W[(long)d * A + a]; sw = fmaf(w, w, sw); dot = fmaf(xr[d], w, dot); }
+            fwd_class(a, sw, dot);
+        }
+    }
+    const float dc = margin_row_math(b, lane, A, mode, s, m, c, yy, yt, gl, probs, loss);
     float proj = 0.f;
     float dxn_l[8];
 #pragma unroll
@@ -147,9 +157,8 @@ __device__ __forceinline__ void margin_train_body(const int b, const int lane, c
         if (d < D) {
             const float xd = CACHE ? xv[i < 4 ? i : 0] : xr[d];
             const float g = (dxn_l[i] - xd * ix * proj) * ix;
-            float* dst = dx + (long)b * D + d;
-            if (DXA) atomicAdd(dst, g);
-            else if (CACHE) *dst = dxo[i < 4 ? i : 0] + g;
+            float* dst = dxrow + d;
+            if (CACHE) *dst = dxo[i < 4 ? i : 0] + g;
             else *dst = accumulate_dx ? *dst + g : g;
         }
     }

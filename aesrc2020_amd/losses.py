@@ -59,6 +59,19 @@ class _MarginHead(Layer):
               self.MODE, self.s, self.m, 1 if accumulate_dx else 0)
         return self.probs, loss
 
+    def train_buffers(self, x, y, B):
+        """Buffers of the training step when another launch runs it (model.py: sar_accent_margin_train_f32): -> (workspace of D*A + 1
+        words the kernel keeps zero, probs, per-sample loss, inv_w)."""
+        D, A = self.D, self.n_classes
+        self.x, self.y, self.B = x, y, B
+        self.probs = self.buf("probs", (B, A)); self.inv_w = self.buf("inv_w", (A,))
+        key = self.name + "/dwn_ws1"
+        fresh = key not in self.store.bufs.d
+        ws = self.buf("dwn_ws1", (D * A + 1,))
+        if fresh:
+            ws.zero_()
+        return ws, self.probs, self.buf("loss", (B,)), self.inv_w
+
     def backward(self, dprobs, dx_out=None, accumulate_dx=False):
         B, D, A = self.B, self.D, self.n_classes
         dx = dx_out if dx_out is not None else self.buf("dx", (B, D))

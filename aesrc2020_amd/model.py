@@ -320,10 +320,11 @@ class SARNetModel:
                 d.copy_(s.view(d.shape))
 
     # ------------------------------------------------------------------ forward / backward plans
-    def _accent_classifier(self, ar, mode):
+    def _accent_classifier(self, ar, mode, margin=False):
         """AR_CF_DS1 -> AR_CF_DS2 -> y_accent (+ categorical cross-entropy, + the whole backward down to d(ar) in mode 'train') in one
         launch (csrc/heads_fused.hip): 15 launches of ~1 us of arithmetic otherwise.  The layers keep their parameters, names,
-        `.output` tensors and gradient buffers; only who computes them changes."""
+        `.output` tensors and gradient buffers; only who computes them changes.
+        margin: the same launch also runs the margin head's training step (forward, cross-entropy, backward; `_fuse_margin`)."""
         l1, l2, l3 = self.AR_CF_DS1, self.AR_CF_DS2, self.y_accent
         B = self.B
         h1, h2, probs = l1.buf("y", (B, l1.units)), l2.buf("y", (B, l2.units)), l3.buf("y", (B, l3.units))
@@ -331,11 +332,27 @@ class SARNetModel:
         self._accent_dx = l1.buf("dx", (B, l1.in_dim))
         want_loss = mode != "predict" and "y_accent" in self.loss_weights
         train = mode == "train" and want_loss
-        _call("sar_accent_classifier_f32", ar, l1.kernel.w, l1.bias.w, l2.kernel.w, l2.bias.w, l3.kernel.w, l3.bias.w,
-              self.in_y_accent if want_loss else None, self.seed["y_accent"] if train else None, h1, h2, probs, self._accent_loss,
-              l1.kernel.g, l1.bias.g, l2.kernel.g, l2.bias.g, l3.kernel.g, l3.bias.g, self._accent_dx, B, l1.in_dim, l1.units, l2.units, l3.units)
+        args = (ar, l1.kernel.w, l1.bias.w, l2.kernel.w, l2.bias.w, l3.kernel.w, l3.bias.w,
+                self.in_y_accent if want_loss else None, self.seed["y_accent"] if train else None, h1, h2, probs, self._accent_loss,
+                l1.kernel.g, l1.bias.g, l2.kernel.g, l2.bias.g, l3.kernel.g, l3.bias.g, self._accent_dx)
+        if margin:
+            d = self.disc
+            ws, mprobs, mloss, minvw = d.train_buffers(ar, self.in_x_accent, B)
+            _call("sar_accent_margin_train_f32", *args, self.in_x_accent, self.in_y_disc, self.seed["y_disc"], d.W.w, mprobs, mloss, minvw,
+                  d.W.g, ws, B, l1.in_dim, l1.units, l2.units, l3.units, d.MODE, d.s, d.m)
+            self.out["y_disc"], self._disc_loss = mprobs, mloss
+        else:
+            _call("sar_accent_classifier_f32", *args, B, l1.in_dim, l1.units, l2.units, l3.units)
         l1.output, l2.output, l3.output = h1, h2, probs
         return probs
+
+    def _fuse_margin(self, mode):
+        """The margin head's training step rides in the accent classifier's launch (sar_accent_margin_train_f32) where its
+        register-cached form applies: both heads trained, A in {4, 8}, hidden_dim <= 256."""
+        c = self.cfg
+        return (mode == "train" and self._fused_accent and c["disc_enable"] and c["metric_loss"] in ("sphereface", "cosface", "arcface")
+                and "y_disc" in self.loss_weights and "y_accent" in self.loss_weights and c["accent_classes"] in (4, 8)
+                and c["hidden_dim"] <= 256 and self.disc.W.w.data_ptr() % 16 == 0 and os.environ.get("SAR_FUSED_HEADS", "1") == "1")
 
     def _forward(self, mode="predict"):
         """mode: 'predict' (outputs only), 'eval' (+ losses follow), 'train' (+ backward follows) -- what the fused accent classifier
@@ -368,8 +385,9 @@ class SARNetModel:
             ar = self.AR_EMBEDDING.forward(ar)
             ar = self.AR_BN2.forward(ar, B)
             self.out["ar"] = ar
+            both = self._fuse_margin(mode)
             if self._fused_accent:
-                self.out["y_accent"] = self._accent_classifier(ar, mode)
+                self.out["y_accent"] = self._accent_classifier(ar, mode, margin=both)
             else:
                 a1 = self.AR_CF_DS2.forward(self.AR_CF_DS1.forward(ar))
                 self.out["y_accent"] = self.y_accent.forward(a1)
@@ -379,6 +397,8 @@ class SARNetModel:
                     self.out["y_disc"] = self.disc.forward(ar)
                 elif ml == "circleloss":
                     self.out["y_disc"] = self.disc.forward(self.disc_norm.forward(ar, B))
+                elif both:
+                    self._fused_disc = True                                   # ran in the classifier's launch above
                 elif mode == "train" and self._fused_accent and "y_disc" in self.loss_weights and "y_accent" in self.loss_weights:
                     # margin head: forward + cross-entropy + backward in two launches; its input gradient joins d(ar), which the
                     # classifier's launch above has just written

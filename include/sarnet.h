@@ -473,6 +473,18 @@ int sar_accent_classifier_f32(const float* x, const float* W1, const float* b1, 
                               const float* b3, const float* y_true, const float* dloss, float* h1, float* h2, float* probs,
                               float* loss, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dx,
                               int B, int H, int D1, int D2, int A, sarStream_t stream);
+/* ---- Both heads of the accent branch in one launch (training step): the accent classifier above (y_true, dloss required) AND the
+ * margin head `mode` (losses.py:28-47 / 74-91 / 121-144; s, m as sar_margin_head_train_f32) with kernel Wm (H,A) on the same embedding
+ * rows x: my = its one-hot second input, myt = its loss target (model.py:354), mdl (B) its loss seed -> mprobs (B,A), mloss (B),
+ * minvw (A) scratch, dWm += ; dx (B,H) = the SUM of the two heads' input gradients (written).  mws: float[H*A + 1], ZERO before the
+ * first call and zero again on return.  Only the sizes of the margin head's register-cached form: A in {4, 8}, H <= 256, Wm 16-byte
+ * aligned -- otherwise SAR_EINVAL and the caller runs sar_accent_classifier_f32 + sar_margin_head_train_f32. */
+int sar_accent_margin_train_f32(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                const float* b3, const float* y_true, const float* dloss, float* h1, float* h2, float* probs,
+                                float* loss, float* dW1, float* db1, float* dW2, float* db2, float* dW3, float* db3, float* dx,
+                                const float* my, const float* myt, const float* mdl, const float* Wm, float* mprobs, float* mloss,
+                                float* minvw, float* dWm, float* mws, int B, int H, int D1, int D2, int A, int mode, float s,
+                                float m, sarStream_t stream);
 /* ---- circle_loss: losses.py:157-172 ; Keras categorical_crossentropy: model.py:350,354 */
 int sar_circle_loss_fwd_f32(const float* y, const float* s, float* loss, int B, int A, float gamma, float margin, sarStream_t stream);
 int sar_circle_loss_bwd_f32(const float* y, const float* s, const float* dloss, float* ds, int B, int A, float gamma, float margin, sarStream_t stream);

@@ -211,6 +211,57 @@ def test_accent_classifier_fused(L, B, H, D1, D2, A):
     check(dxd, dx, name="dx")
 
 
+@pytest.mark.parametrize("B,H,A,mode", [(64, 256, 8, 2), (64, 256, 8, 0), (5, 32, 4, 1), (130, 192, 8, 2), (3, 256, 8, 1)])
+def test_accent_margin_one_launch(L, B, H, A, mode):
+    """sar_accent_margin_train_f32 (accent classifier + margin head, forward + losses + backward, ONE launch) against the two calls it
+    replaces (each held to the float64 oracle above): every output, dx = the sum of both heads' input gradients, every accumulated
+    parameter gradient; three calls in a row rely on the workspace + ticket being left zero; ragged last row block."""
+    rng = np.random.default_rng(7 * B + H + mode)
+    D1 = D2 = 64
+    x = rng.standard_normal((B, H)); Ws = [rng.standard_normal(s_) / np.sqrt(s_[0]) for s_ in ((H, D1), (D1, D2), (D2, A))]
+    bs = [0.1 * rng.standard_normal(n) for n in (D1, D2, A)]
+    y = np.eye(A)[rng.integers(0, A, B)]; dl = rng.uniform(0.5, 1.5, B) / B; mdl = rng.uniform(0.5, 1.5, B) / B
+    Wm = rng.standard_normal((H, A)) / 16; lab = np.eye(A)[rng.integers(0, A, B)]
+    s_, m_ = 30.0, (1.35, 0.35, 0.3)[mode]
+    d = [dev(a) for a in (x, Ws[0], bs[0], Ws[1], bs[1], Ws[2], bs[2])]
+    g0 = [rng.standard_normal(s_) for s_ in ((H, D1), (D1,), (D1, D2), (D2,), (D2, A), (A,))]; dWm0 = rng.standard_normal((H, A))
+    yd, dld, mdld, Wmd, labd = dev(y), dev(dl), dev(mdl), dev(Wm), dev(lab)
+    # the two calls
+    o = (zeros(B, D1), zeros(B, D2), zeros(B, A), zeros(B)); gd = [dev(a) for a in g0]; dxr = zeros(B, H)
+    L.call("sar_accent_classifier_f32", *d, yd, dld, *o, *gd, dxr, B, H, D1, D2, A)
+    mp, ml, miw, dWmr, ws = zeros(B, A), zeros(B), zeros(A), dev(dWm0), zeros(H, A)
+    L.call("sar_margin_head_train_f32", d[0], labd, labd, mdld, Wmd, mp, ml, miw, dxr, dWmr, ws, B, H, A, mode, s_, m_, 1)
+    # one launch
+    o2 = (zeros(B, D1), zeros(B, D2), zeros(B, A), zeros(B)); gd2 = [dev(a) for a in g0]; dx2 = dev(rng.standard_normal((B, H)))
+    mp2, ml2, miw2, dWm2, ws2 = zeros(B, A), zeros(B), zeros(A), dev(dWm0), zeros(H * A + 1)
+    for _ in range(3):
+        for t, a in zip(gd2 + [dWm2], g0 + [dWm0]):
+            t.copy_(dev(a))
+        L.call("sar_accent_margin_train_f32", *d, yd, dld, *o2, *gd2, dx2, labd, labd, mdld, Wmd, mp2, ml2, miw2, dWm2, ws2,
+               B, H, D1, D2, A, mode, s_, m_)
+    ref = lambda t: t.cpu().double().numpy()
+    for got, want, nm in zip(o2, o, ("h1", "h2", "probs", "loss")):
+        check(got, ref(want), 1e-5, nm)
+    for got, want, nm in zip(gd2, gd, ("dW1", "db1", "dW2", "db2", "dW3", "db3")):
+        check(got, ref(want), 1e-5, nm)
+    check(mp2, ref(mp), 1e-5, "margin probs"); check(ml2, ref(ml), 1e-5, "margin loss"); check(miw2, ref(miw), 1e-5, "inv_w")
+    check(dx2, ref(dxr), 1e-4, "dx"); check(dWm2, ref(dWmr), 1e-4, "dWm")
+    assert float(ws2.abs().max()) == 0.0
+    # 200 more calls back to back: the batch's sum crosses workgroups (and XCDs) through device-scope atomics + a ticket inside the launch --
+    # every call must collect all of it (dWm grows by exactly one increment per call) and leave the workspace and the ticket zero
+    inc = ref(dWmr) - dWm0
+    dWm2.zero_()
+    for _ in range(200):
+        L.call("sar_accent_margin_train_f32", *d, yd, dld, *o2, *gd2, dx2, labd, labd, mdld, Wmd, mp2, ml2, miw2, dWm2, ws2,
+               B, H, D1, D2, A, mode, s_, m_)
+    check(dWm2, 200 * inc, 1e-4, "dWm after 200 calls"); check(dx2, ref(dxr), 1e-4, "dx after 200 calls")
+    assert float(ws2.abs().max()) == 0.0
+    # sizes outside the register-cached margin form are refused (the caller keeps the two calls)
+    with pytest.raises(Exception):
+        L.call("sar_accent_margin_train_f32", *d, yd, dld, *o2, *gd2, dx2, labd, labd, mdld, Wmd, mp2, ml2, miw2, dWm2, ws2,
+               B, H, D1, D2, 6, mode, s_, m_)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_margin_head_train_fused(L, mode):
     """sar_margin_head_train_f32 (forward + cross-entropy + backward in two launches) against the per-op entry points it replaces
