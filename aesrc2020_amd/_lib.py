@@ -243,8 +243,9 @@ class GemmWgradGroup:
         self.n, self.blocks = n, tb.value
         self.table = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).cuda()
 
-    def launch(self):
-        call("sar_gemm_wgrad_group_f32", self.table, self.n, self.blocks)
+    def launch(self, gscale=0.0):
+        """gscale > 0: single-pass fp16 operands, dY times gscale (the split-precision mode's backward arithmetic)."""
+        call("sar_gemm_wgrad_group_scaled_f32", self.table, self.n, self.blocks, float(gscale))
 
 
 class WgradConv(ctypes.Structure):

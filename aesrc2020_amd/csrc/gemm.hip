@@ -199,10 +199,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmBatch gb, int M
 typedef __attribute__((ext_vector_type(8))) __bf16 gbf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 gbf16x2;
 typedef __attribute__((ext_vector_type(4))) short gs16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 gf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 gf16x8;
 constexpr int GB_K = 64, GB_RS = 144;          // k-tile; LDS row stride in bytes (64 bf16 + 16: conflict-free b128 column reads)
 
 __device__ __forceinline__ unsigned gpack2(float a, float b) {
     gbf16x2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ unsigned gpack2h(float a, float b) {
+    gf16x2 p; p[0] = (_Float16)a; p[1] = (_Float16)b;          // RNE
     return __builtin_bit_cast(unsigned, p);
 }
 __device__ __forceinline__ gs16x4 g_lds_tr(const unsigned char* base, unsigned off) {
@@ -225,10 +231,21 @@ typedef GemmLdsT<false> GemmLds;
 // (Negative, round 3: 512-thread blocks -- two groups of four waves on the even / odd k-tiles, meeting in LDS -- 7.39 -> 7.15 us for the
 // 156-tile launch but 9.9 -> 12.9 for the 468-tile one and the step 1.981 -> 1.996 ms: the launches with more than 256 tiles already had two
 // blocks per CU.)
-template <bool A_KC, bool B_KC, bool TAIL, bool X3 = false>
+// F16 (round 5: the BACKWARD products of the per-frame Dense / GRU-projection layers in the split-precision mode -- input gradients and the
+// grouped weight gradient): ONE pass on IEEE fp16 copies of the operands, each times a power of two while it is staged (x.sa / x.sb: the
+// gradient operand carries the trunk's static gradient scale, csrc/conv_bf16.hip), the accumulators times 1 / (sa sb) on the way out.  The
+// parameter gradients' precision is set by single-pass fp16 operands since the mixed backward of the trunk (tools/grad_recipe_emulator.py:
+// flat gradient 9.6e-4 -> 1.09e-3 with these products too; bf16 operands here: 4.6e-3), the outputs' 1e-3 only binds the forward pass.
+// GemmX.A2 / B2 (any mode, whole tiles): a SECOND operand pair along k -- C = A B + A2 B2 in one launch, K = both segments, seg = k-tiles of
+// the first (the BiGRU's input gradient: two directions' products into one tensor were two launches, the second a read-modify-write of C).
+struct GemmX { float sa, sb; const float* A2; const float* B2; int seg; };
+constexpr GemmX GX0{1.f, 1.f, nullptr, nullptr, 0};
+template <bool A_KC, bool B_KC, bool TAIL, bool X3 = false, bool F16 = false>
 __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                const float* __restrict__ bias, float* __restrict__ colsum, int M, int N, int K, int lda, int ldb,
-                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLdsT<X3>* Ls) {
+                                               int ldc, int act, int accumulate, int splitk, int bx, int by, int kz, GemmLdsT<X3>* Ls,
+                                               const GemmX x = GX0) {
+    static_assert(!(X3 && F16), "one arithmetic per instantiation");
     constexpr int NPL = X3 ? 2 : 1;
     GemmLdsT<X3>& L = *Ls;
     unsigned char (&As)[2][NPL][64 * GB_RS] = L.As; unsigned char (&Bs)[2][NPL][64 * GB_RS] = L.Bs; float (&csum)[4][64] = L.csum;
@@ -245,13 +262,17 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
     const int srow = tid >> 2, sseg = (tid & 3) * 16;
     float4 ra[4][4], rb[4][4];                           // two rotating sets (long k-loops) or all four k-tiles of a short one (below)
     auto gload = [&](int set, int kt) __attribute__((always_inline)) {
-        const int k0 = min(kt, kt1 - 1) * GB_K;
+        int kk = min(kt, kt1 - 1);
         if constexpr (!TAIL) {
-            const float* pa = A_KC ? A + (long)(m0 + srow) * lda + k0 + sseg : A + (long)(k0 + srow) * lda + m0 + sseg;
-            const float* pb = B_KC ? B + (long)(n0 + srow) * ldb + k0 + sseg : B + (long)(k0 + srow) * ldb + n0 + sseg;
+            const float* Ap = A; const float* Bp = B;
+            if (x.seg && kk >= x.seg) { kk -= x.seg; Ap = x.A2; Bp = x.B2; }      // block-uniform
+            const int k0 = kk * GB_K;
+            const float* pa = A_KC ? Ap + (long)(m0 + srow) * lda + k0 + sseg : Ap + (long)(k0 + srow) * lda + m0 + sseg;
+            const float* pb = B_KC ? Bp + (long)(n0 + srow) * ldb + k0 + sseg : Bp + (long)(k0 + srow) * ldb + n0 + sseg;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ra[set][i] = *reinterpret_cast<const float4*>(pa + 4 * i); rb[set][i] = *reinterpret_cast<const float4*>(pb + 4 * i); }
         } else {
+            const int k0 = kk * GB_K;
             // operand stored [mn][k]: row = mn (always inside for A: M % 64 == 0; B rows < N), pieces along k; stored [k][mn]: row = k, pieces along mn
             const int rowa = A_KC ? m0 + srow : k0 + srow, cola = A_KC ? k0 + sseg : m0 + sseg, lima_r = A_KC ? M : K, lima_c = A_KC ? K : M;
             const int rowb = B_KC ? n0 + srow : k0 + srow, colb = B_KC ? k0 + sseg : n0 + sseg, limb_r = B_KC ? N : K, limb_c = B_KC ? K : N;
@@ -282,8 +303,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 a = ra[set][i], b = rb[set][i];
-                wa[2 * i] = gpack2(a.x, a.y); wa[2 * i + 1] = gpack2(a.z, a.w);
-                wb[2 * i] = gpack2(b.x, b.y); wb[2 * i + 1] = gpack2(b.z, b.w);
+                if constexpr (F16) {
+                    wa[2 * i] = gpack2h(a.x * x.sa, a.y * x.sa); wa[2 * i + 1] = gpack2h(a.z * x.sa, a.w * x.sa);
+                    wb[2 * i] = gpack2h(b.x * x.sb, b.y * x.sb); wb[2 * i + 1] = gpack2h(b.z * x.sb, b.w * x.sb);
+                } else {
+                    wa[2 * i] = gpack2(a.x, a.y); wa[2 * i + 1] = gpack2(a.z, a.w);
+                    wb[2 * i] = gpack2(b.x, b.y); wb[2 * i + 1] = gpack2(b.z, b.w);
+                }
                 if constexpr (X3) {
                     la[2 * i] = lo2(a.x, a.y, wa[2 * i]); la[2 * i + 1] = lo2(a.z, a.w, wa[2 * i + 1]);
                     lb[2 * i] = lo2(b.x, b.y, wb[2 * i]); lb[2 * i + 1] = lo2(b.z, b.w, wb[2 * i + 1]);
@@ -324,6 +350,10 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc2, 0, 0, 0);
+            } else if constexpr (F16) {
+                const gf16x8 ah = __builtin_bit_cast(gf16x8, a), bh = __builtin_bit_cast(gf16x8, b);
+                if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
             } else if (ks & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc2, 0, 0, 0);
             else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
         }
@@ -353,8 +383,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const float* __restrict__ A, cons
             __syncthreads();
         }
     }
+    const float unscale = F16 ? 1.f / (x.sa * x.sb) : 1.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    for (int i = 0; i < 16; ++i) acc[i] = F16 ? (acc[i] + acc2[i]) * unscale : acc[i] + acc2[i];
     if (do_colsum) {                                  // threads with equal tid % 4 hold the same 16 columns
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -403,16 +434,16 @@ template <bool X3> __device__ __forceinline__ GemmLdsT<X3>* gemm_lds() {
     if constexpr (X3) return reinterpret_cast<GemmLdsT<true>*>(gemm_dyn_lds);
     else { __shared__ __attribute__((aligned(16))) GemmLdsT<false> L; return &L; }
 }
-template <bool A_KC, bool B_KC, bool TAIL = false, bool X3 = false>
+template <bool A_KC, bool B_KC, bool TAIL = false, bool X3 = false, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int M, int N,
-                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk) {
+                                                        int K, int lda, int ldb, int ldc, int act, int accumulate, int splitk, const GemmX x) {
     const unsigned nbx = gridDim.x, nby = gridDim.y;
     const unsigned t = xcd_order(blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z), nbx * nby * gridDim.z);
     const int bx = (int)(t % nbx), by = (int)(t / nbx % nby), z = (int)(t / (nbx * nby));
     const int bz = z / splitk, kz = z - bz * splitk;
     GemmLdsT<X3>* L = gemm_lds<X3>();
-    gemm_bf16_tile<A_KC, B_KC, TAIL, X3>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
-                                         bx, by, kz, L);
+    gemm_bf16_tile<A_KC, B_KC, TAIL, X3, F16>(gb.A[bz], gb.B[bz], gb.C[bz], gb.bias[bz], gb.colsum[bz], M, N, K, lda, ldb, ldc, act, accumulate, splitk,
+                                              bx, by, kz, L, x);
 }
 
 // Weight gradients of MANY Dense / GRU kernels in one launch (they are off the critical path of the backward pass: the host collects
@@ -421,8 +452,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int 
 // pack_weights_kernel), then runs the same tile code as sar_gemm_wgrad_f32.  Launches of 7-35 us that each filled a fraction of
 // the chip become one.
 struct WgRow { const float* X; const float* dY; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk, first_block; };   // 64 bytes
-template <bool X3>
-__global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow* __restrict__ tab, int n) {
+template <bool X3, bool F16 = false>
+__global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow* __restrict__ tab, int n, float gscale) {
+    const GemmX x{1.f, gscale, nullptr, nullptr, 0};                 // F16: the dY operands times the gradient scale
     GemmLdsT<X3>* L = gemm_lds<X3>();
     int r = -1;
     for (int base = 0; base < n; base += 64) {
@@ -435,8 +467,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
     const int local = (int)xcd_order(blockIdx.x - p.first_block, (unsigned)(nbx * nby * p.splitk));   // first_block % 8 == 0 (the plan pads)
     const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
     if (kz >= p.splitk) return;                                      // padding blocks of the plan
-    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true, X3>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
-    else gemm_bf16_tile<false, false, false, X3>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L);
+    if ((p.M | p.N | p.K) & 63) gemm_bf16_tile<false, false, true, X3, F16>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L, x);
+    else gemm_bf16_tile<false, false, false, X3, F16>(p.X, p.dY, p.dW, nullptr, p.db, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, ACT_NONE, 1, p.splitk, bx, by, kz, L, x);
 }
 
 }  // namespace
@@ -480,8 +512,8 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     if (tail16) {
         grid.x = cdiv(N, 64); grid.y = cdiv(M, 64);
 #define LAUNCH16T(AK, BK_)                                                                                           \
-    do { if (x3) { static PerDeviceFlag fl; const int rc = launch_x3(gemm_bf16_kernel<AK, BK_, true, true>, fl, grid, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); if (rc != SAR_OK) return rc; } \
-         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); } while (0)
+    do { if (x3) { static PerDeviceFlag fl; const int rc = launch_x3(gemm_bf16_kernel<AK, BK_, true, true>, fl, grid, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk, GX0); if (rc != SAR_OK) return rc; } \
+         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk, GX0); } while (0)
         if (a_kc && b_kc) LAUNCH16T(true, true);
         else if (a_kc && !b_kc) LAUNCH16T(true, false);
         else if (!a_kc && b_kc) LAUNCH16T(false, true);
@@ -492,8 +524,8 @@ static int gemm_launch(const GemmBatch& gb, int nb, int M, int N, int K, int lda
     }
     if (g_gemm_math >= 1 && M % 64 == 0 && N % 64 == 0 && K % 64 == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && aligned && K / 64 >= splitk) {
 #define LAUNCH16(AK, BK_)                                                                                            \
-    do { if (x3) { static PerDeviceFlag fl; const int rc = launch_x3(gemm_bf16_kernel<AK, BK_, false, true>, fl, grid, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); if (rc != SAR_OK) return rc; } \
-         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk); } while (0)
+    do { if (x3) { static PerDeviceFlag fl; const int rc = launch_x3(gemm_bf16_kernel<AK, BK_, false, true>, fl, grid, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk, GX0); if (rc != SAR_OK) return rc; } \
+         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, act, accumulate, splitk, GX0); } while (0)
         if (a_kc && b_kc) LAUNCH16(true, true);
         else if (a_kc && !b_kc) LAUNCH16(true, false);
         else if (!a_kc && b_kc) LAUNCH16(false, true);
@@ -519,6 +551,38 @@ extern "C" int sar_gemm_f32(const float* A, const float* B, float* C, const floa
     GemmBatch gb{};
     gb.A[0] = A; gb.B[0] = B; gb.C[0] = C; gb.bias[0] = bias;
     return gemm_launch(gb, 1, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, accumulate, splitk, stream);
+}
+
+// include/sarnet.h.  C (M,N) (+)= A B + A2 B2 in ONE launch on the 2-byte MFMA kernels: A, A2 (M, Kseg) row-major (lda); B, B2 stored (N, Kseg)
+// (b_kc = 1) or (Kseg, N) (b_kc = 0), ldb; A2 / B2 NULL: one product.  scale_a > 0: single-pass IEEE fp16 operands, A times scale_a and B
+// times scale_b (powers of two) while staged, the result times 1 / (scale_a scale_b) -- the backward products of the split-precision mode;
+// scale_a == 0: the process-wide GEMM arithmetic (bf16 or bf16x3).  Whole 64 x 64 x 64 tiles and 16-byte aligned operands only, GEMM math
+// bf16 / bf16x3 (else SAR_EINVAL: the caller runs sar_gemm_f32 per product).
+extern "C" int sar_gemm_pair_f32(const float* A, const float* B, const float* A2, const float* B2, float* C, int M, int N, int Kseg, int lda,
+                                 int ldb, int ldc, int b_kc, int accumulate, float scale_a, float scale_b, hipStream_t stream) {
+    if (!A || !B || !C || (!A2) != (!B2) || M < 64 || N < 64 || Kseg < 64 || g_gemm_math < 1) return SAR_EINVAL;
+    if ((M | N | Kseg) & 63 || (lda | ldb) & 3 || scale_a < 0.f || (scale_a > 0.f && !(scale_b > 0.f))) return SAR_EINVAL;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(A2) | reinterpret_cast<uintptr_t>(B2);
+    if (al & 15) return SAR_EINVAL;
+    GemmBatch gb{};
+    gb.A[0] = A; gb.B[0] = B; gb.C[0] = C;
+    const GemmX x{scale_a > 0.f ? scale_a : 1.f, scale_a > 0.f ? scale_b : 1.f, A2, B2, A2 ? Kseg / 64 : 0};
+    const int K = A2 ? 2 * Kseg : Kseg;
+    dim3 grid(N / 64, M / 64, 1), block(256);
+    if (scale_a > 0.f) {
+        if (b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, false, false, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, (int)ACT_NONE, accumulate, 1, x);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false, false, false, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, (int)ACT_NONE, accumulate, 1, x);
+    } else if (g_gemm_math == 2) {
+        static PerDeviceFlag f1, f0;
+        const int rc = b_kc ? launch_x3(gemm_bf16_kernel<true, true, false, true>, f1, grid, stream, gb, M, N, K, lda, ldb, ldc, (int)ACT_NONE, accumulate, 1, x)
+                            : launch_x3(gemm_bf16_kernel<true, false, false, true>, f0, grid, stream, gb, M, N, K, lda, ldb, ldc, (int)ACT_NONE, accumulate, 1, x);
+        if (rc != SAR_OK) return rc;
+    } else {
+        if (b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, (int)ACT_NONE, accumulate, 1, x);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, stream, gb, M, N, K, lda, ldb, ldc, (int)ACT_NONE, accumulate, 1, x);
+    }
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
 }
 
 // Weight gradient of a Dense layer with its bias gradient: dW[in,out] += X^T[in,R] dY[R,out], db[out] += sum_R dY.
@@ -578,11 +642,21 @@ extern "C" int sar_gemm_wgrad_group_f32(const void* table_dev, int n, int total_
     if (!table_dev || n < 1 || total_blocks < 1 || g_gemm_math < 1) return SAR_EINVAL;
     if (g_gemm_math == 2) {
         static PerDeviceFlag fl;
-        const int rc = launch_x3(gemm_bf16_wgrad_group_kernel<true>, fl, dim3(total_blocks), stream, static_cast<const WgRow*>(table_dev), n);
+        const int rc = launch_x3(gemm_bf16_wgrad_group_kernel<true>, fl, dim3(total_blocks), stream, static_cast<const WgRow*>(table_dev), n, 1.f);
         if (rc != SAR_OK) return rc;
     } else {
-        hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel<false>, dim3(total_blocks), dim3(256), 0, stream, static_cast<const WgRow*>(table_dev), n);
+        hipLaunchKernelGGL(gemm_bf16_wgrad_group_kernel<false>, dim3(total_blocks), dim3(256), 0, stream, static_cast<const WgRow*>(table_dev), n, 1.f);
     }
     SAR_CHECK_LAUNCH();
     return SAR_OK;
+}
+// gscale > 0: the group in single-pass fp16 (gemm_bf16_tile: F16), every dY operand times gscale while staged; 0: the GEMM arithmetic in force
+extern "C" int sar_gemm_wgrad_group_scaled_f32(const void* table_dev, int n, int total_blocks, float gscale, hipStream_t stream) {
+    if (!table_dev || n < 1 || total_blocks < 1 || g_gemm_math < 1 || gscale < 0.f) return SAR_EINVAL;
+    if (gscale > 0.f) {
+        hipLaunchKernelGGL((gemm_bf16_wgrad_group_kernel<false, true>), dim3(total_blocks), dim3(256), 0, stream, static_cast<const WgRow*>(table_dev), n, gscale);
+        SAR_CHECK_LAUNCH();
+        return SAR_OK;
+    }
+    return sar_gemm_wgrad_group_f32(table_dev, n, total_blocks, stream);
 }

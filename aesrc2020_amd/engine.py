@@ -142,6 +142,14 @@ class ParamStore:
     def begin_deferred_wgrads(self):
         self._defer = [] if (self.training and _lib.get_gemm_math() in ("bf16", "bf16x3") and os.environ.get("SAR_WGRAD_GROUP", "1") == "1") else None
 
+    def bwd_gemm_scale(self):
+        """> 0: the backward products of the per-frame Dense / GRU-projection layers run single-pass on fp16 operands, the gradient operand
+        times this power of two (csrc/gemm.hip: F16) -- the split-precision GEMM mode's backward since round 5 (SAR_GEMM_BWD=x3: three
+        passes as in the forward).  The scale is the 2-byte trunk's: 64 x batch, lowered by the overflow guard (gscale_shift)."""
+        if not self.training or _lib.get_gemm_math() != "bf16x3" or os.environ.get("SAR_GEMM_BWD", "f16") != "f16":
+            return 0.0
+        return float(2 ** (int(round(np.log2(64.0 * max(self.__dict__.get("batch", 64), 1)))) + self.gscale_shift))
+
     def deferring_wgrads(self):
         return self.__dict__.get("_defer") is not None
 
@@ -175,7 +183,7 @@ class ParamStore:
         if grp is None:                                                         # first sighting inside a capture: as without deferral
             grp = (None, probs)
         if grp[0] is not None:
-            grp[0].launch()
+            grp[0].launch(self.bwd_gemm_scale())
         for q in grp[1]:
             _lib.call("sar_gemm_wgrad_f32", *q)
 

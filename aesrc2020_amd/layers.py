@@ -2,6 +2,8 @@
 (/root/reference/model.py:23-53) and owns an explicit backward: forward/backward are sequences of C-ABI kernel
 launches on the current HIP stream (no torch autograd, no torch math).  Weight names/layouts follow Keras so that
 by-name checkpoints map 1:1."""
+import os
+
 import numpy as np
 import torch
 
@@ -100,8 +102,13 @@ class Dense(Layer):
         if not need_dx:
             return None
         dx = dx_out if dx_out is not None else self.buf("dx", (R, self.in_dim))
-        gemm(dz, self.kernel.w, dx, None, R, self.in_dim, self.units, self.units, self.units, self.in_dim, 1, 1, 0,
-             1 if accumulate_dx else 0)
+        gs = self.store.bwd_gemm_scale()
+        if gs > 0 and (R | self.in_dim | self.units) % 64 == 0:     # the split-precision mode's backward: one pass on fp16 operands (csrc/gemm.hip: F16)
+            _call("sar_gemm_pair_f32", dz, self.kernel.w, None, None, dx, R, self.in_dim, self.units, self.units, self.units, self.in_dim, 1,
+                  1 if accumulate_dx else 0, gs, 1.0)
+        else:
+            gemm(dz, self.kernel.w, dx, None, R, self.in_dim, self.units, self.units, self.units, self.in_dim, 1, 1, 0,
+                 1 if accumulate_dx else 0)
         return dx
 
 
@@ -230,10 +237,14 @@ class BiGRU(Layer):
         else:
             _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(ks), 2, I, 3 * H, R, I, 3 * H, 3 * H, sk)
             _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(us), 2, H, 3 * H, R, H, 3 * H, 3 * H, sku)
-        for i, d in enumerate(("forward", "backward")):
-            k, u, b = self.p[d]
-            if need_dx:
-                gemm(dai[i], k.w, dx, None, R, I, 3 * H, 3 * H, 3 * H, I, 1, 1, 0, 1 if (accumulate_dx or i == 1) else 0)
+        if need_dx and (R | I | H) % 64 == 0 and _lib.get_gemm_math() in ("bf16", "bf16x3") and os.environ.get("SAR_GEMM_PAIR", "1") == "1":
+            # both directions' products into dx in ONE launch (two operand pairs along k; csrc/gemm.hip: GemmX) -- they were two, the second a
+            # read-modify-write of dx; in the split-precision mode's backward arithmetic where that applies
+            _call("sar_gemm_pair_f32", dai[0], self.p["forward"][0].w, dai[1], self.p["backward"][0].w, dx, R, I, 3 * H, 3 * H, 3 * H, I, 1,
+                  1 if accumulate_dx else 0, self.store.bwd_gemm_scale(), 1.0)
+        elif need_dx:
+            for i, d in enumerate(("forward", "backward")):
+                gemm(dai[i], self.p[d][0].w, dx, None, R, I, 3 * H, 3 * H, 3 * H, I, 1, 1, 0, 1 if (accumulate_dx or i == 1) else 0)
         return dx
 
 

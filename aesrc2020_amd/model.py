@@ -214,6 +214,7 @@ class SARNetModel:
             self.L = Tp * Dp
         b = self.bufs
         self.B = B; self.T = T
+        self.store.batch = B                                         # (engine.bwd_gemm_scale: the gradient scale of the fp16 backward products)
         self.in_x = b.get("in/x_data", (B, T, D, 1))
         A = c["accent_classes"]
         self.in_y_accent = b.get("in/y_accent", (B, A))

@@ -109,6 +109,18 @@ typedef struct sarGemmWgrad {
 } sarGemmWgrad;
 int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void* table_out, int* total_blocks);
 int sar_gemm_wgrad_group_f32(const void* table_dev, int n, int total_blocks, sarStream_t stream);
+/* The same launch with the BACKWARD arithmetic of the split-precision mode (round 5): gscale > 0 -- one pass on IEEE fp16 copies of the
+ * operands, every dY times gscale (a power of two: the static gradient scale of the 2-byte trunk, 64 x batch) while it is staged, dW and
+ * db in true units, db summed from the fp32 dY; gscale == 0: sar_gemm_wgrad_group_f32. */
+int sar_gemm_wgrad_group_scaled_f32(const void* table_dev, int n, int total_blocks, float gscale, sarStream_t stream);
+/* Input gradients of Dense / GRU-projection layers (model.py:35-42 DS, :46-57 BIGRU: the backward TF derives for them), one or two
+ * products into one tensor in ONE launch of the 2-byte MFMA GEMM: C (M,N) = [C +] A B + A2 B2.  A, A2 (M, Kseg) row-major (lda); B, B2
+ * stored (N, Kseg) when b_kc (a Dense kernel as it lies: dX = dY W^T), else (Kseg, N); A2 = B2 = NULL: one product (the BiGRU's two
+ * directions are the two).  scale_a > 0: single-pass IEEE fp16 operands, A times scale_a and B times scale_b (powers of two) while staged,
+ * the sums times 1 / (scale_a scale_b); scale_a == 0: the process-wide GEMM arithmetic.  Only whole 64 x 64 x 64 tiles, 16-byte aligned
+ * operands, GEMM math bf16 / bf16x3 -- otherwise SAR_EINVAL (the caller runs sar_gemm_f32 per product). */
+int sar_gemm_pair_f32(const float* A, const float* B, const float* A2, const float* B2, float* C, int M, int N, int Kseg, int lda,
+                      int ldb, int ldc, int b_kc, int accumulate, float scale_a, float scale_b, sarStream_t stream);
 /* GEMM arithmetic of sar_gemm_f32 / sar_gemm_wgrad_f32: 0 = fp32 MFMA (default), 1 = operands rounded to bf16 while they are
  * staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate (problems whose M, N, K are multiples of 64; others keep fp32).  The
  * "bf16" mode of BASELINE configs[1]; fp32 tensors at the ABI either way.  Host-side, process-wide (env SAR_GEMM_MATH=bf16). */

@@ -244,9 +244,15 @@ def ln(x, g, b):
     return (x - mu) / torch.sqrt(var + LN_EPS) * g + b
 
 
+def seq_mm(x, w):
+    """The per-frame Dense / GRU-projection products (B*L rows): one name so that tools/grad_recipe_emulator.py can swap in a product whose
+    BACKWARD rounds its operands; here it is the plain product."""
+    return x @ w
+
+
 def gru_dir(x, k, rk, bias, reverse):
     B, L, _ = x.shape; H = rk.shape[0]
-    xa = x @ k + bias[:3 * H]
+    xa = seq_mm(x, k) + bias[:3 * H]
     h = x.new_zeros(B, H); outs = [None] * L
     for t in (range(L - 1, -1, -1) if reverse else range(L)):
         ha = h @ rk + bias[3 * H:]
@@ -315,18 +321,18 @@ def forward(P, batch, cfg, collect=None, state=None, training=True):
     out = {"cnn": x}
     B = x.shape[0]
     x = x.reshape(B, -1, x.shape[-1])                                            # CNN2SEQ model.py:252
-    x = torch.tanh(x @ P["CNN_LIN/kernel"] + P["CNN_LIN/bias"])
+    x = torch.tanh(seq_mm(x, P["CNN_LIN/kernel"]) + P["CNN_LIN/bias"])
     x = ln(x, P["CNN_LIN_LN/gamma"], P["CNN_LIN_LN/beta"])
     crnn = ln(bigru(x, P, "CRNN"), P["CRNN_LN/gamma"], P["CRNN_LN/beta"])
     out["crnn"] = crnn
     if cfg.ctc_enable:
         a = ln(bigru(crnn, P, "CTC_BIGRU"), P["CTC_BIGRU_LN/gamma"], P["CTC_BIGRU_LN/beta"])
-        a = ln(torch.tanh(a @ P["CTC_DS/kernel"] + P["CTC_DS/bias"]), P["CTC_DS_LN/gamma"], P["CTC_DS_LN/beta"])
-        pred = torch.softmax(a @ P["ctc_pred/kernel"] + P["ctc_pred/bias"], -1)
+        a = ln(torch.tanh(seq_mm(a, P["CTC_DS/kernel"]) + P["CTC_DS/bias"]), P["CTC_DS_LN/gamma"], P["CTC_DS_LN/beta"])
+        pred = torch.softmax(seq_mm(a, P["ctc_pred/kernel"]) + P["ctc_pred/bias"], -1)
         out["ctc_pred"] = pred
         out["y_ctc_loss"] = ctc_batch_cost(batch["x_ctc_label"], pred, batch["x_ctc_in_len"], batch["x_ctc_out_len"])
     if cfg.ar_enable:
-        ar = ln(torch.tanh(crnn @ P["AR_DS/kernel"] + P["AR_DS/bias"]), P["AR_DS_LN/gamma"], P["AR_DS_LN/beta"])
+        ar = ln(torch.tanh(seq_mm(crnn, P["AR_DS/kernel"]) + P["AR_DS/bias"]), P["AR_DS_LN/gamma"], P["AR_DS_LN/beta"])
         if cfg.mto == "avg":
             ar = ar.mean(1)
         elif cfg.mto == "bigru":

@@ -149,6 +149,71 @@ def test_gemm_wgrad_group(L):
         L.set_gemm_math(old)
 
 
+@pytest.mark.parametrize("math,scale", [("bf16", 0.0), ("bf16x3", 0.0), ("bf16x3", 4096.0), ("bf16", 4096.0)])
+@pytest.mark.parametrize("b_kc", [1, 0])
+def test_gemm_pair(L, math, scale, b_kc):
+    """sar_gemm_pair_f32: C = [C +] A B + A2 B2 in one launch (the BiGRU's input gradient: both directions' products), in the GEMM arithmetic in
+    force (scale 0) and in the split-precision mode's BACKWARD arithmetic (scale > 0: single-pass fp16 operands, the gradient operand under
+    the scale) -- against float64 products of operands rounded the way the kernel rounds them; small gradient-sized values included."""
+    rng = np.random.default_rng(11 + b_kc)
+    M, N, K = 2496, 256, 768
+    h16 = lambda a, sc=1.0: (torch.tensor(a * sc, dtype=torch.float32).to(torch.float16).double().numpy() / sc)
+    bf = lambda a: torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()
+    ra, rb, tol = ((lambda a: h16(a, scale)), h16, 2e-5) if scale > 0 else ((bf, bf, 2e-5) if math == "bf16" else ((lambda a: a), (lambda a: a), 3e-5))
+    A = [rng.standard_normal((M, K)) * 1e-4 * np.exp(rng.uniform(-6, 0, (M, 1))) for _ in range(2)]      # gradient-sized rows: 2.5e-7 .. 1e-4
+    W = [rng.standard_normal((N, K) if b_kc else (K, N)) / 16 for _ in range(2)]
+    C0 = rng.standard_normal((M, N)) * 1e-4
+    prod = lambda i: ra(A[i]) @ (rb(W[i]).T if b_kc else rb(W[i]))
+    old = L.get_gemm_math()
+    L.set_gemm_math(math)
+    try:
+        Ad, Wd = [dev(a) for a in A], [dev(w) for w in W]
+        ldb = K if b_kc else N
+        C = dev(C0)
+        L.call("sar_gemm_pair_f32", Ad[0], Wd[0], Ad[1], Wd[1], C, M, N, K, K, ldb, N, b_kc, 0, scale, 1.0)
+        check(C, prod(0) + prod(1), tol, "pair, written")
+        C = dev(C0)
+        L.call("sar_gemm_pair_f32", Ad[0], Wd[0], Ad[1], Wd[1], C, M, N, K, K, ldb, N, b_kc, 1, scale, 1.0)
+        check(C, C0 + prod(0) + prod(1), tol, "pair, accumulated")
+        C = dev(C0)
+        L.call("sar_gemm_pair_f32", Ad[0], Wd[0], None, None, C, M, N, K, K, ldb, N, b_kc, 0, scale, 1.0)
+        check(C, prod(0), tol, "single product")
+        with pytest.raises(RuntimeError):                                      # not whole tiles: the caller keeps sar_gemm_f32
+            L.call("sar_gemm_pair_f32", Ad[0], Wd[0], None, None, C, M - 4, N, K, K, ldb, N, b_kc, 0, scale, 1.0)
+        L.set_gemm_math("fp32")
+        with pytest.raises(RuntimeError):
+            L.call("sar_gemm_pair_f32", Ad[0], Wd[0], None, None, C, M, N, K, K, ldb, N, b_kc, 0, scale, 1.0)
+    finally:
+        L.set_gemm_math(old)
+
+
+def test_gemm_wgrad_group_fp16_backward(L):
+    """sar_gemm_wgrad_group_scaled_f32 with gscale > 0 (the split-precision mode's backward arithmetic): dW from fp16 copies of X and of
+    gscale * dY, db from the fp32 dY, against float64 on operands rounded that way; tails and split-K as in the grouped launch's own test."""
+    rng = np.random.default_rng(13)
+    gs = 4096.0
+    h16 = lambda a, sc=1.0: (torch.tensor(a * sc, dtype=torch.float32).to(torch.float16).double().numpy() / sc)
+    shapes = [(2496, 768, 256, 1, True), (2496, 256, 768, 3, True), (64, 8192, 256, 1, True), (2496, 256, 1000, 2, True), (6048, 256, 768, 3, False)]
+    old = L.get_gemm_math()
+    L.set_gemm_math("bf16x3")
+    try:
+        probs, refs = [], []
+        for R, I, N, sk, hb in shapes:
+            X = rng.standard_normal((R, I)); dY = rng.standard_normal((R, N)) * 1e-4 * np.exp(rng.uniform(-6, 0, (R, 1)))
+            dW0 = rng.standard_normal((I, N)) * 1e-3; db0 = rng.standard_normal(N) * 1e-3
+            dW, db = dev(dW0), (dev(db0) if hb else None)
+            probs.append((dev(X), dev(dY), dW, db, I, N, R, I, N, N, sk))
+            refs.append((dW0 + h16(X).T @ h16(dY, gs), db0 + dY.sum(0)))
+        grp = L.GemmWgradGroup(probs)
+        grp.launch(gs)
+        for q, (rw, rb), sh in zip(probs, refs, shapes):
+            check(q[2], rw, 2e-5, "grouped fp16 dW %r" % (sh,))
+            if q[3] is not None:
+                check(q[3], rb, 2e-5, "grouped db %r" % (sh,))
+    finally:
+        L.set_gemm_math(old)
+
+
 @pytest.mark.parametrize("math", ["fp32", "bf16"])
 def test_gemm_batched(L, math):
     """sar_gemm_batched_f32 / sar_gemm_wgrad_batched_f32: up to four equal-shape problems in one launch (the BiGRU's projections

@@ -49,6 +49,25 @@ def make_conv(rec, scale):
     return Conv
 
 
+def make_mm(rec, scale):
+    """seq_mm whose backward rounds: gemm_g the gradient operand (scaled) of both products, gemm_w the kernel in dX = dY W^T, gemm_x the
+    activation in dW = X^T dY."""
+    class MM(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, gy):
+            x, w = ctx.saved_tensors
+            gq = rq(gy, rec.get("gemm_g", "exact"), scale)
+            gx = gq @ rq(w, rec.get("gemm_w", "exact")).T
+            x2, g2 = rq(x, rec.get("gemm_x", "exact")).reshape(-1, x.shape[-1]), gq.reshape(-1, gq.shape[-1])
+            return gx, x2.T @ g2
+    return MM
+
+
 def run(case, rec, seed):
     kw = dict(CASES[case]); B = kw.pop("B")
     cfg = MT.Cfg(**kw)
@@ -66,10 +85,13 @@ def run(case, rec, seed):
             xc = F.pad(xc, (pl, pr, pt, pb))
         return Conv.apply(xc, w.permute(3, 2, 0, 1), b, stride).permute(0, 2, 3, 1)
     MT.conv2d = conv2d
+    o_mm = MT.seq_mm
+    MM = make_mm(rec, 2.0 ** int(round(np.log2(64.0 * B))))
+    MT.seq_mm = lambda x, w: MM.apply(x, w)
     try:
         _, _, _, G1 = net.forward_backward(batch)
     finally:
-        MT.conv2d = o_conv
+        MT.conv2d = o_conv; MT.seq_mm = o_mm
     names = list(G0)
     f0 = torch.cat([G0[k].ravel() for k in names]); f1 = torch.cat([G1[k].ravel() for k in names])
     l2 = float((f1 - f0).norm() / f0.norm())
@@ -90,6 +112,11 @@ TABLE = [
     dict(dgrad_g="fp16", dgrad_w="fp16", store_g="fp16", wgrad_x="fp16"),            # the whole backward chain single-pass fp16
     dict(dgrad_g="fp16", dgrad_w="fp16", store_g="fp32", wgrad_x="fp16"),            # single-pass fp16 products, fp32 residual-stream gradient in HBM
     dict(dgrad_g="bf16", dgrad_w="bf16", store_g="bf16", wgrad_x="bf16"),
+    # + the per-frame Dense / GRU-projection GEMMs' backward single-pass (round 5, second half): gradient operand fp16 under the scale
+    dict(dgrad_g="fp16", dgrad_w="fp16", store_g="fp16", wgrad_x="fp16", gemm_g="fp16", gemm_w="fp16", gemm_x="fp16"),
+    dict(dgrad_g="fp16", dgrad_w="fp16", store_g="fp16", wgrad_x="fp16", gemm_g="fp16", gemm_w="exact", gemm_x="fp16"),
+    dict(dgrad_g="fp16", dgrad_w="fp16", store_g="fp16", wgrad_x="fp16", gemm_g="bf16", gemm_w="bf16", gemm_x="bf16"),
+    dict(dgrad_g="exact", dgrad_w="exact", store_g="exact", wgrad_x="exact", gemm_g="fp16", gemm_w="fp16", gemm_x="fp16"),
 ]
 
 if __name__ == "__main__":
