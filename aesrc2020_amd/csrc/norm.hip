@@ -278,12 +278,38 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
 // ---- LayerNorm: x (R, C), one wave per row, C % 4 == 0, C <= 2048 -------------------------------------
 constexpr int LN_MAXV = 8;   // float4 per lane
 
+// SK (round 5): a narrow Dense on the NORMALISED rows rides along -- s[r][n] = y[r][:] . sW[:, n] + sb[n], n < N <= 16, C <= 256 -- the
+// cluster-assignment 1x1 conv of the (Ghost)VLAD block (model.py:89-95 / 99-105: 8 + 2 columns on the 256-wide AR_DS_LN output), which as a
+// GEMM launch of its own was 8.8 us for 41 MFLOP.  The lane keeps its four kernel rows in registers; N wave sums per row.
+constexpr int SK_N = 16;
+// The lane's four kernel rows sw[e][n] = sW[4 lane + e][n] (zero past C / N).  Through LDS: the block reads the kernel once, coalesced, and
+// transposes it -- as 4 N gathers per lane (64 lanes x 4 bytes at a stride of 4 N bytes: ~20 cache lines per instruction, in every wave of the
+// launch) the address unit made the fused forward launch 15 us against 5.3 + 7.3 for the two it replaced.  All 256 threads call it.
+__device__ __forceinline__ void sk_rows(float (&sw)[4][SK_N], const float* __restrict__ sW, int C, int N) {
+    __shared__ __attribute__((aligned(16))) float wt[SK_N][256 + 4];
+    for (int i = threadIdx.x; i < C * N; i += 256) wt[i % N][i / N] = sW[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int n = 0; n < SK_N; ++n) {
+        const float4 v = (4 * lane < C && n < N) ? *reinterpret_cast<const float4*>(&wt[n][4 * lane]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sw[0][n] = v.x; sw[1][n] = v.y; sw[2][n] = v.z; sw[3][n] = v.w;
+    }
+}
+template <bool SK>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long R, int C,
-                                                     float eps) {
+                                                     float eps, const float* __restrict__ sW, const float* __restrict__ sb,
+                                                     float* __restrict__ sy, int N) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
+    float sw[SK ? 4 : 1][SK ? SK_N : 1];
+    float sbias = 0.f;
+    if constexpr (SK) {
+        sk_rows(sw, sW, C, N);
+        sbias = (lane < N && sb != nullptr) ? sb[lane] : 0.f;
+    }
     for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
         float4 v[LN_MAXV];
         float s = 0.f;
@@ -304,6 +330,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
         const float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+        float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c4 = lane + j * 64;
@@ -313,19 +340,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 o.x = (v[j].x - mu) * rs * g.x + be.x; o.y = (v[j].y - mu) * rs * g.y + be.y;
                 o.z = (v[j].z - mu) * rs * g.z + be.z; o.w = (v[j].w - mu) * rs * g.w + be.w;
                 reinterpret_cast<float4*>(y + r * C)[c4] = o;
+                if (SK && j == 0) o0 = o;
             }
+        }
+        if constexpr (SK) {                                         // (every lane: lanes past the row hold zeros)
+            float mine = 0.f;
+#pragma unroll
+            for (int n = 0; n < SK_N; ++n) {
+                if (n < N) {                                        // kernel-uniform
+                    const float t = wave_sum(fmaf(o0.x, sw[0][n], fmaf(o0.y, sw[1][n], fmaf(o0.z, sw[2][n], o0.w * sw[3][n]))));
+                    if (lane == n) mine = t;
+                }
+            }
+            if (lane < N) sy[r * N + lane] = mine + sbias;
         }
     }
 }
 
+// SK: the incoming gradient is dy + ds sW^T -- the input gradient of the narrow Dense that ln_fwd_kernel<true> evaluated on this layer's output
+// (ds (R,N) = the gradient of its output), which as a GEMM launch accumulating into dy was 10.6 us.
+template <bool SK>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
-                                                     int C, int accumulate, int act) {
+                                                     int C, int accumulate, int act, const float* __restrict__ sds,
+                                                     const float* __restrict__ sW, int N) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // 4 waves x 2 x C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
+    float sw[SK ? 4 : 1][SK ? SK_N : 1];
+    if constexpr (SK) sk_rows(sw, sW, C, N);
     float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = ag[j]; }
@@ -333,12 +378,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float mu = mean[r], rs = rstd[r];
         float4 xh[LN_MAXV], g[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
+        float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SK) {
+            const int dsv = __builtin_bit_cast(int, sds[r * N + min(lane, N - 1)]);
+#pragma unroll
+            for (int n = 0; n < SK_N; ++n) {
+                if (n < N) {                                        // kernel-uniform
+                    const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(dsv, n));
+                    extra.x = fmaf(dn, sw[0][n], extra.x); extra.y = fmaf(dn, sw[1][n], extra.y);
+                    extra.z = fmaf(dn, sw[2][n], extra.z); extra.w = fmaf(dn, sw[3][n], extra.w);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c4 = lane + j * 64;
             if (c4 < C4) {
                 const float4 v = reinterpret_cast<const float4*>(x + r * C)[c4];
-                const float4 d = reinterpret_cast<const float4*>(dy + r * C)[c4];
+                float4 d = reinterpret_cast<const float4*>(dy + r * C)[c4];
+                if (SK && j == 0) { d.x += extra.x; d.y += extra.y; d.z += extra.z; d.w += extra.w; }
                 const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
                 xh[j] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
                 g[j] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
@@ -513,7 +571,7 @@ extern "C" int sar_layernorm_fwd_f32(const float* x, const float* gamma, const f
                                      float* rstd, long R, int C, float eps, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     const int nb = (int)((R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<float*>(nullptr), 0);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -524,7 +582,7 @@ extern "C" int sar_layernorm_bwd_f32(const float* dy, const float* x, const floa
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
     const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, ACT_NONE);
+    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, (int)ACT_NONE, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), 0);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -539,7 +597,30 @@ extern "C" int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const 
     if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
     static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
     const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
+    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), 0);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
+// include/sarnet.h.  sar_layernorm_fwd_f32 + a narrow Dense on its output in one launch: s (R,N) = y sW + sb; sW (C,N) row-major, sb (N) nullable,
+// N <= 16, C <= 256.
+extern "C" int sar_layernorm_dense_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long R,
+                                           int C, float eps, const float* sW, const float* sb, float* s, int N, hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || !sW || !s || C % 4 || C > 256 || N < 1 || N > SK_N || R <= 0) return SAR_EINVAL;
+    const int nb = (int)((R + 7) / 8 < 1024 ? (R + 7) / 8 : 1024);       // two rows per wave: the kernel rows (4 N loads per lane) are fetched per wave
+    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps, sW, sb, s, N);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+// include/sarnet.h.  sar_layernorm_bwd_act_f32 whose incoming gradient is dy + ds sW^T (the input gradient of that narrow Dense); dy is not written.
+extern "C" int sar_layernorm_bwd_dense_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                                           float* dgamma, float* dbeta, long R, int C, int accumulate, int act, const float* ds, const float* sW,
+                                           int N, hipStream_t stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ds || !sW || C % 4 || C > 256 || N < 1 || N > SK_N) return SAR_EINVAL;
+    if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
+    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;
+    const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
+    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act, ds, sW, N);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
