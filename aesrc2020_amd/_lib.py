@@ -234,6 +234,7 @@ class GemmWgradGroup:
         for a, q in zip(arr, probs):
             a.X, a.dY, a.dW, a.db = q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), (None if q[3] is None else q[3].data_ptr())
             a.in_dim, a.out_dim, a.R, a.lda, a.ldb, a.ldc, a.splitk = (int(v) for v in q[4:11])
+            a.pad_ = int(q[11]) if len(q) > 11 else 0                              # this problem's gradient scale: gscale * 2^-pad_
         buf = ctypes.create_string_buffer(n * 64)
         tb = ctypes.c_int(0)
         rc = lib().fn["sar_gemm_wgrad_group_plan"](arr, n, buf, ctypes.byref(tb))

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmBatch gb, int 
 struct WgRow { const float* X; const float* dY; float* dW; float* db; int M, N, K, lda, ldb, ldc, splitk, first_block; };   // 64 bytes
 template <bool X3, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow* __restrict__ tab, int n, float gscale) {
-    const GemmX x{1.f, gscale, nullptr, nullptr, 0};                 // F16: the dY operands times the gradient scale
+
     GemmLdsT<X3>* L = gemm_lds<X3>();
     int r = -1;
     for (int base = 0; base < n; base += 64) {
@@ -462,7 +462,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_wgrad_group_kernel(const WgRow*
         r += __popcll(__ballot(q < n && tab[q].first_block <= (int)blockIdx.x));
     }
     r = __builtin_amdgcn_readfirstlane(r);
-    const WgRow p = tab[r];
+    WgRow p = tab[r];
+    // F16: the dY operand times the gradient scale, lowered by the problem's own 2^-shift (bits 8.. of splitk; the plan's pad_): a per-utterance
+    // layer's gradient rows are ~L times a per-frame layer's, and BatchNorm backward can multiply them by rstd <= 31 on top
+    const GemmX x{1.f, gscale * __builtin_amdgcn_exp2f(-(float)(p.splitk >> 8)), nullptr, nullptr, 0};
+    p.splitk &= 255;
     const int nbx = (p.N + 63) / 64, nby = (p.M + 63) / 64;
     const int local = (int)xcd_order(blockIdx.x - p.first_block, (unsigned)(nbx * nby * p.splitk));   // first_block % 8 == 0 (the plan pads)
     const int bx = local % nbx, by = (local / nbx) % nby, kz = local / (nbx * nby);
@@ -626,11 +630,11 @@ extern "C" int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void*
     for (int i = 0; i < n; ++i) {
         const sarGemmWgrad& q = probs[i];
         const int M = q.in_dim, N = q.out_dim, K = q.R;
-        if (!q.X || !q.dY || !q.dW || M < 64 || N < 64 || K < 64 || q.splitk < 1 || (K + 63) / 64 < q.splitk) return SAR_EINVAL;
+        if (!q.X || !q.dY || !q.dW || M < 64 || N < 64 || K < 64 || q.splitk < 1 || q.splitk > 255 || (K + 63) / 64 < q.splitk || q.pad_ < 0 || q.pad_ > 24) return SAR_EINVAL;
         if (((M | N | K | q.lda | q.ldb) & 3) || ((reinterpret_cast<uintptr_t>(q.X) | reinterpret_cast<uintptr_t>(q.dY)) & 15)) return SAR_EINVAL;
         WgRow r;
         r.X = q.X; r.dY = q.dY; r.dW = q.dW; r.db = q.db; r.M = M; r.N = N; r.K = K; r.lda = q.lda; r.ldb = q.ldb; r.ldc = q.ldc;
-        r.splitk = q.splitk; r.first_block = (int)blk;
+        r.splitk = q.splitk | (q.pad_ << 8); r.first_block = (int)blk;   // pad_ (sar_gemm_wgrad_group_scaled_f32): this problem's gradient scale is gscale * 2^-pad_
         rows[i] = r;
         blk += ((long)((N + 63) / 64) * ((M + 63) / 64) * q.splitk + 7) & ~7L;   // every problem starts on XCD 0 (xcd_order); <= 7 idle blocks each
         if (blk > (1L << 30)) return SAR_EINVAL;

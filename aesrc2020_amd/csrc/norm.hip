@@ -278,23 +278,27 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
 // ---- LayerNorm: x (R, C), one wave per row, C % 4 == 0, C <= 2048 -------------------------------------
 constexpr int LN_MAXV = 8;   // float4 per lane
 
-// SK (round 5): a narrow Dense on the NORMALISED rows rides along -- s[r][n] = y[r][:] . sW[:, n] + sb[n], n < N <= 16, C <= 256 -- the
-// cluster-assignment 1x1 conv of the (Ghost)VLAD block (model.py:89-95 / 99-105: 8 + 2 columns on the 256-wide AR_DS_LN output), which as a
-// GEMM launch of its own was 8.8 us for 41 MFLOP.  The lane keeps its four kernel rows in registers; N wave sums per row.
-constexpr int SK_N = 16;
-// The lane's four kernel rows sw[e][n] = sW[4 lane + e][n] (zero past C / N).  Through LDS: the block reads the kernel once, coalesced, and
-// transposes it -- as 4 N gathers per lane (64 lanes x 4 bytes at a stride of 4 N bytes: ~20 cache lines per instruction, in every wave of the
-// launch) the address unit made the fused forward launch 15 us against 5.3 + 7.3 for the two it replaced.  All 256 threads call it.
-__device__ __forceinline__ void sk_rows(float (&sw)[4][SK_N], const float* __restrict__ sW, int C, int N) {
+// SK (round 5): a narrow Dense on the NORMALISED rows rides along -- s[r][n] = y[r][:] . sW[:, n] + sb[n], n < N <= 48, C <= 256 -- the
+// cluster-assignment 1x1 conv of the (Ghost)VLAD block (model.py:89-95 / 99-105: 8 + 2 ... 32 + 2 columns on the 256-wide AR_DS_LN output),
+// which as a GEMM launch of its own was 8.8 us for 41 - 140 MFLOP.
+constexpr int SK_N = 48;                  // columns of the narrow kernel (LDS: SK_N x 260 floats = 50 KB)
+// The narrow kernel, transposed, in LDS: wt[n][c] = sW[c][n].  The block reads it once, coalesced; a lane then fetches its four rows of
+// column n with ONE conflict-free ds_read_b128.  (As 4 N register-resident gathers per lane -- 64 lanes x 4 bytes at a stride of 4 N bytes,
+// ~20 cache lines per instruction, in every wave of the launch -- the address unit made the fused forward launch 15 us against 5.3 + 7.3
+// for the two it replaced; registers also stop at N = 16.)  All 256 threads call it.
+typedef float SkW[256 + 4];
+__device__ __forceinline__ SkW* sk_stage(const float* __restrict__ sW, int C, int N) {
     __shared__ __attribute__((aligned(16))) float wt[SK_N][256 + 4];
     for (int i = threadIdx.x; i < C * N; i += 256) wt[i % N][i / N] = sW[i];
+    for (int i = threadIdx.x; i < N * (256 - C); i += 256) wt[i % N][C + i / N] = 0.f;       // lanes past the row multiply zeros
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int n = 0; n < SK_N; ++n) {
-        const float4 v = (4 * lane < C && n < N) ? *reinterpret_cast<const float4*>(&wt[n][4 * lane]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sw[0][n] = v.x; sw[1][n] = v.y; sw[2][n] = v.z; sw[3][n] = v.w;
-    }
+    return wt;
+}
+// sum over the wave of p for 16 consecutive columns at a time: four DPP steps leave every 16-lane row's sum of column n in all of its lanes,
+// lane % 16 == n % 16 keeps it; sk_rows_sum then adds the four rows (two cross-row moves per 16 columns instead of a full wave_sum per column)
+__device__ __forceinline__ float sk_row16(float p) {
+    p += SAR_DPP_F(p, 0xB1); p += SAR_DPP_F(p, 0x4E); p += SAR_DPP_F(p, 0x141); p += SAR_DPP_F(p, 0x140);
+    return p;
 }
 template <bool SK>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -304,12 +308,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ sy, int N) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
-    float sw[SK ? 4 : 1][SK ? SK_N : 1];
-    float sbias = 0.f;
-    if constexpr (SK) {
-        sk_rows(sw, sW, C, N);
-        sbias = (lane < N && sb != nullptr) ? sb[lane] : 0.f;
-    }
+    SkW* wt = nullptr;
+    if constexpr (SK) wt = sk_stage(sW, C, N);
     for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
         float4 v[LN_MAXV];
         float s = 0.f;
@@ -344,15 +344,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             }
         }
         if constexpr (SK) {                                         // (every lane: lanes past the row hold zeros)
-            float mine = 0.f;
+            for (int n0 = 0; n0 < N; n0 += 16) {                        // kernel-uniform
+                float t = 0.f;
 #pragma unroll
-            for (int n = 0; n < SK_N; ++n) {
-                if (n < N) {                                        // kernel-uniform
-                    const float t = wave_sum(fmaf(o0.x, sw[0][n], fmaf(o0.y, sw[1][n], fmaf(o0.z, sw[2][n], o0.w * sw[3][n]))));
-                    if (lane == n) mine = t;
+                for (int i = 0; i < 16; ++i) {
+                    if (n0 + i < N) {
+                        const float4 w = *reinterpret_cast<const float4*>(&wt[n0 + i][4 * lane]);
+                        const float p = sk_row16(fmaf(o0.x, w.x, fmaf(o0.y, w.y, fmaf(o0.z, w.z, o0.w * w.w))));
+                        if ((lane & 15) == i) t = p;
+                    }
                 }
+                t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+                const int n = n0 + lane;
+                if (lane < 16 && n < N) sy[r * N + n] = t + (sb != nullptr ? sb[n] : 0.f);
             }
-            if (lane < N) sy[r * N + lane] = mine + sbias;
         }
     }
 }
@@ -369,8 +374,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     extern __shared__ __attribute__((aligned(16))) float sm[];       // 4 waves x 2 x C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
-    float sw[SK ? 4 : 1][SK ? SK_N : 1];
-    if constexpr (SK) sk_rows(sw, sW, C, N);
+    SkW* wt = nullptr;
+    if constexpr (SK) wt = sk_stage(sW, C, N);
     float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = ag[j]; }
@@ -381,13 +386,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (SK) {
             const int dsv = __builtin_bit_cast(int, sds[r * N + min(lane, N - 1)]);
-#pragma unroll
-            for (int n = 0; n < SK_N; ++n) {
-                if (n < N) {                                        // kernel-uniform
-                    const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(dsv, n));
-                    extra.x = fmaf(dn, sw[0][n], extra.x); extra.y = fmaf(dn, sw[1][n], extra.y);
-                    extra.z = fmaf(dn, sw[2][n], extra.z); extra.w = fmaf(dn, sw[3][n], extra.w);
-                }
+#pragma unroll 4
+            for (int n = 0; n < N; ++n) {                           // kernel-uniform
+                const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(dsv, n));
+                const float4 w = *reinterpret_cast<const float4*>(&wt[n][4 * lane]);
+                extra.x = fmaf(dn, w.x, extra.x); extra.y = fmaf(dn, w.y, extra.y);
+                extra.z = fmaf(dn, w.z, extra.z); extra.w = fmaf(dn, w.w, extra.w);
             }
         }
 #pragma unroll
@@ -603,11 +607,11 @@ extern "C" int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const 
 }
 
 // include/sarnet.h.  sar_layernorm_fwd_f32 + a narrow Dense on its output in one launch: s (R,N) = y sW + sb; sW (C,N) row-major, sb (N) nullable,
-// N <= 16, C <= 256.
+// N <= 48, C <= 256.
 extern "C" int sar_layernorm_dense_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long R,
                                            int C, float eps, const float* sW, const float* sb, float* s, int N, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || !sW || !s || C % 4 || C > 256 || N < 1 || N > SK_N || R <= 0) return SAR_EINVAL;
-    const int nb = (int)((R + 7) / 8 < 1024 ? (R + 7) / 8 : 1024);       // two rows per wave: the kernel rows (4 N loads per lane) are fetched per wave
+    const int nb = (int)((R + 15) / 16 < 512 ? (R + 15) / 16 : 512);      // four rows per wave: every block stages the kernel (C N floats) first
     hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps, sW, sb, s, N);
     SAR_CHECK_LAUNCH();
     return SAR_OK;

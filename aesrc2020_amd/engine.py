@@ -142,13 +142,19 @@ class ParamStore:
     def begin_deferred_wgrads(self):
         self._defer = [] if (self.training and _lib.get_gemm_math() in ("bf16", "bf16x3") and os.environ.get("SAR_WGRAD_GROUP", "1") == "1") else None
 
-    def bwd_gemm_scale(self):
+    PER_UTT_SHIFT = 6        # gradient rows per utterance, not per frame: ~L times larger, times rstd <= 31 behind a BatchNorm -- 2^-6 of the scale
+
+    def bwd_gemm_shift(self, rows):
+        return self.PER_UTT_SHIFT if rows < 8 * max(self.__dict__.get("batch", 64), 1) else 0
+
+    def bwd_gemm_scale(self, rows=None):
         """> 0: the backward products of the per-frame Dense / GRU-projection layers run single-pass on fp16 operands, the gradient operand
         times this power of two (csrc/gemm.hip: F16) -- the split-precision GEMM mode's backward since round 5 (SAR_GEMM_BWD=x3: three
         passes as in the forward).  The scale is the 2-byte trunk's: 64 x batch, lowered by the overflow guard (gscale_shift)."""
         if not self.training or _lib.get_gemm_math() != "bf16x3" or os.environ.get("SAR_GEMM_BWD", "f16") != "f16":
             return 0.0
-        return float(2 ** (int(round(np.log2(64.0 * max(self.__dict__.get("batch", 64), 1)))) + self.gscale_shift))
+        shift = self.bwd_gemm_shift(rows) if rows is not None else 0
+        return float(2 ** (int(round(np.log2(64.0 * max(self.__dict__.get("batch", 64), 1)))) + self.gscale_shift - shift))
 
     def deferring_wgrads(self):
         return self.__dict__.get("_defer") is not None
@@ -157,7 +163,7 @@ class ParamStore:
         """The operands must stay as they are until flush_wgrads(): per-layer buffers, not shared scratch."""
         # split-K: pick_splitk aims a SINGLE launch at 256 blocks; the group fills the chip anyway and every extra slice is another
         # round of atomics (tools/gemm_group_bench.py, cfg2 problem set: 1 / 2 / 4 / 8 slices = 85 / 60 / 54 / 67 us)
-        self._defer.append((X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, min(splitk, 4)))
+        self._defer.append((X, dY, dW, db, in_dim, out_dim, R, lda, ldb, ldc, min(splitk, 4), self.bwd_gemm_shift(R)))
 
     def flush_wgrads(self):
         probs, self._defer = self.__dict__.get("_defer"), None
@@ -185,7 +191,7 @@ class ParamStore:
         if grp[0] is not None:
             grp[0].launch(self.bwd_gemm_scale())
         for q in grp[1]:
-            _lib.call("sar_gemm_wgrad_f32", *q)
+            _lib.call("sar_gemm_wgrad_f32", *q[:11])
 
     def zero_grads(self, defer=False):
         """defer: the caller promises that the table this returns is zeroed by the very next launch (the 2-byte trunk's weight packing takes

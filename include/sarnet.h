@@ -105,13 +105,14 @@ int sar_get_conv_math(void);
  * backward pass and launches the group behind its last input gradient, model.py:340-366 compile/fit has no such ordering). */
 typedef struct sarGemmWgrad {
     const float* X; const float* dY; float* dW; float* db;
-    int in_dim, out_dim, R, lda, ldb, ldc, splitk, pad_;
+    int in_dim, out_dim, R, lda, ldb, ldc, splitk, pad_;   /* pad_: 0, or (sar_gemm_wgrad_group_scaled_f32) this problem's dY runs under gscale * 2^-pad_ */
 } sarGemmWgrad;
 int sar_gemm_wgrad_group_plan(const sarGemmWgrad* probs, int n, void* table_out, int* total_blocks);
 int sar_gemm_wgrad_group_f32(const void* table_dev, int n, int total_blocks, sarStream_t stream);
 /* The same launch with the BACKWARD arithmetic of the split-precision mode (round 5): gscale > 0 -- one pass on IEEE fp16 copies of the
- * operands, every dY times gscale (a power of two: the static gradient scale of the 2-byte trunk, 64 x batch) while it is staged, dW and
- * db in true units, db summed from the fp32 dY; gscale == 0: sar_gemm_wgrad_group_f32. */
+ * operands, every dY times gscale * 2^-pad_ (powers of two: gscale = the static gradient scale of the 2-byte trunk, 64 x batch; pad_ = the
+ * problem's own reduction, for layers whose gradient rows are per utterance, not per frame) while it is staged, dW and db in true units,
+ * db summed from the fp32 dY; gscale == 0: sar_gemm_wgrad_group_f32. */
 int sar_gemm_wgrad_group_scaled_f32(const void* table_dev, int n, int total_blocks, float gscale, sarStream_t stream);
 /* Input gradients of Dense / GRU-projection layers (model.py:35-42 DS, :46-57 BIGRU: the backward TF derives for them), one or two
  * products into one tensor in ONE launch of the 2-byte MFMA GEMM: C (M,N) = [C +] A B + A2 B2.  A, A2 (M, Kseg) row-major (lda); B, B2
@@ -407,7 +408,7 @@ int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const float* gamm
                               float* dx, float* dgamma, float* dbeta, long R, int C, int accumulate, int act, sarStream_t stream);
 /* LayerNormalization with a NARROW Dense on its output in the same launch -- the cluster-assignment 1x1 conv of the (Ghost)VLAD block
  * (model.py:89-95 / 99-105: vlad_clusters + ghost_clusters columns on the AR_DS_LN rows): s (R,N) = y sW + sb; sW (C,N) row-major, sb (N)
- * nullable; N <= 16, C <= 256.  And its backward half: sar_layernorm_bwd_act_f32 whose incoming gradient is dy + ds sW^T (ds (R,N) = the
+ * nullable; N <= 48, C <= 256.  And its backward half: sar_layernorm_bwd_act_f32 whose incoming gradient is dy + ds sW^T (ds (R,N) = the
  * gradient of s; dy is not modified) -- the Dense's weight gradient stays sar_gemm_wgrad_f32(y, ds). */
 int sar_layernorm_dense_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long R,
                                 int C, float eps, const float* sW, const float* sb, float* s, int N, sarStream_t stream);
