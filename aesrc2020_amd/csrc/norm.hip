@@ -289,7 +289,15 @@ constexpr int SK_N = 48;                  // columns of the narrow kernel (LDS: 
 typedef float SkW[256 + 4];
 __device__ __forceinline__ SkW* sk_stage(const float* __restrict__ sW, int C, int N) {
     __shared__ __attribute__((aligned(16))) float wt[SK_N][256 + 4];
-    for (int i = threadIdx.x; i < C * N; i += 256) wt[i % N][i / N] = sW[i];
+    // (n, c) of element i = c N + n walk along with i: a division per element was ~40 of this loop's ~45 instructions, 1 400 per thread at
+    // N = 34 -- in every block of the launch
+    const int dn = 256 % N, dc = 256 / N;
+    int n = threadIdx.x % N, c = threadIdx.x / N;
+    for (int i = threadIdx.x; i < C * N; i += 256) {
+        wt[n][c] = sW[i];
+        n += dn; c += dc;
+        if (n >= N) { n -= N; ++c; }
+    }
     for (int i = threadIdx.x; i < N * (256 - C); i += 256) wt[i % N][C + i / N] = 0.f;       // lanes past the row multiply zeros
     __syncthreads();
     return wt;

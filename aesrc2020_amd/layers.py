@@ -124,7 +124,7 @@ class LayerNorm(Layer):
     @staticmethod
     def rides(dense, dim):
         """Can `dense` (a linear Dense on this layer's output) be evaluated inside the LayerNorm launches?  (csrc/norm.hip: SK -- the kernels
-        take up to 48 columns; measured: 10 columns (cfg3) -5.6 us per step, 34 columns (cfg2) +5 us against the GEMM launches, so 16 is the rule)"""
+        take up to 48 columns; measured: 10 columns (cfg3) -2 ... -6 us per step, 34 columns (cfg2) +25 us against the GEMM launches, so 16 is the rule)"""
         return (dense is not None and dense.activation is None and dense.units <= 16 and dim <= 256 and dense.in_dim == dim
                 and os.environ.get("SAR_LN_DENSE", "1") == "1")
 
