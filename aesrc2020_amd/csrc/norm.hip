@@ -278,46 +278,12 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
 // ---- LayerNorm: x (R, C), one wave per row, C % 4 == 0, C <= 2048 -------------------------------------
 constexpr int LN_MAXV = 8;   // float4 per lane
 
-// SK (round 5): a narrow Dense on the NORMALISED rows rides along -- s[r][n] = y[r][:] . sW[:, n] + sb[n], n < N <= 48, C <= 256 -- the
-// cluster-assignment 1x1 conv of the (Ghost)VLAD block (model.py:89-95 / 99-105: 8 + 2 ... 32 + 2 columns on the 256-wide AR_DS_LN output),
-// which as a GEMM launch of its own was 8.8 us for 41 - 140 MFLOP.
-constexpr int SK_N = 48;                  // columns of the narrow kernel (LDS: SK_N x 260 floats = 50 KB)
-// The narrow kernel, transposed, in LDS: wt[n][c] = sW[c][n].  The block reads it once, coalesced; a lane then fetches its four rows of
-// column n with ONE conflict-free ds_read_b128.  (As 4 N register-resident gathers per lane -- 64 lanes x 4 bytes at a stride of 4 N bytes,
-// ~20 cache lines per instruction, in every wave of the launch -- the address unit made the fused forward launch 15 us against 5.3 + 7.3
-// for the two it replaced; registers also stop at N = 16.)  All 256 threads call it.
-typedef float SkW[256 + 4];
-__device__ __forceinline__ SkW* sk_stage(const float* __restrict__ sW, int C, int N) {
-    __shared__ __attribute__((aligned(16))) float wt[SK_N][256 + 4];
-    // (n, c) of element i = c N + n walk along with i: a division per element was ~40 of this loop's ~45 instructions, 1 400 per thread at
-    // N = 34 -- in every block of the launch
-    const int dn = 256 % N, dc = 256 / N;
-    int n = threadIdx.x % N, c = threadIdx.x / N;
-    for (int i = threadIdx.x; i < C * N; i += 256) {
-        wt[n][c] = sW[i];
-        n += dn; c += dc;
-        if (n >= N) { n -= N; ++c; }
-    }
-    for (int i = threadIdx.x; i < N * (256 - C); i += 256) wt[i % N][C + i / N] = 0.f;       // lanes past the row multiply zeros
-    __syncthreads();
-    return wt;
-}
-// sum over the wave of p for 16 consecutive columns at a time: four DPP steps leave every 16-lane row's sum of column n in all of its lanes,
-// lane % 16 == n % 16 keeps it; sk_rows_sum then adds the four rows (two cross-row moves per 16 columns instead of a full wave_sum per column)
-__device__ __forceinline__ float sk_row16(float p) {
-    p += SAR_DPP_F(p, 0xB1); p += SAR_DPP_F(p, 0x4E); p += SAR_DPP_F(p, 0x141); p += SAR_DPP_F(p, 0x140);
-    return p;
-}
-template <bool SK>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long R, int C,
-                                                     float eps, const float* __restrict__ sW, const float* __restrict__ sb,
-                                                     float* __restrict__ sy, int N) {
+                                                     float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
-    SkW* wt = nullptr;
-    if constexpr (SK) wt = sk_stage(sW, C, N);
     for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
         float4 v[LN_MAXV];
         float s = 0.f;
@@ -338,7 +304,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
         const float rs = 1.f / sqrtf(wave_sum(q) / C + eps);
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
-        float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c4 = lane + j * 64;
@@ -348,42 +313,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 o.x = (v[j].x - mu) * rs * g.x + be.x; o.y = (v[j].y - mu) * rs * g.y + be.y;
                 o.z = (v[j].z - mu) * rs * g.z + be.z; o.w = (v[j].w - mu) * rs * g.w + be.w;
                 reinterpret_cast<float4*>(y + r * C)[c4] = o;
-                if (SK && j == 0) o0 = o;
-            }
-        }
-        if constexpr (SK) {                                         // (every lane: lanes past the row hold zeros)
-            for (int n0 = 0; n0 < N; n0 += 16) {                        // kernel-uniform
-                float t = 0.f;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (n0 + i < N) {
-                        const float4 w = *reinterpret_cast<const float4*>(&wt[n0 + i][4 * lane]);
-                        const float p = sk_row16(fmaf(o0.x, w.x, fmaf(o0.y, w.y, fmaf(o0.z, w.z, o0.w * w.w))));
-                        if ((lane & 15) == i) t = p;
-                    }
-                }
-                t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-                const int n = n0 + lane;
-                if (lane < 16 && n < N) sy[r * N + n] = t + (sb != nullptr ? sb[n] : 0.f);
             }
         }
     }
 }
 
-// SK: the incoming gradient is dy + ds sW^T -- the input gradient of the narrow Dense that ln_fwd_kernel<true> evaluated on this layer's output
-// (ds (R,N) = the gradient of its output), which as a GEMM launch accumulating into dy was 10.6 us.
-template <bool SK>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
-                                                     int C, int accumulate, int act, const float* __restrict__ sds,
-                                                     const float* __restrict__ sW, int N) {
+                                                     int C, int accumulate, int act) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // 4 waves x 2 x C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
-    SkW* wt = nullptr;
-    if constexpr (SK) wt = sk_stage(sW, C, N);
     float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = ag[j]; }
@@ -391,24 +333,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float mu = mean[r], rs = rstd[r];
         float4 xh[LN_MAXV], g[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
-        float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (SK) {
-            const int dsv = __builtin_bit_cast(int, sds[r * N + min(lane, N - 1)]);
-#pragma unroll 4
-            for (int n = 0; n < N; ++n) {                           // kernel-uniform
-                const float dn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(dsv, n));
-                const float4 w = *reinterpret_cast<const float4*>(&wt[n][4 * lane]);
-                extra.x = fmaf(dn, w.x, extra.x); extra.y = fmaf(dn, w.y, extra.y);
-                extra.z = fmaf(dn, w.z, extra.z); extra.w = fmaf(dn, w.w, extra.w);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < LN_MAXV; ++j) {
             const int c4 = lane + j * 64;
             if (c4 < C4) {
                 const float4 v = reinterpret_cast<const float4*>(x + r * C)[c4];
-                float4 d = reinterpret_cast<const float4*>(dy + r * C)[c4];
-                if (SK && j == 0) { d.x += extra.x; d.y += extra.y; d.z += extra.z; d.w += extra.w; }
+                const float4 d = reinterpret_cast<const float4*>(dy + r * C)[c4];
                 const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
                 xh[j] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
                 g[j] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
@@ -583,7 +513,7 @@ extern "C" int sar_layernorm_fwd_f32(const float* x, const float* gamma, const f
                                      float* rstd, long R, int C, float eps, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !rstd || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     const int nb = (int)((R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048);
-    hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<float*>(nullptr), 0);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -594,7 +524,7 @@ extern "C" int sar_layernorm_bwd_f32(const float* dy, const float* x, const floa
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
     const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, (int)ACT_NONE, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), 0);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, ACT_NONE);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }
@@ -609,30 +539,7 @@ extern "C" int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const 
     if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
     static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
     const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), 0);
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
-}
-
-// include/sarnet.h.  sar_layernorm_fwd_f32 + a narrow Dense on its output in one launch: s (R,N) = y sW + sb; sW (C,N) row-major, sb (N) nullable,
-// N <= 48, C <= 256.
-extern "C" int sar_layernorm_dense_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long R,
-                                           int C, float eps, const float* sW, const float* sb, float* s, int N, hipStream_t stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || !sW || !s || C % 4 || C > 256 || N < 1 || N > SK_N || R <= 0) return SAR_EINVAL;
-    const int nb = (int)((R + 15) / 16 < 512 ? (R + 15) / 16 : 512);      // four rows per wave: every block stages the kernel (C N floats) first
-    hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(nb), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, R, C, eps, sW, sb, s, N);
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
-}
-// include/sarnet.h.  sar_layernorm_bwd_act_f32 whose incoming gradient is dy + ds sW^T (the input gradient of that narrow Dense); dy is not written.
-extern "C" int sar_layernorm_bwd_dense_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                                           float* dgamma, float* dbeta, long R, int C, int accumulate, int act, const float* ds, const float* sW,
-                                           int N, hipStream_t stream) {
-    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ds || !sW || C % 4 || C > 256 || N < 1 || N > SK_N) return SAR_EINVAL;
-    if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
-    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;
-    const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act, ds, sW, N);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -121,38 +121,19 @@ class LayerNorm(Layer):
         self.beta = self.store.add(name + "/beta", (dim,), np.zeros(dim))
         self.dim = dim; self.output_shape = (None, dim)
 
-    @staticmethod
-    def rides(dense, dim):
-        """Can `dense` (a linear Dense on this layer's output) be evaluated inside the LayerNorm launches?  (csrc/norm.hip: SK -- the kernels
-        take up to 48 columns; measured: 10 columns (cfg3) -2 ... -6 us per step, 34 columns (cfg2) +25 us against the GEMM launches, so 16 is the rule)"""
-        return (dense is not None and dense.activation is None and dense.units <= 16 and dim <= 256 and dense.in_dim == dim
-                and os.environ.get("SAR_LN_DENSE", "1") == "1")
-
-    def forward(self, x, dense=None):
-        """dense (LayerNorm.rides): its forward pass runs in this launch -- dense.y = y W + b is ready on return, dense.x = y."""
+    def forward(self, x):
         R = x.numel() // self.dim
         self.x, self.R = x, R
         y = self.buf("y", (R, self.dim)); self.mean = self.buf("mean", (R,)); self.rstd = self.buf("rstd", (R,))
-        if dense is not None:
-            dense.x, dense.R = y, R
-            dense.y = dense.buf("y", (R, dense.units))
-            _call("sar_layernorm_dense_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, R, self.dim, LN_EPS,
-                  dense.kernel.w, dense.bias.w if dense.bias is not None else None, dense.y, dense.units)
-        else:
-            _call("sar_layernorm_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, R, self.dim, LN_EPS)
+        _call("sar_layernorm_fwd_f32", x, self.gamma.w, self.beta.w, y, self.mean, self.rstd, R, self.dim, LN_EPS)
         return y
 
-    def backward(self, dy, accumulate_dx=False, dx_out=None, act=None, dense=None, ddense=None):
+    def backward(self, dy, accumulate_dx=False, dx_out=None, act=None):
         """act: activation of the Dense whose OUTPUT this layer normalises ('tanh'): its backward is applied here as well, the
-        result is d/dz of that Dense (pass it on with Dense.backward(..., dz_ready=True)).
-        dense, ddense: the incoming gradient is dy + ddense W^T -- the input gradient of the Dense that rode in forward()."""
+        result is d/dz of that Dense (pass it on with Dense.backward(..., dz_ready=True))."""
         dx = dx_out if dx_out is not None else self.buf("dx", (self.R, self.dim))
-        if dense is not None:
-            _call("sar_layernorm_bwd_dense_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g,
-                  self.R, self.dim, 1 if accumulate_dx else 0, ACT[act], ddense, dense.kernel.w, dense.units)
-        else:
-            _call("sar_layernorm_bwd_act_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g,
-                  self.R, self.dim, 1 if accumulate_dx else 0, ACT[act])
+        _call("sar_layernorm_bwd_act_f32", dy, self.x, self.gamma.w, self.mean, self.rstd, dx, self.gamma.g, self.beta.g,
+              self.R, self.dim, 1 if accumulate_dx else 0, ACT[act])
         return dx
 
 

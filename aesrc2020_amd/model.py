@@ -69,21 +69,13 @@ class _VladBlock:
         self.pool = vd.VladPooling(k_centers=vlad_clusters, g_centers=g, mode=aggregation, name=aggregation + "_pool", feat_dim=hidden)
         self.out_dim = vlad_clusters * hidden
 
-    def forward(self, x, B, L, score_ready=False):
-        """score_ready: the assignment conv rode in the LayerNorm launch that produced x (layers.LayerNorm.forward(dense=self.assign))."""
-        score = self.assign.y if score_ready else self.assign.forward(x)
-        self.rode = score_ready
+    def forward(self, x, B, L):
+        score = self.assign.forward(x)
         return self.pool.forward(x.view(B, L, -1), score.view(B, L, -1))
 
     def backward(self, dout):
-        """-> d(x); where the assignment conv rode in the LayerNorm launch, its input gradient is left to that layer's backward
-        (self.dscore: pass it as LayerNorm.backward(dense=self.assign, ddense=self.dscore)) and only its weight gradient runs here."""
         dfeat, dscore = self.pool.backward(dout)
-        if self.rode:
-            self.dscore = dscore.view(-1, dscore.shape[-1])
-            self.assign.backward(self.dscore, need_dx=False)
-        else:
-            self.assign.backward(dscore, dx_out=dfeat.view(-1, dfeat.shape[-1]), accumulate_dx=True)
+        self.assign.backward(dscore, dx_out=dfeat.view(-1, dfeat.shape[-1]), accumulate_dx=True)
         return dfeat.view(-1, dfeat.shape[-1])
 
 
@@ -385,10 +377,9 @@ class SARNetModel:
                   self.ctc_ws, self.ctc_ws_bytes, B, L, c["bpe_classes"], c["max_ctc_len"])
             self.out["y_ctc_loss"] = self.ctc_loss
         if c["ar_enable"]:
-            rides = c["mto"] in ("vlad", "gvlad") and LayerNorm.rides(self.merge.assign, c["hidden_dim"])
-            ar = self.AR_DS_LN.forward(self.AR_DS.forward(crnn), dense=self.merge.assign if rides else None)
-            if rides:
-                ar = self.merge.forward(ar, B, L, score_ready=True)      # the assignment conv ran in the LayerNorm launch
+            ar = self.AR_DS_LN.forward(self.AR_DS.forward(crnn))
+            if c["mto"] == "avg":
+                ar = self.merge.forward(ar, B, L)
             else:
                 ar = self.merge.forward(ar, B, L)
             ar = self.AR_BN1.forward(ar, B)
@@ -504,10 +495,7 @@ class SARNetModel:
                 g = self.merge.backward(g)
             else:
                 g = self.merge.backward(g)
-            if getattr(self.merge, "rode", False):
-                g = self.AR_DS_LN.backward(g, act=self.AR_DS.activation, dense=self.merge.assign, ddense=self.merge.dscore)
-            else:
-                g = self.AR_DS_LN.backward(g, act=self.AR_DS.activation)
+            g = self.AR_DS_LN.backward(g, act=self.AR_DS.activation)
             if d_crnn is not None:
                 self.AR_DS.backward(g, dx_out=d_crnn, accumulate_dx=True, dz_ready=True)
             else:

@@ -406,15 +406,6 @@ int sar_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, c
  * 279-280): x = act(z) is the LayerNorm's input, dx = d/dz.  act: SAR_ACT_NONE / SAR_ACT_TANH. */
 int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               float* dx, float* dgamma, float* dbeta, long R, int C, int accumulate, int act, sarStream_t stream);
-/* LayerNormalization with a NARROW Dense on its output in the same launch -- the cluster-assignment 1x1 conv of the (Ghost)VLAD block
- * (model.py:89-95 / 99-105: vlad_clusters + ghost_clusters columns on the AR_DS_LN rows): s (R,N) = y sW + sb; sW (C,N) row-major, sb (N)
- * nullable; N <= 48, C <= 256.  And its backward half: sar_layernorm_bwd_act_f32 whose incoming gradient is dy + ds sW^T (ds (R,N) = the
- * gradient of s; dy is not modified) -- the Dense's weight gradient stays sar_gemm_wgrad_f32(y, ds). */
-int sar_layernorm_dense_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long R,
-                                int C, float eps, const float* sW, const float* sb, float* s, int N, sarStream_t stream);
-int sar_layernorm_bwd_dense_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
-                                float* dgamma, float* dbeta, long R, int C, int accumulate, int act, const float* ds, const float* sW,
-                                int N, sarStream_t stream);
 
 /* ---- Bidirectional(CuDNNGRU), merge_mode='concat': model.py:44-50.  xa_* = x*kernel + bias[:3H] (B,L,3H);
  * out (B,L,2H) = [fwd | bwd]; gates (2,B,L,4,H), hprev (2,B,L,H) are saved for BPTT; UT_* = U^T (3H,H);

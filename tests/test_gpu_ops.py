@@ -682,34 +682,6 @@ def test_layernorm(L, R, C):
     check(dx, dxt_ref * (1 - xt * xt), name="ln+tanh dz"); check(dg, dgt_ref, name="ln+tanh dgamma"); check(db, dbt_ref, name="ln+tanh dbeta")
 
 
-@pytest.mark.parametrize("R,C,N", [(8000, 256, 10), (8000, 256, 34), (2496, 256, 16), (2496, 256, 48), (77, 64, 6), (5, 128, 1), (300, 32, 17)])
-def test_layernorm_with_narrow_dense(L, R, C, N):
-    """sar_layernorm_dense_fwd_f32 / sar_layernorm_bwd_dense_f32: the LayerNorm launches that also carry the (Ghost)VLAD assignment conv --
-    s = LN(x) W + b forward; backward with incoming gradient dy + ds W^T, with and without the tanh' of the Dense in front -- against the
-    float64 oracle ops chained the way the separate launches were."""
-    rng = np.random.default_rng(R + N)
-    x = np.tanh(rng.standard_normal((R, C))); gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C)
-    W = rng.standard_normal((C, N)) / np.sqrt(C); b = rng.standard_normal(N)
-    y_ref, cache = O.layernorm_fwd(x, gamma, beta)
-    xd, gd, Wd = dev(x), dev(gamma), dev(W); y, mean, rstd, sc = zeros(R, C), zeros(R), zeros(R), zeros(R, N)
-    L.call("sar_layernorm_dense_fwd_f32", xd, gd, dev(beta), y, mean, rstd, R, C, 1e-14, Wd, dev(b), sc, N)
-    check(y, y_ref, name="ln fwd"); check(sc, y_ref @ W + b, name="narrow dense on ln")
-    sc2 = zeros(R, N)
-    L.call("sar_layernorm_dense_fwd_f32", xd, gd, dev(beta), y, mean, rstd, R, C, 1e-14, Wd, None, sc2, N)
-    check(sc2, y_ref @ W, name="narrow dense, no bias")
-    dy = rng.standard_normal((R, C)); ds = rng.standard_normal((R, N))
-    dx_ref, dg_ref, db_ref = O.layernorm_bwd(dy + ds @ W.T, cache)
-    for act, f in ((0, 1.0), (1, 1 - x * x)):
-        dyd = dev(dy); dx, dg, db = zeros(R, C), zeros(C), zeros(C)
-        L.call("sar_layernorm_bwd_dense_f32", dyd, xd, gd, mean, rstd, dx, dg, db, R, C, 0, act, dev(ds), Wd, N)
-        check(dx, dx_ref * f, name="ln+dense dx (act %d)" % act); check(dg, dg_ref, name="dgamma"); check(db, db_ref, name="dbeta")
-        assert torch.equal(dyd.cpu(), dev(dy).cpu())                         # the incoming gradient is read, not modified
-        L.call("sar_layernorm_bwd_dense_f32", dyd, xd, gd, mean, rstd, dx, dg, db, R, C, 1, act, dev(ds), Wd, N)
-        check(dx, 2 * dx_ref * f, name="ln+dense dx accumulate")
-    with pytest.raises(RuntimeError):
-        L.call("sar_layernorm_dense_fwd_f32", xd, gd, dev(beta), y, mean, rstd, R, C, 1e-14, Wd, None, sc2, 49)
-
-
 # ------------------------------------------------------------------ BiGRU
 @pytest.mark.parametrize("B,Lq,I,H", [(5, 7, 12, 64), (64, 39, 256, 256), (3, 12, 40, 20)])
 def test_bigru(L, B, Lq, I, H):
