@@ -318,18 +318,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long R,
                                                      int C, int accumulate, int act) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];       // 4 waves x 2 x C
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // NW waves x 2 x C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C4 = C / 4;
     float4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = ag[j]; }
-    for (long r = (long)blockIdx.x * 4 + wave; r < R; r += (long)gridDim.x * 4) {
+    for (long r = (long)blockIdx.x * NW + wave; r < R; r += (long)gridDim.x * NW) {
         const float mu = mean[r], rs = rstd[r];
         float4 xh[LN_MAXV], g[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -376,9 +377,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (c4 < C4) { reinterpret_cast<float4*>(sg)[c4] = ag[j]; reinterpret_cast<float4*>(sb)[c4] = ab[j]; }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += NW * 64) {
         float a = 0.f, b = 0.f;
-        for (int w = 0; w < 4; ++w) { a += sm[w * 2 * C + c]; b += sm[w * 2 * C + C + c]; }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { a += sm[w * 2 * C + c]; b += sm[w * 2 * C + C + c]; }
         atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b);
     }
 }
@@ -518,15 +520,29 @@ extern "C" int sar_layernorm_fwd_f32(const float* x, const float* gamma, const f
     return SAR_OK;
 }
 
+// Blocks x waves of the backward launch: every block ends in 2C atomics (R = 2496, C = 256, four waves: 32 / 64 / 128 / 256 / 512 blocks = 20.6 /
+// 12.5 / 9.9 / 11.2 / 16.6 us), and with four waves 128 blocks are two waves per CU on half of the chip -- each walking 16 rows one dependent
+// load-reduce-store round after the other.  Round 5: 512-thread blocks, the same number of atomics for twice the waves -- step A/B (three
+// launches per step): 128 x 4 waves 2.0189 ms, 128 x 8 2.0122, 256 x 8 2.0226, 128 / 256 x 16 2.036 (SAR_LN_BWD_WAVES, SAR_LN_BWD_BLOCKS).
+static int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+                         float* dbeta, long R, int C, int accumulate, int act, hipStream_t stream) {
+    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;
+    static const int nw_env = getenv("SAR_LN_BWD_WAVES") ? atoi(getenv("SAR_LN_BWD_WAVES")) : 8;
+    const int nw = (nw_env == 8 || nw_env == 16) && sizeof(float) * 2 * nw_env * C <= 48 * 1024 ? nw_env : 4;   // (the cross-wave reduction's LDS)
+    const long want = (R + nw - 1) / nw;
+    const int nb = (int)(want < ln_cap ? want : ln_cap);
+    if (nw == 16) hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nb), dim3(1024), sizeof(float) * 32 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
+    else if (nw == 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(nb), dim3(512), sizeof(float) * 16 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
+    else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}
+
 extern "C" int sar_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
                                      const float* rstd, float* dx, float* dgamma, float* dbeta, long R, int C,
                                      int accumulate, hipStream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
-    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
-    const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, ACT_NONE);
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, ACT_NONE, stream);
 }
 
 // LayerNormalization backward fused with the backward of the activation in FRONT of it: the reference's DS(..., 'tanh') -> LN pairs
@@ -537,9 +553,5 @@ extern "C" int sar_layernorm_bwd_act_f32(const float* dy, const float* x, const 
                                          int accumulate, int act, hipStream_t stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || C % 4 || C > 64 * 4 * LN_MAXV) return SAR_EINVAL;
     if (act != ACT_NONE && act != ACT_TANH) return SAR_EINVAL;
-    static const int ln_cap = getenv("SAR_LN_BWD_BLOCKS") ? atoi(getenv("SAR_LN_BWD_BLOCKS")) : 128;   // blocks: every block ends in 2C atomics (R = 2496, C = 256: 32 / 64 / 128 / 256 / 512 blocks = 20.6 / 12.5 / 9.9 / 11.2 / 16.6 us)
-    const int nb = (int)((R + 3) / 4 < ln_cap ? (R + 3) / 4 : ln_cap);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act);
-    SAR_CHECK_LAUNCH();
-    return SAR_OK;
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, R, C, accumulate, act, stream);
 }
