@@ -1764,7 +1764,7 @@ static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act3
     if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || ca[4] != cb[4] || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
     typedef void (*pair_t)(const ConvP, const ConvP, unsigned, unsigned, unsigned, unsigned);
     pair_t kern = nullptr;
-    static PerDeviceFlag at[10];
+    static PerDeviceFlag at[12];
     int ki = -1;
     const bool a32 = act32 != 0;
 #define PK(...) (a32 ? conv_bf16_pair_kernel<A32K(__VA_ARGS__) : conv_bf16_pair_kernel<__VA_ARGS__>)
@@ -1773,8 +1773,11 @@ static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act3
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = PK(2, 8, 9, 4, 2, true); ki = 2; }
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = PK(2, 8, 18, 4, 2, true); ki = 3; }
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 18 && ca[3] == 4 && ca[4] == 1 && ca[5]) { kern = PK(2, 8, 18, 4, 1, true); ki = 4; }
+    // (round 5) the 256-pixel form of the 64-channel sources: res34's stem is 64 wide whatever res_filters is (resnet.py:191), so at res_filters 32
+    // the first block's conv and its 1x1 shortcut both read the pooled map -- 30 + 14.6 us as two launches
+    else if (ca[0] == 1 && ca[1] == 4 && ca[2] == 9 && ca[3] == 1 && ca[4] == 8 && !ca[5]) { kern = PK(1, 4, 9, 1, 8, false); ki = 5; }
 #undef PK
-    if (a32 && ki >= 0) ki += 5;
+    if (a32 && ki >= 0) ki += 6;
     if (kern == nullptr) return SAR_EINVAL;
     if (!at[ki]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at[ki] = true; }
     const unsigned na = la.grid.x * la.grid.y, nb = lb.grid.x * lb.grid.y, na8 = (na + 7u) & ~7u;
