@@ -136,6 +136,50 @@ def _forward_backward_parity(case, cfg, ref, model, batch, gtol):
     assert set(r.name for r in model.store.refs if r.l2 > 0) == set(ref.reg)
 
 
+# The backward arithmetic of the default mode at a size where ALL of it is in force (round 5).  The parity cases above have B*L off the 64-row tiles
+# of the 2-byte GEMMs, so their Dense / GRU-projection backward stays on the fp32 kernels; here B*L = 192, every width a multiple of 64: the input
+# gradients run sar_gemm_pair_f32 (single-pass fp16 operands under the gradient scale; both GRU directions in one launch), the weight gradients the
+# scaled grouped launch, the two heads of the accent branch one launch.  Held: (a) against the float64 oracle exactly as the "x3" cases above;
+# (b) every switch's other arm against the default: same gradient to the fp16 operands' rounding.
+ARMS_KW = dict(input_shape=[256, 80, 1], res_type="res18", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=8, ghost_clusters=2,
+               disc_enable=True, ctc_enable=True, bpe_classes=64, max_ctc_len=8, metric_loss="arcface", B=8)
+
+
+def test_default_mode_backward_arms(monkeypatch):
+    from tests._modes import mode, runs_shipped_kernels
+    from aesrc2020_amd import _lib
+
+    def flat(model):
+        return np.concatenate([r.g.cpu().numpy().ravel() for r in model.store.refs]).astype(np.float64)
+
+    with mode("x3"):
+        cfg, ref, model, batch = build_pair(ARMS_KW)
+        assert runs_shipped_kernels(model) and model.L * 8 % 64 == 0
+        calls = []
+        orig = _lib.call
+        monkeypatch.setattr(_lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+        import aesrc2020_amd.layers as LY, aesrc2020_amd.model as MD, aesrc2020_amd.engine as EN
+        for mod in (LY, MD):
+            if getattr(mod, "_call", None) is orig:
+                monkeypatch.setattr(mod, "_call", _lib.call)
+        _forward_backward_parity("default_mode_backward_arms", cfg, ref, model, batch, None)
+        assert model.store.bwd_gemm_scale() > 0
+        assert "sar_gemm_pair_f32" in calls and "sar_accent_margin_train_f32" in calls and "sar_gemm_wgrad_group_scaled_f32" in calls, sorted(set(calls))
+        g0 = flat(model)
+        for env, gone in (("SAR_GEMM_BWD", "x3"), ("SAR_GEMM_PAIR", "0"), ("SAR_FUSED_HEADS", "0"), ("SAR_X3_BWD", "x3")):
+            monkeypatch.setenv(env, gone)
+            try:
+                _, _, m2, _ = build_pair(ARMS_KW)
+                m2.forward_backward_only(batch, batch)
+                torch.cuda.synchronize()
+                g = flat(m2)
+            finally:
+                monkeypatch.delenv(env)
+            l2 = float(np.linalg.norm(g - g0) / np.linalg.norm(g0))
+            print("%s=%s: flat gradient vs the default arm %.2e" % (env, gone, l2))
+            assert np.all(np.isfinite(g)) and l2 < 2e-2, (env, l2)
+
+
 def grad_mismatches(model, ref, G, tol=2e-3):
     """Per-tensor gradient comparison (see test_forward_backward_parity for the zero-gradient rule)."""
     ref_g = {r.name: G[r.name].numpy() - (2 * MT.L2 * ref.P[r.name].numpy() if r.name in ref.reg else 0.0) for r in model.store.refs}
