@@ -785,7 +785,7 @@ def test_bigru_bf16_mfma(L, B, Lq):
 def test_zero_and_copy_ranges(L):
     """sar_zero_ranges / sar_copy_ranges: many buffers in one launch from a device table (the step-start zeroing and the device batch's
     input copies), sizes that are and are not multiples of four words, untouched neighbours."""
-    sizes = [1, 3, 4, 5, 1024, 4099, 1 << 20]
+    sizes = [1, 3, 4, 5, 1024, 4099, 1 << 20, 2_621_447]             # (the last: past one sweep of the copy's four-loads-in-flight loop, ragged end)
     bufs = [torch.full((n + 8,), 7.0, device="cuda") for n in sizes]
     tab = torch.tensor([[b.data_ptr(), n] for b, n in zip(bufs, sizes)], dtype=torch.int64, device="cuda")
     L.call("sar_zero_ranges", tab, len(sizes))
