@@ -55,6 +55,9 @@ SWEEP += [
     dict(input_shape=[65, 40, 1], res_type="res34", res_filters=32, hidden_dim=32, mto="vlad", vlad_clusters=2, disc_enable=True, metric_loss="arcface", B=1),
     dict(input_shape=[81, 80, 1], res_type="res34", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=8, ghost_clusters=2, disc_enable=True,
          ctc_enable=True, bpe_classes=40, max_ctc_len=5, metric_loss="arcface", B=5),
+    # four accents, nine utterances: the one-launch heads (csrc/heads_fused.hip) in their four-class form, the last row block ragged
+    dict(input_shape=[65, 80, 1], res_type="res18", res_filters=32, hidden_dim=64, mto="gvlad", vlad_clusters=4, ghost_clusters=1, disc_enable=True,
+         metric_loss="cosface", accent_classes=4, B=9),
 ]
 
 # every case in the two fp32-storage modes of round 1; every case whose width the shipped kernels take (res_filters 32 / 64) ALSO in the
