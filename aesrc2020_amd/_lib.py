@@ -316,8 +316,9 @@ class WgradPlan:
             raise RuntimeError("%s failed with status %d" % (self.entry, rc))
 
     @staticmethod
-    def reduce_multi(plans, sfx="bf16"):
-        """ONE reduction launch for the plans launched with defer_reduce (sar_wgrad_reduce_multi_*; four plans per launch)."""
+    def reduce_multi(plans, sfx="bf16", overwrite=False):
+        """ONE reduction launch for the plans launched with defer_reduce (sar_wgrad_reduce_multi_*; four plans per launch).
+        overwrite: dw = the sums instead of dw += (the caller knows dw is zero and has no other writer: the train step)."""
         import torch
         todo = [p for p in plans if p.n_tiles]
         for i in range(0, len(todo), 4):
@@ -325,7 +326,7 @@ class WgradPlan:
             arr = (WgradReduce * len(grp))()
             for a, p in zip(arr, grp):
                 a.convs_dev, a.tiles_dev, a.slices_dev, a.slab = p.convs.data_ptr(), p.tiles.data_ptr(), p.slices.data_ptr(), p.slab.data_ptr()
-                a.n_tiles, a.K, a.tile_ci, a.tile_co = p.n_tiles, p.K, p.launch4[3] >> 4, p.launch4[3] & 15
+                a.n_tiles, a.K, a.tile_ci, a.tile_co = p.n_tiles, p.K + (256 if overwrite else 0), p.launch4[3] >> 4, p.launch4[3] & 15
             rc = lib().fn["sar_wgrad_reduce_multi_" + sfx](arr, len(grp), torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 raise RuntimeError("sar_wgrad_reduce_multi_%s failed with status %d" % (sfx, rc))

@@ -1209,7 +1209,9 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
 
 // Sum of the partial tiles of every multi-slice gradient tile, in slice order (deterministic), added into the gradient: grid
 // (tiles, 32 x 32 sub-tiles of a tile = taps x TCI x TCO), 256 threads x float4.  K3: slabs in accumulator-register order (above).
-template <bool K3>
+// WR (round 5): the sums are WRITTEN, dw = ..., not added -- a gradient tile has exactly one reduction block, and in the train step dw was zeroed at the step's start: the
+// read of the read-modify-write was 21 MB of zeros per step (-4 us).
+template <bool K3, bool WR = false>
 __device__ __forceinline__ void wgrad_reduce_body(const unsigned char* __restrict__ convs, const WgTile* __restrict__ tiles,
                                                   const int* __restrict__ slices, const float* __restrict__ slab, int tci, int tco, int tile, int sub, int nsub) {
     const WgTile t = tiles[tile];
@@ -1236,10 +1238,11 @@ __device__ __forceinline__ void wgrad_reduce_body(const unsigned char* __restric
         const int q = tid >> 6, lane = tid & 63, col = lane & 31, row0 = 8 * q + 4 * (lane >> 5);
         float* o = dwp + ((size_t)w * Cin + t.ci0 + i * 32 + row0) * Cout + t.co0 + j * 32 + col;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[(size_t)k * Cout] += r[k];
+        for (int k = 0; k < 4; ++k) { if (WR) o[(size_t)k * Cout] = r[k]; else o[(size_t)k * Cout] += r[k]; }
     } else {
         float4* o = reinterpret_cast<float4*>(dwp + (size_t)(t.ci0 + (tid >> 3)) * Cout + t.co0 + (tid & 7) * 4);
-        float4 v = *o;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!WR) v = *o;
         v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
         *o = v;
     }
@@ -1258,8 +1261,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const RedPlans 
     const int b = blockIdx.x;
     const int i = (b >= P.first[1]) + (b >= P.first[2]) + (b >= P.first[3]);
     const RedPlan& q = P.p[i];
-    const int local = b - P.first[i], nsub = q.k3 ? 9 * q.tci * q.tco : 1, tile = local / nsub, sub = local - tile * nsub;
-    if (q.k3) wgrad_reduce_body<true>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
+    const int local = b - P.first[i], nsub = (q.k3 & 1) ? 9 * q.tci * q.tco : 1, tile = local / nsub, sub = local - tile * nsub;
+    if (q.k3 & 2) {                                                 // (block-uniform) bit 1: written, not added
+        if (q.k3 & 1) wgrad_reduce_body<true, true>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
+        else wgrad_reduce_body<false, true>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
+    } else if (q.k3 & 1) wgrad_reduce_body<true>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
     else wgrad_reduce_body<false>(q.convs, q.tiles, q.slices, q.slab, q.tci, q.tco, tile, sub, nsub);
 }
 
@@ -1980,11 +1986,12 @@ int SAR_T16(sar_wgrad_reduce_multi_)(const sarWgradReduce* plans, int n, hipStre
         P.first[i] = blocks;
         if (i >= n) continue;
         const sarWgradReduce& r = plans[i];
-        if (r.n_tiles < 0 || (r.K != 1 && r.K != 3) || r.tile_ci < 1 || r.tile_ci > 2 || r.tile_co < 1 || r.tile_co > 2) return SAR_EINVAL;
+        const int K = r.K & 255, wr = (r.K >> 8) & 1;                                 // K + 256: the sums are written (dw = ...), not added
+        if (r.n_tiles < 0 || (K != 1 && K != 3) || (r.K & ~0x1ff) || r.tile_ci < 1 || r.tile_ci > 2 || r.tile_co < 1 || r.tile_co > 2) return SAR_EINVAL;
         if (r.n_tiles > 0 && (!r.convs_dev || !r.tiles_dev || !r.slices_dev || !r.slab)) return SAR_EINVAL;
         P.p[i] = RedPlan{static_cast<const unsigned char*>(r.convs_dev), static_cast<const WgTile*>(r.tiles_dev), r.slices_dev, r.slab, r.n_tiles,
-                         r.K == 3 ? 1 : 0, r.tile_ci, r.tile_co};
-        blocks += r.n_tiles * (r.K == 3 ? 9 * r.tile_ci * r.tile_co : 1);
+                         (K == 3 ? 1 : 0) | (wr << 1), r.tile_ci, r.tile_co};
+        blocks += r.n_tiles * (K == 3 ? 9 * r.tile_ci * r.tile_co : 1);
     }
     P.first[4] = blocks;
     for (int i = n; i < 4; ++i) P.first[i] = blocks;                                // (no block falls into an absent plan)

@@ -587,7 +587,9 @@ class ResNetTrunk(Layer):
             for p in plans[key]:
                 p.launch(defer_reduce=multi)
             if multi:
-                _lib.WgradPlan.reduce_multi(plans[key], self.wsfx)
+                # in a train step the kernel gradients are zero here (zeroed at the step's start, this reduction their only writer): written, not added
+                _lib.WgradPlan.reduce_multi(plans[key], self.wsfx, overwrite=self.store.__dict__.get("_zeroed_this_step", False)
+                                            and os.environ.get("SAR_WG_REDUCE_WRITE", "1") == "1")
 
     # stem of the bf16 trunk (csrc/stem_bf16.hip): the 7x7 conv is recomputed wherever its output is needed, so only the pooled map
     # (bf16) and its argmax slots exist in HBM -- no (B, T/2, D/2, C0) tensor, forward or backward

@@ -241,7 +241,9 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
 int sar_conv2d_wgrad_batch_bf16(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                 const int* slices_dev, float* slab, sarStream_t stream);
 /* The reductions of up to four batched launches in ONE launch (round 3): run the batches with launch4[7] = 1 (they then leave their partial
- * tiles in their slabs) and describe each here by its tables, n_tiles = launch4[4], K and the tile class it was planned with. */
+ * tiles in their slabs) and describe each here by its tables, n_tiles = launch4[4], K and the tile class it was planned with.  K + 256 (round 5):
+ * the sums are WRITTEN (dw = ...) instead of added -- every gradient tile has exactly one reduction block; the train step, whose dw is zero at that
+ * point, saves the read half of the read-modify-write. */
 typedef struct sarWgradReduce { const void* convs_dev; const void* tiles_dev; const int* slices_dev; const float* slab; int n_tiles, K, tile_ci, tile_co; } sarWgradReduce;
 int sar_wgrad_reduce_multi_bf16(const sarWgradReduce* plans, int n, sarStream_t stream);
 /* out (bf16) = BatchNorm(+ReLU) backward of dact (bf16, or fp32 when dact_f32) through bn (input x, sums bn->bbins) (+ add) */
