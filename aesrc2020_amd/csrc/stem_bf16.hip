@@ -371,6 +371,10 @@ __device__ __noinline__ float stem_point(const float* __restrict__ x, const floa
 // bbins[bin][0][c] += sum dz, bbins[bin][1][c] += sum dz * xhat over the conv output, where dz is the pooled gradient routed to
 // the argmax position of every window whose maximum is positive (ReLU active).  There z = gamma*xhat + beta equals the pooled
 // value, so xhat = (pooled - beta) / gamma: one pass over the pooled tensors, no full-resolution operand.
+// PH (SAR_X3, round 5): `pooled` is the fp16 copy of the pooled map the forward pass also writes (pooled_h: the first residual block's weight-gradient operand)
+// -- these are BatchNorm-backward SUMS, gradient-class like everything else the mixed backward makes from fp16 copies, and the fp32 map was 33 of
+// this pass's 47 MB.
+template <bool PH = false>
 __global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __restrict__ gp, const u16* __restrict__ pooled, const uint8_t* __restrict__ idx,
                                                                 const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ saved,
@@ -392,7 +396,10 @@ __global__ __launch_bounds__(256) void stem16_bwd_reduce_kernel(const u16* __res
         const size_t o = (size_t)pix * C0 + cv * 8;
         float a[8], gg[8];
         if constexpr (X3) {                                                          // pooled: an fp32 tensor; gp: fp16, scaled (round 5: the mixed backward)
-            f32x8_of(ld16f(pooled, o), ld16f(pooled, o + 4), a);
+            if constexpr (PH) {
+                const uint4 pq = *reinterpret_cast<const uint4*>(pooled + o);
+                a[0] = w_lo(pq.x); a[1] = w_hi(pq.x); a[2] = w_lo(pq.y); a[3] = w_hi(pq.y); a[4] = w_lo(pq.z); a[5] = w_hi(pq.z); a[6] = w_lo(pq.w); a[7] = w_hi(pq.w);
+            } else f32x8_of(ld16f(pooled, o), ld16f(pooled, o + 4), a);
             const uint4 gq = *reinterpret_cast<const uint4*>(gp + o);
             gg[0] = w_lo(gq.x); gg[1] = w_hi(gq.x); gg[2] = w_lo(gq.y); gg[3] = w_hi(gq.y); gg[4] = w_lo(gq.z); gg[5] = w_hi(gq.z); gg[6] = w_lo(gq.w); gg[7] = w_hi(gq.w);
         } else {
@@ -791,9 +798,25 @@ int SAR_STEM(sar_stem16_pool_fwd)(const float* x, const float* w, const float* b
 // Backward pass 1: the BatchNorm-backward sums (sum dz | sum dz*xhat) of the stem's BatchNorm, added into bn->bbins, from the
 // gradient of the pooled map g (bf16), the pooled map and its argmax slots.  Needs bn->saved (written by the forward).  work: the
 // workspace sar_stem16_wgrad will get (its tile counter is reset here).
+static int stem16_bwd_reduce_impl(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                                  const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                                  int pool_pad_top, int pool_pad_left, bool ph, hipStream_t stream);
 int SAR_STEM(sar_stem16_bwd_reduce)(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
                           const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
                           int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+    return stem16_bwd_reduce_impl(g_pooled, pooled, idx, x, w, bias, bn, work, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left, false, stream);
+}
+#if SAR_X3
+// include/sarnet.h: sar_stem16_bwd_reduce_x3 with `pooled` = the FP16 copy of the pooled map (sar_stem16_pool_fwd_x3: pooled_h)
+int sar_stem16_bwd_reduce_x3h(const void* g_pooled, const void* pooled_h, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                              const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                              int pool_pad_top, int pool_pad_left, hipStream_t stream) {
+    return stem16_bwd_reduce_impl(g_pooled, pooled_h, idx, x, w, bias, bn, work, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left, true, stream);
+}
+#endif
+static int stem16_bwd_reduce_impl(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                                  const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                                  int pool_pad_top, int pool_pad_left, bool ph, hipStream_t stream) {
     StemG g;
     if (!g_pooled || !pooled || !idx || !x || !w || !bias || !bn || !bn->bbins || !bn->saved || !work ||
         !stem_geo(g, B, T, D, Ho, Wo, C0, pad_top, pad_left, Hp, Wp, pool_pad_top, pool_pad_left)) return SAR_EINVAL;
@@ -801,8 +824,12 @@ int SAR_STEM(sar_stem16_bwd_reduce)(const void* g_pooled, const void* pooled, co
     if (npix * C0 >= (1L << 31)) return SAR_EINVAL;
     const int npg = 256 / (C0 / 8);
     int nblk = (int)((npix + npg - 1) / npg); nblk = nblk > 1024 ? 1024 : nblk;
-    hipLaunchKernelGGL(stem16_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, stream, static_cast<const u16*>(g_pooled), static_cast<const u16*>(pooled), idx,
-                       x, w, bias, bn->gamma, bn->beta, bn->saved, const_cast<float*>(bn->bbins), reinterpret_cast<int*>(work), g, (unsigned)npix);
+    if (ph && X3)
+        hipLaunchKernelGGL(stem16_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, stream, static_cast<const u16*>(g_pooled), static_cast<const u16*>(pooled), idx,
+                           x, w, bias, bn->gamma, bn->beta, bn->saved, const_cast<float*>(bn->bbins), reinterpret_cast<int*>(work), g, (unsigned)npix);
+    else
+        hipLaunchKernelGGL(stem16_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, stream, static_cast<const u16*>(g_pooled), static_cast<const u16*>(pooled), idx,
+                           x, w, bias, bn->gamma, bn->beta, bn->saved, const_cast<float*>(bn->bbins), reinterpret_cast<int*>(work), g, (unsigned)npix);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
 }

@@ -638,7 +638,11 @@ class ResNetTrunk(Layer):
             g = g16
         ref = sb.ref(B * H * W, "bwd", True, self.ginv)
         work = self.scratch("stem16_work", (_lib.stem16_wgrad_workspace_bytes(cv.cout) // 4,))
-        _call(self._stem_fn("sar_stem16_bwd_reduce"), g, self.pooled16, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)
+        if self.x3 and self.bwd16 and getattr(self, "pooled_h", None) is not None and os.environ.get("SAR_STEM_RED16", "1") == "1":
+            # the BatchNorm-backward sums from the fp16 copy of the pooled map (half the bytes of this HBM-bound pass)
+            _call("sar_stem16_bwd_reduce_x3h", g, self.pooled_h, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)
+        else:
+            _call(self._stem_fn("sar_stem16_bwd_reduce"), g, self.pooled16, self.pool_idx, self.x, cv.kernel.w, cv.bias.w, ref, work, *conv, *pool)
         _call(self._stem_fn("sar_stem16_wgrad"), self.x, cv.kernel.w, cv.bias.w, g, self.pooled16, self.pool_idx, ref, cv.kernel.g, work, *conv, *pool)
 
     def _stem_forward(self, x, B):

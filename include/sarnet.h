@@ -365,6 +365,11 @@ int sar_stem16_pool_fwd_x3(const float* x, const float* w, const float* bias, co
 int sar_stem16_bwd_reduce_x3(const void* g_pooled, const void* pooled, const uint8_t* idx, const float* x, const float* w, const float* bias,
                              const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
                              int pool_pad_top, int pool_pad_left, sarStream_t stream);
+/* sar_stem16_bwd_reduce_x3 reading the FP16 copy of the pooled map (pooled_h of sar_stem16_pool_fwd_x3) instead of the fp32 map: the sums are
+ * gradient-class (round 5: the mixed backward), the fp32 map was 33 of the pass's 47 MB. */
+int sar_stem16_bwd_reduce_x3h(const void* g_pooled, const void* pooled_h, const uint8_t* idx, const float* x, const float* w, const float* bias,
+                              const sarBnRef* bn, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left, int Hp, int Wp,
+                              int pool_pad_top, int pool_pad_left, sarStream_t stream);
 int sar_stem16_wgrad_x3(const float* x, const float* w, const float* bias, const void* g_pooled, const void* pooled, const uint8_t* idx,
                         const sarBnRef* bn, float* dw, float* work, int B, int T, int D, int Ho, int Wo, int C0, int pad_top, int pad_left,
                         int Hp, int Wp, int pool_pad_top, int pool_pad_left, sarStream_t stream);
