@@ -43,7 +43,12 @@ class _Lib:
         self.protos = parse_header()
         self.fn = {}
         for name, (ret, at) in self.protos.items():
-            f = getattr(self.cdll, name)          # AttributeError if the .so lacks a declared symbol
+            try:
+                f = getattr(self.cdll, name)      # AttributeError if the .so lacks a declared symbol
+            except AttributeError:
+                if os.environ.get("SAR_LIB_PATH"):                        # developer A/B run against an OLDER build of the library (tools/ab_bench.sh):
+                    continue                                              # entry points added since are absent there; calling one still fails loudly
+                raise
             f.restype = ret; f.argtypes = at
             self.fn[name] = f
         # The library's own default for the Dense / GRU-projection GEMMs is fp32 MFMA (sar_set_gemm_math(0)); the PACKAGE's default is the
@@ -67,10 +72,36 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+# ---- plan workspace of the 2-byte trunk's conv launcher (csrc/conv_bf16.hip: conv_plan_kernel; include/sarnet.h: sar_conv_plan_workspace_*).
+# The library never allocates: the package lends each build of the launcher ("bf16" | "f16" | "x3") one buffer for the life of the process --
+# captured graphs keep pointers into it, so it is never freed or handed out again -- the first time a conv of that build is launched.
+_PLAN_WS = {}
+_PLAN_SFX = {"sar_conv2d_bf16": "bf16", "sar_conv2d_f16": "f16", "sar_conv2d_f16a": "f16", "sar_conv2d_x3": "x3",
+             "sar_conv2d_pair_bf16": "bf16", "sar_conv2d_pair_f16": "f16", "sar_conv2d_pair_f16a": "f16", "sar_conv2d_pair_x3": "x3"}
+
+
+def conv_plan_workspace(sfx):
+    """Make sure build `sfx` of the conv launcher has its plan workspace (SAR_CONV_PLAN_MB megabytes, default 32; 0: none -- every block of
+    every launch then derives its tables itself, as before round 6).  Not inside a graph capture (it allocates)."""
+    import torch
+    if sfx in _PLAN_WS or torch.cuda.is_current_stream_capturing():
+        return
+    mb = int(os.environ.get("SAR_CONV_PLAN_MB", "32"))
+    if mb <= 0 or "sar_conv_plan_workspace_" + sfx not in lib().fn:          # (absent: an older build under SAR_LIB_PATH)
+        _PLAN_WS[sfx] = None
+        return
+    buf = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+    if lib().fn["sar_conv_plan_workspace_" + sfx](buf.data_ptr(), buf.numel()) != 0:
+        raise RuntimeError("sar_conv_plan_workspace_%s failed" % sfx)
+    _PLAN_WS[sfx] = buf
+
+
 def call(name, *args, stream=None):
     """Invoke a C-ABI entry point on torch's current HIP stream; raises on a non-zero status."""
     import torch
     L = lib()
+    if name in _PLAN_SFX and _PLAN_SFX[name] not in _PLAN_WS:
+        conv_plan_workspace(_PLAN_SFX[name])
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
     conv = [a.data_ptr() if hasattr(a, "data_ptr") else (ctypes.byref(a) if isinstance(a, ctypes.Structure) else a) for a in args]
@@ -194,6 +225,8 @@ class ConvArgs(ctypes.Structure):
 def conv_pair(a, b, sfx="bf16"):
     """sar_conv2d_pair_*: both convolutions in one launch -> True; False (nothing launched) when their instantiations do not pair up."""
     import torch
+    if _PLAN_SFX["sar_conv2d_pair_" + sfx] not in _PLAN_WS:
+        conv_plan_workspace(_PLAN_SFX["sar_conv2d_pair_" + sfx])
     rc = lib().fn["sar_conv2d_pair_" + sfx](ctypes.byref(a), ctypes.byref(b), torch.cuda.current_stream().cuda_stream)
     if rc == -1:
         return False
@@ -326,7 +359,7 @@ class WgradPlan:
             arr = (WgradReduce * len(grp))()
             for a, p in zip(arr, grp):
                 a.convs_dev, a.tiles_dev, a.slices_dev, a.slab = p.convs.data_ptr(), p.tiles.data_ptr(), p.slices.data_ptr(), p.slab.data_ptr()
-                a.n_tiles, a.K, a.tile_ci, a.tile_co = p.n_tiles, p.K + (256 if overwrite else 0), p.launch4[3] >> 4, p.launch4[3] & 15
+                a.n_tiles, a.K, a.tile_ci, a.tile_co = p.n_tiles, p.K + (256 if overwrite else 0), (p.launch4[3] >> 4) & 15, p.launch4[3] & 15
             rc = lib().fn["sar_wgrad_reduce_multi_" + sfx](arr, len(grp), torch.cuda.current_stream().cuda_stream)
             if rc != 0:
                 raise RuntimeError("sar_wgrad_reduce_multi_%s failed with status %d" % (sfx, rc))

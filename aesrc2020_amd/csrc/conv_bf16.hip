@@ -16,27 +16,29 @@
 //  * weight gradient: block = 9 waves (one per tap) x one (32 input, 32 output channel) pair x a slice of the pixels; the
 //    pixel-major LDS images of activation patch and output gradient feed the MFMA through ds_read_b64_tr_b16 (hardware
 //    transpose), so neither operand is transposed in registers; partial tiles are added with fp32 atomics.
-#include "trunk16.h"
-#include <stdlib.h>
-#include <string.h>
-
-namespace {
-
-
+#include <hip/hip_runtime.h>
 // In-kernel phase timing (tools/conv16_timing.py; built only with -DSAR_TIMING into tools/libsarnet_timing16.so, never part
 // of libsarnet_hip.so): thread 0 of every block stamps s_memtime (shader clock) / s_memrealtime (100 MHz, device-wide).
+// 32 slots per block: 0-15 the phases, 16-31 the sub-phases of the prologue (trunk16.h: bn_finish stamps through the same macro).
 #ifdef SAR_TIMING
+namespace {
 __device__ unsigned long long* g_tbuf16 = nullptr;
+}
 #define TSTAMP(slot)                                                                                                   \
     do {                                                                                                               \
         if (g_tbuf16 && threadIdx.x == 0) {                                                                            \
             const long bl = (long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);          \
-            g_tbuf16[bl * 16 + (slot)] = ((slot) == 0 || (slot) == 15) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+            g_tbuf16[bl * 32 + (slot)] = ((slot) == 0 || (slot) == 15) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
         }                                                                                                              \
     } while (0)
 #else
 #define TSTAMP(slot) do {} while (0)
 #endif
+#include "trunk16.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
 
 
 
@@ -69,6 +71,25 @@ __device__ __forceinline__ unsigned src_off(const Geo& g, unsigned Rp, unsigned 
     return ok ? o : NONE;
 }
 
+
+// row table entry of padded row Rp: {element offset of the source row's first pixel | NONE, owner output pixel of that pixel}
+__device__ __forceinline__ uint2 row_entry(const Geo& g, unsigned Rp) {
+    const unsigned b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
+    const int dm = g.d - 1, u = (int)hp - g.pt, us = u >> dm;
+    const bool ok = (u >= 0) & ((u & dm) == 0) & (us < g.Hs) & (b < (unsigned)g.B);
+    uint2 rt;
+    rt.x = ok ? ((b * g.Hs + us) * g.Ws) * g.Cin : NONE;
+    rt.y = b * (unsigned)(g.Ho * g.Wo) + (dm ? 2u * us : (unsigned)us >> (g.s - 1)) * g.Wo;
+    return rt;
+}
+// byte offset, inside a patch that starts at padded row Rp_lo and holds nrows rows, of the first tap of output pixel `pix` (row stride rs)
+__device__ __forceinline__ unsigned patch_pos(const Geo& g, unsigned pix, unsigned Rp_lo, unsigned nrows, int rs) {
+    unsigned Rp, wq;
+    pix_rp(g, pix, Rp, wq);
+    unsigned prow = Rp - Rp_lo;
+    if (prow + g.K > nrows) prow = 0;                              // only with the cap_rows clamp
+    return (prow * g.Wp + wq) * rs;
+}
 
 // Per-thread constants of 8 consecutive channels (a 16-byte piece), read once from the LDS table.
 struct Cst8 { float sc[8], sh[8], mu[8], rs[8], c2[8], c3[8]; };
@@ -117,6 +138,15 @@ __device__ __forceinline__ void xform(const uint4 qh, const uint4 ql, const uint
 
 // ---------------------------------------------------------------------------------------------------- conv (fwd / dgrad)
 struct ConvP {
+    // (the planned instantiations, PL = true: what their requests at kernel entry need sits in ONE 64-byte piece at the front of the argument block
+    // -- a round of kernel-argument loads is a scalar-cache round trip every wave pays before its first request can leave, and the compiler loads
+    // the fields in the order of their use.  Measured on one box, r6: 1.966 ms per step with the copies and the scheduling barrier behind the entry
+    // requests, 1.974 without; the unplanned instantiations read the originals: 1.984 vs 2.006 with the copies)
+    const uint4* pl_thr;        // plan tables, below; null: every block derives them itself (the instantiations with PL = false)
+    const unsigned* pl_tile;
+    const unsigned* pl_lane;
+    const float* ent_bins; const float* ent_bbins;   // fb.bins / fb.bbins (copies: bn_issue's addresses)
+    int pl_ts, cap_rows_e, fill_e, tmv_e, ent_det, rpi;   // (cap_rows, fill, tmv, fb.det: copies)
     Geo g; int Cout;
     const u16* x; const u16* x2; const u16* x3; const h16x8* wpk; const float* bias; const u16* res; u16* y;
     u16* side;                  // nullable: the fill transform T(x) written back to HBM (same shape as x) for the weight gradient
@@ -136,6 +166,15 @@ struct ConvP {
     int patch_bytes;            // LDS bytes of the patch region (all planes, incl. a 1 KiB scratch slot each); the weight ring follows
     int rd;                     // depth of the weight ring: 3, or 4 where the LDS has room (128+-channel stride-1 layers)
     int cw; unsigned mg_cw;     // 16-byte pieces of a patch row (padded width x Cin / 8) and the magic number of the division by it
+    // Plan tables (round 6; null: every block derives them itself, as rounds 2-5 did).  Everything below is a function of the launch's SHAPE --
+    // geometry, tile, thread count -- and was recomputed by every wave of every block of every launch: ~2 000 cycles of dependent integer
+    // arithmetic (three divisions per thread for the fill's piece, four for the tile's first and last row, the row table, two more per lane for
+    // the A address) in front of the first load of the fill.  conv_plan_kernel writes them ONCE per shape into a workspace the caller lends
+    // (sar_conv_plan_workspace_*); a block then asks for them with three loads at kernel entry, in front of the statistic bins.
+    //   pl_thr  [threads] {coloff, own_col (without - m0), lo_col, rsub | c8 << 16 | ok_col << 31}: the fill's per-thread constants
+    //   pl_tile [pixel tiles][pl_ts] {row table rows (uint2) x cap_rows, {nrows, Rp_lo}}
+    //   pl_lane [pixel tiles][TM] byte offset of the pixel's patch position (a_addr without the lane half / k-group terms)
+    //   pl_ts: words per tile of pl_tile; rpi: patch rows per trip of the fill (NTHR / cw)
 };
 constexpr int ROWTAB_BYTES = 1024;   // per patch row {source row base offset | NONE, owner pixel of the row's first column}
 
@@ -252,18 +291,37 @@ __device__ __forceinline__ uint4 xform16(const uint4 q, const uint4 q2, const ui
     return pack8(o);
 }
 
+// The fill's per-thread constants: from the plan table (one 16-byte load the caller issued at kernel entry) or derived here.
+struct FillThr { unsigned rsub, rpi, coloff, own_col, lo_col, c8; bool ok_col; };
+template <int NTHR>
+__device__ __forceinline__ FillThr fill_thread(const Geo& g, int lg_pc, int rs, int tid, unsigned cw, unsigned mg_cw, unsigned m0,
+                                               bool planned, const uint4 pthr, unsigned prpi) {
+    FillThr f;
+    const unsigned pc = 1u << lg_pc;
+    if (planned) {                                                 // (kernel-uniform)
+        f.coloff = pthr.x; f.own_col = pthr.y - m0; f.lo_col = pthr.z;
+        f.rsub = pthr.w & 0xffffu; f.c8 = (pthr.w >> 16) & 0x7fffu; f.ok_col = (pthr.w >> 31) != 0; f.rpi = prpi;   // (conv_plan_kernel packs them)
+        return f;
+    }
+    f.rsub = udiv((unsigned)tid, mg_cw, cw); f.rpi = udiv((unsigned)NTHR, mg_cw, cw);      // row of the trip, rows per trip
+    const unsigned col = tid - f.rsub * cw, wp = col >> lg_pc;     // column piece, padded column
+    f.c8 = col & (pc - 1);
+    const int dm = g.d - 1, ssh = g.s - 1;
+    const int v = (int)wp - g.pl, vs = v >> dm;
+    f.ok_col = (f.rsub < f.rpi) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
+    f.coloff = (unsigned)vs * g.Cin + f.c8 * 8; f.own_col = (dm ? 2u * vs : (unsigned)vs >> ssh) - m0; f.lo_col = wp * rs + f.c8 * 16;
+    return f;
+}
+
 template <int MODE, int TM, int U, int NTHR, bool A32, typename MID>
 __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict__ x, const u16* __restrict__ x2, const u16* __restrict__ x3, u16* __restrict__ side,
                                            int lg_pc, int rs, unsigned char* patch, const float* cst, const uint2* rowtab,
-                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, unsigned tmv, MID&& mid) {
-    const unsigned pc = 1u << lg_pc;
+                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, unsigned cw, unsigned mg_cw, unsigned tmv,
+                                           bool planned, const uint4 pthr, unsigned prpi, MID&& mid) {
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch (the launcher allocates it)
-    const unsigned rsub = udiv((unsigned)tid, mg_cw, cw), col = tid - rsub * cw, rpi = udiv((unsigned)NTHR, mg_cw, cw);   // row of the trip, column piece, rows per trip
-    const unsigned wp = col >> lg_pc, c8 = col & (pc - 1);
-    const int dm = g.d - 1, ssh = g.s - 1;
-    const int v = (int)wp - g.pl, vs = v >> dm;
-    const bool ok_col = (rsub < rpi) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
-    const unsigned coloff = (unsigned)vs * g.Cin + c8 * 8, own_col = (dm ? 2u * vs : (unsigned)vs >> ssh) - m0, lo_col = wp * rs + c8 * 16;
+    const FillThr ft = fill_thread<NTHR>(g, lg_pc, rs, tid, cw, mg_cw, m0, planned, pthr, prpi);
+    const unsigned rsub = ft.rsub, rpi = ft.rpi, coloff = ft.coloff, own_col = ft.own_col, lo_col = ft.lo_col, c8 = ft.c8;
+    const bool ok_col = ft.ok_col;
     const unsigned rowbytes = g.Wp * rs;
     const bool do_side = side != nullptr && first_ntile;           // block-uniform
     Cst8 k;
@@ -292,32 +350,32 @@ __device__ __forceinline__ void fill_patch16(const Geo& g, const u16* __restrict
             if (do_side && off[j] != NONE && own[j] < tmv) nt_store16(side + off[j], r);   // (tmv: the pixels this block OWNS, <= TM)
         }
     };
+    TSTAMP(17);
     issue(rsub);                                                   // trip 0, peeled: `mid` between its loads and their use
+    TSTAMP(18);
     mid();
     if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
+    TSTAMP(22);
     finish();
+    TSTAMP(23);
     for (unsigned base = U * rpi; base < nrows; base += U * rpi) { issue(base + rsub); finish(); }   // U rows in flight per thread
 }
 template <int MODE, int TM, int U, int NTHR, bool A32, typename MID>
 __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch, const float* cst, const uint2* rowtab,
-                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, MID&& mid) {
+                                           unsigned nrows, unsigned m0, int tid, bool first_ntile, bool planned, const uint4 pthr, MID&& mid) {
     if constexpr (!X3) {
-        fill_patch16<MODE, TM, U, NTHR, A32>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, (unsigned)p.tmv, mid);
+        fill_patch16<MODE, TM, U, NTHR, A32>(p.g, p.x, p.x2, p.x3, p.side, p.lg_pc, p.rs, patch, cst, rowtab, nrows, m0, tid, first_ntile, (unsigned)p.cw, p.mg_cw, (unsigned)p.tmv,
+                                             planned, pthr, (unsigned)p.rpi, mid);
         return;
     }
     const Geo& g = p.g;
     const u16* __restrict__ x = p.x; const u16* __restrict__ x2 = p.x2; const u16* __restrict__ x3 = p.x3;
     u16* __restrict__ side = p.side; u16* __restrict__ side2 = p.side2;
     const int lg_pc = p.lg_pc, rs = p.rs;
-    const unsigned cw = (unsigned)p.cw, mg_cw = p.mg_cw;
-    const unsigned pc = 1u << lg_pc;
     const unsigned dummy = nrows * g.Wp * rs + (tid & 63) * 16;   // 1 KiB behind the patch plane (the launcher allocates it)
-    const unsigned rsub = udiv((unsigned)tid, mg_cw, cw), col = tid - rsub * cw, rpi = udiv((unsigned)NTHR, mg_cw, cw);   // row of the trip, column piece, rows per trip
-    const unsigned wp = col >> lg_pc, c8 = col & (pc - 1);
-    const int dm = g.d - 1, ssh = g.s - 1;
-    const int v = (int)wp - g.pl, vs = v >> dm;
-    const bool ok_col = (rsub < rpi) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
-    const unsigned coloff = (unsigned)vs * g.Cin + c8 * 8, own_col = (dm ? 2u * vs : (unsigned)vs >> ssh) - m0, lo_col = wp * rs + c8 * 16;
+    const FillThr ft = fill_thread<NTHR>(g, lg_pc, rs, tid, (unsigned)p.cw, p.mg_cw, m0, planned, pthr, (unsigned)p.rpi);
+    const unsigned rsub = ft.rsub, rpi = ft.rpi, coloff = ft.coloff, own_col = ft.own_col, lo_col = ft.lo_col, c8 = ft.c8;
+    const bool ok_col = ft.ok_col;
     const unsigned rowbytes = g.Wp * rs;
     const bool do_side = (side != nullptr || (X3 && side2 != nullptr)) && first_ntile;           // block-uniform
     Cst8 k;
@@ -372,10 +430,14 @@ __device__ __forceinline__ void fill_patch(const ConvP& p, unsigned char* patch,
             }
         }
     };
+    TSTAMP(17);
     issue(rsub);                                                   // trip 0, peeled: `mid` between its loads and their use
+    TSTAMP(18);
     mid();
     if constexpr (MODE != 0) load_cst8(cst, g.Cin, c8 * 8, MODE >= 2 ? 2 : 1, k);
+    TSTAMP(22);
     finish();
+    TSTAMP(23);
     for (unsigned base = U * rpi; base < nrows; base += U * rpi) { issue(base + rsub); finish(); }   // U rows in flight per thread
 }
 
@@ -403,7 +465,7 @@ constexpr int BR_PD = X3 ? 2 : 4;    // BR form: k-steps of weight fragments in 
 // feeds one MFMA, a B fragment two; round 2's k-phase was bound by LDS reads 2 : 1 -- 2 KB per MFMA -- and by a barrier per 8 fragments).
 // (the body is a device function: conv_bf16_kernel runs it for one convolution, conv_bf16_pair_kernel for TWO independent ones in one launch.
 // lin / ntot / nty: this block's linear index among the ntot blocks of ITS convolution, of which nty are channel tiles per pixel tile)
-template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false, bool A32 = false>
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false, bool A32 = false, bool PL = false>
 __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, const unsigned ntot, const unsigned nty) {
     static_assert(BR || KG == 1, "k-groups exist in the BR form only");
     static_assert(!(X3 && A32), "A32 (fp32 forward tensors beside 2-byte gradients) is a form of the single-plane builds");
@@ -436,11 +498,26 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // tensors).  Here XCD c takes the c-th contiguous eighth of the sequence (channel tile fastest, then pixel tile).
     const unsigned chunk8 = ntot >> 3, tord = lin < (chunk8 << 3) ? (lin & 7u) * chunk8 + (lin >> 3) : lin;
     const unsigned bx = tord >> __builtin_ctz(nty), by = tord & (nty - 1);   // Cout / TN: a power of two
-    const unsigned TMV = (X3 || BR) ? (unsigned)p.tmv : (unsigned)TM;   // pixels this block owns
+    const unsigned TMV = (X3 || BR) ? (unsigned)(PL ? p.tmv_e : p.tmv) : (unsigned)TM;   // pixels this block owns
     const unsigned m0 = bx * TMV;
     const int n0 = by * TN;
     const unsigned M = (unsigned)g.M;
     TSTAMP(0); TSTAMP(1);
+    // ---- plan tables (ConvP::pl_thr): requested FIRST -- loads return in order, and the row table is needed before the statistic bins are
+    constexpr bool planned = PL;                                   // (a template parameter: the planned kernels carry none of the derivations, nor the arguments they read)
+    uint4 pthr = make_uint4(0, 0, 0, 0);
+    uint2 prow = make_uint2(NONE, 0);
+    unsigned pa0 = 0, pa1 = 0;
+    if (planned) {
+        // (the tile's row count travels as row cap_rows of its table, through LDS like the rows: as a scalar load of a header its miss sat in
+        // front of every other request of the kernel -- scalar loads return out of order, the first use waits for all of them)
+        const uint2* tp = reinterpret_cast<const uint2*>(p.pl_tile + (size_t)bx * p.pl_ts);
+        pthr = p.pl_thr[tid];
+        if (tid <= p.cap_rows_e) prow = tp[tid];
+        const unsigned* lp = p.pl_lane + (size_t)bx * (32 * WMX) + wm * 32 + (lane & 31);
+        pa0 = lp[0];
+        if constexpr (BR && WMX == 2) pa1 = lp[32];
+    }
     // ---- BatchNorm constants of the fill by the WHOLE block (trunk16.h).  The bins were written by the producer's atomics -- behind the fabric,
     // never in this XCD's L2: ~2 800 cycles -- and the fill cannot transform a piece without them, so they are the FIRST thing this kernel
     // requests (round 4: in-kernel stamps of the split-precision stage-2 block showed them requested 3 500 cycles after entry, behind the
@@ -449,7 +526,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     // hold them in; on the 128- / 168-register forms the pieces held across it spill).
     BnRaw braw;
     constexpr int CIN = NKC < 8 ? 16 * NKC : 128 * NH;             // source channels of this instantiation (the launcher's table)
-    if (p.fill) bn_issue<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, braw);
+    if constexpr (PL) {
+        if (p.fill_e) bn_issue<NTHR, CIN>(p.ent_bins, p.ent_bbins, p.ent_det, p.fill_e >= 2 ? 2 : 1, braw);
+        __builtin_amdgcn_sched_barrier(0);                         // (nothing of the rest of the kernel in front of these requests)
+    } else if (p.fill) bn_issue<NTHR, CIN>(p.fb, p.fill >= 2 ? 2 : 1, braw);
 
     // ---- epilogue operands that do not depend on the accumulators (bias, residual, BatchNorm constants and input of the
     // backward sums): requested first, consumed ~10 us later
@@ -525,20 +605,18 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     if constexpr (EARLY && !BR) load_epi();
     TSTAMP(12);
 
-    unsigned Rp_lo, Rp_hi, wtmp;
-    pix_rp(g, m0, Rp_lo, wtmp);
-    pix_rp(g, min(m0 + TMV - 1, M - 1), Rp_hi, wtmp);
-    Rp_hi += g.K - 1;
-    unsigned nrows = Rp_hi - Rp_lo + 1;
-    if (nrows > (unsigned)p.cap_rows) nrows = p.cap_rows;          // never taken: the launcher sizes cap_rows as an upper bound
-    if ((unsigned)tid < nrows) {                                   // row table
-        const unsigned Rp = Rp_lo + tid, b = udiv(Rp, g.mg_hp, (unsigned)g.Hp), hp = Rp - b * g.Hp;
-        const int dm = g.d - 1, u = (int)hp - g.pt, us = u >> dm;
-        const bool ok = (u >= 0) & ((u & dm) == 0) & (us < g.Hs) & (b < (unsigned)g.B);
-        uint2 rt;
-        rt.x = ok ? ((b * g.Hs + us) * g.Ws) * g.Cin : NONE;
-        rt.y = b * (unsigned)(g.Ho * g.Wo) + (dm ? 2u * us : (unsigned)us >> (g.s - 1)) * g.Wo;
-        rowtab[tid] = rt;
+    unsigned Rp_lo, nrows;
+    if (planned) {
+        Rp_lo = 0; nrows = 0;                                      // (nrows: read back from the table behind the barrier; Rp_lo: only a_addr's unplanned arm)
+        if (tid <= p.cap_rows) rowtab[tid] = prow;                 // row table: as conv_plan_kernel wrote it (rows past the tile's last: NONE); [cap_rows].x = nrows
+    } else {
+        unsigned Rp_hi, wtmp;
+        pix_rp(g, m0, Rp_lo, wtmp);
+        pix_rp(g, min(m0 + TMV - 1, M - 1), Rp_hi, wtmp);
+        Rp_hi += g.K - 1;
+        nrows = Rp_hi - Rp_lo + 1;
+        if (nrows > (unsigned)p.cap_rows) nrows = p.cap_rows;      // never taken: the launcher sizes cap_rows as an upper bound
+        if ((unsigned)tid < nrows) rowtab[tid] = row_entry(g, Rp_lo + tid);   // row table
     }
     TSTAMP(13);
     constexpr bool MIDFILL = BR;
@@ -548,6 +626,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     TSTAMP(14);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // raw barrier (no vmcnt drain): row table (and constants) complete
     wg_barrier();
+    if (planned) nrows = rowtab[p.cap_rows].x;
+    TSTAMP(16);
 #ifdef SAR_TIMING_PROBE
     TSTAMP(8);
 #endif
@@ -571,23 +651,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     constexpr int FU = (NG == 8 || X3) ? 2 : 4;                    // (SAR_X3: two 32-byte pieces are what four 16-byte ones were; 2.254 vs 2.259 ms)
     // ---- fill: the padded patch, all input channels, transformed once
     // (A32: a piece of the gradient fills is three / four 16-byte loads -- two pieces in flight)
-    if (p.fill == 0) fill_patch<0, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
+    if (p.fill == 0) fill_patch<0, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, planned, pthr, mid);
+    else if (p.fill == 1) fill_patch<1, TM, FU, NTHR, false>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, planned, pthr, mid);
 #ifndef SAR_A32_FU2
 #define SAR_A32_FU2 2
 #endif
-    else if (p.fill == 2) fill_patch<2, TM, (X3 && FU > 2 ? 2 : (A32 && FU > SAR_A32_FU2) ? SAR_A32_FU2 : FU), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);
-    else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
+    else if (p.fill == 2) fill_patch<2, TM, (X3 && FU > 2 ? 2 : (A32 && FU > SAR_A32_FU2) ? SAR_A32_FU2 : FU), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, planned, pthr, mid);
+    else fill_patch<3, TM, (X3 ? 1 : FU < 2 ? FU : 2), NTHR, A32>(p, patch, cst, rowtab, nrows, m0, tid, by == 0, planned, pthr, mid);   // three tensors: two pieces in flight (SAR_X3: six loads a piece)
     if constexpr (EARLY && BR) load_epi();
     // ---- per-lane A address
-    auto a_addr = [&](unsigned pix0) __attribute__((always_inline)) {
-        unsigned Rp, wq;
-        pix_rp(g, min(pix0 + (lane & 31), M - 1), Rp, wq);
-        unsigned prow = Rp - Rp_lo;
-        if (prow + g.K > nrows) prow = 0;                          // only with the clamp above
-        return (prow * g.Wp + wq) * p.rs + (lane >> 5) * 16 + kg * (KPF * 32);   // + the group's channel half of every tap
+    auto a_addr = [&](unsigned pix0, unsigned planned_pos) __attribute__((always_inline)) {
+        const unsigned pos = planned ? planned_pos : patch_pos(g, min(pix0 + (lane & 31), M - 1), Rp_lo, nrows, p.rs);
+        return pos + (lane >> 5) * 16 + kg * (KPF * 32);           // + the group's channel half of every tap
     };
-    const unsigned a_lane = a_addr(m0 + wm * 32);
+    const unsigned a_lane = a_addr(m0 + wm * 32, pa0);
     TSTAMP(3);
 
     // ---- k-phase, straight-line.
@@ -600,7 +677,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
         // acc: pixels 0-31 of the tile, acc2: pixels 32-63 (WMX = 2); both on this wave's 32 channels and its share of every tap's channels.
         // WMX = 1 (32-pixel tiles): acc2 takes the small terms of SAR_X3 (and nothing otherwise).
         unsigned a_hi = 0;
-        if constexpr (WMX == 2) a_hi = a_addr(m0 + 32);
+        if constexpr (WMX == 2) a_hi = a_addr(m0 + 32, pa1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's patch stores
         wg_barrier();
         TSTAMP(4);
@@ -817,14 +894,51 @@ __device__ __forceinline__ void conv_body(const ConvP& p, const unsigned lin, co
     TSTAMP(7); TSTAMP(15);
 }
 
+// ---- plan tables of one launch shape (ConvP::pl_thr / pl_tile / pl_lane), written once per shape by the launcher
+struct PlanArgs {
+    Geo g; int lg_pc, rs, cw; unsigned mg_cw; int nthr, tmv, TM, cap_rows, ntiles, pl_ts;
+    uint4* thr; unsigned* tile; unsigned* lane;
+};
+__global__ __launch_bounds__(256) void conv_plan_kernel(const PlanArgs a) {
+    const Geo& g = a.g;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == a.ntiles) {                              // the fill's per-thread constants (fill_thread with m0 = 0)
+        for (int t = tid; t < a.nthr; t += 256) {
+            const unsigned cw = (unsigned)a.cw, pc = 1u << a.lg_pc;
+            const unsigned rsub = udiv((unsigned)t, a.mg_cw, cw), rpi = udiv((unsigned)a.nthr, a.mg_cw, cw);
+            const unsigned col = t - rsub * cw, wp = col >> a.lg_pc, c8 = col & (pc - 1);
+            const int dm = g.d - 1, ssh = g.s - 1;
+            const int v = (int)wp - g.pl, vs = v >> dm;
+            const bool ok_col = (rsub < rpi) & (v >= 0) & ((v & dm) == 0) & (vs < g.Ws);
+            a.thr[t] = make_uint4((unsigned)vs * g.Cin + c8 * 8, dm ? 2u * vs : (unsigned)vs >> ssh, wp * a.rs + c8 * 16,
+                                  rsub | (c8 << 16) | (ok_col ? 0x80000000u : 0u));
+        }
+        return;
+    }
+    const unsigned bx = blockIdx.x, M = (unsigned)g.M, m0 = bx * (unsigned)a.tmv;
+    unsigned Rp_lo, Rp_hi, wtmp;
+    pix_rp(g, min(m0, M - 1), Rp_lo, wtmp);
+    pix_rp(g, min(m0 + (unsigned)a.tmv - 1, M - 1), Rp_hi, wtmp);
+    Rp_hi += g.K - 1;
+    unsigned nrows = Rp_hi - Rp_lo + 1;
+    if (nrows > (unsigned)a.cap_rows) nrows = a.cap_rows;
+    unsigned* tp = a.tile + (size_t)bx * a.pl_ts;                   // rows 0 .. cap_rows-1, then {nrows, Rp_lo}
+    if (tid == 0) { tp[2 * a.cap_rows] = nrows; tp[2 * a.cap_rows + 1] = Rp_lo; }
+    for (int t = tid; t < a.cap_rows; t += 256) {
+        const uint2 rt = (unsigned)t < nrows ? row_entry(g, Rp_lo + t) : make_uint2(NONE, 0u);
+        tp[2 * t] = rt.x; tp[2 * t + 1] = rt.y;
+    }
+    for (int i = tid; i < a.TM; i += 256) a.lane[(size_t)bx * a.TM + i] = patch_pos(g, min(m0 + i, M - 1), Rp_lo, nrows, a.rs);
+}
+
 // waves per SIMD the register budget is set for.  BR: 1 (KG = 4: 512 threads, one block per CU) or 2; ring forms: 3 (two waves), 4 (eight
 // waves: 128 registers, two blocks per CU), 2 otherwise.  SAR_X3 doubles the fragments a wave holds and its LDS admits one eight-wave block
 // (or two four-wave blocks) per CU anyway: 2 for every ring form.
 #define CONV_OCC (BR ? (KG == 4 ? 1 : 2) : X3 ? (WMX * WN == 8 && NKC == 2 ? 4 : 2) : (WMX * WN == 2 ? 3 : WMX * WN == 8 ? 4 : 2))
 
-template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false, bool A32 = false>
+template <int WN, int NKC, int VT, int KG = 1, int WMX = 4 / WN, bool BR = false, bool A32 = false, bool PL = false>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv_bf16_kernel(const ConvP p) {
-    conv_body<WN, NKC, VT, KG, WMX, BR, A32>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, gridDim.y);
+    conv_body<WN, NKC, VT, KG, WMX, BR, A32, PL>(p, blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y, gridDim.y);
 }
 
 // TWO independent convolutions of equal block size in ONE launch (round 3): the 1x1 shortcut of a residual block that changes the shape
@@ -832,12 +946,12 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv
 // A launch inside the step costs ~4.5 us before it does anything, the shortcut launches are 7-20 us of mostly that, and the
 // 3x3 launches of the stages they sit in front of leave CUs idle.  Blocks [0, na) run the first convolution, the rest the second (1x1:
 // same WN / NKC / KG / WMX / BR, VT = channel parts of ONE tap); LDS and registers are the larger of the two.
-template <int WN, int NKC, int VT, int KG, int WMX, bool BR, bool A32 = false>
+template <int WN, int NKC, int VT, int KG, int WMX, bool BR, bool A32 = false, bool PL = false>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC)
 void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, const unsigned ntya, const unsigned nb, const unsigned ntyb) {
     const unsigned na8 = (na + 7u) & ~7u;                             // the second convolution starts on XCD 0 as well (its XCD-aware tile order)
-    if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR, A32>(pa, blockIdx.x, na, ntya);
-    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMX, BR, A32>(pb, blockIdx.x - na8, nb, ntyb);
+    if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR, A32, PL>(pa, blockIdx.x, na, ntya);
+    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMX, BR, A32, PL>(pb, blockIdx.x - na8, nb, ntyb);
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
@@ -853,9 +967,10 @@ void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, co
 struct WgConv {                 // device table row, written by sar_wgrad_plan_bf16 (128 bytes)
     Geo g; int Cout;
     const u16* x; const u16* dy; float* dw; float* dbias;
-    int nchunks;                // 64-pixel chunks
+    int nchunks;                // chunks of CH pixels (64; 128 for the 3x3 launches since round 6)
     int cap_pos;                // patch positions of one chunk (multiple of 16)
-    int la;                     // 3x3: chunks requested ahead of the one being multiplied (1..3: what the position ring holds)
+    short la;                   // 3x3: chunks requested ahead of the one being multiplied (1..3: what the position ring holds)
+    short ch;                   // 3x3: pixels per chunk of this convolution, 64 or 128 (nchunks, cap_pos, la and the items' runs count in it)
     float ginv;                 // the flush multiplies by it: 1 / (gradient scale dy carries; 1 in the bf16 build)
 };
 static_assert(sizeof(WgConv) <= 128, "WgConv must fit its 128-byte table row");
@@ -994,14 +1109,21 @@ struct Wg3Args { const unsigned char* convs; const WgItem* items; const uint4* z
 // Per wave and 16-pixel step: three A fragments (one activation plane at three consecutive positions) and ONE gradient fragment.
 // (Negative: extra LOADER waves that issue all of the block's LDS-DMA while the compute waves only read LDS and multiply -- 64-wide launch
 // 125 -> 141 us: what a chunk waits for is the ARRIVAL of ~17 KB of 64 / 128-byte pieces per CU, not instruction issue.)
-template <int TCI, int TCO, bool W12 = false>
-__global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3Args a) {
+// CH (round 6): pixels per chunk, 64 or 128.  A chunk is what the block synchronises on -- one barrier, one round of DMA issue, one table of
+// pixel positions -- and at 64 pixels a block spent 3 870 cycles per chunk for 1 150 of MFMA on its fullest SIMD (tools/conv16_timing.py wgrad:
+// the wait for the slowest of twelve waves 1 490, the DMA issue 720).  128 pixels: half the barriers and tables per pixel, the MFMAs of sixteen
+// 16-pixel steps back to back; the ring holds LA + 1 chunks of positions as before, so LA is one less where 64-pixel chunks ran three ahead.
+// The chunk size is a property of the CONVOLUTION (WgConv::ch, the planner's choice: 128 where the convolution's positions fit the ring with a chunk
+// in flight -- the 13 x 3 images of stage 3 do not: a 128-pixel chunk spans three images and their padding rows): a launch whose plan mixes both
+// runs the kernel that holds both bodies (MIX) behind a block-uniform branch.
+template <int TCI, int TCO, bool W12, int CH>
+__device__ __forceinline__ void wgrad3_body(const Wg3Args& a, const WgItem& it, const WgConv* cvp) {
     static_assert(!W12 || (TCI == 2 && TCO == 2), "twelve waves: three tap rows x the four sub-tiles of a 64 x 64 tile");
+    static_assert(CH == 64 || CH == 128, "64- or 128-pixel chunks");
     constexpr int NWV = W12 ? 12 : 9, NTHR = NWV * 64;
+    constexpr int DYI = CH / 16;                                                    // DMA instructions per gradient plane and chunk (16 pixels each)
     constexpr int NA = W12 ? 3 : TCI, NBF = W12 ? 1 : TCO, NJ = W12 ? 3 : TCI * TCO;   // A / B fragments per step, MFMAs per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const WgItem it = a.items[blockIdx.x];
-    const WgConv* cvp = reinterpret_cast<const WgConv*>(a.convs + (size_t)it.conv * 128);
     const Geo g = cvp->g;
     const int Cout = cvp->Cout, LA = cvp->la;
     const u16* __restrict__ xp = cvp->x; const u16* __restrict__ dyp = cvp->dy;
@@ -1010,26 +1132,26 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ci0 = it.ci0, co0 = it.co0;
     const unsigned M = (unsigned)g.M, NP = a.np, mask = a.np - 1;
-    const int c_first = it.c_first, nmine = it.c_count, nbuf = a.nbuf;
-    unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [2][64]: absolute patch position of every pixel
-    unsigned* soff = qring + 128;                                                  // [tab_pos]: source element offset of every position of this item (NONE: zero)
-    unsigned char* dyr = smem + 512 + (size_t)a.tab_pos * 4;                       // [nbuf][TCO][64 px][64 B]
-    unsigned char* pr = dyr + (size_t)nbuf * TCO * 4096;                           // [TCI][NP][64 B]
+    const int c_first = it.c_first, nmine = it.c_count, nbuf = LA + 1;           // gradient-row slots: the chunk being multiplied + LA in flight
+    unsigned* qring = reinterpret_cast<unsigned*>(smem);                          // [2][CH]: absolute patch position of every pixel
+    unsigned* soff = qring + 2 * CH;                                               // [tab_pos]: source element offset of every position of this item (NONE: zero)
+    unsigned char* dyr = smem + 8 * CH + (size_t)a.tab_pos * 4;                    // [nbuf][TCO][CH px][64 B]
+    unsigned char* pr = dyr + (size_t)nbuf * TCO * (CH * 64);                      // [TCI][NP][64 B]
     const unsigned dyr0 = lds_addr(dyr), pr0a = lds_addr(pr);
-    constexpr int MAXNI = 4;
+    constexpr int MAXNI = CH == 64 ? 4 : 6;
 
     auto tables = [&](int lc) __attribute__((always_inline)) {
-        if (tid < 64) {
-            const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+        if (tid < CH) {
+            const unsigned mc0 = (unsigned)(c_first + lc) * CH;
             unsigned Rp, wq;
-            pix_rp(g, min(mc0 + lane, M - 1), Rp, wq);                             // past the batch: the last pixel's position; its dY row is zero
-            qring[(lc & 1) * 64 + lane] = Rp * g.Wp + wq;
+            pix_rp(g, min(mc0 + tid, M - 1), Rp, wq);                              // past the batch: the last pixel's position; its dY row is zero
+            qring[(lc & 1) * CH + tid] = Rp * g.Wp + wq;
         }
     };
     unsigned Gn;                                                                   // first 16-position group not requested yet
     {
         unsigned Rp, wq;
-        pix_rp(g, (unsigned)c_first * 64, Rp, wq);
+        pix_rp(g, (unsigned)c_first * CH, Rp, wq);
         Gn = (Rp * g.Wp + wq) >> 4;
     }
     // Source offsets of all positions this item will ever request, once: position -> (image, row, column) costs two divisions,
@@ -1038,7 +1160,7 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
     const unsigned P0 = Gn * 16;
     {
         unsigned Rpl, wql;
-        pix_rp(g, min((unsigned)(c_first + nmine) * 64, M) - 1, Rpl, wql);
+        pix_rp(g, min((unsigned)(c_first + nmine) * CH, M) - 1, Rpl, wql);
         const unsigned npos = min((((Rpl + g.K) * g.Wp + 15) & ~15u) - P0, (unsigned)a.tab_pos);
         for (unsigned i = tid; i < npos; i += NTHR) {
             const unsigned p = P0 + i;
@@ -1052,24 +1174,24 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
     // per-lane constants of a DMA piece: 4 lanes per position / pixel, 16 bytes = 8 channels each
     const unsigned l4 = lane >> 2, pc8 = (lane & 3) * 8;
     auto issue = [&](int lc) __attribute__((always_inline)) -> int {
-        const unsigned mc0 = (unsigned)(c_first + lc) * 64;
+        const unsigned mc0 = (unsigned)(c_first + lc) * CH;
         unsigned Rpl, wql;
-        pix_rp(g, min(mc0 + 63, M - 1), Rpl, wql);
+        pix_rp(g, min(mc0 + CH - 1, M - 1), Rpl, wql);
         const unsigned Gh = ((Rpl + g.K) * g.Wp + 15) >> 4;                        // every position in front of (last row + K) * Wp
         const int npg = Gh > Gn ? (int)(Gh - Gn) : 0;
-        const int total = 4 * TCO + npg * TCI;
+        const int total = DYI * TCO + npg * TCI;
         const int NI = (total + NWV - 1) / NWV;
-        const unsigned dyslot = dyr0 + (unsigned)(lc % nbuf) * (TCO * 4096);
+        const unsigned dyslot = dyr0 + (unsigned)(lc % nbuf) * (TCO * CH * 64);
         // (Computing the addresses of a batch first and issuing its DMA instructions back to back -- dma16's memory clobber keeps the
         // next instruction's table read behind it -- was measured: 125 -> 134 us for the 64-wide launch.  Issue order is not the limit.)
         auto addr = [&](int j, const void*& src, unsigned& dst) __attribute__((always_inline)) {
-            if (j < 4 * TCO) {                                                     // gradient rows: plane j/4, 16 pixels j%4
-                const int pl = j >> 2, blk = j & 3;
+            if (j < DYI * TCO) {                                                   // gradient rows: plane j / DYI, 16 pixels j % DYI
+                const int pl = j / DYI, blk = j % DYI;
                 const unsigned m = mc0 + blk * 16 + l4;
                 src = m < M ? (const void*)(dyp + (size_t)m * Cout + co0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
-                dst = dyslot + (unsigned)(pl * 4096 + blk * 1024);
+                dst = dyslot + (unsigned)(pl * (CH * 64) + blk * 1024);
             } else {                                                               // 16 new patch positions of one activation plane
-                const int jj = j - 4 * TCO, pl = TCI == 1 ? 0 : (jj & 1);
+                const int jj = j - DYI * TCO, pl = TCI == 1 ? 0 : (jj & 1);
                 const unsigned gi = Gn + (unsigned)(TCI == 1 ? jj : jj >> 1);
                 const unsigned so = soff[gi * 16 + l4 - P0];
                 src = so != NONE ? (const void*)(xp + so + ci0 + pl * 32 + pc8) : (const void*)(a.zero + lane);
@@ -1128,8 +1250,8 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
         TACC(t_issue, if (lc + LA < nmine) qn = issue(lc + LA));   // dY slot of chunk lc+LA-nbuf <= lc-1; ring positions behind chunk lc
         if (LA == 3) q3 = qn; else if (LA == 2) q2 = qn; else q1 = qn;
         if (lc + 1 < nmine) tables(lc + 1);
-        const unsigned* qtab = qring + (lc & 1) * 64;
-        const unsigned char* dyt = dyr + (size_t)(lc % nbuf) * (TCO * 4096);
+        const unsigned* qtab = qring + (lc & 1) * CH;
+        const unsigned char* dyt = dyr + (size_t)(lc % nbuf) * (TCO * CH * 64);
         h16x8 A[2][NA], Bm[2][NBF];
         auto rd = [&](int ks, h16x8 (&Ao)[NA], h16x8 (&Bo)[NBF]) __attribute__((always_inline)) {
             const unsigned p0 = 16 * ks + prb, p1 = p0 + 4;
@@ -1144,15 +1266,15 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
             }
 #pragma unroll
             for (int j = 0; j < NBF; ++j) {
-                const unsigned char* pl = dyt + (W12 ? wj : j) * 4096;
+                const unsigned char* pl = dyt + (W12 ? wj : j) * (CH * 64);
                 const s16x4 lo = lds_tr(pl, p0 * 64 + colb), hi = lds_tr(pl, p1 * 64 + colb);
                 Bo[j] = __builtin_bit_cast(h16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
         };
         rd(0, A[0], Bm[0]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) rd(ks + 1, A[(ks + 1) & 1], Bm[(ks + 1) & 1]);
+        for (int ks = 0; ks < CH / 16; ++ks) {
+            if (ks + 1 < CH / 16) rd(ks + 1, A[(ks + 1) & 1], Bm[(ks + 1) & 1]);
 #pragma unroll
             for (int k = 0; k < NJ; ++k)
                 acc[k] = MFMA16(A[ks & 1][W12 ? k : k / TCO], Bm[ks & 1][W12 ? 0 : k % TCO], acc[k], 0, 0, 0);
@@ -1169,7 +1291,7 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
 #ifdef SAR_TIMING
     if (g_tbuf16 && threadIdx.x == 0) {
         const long bl = blockIdx.x;
-        g_tbuf16[bl * 16 + 8] = t_wait; g_tbuf16[bl * 16 + 9] = t_issue; g_tbuf16[bl * 16 + 10] = (unsigned long long)nmine;
+        g_tbuf16[bl * 32 + 8] = t_wait; g_tbuf16[bl * 32 + 9] = t_issue; g_tbuf16[bl * 32 + 10] = (unsigned long long)nmine;
     }
 #endif
     // ---- flush
@@ -1205,6 +1327,15 @@ __global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3A
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP(4); TSTAMP(15);
+}
+template <int TCI, int TCO, bool W12 = false, bool MIX = false>
+__global__ __launch_bounds__(W12 ? 768 : 576) void wgrad3_bf16_kernel(const Wg3Args a) {
+    const WgItem it = a.items[blockIdx.x];
+    const WgConv* cvp = reinterpret_cast<const WgConv*>(a.convs + (size_t)it.conv * 128);
+    if constexpr (MIX) {
+        if (cvp->ch == 128) { wgrad3_body<TCI, TCO, W12, 128>(a, it, cvp); return; }   // (block-uniform)
+    }
+    wgrad3_body<TCI, TCO, W12, 64>(a, it, cvp);
 }
 
 // Sum of the partial tiles of every multi-slice gradient tile, in slice order (deterministic), added into the gradient: grid
@@ -1517,13 +1648,66 @@ extern "C" {
 typedef BnP sarBnRef;
 
 static int g_last_class[6];
+static int g_last_planned = 0;
 // sar_conv2d_pair_* runs sar_conv2d_* twice with this set: the launcher then hands back what it would have launched instead of launching it
 struct ConvLaunch { ConvP p; dim3 grid; int nthr; size_t lds; int cls[6]; int act32; };
 static ConvLaunch* g_capture = nullptr;
+
+// Plan tables live in a workspace the CALLER lends for the life of the process (this library never allocates): sar_conv_plan_workspace_*.
+// A shape's tables are written by conv_plan_kernel, on the stream of the launch that first meets the shape and in front of it; later launches
+// find them (host-side list, one caller thread like g_last_class).  Without a workspace -- or once it is full -- blocks derive everything
+// themselves, as before.
+struct PlanKey { int v[16]; };
+struct PlanEntry { PlanKey key; size_t thr, tile, lane; int pl_ts; };
+static unsigned char* g_plan_ws = nullptr;
+static size_t g_plan_bytes = 0, g_plan_used = 0;
+static PlanEntry g_plans[256];
+static int g_nplans = 0;
+static void conv_plan_attach(ConvP& p, int TM, int nthr, int ntiles, hipStream_t stream) {
+    p.pl_thr = nullptr; p.pl_tile = nullptr; p.pl_lane = nullptr; p.pl_ts = 0; p.rpi = p.cw > 0 ? nthr / p.cw : 0;
+    p.ent_bins = p.fb.bins; p.ent_bbins = p.fb.bbins; p.ent_det = p.fb.det; p.cap_rows_e = p.cap_rows; p.fill_e = p.fill; p.tmv_e = p.tmv;
+    static const bool off = getenv("SAR_CONV_PLAN") != nullptr && atoi(getenv("SAR_CONV_PLAN")) == 0;
+    if (g_plan_ws == nullptr || off || (p.cap_rows + 1) * 8 > ROWTAB_BYTES || p.cap_rows + 1 > nthr) return;
+    const Geo& g = p.g;
+    PlanKey k = {{g.B, g.Hs, g.Ws, g.Cin, g.Ho, g.Wo, g.K, g.s, g.d, g.pt, g.pl, p.tmv, TM, nthr, p.cap_rows, p.rs}};
+    const PlanEntry* e = nullptr;
+    for (int i = 0; i < g_nplans && e == nullptr; ++i)
+        if (memcmp(&g_plans[i].key, &k, sizeof(k)) == 0) e = &g_plans[i];
+    if (e == nullptr) {
+        if (g_nplans >= 256) return;
+        const int pl_ts = 2 + 2 * p.cap_rows;
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t b_thr = up((size_t)nthr * 16), b_tile = up((size_t)ntiles * pl_ts * 4), b_lane = up((size_t)ntiles * TM * 4);
+        if (g_plan_used + b_thr + b_tile + b_lane > g_plan_bytes) return;
+        PlanEntry& n = g_plans[g_nplans];
+        n.key = k; n.thr = g_plan_used; n.tile = n.thr + b_thr; n.lane = n.tile + b_tile; n.pl_ts = pl_ts;
+        PlanArgs a;
+        memset(&a, 0, sizeof(a));
+        a.g = g; a.lg_pc = p.lg_pc; a.rs = p.rs; a.cw = p.cw; a.mg_cw = p.mg_cw; a.nthr = nthr; a.tmv = p.tmv; a.TM = TM; a.cap_rows = p.cap_rows;
+        a.ntiles = ntiles; a.pl_ts = pl_ts;
+        a.thr = reinterpret_cast<uint4*>(g_plan_ws + n.thr); a.tile = reinterpret_cast<unsigned*>(g_plan_ws + n.tile);
+        a.lane = reinterpret_cast<unsigned*>(g_plan_ws + n.lane);
+        hipLaunchKernelGGL(conv_plan_kernel, dim3(ntiles + 1), dim3(256), 0, stream, a);
+        if (hipGetLastError() != hipSuccess) return;
+        g_plan_used += b_thr + b_tile + b_lane; ++g_nplans;
+        e = &n;
+    }
+    p.pl_thr = reinterpret_cast<const uint4*>(g_plan_ws + e->thr); p.pl_tile = reinterpret_cast<const unsigned*>(g_plan_ws + e->tile);
+    p.pl_lane = reinterpret_cast<const unsigned*>(g_plan_ws + e->lane); p.pl_ts = e->pl_ts;
+}
+// buf: device memory, 256-byte aligned, that stays valid (and is not written by anyone else) until the next call of this function or the end of
+// the process; bytes = 0 / buf = NULL detaches.  A few MB hold every shape of a model (~100 KB per conv shape at B = 64).
+int SAR_T16(sar_conv_plan_workspace_)(void* buf, long bytes) {
+    if (bytes < 0 || (buf == nullptr && bytes != 0) || ((size_t)buf & 255)) return SAR_EINVAL;
+    g_plan_ws = bytes > 0 ? static_cast<unsigned char*>(buf) : nullptr;
+    g_plan_bytes = bytes > 0 ? (size_t)bytes : 0; g_plan_used = 0; g_nplans = 0;
+    return SAR_OK;
+}
 // <WN, NKC, VT, KG, WMX, BR> of the most recent sar_conv2d_* launch of this process (introspection for bench.py / tools; not thread-safe)
 int SAR_T16(sar_conv2d_last_class_)(int* out6) {
     if (out6 == nullptr) return SAR_EINVAL;
     for (int i = 0; i < 6; ++i) out6[i] = g_last_class[i];
+    out6[5] |= g_last_planned << 1;                                   // bit 1 (round 6): the planned instantiation (template argument PL) ran
     return SAR_OK;
 }
 
@@ -1552,9 +1736,9 @@ int SAR_T16(sar_conv_pack_weights_zero_)(const void* table, int n, int total_blo
 // SAR_X3 (sar_conv2d_x3): every 2-byte tensor is a plane pair, `side` ONE fp16 tensor = fp16(T(src) * side_scale), side2 (nullable) T(src) as planes.
 // act32 (the fp16 build only; sar_conv2d_f16a): src2 and e_y -- tensors of the FORWARD pass -- are fp32, everything else this build's 2-byte type.
 #if SAR_HALF
-#define A32K(...) __VA_ARGS__, true>
+#define A32V true
 #else
-#define A32K(...) __VA_ARGS__, false>                                 // (no such instantiations in the other builds: the table rows alias the plain ones)
+#define A32V false                                                    // (no such instantiations in the other builds: the table rows alias the plain ones)
 #endif
 static int conv2d_impl(const void* src, const void* src2, const void* src3, const void* wpk, const float* bias, const void* res, void* y, void* side,
                        int B, int Hs, int Ws, int Cin, int Ho, int Wo, int Cout, int K, int s, int d, int pt, int pl, int fill,
@@ -1663,6 +1847,9 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     const size_t lds = (size_t)6 * Cin * 4 + ROWTAB_BYTES + patch_bytes + ring_bytes;
     if (lds > 160 * 1024) return SAR_EINVAL;
     const dim3 grid((unsigned)cdiv(p.g.M, p.tmv), (unsigned)(Cout / TN));
+    conv_plan_attach(p, TM, nthr, (int)grid.x, stream);
+    const int pln = p.pl_thr != nullptr ? 1 : 0;                                  // the planned instantiation (ConvP: plan tables)
+    g_last_planned = pln;
     // template arguments of the instantiation this launch runs, as rocprofv3 prints them (bench.py classes its conv timings by them)
     g_last_class[0] = WN; g_last_class[1] = Cin / 16 < 8 ? Cin / 16 : 8; g_last_class[2] = K * K * (Cin / 128 > 1 ? Cin / 128 : 1);
     g_last_class[3] = KG; g_last_class[4] = br32 ? 1 : br ? 2 : tm256 ? 8 : 4 / WN; g_last_class[5] = br ? 1 : 0;
@@ -1676,44 +1863,42 @@ static int conv2d_impl(const void* src, const void* src2, const void* src3, cons
     const int ki = ilog2(Cin / 16) - 1, k3 = K == 3 ? 1 : 0;
     if (br) {
         // 64-pixel tiles: 64 | 128 | 256 source channels; 32-pixel tiles: 64 | 128 | 256 | 512
-#define CVB(NKC_, NH_, KG_, WMX_) {conv_bf16_kernel<2, NKC_, NH_, KG_, WMX_, true>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, WMX_, true>}
-#define CVBA(NKC_, NH_, KG_, WMX_) {conv_bf16_kernel<A32K(2, NKC_, NH_, KG_, WMX_, true), conv_bf16_kernel<A32K(2, NKC_, 9 * NH_, KG_, WMX_, true)}
-        static const kern_t kernsb[2][7][2] = {{CVB(4, 1, 2, 2), CVB(8, 1, 4, 2), CVB(8, 2, 4, 2), CVB(4, 1, 2, 1), CVB(8, 1, 4, 1), CVB(8, 2, 4, 1), CVB(8, 4, 4, 1)},
-                                               {CVBA(4, 1, 2, 2), CVBA(8, 1, 4, 2), CVBA(8, 2, 4, 2), CVBA(4, 1, 2, 1), CVBA(8, 1, 4, 1), CVBA(8, 2, 4, 1), CVBA(8, 4, 4, 1)}};
+        // [planned][act32][class][K == 3]
+#define CVB(A_, P_, NKC_, NH_, KG_, WMX_) {conv_bf16_kernel<2, NKC_, NH_, KG_, WMX_, true, A_, P_>, conv_bf16_kernel<2, NKC_, 9 * NH_, KG_, WMX_, true, A_, P_>}
+#define CVB7(A_, P_) {CVB(A_, P_, 4, 1, 2, 2), CVB(A_, P_, 8, 1, 4, 2), CVB(A_, P_, 8, 2, 4, 2), CVB(A_, P_, 4, 1, 2, 1), CVB(A_, P_, 8, 1, 4, 1), CVB(A_, P_, 8, 2, 4, 1), CVB(A_, P_, 8, 4, 4, 1)}
+        static const kern_t kernsb[2][2][7][2] = {{CVB7(false, false), CVB7(A32V, false)}, {CVB7(false, true), CVB7(A32V, true)}};
 #undef CVB
-#undef CVBA
-        static PerDeviceFlag attrb[2][7][2];
+#undef CVB7
+        static PerDeviceFlag attrb[2][2][7][2];
         const int kb = br32 ? ki + 2 : ki - 1;
-        const kern_t kern = kernsb[a32][kb][k3];
-        if (!attrb[a32][kb][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[a32][kb][k3] = true; }
+        const kern_t kern = kernsb[pln][a32][kb][k3];
+        if (!attrb[pln][a32][kb][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrb[pln][a32][kb][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
     if (tm256) {
-#define CVX(NKC_, WMX_) {conv_bf16_kernel<1, NKC_, 1, 1, WMX_>, conv_bf16_kernel<1, NKC_, 9, 1, WMX_>}
-#define CVXA(NKC_, WMX_) {conv_bf16_kernel<A32K(1, NKC_, 1, 1, WMX_, false), conv_bf16_kernel<A32K(1, NKC_, 9, 1, WMX_, false)}
-        static const kern_t kernsx[2][2][2] = {{CVX(2, 8), CVX(4, 8)}, {CVXA(2, 8), CVXA(4, 8)}};
+#define CVX(A_, P_, NKC_, WMX_) {conv_bf16_kernel<1, NKC_, 1, 1, WMX_, false, A_, P_>, conv_bf16_kernel<1, NKC_, 9, 1, WMX_, false, A_, P_>}
+#define CVX2(A_, P_) {CVX(A_, P_, 2, 8), CVX(A_, P_, 4, 8)}
+        static const kern_t kernsx[2][2][2][2] = {{CVX2(false, false), CVX2(A32V, false)}, {CVX2(false, true), CVX2(A32V, true)}};
 #undef CVX
-#undef CVXA
-        static PerDeviceFlag attrx[2][2][2];
-        const kern_t kern = kernsx[a32][ki][k3];
-        if (!attrx[a32][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[a32][ki][k3] = true; }
+#undef CVX2
+        static PerDeviceFlag attrx[2][2][2][2];
+        const kern_t kern = kernsx[pln][a32][ki][k3];
+        if (!attrx[pln][a32][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attrx[pln][a32][ki][k3] = true; }
         hipLaunchKernelGGL(kern, grid, dim3(nthr), lds, stream, p);
         SAR_CHECK_LAUNCH();
         return SAR_OK;
     }
-#define CV(WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_>}
-#define CVA(WN_, NKC_, NH_) {conv_bf16_kernel<A32K(WN_, NKC_, NH_, 1, 4 / WN_, false), conv_bf16_kernel<A32K(WN_, NKC_, 9 * NH_, 1, 4 / WN_, false)}
-    static const kern_t kerns[2][2][5][2] = {{{CV(1, 2, 1), CV(1, 4, 1), CV(1, 8, 1), CV(1, 8, 2), CV(1, 8, 4)},
-                                              {CV(2, 2, 1), CV(2, 4, 1), CV(2, 8, 1), CV(2, 8, 2), CV(2, 8, 4)}},
-                                             {{CVA(1, 2, 1), CVA(1, 4, 1), CVA(1, 8, 1), CVA(1, 8, 2), CVA(1, 8, 4)},
-                                              {CVA(2, 2, 1), CVA(2, 4, 1), CVA(2, 8, 1), CVA(2, 8, 2), CVA(2, 8, 4)}}};
+#define CV(A_, P_, WN_, NKC_, NH_) {conv_bf16_kernel<WN_, NKC_, NH_, 1, 4 / WN_, false, A_, P_>, conv_bf16_kernel<WN_, NKC_, 9 * NH_, 1, 4 / WN_, false, A_, P_>}
+#define CV10(A_, P_) {{CV(A_, P_, 1, 2, 1), CV(A_, P_, 1, 4, 1), CV(A_, P_, 1, 8, 1), CV(A_, P_, 1, 8, 2), CV(A_, P_, 1, 8, 4)}, \
+                      {CV(A_, P_, 2, 2, 1), CV(A_, P_, 2, 4, 1), CV(A_, P_, 2, 8, 1), CV(A_, P_, 2, 8, 2), CV(A_, P_, 2, 8, 4)}}
+    static const kern_t kerns[2][2][2][5][2] = {{CV10(false, false), CV10(A32V, false)}, {CV10(false, true), CV10(A32V, true)}};
 #undef CV
-#undef CVA
-    static PerDeviceFlag attr[2][2][5][2];
-    const kern_t kern = kerns[a32][WN - 1][ki][k3];
-    if (!attr[a32][WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[a32][WN - 1][ki][k3] = true; }
+#undef CV10
+    static PerDeviceFlag attr[2][2][2][5][2];
+    const kern_t kern = kerns[pln][a32][WN - 1][ki][k3];
+    if (!attr[pln][a32][WN - 1][ki][k3]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; attr[pln][a32][WN - 1][ki][k3] = true; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     SAR_CHECK_LAUNCH();
     return SAR_OK;
@@ -1770,10 +1955,12 @@ static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act3
     if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || ca[4] != cb[4] || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
     typedef void (*pair_t)(const ConvP, const ConvP, unsigned, unsigned, unsigned, unsigned);
     pair_t kern = nullptr;
-    static PerDeviceFlag at[12];
+    static PerDeviceFlag at[24];
     int ki = -1;
-    const bool a32 = act32 != 0;
-#define PK(...) (a32 ? conv_bf16_pair_kernel<A32K(__VA_ARGS__) : conv_bf16_pair_kernel<__VA_ARGS__>)
+    const bool a32 = act32 != 0, pl = la.p.pl_thr != nullptr && lb.p.pl_thr != nullptr;   // (both planned, or neither: one kernel runs both bodies)
+    if (!pl) { la.p.pl_thr = nullptr; lb.p.pl_thr = nullptr; }
+#define PK(...) (pl ? (a32 ? conv_bf16_pair_kernel<__VA_ARGS__, A32V, true> : conv_bf16_pair_kernel<__VA_ARGS__, false, true>) \
+                    : (a32 ? conv_bf16_pair_kernel<__VA_ARGS__, A32V, false> : conv_bf16_pair_kernel<__VA_ARGS__, false, false>))
     if (ca[0] == 2 && ca[1] == 2 && ca[2] == 9 && ca[3] == 1 && ca[4] == 2 && !ca[5]) { kern = PK(2, 2, 9, 1, 2, false); ki = 0; }
     else if (ca[0] == 2 && ca[1] == 4 && ca[2] == 9 && ca[3] == 2 && ca[4] == 2 && ca[5]) { kern = PK(2, 4, 9, 2, 2, true); ki = 1; }
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = PK(2, 8, 9, 4, 2, true); ki = 2; }
@@ -1784,6 +1971,7 @@ static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act3
     else if (ca[0] == 1 && ca[1] == 4 && ca[2] == 9 && ca[3] == 1 && ca[4] == 8 && !ca[5]) { kern = PK(1, 4, 9, 1, 8, false); ki = 5; }
 #undef PK
     if (a32 && ki >= 0) ki += 6;
+    if (pl && ki >= 0) ki += 12;
     if (kern == nullptr) return SAR_EINVAL;
     if (!at[ki]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at[ki] = true; }
     const unsigned na = la.grid.x * la.grid.y, nb = lb.grid.x * lb.grid.y, na8 = (na + 7u) & ~7u;
@@ -1805,16 +1993,21 @@ struct sarWgradConv { const void* x; const void* dy; float* dw; float* dbias; in
 // of 32*tile_ci, every Cout of 32*tile_co).  Runs of chunks are cut so that the launch has about `target_blocks` items.
 int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int tile_ci, int tile_co, void* convs_out, void* items_out,
                         int max_items, int* n_items, int* launch4, void* tiles_out, int* slices_out) {
-    if (convs == nullptr || n < 1 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || launch4 == nullptr ||
+    if (convs == nullptr || n < 1 || n > 1024 || target_blocks < 1 || convs_out == nullptr || items_out == nullptr || n_items == nullptr || launch4 == nullptr ||
         tiles_out == nullptr || slices_out == nullptr)
         return SAR_EINVAL;
     const int K = convs[0].K;
     if (K != 1 && K != 3) return SAR_EINVAL;
     if (tile_ci < 1 || tile_ci > 2 || tile_co < 1 || tile_co > 2 || (K == 1 && (tile_ci != 1 || tile_co != 1))) return SAR_EINVAL;
+    // pixels per chunk (wgrad3_body: CH), per CONVOLUTION: 128 since round 6 where the convolution's positions fit the 512-position ring with a
+    // chunk in flight, else 64 as in rounds 2-5 (SAR_WG_CH=64 forces that, for A/B runs).  Bit 8 of launch4[3]: some convolution of the plan runs
+    // 128-pixel chunks (the launcher then takes the kernel that holds both bodies).
+    static const int ch_env = getenv("SAR_WG_CH") ? atoi(getenv("SAR_WG_CH")) : 128;
+    const int NWV = (tile_ci == 2 && tile_co == 2) ? 12 : 9;
     WgConv tmp;
     unsigned char* co = static_cast<unsigned char*>(convs_out);
-    long total = 0;
-    auto prep = [&](int i) -> bool {                                 // validates descriptor i and builds its table row in tmp
+    long total = 0;                                                  // 64-pixel chunk x channel-tile units of the whole launch
+    auto prep = [&](int i, int ch) -> bool {                         // validates descriptor i and builds its table row in tmp
         const sarWgradConv& c = convs[i];
         memset(&tmp, 0, sizeof(tmp));
         if (c.K != K || !make_geo(tmp.g, c.B, c.H, c.W, c.Cin, c.Ho, c.Wo, c.K, c.s, 1, c.pt, c.pl)) return false;
@@ -1823,36 +2016,46 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
         if ((long)c.B * c.H * c.W * c.Cin >= (1L << 31) || (long)tmp.g.M * c.Cout >= (1L << 31)) return false;
         tmp.Cout = c.Cout;
         tmp.x = static_cast<const u16*>(c.x); tmp.dy = static_cast<const u16*>(c.dy); tmp.dw = c.dw; tmp.dbias = c.dbias;
-        tmp.nchunks = cdiv(tmp.g.M, 64);
-        tmp.cap_pos = K == 1 ? 64 : (patch_rows_bound(tmp.g, 64 < tmp.g.M ? 64 : tmp.g.M) * tmp.g.Wp + 15) & ~15;
+        tmp.ch = (short)ch;
+        tmp.nchunks = cdiv(tmp.g.M, ch);
+        tmp.cap_pos = K == 1 ? 64 : (patch_rows_bound(tmp.g, ch < tmp.g.M ? ch : tmp.g.M) * tmp.g.Wp + 15) & ~15;
         tmp.la = 3;
         tmp.ginv = c.ginv != 0.f ? c.ginv : 1.f;                        // (0: descriptors written before the field existed)
-        // 3x3: DMA instructions of an item's first chunk (the whole patch) dealt to nine waves: at most 4 each
-        return K == 1 || 4 * tile_co + (tmp.cap_pos / 16 + 1) * tile_ci <= 36;
+        // 3x3: DMA instructions of an item's first chunk (the whole patch) dealt to the block's waves: at most 4 (128-pixel chunks: 6) each
+        return K == 1 || (ch / 16) * tile_co + (tmp.cap_pos / 16 + 1) * tile_ci <= (ch == 64 ? 4 : 6) * NWV;
     };
     // 3x3: the ring must hold the padded positions of la + 1 consecutive chunks (the one being multiplied and la in flight) plus
-    // the 16-position alignment at both ends.  512 positions when every convolution then gets la >= 2, otherwise the smallest
-    // power of two with la >= 1; every convolution takes the deepest la <= 3 that fits.
-    auto need = [](const Geo& g, int la) { const int px = (la + 1) * 64; return patch_rows_bound(g, px < g.M ? px : g.M) * g.Wp + 32; };
-    int np = 512, la_max = 1;
+    // the 16-position alignment at both ends.  64-pixel chunks: 512 positions when every convolution then gets la >= 2, otherwise the smallest
+    // power of two with la >= 1; every convolution takes the deepest la <= 3 that fits.  128-pixel chunks: where 512 positions hold two of them
+    // (la = 1; la = 2 -- what three 64-pixel chunks in flight were -- where they hold three).
+    auto need = [](const Geo& g, int la, int ch) { const int px = (la + 1) * ch; return patch_rows_bound(g, px < g.M ? px : g.M) * g.Wp + 32; };
+    int np = 512, la_max = 1, any128 = 0, front_max = 0;
+    static unsigned char chs[1024];
     for (int i = 0; i < n; ++i) {
-        if (!prep(i)) return SAR_EINVAL;
-        if (K == 3)
-            while (need(tmp.g, np <= 512 ? 2 : 1) > np) { np *= 2; if (np > 2048) return SAR_EINVAL; }
+        int ch = 64;
+        if (K == 3 && ch_env != 64 && prep(i, 128) && need(tmp.g, 1, 128) <= 512) ch = 128;
+        chs[i] = (unsigned char)ch;
+        if (!prep(i, ch)) return SAR_EINVAL;
+        if (K == 3 && ch == 64)
+            while (need(tmp.g, np <= 512 ? 2 : 1, 64) > np) { np *= 2; if (np > 2048) return SAR_EINVAL; }
     }
     for (int i = 0; i < n; ++i) {
-        prep(i);
+        const int ch = chs[i];
+        prep(i, ch);
         if (K == 3) {
-            tmp.la = 3;
-            while (tmp.la > 1 && need(tmp.g, tmp.la) > np) --tmp.la;
-            if (need(tmp.g, tmp.la) > np) return SAR_EINVAL;
+            tmp.la = ch == 128 ? 2 : 3;
+            while (tmp.la > 1 && need(tmp.g, tmp.la, ch) > np) --tmp.la;
+            if (need(tmp.g, tmp.la, ch) > np) return SAR_EINVAL;
             if (tmp.la > la_max) la_max = tmp.la;
+            if (ch == 128) any128 = 1;
+            const int front = 8 * ch + (tmp.la + 1) * tile_co * ch * 64;    // position tables + gradient-row slots of this convolution's blocks
+            if (front > front_max) front_max = front;
         }
         memset(co + (size_t)i * 128, 0, 128);
         memcpy(co + (size_t)i * 128, &tmp, sizeof(tmp));
-        total += (long)tmp.nchunks * (convs[i].Cin / (32 * tile_ci)) * (convs[i].Cout / (32 * tile_co));
+        total += (long)cdiv(tmp.g.M, 64) * (convs[i].Cin / (32 * tile_ci)) * (convs[i].Cout / (32 * tile_co));
     }
-    int maxc = (int)((total + target_blocks - 1) / target_blocks);
+    int maxc = (int)((total + target_blocks - 1) / target_blocks);   // 64-pixel chunks per item
     static const int minc3 = getenv("SAR_WG_MINC") ? atoi(getenv("SAR_WG_MINC")) : 16;   // chunks per item at least: an item ends in its tiles' atomics (8 / 16 / 24 / 32 / 48: 2.327 / 2.307 / 2.317 / 2.331 / 2.365 ms, forced one-rank three-graph step)
     const int minc = K == 3 ? minc3 : 2 * WG_NW1;
     if (maxc < minc) maxc = minc;
@@ -1860,12 +2063,13 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
     int ni = 0, tab_pos = 0;
     for (int i = 0; i < n; ++i) {
         const sarWgradConv& c = convs[i];
-        const int nchunks = cdiv((long)c.B * c.Ho * c.Wo, 64);
-        int slices = cdiv(nchunks, maxc), cpb = cdiv(nchunks, slices);
+        const int CH = chs[i], maxc_i = maxc * 64 / CH > 0 ? maxc * 64 / CH : 1;
+        const int nchunks = cdiv((long)c.B * c.Ho * c.Wo, CH);
+        int slices = cdiv(nchunks, maxc_i), cpb = cdiv(nchunks, slices);
         if (K == 3) {
             // the item's position -> source-offset table (4 bytes per padded position of its run): at most WG_TAB_MAX positions
-            prep(i);
-            auto run_pos = [&](int chunks) { const long px = (long)chunks * 64; return patch_rows_bound(tmp.g, (int)(px < tmp.g.M ? px : tmp.g.M)) * tmp.g.Wp + 48; };
+            prep(i, CH);
+            auto run_pos = [&](int chunks) { const long px = (long)chunks * CH; return patch_rows_bound(tmp.g, (int)(px < tmp.g.M ? px : tmp.g.M)) * tmp.g.Wp + 48; };
             while (cpb > 1 && run_pos(cpb) > WG_TAB_MAX) { ++slices; cpb = cdiv(nchunks, slices); }
             if (run_pos(cpb) > WG_TAB_MAX) return SAR_EINVAL;
             if (run_pos(cpb) > tab_pos) tab_pos = run_pos(cpb);
@@ -1886,7 +2090,7 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
     for (int a = 1; a < ni; ++a) {
         const WgItem it = items[a];
         int b = a - 1;
-        while (b >= 0 && items[b].c_count < it.c_count) { items[b + 1] = items[b]; --b; }
+        while (b >= 0 && items[b].c_count * (int)chs[items[b].conv] < it.c_count * (int)chs[it.conv]) { items[b + 1] = items[b]; --b; }   // (by pixels: chunk sizes differ)
         items[b + 1] = it;
     }
     *n_items = ni;
@@ -1919,11 +2123,11 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
     }
     if (K == 3) {
         tab_pos = (tab_pos + 127) & ~127;
-        launch4[0] = 512 + tab_pos * 4 + (la_max + 1) * tile_co * 4096 + tile_ci * np * 64; launch4[1] = np; launch4[2] = la_max + 1;
+        launch4[0] = front_max + tab_pos * 4 + tile_ci * np * 64; launch4[1] = np; launch4[2] = la_max + 1;
     } else {
         launch4[0] = WG_NW1 * WG_NBUF * 8192; launch4[1] = 0; launch4[2] = WG_NBUF;
     }
-    launch4[3] = (tile_ci << 4) | tile_co;
+    launch4[3] = (tile_ci << 4) | tile_co | (any128 ? 0x100 : 0) | ((K == 3 ? tab_pos / 128 : 0) << 16);
     return launch4[0] <= 160 * 1024 ? SAR_OK : SAR_EINVAL;
 }
 
@@ -1934,7 +2138,8 @@ int sar_wgrad_plan_bf16(const sarWgradConv* convs, int n, int target_blocks, int
 int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_dev, int n_items, int K, const int* launch4, const void* tiles_dev,
                                      const int* slices_dev, float* slab, hipStream_t stream) {
     if (convs_dev == nullptr || items_dev == nullptr || launch4 == nullptr || n_items < 1 || (K != 1 && K != 3)) return SAR_EINVAL;
-    const int lds_bytes = launch4[0], np = launch4[1], nbuf = launch4[2], tci = launch4[3] >> 4, tco = launch4[3] & 15;
+    const int lds_bytes = launch4[0], np = launch4[1], nbuf = launch4[2], tci = (launch4[3] >> 4) & 15, tco = launch4[3] & 15, mix = (launch4[3] >> 8) & 1;
+    const int tab_pos = (launch4[3] >> 16) * 128;
     const int n_tiles = launch4[4], n_slabs = launch4[5];
     if (n_tiles < 0 || n_slabs < 0 || (n_slabs > 0 && (n_tiles < 1 || tiles_dev == nullptr || slices_dev == nullptr || slab == nullptr))) return SAR_EINVAL;
     if (lds_bytes <= 0 || lds_bytes > 160 * 1024 || tci < 1 || tci > 2 || tco < 1 || tco > 2) return SAR_EINVAL;
@@ -1945,16 +2150,19 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
         zero_page = static_cast<const uint4*>(zp);
     }
     if (K == 3) {
-        const int tab_bytes = lds_bytes - (512 + nbuf * tco * 4096 + tci * np * 64);
-        if (!pow2(np) || np < 512 || nbuf < 2 || nbuf > 4 || tab_bytes < 0 || tab_bytes % 512 || tab_bytes > WG_TAB_MAX * 4) return SAR_EINVAL;
+        const int tab_bytes = tab_pos * 4;
+        // (the front of a block's LDS -- position tables and gradient-row slots -- is per convolution: WgConv::ch, la; the plan's launch4[0] holds the largest)
+        if (!pow2(np) || np < 512 || nbuf < 2 || nbuf > 4 || tab_bytes > WG_TAB_MAX * 4 || lds_bytes < 512 + 2 * tco * 4096 + tab_bytes + tci * np * 64) return SAR_EINVAL;
         if (launch4[6] != 9 * tci * tco * 1024) return SAR_EINVAL;
         Wg3Args a{static_cast<const unsigned char*>(convs_dev), static_cast<const WgItem*>(items_dev), zero_page, (unsigned)np, nbuf, tab_bytes / 4, slab};
         typedef void (*k3_t)(const Wg3Args);
         // 64 x 64 tiles: the twelve-wave form
-        static const k3_t k3[2][2] = {{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2, true>}};
-        static PerDeviceFlag attr3[2][2];
-        const k3_t kern = k3[tci - 1][tco - 1];
-        PerDeviceFlag& at = attr3[tci - 1][tco - 1];
+        static const k3_t k3[2][2][2] = {{{wgrad3_bf16_kernel<1, 1>, wgrad3_bf16_kernel<1, 2>}, {wgrad3_bf16_kernel<2, 1>, wgrad3_bf16_kernel<2, 2, true>}},
+                                         {{wgrad3_bf16_kernel<1, 1, false, true>, wgrad3_bf16_kernel<1, 2, false, true>},
+                                          {wgrad3_bf16_kernel<2, 1, false, true>, wgrad3_bf16_kernel<2, 2, true, true>}}};
+        static PerDeviceFlag attr3[2][2][2];
+        const k3_t kern = k3[mix][tci - 1][tco - 1];
+        PerDeviceFlag& at = attr3[mix][tci - 1][tco - 1];
         if (!at) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at = true; }
         const int threads = tci == 2 && tco == 2 ? 768 : 576;
         hipLaunchKernelGGL(kern, dim3(n_items), dim3(threads), lds_bytes, stream, a);
@@ -1962,7 +2170,7 @@ int SAR_T16(sar_conv2d_wgrad_batch_)(const void* convs_dev, const void* items_de
             hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(n_tiles, 9 * tci * tco), dim3(256), 0, stream, static_cast<const unsigned char*>(convs_dev),
                                static_cast<const WgTile*>(tiles_dev), slices_dev, slab, tci, tco);
     } else {
-        if (tci != 1 || tco != 1 || nbuf != WG_NBUF || lds_bytes != WG_NW1 * WG_NBUF * 8192) return SAR_EINVAL;
+        if (tci != 1 || tco != 1 || mix || nbuf != WG_NBUF || lds_bytes != WG_NW1 * WG_NBUF * 8192) return SAR_EINVAL;
         static PerDeviceFlag attr1;
         if (!attr1) { if (!allow_lds(wgrad1_bf16_kernel, 160 * 1024)) return SAR_ELAUNCH; attr1 = true; }
         hipLaunchKernelGGL(wgrad1_bf16_kernel, dim3(n_items), dim3(WG_NW1 * 64), lds_bytes, stream, static_cast<const unsigned char*>(convs_dev),

@@ -25,6 +25,7 @@ namespace {
 
 // In-kernel phase timing (tools/stem_timing.py; only with -DSAR_TIMING into tools/libsarnet_timing_stem.so, never part of
 // libsarnet_hip.so): thread 0 of every block stamps s_memtime (shader clock) / s_memrealtime (100 MHz, device-wide: slots 0, 15).
+#undef TSTAMP                    // (trunk16.h's default; the stem kernels stamp into their own buffer)
 #ifdef SAR_TIMING
 __device__ unsigned long long* g_tbuf_stem = nullptr;
 #define TSTAMP(slot)                                                                                                   \

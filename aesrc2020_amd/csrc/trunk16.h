@@ -2,6 +2,9 @@
 // plumbing (statistic bins -> constants in every consumer's prologue) and the LDS transpose-read.
 #pragma once
 #include "common.h"
+#ifndef TSTAMP
+#define TSTAMP(slot) do {} while (0)    // (conv_bf16.hip defines it in the -DSAR_TIMING build of tools/)
+#endif
 
 namespace {
 
@@ -370,6 +373,14 @@ __device__ __forceinline__ void bn_issue(const BnP& bn, int mode, BnRaw& r) {
         if ((fwd_bins || mode == 2) && q < G) bn_issue_g<G>(bn, mode, fwd_bins, C, c, q, r);
     }
 }
+
+// (the three fields of the BatchNorm it reads, handed over one by one: the planned conv kernels keep copies of them in the first piece of their argument block)
+template <int NTHR, int C>
+__device__ __forceinline__ void bn_issue(const float* bins, const float* bbins, int det, int mode, BnRaw& r) {
+    BnP bn;
+    bn.bins = bins; bn.bbins = bbins; bn.det = det;
+    bn_issue<NTHR, C>(bn, mode, r);
+}
 template <int NTHR, int C>
 __device__ __forceinline__ void bn_finish(const BnP& bn, int mode, float* cst, int cs, bool owner, const BnRaw& r, double* scr) {
     constexpr int G = NTHR / C >= 4 ? 4 : NTHR / C >= 2 ? 2 : 1;
@@ -381,9 +392,12 @@ __device__ __forceinline__ void bn_finish(const BnP& bn, int mode, float* cst, i
             if constexpr (G > 1) bn_sum_g<G>(bn, mode, fwd_bins, C, c, q, r, scr);
             else bn_partials<1>(bn, mode, fwd_bins, C, c, q, scr);
         }
+        TSTAMP(19);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        TSTAMP(20);
     }
     bn_finalize(bn, mode, fwd_bins, G, C, cst, cs, owner, scr);
+    TSTAMP(21);
 }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }

@@ -144,14 +144,21 @@ class ParamStore:
 
     PER_UTT_SHIFT = 6        # gradient rows per utterance, not per frame: ~L times larger, times rstd <= 31 behind a BatchNorm -- 2^-6 of the scale
 
-    def bwd_gemm_shift(self, rows):
-        return self.PER_UTT_SHIFT if rows < 8 * max(self.__dict__.get("batch", 64), 1) else 0
+    def bwd_gemm_shift(self, rows, per_utt=None):
+        """per_utt: the layer's gradient rows are per utterance (one row per batch element: AR_EMBEDDING and what follows it).  A layer that does
+        not say is classed by its row count: rows <= batch is one row per utterance -- a per-frame layer has batch x L rows, and at L = 1 the
+        two are the same thing (round 5 tested rows < 8 x batch, which gave per-frame layers of short inputs the extra 2^-6: ADVICE r5)."""
+        if per_utt is None:
+            per_utt = rows <= max(self.__dict__.get("batch", 64), 1)
+        return self.PER_UTT_SHIFT if per_utt else 0
 
     def bwd_gemm_scale(self, rows=None):
         """> 0: the backward products of the per-frame Dense / GRU-projection layers run single-pass on fp16 operands, the gradient operand
         times this power of two (csrc/gemm.hip: F16) -- the split-precision GEMM mode's backward since round 5 (SAR_GEMM_BWD=x3: three
         passes as in the forward).  The scale is the 2-byte trunk's: 64 x batch, lowered by the overflow guard (gscale_shift)."""
         if not self.training or _lib.get_gemm_math() != "bf16x3" or os.environ.get("SAR_GEMM_BWD", "f16") != "f16":
+            return 0.0
+        if not self.__dict__.get("_adam_guard", False):                      # no overflow guard on this store: no fp16 gradient operands (ADVICE r5)
             return 0.0
         shift = self.bwd_gemm_shift(rows) if rows is not None else 0
         return float(2 ** (int(round(np.log2(64.0 * max(self.__dict__.get("batch", 64), 1)))) + self.gscale_shift - shift))

@@ -14,6 +14,11 @@ _call = _lib.call
 BN_EPS, BN_MOMENTUM, LN_EPS = 1e-3, 0.99, 1e-14
 
 
+def _aligned16(*tensors):
+    """every operand starts on a 16-byte boundary (what the vector loads / stores of sar_gemm_pair_f32 need)"""
+    return all(t.data_ptr() % 16 == 0 for t in tensors)
+
+
 class Layer:
     def __init__(self, name):
         self.name = name
@@ -103,7 +108,9 @@ class Dense(Layer):
             return None
         dx = dx_out if dx_out is not None else self.buf("dx", (R, self.in_dim))
         gs = self.store.bwd_gemm_scale(R)
-        if gs > 0 and (R | self.in_dim | self.units) % 64 == 0:     # the split-precision mode's backward: one pass on fp16 operands (csrc/gemm.hip: F16)
+        # the split-precision mode's backward: one pass on fp16 operands (csrc/gemm.hip: F16).  (16-byte aligned operands only: the entry
+        # returns SAR_EINVAL for a view that is not, and the per-product path below takes any -- ADVICE r5)
+        if gs > 0 and (R | self.in_dim | self.units) % 64 == 0 and _aligned16(dz, self.kernel.w, dx):
             _call("sar_gemm_pair_f32", dz, self.kernel.w, None, None, dx, R, self.in_dim, self.units, self.units, self.units, self.in_dim, 1,
                   1 if accumulate_dx else 0, gs, 1.0)
         else:
@@ -237,7 +244,8 @@ class BiGRU(Layer):
         else:
             _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(ks), 2, I, 3 * H, R, I, 3 * H, 3 * H, sk)
             _call("sar_gemm_wgrad_batched_f32", _lib.GemmBatch(us), 2, H, 3 * H, R, H, 3 * H, 3 * H, sku)
-        if need_dx and (R | I | H) % 64 == 0 and _lib.get_gemm_math() in ("bf16", "bf16x3") and os.environ.get("SAR_GEMM_PAIR", "1") == "1":
+        if (need_dx and (R | I | H) % 64 == 0 and _lib.get_gemm_math() in ("bf16", "bf16x3") and os.environ.get("SAR_GEMM_PAIR", "1") == "1"
+                and _aligned16(dai[0], dai[1], self.p["forward"][0].w, self.p["backward"][0].w, dx)):
             # both directions' products into dx in ONE launch (two operand pairs along k; csrc/gemm.hip: GemmX) -- they were two, the second a
             # read-modify-write of dx; in the split-precision mode's backward arithmetic where that applies
             _call("sar_gemm_pair_f32", dai[0], self.p["forward"][0].w, dai[1], self.p["backward"][0].w, dx, R, I, 3 * H, 3 * H, 3 * H, I, 1,

@@ -101,10 +101,12 @@ class SARNetModel:
                 print("======= ERROR: please specify cnn in res-[18,34,50,101,152] ======")
                 raise ValueError("res_type")
             self.trunk = fn[c["res_type"]](inputs, filters=c["res_filters"])
-            if getattr(self.trunk, "half", False) or getattr(self.trunk, "x3", False) or (H == 256 and _lib.get_gemm_math() == "bf16x3"):
+            if getattr(self.trunk, "half", False) or getattr(self.trunk, "x3", False) or _lib.get_gemm_math() == "bf16x3":
                 # fp16 operands can overflow (csrc/optim.hip): the fp16 / split-precision trunk's activation gradients, and -- whatever the trunk
-                # runs on (res_filters off {32, 64}, SAR_TRUNK_DTYPE=fp32 / bf16) -- the fp16 MFMA recurrence the split-precision GEMM mode gives
-                # the Bi-GRUs at hidden_dim 256 (layers.BIGRU: msfx "f16")
+                # runs on (res_filters off {32, 64}, SAR_TRUNK_DTYPE=fp32 / bf16) and whatever hidden_dim is -- the split-precision GEMM mode's
+                # backward: Dense dX, the Bi-GRU pair dX and the grouped weight gradients are single-pass fp16 under 64 x batch
+                # (ParamStore.bwd_gemm_scale), and at hidden_dim 256 the recurrence is the fp16 MFMA form (layers.BIGRU: msfx "f16").  Without
+                # the guard an overflow would reach Adam's moments for good
                 self.store.set_adam_guard(True)
             Tp, Dp = self.trunk.out_hw
             self.L = Tp * Dp

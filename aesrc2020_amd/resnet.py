@@ -625,6 +625,11 @@ class ResNetTrunk(Layer):
     def _stem_backward16(self, g, B):
         """g: gradient of the pooled map (bf16).  BatchNorm sums from (g, pooled, slots), then the 7x7 kernel gradient."""
         if self.x3 and not self.STEM_X3:
+            if self.bwd16:
+                # the mixed backward hands this function ONE fp16 tensor under the gradient scale; round 1's fp32 stem takes a true-unit fp32
+                # gradient and sar_cast_x3_f32 would read the 2-byte tensor as 4-byte elements (ADVICE r5)
+                raise RuntimeError("SAR_STEM_X3=0 (round 1's fp32 stem, an A/B switch) needs SAR_X3_BWD=x3: the default mixed backward "
+                                   "carries the stem's gradient as a scaled fp16 tensor")
             g32 = self.scratch("stem_g32", tuple(g.shape[1:]))
             _call("sar_cast_x3_f32", g, g32, g32.numel())
             return self._stem_backward(g32, B)

@@ -142,8 +142,8 @@ def conv_roofline(model, B, iters=10, in_step=None):
             out = (ctypes.c_int * 6)()
             sfx = tr.bsfx.replace("f16a", "f16") if bwd else tr.sfx
             assert _lib.lib().fn["sar_conv2d_last_class_" + sfx](out) == 0
-            return "conv_bf16_kernel<%d, %d, %d, %d, %d, %s, %s>" % (out[0], out[1], out[2], out[3], out[4], "true" if out[5] else "false",
-                                                                     "true" if (bwd and hyb) else "false")
+            return "conv_bf16_kernel<%d, %d, %d, %d, %d, %s, %s, %s>" % (out[0], out[1], out[2], out[3], out[4], "true" if out[5] & 1 else "false",
+                                                                         "true" if (bwd and hyb) else "false", "true" if out[5] & 2 else "false")
 
         def add_l(cls_fn, secs, flops, nbytes):                       # the class is asked for after `secs` was measured (argument order)
             add(cls_fn(), secs, flops, nbytes)
@@ -208,7 +208,8 @@ def conv_roofline(model, B, iters=10, in_step=None):
             sel = [w_ for w_ in wg if tr._wgrad_class(w_[0]) == cls]
             if sel:
                 plan = _lib.WgradPlan([w_[0] for w_ in sel], target, (2, 2) if cls[2] else (1, 1), tr.wsfx)
-                nm = ("wgrad3_bf16_kernel<2, 2, true>" if cls[2] else "wgrad3_bf16_kernel<1, 1, false>") if cls[0] == 3 else "wgrad1_bf16_kernel"   # (as rocprofv3 prints them)
+                mixw = "true" if (plan.launch4[3] >> 8) & 1 else "false"                # (round 6) some convolution of the plan runs 128-pixel chunks: the kernel with both bodies
+                nm = ("wgrad3_bf16_kernel<2, 2, true, %s>" % mixw if cls[2] else "wgrad3_bf16_kernel<1, 1, false, %s>" % mixw) if cls[0] == 3 else "wgrad1_bf16_kernel"   # (as rocprofv3 prints them)
                 c = classes.setdefault(nm, dict(time=0.0, flops=0.0, bytes=0.0, design_bytes=0.0, launches=0))
                 c["time"] += timed(plan.launch); c["flops"] += sum(w_[1] for w_ in sel); c["launches"] += 1
                 c["bytes"] += sum(w_[2][0] for w_ in sel); c["design_bytes"] += sum(w_[2][1] for w_ in sel)

@@ -211,6 +211,17 @@ typedef struct sarConvArgs {
     void* side2; float side_scale;   /* sar_conv2d_x3 only (below); NULL / 0 elsewhere */
 } sarConvArgs;
 int sar_conv2d_pair_bf16(const sarConvArgs* a, const sarConvArgs* b, sarStream_t stream);
+/* Plan workspace of sar_conv2d_bf16 / sar_conv2d_pair_bf16 (round 6; resnet.py:22-125 -- every conv of the trunk is launched once per step with
+ * the same shape).  What a block derives from the launch's SHAPE alone -- the fill's per-thread piece, the tile's row table, the patch position of
+ * every output pixel: ~2 000 cycles of integer divisions in front of the first load of the fill, by every wave of every block of every launch --
+ * is written ONCE per shape into `buf` (by a small kernel on the stream of the launch that first meets the shape, in front of it) and read back
+ * with three loads at kernel entry.  The library does not allocate: the caller lends `buf` (device memory, 256-byte aligned, `bytes` long; ~100 KB
+ * per conv shape at B = 64, a few MB per model) until the next call of this function or the end of the process -- captured graphs keep pointers
+ * into it.  Without a workspace, or once it is full, launches run the instantiations that derive everything themselves (results identical).
+ * buf = NULL, bytes = 0 detaches.  One per build of the trunk kernels (…_f16: sar_conv2d_f16 / _f16a; …_x3: sar_conv2d_x3).  Not thread-safe. */
+int sar_conv_plan_workspace_bf16(void* buf, long bytes);
+int sar_conv_plan_workspace_f16(void* buf, long bytes);
+int sar_conv_plan_workspace_x3(void* buf, long bytes);
 /* Introspection (bench.py, tools): the template arguments <WN, NKC, VT, KG, WMX, BR> of the conv_bf16_kernel instantiation the most
  * recent sar_conv2d_bf16 launch of this process ran -- the name rocprofv3 reports it under.  Not thread-safe. */
 int sar_conv2d_last_class_bf16(int* out6);
@@ -221,9 +232,10 @@ int sar_conv2d_last_class_bf16(int* out6);
  * They are off the critical path of the backward pass, so the trunk collects them and runs them once per backward part.
  * (1) sar_wgrad_plan_bf16 -- host only, no device access -- turns n descriptors of equal K (1 or 3) into the two device tables of
  * one launch: convs_out (n rows of 128 bytes) and items_out (<= max_items rows of 32 bytes: one block each = one convolution, a
- * tile of 32*tile_ci input x 32*tile_co output channels, a run of 64-pixel chunks; longest first; runs are cut so that the launch
- * has about target_blocks items), the item count, and launch4 = {dynamic LDS bytes, positions of the patch ring, chunk buffers,
- * tile_ci << 4 | tile_co}.  tile_ci, tile_co in {1, 2} (3x3; 1x1: both 1): 64-wide tiles halve the bytes per MFMA where the
+ * tile of 32*tile_ci input x 32*tile_co output channels, a run of pixel chunks -- 128 pixels for 3x3, 64 for 1x1 (round 6; 64 for
+ * both until then: a chunk is one barrier, one round of DMA issue and one position table of the block) --; longest first; runs are cut
+ * so that the launch has about target_blocks items), the item count, and launch4 = {dynamic LDS bytes, positions of the patch ring,
+ * chunk buffers, tile_ci << 4 | tile_co | (128-pixel chunks ? 0x100 : 0)}.  tile_ci, tile_co in {1, 2} (3x3; 1x1: both 1): 64-wide tiles halve the bytes per MFMA where the
  * layer has 64+ channels.  Plan stride-2 convolutions (4x larger patch ring) and the tile classes separately.
  * (2) The caller uploads both tables once; sar_conv2d_wgrad_batch_bf16 launches them. */
 typedef struct sarWgradConv {

@@ -400,8 +400,9 @@ def test_conv_wgrad(L, shape):
     dw3, db3 = cv.wgrad(dbf(x), dbf(dy), target_blocks=100000)                   # shortest runs: the atomic flush
     check(dw3, dw_ref, TOL_F32, "dw (shortest runs)"); check(db3, db_ref, TOL_F32, "db (shortest runs)")
     items = np.frombuffer(cv.last_plan.items.cpu().numpy().tobytes(), np.int32).reshape(-1, 8)
-    nch = -(-B * ho * wo // 64)
-    assert items[:, 4].max() <= (16 if k == 3 else 8) and (nch <= items[:, 4].max() or not items[:, 5].any())   # the planner's shortest runs
+    ch = 128 if (cv.last_plan.launch4[3] >> 8) & 1 else 64                       # pixels per chunk (round 6: 128 where the convolution fits the ring with one in flight)
+    nch = -(-B * ho * wo // ch)
+    assert items[:, 4].max() * ch <= (16 if k == 3 else 8) * 64 and (nch <= items[:, 4].max() or not items[:, 5].any())   # the planner's shortest runs
 
 
 def test_conv_wgrad_many_convolutions_in_one_launch(L):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert exported == set(protos), (exported ^ set(protos))
     # every entry point takes the stream last and returns int (or size_t for workspace queries)
     for name, (ret, at) in protos.items():
-        if name.endswith("_bytes") or name.endswith("_conv_math") or name.endswith("_gemm_math") or name in ("sar_bn_bins", "sar_wgrad_plan_bf16", "sar_dbg_last_wgrad_launch",
+        if name.endswith("_bytes") or name.endswith("_conv_math") or name.endswith("_gemm_math") or name.startswith("sar_conv_plan_workspace_") or name in ("sar_bn_bins", "sar_wgrad_plan_bf16", "sar_dbg_last_wgrad_launch",
                                                                                                                           "sar_comm_unique_id", "sar_comm_init", "sar_comm_destroy"):   # host-side calls: no stream
             continue
         assert at[-1].__name__ == "c_void_p", name
@@ -42,28 +42,44 @@ def test_wgrad_plan_covers_every_tile_and_chunk_once():
     descs = [dict(x=0x1000, dy=0x2000, dw=0x3000 + i, dbias=None, B=B, H=h, W=w, Cin=ci, Ho=h, Wo=w, Cout=co, K=3, s=1, pt=1, pl=1)
              for i, (h, w, ci, co) in enumerate(shapes)]
     convs, items, n, l4, tiles, slices = _lib.WgradPlan.plan_host(descs, 768)
-    # 32 x 32 tiles: 512-position ring, three chunks in flight -> 512 B + 4 x 4 KB + 32 KB + the items' source-offset table
-    # (4 bytes per padded position of the longest run, <= 24 KB): three blocks per CU
-    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 600 <= n <= 1400 and l4[1:4] == [512, 4, 0x11]
-    tab = l4[0] - (512 + 4 * 4096 + 512 * 64)
-    assert 0 < tab <= 24576 and tab % 512 == 0 and l4[0] <= 80 * 1024
+
+    def conv_rows(cv):
+        """(chunks in flight, pixels per chunk) of every convolution: WgConv::la, ::ch (csrc/conv_bf16.hip; two shorts at byte 120 of a 128-byte row)."""
+        r = np.frombuffer(cv, np.int16).reshape(-1, 64)
+        return r[:, 60].astype(int), r[:, 61].astype(int)
+
+    def front(cv, tco):
+        """what a block keeps in FRONT of the offset table and the ring: position tables 8 x ch + (la + 1) gradient-row slots of tco x ch x 64 bytes"""
+        la, ch = conv_rows(cv)
+        return int((8 * ch + (la + 1) * tco * ch * 64).max())
+
+    # 32 x 32 tiles: 512-position ring.  Round 6: 128-pixel chunks where a convolution's positions fit the ring with one chunk in flight (stages 0-2
+    # here; the 13 x 3 images of stage 3 keep 64-pixel chunks, three in flight) -> position tables + gradient-row slots (at most 1 KB + 3 x 8 KB) + 32 KB
+    # + the items' source-offset table (4 bytes per padded position of the longest run, <= 24 KB): two to three blocks per CU
+    la, ch = conv_rows(convs)
+    assert len(convs) == 128 * len(descs) and len(items) == 32 * n and 300 <= n <= 1400 and l4[1] == 512 and l4[3] & 0xff == 0x11
+    assert set(ch) <= {64, 128} and ((ch == 128) == np.array([h * w >= 64 for h, w, _, _ in shapes])).all() and (la >= 1).all() and (la[ch == 64] >= 2).all()
+    assert (l4[3] >> 8) & 1 == int((ch == 128).any()) and l4[2] == la.max() + 1
+    tab = (l4[3] >> 16) * 128 * 4
+    assert 0 < tab <= 24576 and l4[0] == front(convs, 1) + tab + 512 * 64 and l4[0] <= 80 * 1024
     wide = [d for d in descs if d["Cin"] >= 64 and d["Cout"] >= 64]
-    _, items64, n64, l64 = _lib.WgradPlan.plan_host(wide, 640, (2, 2))[:4]
-    tab64 = l64[0] - (512 + 4 * 2 * 4096 + 2 * 512 * 64)
-    assert l64[1:4] == [512, 4, 0x22] and l64[6] == 9 * 4 * 1024 and 400 <= n64 <= 900 and 0 < tab64 <= 24576 and tab64 % 512 == 0
-    _, items1, n1, l1, tiles1, _ = _lib.WgradPlan.plan_host(wide, 1, (2, 2))       # asks for one item per tile: runs still fit the offset table
+    convs64, items64, n64, l64 = _lib.WgradPlan.plan_host(wide, 640, (2, 2))[:4]
+    tab64 = (l64[3] >> 16) * 128 * 4
+    assert l64[1] == 512 and l64[3] & 0xff == 0x22 and l64[6] == 9 * 4 * 1024 and 200 <= n64 <= 900 and 0 < tab64 <= 24576
+    assert l64[0] == front(convs64, 2) + tab64 + 2 * 512 * 64
+    convs1, items1, n1, l1, tiles1, _ = _lib.WgradPlan.plan_host(wide, 1, (2, 2))   # asks for one item per tile: runs still fit the offset table
     it1 = np.frombuffer(items1, np.int32).reshape(n1, 8)
-    assert it1[:, 4].max() * 64 <= 64 * 500
+    assert (it1[:, 4] * conv_rows(convs1)[1][it1[:, 0]]).max() <= 64 * 500
     it64 = np.frombuffer(items64, np.int32).reshape(n64, 8)
     assert (it64[:, 1] % 64 == 0).all() and (it64[:, 2] % 64 == 0).all()
     # stride-2 convolutions: a 1024-position ring
     s2 = [dict(x=1, dy=2, dw=3, dbias=None, B=B, H=100, W=20, Cin=32, Ho=50, Wo=10, Cout=64, K=3, s=2, pt=0, pl=0)]
     assert _lib.WgradPlan.plan_host(s2, 512)[3][1] == 1024
     it = np.frombuffer(items, np.int32).reshape(n, 8)
-    assert (np.diff(it[:, 4]) <= 0).all()
+    assert (np.diff(it[:, 4] * ch[it[:, 0]]) <= 0).all()                          # longest first, in pixels
     for i, (h, w, ci, co) in enumerate(shapes):
         mine = it[it[:, 0] == i]
-        nch = -(-B * h * w // 64)
+        nch = -(-B * h * w // ch[i])
         for a in range(0, ci, 32):
             for b in range(0, co, 32):
                 runs = sorted((r[3], r[4]) for r in mine if r[1] == a and r[2] == b)

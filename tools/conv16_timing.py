@@ -27,6 +27,11 @@ else:
     lib.sar_conv2d_bf16.argtypes = [vp] * 8 + [ci] * 13 + [vp, ci, vp, vp, vp, vp]
     lib.sar_conv_pack_weights_bf16.argtypes = [vp, ci, ci, vp]
 lib.sar_dbg_set_timing_buffer16.argtypes = [vp]
+if os.environ.get("TIMING_PLAN", "1") == "1":                   # the launch shapes' plan tables (round 6): TIMING_PLAN=0 = every block derives them
+    plan_ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+    fnp = lib.sar_conv_plan_workspace_x3 if X3 else lib.sar_conv_plan_workspace_bf16
+    fnp.argtypes = [vp, ctypes.c_long]
+    assert fnp(plan_ws.data_ptr(), plan_ws.numel()) == 0
 BF = torch.bfloat16
 NPL = 2 if X3 else 1
 planes = lambda t: t.float().contiguous() if X3 else t.to(BF)            # split precision: the trunk's tensors are fp32 in HBM
@@ -34,6 +39,8 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 B = int(os.environ.get("CB", 64))
 SHAPES = [("s0 3x3 32->32", 100, 20, 32, 32, 3), ("s1 3x3 64->64", 50, 10, 64, 64, 3), ("s2 3x3 128->128", 25, 5, 128, 128, 3),
           ("s3 3x3 256->256", 13, 3, 256, 256, 3)]
+if os.environ.get("TIMING_SHAPES"):                             # e.g. TIMING_SHAPES=s2,s3
+    SHAPES = [s for s in SHAPES if s[0].split()[0] in os.environ["TIMING_SHAPES"].split(",")]
 st = torch.cuda.current_stream().cuda_stream
 for name, H, W, Cin, Cout, k in SHAPES:
     x = planes(torch.randn(B, H, W, Cin, device="cuda")); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
@@ -66,8 +73,10 @@ for name, H, W, Cin, Cout, k in SHAPES:
                                          0, None, 1, bins.data_ptr(), None, None, st)
     if mode != "wgrad":
         names = {"  entry->epi loads": (1, 11), "  ->dma issued": (11, 12), "  ->row table": (12, 13), "  ->bn prologue": (13, 14), "  ->barrier": (14, 2), "  (probe build: 14 -> first barrier passed)": (14, 8), "  (probe build: -> constants done)": (8, 2),
+                 "  [14 -> barrier 1 passed]": (14, 16), "  [-> fill set-up]": (16, 17), "  [-> first loads issued]": (17, 18), "  [-> bins summed]": (18, 19), "  [-> barrier 2]": (19, 20),
+                 "  [-> finalize]": (20, 21), "  [-> barrier 3]": (21, 2), "  [fill: -> constants read]": (2, 22), "  [fill: -> trip 0 done]": (22, 23), "  [fill: -> rest]": (23, 3),
                  "prologue": (1, 2), "fill": (2, 3), "  k first half": (4, 8), "fill sync": (3, 4), "k-phase": (4, 5), "  epi: loads + barrier": (5, 10), "  epi: staging + barrier": (10, 9), "  epi: row pass": (9, 6), "epilogue": (5, 6), "stats": (6, 7), "total": (1, 7)}
-    tb = torch.zeros(1 << 16, 16, dtype=torch.int64, device="cuda")
+    tb = torch.zeros(1 << 16, 32, dtype=torch.int64, device="cuda")
     for it in range(3):
         lib.sar_dbg_set_timing_buffer16(None); torch.cuda.synchronize(); fn()
     torch.cuda.synchronize()
@@ -97,6 +106,8 @@ if mode == "wgrad":
     lib.sar_wgrad_plan_bf16.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp]
     lib.sar_conv2d_wgrad_batch_bf16.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, vp]
     for label, tile, target, layers in (("stages 1-3, 64x64 tiles", (2, 2), 640, [(50, 10, 64, 7), (25, 5, 128, 11), (13, 3, 256, 5)]),
+                                        ("stages 1-2, 64x64 tiles", (2, 2), 448, [(50, 10, 64, 7), (25, 5, 128, 11)]),
+                                        ("stage 3, 64x64 tiles", (2, 2), 192, [(13, 3, 256, 5)]),
                                         ("stage 0, 32x32 tiles", (1, 1), 768, [(100, 20, 32, 6)])):
         keep, descs = [], []
         for H, W, C, cnt in layers:
@@ -113,7 +124,7 @@ if mode == "wgrad":
         slab = torch.empty(max(l4[5] * l4[6], 1), device="cuda")
         cd = torch.frombuffer(bytearray(cbuf.raw), dtype=torch.uint8).cuda(); idv = torch.frombuffer(bytearray(ibuf.raw[:ni.value * 32]), dtype=torch.uint8).cuda()
         fn = lambda: lib.sar_conv2d_wgrad_batch_bf16(cd.data_ptr(), idv.data_ptr(), ni.value, 3, l4, td.data_ptr(), sd.data_ptr(), slab.data_ptr(), st)
-        tb = torch.zeros(1 << 14, 16, dtype=torch.int64, device="cuda")
+        tb = torch.zeros(1 << 14, 32, dtype=torch.int64, device="cuda")
         for it in range(3):
             lib.sar_dbg_set_timing_buffer16(None); torch.cuda.synchronize(); fn()
         torch.cuda.synchronize()
