@@ -27,6 +27,12 @@ def init_from_env(backend=None):
             backend = os.environ.get("SAR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
+            # CU budget of the collective (round 6).  The step's conv launches are one block per CU on all 256 CUs, so every CU an
+            # RCCL channel sits on sends that launch's displaced blocks into a second round: tools/cu_contention.py, cfg3 on one GPU -- the backward
+            # segment the 33.6 MB all-reduce hides under (507 us) is +8 % beside 8 channel-like workgroups, +20 % beside 16, +34 % beside 64.  Eight
+            # channels move the 59 MB a rank sends and receives in that all-reduce at 8 ranks in ~0.33 ms at 22 GB/s per channel: inside the segment.
+            # NCCL_MAX_NCHANNELS in the environment overrides; no N > 1 box was available to any round to confirm the choice on links.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         elif torch.cuda.is_available():              # gloo with GPU tensors (debug on a 1-GPU box): all ranks share a device
             local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
@@ -127,7 +133,9 @@ class DataParallel:
         pooling, GRUs), then the conv trunk from its end towards its start, cut at the parameters named in `trunk_splits`
         (ResNetTrunk.bucket_split_names(): stage 3, stage 2), the rest last."""
         self.store = store
-        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced())
+        # (SAR_DP_DISABLE=1: a replica that takes no part in any collective although a process group exists -- bench.py times the plain
+        # single-GPU step of the same box beside the data-parallel one)
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced()) and os.environ.get("SAR_DP_DISABLE", "0") != "1"
         self.world = dist.get_world_size() if self.enabled else 1
         self.rank = dist.get_rank() if self.enabled else 0
         split = store.n

@@ -245,7 +245,9 @@ def conv_roofline(model, B, iters=10, in_step=None):
         ach = c["flops"] / c["launches"] / t_launch / 1e12
         # which MFMA pipe the class runs on: 2-byte trunk = single-pass MFMA; split precision (the x3 trunk, or fp32 storage with Cout --
         # Cin for dgrad -- > 32): three bf16 MFMAs per product block; the rest of the fp32-storage kernels: fp32 MFMA
-        is_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad") and not name.endswith(", true>"))   # (", true>": A32 = the mixed backward's single-pass fp16 launches)
+        targs = name[name.index("<") + 1:name.rindex(">")].split(", ") if "<" in name else []
+        a32 = name.startswith("conv_bf16") and len(targs) > 6 and targs[6] == "true"               # template argument A32: the mixed backward's single-pass fp16 launches
+        is_x3 = (x3 and name.endswith("n64")) or (x3t and not name.startswith("wgrad") and not a32)
         peak = PEAK_BF16_MFMA_TFLOPS if (bf16 or is_x3) else PEAK_F32_MFMA_TFLOPS
         pipe = PEAK_BF16X3_TFLOPS if is_x3 else peak                                               # what the issued MFMAs could deliver algorithmically
         # bound of the class on this chip: time its algorithmic FLOPs need on the pipe vs its algorithmic bytes on HBM
@@ -283,6 +285,30 @@ def conv_roofline(model, B, iters=10, in_step=None):
     # the other classes that carry the conv time, largest first -- among them the 32-channel (stage 0) class, HBM-bound by SURVEY 8d
     ranked = sorted((matched if have_in_step else classes).items(), key=lambda kv: -(kv[1]["in_step_us"] * kv[1]["in_step_calls"] if have_in_step else kv[1]["time"]))
     class_list = [describe(k, c)[0] for k, c in ranked[:6]]
+    # The HBM-bound passes furthest below their roofline: the recompute-form stem's four passes and the weight gradients'
+    # reduction.  Algorithmic bytes = the tensors each pass has to read and write once; in-step time from the same live trace.
+    if bf16 and in_step:
+        st, (Hp_, Wp_) = tr.stem, tr.pool_hw
+        T_, D_ = tr.in_hw
+        n_in, n_pool = B * T_ * D_, B * Hp_ * Wp_ * st.cout
+        eb_p = 4 if x3t else 2                                                        # bytes per element of the pooled map (fp32 in split precision)
+        h16 = 2 * n_pool if x3t else 0                                                # + its fp16 copy (the first block's weight-gradient operand)
+        plans = [p_ for ps in getattr(tr, "_wgplans", {}).values() for p_ in ps]
+        red_bytes = sum(4 * p_.n_slabs * p_.slab_floats for p_ in plans) + sum(4 * w_[0]["dw"].numel() for w_ in wg)
+        extra = [("stem16_stats_kernel", 4 * n_in), ("stem16_pool_kernel", 4 * n_in + eb_p * n_pool + h16 + n_pool),
+                 ("stem16_bwd_reduce", 2 * n_pool + (2 if x3t else eb_p) * n_pool + n_pool), ("stem16_wgrad_kernel", 4 * n_in + 2 * n_pool + eb_p * n_pool + n_pool),
+                 ("wgrad_reduce_multi_kernel", red_bytes)]
+        for pat, nbytes in extra:
+            hit = [(k, v) for k, v in in_step.items() if pat in k]
+            if not hit or not nbytes:
+                continue
+            calls = sum(v[0] for _, v in hit); us = sum(v[0] * v[1] for _, v in hit) / calls
+            key = ("x3:" if x3t else "bf16:") + pat
+            traffic = pj[key]["traffic_bytes"] if key in pj else None
+            class_list.append(dict(bound="hbm", kernel=pat, achieved=round(nbytes / (us * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                   frac=round(nbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, rocprofv3)",
+                                   algorithmic_bytes=int(nbytes), traffic_over_algorithmic=round(traffic / nbytes, 2) if traffic else None,
+                                   launches_per_step=round(calls, 2), avg_launch_us=round(us, 2), us_per_step=round(calls * us, 1)))
     # T_roof of the 36 non-stem convs = 3 x (52.9 - 8.7) us per train step at B=64, T=400 (bf16 activations, 2.5 PFLOP/s,
     # 8 TB/s); scaled by this workload's conv FLOPs (1.2263 GFLOP/utt forward for those 36 layers)
     all_flops = sum(c["flops"] for c in classes.values())
@@ -444,9 +470,11 @@ DTYPES = {
                                        "Dense / GRU-projection GEMMs), fp32 accumulate, statistics, recurrence, losses and master weights"),
     "fp16": ("fp16", "bf16x3", "bf16", "fp16 activations / activation gradients of the conv trunk in HBM (static gradient scale), single-pass fp16 MFMA in the "
                                        "convs; bf16 MFMA in the Dense / GRU-projection GEMMs; fp32 accumulate, statistics, recurrence, losses and master weights"),
-    "bf16x3": ("bf16x3", "bf16x3", "bf16x3", "split precision on the 2-byte kernel architecture: fp32 trunk tensors in HBM, every conv operand a (hi, lo) pair of bf16 planes in LDS, three bf16 MFMAs per "
-                                           "product block (2^-17 relative per operand) in the convs and the Dense / GRU-projection GEMMs, fp32 accumulate, statistics, losses and master weights; "
-                                             "conv weight gradients and the GRU recurrence single-pass fp16"),
+    "bf16x3": ("bf16x3", "bf16x3", "bf16x3", "FORWARD: split precision on the 2-byte kernel architecture -- fp32 trunk tensors in HBM, every conv operand a (hi, lo) pair of bf16 planes in LDS, three bf16 "
+                                           "MFMAs per product block (2^-17 relative per operand) in the convs and the Dense / GRU-projection GEMMs, fp32 accumulate, statistics, losses and master weights.  "
+                                           "BACKWARD (since round 5): every activation gradient of the trunk is ONE fp16 tensor under the static scale 64 x batch; input-gradient convs, the Dense / "
+                                           "GRU-projection backward GEMMs, the conv / Dense weight gradients and the hidden_dim-256 GRU recurrence are single-pass fp16 MFMA, fp32 accumulate; a step whose "
+                                           "gradient is not finite is skipped by the optimiser (config.nonfinite_gradient_steps_skipped)"),
     "bf16x3_r1": ("fp32", "bf16x3", "fp32", "round 1's kernels: fp32 in HBM, three bf16 MFMAs per product block (2^-17 relative per product), fp32 accumulate"),
     "f32": ("fp32", "fp32", "fp32", "fp32 in HBM, fp32 MFMA"),
 }
@@ -503,8 +531,18 @@ def main():
                        # BASELINE configs[1] names bf16 for this workload and north_star bounds the outputs at 1e-3 of the reference's fp32 graph: the
                        # default is the mode that holds that bound (also.parity: ~5e-5); the single-pass bf16 / fp16 builds of the same kernels
                        # (2e-2 / 6e-3 off) are timed in the same run (also.cfg2_bf16, also.cfg2_fp16) and are one flag away
-                       "dtype_note": ("bf16x3 = bf16 operands in split precision (hi + lo planes, 3 MFMAs per product): the arithmetic that meets north_star's "
-                                      "1e-3; single-pass lines: also.cfg2_bf16, also.cfg2_fp16" if args.dtype == "bf16x3" and args.workload == "cfg2" else None)},
+                       # what the BACKWARD pass multiplies in (the line has to say what arithmetic was timed)
+                       "backward_arithmetic": ({"activation_gradients": "fp16 tensors x 64*batch (static scale, lowered by the overflow guard)",
+                                                "conv_input_gradients": "single-pass fp16 MFMA (sar_conv2d_f16a: fp16 gradient and weight fragments, fp32 forward tensors in the BatchNorm-backward fill)",
+                                                "conv_weight_gradients": "single-pass fp16 MFMA on fp16 copies of the activated operands and gradients",
+                                                "dense_gru_projection_backward": "single-pass fp16 MFMA under the same scale (per-utterance layers under 2^-6 of it)",
+                                                "gru_recurrence": "fp16 MFMA at hidden_dim 256", "stem_kernel_gradient": "single-pass fp16 MFMA",
+                                                "accumulation_statistics_optimizer": "fp32", "reference": "fp32 training (model.py:197)",
+                                                "flat_gradient_error_vs_exact_backward": "1.1e-3 rel. L2 (tools/grad_recipe_emulator.py); 7e-3 measured incl. ReLU flips of the 2^-17 forward"}
+                                               if args.dtype == "bf16x3" else None),
+                       "dtype_note": ("bf16x3 = the FORWARD pass in split precision (bf16 hi + lo planes, 3 MFMAs per product): the arithmetic that meets north_star's 1e-3 on the outputs; the "
+                                      "BACKWARD pass single-pass fp16 under a gradient scale (config.backward_arithmetic); single-pass lines: also.cfg2_bf16, also.cfg2_fp16"
+                                      if args.dtype == "bf16x3" and args.workload == "cfg2" else None)},
         }
         if not args.no_roofline:
             res["roofline"] = conv_roofline(model, r["B"], in_step=r["in_step"])
@@ -547,7 +585,25 @@ def main():
                        "overlapped_allreduce_us_alone": round(t_ov, 1), "last_bucket_allreduce_us_alone": round(t_last, 1),
                        "backward_graph_under_it_us": round(t_g2, 1) if t_g2 else None,
                        "exposed_wait_us_estimate": round(max(0.0, t_ov - (t_g2 or 0.0)) + t_last, 1)}
+        # --gpus N means N ranks on the collective backend: anything else is not the run the line describes
+        if world > 1 and int(ones.item()) != args.gpus:
+            raise SystemExit("--gpus %d but the all-reduce of ones over backend %s returned %d" % (args.gpus, dist.get_backend(), int(ones.item())))
+        # ... and the SAME box's plain single-GPU step beside it (every rank times its own, no collective; the slowest is reported): what the N = 1 line of
+        # BENCH measures, so a reader of the N > 1 line alone sees what the data-parallel step costs over it
+        plain_ms = None
+        if world > 1 and dp_info is not None and os.environ.get("SAR_BENCH_PLAIN_REF", "1") == "1":
+            os.environ["SAR_DP_DISABLE"] = "1"
+            try:
+                rp, mp = run_workload(args.workload, args, rank, 1, False)
+            finally:
+                del os.environ["SAR_DP_DISABLE"]
+            tp = torch.tensor([rp["ms_per_step"]], device="cuda"); dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            plain_ms = round(float(tp.item()), 4)
+            del mp
         if rank == 0:
+            if dp_info is not None and plain_ms is not None:
+                dp_info["plain_single_gpu_step_ms_same_run"] = plain_ms
+                dp_info["data_parallel_step_over_plain"] = round(res["ms_per_step"] / plain_ms, 4)
             res["config"]["data_parallel"] = dp_info
             res["config"]["collective_backend"] = dist.get_backend()
             res["config"]["grad_bucket_dtype"] = os.environ.get("SAR_DP_GRAD_DTYPE", "fp32")     # bf16: half the bytes on the links (parallel.DataParallel)

@@ -66,6 +66,14 @@ CASES = [(i, m) for i in range(len(SWEEP)) for m in ("fp32", "bf16x3_r1")] + \
         [(i, "x3") for i in range(len(SWEEP)) if SWEEP[i]["res_filters"] in (32, 64)]
 
 
+# the shipped (split-precision) mode's gradient bounds (round 6; 3e-2 on the flat vector alone until then).  Measured over the sweep's 17 shapes in
+# that mode (gpurun, r6): flat vector 9e-4 .. 1.24e-2 (the largest at 4 x 3 stage-3 pixels per utterance, B = 3), worst tensor -- max-abs error relative
+# to the tensor's largest element -- 1e-3 .. 0.20: at these sizes (tensors of six rows, B <= 9) flipped ReLU / max-pool decisions move up to twenty
+# tensors by percents, so the per-tensor view is a ceiling on the WORST tensor here (the "at most three tensors" rule of the exact-fp32 arm holds at
+# the golden / whole-graph sizes: tests/test_gpu_golden.py, tests/test_gpu_model.py)
+X3_FLAT, X3_WORST = 2e-2, 0.4
+
+
 @pytest.mark.parametrize("i,mode_name", CASES, ids=["%d-%s" % c for c in CASES])
 def test_config_sweep(i, mode_name):
     from tests._modes import mode
@@ -110,20 +118,28 @@ def _config_sweep(i, conv_math):
     # (B = 1: the 2-D BatchNorms AR_BN1 / AR_BN2 see a batch of one -- their output is beta, every gradient in front of them is zero up to
     # rounding, in the oracle and on the device: compared against the scale of the parameters' own gradients behind them, not against ~0)
     floor = 1e-12 * max(float(np.abs(v).max()) for v in ref_g.values()) ** 2 * len(ref_g)
-    assert num ** 0.5 <= {"fp32": 2e-3, "bf16x3_r1": 1e-2, "x3": 3e-2}[conv_math] * max(den, floor) ** 0.5, (i, conv_math, (num / max(den, floor)) ** 0.5)
-    if conv_math == "fp32":
+    # (round 6, VERDICT r5 item 6: the shipped mode's flat bound is 2 x the worst measured -- 3e-2 until then, under which a backward regression of 3 x passed)
+    assert num ** 0.5 <= {"fp32": 2e-3, "bf16x3_r1": 1e-2, "x3": X3_FLAT}[conv_math] * max(den, floor) ** 0.5, (i, conv_math, (num / max(den, floor)) ** 0.5)
+    if conv_math in ("fp32", "x3"):
+        # per tensor.  fp32: 5e-3, at most three tensors over it (ONE flipped ReLU / max-pool decision moves a six-row tensor's gradient by percents), none
+        # by more than 0.1; the shipped mode: no tensor over X3_WORST (above)
+        x3m = conv_math == "x3"
+        tol, flip = (5e-3, 0.1) if not x3m else (X3_WORST, X3_WORST)
         med = float(np.median([np.abs(v).max() for v in ref_g.values()]))
-        bad = []
+        bad, worst = [], 0.0
         for r in model.store.refs:
             g = r.g.cpu().numpy(); gr = ref_g[r.name]
             if np.abs(gr).max() < 1e-9 * med:
-                if not np.abs(g).max() < 1e-4 * med:
+                # (the shipped mode: a structurally zero bias gradient is a column sum of the fp16 copy of a gradient tensor whose exact sums cancel)
+                if not np.abs(g).max() < (2e-2 if x3m else 1e-4) * med:
                     bad.append((r.name, "zero-grad tensor", 1.0))
                 continue
             e = np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-3 * med, 1e-30)
-            if not e < 5e-3:
+            worst = max(worst, float(e))
+            if not e < tol:
                 bad.append((r.name, float(e), float(np.abs(gr).max())))
-        assert len(bad) <= 3 and all(b[1] != "zero-grad tensor" and b[1] < 0.1 for b in bad), (i, med, bad[:10])
+        print("sweep %d %s: worst tensor max-abs rel. %.3e, %d over %.0e" % (i, conv_math, worst, len(bad), tol))
+        assert len(bad) <= (0 if x3m else 3) and all(b[1] != "zero-grad tensor" and b[1] < flip for b in bad), (i, med, bad[:10])
     # the update: Keras-Adam (float64 restatement) applied to the device gradients
     for r in model.store.refs:
         g = r.g.cpu().double().numpy() + 2 * r.l2 * p0[r.name]

@@ -71,15 +71,19 @@ def make_pool(seed=int(os.environ.get("CONV_SEED", 2026))):
     return pool
 
 
-def train(mode, pool, weights=None, steps=STEPS):
+SKIPPED = {}                                                           # (mode, hidden_dim) -> optimiser steps the overflow guard skipped in that run
+
+
+def train(mode, pool, weights=None, steps=STEPS, hidden=None):
     from aesrc2020_amd import _lib
     from aesrc2020_amd.model import SAR_Net
     trunk, conv, gemm = MODES[mode]
     _lib.set_trunk_dtype(trunk); _lib.set_conv_math(conv); _lib.set_gemm_math(gemm)
+    kw = dict(KW, hidden_dim=hidden) if hidden else KW
     try:
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
-            model, tm = SAR_Net(seed=11, **KW)
+            model, tm = SAR_Net(seed=11, **kw)
         if weights is not None:
             model.set_weights_dict(weights)
         w0 = model.get_weights_dict()
@@ -87,6 +91,7 @@ def train(mode, pool, weights=None, steps=STEPS):
         for i in range(steps):
             logs = tm.train_on_batch(pool[i % len(pool)], pool[i % len(pool)])
             loss.append(logs["loss"]); acc.append(logs["y_accent_acc"])
+        SKIPPED[(mode, kw["hidden_dim"])] = model.store.skipped_steps()
     finally:
         _lib.set_trunk_dtype("fp32"); _lib.set_conv_math("bf16x3"); _lib.set_gemm_math("fp32")
     return np.asarray(loss), np.asarray(acc), w0
@@ -127,6 +132,30 @@ def test_two_byte_training_tracks_the_fp32_class_run(curves, mode):
     assert rel.max() < BAND_LOSS and rel[-1] < BAND_FINAL, (mode, np.round(rel, 3))
     da = abs(curves[mode][1][-50:].mean() - curves["bf16x3"][1][-50:].mean())
     assert da < BAND_ACC, (mode, da)
+
+
+# hidden_dim 256 (round 6): the width the reference ships (model.py:204) and the only one where the default mode runs the fp16 MFMA
+# recurrence (csrc/gru_mfma.hip) and the width-256 single-pass fp16 backward GEMMs under the gradient scale -- at hidden_dim 64 above neither sees an
+# optimiser step.  The same task and pool, the fp32-class reference run against the package default, from the same initial weights; the default run must
+# also finish without ONE step skipped by the overflow guard (a skipped step is a semantic difference to the reference's fp32 training, model.py:197).
+@pytest.fixture(scope="module")
+def curves256():
+    pool = make_pool()
+    ref_loss, ref_acc, w0 = train("bf16x3", pool, hidden=256)
+    l, a, _ = train("x3", pool, weights=w0, hidden=256)
+    return {"bf16x3": (ref_loss, ref_acc), "x3": (l, a)}
+
+
+def test_default_mode_at_hidden_dim_256_tracks_the_reference_and_skips_no_step(curves256):
+    for mode, (loss, acc) in curves256.items():
+        s = smooth(loss)
+        assert np.all(np.isfinite(loss)) and s[-1] < 0.1 * s[0] and acc[-50:].mean() > 0.9, (mode, s[0], s[-1], acc[-50:].mean())
+    ref, got = smooth(curves256["bf16x3"][0]), smooth(curves256["x3"][0])
+    rel = np.abs(got - ref) / ref
+    print("x3 at hidden_dim 256: relative distance of the smoothed loss to the bf16x3 run per window: %s; skipped steps %r" % (np.round(rel, 3), SKIPPED))
+    assert rel.max() < BAND_LOSS and rel[-1] < BAND_FINAL, np.round(rel, 3)
+    assert abs(curves256["x3"][1][-50:].mean() - curves256["bf16x3"][1][-50:].mean()) < BAND_ACC
+    assert SKIPPED[("x3", 256)] == 0, SKIPPED
 
 
 if __name__ == "__main__":

@@ -77,6 +77,9 @@ def conv_math(request):
 # tools/x3_grad_diag.py: the SAME tensors move by the same 9e-2 .. 1.7e-1 of their max in round 1's split-precision kernels at this width, exact
 # fp32 convs stay at 2e-5 -- so the per-tensor max-abs bound is meaningless here; held instead, as in tests/test_gpu_bf16_model.py: per-tensor
 # cosine >= 0.998 (measured >= 0.9990) and the flat gradient within 5e-2 in L2 (measured 9e-4 .. 2.8e-2).
+X3_TENSOR, X3_FLIP = 5e-2, 0.3                    # the default mode's per-tensor gradient bounds (see _forward_backward_parity)
+
+
 @pytest.mark.parametrize("mode_name,gtol", [("fp32", 2e-3), ("bf16x3_r1", 5e-3), ("x3", None)])
 @pytest.mark.parametrize("case", list(CASES))
 def test_forward_backward_parity(case, mode_name, gtol):
@@ -105,7 +108,7 @@ def _forward_backward_parity(case, cfg, ref, model, batch, gtol):
     # max(|g_ref|_max, 1e-3 * median tensor scale) to keep fp32 noise on such tensors from dominating.
     ref_g = {r.name: G[r.name].numpy() - (2 * MT.L2 * ref.P[r.name].numpy() if r.name in ref.reg else 0.0) for r in model.store.refs}
     med = float(np.median([np.abs(v).max() for v in ref_g.values()]))
-    bad = []; worst = (0.0, ""); wcos = (1.0, "")
+    bad = []; worst = (0.0, ""); wcos = (1.0, ""); errs = []
     big = max(float(np.linalg.norm(v)) for v in ref_g.values())
     for r in model.store.refs:
         g = r.g.cpu().numpy(); gr = ref_g[r.name]
@@ -116,7 +119,7 @@ def _forward_backward_parity(case, cfg, ref, model, batch, gtol):
                 bad.append((r.name, "zero-grad tensor", float(np.abs(g).max())))
             continue
         e = np.abs(g - gr).max() / max(np.abs(gr).max(), 1e-3 * med)
-        worst = max(worst, (float(e), r.name))
+        worst = max(worst, (float(e), r.name)); errs.append((float(e), r.name))
         if gtol is None:                             # the package default mode: cosine per tensor (see above)
             if float(np.linalg.norm(gr)) < 1e-3 * big:
                 continue
@@ -131,6 +134,10 @@ def _forward_backward_parity(case, cfg, ref, model, batch, gtol):
     l2 = float(np.linalg.norm(flat - flat_ref) / np.linalg.norm(flat_ref))
     print("%s: worst gradient tensor %.2e (%s), lowest cosine %.5f (%s), flat gradient rel. L2 %.2e" % (case, worst[0], worst[1], wcos[0], wcos[1], l2))
     assert not bad, (case, med, bad[:12])
+    if gtol is None:
+        # next to the cosine (round 6): the per-tensor max-abs error -- at most three flip-dominated tensors over X3_TENSOR, none over X3_FLIP
+        over = sorted(((e_, n_) for e_, n_ in errs if e_ >= X3_TENSOR), reverse=True)
+        assert len(over) <= 3 and all(e_ < X3_FLIP for e_, _ in over), (case, over)
     assert l2 < (5e-2 if gtol is None else 3e-2), (case, l2)        # (measured in the default mode: 9e-4 .. 2.8e-2 -- the largest at 9 stage-3 pixels per utterance, B = 3)
     # L2 flags agree with the oracle's regulariser set
     assert set(r.name for r in model.store.refs if r.l2 > 0) == set(ref.reg)
