@@ -229,9 +229,14 @@ template <int W> __device__ __forceinline__ void st_out(void* dst, const unsigne
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
 #if SAR_ST_WT >= 1
+    // (round 6: the 16-byte form carries its own wait states.  A VMEM store of more than 64 bits must not be followed at once by a VALU write of its
+    // data registers; hipcc's hazard recognizer pads its OWN stores and cannot see into an asm statement.  That -- not a cache effect -- was round 5's
+    // "write-through anomaly" of the Adam sweep: `global_store_dwordx4 v[72:73], v[60:63], off sc1` straight in front of `v_pk_mul_f32 v[60:61], ...`,
+    // 12 of 64 lanes of every chunk wrong; tools/sc1_adam_repro.py.  None of this file's 156 such stores happened to be followed by one -- by register
+    // allocation, not by construction; tests/test_host_cpu.py now checks the rule on the built code.)
     if constexpr (W == 1) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(dst), "v"(v[0]) : "memory");
     else if constexpr (W == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst), "v"(u32x2_{v[0], v[1]}) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(u32x4_{v[0], v[1], v[2], v[3]}) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(u32x4_{v[0], v[1], v[2], v[3]}) : "memory");
 #else
     if constexpr (W == 1) __builtin_nontemporal_store(v[0], reinterpret_cast<unsigned*>(dst));
     else if constexpr (W == 2) __builtin_nontemporal_store(u32x2_{v[0], v[1]}, reinterpret_cast<u32x2_*>(dst));
@@ -241,7 +246,7 @@ template <int W> __device__ __forceinline__ void st_out(void* dst, const unsigne
 __device__ __forceinline__ void nt_store16(u16* dst, const uint4 v) {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #if SAR_ST_WT >= 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(u32x4{v.x, v.y, v.z, v.w}) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(u32x4{v.x, v.y, v.z, v.w}) : "memory");
 #else
     __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(dst));
 #endif

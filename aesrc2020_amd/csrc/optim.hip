@@ -5,6 +5,10 @@
 // the launch can be replayed from a HIP graph.
 #include "common.h"
 
+#ifndef SAR_ADAM_WT
+#define SAR_ADAM_WT 0
+#endif
+
 struct SarAdamState {      // mirrored by aesrc2020_amd/_lib.py (8 x 4 bytes)
     float lr, decay, beta1, beta2, eps, lr_t;
     int iterations;
@@ -63,7 +67,22 @@ __global__ __launch_bounds__(256) void adam_l2_kernel(float* __restrict__ p, con
         w.z = upd(w.z, gg.z, mm.z, vv.z, l2); w.w = upd(w.w, gg.w, mm.w, vv.w, l2);
         if (skip) return;                                           // (block-uniform: the l2 sum above is of the unchanged weights)
         const long i = c * 256 + lane * 4;
+#if SAR_ADAM_WT                                                      // write-through (sc1) stores of p, m, v
+        // SAR_ADAM_WT=1 (tools/sc1_adam_repro.py only, never in libsarnet_hip.so): round 5's form, a bare store in an asm statement -- wrong results, the
+        // "write-through anomaly" of DESIGN 5.000; 2: the same with the wait states a >64-bit VMEM store needs in front of a VALU write of its data
+        // registers -- hipcc's hazard recognizer inserts them for its own stores and cannot see into an asm statement
+#if SAR_ADAM_WT >= 2
+#define WT_TAIL "\n\ts_nop 1"
+#else
+#define WT_TAIL ""
+#endif
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" WT_TAIL :: "v"(m + i), "v"(f32x4{mm.x, mm.y, mm.z, mm.w}) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" WT_TAIL :: "v"(v + i), "v"(f32x4{vv.x, vv.y, vv.z, vv.w}) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" WT_TAIL :: "v"(p + i), "v"(f32x4{w.x, w.y, w.z, w.w}) : "memory");
+#undef WT_TAIL
+#else
         *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv; *reinterpret_cast<float4*>(p + i) = w;
+#endif
     };
     const long stride = (long)gridDim.x * 4;
     long c = (long)blockIdx.x * 4 + wv;

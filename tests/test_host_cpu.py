@@ -153,6 +153,14 @@ def test_hand_counted_vmcnt_kernels_use_no_scratch(build):
             assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
             assert int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)) == 0, name
     assert seen >= (20 if build == "x3" else 25)          # (the split-precision build has no weight-gradient kernels of its own)
+    # Round 6: a VMEM store of more than 64 bits needs wait states in front of a VALU write of its data registers.  hipcc pads its own stores; a store
+    # issued from an asm statement (the write-through `sc1` stores of the conv epilogue) has to carry them itself -- round 5's "write-through anomaly"
+    # of the Adam sweep was exactly this hazard (tools/sc1_adam_repro.py: 12 of 64 lanes of every chunk wrong), not a cache effect.  Every asm block of
+    # the built code that holds a 12- or 16-byte store must end in an s_nop.
+    blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", asm, flags=re.S)
+    wide = [b for b in blocks if re.search(r"global_store_dwordx[34]\b", b)]
+    assert (len(wide) >= 100) == (build == "x3"), len(wide)   # (the 2-byte builds store 8 bytes a thread; the split-precision build 16)
+    assert all(re.search(r"s_nop\s+[1-9]", b) for b in wide), [b for b in wide if not re.search(r"s_nop\s+[1-9]", b)][:3]
 
 
 def test_data_loader_batch_contract(monkeypatch):

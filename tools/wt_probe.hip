@@ -2,6 +2,9 @@
 // R: every block reads the buffer (plain loads, warms its CU's L1 / its XCD's L2) and writes a checksum; W: rewrites the buffer with value k by
 // plain | nt | sc1 stores, from the SAME or from OTHER blocks than those that read it; R again: does it see k everywhere?
 //   hipcc --offload-arch=gfx950 -O3 tools/wt_probe.hip -o tools/wt_probe && tools/wt_probe
+// (Round 6: the one failure that motivated this probe -- the Adam sweep with sc1 stores, DESIGN 5.000 -- was NOT a visibility effect, which is why none
+// of these 72 patterns shows it: an asm-issued 16-byte store followed at once by a VALU write of its data registers, a wait-state hazard hipcc pads only
+// for its own stores.  tools/sc1_adam_repro.py reproduces and bisects it; the conv epilogue's stores carry `s_nop 1` since.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
