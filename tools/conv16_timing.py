@@ -42,6 +42,7 @@ SHAPES = [("s0 3x3 32->32", 100, 20, 32, 32, 3), ("s1 3x3 64->64", 50, 10, 64, 6
 if os.environ.get("TIMING_SHAPES"):                             # e.g. TIMING_SHAPES=s2,s3
     SHAPES = [s for s in SHAPES if s[0].split()[0] in os.environ["TIMING_SHAPES"].split(",")]
 st = torch.cuda.current_stream().cuda_stream
+cur = lambda: torch.cuda.current_stream().cuda_stream           # (inside a graph capture the launches go to the capturing stream)
 for name, H, W, Cin, Cout, k in SHAPES:
     x = planes(torch.randn(B, H, W, Cin, device="cuda")); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
     y = torch.zeros(B, H, W, Cout, device="cuda", dtype=torch.float32 if X3 else BF); dw = torch.zeros_like(w)
@@ -66,11 +67,11 @@ for name, H, W, Cin, Cout, k in SHAPES:
         bn = BN(gam.data_ptr(), bet.data_ptr(), fbins.data_ptr(), None, saved.data_ptr(), None, None, None, None, 1.0 / n, 1.0, 1e-3, 0.99, 0, 1.0, 0, 0)
         keepalive = (gam, bet, saved, fbins, res, side, bn)
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wf.data_ptr(), None, res.data_ptr(), y.data_ptr(), side.data_ptr(), B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
-                                         1, ctypes.byref(bn), 1, bins.data_ptr(), None, None, st)
+                                         1, ctypes.byref(bn), 1, bins.data_ptr(), None, None, cur())
     else:
         wp = wf if mode == "fwd" else wd
         fn = lambda: lib.sar_conv2d_bf16(x.data_ptr(), None, None, wp.data_ptr(), None, None, y.data_ptr(), None, B, H, W, Cin, H, W, Cout, k, 1, 1, 1, 1,
-                                         0, None, 1, bins.data_ptr(), None, None, st)
+                                         0, None, 1, bins.data_ptr(), None, None, cur())
     if mode != "wgrad":
         names = {"  entry->epi loads": (1, 11), "  ->dma issued": (11, 12), "  ->row table": (12, 13), "  ->bn prologue": (13, 14), "  ->barrier": (14, 2), "  (probe build: 14 -> first barrier passed)": (14, 8), "  (probe build: -> constants done)": (8, 2),
                  "  [14 -> barrier 1 passed]": (14, 16), "  [-> fill set-up]": (16, 17), "  [-> first loads issued]": (17, 18), "  [-> bins summed]": (18, 19), "  [-> barrier 2]": (19, 20),
@@ -80,6 +81,16 @@ for name, H, W, Cin, Cout, k in SHAPES:
     for it in range(3):
         lib.sar_dbg_set_timing_buffer16(None); torch.cuda.synchronize(); fn()
     torch.cuda.synchronize()
+    if os.environ.get("TIMING_NOSTAMP"):                          # launch time without the stamps' own cost: 20 launches in a captured graph, as the step runs them
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                fn()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        print("== %s %s B=%d: %.2f us per launch (20 launches in one graph, no stamps)" % (mode, name, B, e0.elapsed_time(e1) * 1e3 / 20))
+        continue
     lib.sar_dbg_set_timing_buffer16(tb.data_ptr()); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); rc = fn(); e1.record(); torch.cuda.synchronize()

@@ -30,6 +30,11 @@ for k, d in vals.items():
     if m and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
         out[prefix + m.group(1)] = {"source": src, "kernel": m.group(1), "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}
+    # (round 6) the HBM-bound passes bench.py lists beside the conv classes: the stem's four passes and the weight gradients' reduction, keyed as bench.py names them
+    m = re.search(r"(stem16_stats_kernel|stem16_pool_kernel|stem16_bwd_reduce|stem16_wgrad_kernel|wgrad_reduce_multi_kernel)", k)
+    if m and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
+        out[prefix + m.group(1)] = {"source": src, "kernel": m.group(1), "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}
 for kname, cls in CLASS:
     for k, d in vals.items():
         if kname in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
