@@ -90,7 +90,7 @@ def conv_plan_workspace(sfx):
     if mb <= 0 or "sar_conv_plan_workspace_" + sfx not in lib().fn:          # (absent: an older build under SAR_LIB_PATH)
         _PLAN_WS[sfx] = None
         return
-    buf = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+    buf = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")            # on the process's current device: one process per GPU (parallel.py)
     if lib().fn["sar_conv_plan_workspace_" + sfx](buf.data_ptr(), buf.numel()) != 0:
         raise RuntimeError("sar_conv_plan_workspace_%s failed" % sfx)
     _PLAN_WS[sfx] = buf
