@@ -218,7 +218,8 @@ int sar_conv2d_pair_bf16(const sarConvArgs* a, const sarConvArgs* b, sarStream_t
  * with three loads at kernel entry.  The library does not allocate: the caller lends `buf` (device memory, 256-byte aligned, `bytes` long; ~100 KB
  * per conv shape at B = 64, a few MB per model) until the next call of this function or the end of the process -- captured graphs keep pointers
  * into it.  Without a workspace, or once it is full, launches run the instantiations that derive everything themselves (results identical).
- * buf = NULL, bytes = 0 detaches.  One per build of the trunk kernels (…_f16: sar_conv2d_f16 / _f16a; …_x3: sar_conv2d_x3).  Not thread-safe. */
+ * The tables of a shape are complete when the launch that first met the shape has run: launches of that shape on OTHER streams must be ordered behind
+ * it (the package runs every conv of a model on one stream).  buf = NULL, bytes = 0 detaches.  One per build of the trunk kernels (…_f16: sar_conv2d_f16 / _f16a; …_x3: sar_conv2d_x3).  Not thread-safe. */
 int sar_conv_plan_workspace_bf16(void* buf, long bytes);
 int sar_conv_plan_workspace_f16(void* buf, long bytes);
 int sar_conv_plan_workspace_x3(void* buf, long bytes);
