@@ -687,8 +687,264 @@ __global__ __launch_bounds__(256, 2) void stem16_wgrad_kernel(const float* __res
     TSTAMP(4); TSTAMP(15);
 }
 
+constexpr int WS_SLICES = 8;    // slices of the blocks' parts in the kernel gradient's final sum (stem16_wsum_kernel / stem16_wfin_kernel)
+
+// ---------------------------------------------------------------------------------------------------- backward pass 2, second form (round 6)
+// The kernel gradient WITHOUT recomputing the conv.  With P = the im2col rows of the conv pixels (64 taps, ky*8 + kx), dz = the scattered pooled
+// gradient and dy = A*dz + E*acc + F (above), acc = P w:
+//     dW = P^T dy = A (.) (P^T dz) + E (.) ((P^T P) w) + (P^T 1) (x) F
+// -- the dense part of dy is a fixed linear map of P, so its product with P^T is a product with the 64 x 64 GRAM matrix G = P^T P of the input's
+// patches, which no channel, no gradient and no BatchNorm constant enters.  stem16_wgrad_kernel spent its m-tiles on exactly that dense part: per
+// 32-pixel block and 32-channel pass twelve MFMAs to recompute acc (split precision), sixteen FMAs per lane to form dy, an image write -- to multiply
+// a term that is known in closed form.  Here a block accumulates T = P^T dz (the dz image feeds the MFMA as it lies: its transposed reads ARE the B
+// fragments) and G (its A fragments are its B fragments: three MFMAs per 16 pixels, no further LDS read), with P^T 1 riding along as column 7 of G (tap
+// ky = 0, kx = 7 is a zero row of the kernel: the image carries 1.0 there); stem16_wfin_kernel then forms A (.) T + E (.) (G w) + G[:, 7] (x) F per slice of
+// the blocks -- the map is linear, so slices add.  No kernel fragments, no BatchNorm constants, one patch plane, ONE scatter for all channels per tile.
+// The products are single-pass on the same 2-byte operands as before (P and dz), the rest fp32: dy is no longer rounded to 2 bytes, G sums 5e5 products.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void stem16_wgrad2_kernel(const float* __restrict__ x, const u16* __restrict__ gp, const u16* __restrict__ pooled,
+                                                               const uint8_t* __restrict__ idx, int* __restrict__ counter, float* __restrict__ part,
+                                                               const StemG g, int ntiles, int dz_bytes) {
+    constexpr int C0 = NT * 32, DZ2 = C0 * 2 + 8, CG = C0 / 8, LCG = NT == 2 ? 3 : 2;   // dz image: bytes per pixel row, channel groups of eight
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u16* patch = reinterpret_cast<u16*>(smem);                                       // ONE plane of the weight gradient's 2-byte type, [row][pld]
+    unsigned char* dz = smem + g.patch_bytes;                                        // [pixel, rounded up to 32][DZ2]
+    unsigned char* scr0 = dz + dz_bytes + 256;                                       // [4 waves][2 planes]: the im2col image of a 32-pixel block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, q = lane & 31;
+    unsigned char* scr = scr0 + wave * 2 * PLANE;
+    f32x16 accw[2][NT], accg[3];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) accw[tp][ct][r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) accg[k][r] = 0.f;
+    }
+    const int gi = lane & 15, gg = lane >> 4, cb = gg & 1, kh2 = gg >> 1;
+    const unsigned colb = (16 * cb + 4 * (gi & 3)) * 2, prb = 8 * kh2 + (gi >> 2);
+    const unsigned one16 = (unsigned)__builtin_bit_cast(unsigned short, (w16)1.f) << 16;   // 1.0 in the high half of a pair
+    for (int i = tid * 16; i < dz_bytes; i += 256 * 16) *reinterpret_cast<uint4*>(dz + i) = make_uint4(0u, 0u, 0u, 0u);
+    // Tiles are dealt statically, tile = block + k * blocks: with ~3 tiles per block a ticket balances nothing a static deal does not (round 3: drawing
+    // the next ticket early cost balance), and a block that knows its next tile requests that tile's operands -- the input rows, the pooled windows'
+    // gradient, positivity and slots -- BEFORE it multiplies the current one: the round trip that stood in front of every tile runs under the m-tiles.
+    struct TG { int n, r0, nr, npix, i_lo, nitems; };
+    auto geo = [&](int tile) __attribute__((always_inline)) {
+        TG t;
+        t.n = tile / g.tiles; const int tr = tile % g.tiles;
+        t.r0 = tr * g.TR; t.nr = min(g.TR, g.Ho - t.r0); t.npix = t.nr * g.Wo;
+        t.i_lo = max((t.r0 + g.ppt - 1) >> 1, 0);
+        const int i_hi = min((t.r0 + t.nr - 1 + g.ppt) >> 1, g.Hp - 1);
+        t.nitems = (i_hi - t.i_lo + 1) * g.Wp * CG;                                  // (window, eight channels)
+        return t;
+    };
+    // which of eight pooled values are positive (>= 0 always: non-zero magnitude bits), one bit each; SAR_X3: `pooled` is the fp32 map
+    auto pmask_at = [&](size_t o) __attribute__((always_inline)) -> unsigned {
+        unsigned m = 0u;
+        if constexpr (X3) {
+            const uint4 a = ld16f(pooled, o), b = ld16f(pooled, o + 4);
+            const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= ((w[k] & 0x7fffffffu) != 0u ? 1u : 0u) << k;
+        } else {
+            const uint4 a = *reinterpret_cast<const uint4*>(pooled + o);
+            const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= ((((w[k >> 1] >> (16 * (k & 1))) & 0x7fffu) != 0u) ? 1u : 0u) << k;
+        }
+        return m;
+    };
+    auto item_off = [&](const TG& t, int it) __attribute__((always_inline)) -> size_t {
+        return (((size_t)t.n * g.Hp + t.i_lo) * g.Wp + (it >> LCG)) * C0 + (it & (CG - 1)) * 8;
+    };
+    constexpr int SU = NT == 2 ? 3 : 2;                                              // items per thread held in registers (a tile of eight rows: ~800 / ~400 items)
+    XStage<6> xs; unsigned pm[SU]; uint4 gv[SU]; uint2 iv[SU];
+    auto request = [&](const TG& t) __attribute__((always_inline)) {
+        stem_x_load<6>(xs, x, g, t.n, 2 * t.r0 - g.pt, 2 * (t.nr - 1) + 8, tid);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const size_t o = item_off(t, min(tid + 256 * u, t.nitems - 1));
+            pm[u] = pmask_at(o); gv[u] = *reinterpret_cast<const uint4*>(gp + o); iv[u] = *reinterpret_cast<const uint2*>(idx + o);
+        }
+    };
+    int tile = blockIdx.x;
+    TG t = geo(min(tile, ntiles - 1));
+    if (tile < ntiles) request(t);
+    while (tile < ntiles) {
+        const int n = t.n, r0 = t.r0, nr = t.nr, npix = t.npix, i_lo = t.i_lo, nitems = t.nitems;
+        (void)n;
+        __syncthreads();                                                             // the previous tile's readers are done, its dz entries cleared
+        // ---- stage: the scatter's LDS adds, the patch's stores (their operands were requested a tile ago)
+        {
+            auto add_item = [&](int it, unsigned pmk, const uint4 gvv, const uint2 ivv) __attribute__((always_inline)) {
+                const int cg = it & (CG - 1), pp = it >> LCG;
+                const int wi = (int)udiv((unsigned)pp, g.mg_wp, (unsigned)g.Wp), wj = pp - wi * g.Wp;
+                const int rb = 2 * (i_lo + wi) - g.ppt - r0, cbase = 2 * wj - g.ppl;
+                const unsigned gw[4] = {gvv.x, gvv.y, gvv.z, gvv.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned sh = 16 * (k & 1), gz = (gw[k >> 1] >> sh) & 0xffffu;
+                    const int slot = ((k < 4 ? ivv.x : ivv.y) >> (8 * (k & 3))) & 255, kh = (slot * 11) >> 5, kw = slot - 3 * kh;
+                    const int r = rb + kh, c = cbase + kw;
+                    if (((pmk >> k) & 1u) != 0u && r >= 0 && r < nr)
+                        lds_pk_add_w(dz + (size_t)(r * g.Wo + c) * DZ2 + (cg * 8 + (k & ~1)) * 2, gz << sh);
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+                if (tid + 256 * u < nitems) add_item(tid + 256 * u, pm[u], gv[u], iv[u]);
+            for (int it = tid + 256 * SU; it < nitems; it += 256) {                  // wider inputs: one at a time
+                const size_t o = item_off(t, it);
+                add_item(it, pmask_at(o), *reinterpret_cast<const uint4*>(gp + o), *reinterpret_cast<const uint2*>(idx + o));
+            }
+            const int c = 2 * (tid & 63), nprow = 2 * (nr - 1) + 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int r = (tid >> 6) + 4 * i;
+                if (r < nprow && c < g.pld) *reinterpret_cast<unsigned*>(patch + r * g.pld + c) = wpack2(xs.v[i].x, xs.v[i].y);
+            }
+        }
+        __syncthreads();
+        tile += gridDim.x;
+        if (tile < ntiles) { t = geo(tile); request(t); }                            // the NEXT tile's operands, under this tile's m-tiles
+        // ---- 32-pixel blocks over the four waves
+        for (int mt = wave; mt * 32 < npix; mt += 4) {
+            const int p = mt * 32 + q;
+            const bool valid = p < npix;
+            const unsigned pc = (unsigned)min(p, npix - 1), ty = udiv(pc, g.mg_wo, (unsigned)g.Wo), tx = pc - ty * g.Wo;
+            // the lane's pixel's im2col row, taps (2s + h) * 8 .. + 8: plane (2s + h) / 4, 16 bytes at ((2s + h) % 4) * 16; tap 7 (ky = 0, kx = 7) carries 1.0
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const unsigned* qw = reinterpret_cast<const unsigned*>(patch + (2 * ty + h) * g.pld + 2 * tx + 2 * s2 * g.pld);
+                uint4 vw = make_uint4(qw[0], qw[1], qw[2], qw[3]);
+                if (s2 == 0 && h == 0) vw.w = (vw.w & 0xffffu) | one16;
+                *reinterpret_cast<uint4*>(scr + ((2 * s2 + h) >> 2) * PLANE + q * IP + ((2 * s2 + h) & 3) * 16) = valid ? vw : make_uint4(0u, 0u, 0u, 0u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the wave's own stores are in front of its own reads
+            unsigned char* dzb = dz + (size_t)(mt * 32) * DZ2;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned o0 = (16 * ks + prb) * IP + colb, o1 = o0 + 4 * IP;
+                const unsigned d0 = (16 * ks + prb) * DZ2 + colb, d1 = d0 + 4 * DZ2;
+                w16x8 Af[2], Bd[NT];
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp) {
+                    const s16x4 lo = lds_tr(scr + tp * PLANE, o0), hi = lds_tr(scr + tp * PLANE, o1);
+                    Af[tp] = __builtin_bit_cast(w16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) {
+                    const s16x4 lo = lds_tr(dzb + ct * 64, d0), hi = lds_tr(dzb + ct * 64, d1);
+                    Bd[ct] = __builtin_bit_cast(w16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // leave the image clean for the next tile's scatter: every 8-byte piece of the block's rows was read by exactly one lane
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) {
+                    *reinterpret_cast<uint2*>(dzb + ct * 64 + d0) = make_uint2(0u, 0u);
+                    *reinterpret_cast<uint2*>(dzb + ct * 64 + d1) = make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) accw[tp][ct] = MFMA16W(Af[tp], Bd[ct], accw[tp][ct], 0, 0, 0);
+                accg[0] = MFMA16W(Af[0], Af[0], accg[0], 0, 0, 0);
+                accg[1] = MFMA16W(Af[0], Af[1], accg[1], 0, 0, 0);
+                accg[2] = MFMA16W(Af[1], Af[1], accg[2], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // reads and clears done before the images are rewritten
+        }
+    }
+    // ---- merge the four waves' tiles in LDS (everything is dead), then coalesced stores: part[block] = {T [64][C0], G [64][64] (rows 32-63 x columns 0-31 unset)}
+    __syncthreads();
+    float* ot = reinterpret_cast<float*>(smem);                                      // [64][C0] | [64][64]
+    float* og = ot + 64 * C0;
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int ct = 0; ct < NT; ++ct) {
+                        const int row = tp * 32 + rr, col = ct * 32 + q;
+                        if (wv == 0) ot[row * C0 + col] = accw[tp][ct][r]; else ot[row * C0 + col] += accw[tp][ct][r];
+                    }
+                const int gr[3] = {rr, rr, 32 + rr}, gc[3] = {q, 32 + q, 32 + q};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { if (wv == 0) og[gr[k] * 64 + gc[k]] = accg[k][r]; else og[gr[k] * 64 + gc[k]] += accg[k][r]; }
+            }
+        }
+        __syncthreads();
+    }
+    float4* dst = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * (64 * C0 + 64 * 64));
+    for (int i = tid; i < (64 * C0 + 64 * 64) / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(ot)[i];
+}
+
+// dw[(ky*7 + kx)][c] += (A_c T[k][c] + E_c (G w)[k][c] + G[k][7] F_c) * ginv over one slice of the blocks' parts (the map is linear: slices add);
+// grid (49 taps, WS_SLICES).  A = scale, E = -scale c3 rstd, F = -scale (c2 + c3 (bias - mean) rstd) from the BatchNorm's backward sums (bn: saved +
+// bbins); block (0, 0) owns the BatchNorm's parameter gradients when bn.write, as stem16_wgrad_kernel's block 0 did.
+__global__ __launch_bounds__(256) void stem16_wfin_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          const BnP bn, float* __restrict__ dw, int C0, int* __restrict__ counter) {
+    __shared__ float cst[6 * 64], red[256], grow[64], gred[256];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *counter = 0;
+    const int t = blockIdx.x, row = (t / 7) * 8 + (t % 7), tid = threadIdx.x;
+    const int c = tid % C0, sl = tid / C0, nsl = 256 / C0;
+    const size_t ps = (size_t)64 * C0 + 64 * 64;
+    const int per = (nblk + WS_SLICES - 1) / WS_SLICES, b0 = blockIdx.y * per, b1 = min(b0 + per, nblk);
+    // every request of this block first -- the slice's parts of T[row][c] and G[row][k'], the kernel column of this thread's channel, then (inside
+    // bn_prologue) the BatchNorm's sums -- and only then the first use: the block is three round trips if they are taken one after the other
+    float tsum, gsum, wc[49];
+    {
+        float s0 = 0.f, s1 = 0.f;
+        int b = b0 + sl;
+        for (; b + 7 * nsl < b1; b += 8 * nsl) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + u * nsl) * ps + row * C0 + c];
+            s0 += (v[0] + v[1]) + (v[2] + v[3]); s1 += (v[4] + v[5]) + (v[6] + v[7]);
+        }
+        for (; b < b1; b += nsl) s0 += part[(size_t)b * ps + row * C0 + c];
+        tsum = s0 + s1;
+    }
+    {   // (the lower-left quadrant of G is the upper-right one transposed)
+        const int k2 = tid & 63, s4 = tid >> 6;
+        const bool tr = row >= 32 && k2 < 32;
+        const size_t go = (size_t)64 * C0 + (tr ? k2 * 64 + row : row * 64 + k2);
+        float s0 = 0.f, s1 = 0.f;
+        int b = b0 + s4;
+        for (; b + 28 < b1; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 4 * u) * ps + go];
+            s0 += (v[0] + v[1]) + (v[2] + v[3]); s1 += (v[4] + v[5]) + (v[6] + v[7]);
+        }
+        for (; b < b1; b += 4) s0 += part[(size_t)b * ps + go];
+        gsum = s0 + s1;
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 49; ++t2) wc[t2] = w[t2 * C0 + c];
+    bn_prologue(bn, 2, C0, 0, C0, cst, C0, blockIdx.x == 0 && blockIdx.y == 0, 256);
+    red[tid] = tsum; gred[tid] = gsum;
+    __syncthreads();
+    if (tid < 64) grow[tid] = (gred[tid] + gred[64 + tid]) + (gred[128 + tid] + gred[192 + tid]);
+    __syncthreads();
+    if (tid < C0) {
+        float T = 0.f;
+        for (int k = 0; k < nsl; ++k) T += red[k * C0 + c];
+        float gw = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 49; ++t2) gw = fmaf(grow[(t2 / 7) * 8 + (t2 % 7)], wc[t2], gw);
+        const float scale = cst[c], mean = cst[2 * C0 + c], rstd = cst[3 * C0 + c], c2 = cst[4 * C0 + c], c3 = cst[5 * C0 + c];
+        const float xb = (bias[c] - mean) * rstd, Cc = -scale * c3;
+        const float A = scale, E = Cc * rstd, F = -scale * c2 + Cc * xb;
+        atomicAdd(dw + t * C0 + c, (A * T + E * gw + grow[7] * F) * bn.ginv);
+    }
+}
+
 // dw[(ky*7 + kx)][c] += sum over blocks of part[block][ky*8 + kx][c]; grid (49 taps, WS_SLICES slices of the blocks)
-constexpr int WS_SLICES = 8;
 __global__ __launch_bounds__(256) void stem16_wsum_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw, int C0, int* __restrict__ counter, float ginv) {
     __shared__ float red[256];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *counter = 0;
@@ -836,7 +1092,7 @@ static int stem16_bwd_reduce_impl(const void* g_pooled, const void* pooled, cons
 }
 
 #if !SAR_HALF && !SAR_X3
-size_t sar_stem16_wgrad_workspace_bytes(int C0) { return 64 + (size_t)WG_MAX_BLOCKS * 64 * C0 * sizeof(float); }
+size_t sar_stem16_wgrad_workspace_bytes(int C0) { return 64 + (size_t)WG_MAX_BLOCKS * (64 * C0 + 64 * 64) * sizeof(float); }   // (round 6: + every block's share of the patches' Gram matrix)
 #endif
 
 // Backward pass 2: dw (7,7,1,C0) fp32 += kernel gradient.  bn: saved + bbins (after sar_stem16_bwd_reduce); the launch owns the
@@ -863,6 +1119,37 @@ int SAR_STEM(sar_stem16_wgrad)(const float* x, const float* w, const float* bias
     const int nblk = ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS;
     int* counter = reinterpret_cast<int*>(work);
     float* part = work + 16;
+    // The second form (round 6: stem16_wgrad2_kernel -- no conv recomputation, the dense part of dy through the patches' Gram matrix) where the patch
+    // fill has its fast form (D and the left padding even, a patch row of at most 128 elements: every configuration of the reference's 80-dim
+    // features); SAR_STEM_WG2=0 keeps the first form, for A/B runs.
+    static const int wg2 = env_int("SAR_STEM_WG2", 1);
+    if (wg2 && g.fast) {
+        int TR2 = env_int("SAR_STEM_WG_ROWS", 8); TR2 = TR2 < 1 ? 1 : (TR2 > Ho ? Ho : TR2);
+        if (2 * (TR2 - 1) + 8 > 24) TR2 = 9;                               // (the fast fill holds 24 patch rows)
+        StemG g2 = g;
+        stem_tiles(g2, TR2, Ho, TR2);
+        g2.patch_bytes = (g2.patch_bytes / (X3 ? 3 : 1) + 15) & ~15;        // ONE plane of the weight gradient's 2-byte type
+        const int DZ2 = C0 * 2 + 8;
+        const int dz2 = ((TR2 * Wo + 31) / 32 * 32 * DZ2 + 15) & ~15;
+        size_t lds2 = (size_t)g2.patch_bytes + dz2 + 256 + 4 * 2 * PLANE;
+        const size_t merge2 = (size_t)(64 * C0 + 64 * 64) * 4;
+        if (lds2 < merge2) lds2 = merge2;
+        if (lds2 <= 160 * 1024) {
+            const int ntiles2 = B * g2.tiles, nblk2 = ntiles2 < WG_MAX_BLOCKS ? ntiles2 : WG_MAX_BLOCKS;
+            if (C0 == 64) {
+                if (!allow_lds(stem16_wgrad2_kernel<2>, lds2)) return SAR_ELAUNCH;
+                hipLaunchKernelGGL(stem16_wgrad2_kernel<2>, dim3(nblk2), dim3(256), lds2, stream, x, static_cast<const u16*>(g_pooled), static_cast<const u16*>(pooled), idx,
+                                   counter, part, g2, ntiles2, dz2);
+            } else {
+                if (!allow_lds(stem16_wgrad2_kernel<1>, lds2)) return SAR_ELAUNCH;
+                hipLaunchKernelGGL(stem16_wgrad2_kernel<1>, dim3(nblk2), dim3(256), lds2, stream, x, static_cast<const u16*>(g_pooled), static_cast<const u16*>(pooled), idx,
+                                   counter, part, g2, ntiles2, dz2);
+            }
+            hipLaunchKernelGGL(stem16_wfin_kernel, dim3(49, WS_SLICES), dim3(256), 0, stream, part, nblk2, w, bias, *bn, dw, C0, counter);
+            SAR_CHECK_LAUNCH();
+            return SAR_OK;
+        }
+    }
     // SAR_X3 (round 5): g_pooled is the fp16 tensor the mixed backward's last input-gradient launches wrote, times the static scale 1 / bn->ginv,
     // exactly as in the fp16 build: the BatchNorm sums carry the scale, bn->ginv undoes it in dgamma / dbeta and (stem16_wsum) in dw
     sarBnRef bnk = *bn;
