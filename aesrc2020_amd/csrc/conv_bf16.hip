@@ -951,12 +951,14 @@ __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC) void conv
 // A launch inside the step costs ~4.5 us before it does anything, the shortcut launches are 7-20 us of mostly that, and the
 // 3x3 launches of the stages they sit in front of leave CUs idle.  Blocks [0, na) run the first convolution, the rest the second (1x1:
 // same WN / NKC / KG / WMX / BR, VT = channel parts of ONE tap); LDS and registers are the larger of the two.
-template <int WN, int NKC, int VT, int KG, int WMX, bool BR, bool A32 = false, bool PL = false>
+// (WMXB, round 6: the second convolution's pixel-tile class where it differs -- the stride-2 entry of the last stage runs 32-pixel tiles because its
+// patch does not fit otherwise, its 1x1 shortcut 64-pixel ones; BR forms only: the block size does not depend on WMX there.)
+template <int WN, int NKC, int VT, int KG, int WMX, bool BR, bool A32 = false, bool PL = false, int WMXB = WMX>
 __global__ __launch_bounds__(64 * (BR ? WN : WMX * WN) * KG, CONV_OCC)
 void conv_bf16_pair_kernel(const ConvP pa, const ConvP pb, const unsigned na, const unsigned ntya, const unsigned nb, const unsigned ntyb) {
     const unsigned na8 = (na + 7u) & ~7u;                             // the second convolution starts on XCD 0 as well (its XCD-aware tile order)
     if (blockIdx.x < na) conv_body<WN, NKC, VT, KG, WMX, BR, A32, PL>(pa, blockIdx.x, na, ntya);
-    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMX, BR, A32, PL>(pb, blockIdx.x - na8, nb, ntyb);
+    else if (blockIdx.x >= na8) conv_body<WN, NKC, (VT % 9 == 0 ? VT / 9 : VT), KG, WMXB, BR, A32, PL>(pb, blockIdx.x - na8, nb, ntyb);
 }
 
 // ---------------------------------------------------------------------------------------------------- weight gradient
@@ -1957,15 +1959,23 @@ static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act3
     }
     const int* ca = la.cls; const int* cb = lb.cls;
     // same WN, NKC, KG, WMX, BR and block size; a: nine taps, b: one
-    if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || ca[4] != cb[4] || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
+    // (or, BR forms: a on 32-pixel tiles, b on 64-pixel ones -- `mixed`)
+    const bool mixed = ca[5] && ca[4] == 1 && cb[4] == 2;
+    if (ca[0] != cb[0] || ca[1] != cb[1] || ca[3] != cb[3] || (ca[4] != cb[4] && !mixed) || ca[5] != cb[5] || la.nthr != lb.nthr || ca[2] != 9 * cb[2]) return SAR_EINVAL;
     typedef void (*pair_t)(const ConvP, const ConvP, unsigned, unsigned, unsigned, unsigned);
     pair_t kern = nullptr;
-    static PerDeviceFlag at[24];
+    static PerDeviceFlag at[28];
     int ki = -1;
     const bool a32 = act32 != 0, pl = la.p.pl_thr != nullptr && lb.p.pl_thr != nullptr;   // (both planned, or neither: one kernel runs both bodies)
     if (!pl) { la.p.pl_thr = nullptr; lb.p.pl_thr = nullptr; }
 #define PK(...) (pl ? (a32 ? conv_bf16_pair_kernel<__VA_ARGS__, A32V, true> : conv_bf16_pair_kernel<__VA_ARGS__, false, true>) \
                     : (a32 ? conv_bf16_pair_kernel<__VA_ARGS__, A32V, false> : conv_bf16_pair_kernel<__VA_ARGS__, false, false>))
+#define PKB(...) (pl ? (a32 ? conv_bf16_pair_kernel<__VA_ARGS__, A32V, true, 2> : conv_bf16_pair_kernel<__VA_ARGS__, false, true, 2>) \
+                     : (a32 ? conv_bf16_pair_kernel<__VA_ARGS__, A32V, false, 2> : conv_bf16_pair_kernel<__VA_ARGS__, false, false, 2>))
+    if (mixed) {
+        // the forward entry of the last stage at res_filters 32 (128 -> 256 channels, stride 2): 21.6 + 7.3 us as two launches
+        if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4) { kern = PKB(2, 8, 9, 4, 1, true); ki = 24 + (a32 ? 1 : 0) + (pl ? 2 : 0); }
+    } else
     if (ca[0] == 2 && ca[1] == 2 && ca[2] == 9 && ca[3] == 1 && ca[4] == 2 && !ca[5]) { kern = PK(2, 2, 9, 1, 2, false); ki = 0; }
     else if (ca[0] == 2 && ca[1] == 4 && ca[2] == 9 && ca[3] == 2 && ca[4] == 2 && ca[5]) { kern = PK(2, 4, 9, 2, 2, true); ki = 1; }
     else if (ca[0] == 2 && ca[1] == 8 && ca[2] == 9 && ca[3] == 4 && ca[4] == 2 && ca[5]) { kern = PK(2, 8, 9, 4, 2, true); ki = 2; }
@@ -1975,8 +1985,9 @@ static int conv2d_pair_impl(const sarConvArgs* a, const sarConvArgs* b, int act3
     // the first block's conv and its 1x1 shortcut both read the pooled map -- 30 + 14.6 us as two launches
     else if (ca[0] == 1 && ca[1] == 4 && ca[2] == 9 && ca[3] == 1 && ca[4] == 8 && !ca[5]) { kern = PK(1, 4, 9, 1, 8, false); ki = 5; }
 #undef PK
-    if (a32 && ki >= 0) ki += 6;
-    if (pl && ki >= 0) ki += 12;
+#undef PKB
+    if (a32 && ki >= 0 && ki < 24) ki += 6;
+    if (pl && ki >= 0 && ki < 24) ki += 12;                                         // (24-27: the mixed form carries its own)
     if (kern == nullptr) return SAR_EINVAL;
     if (!at[ki]) { if (!allow_lds(kern, 160 * 1024)) return SAR_ELAUNCH; at[ki] = true; }
     const unsigned na = la.grid.x * la.grid.y, nb = lb.grid.x * lb.grid.y, na8 = (na + 7u) & ~7u;

@@ -279,7 +279,13 @@ int sar_cast_bf16_f32(const void* x, float* y, long n, sarStream_t stream);
  *   backward: sar_stem16_bwd_reduce (the two BatchNorm-backward sums into bn->bbins, from g_pooled / pooled / idx alone; it also
  *             resets the tile counter at the head of `work`, the buffer sar_stem16_wgrad gets) ->
  *             sar_stem16_wgrad (dw += kernel gradient; owns dgamma / dbeta when bn->write; the bias gradient is exactly zero and
- *             not computed; work = sar_stem16_wgrad_workspace_bytes(C0) bytes of scratch).  No input gradient: first layer. */
+ *             not computed; work = sar_stem16_wgrad_workspace_bytes(C0) bytes of scratch).  No input gradient: first layer.
+ *             Round 6: the BatchNorm-backward gradient at the conv is dy = A (.) dz + E (.) z + F (dz = the pooled gradient scattered to
+ *             its maxima, z = P w the conv output, P = the im2col image, A / E / F per channel from the BatchNorm's sums), so
+ *             dW = P^T dy = A (.) (P^T dz) + E (.) ((P^T P) w) + (P^T 1) (x) F: one pass builds P^T dz and the 64 x 64 Gram matrix P^T P per
+ *             tile on MFMA WITHOUT recomputing the conv (tap 7 of the 8 x 8 tap grid is a zero kernel row and carries 1.0, so P^T 1 is a
+ *             Gram column); a finisher sums the per-block parts and applies A, E, F.  work holds the per-block parts:
+ *             64 + 512 * (64*C0 + 64*64) * 4 bytes.  SAR_STEM_WG2=0 selects the round-5 recompute form. */
 int sar_stem16_stats(const float* x, const float* w, const float* bias, float* bins, int B, int T, int D, int Ho, int Wo, int C0,
                      int pad_top, int pad_left, int det, sarStream_t stream);   /* det: bins is int64 fixed point (sarBnRef.det) */
 int sar_stem16_pool_fwd(const float* x, const float* w, const float* bias, const sarBnRef* bn, void* pooled, uint8_t* idx, int B, int T, int D,
