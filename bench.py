@@ -296,7 +296,7 @@ def conv_roofline(model, B, iters=10, in_step=None):
         plans = [p_ for ps in getattr(tr, "_wgplans", {}).values() for p_ in ps]
         red_bytes = sum(4 * p_.n_slabs * p_.slab_floats for p_ in plans) + sum(4 * w_[0]["dw"].numel() for w_ in wg)
         extra = [("stem16_stats_kernel", 4 * n_in), ("stem16_pool_kernel", 4 * n_in + eb_p * n_pool + h16 + n_pool),
-                 ("stem16_bwd_reduce", 2 * n_pool + (2 if x3t else eb_p) * n_pool + n_pool), ("stem16_wgrad_kernel", 4 * n_in + 2 * n_pool + eb_p * n_pool + n_pool),
+                 ("stem16_bwd_reduce", 2 * n_pool + (2 if x3t else eb_p) * n_pool + n_pool), ("stem16_wgrad", 4 * n_in + 2 * n_pool + eb_p * n_pool + n_pool),   # (stem16_wgrad2_kernel since round 6; its finisher is not in this entry)
                  ("wgrad_reduce_multi_kernel", red_bytes)]
         for pat, nbytes in extra:
             hit = [(k, v) for k, v in in_step.items() if pat in k]

@@ -22,6 +22,7 @@ CLASS = [("conv_wgrad_x3_kernel<64>", "conv_wgrad_3x3_n64"), ("conv_fwd_x3_kerne
 out = {}
 if os.path.exists("profiles/pmc_traffic.json"):                # other modes' entries stay
     out = json.load(open("profiles/pmc_traffic.json"))
+out.pop(prefix + "stem16_wgrad_kernel", None)               # (round 5's key of the stem's kernel-gradient pass: "stem16_wgrad" since round 6)
 out.update({"source": src, "note": "per-launch average over all dispatches of the kernel in a step (3x3 and 1x1 launches of one template together); "
        "traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024"})
 # bf16 trunk: bench.py's classes ARE the kernel instantiations
@@ -31,7 +32,7 @@ for k, d in vals.items():
         f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
         out[prefix + m.group(1)] = {"source": src, "kernel": m.group(1), "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}
     # (round 6) the HBM-bound passes bench.py lists beside the conv classes: the stem's four passes and the weight gradients' reduction, keyed as bench.py names them
-    m = re.search(r"(stem16_stats_kernel|stem16_pool_kernel|stem16_bwd_reduce|stem16_wgrad_kernel|wgrad_reduce_multi_kernel)", k)
+    m = re.search(r"(stem16_stats_kernel|stem16_pool_kernel|stem16_bwd_reduce|stem16_wgrad(?=2?_kernel)|wgrad_reduce_multi_kernel)", k)
     if m and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         f, w = d["FETCH_SIZE"][0], d["WRITE_SIZE"][0]
         out[prefix + m.group(1)] = {"source": src, "kernel": m.group(1), "fetch_size_kb": f, "write_size_kb": w, "traffic_bytes": int((2 * f + w) * 1024), "dispatches": d["FETCH_SIZE"][1]}

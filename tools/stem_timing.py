@@ -17,10 +17,14 @@ sys.path.insert(0, os.path.dirname(HERE))
 from aesrc2020_amd import _lib as L  # noqa: E402  (BnRef struct + geometry only)
 from oracle.ops_np import same_pads  # noqa: E402
 
-lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing_stem.so"))
+X3 = os.environ.get("TIMING_X3", "0") == "1"     # the split-precision build (statistics + pooling passes only): hipcc ... -DSAR_TIMING -DSAR_X3=1 -> libsarnet_timing_stem_x3.so
+lib = ctypes.CDLL(os.path.join(HERE, "libsarnet_timing_stem_x3.so" if X3 else "libsarnet_timing_stem.so"))
+if X3:
+    lib.sar_stem16_stats, lib.sar_stem16_pool_fwd = lib.sar_stem16_stats_x3, lib.sar_stem16_pool_fwd_x3
+    lib.sar_stem16_bwd_reduce, lib.sar_stem16_wgrad = lib.sar_stem16_bwd_reduce_x3, lib.sar_stem16_wgrad_x3
 vp, ci = ctypes.c_void_p, ctypes.c_int
 lib.sar_stem16_stats.argtypes = [vp] * 4 + [ci] * 9 + [vp]
-lib.sar_stem16_pool_fwd.argtypes = [vp] * 6 + [ci] * 12 + [vp]
+lib.sar_stem16_pool_fwd.argtypes = [vp] * (7 if X3 else 6) + [ci] * 12 + [vp]
 lib.sar_stem16_bwd_reduce.argtypes = [vp] * 8 + [ci] * 12 + [vp]
 lib.sar_stem16_wgrad.argtypes = [vp] * 9 + [ci] * 12 + [vp]
 lib.sar_dbg_set_timing_buffer_stem.argtypes = [vp]
@@ -33,7 +37,7 @@ x = torch.rand(B, T, D, device="cuda"); w = torch.randn(7, 7, 1, C0, device="cud
 b = torch.zeros(C0, device="cuda"); gamma = torch.ones(C0, device="cuda"); beta = torch.zeros(C0, device="cuda")
 bins = torch.zeros(16, 2, C0, device="cuda"); bbins = torch.zeros(16, 2, C0, device="cuda"); saved = torch.zeros(4, C0, device="cuda")
 mm = torch.zeros(C0, device="cuda"); mv = torch.ones(C0, device="cuda"); dg = torch.zeros(C0, device="cuda"); db = torch.zeros(C0, device="cuda")
-pooled = torch.zeros(B, Hp, Wp, C0, dtype=torch.bfloat16, device="cuda"); idx = torch.zeros(B, Hp, Wp, C0, dtype=torch.uint8, device="cuda")
+pooled = torch.zeros(B, Hp, Wp, C0, dtype=torch.float32 if X3 else torch.bfloat16, device="cuda"); pooled_h = torch.zeros(B, Hp, Wp, C0, dtype=torch.float16, device="cuda"); idx = torch.zeros(B, Hp, Wp, C0, dtype=torch.uint8, device="cuda")
 g = torch.randn(B, Hp, Wp, C0, device="cuda").to(torch.bfloat16)
 dw = torch.zeros(7, 7, 1, C0, device="cuda"); work = torch.zeros(lib.sar_stem16_wgrad_workspace_bytes(C0) // 4, device="cuda")
 R = B * Ho * Wo
@@ -56,12 +60,15 @@ rf, rb = ref("fwd"), ref("bwd")
 runs = [
     ("stats", lambda: lib.sar_stem16_stats(P(x), P(w), P(b), P(bins), *conv, 0, st),
      {"stage": (1, 2), "m-tiles": (2, 3), "reduce": (3, 4), "flush": (4, 5), "total": (1, 5)}),
-    ("pool_fwd", lambda: lib.sar_stem16_pool_fwd(P(x), P(w), P(b), ctypes.byref(rf), P(pooled), P(idx), *conv, *pool, st),
+    ("pool_fwd", lambda: (lib.sar_stem16_pool_fwd(P(x), P(w), P(b), ctypes.byref(rf), P(pooled), P(pooled_h), P(idx), *conv, *pool, st) if X3 else
+                          lib.sar_stem16_pool_fwd(P(x), P(w), P(b), ctypes.byref(rf), P(pooled), P(idx), *conv, *pool, st)),
      {"stage+prologue": (1, 2), "conv pass 0": (2, 3), "pool pass 0": (3, 4), "conv pass 1": (4, 5), "pool pass 1": (5, 6), "total": (1, 6)}),
     ("wgrad", lambda: (lib.sar_stem16_bwd_reduce(P(g), P(pooled), P(idx), P(x), P(w), P(b), ctypes.byref(rb), P(work), *conv, *pool, st),
                        lib.sar_stem16_wgrad(P(x), P(w), P(b), P(g), P(pooled), P(idx), ctypes.byref(rb), P(dw), P(work), *conv, *pool, st))[1],
      {"prologue": (1, 2), "tile loop": (2, 3), "merge+store": (3, 4), "total": (1, 4)}),
 ]
+if X3:
+    runs = runs[:2]
 for name, fn, phases in runs:
     tb = torch.zeros(1 << 14, 16, dtype=torch.int64, device="cuda")
     for _ in range(3):
