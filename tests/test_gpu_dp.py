@@ -24,6 +24,15 @@ STEPS = 3
 GRAPHS = {"3": ["adam", "heads_s32", "trunk_s10"], "5": ["adam", "heads", "trunk0", "trunk1", "trunk2"], "1": ["step_dp"]}   # SAR_DP_SEGMENTS -> captured graphs
 
 
+
+def _free_port():
+    """A port the OS says is free right now (a port derived from the pid repeats between parametrised cases of one pytest process, and the previous
+    case's listening socket may still be in TIME_WAIT: EADDRINUSE, seen once in round 6)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _set_mode(mode):
     """The trunk / GEMM arithmetic of a test mode: "bf16" = the single-pass 2-byte trunk with DETERMINISTIC forward statistics (SAR_BN_DET: the
     same utterances give bit-identical BatchNorm constants however the batch is cut, so the two-rank step can be held tightly against the
@@ -92,7 +101,7 @@ def test_two_rank_step_matches_mean_of_shard_gradients(backend, via_gpus, mode, 
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 31000 + (os.getpid() + 7 * len(backend) + int(via_gpus) + 3 * len(mode) + 13 * int(segments)) % 2000
+    q = ctx.Queue(); port = _free_port()
     ps = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, via_gpus, mode, segments, grad16)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=600) for _ in ps], key=lambda t: t[0])
@@ -225,7 +234,7 @@ def test_rccl_one_rank_segmented_step(mode, collective, segments):
     from aesrc2020_amd.model import SAR_Net
     from oracle import model_torch as MT
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 33000 + (os.getpid() + 11 * len(mode) + 5 * len(collective) + 17 * int(segments)) % 2000
+    q = ctx.Queue(); port = _free_port()
     p = ctx.Process(target=_worker_one_rank, args=(port, q, mode, collective, segments))
     p.start()
     out, graphs = q.get(timeout=600)

@@ -10,6 +10,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def _free_port():
+    """A port the OS says is free right now (a port derived from the pid repeats between parametrised cases of one pytest process, and the previous
+    case's listening socket may still be in TIME_WAIT: EADDRINUSE, seen once in round 6)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def test_library_exports_every_declared_symbol():
     from aesrc2020_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
@@ -322,7 +331,7 @@ def _dp_worker(rank, world, port, q):
 def test_data_parallel_gloo_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    q = ctx.Queue(); port = 29000 + os.getpid() % 2000
+    q = ctx.Queue(); port = _free_port()
     ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
