@@ -664,3 +664,152 @@ extern "C" int sar_gemm_wgrad_group_scaled_f32(const void* table_dev, int n, int
     }
     return sar_gemm_wgrad_group_f32(table_dev, n, total_blocks, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------- Dense(tanh) + LayerNormalization in one launch
+// DS(hidden_dim, 'tanh') -> LN, the reference's per-frame pairs (model.py:253-254 CNN_LIN, 265-266 CTC_DS, 279-280 AR_DS): with 64 x 64
+// output tiles a LayerNorm row (256 units) is spread over four workgroups, so the normalisation was a launch of its own behind the GEMM -- 12 + 5 and
+// 14 + 4.4 us in the step for 0.3 GFLOP each.  Here a workgroup owns 16 COMPLETE rows: wave w multiplies columns [64 w, 64 w + 64) as four
+// v_mfma_f32_16x16x32_bf16 tiles in split precision (hi x hi + hi x lo + lo x hi, the GEMM arithmetic "bf16x3"), operands straight from global memory
+// into fragments (an x row piece is 8 consecutive floats of the lane's row; a kernel piece is a float4 of FOUR consecutive columns at one k, whose
+// components go to the four tiles: tile q of the wave holds columns 64 w + 4 (lane % 16) + q, so a lane ends up with four consecutive columns of its
+// four rows -- 16-byte stores), two k-steps of 32 in flight; bias, tanh, the row's mean and variance (16-lane DPP sums, the four waves meet in LDS
+// twice) and the normalisation follow in registers.  Writes both tensors the backward reads: tanh's output (the LayerNorm's input) and the result.
+namespace {
+constexpr int DL_N = 256, DL_ROWS = 16, DL_RS = DL_N + 4;   // (DL_RS: row stride of the k-groups' partial tiles in LDS, floats)
+struct DlStage { float4 a0, a1; float4 w[8]; };
+
+// KG k-groups of four waves: group g multiplies k in [g K / KG, (g + 1) K / KG) (a multiple of 64 each) and the groups' tiles meet in LDS -- 52
+// workgroups on 52 CUs are all this launch is at the step's 832 rows, each wave a chain of load round trips: more waves per CU is what shortens it.
+template <int KG>
+__global__ __launch_bounds__(256 * KG) void dense_tanh_ln_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ act_out,
+                                                                 float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int R, int K, float eps) {
+    __shared__ float part[2][4][DL_ROWS];
+    __shared__ __attribute__((aligned(16))) float red[KG > 1 ? KG - 1 : 1][KG > 1 ? DL_ROWS : 1][KG > 1 ? DL_RS : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = wv & 3, g = wv >> 2, r16 = lane & 15, kg = lane >> 4;
+    const int row0 = blockIdx.x * DL_ROWS;
+    const int arow = min(row0 + r16, R - 1);                          // (rows past R: a clamped read, no store)
+    const int Kg = K / KG, k0 = g * Kg;
+    const float* xa = x + (size_t)arow * K + k0 + 8 * kg;
+    const float* wb = W + (size_t)(k0 + 8 * kg) * DL_N + 64 * w + 4 * r16;
+    auto load = [&](DlStage& s, int kk) __attribute__((always_inline)) {
+        s.a0 = *reinterpret_cast<const float4*>(xa + kk); s.a1 = *reinterpret_cast<const float4*>(xa + kk + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.w[i] = *reinterpret_cast<const float4*>(wb + (size_t)(kk + i) * DL_N);
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const DlStage& s) __attribute__((always_inline)) {
+        const float av[8] = {s.a0.x, s.a0.y, s.a0.z, s.a0.w, s.a1.x, s.a1.y, s.a1.z, s.a1.w};
+        gbf16x8 ah, al;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const __bf16 h = (__bf16)av[i]; ah[i] = h; al[i] = (__bf16)(av[i] - (float)h); }
+        float wq[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wq[0][i] = s.w[i].x; wq[1][i] = s.w[i].y; wq[2][i] = s.w[i].z; wq[3][i] = s.w[i].w; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            gbf16x8 bh, bl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const __bf16 h = (__bf16)wq[q][i]; bh[i] = h; bl[i] = (__bf16)(wq[q][i] - (float)h); }
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[q], 0, 0, 0);      // small terms first
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[q], 0, 0, 0);
+        }
+    };
+    DlStage s0, s1;
+    load(s0, 0); load(s1, 32);
+    for (int kk = 0; kk < Kg; kk += 64) {                             // Kg % 64 == 0 (the launcher picks KG so)
+        compute(s0);
+        if (kk + 64 < Kg) load(s0, kk + 64);
+        compute(s1);
+        if (kk + 96 < Kg) load(s1, kk + 96);
+    }
+    // lane: rows 4 kg + i (i < 4), columns c0 .. c0 + 3
+    const int c0 = 64 * w + 4 * r16;
+    if constexpr (KG > 1) {
+        if (g > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&red[g - 1][4 * kg + i][c0]) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+        }
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < KG - 1; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(&red[j][4 * kg + i][c0]);
+                    acc[0][i] += v.x; acc[1][i] += v.y; acc[2][i] += v.z; acc[3][i] += v.w;
+                }
+        }
+    }
+    const bool own = g == 0;                                          // (block-uniform per wave) the first group finishes the rows; the others keep the barriers company
+    float t[4][4], rs[4], mu[4], d[4][4];
+    if (own) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            t[i][0] = fast_tanh(acc[0][i] + bv.x); t[i][1] = fast_tanh(acc[1][i] + bv.y); t[i][2] = fast_tanh(acc[2][i] + bv.z); t[i][3] = fast_tanh(acc[3][i] + bv.w);
+            float s = (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+            s += SAR_DPP_F(s, 0xB1); s += SAR_DPP_F(s, 0x4E); s += SAR_DPP_F(s, 0x141); s += SAR_DPP_F(s, 0x140);   // the 16 lanes of this k-group = the wave's 64 columns
+            rs[i] = s;
+        }
+        if (r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[0][w][4 * kg + i] = rs[i];
+        }
+    }
+    __syncthreads();
+    if (own) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = 4 * kg + i;
+            mu[i] = ((part[0][0][rr] + part[0][1][rr]) + (part[0][2][rr] + part[0][3][rr])) * (1.f / DL_N);
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { d[i][q] = t[i][q] - mu[i]; s = fmaf(d[i][q], d[i][q], s); }
+            s += SAR_DPP_F(s, 0xB1); s += SAR_DPP_F(s, 0x4E); s += SAR_DPP_F(s, 0x141); s += SAR_DPP_F(s, 0x140);
+            rs[i] = s;
+        }
+        if (r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) part[1][w][4 * kg + i] = rs[i];
+        }
+    }
+    __syncthreads();
+    if (!own) return;
+    const float4 gv = *reinterpret_cast<const float4*>(gamma + c0), be = *reinterpret_cast<const float4*>(beta + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = 4 * kg + i, row = row0 + rr;
+        const float var = ((part[1][0][rr] + part[1][1][rr]) + (part[1][2][rr] + part[1][3][rr])) * (1.f / DL_N);
+        const float r = 1.f / sqrtf(var + eps);
+        if (row < R) {
+            *reinterpret_cast<float4*>(act_out + (size_t)row * DL_N + c0) = make_float4(t[i][0], t[i][1], t[i][2], t[i][3]);
+            *reinterpret_cast<float4*>(y + (size_t)row * DL_N + c0) = make_float4(fmaf(d[i][0] * r, gv.x, be.x), fmaf(d[i][1] * r, gv.y, be.y),
+                                                                                  fmaf(d[i][2] * r, gv.z, be.z), fmaf(d[i][3] * r, gv.w, be.w));
+            if (w == 0 && r16 == 0) { mean[row] = mu[i]; rstd[row] = r; }
+        }
+    }
+}
+}  // namespace
+
+// include/sarnet.h.  N = 256 only, K a multiple of 64, 16-byte aligned x (R, K) and W (K, 256), GEMM arithmetic bf16x3 -- otherwise SAR_EINVAL
+// (the caller runs sar_gemm_f32 + sar_layernorm_fwd_f32).
+extern "C" int sar_dense_tanh_ln_f32(const float* x, const float* W, const float* bias, const float* gamma, const float* beta, float* act_out, float* y,
+                                     float* mean, float* rstd, long R, int K, int N, float eps, hipStream_t stream) {
+    if (!x || !W || !bias || !gamma || !beta || !act_out || !y || !mean || !rstd || R < 1 || R > (1L << 30) || N != DL_N || K < 64 || K % 64 || g_gemm_math != 2)
+        return SAR_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gamma) |
+         reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(act_out) | reinterpret_cast<uintptr_t>(y)) & 15)
+        return SAR_EINVAL;
+    static const int kg_env = getenv("SAR_DENSE_LN_KG") ? atoi(getenv("SAR_DENSE_LN_KG")) : 4;
+    const dim3 grid(cdiv(R, DL_ROWS));
+    const int kgs = kg_env >= 4 && K % 256 == 0 ? 4 : kg_env >= 2 && K % 128 == 0 ? 2 : 1;
+    if (kgs == 4) hipLaunchKernelGGL(dense_tanh_ln_kernel<4>, grid, dim3(1024), 0, stream, x, W, bias, gamma, beta, act_out, y, mean, rstd, (int)R, K, eps);
+    else if (kgs == 2) hipLaunchKernelGGL(dense_tanh_ln_kernel<2>, grid, dim3(512), 0, stream, x, W, bias, gamma, beta, act_out, y, mean, rstd, (int)R, K, eps);
+    else hipLaunchKernelGGL(dense_tanh_ln_kernel<1>, grid, dim3(256), 0, stream, x, W, bias, gamma, beta, act_out, y, mean, rstd, (int)R, K, eps);
+    SAR_CHECK_LAUNCH();
+    return SAR_OK;
+}

@@ -144,6 +144,26 @@ class LayerNorm(Layer):
         return dx
 
 
+_FUSE_DENSE_LN = os.environ.get("SAR_DENSE_LN", "1") != "0"
+
+
+def dense_ln_forward(dense, ln, x):
+    """DS(..., 'tanh') -> LN (model.py:253-254, 265-266, 279-280): ONE launch (sar_dense_tanh_ln_f32, csrc/gemm.hip) where the fused kernel takes
+    the shape -- 256 units, bias, in_dim a multiple of 64, split-precision GEMM arithmetic -- else the two launches.  Both layers end up with exactly
+    the tensors their own forward() leaves for the backward (Dense: x, y = tanh's output; LayerNorm: x = that y, mean, rstd) and `.output`."""
+    R = x.numel() // dense.in_dim
+    if (_FUSE_DENSE_LN and dense.activation == "tanh" and dense.bias is not None and dense.units == 256 and ln.dim == 256 and dense.in_dim % 64 == 0
+            and _lib.get_gemm_math() == "bf16x3" and x.is_contiguous() and _aligned16(x, dense.kernel.w, dense.bias.w, ln.gamma.w, ln.beta.w)):
+        dense.x, dense.R = x, R
+        a = dense.buf("y", (R, dense.units)); dense.y = a; dense.output = a
+        ln.x, ln.R = a, R
+        y = ln.buf("y", (R, ln.dim)); ln.mean = ln.buf("mean", (R,)); ln.rstd = ln.buf("rstd", (R,))
+        _call("sar_dense_tanh_ln_f32", x, dense.kernel.w, dense.bias.w, ln.gamma.w, ln.beta.w, a, y, ln.mean, ln.rstd, R, dense.in_dim, dense.units, LN_EPS)
+        ln.output = y
+        return y
+    return ln.forward(dense.forward(x))
+
+
 class BiGRU(Layer):
     """Bidirectional(CuDNNGRU(hidden, return_sequences=seq), merge_mode='concat') (model.py:44-50)."""
 

@@ -15,7 +15,7 @@ from . import _lib
 from . import losses as ls
 from . import VLAD as vd
 from .engine import ParamStore, store_scope, orthogonal, glorot_uniform
-from .layers import Dense, LayerNorm, BiGRU, BatchNorm1d, GlobalAveragePooling1D, L2Normalize, Layer
+from .layers import Dense, LayerNorm, BiGRU, dense_ln_forward, BatchNorm1d, GlobalAveragePooling1D, L2Normalize, Layer
 from .resnet import resnet18_, resnet34_, resnet50_, resnet101_, resnet152_
 from .parallel import DataParallel
 
@@ -364,22 +364,21 @@ class SARNetModel:
         B, L = self.B, self.L
         self._fused_disc = False
         cnn = self.trunk.forward(self.in_x, B)
-        x = self.CNN_LIN.forward(cnn.view(B * L, -1))                         # CNN2SEQ (model.py:252) is a view
-        x = self.CNN_LIN_LN.forward(x)
+        x = dense_ln_forward(self.CNN_LIN, self.CNN_LIN_LN, cnn.view(B * L, -1))   # CNN2SEQ (model.py:252) is a view; DS(tanh) -> LN: one launch
         x = self.CRNN.forward(x, B, L)
         crnn = self.CRNN_LN.forward(x.view(B * L, -1))
         self.out = {}
         if c["ctc_enable"]:
             a = self.CTC_BIGRU.forward(crnn, B, L)
             a = self.CTC_BIGRU_LN.forward(a.view(B * L, -1))
-            a = self.CTC_DS_LN.forward(self.CTC_DS.forward(a))
+            a = dense_ln_forward(self.CTC_DS, self.CTC_DS_LN, a)
             pred = self.ctc_pred.forward(a)
             self.out["ctc_pred"] = pred
             _call("sar_ctc_batch_cost_fwd_f32", pred, self.in_ctc_label, self.in_ctc_in_len, self.in_ctc_out_len, self.ctc_loss,
                   self.ctc_ws, self.ctc_ws_bytes, B, L, c["bpe_classes"], c["max_ctc_len"])
             self.out["y_ctc_loss"] = self.ctc_loss
         if c["ar_enable"]:
-            ar = self.AR_DS_LN.forward(self.AR_DS.forward(crnn))
+            ar = dense_ln_forward(self.AR_DS, self.AR_DS_LN, crnn)
             if c["mto"] == "avg":
                 ar = self.merge.forward(ar, B, L)
             else:

@@ -424,6 +424,13 @@ int sar_bn1d_bwd_f32(const float* dy, const float* x, const float* gamma, const 
                      float* dx, float* dgamma, float* dbeta, int B, int C, sarStream_t stream);
 
 /* ---- LayerNormalization (keras_layer_normalization, eps = K.epsilon()^2): model.py:4,32-33 */
+/* DS(hidden_dim, 'tanh') -> LN in ONE launch (round 6; model.py:253-254 CNN_LIN / CNN_LIN_LN, 265-266 CTC_DS / CTC_DS_LN, 279-280 AR_DS / AR_DS_LN;
+ * DS = model.py:35-42, LN = model.py:32-33): act_out (R,256) = tanh(x W + bias), y (R,256) = LayerNormalization(act_out) with gamma / beta / eps,
+ * mean / rstd (R) as sar_layernorm_fwd_f32 writes them -- both tensors and both vectors are what the backward launches read.  x (R,K) and W (K,256)
+ * row-major and 16-byte aligned, N = 256, K % 64 == 0, GEMM arithmetic bf16x3 (split precision); anything else: SAR_EINVAL, and the caller runs
+ * sar_gemm_f32 + sar_layernorm_fwd_f32. */
+int sar_dense_tanh_ln_f32(const float* x, const float* W, const float* bias, const float* gamma, const float* beta, float* act_out, float* y,
+                          float* mean, float* rstd, long R, int K, int N, float eps, sarStream_t stream);
 int sar_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                           long R, int C, float eps, sarStream_t stream);
 int sar_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

@@ -682,6 +682,47 @@ def test_layernorm(L, R, C):
     check(dx, dxt_ref * (1 - xt * xt), name="ln+tanh dz"); check(dg, dgt_ref, name="ln+tanh dgamma"); check(db, dbt_ref, name="ln+tanh dbeta")
 
 
+@pytest.mark.parametrize("R,K", [(832, 768), (832, 512), (2496, 256), (5, 64), (16, 128), (2496 + 7, 512)])
+def test_dense_tanh_layernorm_one_launch(L, R, K):
+    """sar_dense_tanh_ln_f32 (round 6; DS(256, 'tanh') -> LN, model.py:253-254 / 265-266 / 279-280): tanh's output, the normalised rows and the
+    saved mean / rstd against the float64 oracle, at the step's shapes (832 x 768, 832 x 512), the CTC configurations' 2 496 rows and ragged
+    row counts (the last workgroup's rows past R are read clamped and never stored); the two launches it replaces give the same tensors to fp32
+    rounding; shapes it does not take return SAR_EINVAL and launch nothing."""
+    rng = np.random.default_rng(R + K)
+    N = 256
+    x = rng.standard_normal((R, K)); W = rng.standard_normal((K, N)) / np.sqrt(K); b = 0.1 * rng.standard_normal(N)
+    gamma = rng.uniform(0.5, 1.5, N); beta = rng.standard_normal(N)
+    a_ref = np.tanh(x @ W + b); y_ref, cache = O.layernorm_fwd(a_ref, gamma, beta)
+    xd, Wd, bd, gd, bed = dev(x), dev(W), dev(b), dev(gamma), dev(beta)
+    a, y = torch.full((R + 1, N), 7.0, device="cuda"), torch.full((R + 1, N), 7.0, device="cuda")
+    mean, rstd = zeros(R), zeros(R)
+    old = L.get_gemm_math()
+    L.set_gemm_math("bf16x3")
+    try:
+        L.call("sar_dense_tanh_ln_f32", xd, Wd, bd, gd, bed, a, y, mean, rstd, R, K, N, 1e-14)
+        torch.cuda.synchronize()
+        assert float((a[R] - 7.0).abs().max()) == 0.0 and float((y[R] - 7.0).abs().max()) == 0.0      # nothing past row R
+        # (split precision drops lo x lo and rounds lo: ~2^-16 per product, ~2e-5 of a unit-variance sum; the LayerNorm divides by a deviation of ~0.6)
+        check(a[:R], a_ref, 1e-4, name="tanh(x W + b)"); check(y[:R], y_ref, 3e-4, name="LN(tanh(x W + b))")
+        mu_ref = a_ref.mean(1); rs_ref = 1.0 / np.sqrt(a_ref.var(1) + 1e-14)
+        check(mean, mu_ref, 2e-5, name="mean", scale=1.0); check(rstd, rs_ref, 1e-4, name="rstd")
+        # the two launches
+        a2, y2, m2, r2 = zeros(R, N), zeros(R, N), zeros(R), zeros(R)
+        L.call("sar_gemm_f32", xd, Wd, a2, bd, R, N, K, K, N, N, 1, 0, 1, 0, 1)
+        L.call("sar_layernorm_fwd_f32", a2, gd, bed, y2, m2, r2, R, N, 1e-14)
+        check(a[:R], a2.cpu().numpy(), 1e-4, name="against sar_gemm_f32"); check(y[:R], y2.cpu().numpy(), 3e-4, name="against sar_layernorm_fwd_f32")
+        # not this kernel's shapes / arithmetic
+        with pytest.raises(RuntimeError, match="status -1"):
+            L.call("sar_dense_tanh_ln_f32", xd, Wd, bd, gd, bed, a, y, mean, rstd, R, K, 128, 1e-14)
+        with pytest.raises(RuntimeError, match="status -1"):
+            L.call("sar_dense_tanh_ln_f32", xd, Wd, bd, gd, bed, a, y, mean, rstd, R, K - 32, N, 1e-14)
+        L.set_gemm_math("fp32")
+        with pytest.raises(RuntimeError, match="status -1"):
+            L.call("sar_dense_tanh_ln_f32", xd, Wd, bd, gd, bed, a, y, mean, rstd, R, K, N, 1e-14)
+    finally:
+        L.set_gemm_math(old)
+
+
 # ------------------------------------------------------------------ BiGRU
 @pytest.mark.parametrize("B,Lq,I,H", [(5, 7, 12, 64), (64, 39, 256, 256), (3, 12, 40, 20)])
 def test_bigru(L, B, Lq, I, H):
