@@ -120,7 +120,9 @@ def smooth(v):
     0 / 35 / 2 / 2 steps beyond twice the median in steps 200-400 of the fp32-class reference run (one episode up to 23.4: its last window's MEAN was 4.0,
     its median 1.59) and 5 / 13 / 30 / 29 in the default mode (up to 24.4) -- and a window's mean is then whatever its spikes are, while the medians of all
     eight runs sit at 1.20 ... 1.24 (the one episode apart).  The default mode spiked in more of these runs than the reference did (3 of 4 against 1 of 4
-    with ten or more); eight runs do not settle whether that is the fp16 backward or chance, and it is recorded here rather than averaged away."""
+    with ten or more).  tools/loss_spikes.py, eight further runs of three arithmetics (profiles/r6_loss_spikes.txt): reference 12 spiking steps, default
+    42, the default's forward with the THREE-PASS backward restored 40 -- so it is not the fp16 backward; what the two have in common against the
+    reference is the forward on the 2-byte kernel architecture (split-precision GEMMs, fp16 MFMA recurrence).  The floor is 1.216 ... 1.232 in all 24."""
     return np.asarray([np.median(v[i:i + WIN]) for i in range(0, len(v) - WIN + 1, WIN)])
 
 
