@@ -121,8 +121,9 @@ def smooth(v):
     its median 1.59) and 5 / 13 / 30 / 29 in the default mode (up to 24.4) -- and a window's mean is then whatever its spikes are, while the medians of all
     eight runs sit at 1.20 ... 1.24 (the one episode apart).  The default mode spiked in more of these runs than the reference did (3 of 4 against 1 of 4
     with ten or more).  tools/loss_spikes.py, eight further runs of three arithmetics (profiles/r6_loss_spikes.txt): reference 12 spiking steps, default
-    42, the default's forward with the THREE-PASS backward restored 40 -- so it is not the fp16 backward; what the two have in common against the
-    reference is the forward on the 2-byte kernel architecture (split-precision GEMMs, fp16 MFMA recurrence).  The floor is 1.216 ... 1.232 in all 24."""
+    42, the default's forward with the THREE-PASS backward restored 40; a second sample of eight: reference 90, default 45, three-pass backward 70, either
+    half of the forward alone on the 2-byte architecture 77 / 23.  All samples together: reference 141 spiking steps in 20 runs, default 164 in 20 -- the
+    first sample's difference was chance; the spikes belong to the task (Adam at lr 1e-3 on this floor), not to an arithmetic.  The floor is 1.21 ... 1.23 in all."""
     return np.asarray([np.median(v[i:i + WIN]) for i in range(0, len(v) - WIN + 1, WIN)])
 
 

@@ -30,6 +30,11 @@ for rep in range(runs):
         curves.append(("x3 forward, three-pass backward", m.train("x3", pool, weights=w0, hidden=256)[0]))
     finally:
         del os.environ["SAR_X3_BWD"]; del os.environ["SAR_GEMM_BWD"]
+    if os.environ.get("LOSS_SPIKES_EXTRA"):
+        # which half of the forward: the split-precision trunk with fp32 GEMMs / recurrence, and round 1's trunk with split-precision GEMMs + fp16 MFMA recurrence
+        m.MODES["x3_trunk_only"] = ("bf16x3", "bf16x3", "fp32"); m.MODES["x3_gemm_only"] = ("fp32", "bf16x3", "bf16x3")
+        curves.append(("x3 trunk, fp32 GEMMs and recurrence", m.train("x3_trunk_only", pool, weights=w0, hidden=256)[0]))
+        curves.append(("round-1 trunk, x3 GEMMs + fp16 recurrence", m.train("x3_gemm_only", pool, weights=w0, hidden=256)[0]))
     for name, v in curves:
         tail = v[200:]; med = float(np.median(tail)); n = int((tail > 2 * med).sum())
         t = tot.setdefault(name, [0, 0, 0.0]); t[0] += n; t[1] += int(n >= 10); t[2] = max(t[2], float(tail.max()))
