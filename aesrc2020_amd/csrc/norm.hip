@@ -220,6 +220,9 @@ __device__ __forceinline__ float bn1d_colsum(float v, float (*red)[BN1_CH], int 
     for (int g = 0; g < BN1_RG; ++g) t += red[g][cl];
     return t;
 }
+// (round 6: a thread's rows are loaded ONCE, all in flight, and kept in registers -- B <= BN1_RG * BN1_RM, the model's batches; the three passes over
+// x (sum, squared deviations, normalise) were three dependent round trips of a kernel that is nothing but round trips.  Larger batches re-read.)
+constexpr int BN1_RM = 16;
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
                                 float* __restrict__ rstd, float* __restrict__ mov_mean, float* __restrict__ mov_var,
@@ -228,16 +231,29 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
     const int cl = threadIdx.x % BN1_CH, rg = threadIdx.x / BN1_CH;
     const int c = blockIdx.x * BN1_CH + cl;
     const bool ok = c < C;
+    const bool held = B <= BN1_RG * BN1_RM;                        // (kernel-uniform)
+    float xv[BN1_RM];
     float s = 0.f;
-    if (ok) for (int b = rg; b < B; b += BN1_RG) s += x[(long)b * C + c];
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) { const int b = rg + i * BN1_RG; xv[i] = (ok && b < B) ? x[(long)b * C + c] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) s += xv[i];
+    } else if (ok) for (int b = rg; b < B; b += BN1_RG) s += x[(long)b * C + c];
+    const float g = ok ? gamma[c] : 0.f, be = ok ? beta[c] : 0.f;  // (requested here: behind the two reductions they were one more round trip)
     const float mu = bn1d_colsum(s, red, rg, cl) / B;
     float q = 0.f;
-    if (ok) for (int b = rg; b < B; b += BN1_RG) { const float d = x[(long)b * C + c] - mu; q = fmaf(d, d, q); }
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) { const float d = (rg + i * BN1_RG < B) ? xv[i] - mu : 0.f; q = fmaf(d, d, q); }
+    } else if (ok) for (int b = rg; b < B; b += BN1_RG) { const float d = x[(long)b * C + c] - mu; q = fmaf(d, d, q); }
     const float var = bn1d_colsum(q, red, rg, cl) / B;
     if (!ok) return;
     const float rs = 1.f / sqrtf(var + eps);
-    const float g = gamma[c], be = beta[c];
-    for (int b = rg; b < B; b += BN1_RG) y[(long)b * C + c] = (x[(long)b * C + c] - mu) * rs * g + be;
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) { const int b = rg + i * BN1_RG; if (b < B) y[(long)b * C + c] = (xv[i] - mu) * rs * g + be; }
+    } else for (int b = rg; b < B; b += BN1_RG) y[(long)b * C + c] = (x[(long)b * C + c] - mu) * rs * g + be;
     if (rg == 0) {
         mean[c] = mu; rstd[c] = rs;
         if (mov_mean) {
@@ -258,9 +274,19 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
     const int cl = threadIdx.x % BN1_CH, rg = threadIdx.x / BN1_CH;
     const int c = blockIdx.x * BN1_CH + cl;
     const bool ok = c < C;
-    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
+    const bool held = B <= BN1_RG * BN1_RM;                        // (kernel-uniform)
+    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f, gm = ok ? gamma[c] : 0.f;
+    float gv[BN1_RM], xh[BN1_RM];
     float a1 = 0.f, a2 = 0.f;
-    if (ok)
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) {
+            const int b = rg + i * BN1_RG; const bool in = ok && b < B;
+            gv[i] = in ? dy[(long)b * C + c] : 0.f; xh[i] = in ? x[(long)b * C + c] : mu;
+        }
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) { xh[i] = (xh[i] - mu) * rs; a1 += gv[i]; a2 = fmaf(gv[i], xh[i], a2); }
+    } else if (ok)
         for (int b = rg; b < B; b += BN1_RG) {
             const float g = dy[(long)b * C + c];
             a1 += g; a2 = fmaf(g, (x[(long)b * C + c] - mu) * rs, a2);
@@ -268,11 +294,15 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
     const float s1 = bn1d_colsum(a1, red, rg, cl), s2 = bn1d_colsum(a2, red, rg, cl);
     if (!ok) return;
     if (rg == 0) { dgamma[c] += s2; dbeta[c] += s1; }
-    const float k = gamma[c] * rs, m1 = s1 / B, m2 = s2 / B;
-    for (int b = rg; b < B; b += BN1_RG) {
-        const float xh = (x[(long)b * C + c] - mu) * rs;
-        dx[(long)b * C + c] = k * (dy[(long)b * C + c] - m1 - xh * m2);
-    }
+    const float k = gm * rs, m1 = s1 / B, m2 = s2 / B;
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < BN1_RM; ++i) { const int b = rg + i * BN1_RG; if (b < B) dx[(long)b * C + c] = k * (gv[i] - m1 - xh[i] * m2); }
+    } else
+        for (int b = rg; b < B; b += BN1_RG) {
+            const float xhh = (x[(long)b * C + c] - mu) * rs;
+            dx[(long)b * C + c] = k * (dy[(long)b * C + c] - m1 - xhh * m2);
+        }
 }
 
 // ---- LayerNorm: x (R, C), one wave per row, C % 4 == 0, C <= 2048 -------------------------------------

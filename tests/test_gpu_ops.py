@@ -639,7 +639,7 @@ def test_batchnorm_4d(L, R, C, relu):
     check(dx, dx_ref + add, name="bn bwd dx"); check(dg, dg_ref, name="bn dgamma"); check(db, db_ref, name="bn dbeta")
 
 
-@pytest.mark.parametrize("B,C", [(64, 2048), (5, 130), (64, 256)])
+@pytest.mark.parametrize("B,C", [(64, 2048), (5, 130), (64, 256), (128, 64), (200, 96)])    # (the last: more rows than a thread keeps in registers)
 def test_batchnorm_2d(L, B, C):
     rng = np.random.default_rng(C)
     x = rng.standard_normal((B, C)); gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C)
