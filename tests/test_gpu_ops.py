@@ -658,7 +658,7 @@ def test_batchnorm_2d(L, B, C):
     check(dx, dx_ref, name="bn1d dx"); check(dg, dg_ref, name="bn1d dgamma"); check(db, db_ref, name="bn1d dbeta")
 
 
-@pytest.mark.parametrize("R,C", [(2496, 256), (100, 512), (7, 16), (33, 2048)])
+@pytest.mark.parametrize("R,C", [(2496, 256), (2496, 512), (100, 512), (4099, 256), (7, 16), (33, 2048)])
 def test_layernorm(L, R, C):
     rng = np.random.default_rng(R)
     x = rng.standard_normal((R, C)); gamma = rng.uniform(0.5, 1.5, C); beta = rng.standard_normal(C)
